@@ -1,0 +1,80 @@
+"""All-pairs correlation volume, 4-level pyramid and radius-r lookup on HIP kernels.
+
+Interface of the reference's ``core/corr.py``: ``CorrBlock(fmap1, fmap2, ...)`` (plain dot-product
+volume, corr.py:16-81) and ``TransCorrBlock(config, ...)`` with ``update(...)`` + ``__call__(coords)``
+(cross-attention volume, corr.py:132-207).  The volume is produced by one fused kernel
+(``craft_corr_build``): 4-mode Q K^T, clamp, softmax-over-modes pooling, positional bias, written once
+into pyramid level 0 together with (sum, sum^2) for the global LayerNorm, which the lookup applies
+lazily per in-bounds tap.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .hip import PREC_F32
+from .setrans import CrossAttFeatTrans, SETransConfig, SETransInputFeatEncoder
+
+
+class CorrBlock:
+    """Plain correlation volume <fmap1(:,i), fmap2(:,j)>/sqrt(C) (``craft=False`` variant)."""
+
+    def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4,
+                 do_corr_global_norm: bool = False, prec: int = PREC_F32):
+        B, C, H8, W8 = fmap1.shape
+        self.num_levels, self.radius = num_levels, radius
+        self.shape = (B, H8, W8)
+        t1 = ops.tokens_from_nchw(fmap1)
+        t2 = ops.tokens_from_nchw(fmap2)
+        self.pyramid = ops.CorrPyramid(B, H8, W8, num_levels, fmap1.device)
+        ops.corr_build(t1, t2, H8, W8, 1, 1.0 / math.sqrt(C), None, 0.0, 1.0, None, self.pyramid, do_corr_global_norm, prec)
+
+    def lookup_tokens(self, coords_tokens: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return ops.corr_lookup(self.pyramid, coords_tokens, self.radius, out=out)
+
+    def __call__(self, coords: torch.Tensor) -> torch.Tensor:
+        """coords NCHW [B, 2, H8, W8] (x, y) -> [B, L*(2r+1)^2, H8, W8]   (corr.py:47-71)."""
+        B, H8, W8 = self.shape
+        ct = ops.tokens_from_nchw(coords.float())
+        return ops.tokens_to_nchw(self.lookup_tokens(ct), H8, W8)
+
+
+class TransCorrBlock(CorrBlock, nn.Module):
+    def __init__(self, config: SETransConfig, num_levels: int = 4, radius: int = 4, do_corr_global_norm: bool = False):
+        nn.Module.__init__(self)
+        self.num_levels, self.radius = num_levels, radius
+        self.config = config
+        self.setrans = CrossAttFeatTrans(config, "Inter-frame correlation block")
+        self.vispos_encoder = SETransInputFeatEncoder(config)
+        self.do_corr_global_norm = do_corr_global_norm
+        self.pyramid = None
+        self.shape = None
+
+    def update_tokens(self, x1_ln: torch.Tensor, x2_ln: torch.Tensor, hw, prec: int):
+        """x1_ln / x2_ln: LayerNorm-ed tokens of frame-1 conv features and frame-2 (transformed) features."""
+        H8, W8 = hw
+        B = x1_ln.shape[0]
+        st = self.setrans
+        q = ops.linear(x1_ln, st.query.weight, st.query.bias, prec)
+        k = ops.linear(x2_ln, st.key.weight, st.key.bias, prec)
+        scale = 1.0 / math.sqrt(st.attention_mode_dim)
+        mx = ops.score_max(q, k, H8, W8, st.num_modes, scale, prec)
+        if self.pyramid is None or self.shape != (B, H8, W8) or self.pyramid.lv[0].device != q.device:
+            self.pyramid = ops.CorrPyramid(B, H8, W8, self.num_levels, q.device)
+            self.shape = (B, H8, W8)
+        w_aggr = float(st.attn_softaggr.feat2score.weight.item()) if st.num_modes > 1 else 1.0
+        ops.corr_build(q, k, H8, W8, st.num_modes, scale, self.vispos_encoder.pos_coder.biases, float(st.pos_code_weight),
+                       w_aggr, mx, self.pyramid, self.do_corr_global_norm, prec)
+
+    def update(self, fmap1, fmap2, fmap1o=None, fmap2o=None, coords1=None, coords2=None):
+        """corr.py:148-189.  Single-way correlation only (fmap1o must be None: ``--f1 none``)."""
+        if fmap1o is not None:
+            raise NotImplementedError("two-way correlation (--f1 shared|private) is outside the HIP path")
+        B, C, H8, W8 = fmap1.shape
+        x1 = ops.tokens_from_nchw(fmap1.float(), ln=True)
+        x2 = ops.tokens_from_nchw(fmap2.float(), ln=True)
+        self.update_tokens(x1, x2, (H8, W8), getattr(self, "hip_prec", PREC_F32))

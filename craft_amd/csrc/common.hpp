@@ -1,0 +1,66 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+#define CRAFT_PREC_F32 0
+#define CRAFT_PREC_BF16 1
+#define CRAFT_PREC_F16 2
+
+#define CRAFT_ACT_NONE 0
+#define CRAFT_ACT_TANH 1
+#define CRAFT_ACT_RELU 2
+#define CRAFT_ACT_SIGMOID 3
+
+#define CRAFT_ATTN_CLIP 100.0f   // setrans.py:98
+#define CRAFT_LN_EPS 1e-12f      // setrans.py:715, :362; corr.py:203
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case CRAFT_ACT_TANH: return tanhf(v);
+    case CRAFT_ACT_RELU: return fmaxf(v, 0.f);
+    case CRAFT_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    default: return v;
+  }
+}
+__device__ __forceinline__ float sigmoid_precise(float v) { return 1.f / (1.f + expf(-v)); }
+
+// order-preserving float <-> uint map, for atomicMax on floats
+__device__ __forceinline__ unsigned f2ord(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// sliding positional bias: biases[(dh+R)*(2R+1) + (dw+R)] if |dh|<=R && |dw|<=R else 0
+// (closed form of SlidingPosBiases2D.forward, setrans.py:690-708)
+__device__ __forceinline__ float pos_bias_at(const float* __restrict__ tab, int R, int h1, int w1, int h2, int w2) {
+  int dh = h2 - h1, dw = w2 - w1;
+  if (dh < -R || dh > R || dw < -R || dw > R) return 0.f;
+  return tab[(dh + R) * (2 * R + 1) + (dw + R)];
+}
+
+#define HIP_CHECK_RET(expr)                 \
+  do {                                      \
+    hipError_t _e = (expr);                 \
+    if (_e != hipSuccess) return (int)_e;   \
+  } while (0)

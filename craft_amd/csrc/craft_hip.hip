@@ -1,0 +1,210 @@
+// C ABI of libcraft_hip.so (declared in include/craft_hip.h): thin argument marshalling over the kernel
+// launchers; operator-level entry points (motion encoder, GRU, heads) compose several launches.
+#include "launch.hpp"
+#include "../../include/craft_hip.h"
+
+using namespace craft;
+
+#define S(stream) reinterpret_cast<hipStream_t>(stream)
+#define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+extern "C" {
+
+int craft_hip_abi_version(void) { return CRAFT_HIP_ABI_VERSION; }
+
+const char* craft_hip_error_string(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case CRAFT_ERR_ARG: return "craft: invalid argument";
+    case CRAFT_ERR_ALIGN: return "craft: alignment / divisibility requirement violated (strides %4, segment channels %32, d %32)";
+    case CRAFT_ERR_UNSUPPORTED: return "craft: size outside supported range";
+    default: return hipGetErrorString((hipError_t)code);
+  }
+}
+
+int craft_tokens(const float* src, int src_nchw, int B, int Ctot, int c_off, int C, int HW, long src_ld, int act,
+                 int do_ln, float* dst, long dst_ld, void* stream) {
+  return launch_tokens(src, src_nchw, B, Ctot, c_off, C, HW, src_ld, act, do_ln, dst, dst_ld, S(stream));
+}
+
+int craft_tokens_to_nchw(const float* src, long ld, int B, int C, int HW, float* dst, void* stream) {
+  return launch_tokens_to_nchw(src, ld, B, C, HW, dst, S(stream));
+}
+
+int craft_linear(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, long rows, int cin,
+                 int cout, int prec, void* stream) {
+  RowsGemmParams p = {};
+  p.A = x; p.lda = ldx; p.B = w; p.ldb = cin; p.C = y; p.ldc = ldy;
+  p.zdiv = 1; p.batch = 1; p.M = (int)rows; p.N = cout; p.K = cin;
+  p.bias = bias; p.scale = 1.f; p.act = CRAFT_ACT_NONE;
+  return launch_gemm_rows(p, prec, false, S(stream));
+}
+
+int craft_linear_t(const float* x, long ldx, const float* w, float* yT, long ldt, int B, int N, int cin, int cout,
+                   int prec, void* stream) {
+  RowsGemmParams p = {};
+  p.A = w; p.lda = cin; p.B = x; p.ldb = ldx; p.b_bs0 = (long)N * ldx; p.C = yT; p.ldc = ldt; p.c_bs0 = (long)cout * ldt;
+  p.zdiv = 1; p.batch = B; p.M = cout; p.N = N; p.K = cin;
+  p.bias = nullptr; p.scale = 1.f; p.act = CRAFT_ACT_NONE;
+  return launch_gemm_rows(p, prec, false, S(stream));
+}
+
+static ScoreParams make_score(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d,
+                              float scale, const float* pos_tab, int R, float pos_w, int mask_radius,
+                              const unsigned* clamp_ord) {
+  ScoreParams p = {};
+  p.Q = q; p.Kf = k; p.ldq = ldq; p.ldk = ldk;
+  p.B = B; p.H8 = H8; p.W8 = W8; p.N = H8 * W8;
+  p.q_bs = (long)p.N * ldq; p.k_bs = (long)p.N * ldk;
+  p.M = M; p.d = d; p.scale = scale; p.pos_tab = pos_tab; p.R = R; p.pos_w = pos_w; p.mask_radius = mask_radius;
+  p.clamp_ord = clamp_ord;
+  return p;
+}
+
+int craft_score_max(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d, float scale,
+                    unsigned* max_ord, int prec, void* stream) {
+  return launch_score_max(make_score(q, ldq, k, ldk, B, H8, W8, M, d, scale, nullptr, 0, 0.f, -1, nullptr), max_ord, prec,
+                          S(stream));
+}
+
+int craft_corr_build(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d, float scale,
+                     const float* pos_tab, int R, float pos_w, float w_aggr, const unsigned* clamp_ord, float* pyr0,
+                     double* sums, int prec, void* stream) {
+  return launch_corr_build(make_score(q, ldq, k, ldk, B, H8, W8, M, d, scale, pos_tab, R, pos_w, -1, clamp_ord), w_aggr,
+                           pyr0, sums, prec, S(stream));
+}
+
+int craft_corr_finish(const float* pyr0, float* pyr1, float* pyr2, float* pyr3, const double* sums, float* mu_rstd, int B,
+                      int H8, int W8, int do_norm, void* stream) {
+  const long N = (long)H8 * W8;
+  if (pyr1) TRY(launch_corr_pyramid(pyr0, pyr1, pyr2, pyr3, (long)B * N, H8, W8, S(stream)));
+  return launch_corr_stats(sums, mu_rstd, B, (double)N * (double)N, do_norm, S(stream));
+}
+
+int craft_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3, int levels,
+                      const float* mu_rstd, const float* coords, int B, int H8, int W8, int radius, float* out, long ldo,
+                      void* stream) {
+  return launch_corr_lookup(pyr0, pyr1, pyr2, pyr3, levels, mu_rstd, coords, B, H8, W8, radius, out, ldo, S(stream));
+}
+
+int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d, float scale,
+                     const float* pos_tab, int R, float pos_w, int mask_radius, const unsigned* clamp_ord, void* P,
+                     long ldp, int prec, void* stream) {
+  return launch_attn_probs(make_score(q, ldq, k, ldk, B, H8, W8, M, d, scale, pos_tab, R, pos_w, mask_radius, clamp_ord), P,
+                           ldp, prec, S(stream));
+}
+
+int craft_attn_apply(const void* P, long ldp, const float* vT, int B, int N, int M, int Dv, float* O, int prec,
+                     void* stream) {
+  RowsGemmParams p = {};
+  p.A = P; p.lda = ldp; p.a_bs0 = (long)M * N * ldp; p.a_bs1 = (long)N * ldp;
+  p.B = vT; p.ldb = ldp; p.b_bs0 = (long)M * Dv * ldp; p.b_bs1 = (long)Dv * ldp;
+  p.C = O; p.ldc = Dv; p.c_bs0 = (long)M * N * Dv; p.c_bs1 = (long)N * Dv;
+  p.zdiv = M; p.batch = B * M; p.M = N; p.N = Dv; p.K = (int)ldp;
+  p.bias = nullptr; p.scale = 1.f; p.act = CRAFT_ACT_NONE;
+  return launch_gemm_rows(p, prec, prec != CRAFT_PREC_F32, S(stream));
+}
+
+int craft_mode_pool_ln(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff, int B, int N,
+                       int M, int C, float* out, long ldo, void* stream) {
+  return launch_mode_pool_ln(O, x, ldx, w_agg, skip_coeff, B, N, M, C, out, ldo, S(stream));
+}
+
+int craft_gma_residual(const float* mf, long ldm, const float* O, const float* gamma, int B, int N, int C, float* out,
+                       long ldo, void* stream) {
+  return launch_gma_residual(mf, ldm, O, gamma, B, N, C, out, ldo, S(stream));
+}
+
+static ConvGemmParams conv_params(const float* in0, int ld0, int c0, const float* in1, int ld1, int c1, int B, int H8, int W8,
+                                  int KH, int KW, const float* W, const float* bias, int cout, int epi, int act, float scale,
+                                  float* out, int ldo) {
+  ConvGemmParams p = {};
+  p.g.seg0 = in0; p.g.ld0 = ld0; p.g.c0 = c0; p.g.seg1 = in1; p.g.ld1 = ld1; p.g.c1 = c1;
+  p.g.H = H8; p.g.W = W8; p.g.KH = KH; p.g.KW = KW; p.g.padH = KH / 2; p.g.padW = KW / 2; p.g.npix = B * H8 * W8;
+  p.W = W; p.bias = bias; p.cout = cout; p.epi = epi; p.act = act; p.scale = scale; p.out = out; p.ldo = ldo;
+  return p;
+}
+
+int craft_motion_encoder(const float* corr, long ldc, int cor_planes, const float* flow, const float* wc1, const float* bc1,
+                         const float* wc2, const float* bc2, const float* wf1, const float* bf1, const float* wf2,
+                         const float* bf2, const float* wcv, const float* bcv, int B, int H8, int W8, float* out, long ldo,
+                         float* ws, int prec, void* stream) {
+  const long npix = (long)B * H8 * W8;
+  float* cor1 = ws;                    // [npix][256]
+  float* corflo = ws + npix * 256;     // [npix][256] = [cor (192) | flo (64)]
+  float* flo1 = ws + npix * 512;       // [npix][128]
+  hipStream_t s = S(stream);
+  {  // cor = relu(convc1(corr))  1x1, cor_planes -> 256   (update.py:80)
+    RowsGemmParams p = {};
+    p.A = corr; p.lda = ldc; p.B = wc1; p.ldb = cor_planes; p.C = cor1; p.ldc = 256;
+    p.zdiv = 1; p.batch = 1; p.M = (int)npix; p.N = 256; p.K = cor_planes; p.bias = bc1; p.scale = 1.f; p.act = CRAFT_ACT_RELU;
+    TRY(launch_gemm_rows(p, prec, false, s));
+  }
+  // cor = relu(convc2(cor))  3x3, 256 -> 192   (update.py:81)
+  TRY(launch_gemm_conv(conv_params(cor1, 256, 256, nullptr, 0, 0, B, H8, W8, 3, 3, wc2, bc2, 192, CONV_EPI_BIAS_ACT,
+                                   CRAFT_ACT_RELU, 1.f, corflo, 256), prec, s));
+  // flo = relu(convf1(flow))  7x7, 2 -> 128   (update.py:82)
+  TRY(launch_convf1(flow, wf1, bf1, B, H8, W8, flo1, 128, s));
+  // flo = relu(convf2(flo))  3x3, 128 -> 64   (update.py:83) -> columns 192..255 of corflo (the torch.cat of :85)
+  TRY(launch_gemm_conv(conv_params(flo1, 128, 128, nullptr, 0, 0, B, H8, W8, 3, 3, wf2, bf2, 64, CONV_EPI_BIAS_ACT,
+                                   CRAFT_ACT_RELU, 1.f, corflo + 192, 256), prec, s));
+  // out = cat[relu(conv(cor_flo)) (126), flow (2)]  (update.py:86-87)
+  ConvGemmParams p = conv_params(corflo, 256, 256, nullptr, 0, 0, B, H8, W8, 3, 3, wcv, bcv, 126, CONV_EPI_MENC,
+                                 CRAFT_ACT_RELU, 1.f, out, (int)ldo);
+  p.aux0 = flow; p.ld0 = 2;
+  return launch_gemm_conv(p, prec, s);
+}
+
+int craft_sepconv_gru(float* hx, long ldhx, int cx, const float* wzr1, const float* bzr1, const float* wq1,
+                      const float* bq1, const float* wzr2, const float* bzr2, const float* wq2, const float* bq2, int B,
+                      int H8, int W8, float* ws, int prec, void* stream) {
+  const long npix = (long)B * H8 * W8;
+  float* z = ws;                 // [npix][128]
+  float* rh = ws + npix * 128;   // [npix][128]
+  hipStream_t s = S(stream);
+  const float* wzr[2] = {wzr1, wzr2};
+  const float* bzr[2] = {bzr1, bzr2};
+  const float* wq[2] = {wq1, wq2};
+  const float* bq[2] = {bq1, bq2};
+  for (int pass = 0; pass < 2; ++pass) {
+    const int KH = pass == 0 ? 1 : 5, KW = pass == 0 ? 5 : 1;
+    // z = sigmoid(convz(hx)), r = sigmoid(convr(hx)); rh = r*h   (update.py:51-53 / :58-60)
+    ConvGemmParams a = conv_params(hx, (int)ldhx, 128 + cx, nullptr, 0, 0, B, H8, W8, KH, KW, wzr[pass], bzr[pass], 256,
+                                   CONV_EPI_GRU_ZR, 0, 1.f, z, 128);
+    a.aux0 = hx; a.ld0 = (int)ldhx; a.aux1 = rh; a.ld1 = 128;
+    TRY(launch_gemm_conv(a, prec, s));
+    // q = tanh(convq(cat[r*h, x])); h = (1-z)*h + z*q   (update.py:54-55 / :61-62)
+    ConvGemmParams q = conv_params(rh, 128, 128, hx + 128, (int)ldhx, cx, B, H8, W8, KH, KW, wq[pass], bq[pass], 128,
+                                   CONV_EPI_GRU_Q, 0, 1.f, hx, (int)ldhx);
+    q.aux0 = hx; q.ld0 = (int)ldhx; q.aux1 = z; q.ld1 = 128;
+    TRY(launch_gemm_conv(q, prec, s));
+  }
+  return 0;
+}
+
+int craft_flow_head(const float* h, long ldh, const float* w1, const float* b1, const float* w2, const float* b2, int B,
+                    int H8, int W8, float* coords1, const float* coords0, float* flow, float* delta, float* ws, int prec,
+                    void* stream) {
+  TRY(launch_gemm_conv(conv_params(h, (int)ldh, 128, nullptr, 0, 0, B, H8, W8, 3, 3, w1, b1, 256, CONV_EPI_BIAS_ACT,
+                                   CRAFT_ACT_RELU, 1.f, ws, 256), prec, S(stream)));
+  return launch_flow_head2(ws, w2, b2, B, H8, W8, coords1, coords0, flow, delta, S(stream));
+}
+
+int craft_mask_head(const float* h, long ldh, const float* w0, const float* b0, const float* w2, const float* b2, int B,
+                    int H8, int W8, float* mask, float* ws, int prec, void* stream) {
+  TRY(launch_gemm_conv(conv_params(h, (int)ldh, 128, nullptr, 0, 0, B, H8, W8, 3, 3, w0, b0, 256, CONV_EPI_BIAS_ACT,
+                                   CRAFT_ACT_RELU, 1.f, ws, 256), prec, S(stream)));
+  return launch_gemm_conv(conv_params(ws, 256, 256, nullptr, 0, 0, B, H8, W8, 1, 1, w2, b2, 576, CONV_EPI_BIAS_ACT,
+                                      CRAFT_ACT_NONE, 0.25f, mask, 576), prec, S(stream));
+}
+
+int craft_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, void* stream) {
+  return launch_convex_upsample(mask, flow, B, H8, W8, up, S(stream));
+}
+
+int craft_coords_init(const float* flow_init_nchw, int B, int H8, int W8, float* coords0, float* coords1, float* flow,
+                      void* stream) {
+  return launch_coords_init(flow_init_nchw, B, H8, W8, coords0, coords1, flow, S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,304 @@
+// Tiled MFMA "NT" GEMM engine for gfx950:  C[m,n] = sum_k A[m,k] * B[n,k]   (both operands K-contiguous).
+//
+// Everything dense on CRAFT's hot path is expressed in this one form:
+//   * nn.Linear projections                       A = tokens [rows, Cin],          B = W [Cout, Cin]
+//   * NHWC implicit-GEMM convolutions             A = gathered pixels [B*H*W, taps*Cin], B = packed W [Cout, taps*Cin]
+//   * attention scores / correlation volume       A = Q rows, B = K rows (mode m = column slice m*d..)
+//   * attention apply  O = P V                    A = P [N, N],  B = V^T [Dv, N]
+//
+// Block = 256 threads = 4 waves (WM x WN); block tile BM x BN, K-tile 32; each wave owns
+// (BM/WM) x (BN/WN) as MT x NT MFMA tiles of 32x32.  Operands are staged global -> registers -> LDS
+// (double-buffered, one barrier per K-tile; the next tile's global loads are in flight during the
+// MFMAs) and read back as 16-byte fragments.
+//
+// Precision (template PREC): F32 uses v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain);
+// BF16 / F16 convert while staging into LDS and use v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulate.
+//
+// K-slot trick: an NT product is invariant under any permutation of k applied to both operands, so
+// each lane reads ONE 16-byte vector per operand per MFMA group and feeds its components to
+// successive MFMAs; which k lands in which hardware k-slot is irrelevant as long as A and B agree.
+// LDS rows are padded (fp32: 36 floats = 144 B, 16-bit: 40 halves = 80 B) so the 16-lane groups of
+// ds_read_b128 hit distinct 16-B bank slots (MI355X_MICROARCH §LDS).
+#pragma once
+#include "common.hpp"
+
+namespace craft {
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+
+template <int PREC> struct PrecT;
+template <> struct PrecT<CRAFT_PREC_F32> { typedef float lds_t; static constexpr int LD = 36; };
+template <> struct PrecT<CRAFT_PREC_BF16> { typedef __bf16 lds_t; static constexpr int LD = 40; };
+template <> struct PrecT<CRAFT_PREC_F16> { typedef _Float16 lds_t; static constexpr int LD = 40; };
+
+template <int PREC, int BM, int BN> struct TileLds {
+  typedef typename PrecT<PREC>::lds_t lds_t;
+  static constexpr int LD = PrecT<PREC>::LD;
+  static constexpr int A_ELEMS = BM * LD;
+  static constexpr int B_ELEMS = BN * LD;
+  static constexpr int BYTES = 2 * (A_ELEMS + B_ELEMS) * (int)sizeof(lds_t);
+};
+
+// ---------------------------------------------------------------------------------------------
+// staging registers
+// ---------------------------------------------------------------------------------------------
+template <int ROWS> struct RegsF32 { float4 v[ROWS / 32]; };   // thread: k-chunk (tid&7)*4, rows (tid>>3)+32*i
+template <int ROWS> struct RegsH16 { uint4 v[ROWS / 64]; };    // thread: k-chunk (tid&3)*8, rows (tid>>2)+64*i
+
+template <int PREC, int ROWS>
+__device__ __forceinline__ void stage_store(typename PrecT<PREC>::lds_t* S, const RegsF32<ROWS>& r, int tid) {
+  constexpr int LD = PrecT<PREC>::LD;
+  const int c4 = tid & 7, r0 = tid >> 3;
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) {
+    const int row = r0 + 32 * i;
+    if constexpr (PREC == CRAFT_PREC_F32) {
+      *reinterpret_cast<float4*>(&S[row * LD + c4 * 4]) = r.v[i];
+    } else if constexpr (PREC == CRAFT_PREC_BF16) {
+      bf16x4 h;
+      h[0] = (__bf16)r.v[i].x; h[1] = (__bf16)r.v[i].y; h[2] = (__bf16)r.v[i].z; h[3] = (__bf16)r.v[i].w;
+      *reinterpret_cast<bf16x4*>(&S[row * LD + c4 * 4]) = h;
+    } else {
+      f16x4 h;
+      h[0] = (_Float16)r.v[i].x; h[1] = (_Float16)r.v[i].y; h[2] = (_Float16)r.v[i].z; h[3] = (_Float16)r.v[i].w;
+      *reinterpret_cast<f16x4*>(&S[row * LD + c4 * 4]) = h;
+    }
+  }
+}
+template <int PREC, int ROWS>
+__device__ __forceinline__ void stage_store(typename PrecT<PREC>::lds_t* S, const RegsH16<ROWS>& r, int tid) {
+  static_assert(PREC != CRAFT_PREC_F32, "16-bit operands need a 16-bit MFMA mode");
+  constexpr int LD = PrecT<PREC>::LD;
+  const int c8 = tid & 3, r0 = tid >> 2;
+#pragma unroll
+  for (int i = 0; i < ROWS / 64; ++i) {
+    const int row = r0 + 64 * i;
+    *reinterpret_cast<uint4*>(&S[row * LD + c8 * 8]) = r.v[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// loaders (global -> registers).  fetch(kt, regs) loads K-tile kt (k in [32kt, 32kt+32)).
+// ---------------------------------------------------------------------------------------------
+// Plain fp32 rows: element (row, k) at base[row*ld + k]; rows >= nrows and k >= K read as zero.
+// Requirements: base 16-B aligned, ld % 4 == 0, K % 4 == 0.
+template <int ROWS> struct LoaderRowsF32 {
+  typedef RegsF32<ROWS> Regs;
+  const float* p[ROWS / 32];
+  int K, kcol;
+  __device__ __forceinline__ void init(const float* base, long ld, int row0, int nrows, int K_, int tid) {
+    K = K_;
+    kcol = (tid & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+      const int row = row0 + (tid >> 3) + 32 * i;
+      p[i] = (row < nrows) ? base + (long)row * ld + kcol : nullptr;
+    }
+  }
+  __device__ __forceinline__ void fetch(int kt, Regs& r) const {
+    const bool kok = kt * BK + kcol < K;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+      if (p[i] != nullptr && kok) r.v[i] = *reinterpret_cast<const float4*>(p[i] + kt * BK);
+      else r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+};
+
+// 16-bit rows (attention probabilities P): ld % 8 == 0, K % 8 == 0.
+template <int ROWS> struct LoaderRowsH16 {
+  typedef RegsH16<ROWS> Regs;
+  const uint16_t* p[ROWS / 64];
+  int K, kcol;
+  __device__ __forceinline__ void init(const uint16_t* base, long ld, int row0, int nrows, int K_, int tid) {
+    K = K_;
+    kcol = (tid & 3) * 8;
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) {
+      const int row = row0 + (tid >> 2) + 64 * i;
+      p[i] = (row < nrows) ? base + (long)row * ld + kcol : nullptr;
+    }
+  }
+  __device__ __forceinline__ void fetch(int kt, Regs& r) const {
+    const bool kok = kt * BK + kcol < K;
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) {
+      if (p[i] != nullptr && kok) r.v[i] = *reinterpret_cast<const uint4*>(p[i] + kt * BK);
+      else r.v[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+};
+
+// NHWC implicit-GEMM gather: row = pixel (b, y, x); k = (tap, channel) over up to two concatenated
+// channel segments (a virtual torch.cat: seg0 has c0 channels at row stride ld0, seg1 c1 at ld1).
+// Each segment's channel count must be a multiple of 32, so a K-tile never straddles a tap or segment.
+struct ConvGeom {
+  const float* seg0; const float* seg1;
+  int ld0, ld1, c0, c1;
+  int H, W, KH, KW, padH, padW;
+  int npix;                                  // B*H*W
+};
+template <int ROWS> struct LoaderConvF32 {
+  typedef RegsF32<ROWS> Regs;
+  ConvGeom g;
+  int py[ROWS / 32], px[ROWS / 32];
+  long pimg[ROWS / 32];
+  int kcol, ctot;
+  __device__ __forceinline__ void init(const ConvGeom& g_, int row0, int tid) {
+    g = g_;
+    kcol = (tid & 7) * 4;
+    ctot = g.c0 + g.c1;
+    const int hw = g.H * g.W;
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+      const int row = row0 + (tid >> 3) + 32 * i;
+      if (row < g.npix) {
+        const int b = row / hw, rem = row - b * hw;
+        py[i] = rem / g.W;
+        px[i] = rem - py[i] * g.W;
+        pimg[i] = (long)b * hw;
+      } else {
+        py[i] = -100000; px[i] = 0; pimg[i] = 0;
+      }
+    }
+  }
+  __device__ __forceinline__ void fetch(int kt, Regs& r) const {
+    const int k0 = kt * BK;
+    const int tap = k0 / ctot, cb = k0 - tap * ctot;
+    const int ty = tap / g.KW;
+    const int dy = ty - g.padH, dx = (tap - ty * g.KW) - g.padW;
+    const float* sp; int ld, c;
+    if (cb < g.c0) { sp = g.seg0; ld = g.ld0; c = cb; } else { sp = g.seg1; ld = g.ld1; c = cb - g.c0; }
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; ++i) {
+      const int yy = py[i] + dy, xx = px[i] + dx;
+      if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)
+        r.v[i] = *reinterpret_cast<const float4*>(sp + (pimg[i] + (long)yy * g.W + xx) * ld + c + kcol);
+      else
+        r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// LDS fragments -> MFMA
+// ---------------------------------------------------------------------------------------------
+template <int PREC, int MT, int NT>
+__device__ __forceinline__ void mma_tile(const typename PrecT<PREC>::lds_t* As, const typename PrecT<PREC>::lds_t* Bs,
+                                         int wm0, int wn0, int lane, f32x16 (&acc)[MT][NT]) {
+  constexpr int LD = PrecT<PREC>::LD;
+  const int r = lane & 31, g = lane >> 5;
+  if constexpr (PREC == CRAFT_PREC_F32) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float4 a[MT], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(&As[(wm0 + mt * 32 + r) * LD + kk * 8 + g * 4]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(&Bs[(wn0 + nt * 32 + r) * LD + kk * 8 + g * 4]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
+        }
+    }
+  } else if constexpr (PREC == CRAFT_PREC_BF16) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 a[MT], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(&As[(wm0 + mt * 32 + r) * LD + kk * 16 + g * 8]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const bf16x8*>(&Bs[(wn0 + nt * 32 + r) * LD + kk * 16 + g * 8]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      f16x8 a[MT], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f16x8*>(&As[(wm0 + mt * 32 + r) * LD + kk * 16 + g * 8]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f16x8*>(&Bs[(wn0 + nt * 32 + r) * LD + kk * 16 + g * 8]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+}
+
+template <int MT, int NT> __device__ __forceinline__ void acc_zero(f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+}
+
+// Visit every accumulator element of this lane: f(row_in_wave_tile, col_in_wave_tile, value, mt, nt, reg).
+// C/D layout of the 32x32 MFMA family: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+template <int MT, int NT, class F>
+__device__ __forceinline__ void acc_foreach(f32x16 (&acc)[MT][NT], int lane, F&& f) {
+  const int c = lane & 31, rh = 4 * (lane >> 5);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) f(mt * 32 + (e & 3) + 8 * (e >> 2) + rh, nt * 32 + c, acc[mt][nt][e], mt, nt, e);
+}
+
+struct NoFold { __device__ __forceinline__ void operator()(int) const {} };
+
+// The K loop.  `fold(kt)` runs after K-tile kt has been accumulated (used by the correlation build to
+// close a mode every d/32 tiles).  Ends with a barrier, so it can be called repeatedly.
+template <int PREC, int BM, int BN, int WM, int WN, class LA, class LB, class FOLD>
+__device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int nk, char* smem,
+                                              f32x16 (&acc)[BM / WM / 32][BN / WN / 32], FOLD&& fold) {
+  typedef typename PrecT<PREC>::lds_t lds_t;
+  typedef TileLds<PREC, BM, BN> L;
+  constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
+  lds_t* As[2];
+  lds_t* Bs[2];
+  As[0] = reinterpret_cast<lds_t*>(smem);
+  As[1] = As[0] + L::A_ELEMS;
+  Bs[0] = As[1] + L::A_ELEMS;
+  Bs[1] = Bs[0] + L::B_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+  typename LA::Regs ra;
+  typename LB::Regs rb;
+  la.fetch(0, ra);
+  lb.fetch(0, rb);
+  stage_store<PREC>(As[0], ra, tid);
+  stage_store<PREC>(Bs[0], rb, tid);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      la.fetch(kt + 1, ra);
+      lb.fetch(kt + 1, rb);
+    }
+    mma_tile<PREC, MT, NT>(As[cur], Bs[cur], wm0, wn0, lane, acc);
+    fold(kt);
+    if (kt + 1 < nk) {
+      stage_store<PREC>(As[cur ^ 1], ra, tid);
+      stage_store<PREC>(Bs[cur ^ 1], rb, tid);
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace craft

@@ -1,0 +1,269 @@
+// Multi-mode attention scores on the GEMM engine (CrossAttFeatTrans, setrans.py:501-566):
+//   k_corr_build<MAXONLY=false> : inter-frame correlation volume  c(i,j) = sum_m s_m softmax_m(w s_m) + pw*pb(i,j)
+//                                 written straight into pyramid level 0, plus per-sample (sum, sum^2) for the
+//                                 lazy global LayerNorm (corr.py:200-204).  The 4-mode score tensor never exists.
+//   k_corr_build<MAXONLY=true>  : global max of the raw scaled scores -> clamp decision (setrans.py:520-529)
+//   k_attn_probs                : P_m = softmax_j(S_m + pw*pb (+mask)), two passes over the keys per query tile
+//                                 (row max / row sum, then normalised write); P is written once, fp32 or 16-bit.
+#include "gemm_engine.hpp"
+#include "launch.hpp"
+
+namespace craft {
+
+// ---------------------------------------------------------------------------------------------
+// correlation build / score max.  grid (query tiles of 128, key tiles of 64, B)
+// ---------------------------------------------------------------------------------------------
+template <int PREC, bool MAXONLY>
+__global__ __launch_bounds__(NTHREADS) void k_corr_build(ScoreParams p, float w_aggr, float* __restrict__ pyr0,
+                                                        double* __restrict__ sums, unsigned* __restrict__ max_ord) {
+  constexpr int BM = 128, BN = 64, WM = 2, WN = 2, MT = 2, NT = 1;
+  __shared__ __attribute__((aligned(16))) char smem[TileLds<PREC, BM, BN>::BYTES];
+  __shared__ int s_rh[BM], s_rw[BM];
+  __shared__ float s_tab[961];
+  __shared__ float s_red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, b = blockIdx.z;
+  const int N = p.N;
+  const int K = p.M * p.d, tpm = p.d / BK, nk = K / BK;
+  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+  const int c_lane = lane & 31, rh4 = 4 * (lane >> 5);
+  const int col = n0 + wn0 + c_lane;
+  const bool clamp = (!MAXONLY) && p.clamp_ord != nullptr && ord2f(*p.clamp_ord) > CRAFT_ATTN_CLIP;
+
+  if (!MAXONLY) {
+    if (tid < BM) { const int r = m0 + tid; s_rh[tid] = r / p.W8; s_rw[tid] = r - (r / p.W8) * p.W8; }
+    if (p.pos_tab) { const int T = (2 * p.R + 1) * (2 * p.R + 1); for (int i = tid; i < T; i += NTHREADS) s_tab[i] = p.pos_tab[i]; }
+  }
+
+  LoaderRowsF32<BM> la;
+  la.init(p.Q + (long)b * p.q_bs, p.ldq, m0, N, K, tid);
+  LoaderRowsF32<BN> lb;
+  lb.init(p.Kf + (long)b * p.k_bs, p.ldk, n0, N, K, tid);
+
+  f32x16 acc[MT][NT];
+  acc_zero(acc);
+  float mx[MT][16], den[MT][16], num[MT][16];
+  float vmax = -INFINITY;
+
+  auto fold = [&](int kt) {
+    if ((kt + 1) % tpm != 0) return;
+    const bool first = (kt + 1 == tpm);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float s = acc[mt][0][e] * p.scale;
+        acc[mt][0][e] = 0.f;
+        if (MAXONLY) {
+          const int row = m0 + wm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
+          if (row < N && col < N) vmax = fmaxf(vmax, s);
+        } else {
+          if (clamp) s = fminf(fmaxf(s, -CRAFT_ATTN_CLIP), CRAFT_ATTN_CLIP);
+          const float t = w_aggr * s;
+          if (first) { mx[mt][e] = t; den[mt][e] = 1.f; num[mt][e] = s; }
+          else {
+            const float nm = fmaxf(mx[mt][e], t);
+            const float e0 = expf(mx[mt][e] - nm), e1 = expf(t - nm);
+            den[mt][e] = den[mt][e] * e0 + e1;
+            num[mt][e] = num[mt][e] * e0 + s * e1;
+            mx[mt][e] = nm;
+          }
+        }
+      }
+  };
+  gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, smem, acc, fold);
+
+  if (MAXONLY) {
+    vmax = wave_max(vmax);
+    if (lane == 0) s_red[wave] = vmax;
+    __syncthreads();
+    if (tid == 0) {
+      const float v = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+      if (v > -INFINITY) atomicMax(max_ord, f2ord(v));
+    }
+    return;
+  }
+
+  const int h2 = col / p.W8, w2 = col - h2 * p.W8;
+  float s1 = 0.f, s2 = 0.f;
+  float* out = pyr0 + (long)b * N * N;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rl = wm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
+      const int row = m0 + rl;
+      if (row < N && col < N) {
+        float c = num[mt][e] / den[mt][e];
+        if (p.pos_tab) {
+          const int dh = h2 - s_rh[rl], dw = w2 - s_rw[rl];
+          if (dh >= -p.R && dh <= p.R && dw >= -p.R && dw <= p.R) c += p.pos_w * s_tab[(dh + p.R) * (2 * p.R + 1) + dw + p.R];
+        }
+        out[(long)row * N + col] = c;
+        s1 += c;
+        s2 += c * c;
+      }
+    }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) { s_red[wave] = s1; s_red[4 + wave] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    const double a = (double)s_red[0] + (double)s_red[1] + (double)s_red[2] + (double)s_red[3];
+    const double q = (double)s_red[4] + (double)s_red[5] + (double)s_red[6] + (double)s_red[7];
+    atomicAdd(&sums[2 * b], a);
+    atomicAdd(&sums[2 * b + 1], q);
+  }
+}
+
+static int check_score(const ScoreParams& p) {
+  if (p.d % BK || p.M < 1 || (p.ldq & 3) || (p.ldk & 3) || (p.q_bs & 3) || (p.k_bs & 3)) return CRAFT_ERR_ALIGN;
+  if (p.pos_tab && p.R > 15) return CRAFT_ERR_UNSUPPORTED;
+  return 0;
+}
+
+int launch_score_max(const ScoreParams& p, unsigned* max_ord, int prec, hipStream_t s) {
+  if (int e = check_score(p)) return e;
+  dim3 grid((p.N + 127) / 128, (p.N + 63) / 64, p.B);
+  hipError_t me = hipMemsetAsync(max_ord, 0, sizeof(unsigned), s);
+  if (me != hipSuccess) return (int)me;
+  if (prec == CRAFT_PREC_F32) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_F32, true>), grid, dim3(NTHREADS), 0, s, p, 0.f, nullptr, nullptr, max_ord);
+  else if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_BF16, true>), grid, dim3(NTHREADS), 0, s, p, 0.f, nullptr, nullptr, max_ord);
+  else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_F16, true>), grid, dim3(NTHREADS), 0, s, p, 0.f, nullptr, nullptr, max_ord);
+  else return CRAFT_ERR_ARG;
+  return (int)hipGetLastError();
+}
+
+int launch_corr_build(const ScoreParams& p, float w_aggr, float* pyr0, double* sums, int prec, hipStream_t s) {
+  if (int e = check_score(p)) return e;
+  dim3 grid((p.N + 127) / 128, (p.N + 63) / 64, p.B);
+  hipError_t me = hipMemsetAsync(sums, 0, sizeof(double) * 2 * p.B, s);
+  if (me != hipSuccess) return (int)me;
+  if (prec == CRAFT_PREC_F32) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_F32, false>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums, nullptr);
+  else if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_BF16, false>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums, nullptr);
+  else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_F16, false>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums, nullptr);
+  else return CRAFT_ERR_ARG;
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention probabilities.  grid (query tiles of 128, B*M).  "Swapped" product: keys are the MFMA row
+// operand and queries the column operand, so a lane owns ONE query (col = lane&31) and 64 of the 128
+// keys of a tile: the softmax row statistics stay lane-local (one cross-half exchange at the end).
+// ---------------------------------------------------------------------------------------------
+template <int PREC> struct ProbT;
+template <> struct ProbT<CRAFT_PREC_F32> { typedef float t; };
+template <> struct ProbT<CRAFT_PREC_BF16> { typedef __bf16 t; };
+template <> struct ProbT<CRAFT_PREC_F16> { typedef _Float16 t; };
+
+template <int PREC>
+__global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __restrict__ Pout, long ldp) {
+  constexpr int BM = 128, BN = 128, WM = 1, WN = 4, MT = 4, NT = 1;
+  typedef typename ProbT<PREC>::t prob_t;
+  __shared__ __attribute__((aligned(16))) char smem[TileLds<PREC, BM, BN>::BYTES];
+  __shared__ int s_kh[BM], s_kw[BM];
+  __shared__ float s_tab[961];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * BN, z = blockIdx.y;
+  const int b = z / p.M, m = z - b * p.M;
+  const int N = p.N;
+  const int qcol = n0 + wave * 32 + (lane & 31);
+  const int h1 = qcol / p.W8, w1 = qcol - h1 * p.W8;
+  const int rh4 = 4 * (lane >> 5);
+  const bool clamp = p.clamp_ord != nullptr && ord2f(*p.clamp_ord) > CRAFT_ATTN_CLIP;
+  const int nkt = (N + BM - 1) / BM, nk = p.d / BK;
+  if (p.pos_tab) { const int T = (2 * p.R + 1) * (2 * p.R + 1); for (int i = tid; i < T; i += NTHREADS) s_tab[i] = p.pos_tab[i]; }
+
+  LoaderRowsF32<BN> lb;
+  lb.init(p.Q + (long)b * p.q_bs + (long)m * p.d, p.ldq, n0, N, p.d, tid);
+  const float* kbase = p.Kf + (long)b * p.k_bs + (long)m * p.d;
+  prob_t* Prow = reinterpret_cast<prob_t*>(Pout) + ((long)z * N + qcol) * ldp;
+
+  float m_run = -INFINITY, l_run = 0.f, inv_l = 0.f;
+  f32x16 acc[MT][NT];
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int jt = 0; jt < nkt; ++jt) {
+      if (tid < BM) { const int j = jt * BM + tid; s_kh[tid] = j / p.W8; s_kw[tid] = j - (j / p.W8) * p.W8; }
+      LoaderRowsF32<BM> la;
+      la.init(kbase, p.ldk, jt * BM, N, p.d, tid);
+      acc_zero(acc);
+      gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, smem, acc, NoFold());
+      // scores of this lane: key row r = mt*32 + 8*q + rh4 + i  (q = reg>>2, i = reg&3)
+      float sv[MT][16];
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
+          float s = acc[mt][0][e] * p.scale;
+          if (clamp) s = fminf(fmaxf(s, -CRAFT_ATTN_CLIP), CRAFT_ATTN_CLIP);
+          const int dh = s_kh[r] - h1, dw = s_kw[r] - w1;
+          if (p.pos_tab && dh >= -p.R && dh <= p.R && dw >= -p.R && dw <= p.R)
+            s += p.pos_w * s_tab[(dh + p.R) * (2 * p.R + 1) + dw + p.R];
+          if (p.mask_radius > 0 && max(abs(dh), abs(dw)) > p.mask_radius) s += -1e9f;
+          if (jt * BM + r >= N) s = -INFINITY;
+          sv[mt][e] = s;
+          tmax = fmaxf(tmax, s);
+        }
+      if (pass == 0) {
+        const float m_new = fmaxf(m_run, tmax);
+        if (m_new > -INFINITY) {
+          float add = 0.f;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) add += (PREC == CRAFT_PREC_F32) ? expf(sv[mt][e] - m_new) : __expf(sv[mt][e] - m_new);
+          l_run = l_run * ((m_run > -INFINITY) ? expf(m_run - m_new) : 0.f) + add;
+          m_run = m_new;
+        }
+      } else if (qcol < N) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int j = jt * BM + mt * 32 + 8 * q + rh4;
+            if (j < ldp) {
+              float pv[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float d = sv[mt][4 * q + i] - m_run;
+                pv[i] = ((PREC == CRAFT_PREC_F32) ? expf(d) : __expf(d)) * inv_l;
+              }
+              if constexpr (PREC == CRAFT_PREC_F32) {
+                *reinterpret_cast<float4*>(Prow + j) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+              } else {
+                typedef prob_t pt4 __attribute__((ext_vector_type(4)));
+                pt4 h;
+                h[0] = (prob_t)pv[0]; h[1] = (prob_t)pv[1]; h[2] = (prob_t)pv[2]; h[3] = (prob_t)pv[3];
+                *reinterpret_cast<pt4*>(Prow + j) = h;
+              }
+            }
+          }
+      }
+      __syncthreads();   // s_kh / s_kw are rewritten by the next tile
+    }
+    if (pass == 0) {
+      // merge the two half-waves (same query, disjoint keys)
+      const float m_o = __shfl_xor(m_run, 32), l_o = __shfl_xor(l_run, 32);
+      const float m_f = fmaxf(m_run, m_o);
+      const float la_ = (m_run > -INFINITY) ? l_run * expf(m_run - m_f) : 0.f;
+      const float lo_ = (m_o > -INFINITY) ? l_o * expf(m_o - m_f) : 0.f;
+      m_run = m_f;
+      inv_l = 1.f / (la_ + lo_);
+    }
+  }
+}
+
+int launch_attn_probs(const ScoreParams& p, void* P, long ldp, int prec, hipStream_t s) {
+  if (int e = check_score(p)) return e;
+  if (ldp % 32 || ldp < p.N) return CRAFT_ERR_ALIGN;
+  dim3 grid((p.N + 127) / 128, p.B * p.M, 1);
+  if (prec == CRAFT_PREC_F32) hipLaunchKernelGGL((k_attn_probs<CRAFT_PREC_F32>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
+  else if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_attn_probs<CRAFT_PREC_BF16>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
+  else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_attn_probs<CRAFT_PREC_F16>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
+  else return CRAFT_ERR_ARG;
+  return (int)hipGetLastError();
+}
+
+}  // namespace craft

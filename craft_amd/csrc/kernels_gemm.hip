@@ -1,0 +1,159 @@
+// GEMM-engine instantiations with store-type epilogues:
+//   * rows x rows GEMM (nn.Linear, V^T projection, attention apply O = P V)
+//   * NHWC implicit-GEMM convolution with the update block's fused epilogues
+#include "gemm_engine.hpp"
+#include "launch.hpp"
+
+namespace craft {
+
+// ---------------------------------------------------------------------------------------------
+// rows GEMM:  C[z][m, n] = act(scale * sum_k A[z][m,k] B[z][n,k] + bias[n])
+// ---------------------------------------------------------------------------------------------
+template <int PREC, int BN, bool A16>
+__global__ __launch_bounds__(NTHREADS) void k_gemm_rows(RowsGemmParams p) {
+  constexpr int BM = 128, WM = 2, WN = 2, MT = BM / WM / 32, NT = BN / WN / 32;
+  __shared__ __attribute__((aligned(16))) char smem[TileLds<PREC, BM, BN>::BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
+  const int z0 = z / p.zdiv, z1 = z - z0 * p.zdiv;
+  f32x16 acc[MT][NT];
+  acc_zero(acc);
+  LoaderRowsF32<BN> lb;
+  lb.init(reinterpret_cast<const float*>(p.B) + z0 * p.b_bs0 + z1 * p.b_bs1, p.ldb, n0, p.N, p.K, tid);
+  const int nk = (p.K + BK - 1) / BK;
+  if constexpr (A16) {
+    LoaderRowsH16<BM> la;
+    la.init(reinterpret_cast<const uint16_t*>(p.A) + z0 * p.a_bs0 + z1 * p.a_bs1, p.lda, m0, p.M, p.K, tid);
+    gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, smem, acc, NoFold());
+  } else {
+    LoaderRowsF32<BM> la;
+    la.init(reinterpret_cast<const float*>(p.A) + z0 * p.a_bs0 + z1 * p.a_bs1, p.lda, m0, p.M, p.K, tid);
+    gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, smem, acc, NoFold());
+  }
+  float* C = p.C + z0 * p.c_bs0 + z1 * p.c_bs1;
+  const int rb = m0 + (wave / WN) * (BM / WM), cb = n0 + (wave % WN) * (BN / WN);
+  acc_foreach<MT, NT>(acc, lane, [&](int r, int c, float v, int, int, int) {
+    const int row = rb + r, col = cb + c;
+    if (row < p.M && col < p.N) {
+      v *= p.scale;
+      if (p.bias) v += p.bias[col];
+      C[(long)row * p.ldc + col] = act_apply(v, p.act);
+    }
+  });
+}
+
+template <int PREC, int BN, bool A16> static int launch_rows_t(const RowsGemmParams& p, hipStream_t s) {
+  dim3 grid((p.M + 127) / 128, (p.N + BN - 1) / BN, p.batch);
+  hipLaunchKernelGGL((k_gemm_rows<PREC, BN, A16>), grid, dim3(NTHREADS), 0, s, p);
+  return (int)hipGetLastError();
+}
+
+static int pick_bn(int N) {
+  if (N % 128 == 0) return 128;
+  if (N % 64 == 0) return 64;
+  return N > 64 ? 128 : 64;
+}
+
+int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s) {
+  if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return 0;
+  if ((p.K & 3) || (p.lda & 3) || (p.ldb & 3)) return CRAFT_ERR_ALIGN;
+  if (a16 && ((p.K & 7) || (p.lda & 7) || prec == CRAFT_PREC_F32)) return CRAFT_ERR_ALIGN;
+  const int bn = pick_bn(p.N);
+#define GO(PR, BNV, A) return launch_rows_t<PR, BNV, A>(p, s)
+  if (prec == CRAFT_PREC_F32) { if (bn == 128) GO(CRAFT_PREC_F32, 128, false); else GO(CRAFT_PREC_F32, 64, false); }
+  if (prec == CRAFT_PREC_BF16) {
+    if (a16) { if (bn == 128) GO(CRAFT_PREC_BF16, 128, true); else GO(CRAFT_PREC_BF16, 64, true); }
+    if (bn == 128) GO(CRAFT_PREC_BF16, 128, false); else GO(CRAFT_PREC_BF16, 64, false);
+  }
+  if (prec == CRAFT_PREC_F16) {
+    if (a16) { if (bn == 128) GO(CRAFT_PREC_F16, 128, true); else GO(CRAFT_PREC_F16, 64, true); }
+    if (bn == 128) GO(CRAFT_PREC_F16, 128, false); else GO(CRAFT_PREC_F16, 64, false);
+  }
+#undef GO
+  return CRAFT_ERR_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NHWC implicit-GEMM conv: out[pix, co] = epi( sum_{tap,c} in[pix+tap, c] * W[co, tap, c] + bias[co] )
+// ---------------------------------------------------------------------------------------------
+template <int PREC, int BN>
+__global__ __launch_bounds__(NTHREADS) void k_gemm_conv(ConvGemmParams p) {
+  constexpr int BM = 128, WM = 2, WN = 2, MT = BM / WM / 32, NT = BN / WN / 32;
+  __shared__ __attribute__((aligned(16))) char smem[TileLds<PREC, BM, BN>::BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  f32x16 acc[MT][NT];
+  acc_zero(acc);
+  const int K = p.g.KH * p.g.KW * (p.g.c0 + p.g.c1);
+  LoaderConvF32<BM> la;
+  la.init(p.g, m0, tid);
+  LoaderRowsF32<BN> lb;
+  lb.init(p.W, K, n0, p.cout, K, tid);
+  gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, K / BK, smem, acc, NoFold());
+  const int rb = m0 + (wave / WN) * (BM / WM), cb = n0 + (wave % WN) * (BN / WN);
+  const int M = p.g.npix, N = p.cout;
+  switch (p.epi) {
+    case CONV_EPI_BIAS_ACT:
+      acc_foreach<MT, NT>(acc, lane, [&](int r, int c, float v, int, int, int) {
+        const int row = rb + r, col = cb + c;
+        if (row < M && col < N) {
+          v += p.bias[col];
+          if (p.act == CRAFT_ACT_RELU) v = fmaxf(v, 0.f);
+          p.out[(long)row * p.ldo + col] = v * p.scale;
+        }
+      });
+      break;
+    case CONV_EPI_GRU_ZR:   // cols [0,128): z = sigmoid -> out ; cols [128,256): r = sigmoid, rh = r*h -> aux1
+      acc_foreach<MT, NT>(acc, lane, [&](int r, int c, float v, int, int, int) {
+        const int row = rb + r, col = cb + c;
+        if (row < M && col < N) {
+          const float s = sigmoid_precise(v + p.bias[col]);
+          if (col < 128) p.out[(long)row * p.ldo + col] = s;
+          else p.aux1[(long)row * p.ld1 + (col - 128)] = s * p.aux0[(long)row * p.ld0 + (col - 128)];
+        }
+      });
+      break;
+    case CONV_EPI_GRU_Q:    // q = tanh; h' = (1-z) h + z q  (z = aux1, h = aux0; out may alias h)
+      acc_foreach<MT, NT>(acc, lane, [&](int r, int c, float v, int, int, int) {
+        const int row = rb + r, col = cb + c;
+        if (row < M && col < N) {
+          const float q = tanhf(v + p.bias[col]);
+          const float z = p.aux1[(long)row * p.ld1 + col];
+          const float h = p.aux0[(long)row * p.ld0 + col];
+          p.out[(long)row * p.ldo + col] = (1.f - z) * h + z * q;
+        }
+      });
+      break;
+    case CONV_EPI_MENC:     // cols [0,N): relu(conv) ; cols N, N+1: the 2 flow channels (update.py:86-87)
+      acc_foreach<MT, NT>(acc, lane, [&](int r, int c, float v, int, int, int) {
+        const int row = rb + r, col = cb + c;
+        if (row < M) {
+          if (col < N) p.out[(long)row * p.ldo + col] = fmaxf(v + p.bias[col], 0.f);
+          else if (col < N + 2) p.out[(long)row * p.ldo + col] = p.aux0[(long)row * p.ld0 + (col - N)];
+        }
+      });
+      break;
+  }
+}
+
+template <int PREC, int BN> static int launch_conv_t(const ConvGemmParams& p, hipStream_t s) {
+  const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
+  dim3 grid((p.g.npix + 127) / 128, (ncols + BN - 1) / BN, 1);
+  hipLaunchKernelGGL((k_gemm_conv<PREC, BN>), grid, dim3(NTHREADS), 0, s, p);
+  return (int)hipGetLastError();
+}
+
+int launch_gemm_conv(const ConvGemmParams& p, int prec, hipStream_t s) {
+  if (p.g.npix <= 0) return 0;
+  if ((p.g.c0 % 32) || (p.g.c1 % 32) || (p.g.ld0 & 3) || (p.g.c1 && (p.g.ld1 & 3))) return CRAFT_ERR_ALIGN;
+  const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
+  const int bn = pick_bn(ncols);
+#define GO(PR) do { if (bn == 128) return launch_conv_t<PR, 128>(p, s); else return launch_conv_t<PR, 64>(p, s); } while (0)
+  if (prec == CRAFT_PREC_F32) GO(CRAFT_PREC_F32);
+  if (prec == CRAFT_PREC_BF16) GO(CRAFT_PREC_BF16);
+  if (prec == CRAFT_PREC_F16) GO(CRAFT_PREC_F16);
+#undef GO
+  return CRAFT_ERR_ARG;
+}
+
+}  // namespace craft

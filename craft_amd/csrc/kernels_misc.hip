@@ -1,0 +1,444 @@
+// HBM-bound kernels of the hot path: token LayerNorm, mode pooling + skip + LayerNorm, pyramid pooling,
+// correlation lookup (radius-r bilinear gather), the two tiny convolutions that are not worth a GEMM,
+// convex upsampling and coordinate bookkeeping.  All activations are channels-last ("tokens": [B, N, C]).
+#include "launch.hpp"
+
+namespace craft {
+
+// ---------------------------------------------------------------------------------------------
+// tokens: (NCHW | tokens) -> activation -> optional LayerNorm over C -> tokens  (K1; network.py:209-212)
+// block = 256 threads handles 32 pixels x C channels (C <= 256) through a padded LDS tile.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tokens(const float* __restrict__ src, int src_nchw, int Ctot, int c_off, int C,
+                                                int HW, long src_ld, int act, int do_ln, float* __restrict__ dst, long dst_ld) {
+  __shared__ float tile[256 * 33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, p0 = blockIdx.x * 32;
+  if (src_nchw) {
+    const int px = tid & 31;
+    const bool ok = p0 + px < HW;
+    for (int c = tid >> 5; c < C; c += 8) {
+      float v = ok ? src[((long)b * Ctot + c_off + c) * HW + p0 + px] : 0.f;
+      tile[c * 33 + px] = act_apply(v, act);
+    }
+  } else {
+    for (int idx = tid; idx < 32 * C; idx += 256) {
+      const int px = idx / C, c = idx - px * C;
+      float v = (p0 + px < HW) ? src[((long)b * HW + p0 + px) * src_ld + c_off + c] : 0.f;
+      tile[c * 33 + px] = act_apply(v, act);
+    }
+  }
+  __syncthreads();
+  for (int px = wave; px < 32; px += 4) {
+    if (p0 + px >= HW) break;
+    float v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (c < C) ? tile[c * 33 + px] : 0.f;
+      s += v[i];
+    }
+    float* o = dst + ((long)b * HW + p0 + px) * dst_ld;
+    if (do_ln) {
+      const float mean = wave_sum(s) / (float)C;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        const float d = (c < C) ? v[i] - mean : 0.f;
+        q += d * d;
+      }
+      const float rstd = 1.f / sqrtf(wave_sum(q) / (float)C + CRAFT_LN_EPS);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) o[c] = (v[i] - mean) * rstd;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) o[c] = v[i];
+      }
+    }
+  }
+}
+
+int launch_tokens(const float* src, int src_nchw, int B, int Ctot, int c_off, int C, int HW, long src_ld, int act,
+                  int do_ln, float* dst, long dst_ld, hipStream_t s) {
+  if (C > 256 || C < 1) return CRAFT_ERR_UNSUPPORTED;
+  dim3 grid((HW + 31) / 32, B);
+  hipLaunchKernelGGL(k_tokens, grid, dim3(256), 0, s, src, src_nchw, Ctot, c_off, C, HW, src_ld, act, do_ln, dst, dst_ld);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// ExpandedFeatTrans tail (setrans.py:395-407): a_m = softmax_m(<O_m, w>), y = sum_m a_m O_m,
+// out = LN(c_skip * x + y).  One wave per token; C <= 256, M <= 8.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mode_pool_ln(const float* __restrict__ O, const float* __restrict__ x, long ldx,
+                                                      const float* __restrict__ w_agg, const float* __restrict__ skip_coeff,
+                                                      int N, int M, int C, float* __restrict__ out, long ldo, long ntok) {
+  const int lane = threadIdx.x & 63;
+  const long tok = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= ntok) return;
+  const int b = (int)(tok / N), n = (int)(tok - (long)b * N);
+  const int nc = C / 64;   // 1..4
+  float o[8][4];
+  float sc[8];
+  for (int m = 0; m < M; ++m) {
+    const float* Om = O + (((long)b * M + m) * N + n) * C;
+    float s = 0.f;
+    for (int i = 0; i < nc; ++i) {
+      o[m][i] = Om[lane + 64 * i];
+      s += o[m][i] * w_agg[lane + 64 * i];
+    }
+    sc[m] = wave_sum(s);
+  }
+  float mxs = sc[0];
+  for (int m = 1; m < M; ++m) mxs = fmaxf(mxs, sc[m]);
+  float den = 0.f;
+  for (int m = 0; m < M; ++m) { sc[m] = expf(sc[m] - mxs); den += sc[m]; }
+  const float cs = skip_coeff[0];
+  float t[4];
+  float sum = 0.f;
+  for (int i = 0; i < nc; ++i) {
+    float y = 0.f;
+    for (int m = 0; m < M; ++m) y += o[m][i] * (sc[m] / den);
+    t[i] = cs * x[tok * ldx + lane + 64 * i] + y;
+    sum += t[i];
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float q = 0.f;
+  for (int i = 0; i < nc; ++i) { const float d = t[i] - mean; q += d * d; }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)C + CRAFT_LN_EPS);
+  for (int i = 0; i < nc; ++i) out[tok * ldo + lane + 64 * i] = (t[i] - mean) * rstd;
+}
+
+int launch_mode_pool_ln(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff, int B, int N,
+                        int M, int C, float* out, long ldo, hipStream_t s) {
+  if (C % 64 || C > 256 || M < 1 || M > 8) return CRAFT_ERR_UNSUPPORTED;
+  const long ntok = (long)B * N;
+  hipLaunchKernelGGL(k_mode_pool_ln, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, s, O, x, ldx, w_agg, skip_coeff, N, M, C,
+                     out, ldo, ntok);
+  return (int)hipGetLastError();
+}
+
+// gma.Aggregate tail (gma.py:138): out = fmap + gamma * O
+__global__ void k_gma_residual(const float* __restrict__ mf, long ldm, const float* __restrict__ O,
+                               const float* __restrict__ gamma, long ntok, int C, float* __restrict__ out, long ldo) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ntok * C) return;
+  const long tok = i / C;
+  const int c = (int)(i - tok * C);
+  out[tok * ldo + c] = mf[tok * ldm + c] + gamma[0] * O[i];
+}
+int launch_gma_residual(const float* mf, long ldm, const float* O, const float* gamma, int B, int N, int C, float* out,
+                        long ldo, hipStream_t s) {
+  const long tot = (long)B * N * C;
+  hipLaunchKernelGGL(k_gma_residual, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, mf, ldm, O, gamma, (long)B * N, C,
+                     out, ldo);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// correlation pyramid: levels 1..3 by repeated 2x2 average pooling (corr.py:186-189); one block per
+// (sample, query) image.  Level l+1 is computed from level l held in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_corr_pyramid(const float* __restrict__ l0, float* __restrict__ l1,
+                                                      float* __restrict__ l2, float* __restrict__ l3, int H8, int W8) {
+  extern __shared__ float sm[];
+  const long img = blockIdx.x;
+  const int h1 = H8 / 2, w1 = W8 / 2, h2 = h1 / 2, w2 = w1 / 2, h3 = h2 / 2, w3 = w2 / 2;
+  float* s1 = sm;
+  float* s2 = sm + h1 * w1;
+  const float* src = l0 + img * (long)H8 * W8;
+  for (int i = threadIdx.x; i < h1 * w1; i += 256) {
+    const int y = i / w1, x = i - y * w1;
+    const float* r0 = src + (2 * y) * W8 + 2 * x;
+    const float* r1 = r0 + W8;
+    const float v = (((r0[0] + r0[1]) + r1[0]) + r1[1]) * 0.25f;
+    s1[i] = v;
+    l1[img * (long)h1 * w1 + i] = v;
+  }
+  __syncthreads();
+  if (l2 == nullptr) return;
+  for (int i = threadIdx.x; i < h2 * w2; i += 256) {
+    const int y = i / w2, x = i - y * w2;
+    const float* r0 = s1 + (2 * y) * w1 + 2 * x;
+    const float* r1 = r0 + w1;
+    const float v = (((r0[0] + r0[1]) + r1[0]) + r1[1]) * 0.25f;
+    s2[i] = v;
+    l2[img * (long)h2 * w2 + i] = v;
+  }
+  __syncthreads();
+  if (l3 == nullptr) return;
+  for (int i = threadIdx.x; i < h3 * w3; i += 256) {
+    const int y = i / w3, x = i - y * w3;
+    const float* r0 = s2 + (2 * y) * w2 + 2 * x;
+    const float* r1 = r0 + w2;
+    l3[img * (long)h3 * w3 + i] = (((r0[0] + r0[1]) + r1[0]) + r1[1]) * 0.25f;
+  }
+}
+
+int launch_corr_pyramid(const float* l0, float* l1, float* l2, float* l3, long nimg, int H8, int W8, hipStream_t s) {
+  if (H8 < 2 || W8 < 2) return CRAFT_ERR_UNSUPPORTED;
+  const int h1 = H8 / 2, w1 = W8 / 2, h2 = h1 / 2, w2 = w1 / 2;
+  const size_t lds = sizeof(float) * ((size_t)h1 * w1 + (size_t)h2 * w2 + 4);
+  if (lds > 150 * 1024) return CRAFT_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_corr_pyramid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k_corr_pyramid, dim3((unsigned)nimg), dim3(256), lds, s, l0, l1, l2, l3, H8, W8);
+  return (int)hipGetLastError();
+}
+
+// (sum, sum^2) -> (mean, 1/sqrt(var+eps)) per sample (corr.py:200-204); identity when !do_norm
+__global__ void k_corr_stats(const double* __restrict__ sums, float* __restrict__ mu_rstd, int B, double count, int do_norm) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (!do_norm) { mu_rstd[2 * b] = 0.f; mu_rstd[2 * b + 1] = 1.f; return; }
+  const double mu = sums[2 * b] / count;
+  double var = sums[2 * b + 1] / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mu_rstd[2 * b] = (float)mu;
+  mu_rstd[2 * b + 1] = (float)(1.0 / sqrt(var + (double)CRAFT_LN_EPS));
+}
+int launch_corr_stats(const double* sums, float* mu_rstd, int B, double count, int do_norm, hipStream_t s) {
+  hipLaunchKernelGGL(k_corr_stats, dim3((B + 63) / 64), dim3(64), 0, s, sums, mu_rstd, B, count, do_norm);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// correlation lookup (CorrBlock.__call__, corr.py:47-71; bilinear_sampler utils.py:65-79).
+// One wave per query pixel.  Per level: gather the (2r+2)^2 patch around floor(coords/2^l) into LDS,
+// normalising in-bounds taps with the lazy global LayerNorm ((v-mu)*rstd; out of bounds = 0, which is
+// exactly grid_sample's zero padding applied to the normalised volume), then each lane blends 4 patch
+// values per output channel k = l*(2r+1)^2 + a*(2r+1) + b  with  X = x/2^l + a - r,  Y = y/2^l + b - r
+// (the x offset runs along the FIRST window axis).
+// ---------------------------------------------------------------------------------------------
+#define LOOKUP_MAXP 16
+__global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ l0, const float* __restrict__ l1,
+                                                     const float* __restrict__ l2, const float* __restrict__ l3, int levels,
+                                                     const float* __restrict__ mu_rstd, const float* __restrict__ coords,
+                                                     int N, int H8, int W8, int radius, float* __restrict__ out, long ldo,
+                                                     long nq) {
+  __shared__ float patch[4][4][LOOKUP_MAXP * LOOKUP_MAXP];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long q0 = (long)blockIdx.x * 4 + wv;
+  const bool valid = q0 < nq;
+  const long q = valid ? q0 : nq - 1;      // idle waves shadow the last query (no early return before the barrier)
+  const int b = (int)(q / N);
+  const float cx = coords[2 * q], cy = coords[2 * q + 1];
+  const float mu = mu_rstd[2 * b], rstd = mu_rstd[2 * b + 1];
+  const int PS = 2 * radius + 2, win = 2 * radius + 1;
+  float fxs[4], fys[4];
+  const float* lv[4] = {l0, l1, l2, l3};
+  int h = H8, w = W8;
+  float sc = 1.f;
+  for (int l = 0; l < levels; ++l) {
+    const float X = cx * sc, Y = cy * sc;
+    const float x0f = floorf(X), y0f = floorf(Y);
+    fxs[l] = X - x0f;
+    fys[l] = Y - y0f;
+    // clamp the integer base far outside the image so int conversion can not overflow
+    const int x0 = (int)fminf(fmaxf(x0f, -100000.f), 100000.f) - radius;
+    const int y0 = (int)fminf(fmaxf(y0f, -100000.f), 100000.f) - radius;
+    const float* img = lv[l] + q * (long)h * w;
+    for (int idx = lane; idx < PS * PS; idx += 64) {
+      const int py = idx / PS, px = idx - py * PS;
+      const int y = y0 + py, x = x0 + px;
+      float v = 0.f;
+      if (y >= 0 && y < h && x >= 0 && x < w) v = (img[y * w + x] - mu) * rstd;
+      patch[wv][l][py * LOOKUP_MAXP + px] = v;
+    }
+    h >>= 1; w >>= 1; sc *= 0.5f;
+  }
+  __syncthreads();
+  if (!valid) return;
+  const int nch = levels * win * win;
+  float* o = out + q * ldo;
+  for (int k = lane; k < nch; k += 64) {
+    const int l = k / (win * win), rem = k - l * win * win;
+    const int a = rem / win, bb = rem - a * win;
+    const float fx = fxs[l], fy = fys[l];
+    const float* P = &patch[wv][l][bb * LOOKUP_MAXP + a];
+    const float nw = (1.f - fx) * (1.f - fy), ne = fx * (1.f - fy), sw = (1.f - fx) * fy, se = fx * fy;
+    o[k] = ((P[0] * nw + P[1] * ne) + P[LOOKUP_MAXP] * sw) + P[LOOKUP_MAXP + 1] * se;
+  }
+}
+
+int launch_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3, int levels, const float* mu_rstd,
+                       const float* coords, int B, int H8, int W8, int radius, float* out, long ldo, hipStream_t s) {
+  if (levels < 1 || levels > 4 || radius < 0 || 2 * radius + 2 > LOOKUP_MAXP) return CRAFT_ERR_UNSUPPORTED;
+  const long nq = (long)B * H8 * W8;
+  hipLaunchKernelGGL(k_corr_lookup, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, l0, l1, l2, l3, levels, mu_rstd, coords,
+                     H8 * W8, H8, W8, radius, out, ldo, nq);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// convf1: 7x7 conv 2 -> 128 + ReLU on the flow field (update.py:75,82).  w packed [7*7*2][128]
+// (tap-major: ((ky*7+kx)*2 + c), output channel contiguous).  block = 2 pixels x 128 channels.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_convf1(const float* __restrict__ flow, const float* __restrict__ w,
+                                                const float* __restrict__ bias, int H8, int W8, long npix,
+                                                float* __restrict__ out, long ldo) {
+  __shared__ float pat[2][98];
+  const int tid = threadIdx.x, co = tid & 127, pl = tid >> 7;
+  const long pix = (long)blockIdx.x * 2 + pl;
+  const int hw = H8 * W8;
+  if (co < 98 && pix < npix) {
+    const int b = (int)(pix / hw), rem = (int)(pix - (long)b * hw);
+    const int y = rem / W8, x = rem - y * W8;
+    const int t = co >> 1, c = co & 1;
+    const int ky = t / 7, kx = t - ky * 7;
+    const int yy = y + ky - 3, xx = x + kx - 3;
+    pat[pl][co] = (yy >= 0 && yy < H8 && xx >= 0 && xx < W8) ? flow[((long)b * hw + yy * W8 + xx) * 2 + c] : 0.f;
+  }
+  __syncthreads();
+  if (pix >= npix) return;
+  float acc = bias[co];
+#pragma unroll 14
+  for (int k = 0; k < 98; ++k) acc += pat[pl][k] * w[k * 128 + co];
+  out[pix * ldo + co] = fmaxf(acc, 0.f);
+}
+int launch_convf1(const float* flow, const float* w, const float* bias, int B, int H8, int W8, float* out, long ldo,
+                  hipStream_t s) {
+  const long npix = (long)B * H8 * W8;
+  hipLaunchKernelGGL(k_convf1, dim3((unsigned)((npix + 1) / 2)), dim3(256), 0, s, flow, w, bias, H8, W8, npix, out, ldo);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// FlowHead.conv2: 3x3 conv 256 -> 2 (update.py:12,16) fused with the coordinate update
+// coords1 += delta (network.py:247) and flow = coords1 - coords0.  One wave per pixel; lane owns 4 channels.
+// w packed [2][3*3][256].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flow_head2(const float* __restrict__ hid, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, int H8, int W8, long npix,
+                                                    float* __restrict__ coords1, const float* __restrict__ coords0,
+                                                    float* __restrict__ flow, float* __restrict__ delta) {
+  const int lane = threadIdx.x & 63;
+  const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= npix) return;
+  const int hw = H8 * W8;
+  const int b = (int)(pix / hw), rem = (int)(pix - (long)b * hw);
+  const int y = rem / W8, x = rem - y * W8;
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    if (yy < 0 || yy >= H8 || xx < 0 || xx >= W8) continue;
+    const float4 h = *reinterpret_cast<const float4*>(hid + ((long)b * hw + yy * W8 + xx) * 256 + lane * 4);
+    const float4 w0 = *reinterpret_cast<const float4*>(w + (0 * 9 + t) * 256 + lane * 4);
+    const float4 w1 = *reinterpret_cast<const float4*>(w + (1 * 9 + t) * 256 + lane * 4);
+    a0 += h.x * w0.x + h.y * w0.y + h.z * w0.z + h.w * w0.w;
+    a1 += h.x * w1.x + h.y * w1.y + h.z * w1.z + h.w * w1.w;
+  }
+  a0 = wave_sum(a0);
+  a1 = wave_sum(a1);
+  if (lane == 0) {
+    const float dx = a0 + bias[0], dy = a1 + bias[1];
+    const float nx = coords1[2 * pix] + dx, ny = coords1[2 * pix + 1] + dy;
+    coords1[2 * pix] = nx;
+    coords1[2 * pix + 1] = ny;
+    flow[2 * pix] = nx - coords0[2 * pix];
+    flow[2 * pix + 1] = ny - coords0[2 * pix + 1];
+    if (delta) { delta[2 * pix] = dx; delta[2 * pix + 1] = dy; }
+  }
+}
+int launch_flow_head2(const float* hid, const float* w, const float* bias, int B, int H8, int W8, float* coords1,
+                      const float* coords0, float* flow, float* delta, hipStream_t s) {
+  const long npix = (long)B * H8 * W8;
+  hipLaunchKernelGGL(k_flow_head2, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, hid, w, bias, H8, W8, npix, coords1,
+                     coords0, flow, delta);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// convex upsampling (CRAFT.upsample_flow, network.py:151-162).  One wave per low-res pixel, lane = the
+// 8x8 sub-pixel: softmax over the 9 neighbours of mask[k*64 + lane], weighted sum of 8*flow (zero pad).
+// mask: tokens [B*N, 576] (already 0.25*(conv+bias)); flow tokens [B*N, 2]; up: NCHW [B, 2, 8*H8, 8*W8].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_convex_upsample(const float* __restrict__ mask, const float* __restrict__ flow,
+                                                         int H8, int W8, long npix, float* __restrict__ up) {
+  const int lane = threadIdx.x & 63;
+  const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= npix) return;
+  const int hw = H8 * W8;
+  const int b = (int)(pix / hw), rem = (int)(pix - (long)b * hw);
+  const int y = rem / W8, x = rem - y * W8;
+  float mk[9];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { mk[k] = mask[pix * 576 + k * 64 + lane]; mx = fmaxf(mx, mk[k]); }
+  float den = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { mk[k] = expf(mk[k] - mx); den += mk[k]; }
+  float ox = 0.f, oy = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+    float fx = 0.f, fy = 0.f;
+    if (yy >= 0 && yy < H8 && xx >= 0 && xx < W8) {
+      const float2 f = *reinterpret_cast<const float2*>(flow + ((long)b * hw + yy * W8 + xx) * 2);
+      fx = 8.f * f.x; fy = 8.f * f.y;
+    }
+    const float pk = mk[k] / den;
+    ox += pk * fx;
+    oy += pk * fy;
+  }
+  const int i = lane >> 3, j = lane & 7;
+  const long H = 8L * H8, W = 8L * W8;
+  up[(((long)b * 2 + 0) * H + 8 * y + i) * W + 8 * x + j] = ox;
+  up[(((long)b * 2 + 1) * H + 8 * y + i) * W + 8 * x + j] = oy;
+}
+int launch_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, hipStream_t s) {
+  const long npix = (long)B * H8 * W8;
+  hipLaunchKernelGGL(k_convex_upsample, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, mask, flow, H8, W8, npix, up);
+  return (int)hipGetLastError();
+}
+
+// coords_grid + flow_init (utils.py:82-85, network.py:219-222): tokens [B*N, 2] with (x, y) order
+__global__ void k_coords_init(const float* __restrict__ flow_init, int H8, int W8, long npix, float* __restrict__ c0,
+                              float* __restrict__ c1, float* __restrict__ flow) {
+  const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int hw = H8 * W8;
+  const int b = (int)(pix / hw), rem = (int)(pix - (long)b * hw);
+  const int y = rem / W8, x = rem - y * W8;
+  float fx = 0.f, fy = 0.f;
+  if (flow_init) { fx = flow_init[((long)b * 2 + 0) * hw + rem]; fy = flow_init[((long)b * 2 + 1) * hw + rem]; }
+  c0[2 * pix] = (float)x; c0[2 * pix + 1] = (float)y;
+  const float nx = (float)x + fx, ny = (float)y + fy;
+  c1[2 * pix] = nx; c1[2 * pix + 1] = ny;
+  flow[2 * pix] = nx - (float)x; flow[2 * pix + 1] = ny - (float)y;
+}
+int launch_coords_init(const float* flow_init_nchw, int B, int H8, int W8, float* coords0, float* coords1, float* flow,
+                       hipStream_t s) {
+  const long npix = (long)B * H8 * W8;
+  hipLaunchKernelGGL(k_coords_init, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, flow_init_nchw, H8, W8, npix,
+                     coords0, coords1, flow);
+  return (int)hipGetLastError();
+}
+
+// tokens [B, HW, ld] (first C columns) -> NCHW [B, C, HW]
+__global__ void k_tokens_to_nchw(const float* __restrict__ src, long ld, int C, int HW, long tot, float* __restrict__ dst) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= tot) return;
+  const int p = (int)(i % HW);
+  const long bc = i / HW;
+  const int c = (int)(bc % C);
+  const long b = bc / C;
+  dst[i] = src[(b * HW + p) * ld + c];
+}
+int launch_tokens_to_nchw(const float* src, long ld, int B, int C, int HW, float* dst, hipStream_t s) {
+  const long tot = (long)B * C * HW;
+  hipLaunchKernelGGL(k_tokens_to_nchw, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, ld, C, HW, tot, dst);
+  return (int)hipGetLastError();
+}
+
+}  // namespace craft

@@ -1,0 +1,79 @@
+// Host-visible parameter blocks and launcher prototypes shared by the .hip translation units and the
+// C-ABI layer (craft_hip.hip).  Nothing here is part of the public ABI (see include/craft_hip.h).
+#pragma once
+#include "common.hpp"
+#include "gemm_engine.hpp"
+
+#define CRAFT_OK 0
+#define CRAFT_ERR_ARG 10001
+#define CRAFT_ERR_ALIGN 10002
+#define CRAFT_ERR_UNSUPPORTED 10003
+
+namespace craft {
+
+struct RowsGemmParams {
+  const void* A; const void* B; float* C;
+  long lda, ldb, ldc;
+  long a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1;   // batch z -> (z / zdiv, z % zdiv) strides, in elements
+  int zdiv, batch;
+  int M, N, K;
+  const float* bias;     // per output column, may be null
+  float scale;
+  int act;
+};
+
+enum { CONV_EPI_BIAS_ACT = 0, CONV_EPI_GRU_ZR = 1, CONV_EPI_GRU_Q = 2, CONV_EPI_MENC = 3 };
+
+struct ConvGemmParams {
+  ConvGeom g;
+  const float* W;        // packed [cout][KH][KW][c0+c1]
+  const float* bias;     // [cout]
+  int cout;
+  int epi, act;
+  float scale;
+  float* out; int ldo;
+  const float* aux0; int ld0;
+  float* aux1; int ld1;
+};
+
+int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s);
+int launch_gemm_conv(const ConvGemmParams& p, int prec, hipStream_t s);
+
+// ---- attention / correlation (kernels_attn.hip) ----
+struct ScoreParams {
+  const float* Q; const float* Kf;    // [B][N][ld] token-major features (already projected)
+  long ldq, ldk, q_bs, k_bs;          // row strides and per-sample strides (elements)
+  int B, H8, W8, N;
+  int M, d;                           // modes, per-mode width (columns m*d .. m*d+d)
+  float scale;                        // 1/sqrt(d)
+  const float* pos_tab; int R; float pos_w;   // sliding bias table [(2R+1)^2] (null: no bias)
+  int mask_radius;                    // Chebyshev mask radius (<=0: none)
+  const unsigned* clamp_ord;          // ordered-uint global max of the raw scores (null: never clamp)
+};
+
+int launch_score_max(const ScoreParams& p, unsigned* max_ord, int prec, hipStream_t s);
+int launch_corr_build(const ScoreParams& p, float w_aggr, float* pyr0, double* sums, int prec, hipStream_t s);
+int launch_attn_probs(const ScoreParams& p, void* P, long ldp, int prec, hipStream_t s);
+
+// ---- element-wise / gather kernels (kernels_misc.hip) ----
+int launch_tokens(const float* src, int src_nchw, int B, int Ctot, int c_off, int C, int HW, long src_ld,
+                  int act, int do_ln, float* dst, long dst_ld, hipStream_t s);
+int launch_mode_pool_ln(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff,
+                        int B, int N, int M, int C, float* out, long ldo, hipStream_t s);
+int launch_corr_pyramid(const float* l0, float* l1, float* l2, float* l3, long nimg, int H8, int W8, hipStream_t s);
+int launch_corr_stats(const double* sums, float* mu_rstd, int B, double count, int do_norm, hipStream_t s);
+int launch_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3, int levels,
+                       const float* mu_rstd, const float* coords, int B, int H8, int W8, int radius,
+                       float* out, long ldo, hipStream_t s);
+int launch_convf1(const float* flow, const float* w, const float* bias, int B, int H8, int W8, float* out, long ldo,
+                  hipStream_t s);
+int launch_flow_head2(const float* hid, const float* w, const float* bias, int B, int H8, int W8, float* coords1,
+                      const float* coords0, float* flow, float* delta, hipStream_t s);
+int launch_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, hipStream_t s);
+int launch_coords_init(const float* flow_init_nchw, int B, int H8, int W8, float* coords0, float* coords1, float* flow,
+                       hipStream_t s);
+int launch_tokens_to_nchw(const float* src, long ld, int B, int C, int HW, float* dst, hipStream_t s);
+int launch_gma_residual(const float* mf, long ldm, const float* O, const float* gamma, int B, int N, int C, float* out,
+                        long ldo, hipStream_t s);
+
+}  // namespace craft

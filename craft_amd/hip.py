@@ -1,0 +1,106 @@
+"""ctypes binding of ``libcraft_hip.so`` (C ABI in ``include/craft_hip.h``).
+
+PyTorch is used here only as plumbing: device memory (``tensor.data_ptr()``) and the current HIP
+stream.  There is NO fallback: if the shared library is missing or a call fails, an exception is
+raised — the product path never silently runs on PyTorch ops or the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_long, c_void_p, c_char_p
+
+import torch
+
+PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
+ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
+PREC_NAMES = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16}
+PROB_DTYPE = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_F16: torch.float16}
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcraft_hip.so")
+_lib = None
+
+P, I, L, F = c_void_p, c_int, c_long, c_float
+
+# name -> argtypes; every function returns int.  Kept in sync with include/craft_hip.h
+# (tests/test_abi.py checks that each declared symbol is exported).
+_SIGS = {
+    "craft_tokens": [P, I, I, I, I, I, I, L, I, I, P, L, P],
+    "craft_tokens_to_nchw": [P, L, I, I, I, P, P],
+    "craft_linear": [P, L, P, P, P, L, L, I, I, I, P],
+    "craft_linear_t": [P, L, P, P, L, I, I, I, I, I, P],
+    "craft_score_max": [P, L, P, L, I, I, I, I, I, F, P, I, P],
+    "craft_corr_build": [P, L, P, L, I, I, I, I, I, F, P, I, F, F, P, P, P, I, P],
+    "craft_corr_finish": [P, P, P, P, P, P, I, I, I, I, P],
+    "craft_corr_lookup": [P, P, P, P, I, P, P, I, I, I, I, P, L, P],
+    "craft_attn_probs": [P, L, P, L, I, I, I, I, I, F, P, I, F, I, P, P, L, I, P],
+    "craft_attn_apply": [P, L, P, I, I, I, I, P, I, P],
+    "craft_mode_pool_ln": [P, P, L, P, P, I, I, I, I, P, L, P],
+    "craft_gma_residual": [P, L, P, P, I, I, I, P, L, P],
+    "craft_motion_encoder": [P, L, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, L, P, I, P],
+    "craft_sepconv_gru": [P, L, I, P, P, P, P, P, P, P, P, I, I, I, P, I, P],
+    "craft_flow_head": [P, L, P, P, P, P, I, I, I, P, P, P, P, P, I, P],
+    "craft_mask_head": [P, L, P, P, P, P, I, I, I, P, P, I, P],
+    "craft_convex_upsample": [P, P, I, I, I, P, P],
+    "craft_coords_init": [P, I, I, I, P, P, P, P],
+}
+
+
+class CraftHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """dlopen the extension (once).  Raises if it has not been built (python -m craft_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise CraftHipError(f"{_LIB_PATH} not found: build it with `python -m craft_amd.build` "
+                            "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    lib = ctypes.CDLL(_LIB_PATH)
+    lib.craft_hip_abi_version.restype = c_int
+    lib.craft_hip_error_string.restype = c_char_p
+    lib.craft_hip_error_string.argtypes = [c_int]
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = c_int
+        fn.argtypes = sig
+    if lib.craft_hip_abi_version() != 1:
+        raise CraftHipError("libcraft_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise CraftHipError("craft_amd HIP ops need device tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    lib = load()
+    conv = []
+    for a in args:
+        if isinstance(a, torch.Tensor) or a is None:
+            conv.append(_ptr(a))
+        else:
+            conv.append(a)
+    rc = getattr(lib, name)(*conv, _stream())
+    if rc != 0:
+        msg = lib.craft_hip_error_string(rc).decode()
+        raise CraftHipError(f"{name} failed with code {rc}: {msg}")
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m

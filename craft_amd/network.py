@@ -1,0 +1,225 @@
+"""CRAFT model with the inner-loop hot path on hand-written gfx950 kernels.
+
+Drop-in for the reference's ``core.network.CRAFT`` (network.py:26-267): same constructor
+arguments (an argparse Namespace; the ctor writes ``corr_levels``, ``corr_multiplier`` and the
+three ``*_trans_config`` objects back into it), same ``forward(image1, image2, iters, flow_init,
+upsample, test_mode)`` signature / return conventions, same ``state_dict`` keys (202 in the
+canonical ``--craft --f2 full --setrans`` configuration), ``freeze_bn()``.
+
+Execution: the CNN encoders stay on PyTorch-ROCm (MIOpen); everything after them — F2 transformer,
+intra-frame attention, correlation volume + pyramid, and the T refinement iterations — runs through
+``libcraft_hip.so`` on channels-last token buffers.  Inference only in this round: tensors produced
+by the HIP path carry no autograd graph.
+
+Extra (non-reference) argument fields, all optional:
+  ``hip_precision``: "fp32" | "bf16" | "fp16" MFMA operand precision of the hot path.  Default: "fp32"
+                     when ``mixed_precision`` is False (the reference's fp32 path), "bf16" when it is
+                     True (the reference autocasts to fp16 there).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .corr import CorrBlock, TransCorrBlock
+from .extractor import BasicEncoder
+from .gma import Attention
+from .hip import ACT_RELU, ACT_TANH, PREC_BF16, PREC_F32, PREC_NAMES
+from .setrans import SelfAttVisPosTrans, SETransConfig
+from .update import GMAUpdateBlock
+
+
+def _autocast(enabled: bool):
+    return torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=bool(enabled) and torch.cuda.is_available())
+
+
+class CRAFT(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.hidden_dim = hdim = 128
+        self.context_dim = cdim = 128
+        args.corr_levels = 4
+        if "dropout" not in vars(args):
+            args.dropout = 0
+        if getattr(args, "corr_radius", -1) == -1:
+            args.corr_radius = 4
+        for name, default in (("f1trans", "none"), ("f2trans", "full"), ("mixed_precision", False),
+                              ("pos_bias_radius", 7), ("num_heads", 1), ("position_only", False),
+                              ("position_and_content", False), ("f2_pos_code_weight", 0.5), ("f2_attn_mask_radius", -1),
+                              ("inter_num_modes", 4), ("intra_num_modes", 4), ("f2_num_modes", 4),
+                              ("inter_qk_have_bias", True), ("inter_pos_code_type", "bias"), ("inter_pos_code_weight", 0.5),
+                              ("intra_pos_code_type", "bias"), ("intra_pos_code_weight", 1.0)):
+            if not hasattr(args, name):
+                setattr(args, name, default)
+        if args.f1trans != "none":
+            raise NotImplementedError("--f1 shared|private (two-way correlation) is outside the HIP path")
+        if args.f2trans == "none":
+            # the reference itself raises AttributeError here (corr_multiplier is never set)
+            raise NotImplementedError("--f2 none is not supported (the reference crashes on it as well)")
+
+        if args.craft:
+            cfg = SETransConfig()
+            cfg.update_config(args)
+            cfg.in_feat_dim = cfg.feat_dim = 256
+            cfg.max_pos_size = 160
+            cfg.out_attn_scores_only = True
+            cfg.num_modes = args.inter_num_modes
+            cfg.tie_qk_scheme = "shared"
+            cfg.qk_have_bias = args.inter_qk_have_bias
+            cfg.pos_code_type = args.inter_pos_code_type
+            cfg.pos_code_weight = args.inter_pos_code_weight
+            self.inter_trans_config = args.inter_trans_config = cfg
+            self.corr_fn = TransCorrBlock(cfg, radius=args.corr_radius, do_corr_global_norm=True)
+
+        self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", dropout=args.dropout)
+        self.cnet = BasicEncoder(output_dim=hdim + cdim, norm_fn="batch", dropout=args.dropout)
+
+        cfg = SETransConfig()
+        cfg.update_config(args)
+        cfg.in_feat_dim = cfg.feat_dim = 256
+        cfg.has_input_skip = True
+        cfg.has_FFN = False
+        cfg.attn_mask_radius = args.f2_attn_mask_radius
+        cfg.tie_qk_scheme = None
+        cfg.qk_have_bias = False
+        cfg.out_attn_probs_only = False
+        cfg.num_modes = args.f2_num_modes
+        cfg.pos_code_type = args.intra_pos_code_type
+        cfg.pos_code_weight = args.f2_pos_code_weight
+        self.f2_trans_config = args.f2_trans_config = cfg
+        self.f2_trans = SelfAttVisPosTrans(cfg, "F2 transformer")
+        self.f1_trans = None
+        args.corr_multiplier = 1
+
+        if args.use_setrans:
+            cfg = SETransConfig()
+            cfg.update_config(args)
+            cfg.in_feat_dim = cfg.feat_dim = 128
+            cfg.has_FFN = False
+            cfg.has_input_skip = True
+            cfg.attn_mask_radius = -1
+            cfg.tie_qk_scheme = None
+            cfg.qk_have_bias = False
+            cfg.out_attn_probs_only = True
+            cfg.num_modes = args.intra_num_modes
+            cfg.pos_code_type = args.intra_pos_code_type
+            cfg.pos_code_weight = args.intra_pos_code_weight
+            self.intra_trans_config = args.intra_trans_config = cfg
+            self.att = SelfAttVisPosTrans(cfg, "Intra-frame attention")
+        else:
+            self.att = Attention(args=args, dim=cdim, heads=args.num_heads, max_pos_size=160, dim_head=cdim)
+
+        self.update_block = GMAUpdateBlock(args, hidden_dim=hdim)
+        self.call_counter = 0
+
+    # ------------------------------------------------------------------------------------------
+    def hip_prec(self) -> int:
+        name = getattr(self.args, "hip_precision", None)
+        if name is None:
+            return PREC_BF16 if getattr(self.args, "mixed_precision", False) else PREC_F32
+        return PREC_NAMES[name]
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    def initialize_flow(self, img):
+        """coords0, coords1 as NCHW grids (network.py:142-149); kept for API parity."""
+        B, _, H, W = img.shape
+        ys, xs = torch.meshgrid(torch.arange(H // 8, device=img.device, dtype=torch.float32),
+                                torch.arange(W // 8, device=img.device, dtype=torch.float32), indexing="ij")
+        c = torch.stack([xs, ys], dim=0)[None].expand(B, -1, -1, -1)
+        return c, c.clone()
+
+    def upsample_flow(self, flow, mask):
+        """NCHW flow [B,2,H8,W8] and mask [B,576,H8,W8] -> [B,2,H,W]  (network.py:151-162)."""
+        B, _, H8, W8 = flow.shape
+        return ops.convex_upsample(ops.tokens_from_nchw_wide(mask.float()).contiguous(), ops.tokens_from_nchw(flow.float()),
+                                   H8, W8)
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, image1, image2, iters=12, flow_init=None, upsample=True, test_mode=0):
+        """Estimate optical flow between a pair of frames (network.py:164-267)."""
+        if not image1.is_cuda:
+            raise RuntimeError("craft_amd.CRAFT runs its hot path on HIP kernels: inputs must be on the GPU "
+                               "(there is no CPU fallback)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.update_block.parameters()) and self.training:
+            raise NotImplementedError("training (backward kernels) is not implemented in this round: "
+                                      "call model.eval() / use torch.no_grad()")
+        args = self.args
+        prec = self.hip_prec()
+        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        B, _, H, W = image1.shape
+        if H % 8 or W % 8:
+            raise ValueError("image height and width must be multiples of 8 (use InputPadder)")
+        H8, W8, N = H // 8, W // 8, (H // 8) * (W // 8)
+        hw = (H8, W8)
+        dev = image1.device
+
+        with torch.no_grad():
+            with _autocast(args.mixed_precision):
+                fmap1, fmap2 = self.fnet([image1, image2])
+                cnet_feat = self.cnet(image1)
+            fmap1, fmap2, cnet_feat = fmap1.float(), fmap2.float(), cnet_feat.float()
+
+            # ---- F2 transformer (network.py:185-187): tokens in, LayerNorm-ed tokens out ------------
+            x2 = ops.tokens_from_nchw(fmap2, ln=True)
+            fmap2_t = self.f2_trans.forward_tokens(x2, hw, prec=prec)                 # [B, N, 256]
+
+            # ---- context split + intra-frame attention (network.py:206-214) -----------------------
+            hx = torch.empty(B, N, 512, device=dev, dtype=torch.float32)              # [net | inp | mf | mfg]
+            ops.tokens_from_nchw(cnet_feat, c_off=0, C=128, act=ACT_TANH, out=hx[..., 0:128])
+            ops.tokens_from_nchw(cnet_feat, c_off=128, C=128, act=ACT_RELU, out=hx[..., 128:256])
+            if args.use_setrans:
+                xc = ops.tokens_norm(hx[..., 128:256])
+                attention = self.att.forward_tokens(xc, hw, prec=prec)                # [B, 4, N, ldp]
+            else:
+                attention = self.att.forward_tokens(hx[..., 128:256], hw, prec)
+
+            # ---- correlation volume + pyramid (network.py:196-197, :225-228) ---------------------
+            if args.craft:
+                x1 = ops.tokens_from_nchw(fmap1, ln=True)
+                x2t = ops.tokens_norm(fmap2_t)
+                self.corr_fn.update_tokens(x1, x2t, hw, prec)
+                corr_fn = self.corr_fn
+            else:
+                corr_fn = CorrBlock.__new__(CorrBlock)
+                corr_fn.num_levels, corr_fn.radius, corr_fn.shape = 4, args.corr_radius, (B, H8, W8)
+                corr_fn.pyramid = ops.CorrPyramid(B, H8, W8, 4, dev)
+                import math
+                ops.corr_build(ops.tokens_from_nchw(fmap1), fmap2_t, H8, W8, 1, 1.0 / math.sqrt(256), None, 0.0, 1.0, None,
+                               corr_fn.pyramid, False, prec)
+                self.corr_fn = corr_fn
+
+            coords0, coords1, flow = ops.coords_init(flow_init, B, H8, W8, dev)
+            ws = GMAUpdateBlock.workspace(B, N, dev)
+            nch = corr_fn.num_levels * (2 * corr_fn.radius + 1) ** 2
+            corr = torch.empty(B, N, nch, device=dev, dtype=torch.float32)
+            mask = torch.empty(B, N, 576, device=dev, dtype=torch.float32)
+            need_all = test_mode != 1
+            flow_predictions = []
+            flow_up = None
+            for itr in range(iters):
+                corr_fn.lookup_tokens(coords1, out=corr)                               # network.py:235
+                self.update_block.step_tokens(hx, corr, flow, attention, hw, ws, prec)  # :244 (to the new net)
+                self.update_block.flow_head_tokens(hx, hw, coords1, coords0, flow, None, ws, prec)   # :244-247
+                # the mask head + convex upsampling only feed the returned predictions: in test_mode=1 only
+                # the last one is returned (network.py:262-263), so earlier ones are skipped (same result).
+                if need_all or itr == iters - 1:
+                    self.update_block.mask_tokens(hx, hw, ws, prec, out=mask)
+                    flow_up = ops.convex_upsample(mask, flow, H8, W8)                  # :258
+                    flow_predictions.append(flow_up)
+            flow_lo = ops.tokens_to_nchw(flow, H8, W8)
+
+        self.call_counter += 1
+        if test_mode == 1:
+            return flow_lo, flow_up
+        if test_mode == 2:
+            return flow_lo, flow_predictions
+        return flow_predictions

@@ -1,0 +1,227 @@
+"""Tensor-level wrappers over the C ABI: allocate outputs with torch, enqueue the HIP kernels.
+
+Every function maps 1:1 to an entry point of ``include/craft_hip.h``; "tokens" = channels-last fp32
+``[B, N, C]`` (possibly a column slice of a wider buffer: pass ``t[..., a:b]`` views, their row stride
+is forwarded as ``ld``).  No compute happens in Python.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import hip
+from .hip import ACT_NONE, ACT_RELU, ACT_TANH, PREC_F32, PROB_DTYPE, call, round_up
+
+
+def _ld(t: torch.Tensor) -> int:
+    """Row stride (in elements) of a tokens view [..., n, c] whose channel stride is 1."""
+    if t.stride(-1) != 1:
+        raise hip.CraftHipError("tokens view must have unit channel stride")
+    return t.stride(-2)
+
+
+def _check_rows(t: torch.Tensor):
+    # rows of a [B, N, C] view must be uniformly strided: stride(0) == N * stride(1)
+    if t.dim() == 3 and t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1):
+        raise hip.CraftHipError("tokens view must be uniformly row-strided")
+
+
+def tokens_from_nchw(x: torch.Tensor, c_off: int = 0, C: Optional[int] = None, act: int = ACT_NONE, ln: bool = False,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NCHW [B, Ctot, H, W] channels [c_off, c_off+C) -> tokens [B, H*W, C] (+activation, +LayerNorm)."""
+    B, Ctot, H, W = x.shape
+    C = Ctot - c_off if C is None else C
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty(B, H * W, C, device=x.device, dtype=torch.float32)
+    _check_rows(out)
+    call("craft_tokens", x, 1, B, Ctot, c_off, C, H * W, 0, act, int(ln), out, _ld(out))
+    return out
+
+
+def tokens_from_nchw_wide(x: torch.Tensor) -> torch.Tensor:
+    """NCHW -> tokens for any channel count (chunks of <= 256 channels written into column slices)."""
+    B, C, H, W = x.shape
+    ld = round_up(C, 4)
+    out = torch.empty(B, H * W, ld, device=x.device, dtype=torch.float32)
+    if ld != C:
+        out[..., C:].zero_()
+    for c0 in range(0, C, 256):
+        c1 = min(C, c0 + 256)
+        tokens_from_nchw(x, c_off=c0, C=c1 - c0, out=out[..., c0:c1])
+    return out[..., :C]
+
+
+def tokens_norm(t: torch.Tensor, act: int = ACT_NONE, ln: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """tokens -> (activation) -> LayerNorm over C -> tokens."""
+    B, N, C = t.shape
+    _check_rows(t)
+    if out is None:
+        out = torch.empty(B, N, C, device=t.device, dtype=torch.float32)
+    call("craft_tokens", t, 0, B, C, 0, C, N, _ld(t), act, int(ln), out, _ld(out))
+    return out
+
+
+def tokens_to_nchw(t: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    B, N, C = t.shape
+    _check_rows(t)
+    out = torch.empty(B, C, H, W, device=t.device, dtype=torch.float32)
+    call("craft_tokens_to_nchw", t, _ld(t), B, C, N, out)
+    return out
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], prec: int,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Linear on tokens: [B, N, Cin] x [Cout, Cin]^T (+bias) -> [B, N, Cout]."""
+    B, N, Cin = x.shape
+    _check_rows(x)
+    Cout = w.shape[0]
+    if out is None:
+        out = torch.empty(B, N, Cout, device=x.device, dtype=torch.float32)
+    _check_rows(out)
+    call("craft_linear", x, _ld(x), w.contiguous(), bias, out, _ld(out), B * N, Cin, Cout, prec)
+    return out
+
+
+def linear_t(x: torch.Tensor, w: torch.Tensor, ldt: int, prec: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-sample transposed projection: yT[b][o][n] (row stride ldt >= N, tail zero)."""
+    B, N, Cin = x.shape
+    _check_rows(x)
+    Cout = w.shape[0]
+    if out is None:
+        out = torch.zeros(B, Cout, ldt, device=x.device, dtype=torch.float32)
+    call("craft_linear_t", x, _ld(x), w.contiguous(), out, ldt, B, N, Cin, Cout, prec)
+    return out
+
+
+def score_max(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale: float, prec: int,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Device-side global max of the raw scaled scores as an ordered uint32 (setrans.py:520-529)."""
+    B, N, C = q.shape
+    if out is None:
+        out = torch.zeros(1, device=q.device, dtype=torch.int32)
+    call("craft_score_max", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale, out, prec)
+    return out
+
+
+def decode_ord(o: torch.Tensor) -> float:
+    """Host decode of the ordered-uint max (diagnostics / tests only; forces a sync)."""
+    u = int(o.item()) & 0xFFFFFFFF
+    import struct
+    if u == 0:
+        return float("nan")
+    bits = (u & 0x7FFFFFFF) if (u & 0x80000000) else (~u & 0xFFFFFFFF)
+    return struct.unpack("<f", struct.pack("<I", bits))[0]
+
+
+class CorrPyramid:
+    """Un-normalised correlation pyramid + lazy global-LayerNorm statistics."""
+
+    def __init__(self, B: int, H8: int, W8: int, levels: int, device):
+        self.B, self.H8, self.W8, self.levels = B, H8, W8, levels
+        N = H8 * W8
+        self.lv = []
+        h, w = H8, W8
+        for _ in range(levels):
+            self.lv.append(torch.empty(B * N, h, w, device=device, dtype=torch.float32))
+            h, w = h // 2, w // 2
+        self.sums = torch.zeros(B, 2, device=device, dtype=torch.float64)
+        self.mu_rstd = torch.empty(B, 2, device=device, dtype=torch.float32)
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * 4 for t in self.lv)
+
+
+def corr_build(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale: float, pos_tab: Optional[torch.Tensor],
+               pos_w: float, w_aggr: float, clamp_ord: Optional[torch.Tensor], pyr: CorrPyramid, do_norm: bool,
+               prec: int) -> CorrPyramid:
+    B, N, C = q.shape
+    R = 0 if pos_tab is None else (pos_tab.shape[0] - 1) // 2
+    call("craft_corr_build", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale,
+         None if pos_tab is None else pos_tab.contiguous(), R, pos_w, w_aggr, clamp_ord, pyr.lv[0], pyr.sums, prec)
+    lv = pyr.lv + [None] * (4 - len(pyr.lv))
+    call("craft_corr_finish", lv[0], lv[1], lv[2], lv[3], pyr.sums, pyr.mu_rstd, B, H8, W8, int(do_norm))
+    return pyr
+
+
+def corr_lookup(pyr: CorrPyramid, coords: torch.Tensor, radius: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """coords tokens [B, N, 2] -> tokens [B, N, levels*(2r+1)^2]."""
+    B, N, _ = coords.shape
+    nch = pyr.levels * (2 * radius + 1) ** 2
+    if out is None:
+        out = torch.empty(B, N, nch, device=coords.device, dtype=torch.float32)
+    lv = pyr.lv + [None] * (4 - len(pyr.lv))
+    call("craft_corr_lookup", lv[0], lv[1], lv[2], lv[3], pyr.levels, pyr.mu_rstd, coords.contiguous(), B, pyr.H8, pyr.W8,
+         radius, out, _ld(out))
+    return out
+
+
+def attn_probs(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale: float, pos_tab: Optional[torch.Tensor],
+               pos_w: float, mask_radius: int, clamp_ord: Optional[torch.Tensor], prec: int,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """P [B, M, N, ldp] (ldp = N rounded up to 32; the tail columns are zero)."""
+    B, N, C = q.shape
+    ldp = round_up(N, 32)
+    if out is None:
+        out = torch.empty(B, M, N, ldp, device=q.device, dtype=PROB_DTYPE[prec])
+    R = 0 if pos_tab is None else (pos_tab.shape[0] - 1) // 2
+    call("craft_attn_probs", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale,
+         None if pos_tab is None else pos_tab.contiguous(), R, pos_w, mask_radius, clamp_ord, out, ldp, prec)
+    return out
+
+
+def attn_apply(P: torch.Tensor, vT: torch.Tensor, Dv: int, prec: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """O[b][m] = P[b][m] @ V_m with vT [B, M*Dv, ldp] -> O [B, M, N, Dv]."""
+    B, M, N, ldp = P.shape
+    if out is None:
+        out = torch.empty(B, M, N, Dv, device=P.device, dtype=torch.float32)
+    call("craft_attn_apply", P, ldp, vT, B, N, M, Dv, out, prec)
+    return out
+
+
+def mode_pool_ln(O: torch.Tensor, x: torch.Tensor, w_agg: torch.Tensor, skip_coeff: torch.Tensor,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    B, M, N, C = O.shape
+    _check_rows(x)
+    if out is None:
+        out = torch.empty(B, N, C, device=O.device, dtype=torch.float32)
+    _check_rows(out)
+    call("craft_mode_pool_ln", O, x, _ld(x), w_agg.contiguous().view(-1), skip_coeff, B, N, M, C, out, _ld(out))
+    return out
+
+
+def gma_residual(mf: torch.Tensor, O: torch.Tensor, gamma: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    B, N, C = mf.shape
+    if out is None:
+        out = torch.empty(B, N, C, device=mf.device, dtype=torch.float32)
+    call("craft_gma_residual", mf, _ld(mf), O, gamma, B, N, C, out, _ld(out))
+    return out
+
+
+def convex_upsample(mask: torch.Tensor, flow: torch.Tensor, H8: int, W8: int) -> torch.Tensor:
+    B = mask.shape[0]
+    up = torch.empty(B, 2, 8 * H8, 8 * W8, device=mask.device, dtype=torch.float32)
+    call("craft_convex_upsample", mask, flow, B, H8, W8, up)
+    return up
+
+
+def coords_init(flow_init: Optional[torch.Tensor], B: int, H8: int, W8: int, device):
+    N = H8 * W8
+    c0 = torch.empty(B, N, 2, device=device, dtype=torch.float32)
+    c1 = torch.empty_like(c0)
+    fl = torch.empty_like(c0)
+    call("craft_coords_init", None if flow_init is None else flow_init.contiguous().float(), B, H8, W8, c0, c1, fl)
+    return c0, c1, fl
+
+
+# ---- weight packing (layout plumbing, cached by the modules) --------------------------------------
+def pack_conv(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, KH, KW] -> [Cout, KH, KW, Cin] contiguous."""
+    return w.detach().permute(0, 2, 3, 1).contiguous().float()
+
+
+def pack_convf1(w: torch.Tensor) -> torch.Tensor:
+    """[128, 2, 7, 7] -> [7*7*2, 128] (tap-major, output channel contiguous)."""
+    return w.detach().permute(2, 3, 1, 0).reshape(-1, w.shape[0]).contiguous().float()

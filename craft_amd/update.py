@@ -1,0 +1,199 @@
+"""Per-iteration update block of CRAFT on HIP kernels.
+
+Parameter layout of the reference's ``core/update.py``: ``BasicMotionEncoder`` :67-87,
+``SepConvGRU`` :37-64, ``FlowHead`` :8-16, mask head :124-127, ``GMAUpdateBlock`` :116-162.
+The convolutions run as NHWC implicit GEMMs on MFMA with fused epilogues (ReLU, sigmoid gates,
+r*h, GRU blend, 0.25 mask scale); every ``torch.cat`` of the reference is a column range of one
+512-wide token buffer ``hx = [h | inp | motion | motion_global]``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .gma import Aggregate
+from .hip import PREC_F32, call
+from .setrans import ExpandedFeatTrans
+
+
+class _PackCache:
+    """Caches re-laid-out weights; invalidated when any source parameter is updated in place or replaced."""
+
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, params, fn):
+        key = tuple((p.data_ptr(), p._version, p.device) for p in params)
+        if key != self._key:
+            with torch.no_grad():
+                self._val = fn()
+            self._key = key
+        return self._val
+
+
+class FlowHead(nn.Module):
+    def __init__(self, input_dim: int = 128, hidden_dim: int = 256):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, 2, 3, padding=1)
+        self._pk = _PackCache()
+
+    def packed(self):
+        return self._pk.get([self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias],
+                            lambda: (ops.pack_conv(self.conv1.weight), self.conv1.bias.detach().float().contiguous(),
+                                     ops.pack_conv(self.conv2.weight), self.conv2.bias.detach().float().contiguous()))
+
+
+class SepConvGRU(nn.Module):
+    def __init__(self, hidden_dim: int = 128, input_dim: int = 192 + 128):
+        super().__init__()
+        c = hidden_dim + input_dim
+        self.hidden_dim, self.input_dim = hidden_dim, input_dim
+        self.convz1 = nn.Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
+        self.convr1 = nn.Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
+        self.convq1 = nn.Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
+        self.convz2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
+        self.convr2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
+        self.convq2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
+        self._pk = _PackCache()
+
+    def packed(self):
+        mods = [self.convz1, self.convr1, self.convq1, self.convz2, self.convr2, self.convq2]
+        params = [p for m in mods for p in (m.weight, m.bias)]
+
+        def make():
+            out = []
+            for z, r, q in ((self.convz1, self.convr1, self.convq1), (self.convz2, self.convr2, self.convq2)):
+                out += [ops.pack_conv(torch.cat([z.weight, r.weight], 0)),
+                        torch.cat([z.bias, r.bias], 0).detach().float().contiguous(),
+                        ops.pack_conv(q.weight), q.bias.detach().float().contiguous()]
+            return tuple(out)
+        return self._pk.get(params, make)
+
+    def forward_tokens(self, hx: torch.Tensor, hw, ws: torch.Tensor, prec: int):
+        """In place on hx = [h (128) | x (input_dim)] tokens [B, N, 128+input_dim]."""
+        B, N, _ = hx.shape
+        H8, W8 = hw
+        wzr1, bzr1, wq1, bq1, wzr2, bzr2, wq2, bq2 = self.packed()
+        call("craft_sepconv_gru", hx, hx.stride(1), self.input_dim, wzr1, bzr1, wq1, bq1, wzr2, bzr2, wq2, bq2, B, H8, W8,
+             ws, prec)
+
+
+class BasicMotionEncoder(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        cor_planes = args.corr_levels * args.corr_multiplier * (2 * args.corr_radius + 1) ** 2
+        self.cor_planes = cor_planes
+        self.convc1 = nn.Conv2d(cor_planes, 256, 1, padding=0)
+        self.convc2 = nn.Conv2d(256, 192, 3, padding=1)
+        self.convf1 = nn.Conv2d(2, 128, 7, padding=3)
+        self.convf2 = nn.Conv2d(128, 64, 3, padding=1)
+        self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
+        self._pk = _PackCache()
+
+    def packed(self):
+        mods = [self.convc1, self.convc2, self.convf1, self.convf2, self.conv]
+        params = [p for m in mods for p in (m.weight, m.bias)]
+
+        def b(m):
+            return m.bias.detach().float().contiguous()
+        return self._pk.get(params, lambda: (self.convc1.weight.detach().view(256, -1).float().contiguous(), b(self.convc1),
+                                             ops.pack_conv(self.convc2.weight), b(self.convc2),
+                                             ops.pack_convf1(self.convf1.weight), b(self.convf1),
+                                             ops.pack_conv(self.convf2.weight), b(self.convf2),
+                                             ops.pack_conv(self.conv.weight), b(self.conv)))
+
+    def forward_tokens(self, flow: torch.Tensor, corr: torch.Tensor, hw, out: torch.Tensor, ws: torch.Tensor, prec: int):
+        """flow tokens [B,N,2], corr tokens [B,N,cor_planes] -> out tokens view [B,N,128]."""
+        B, N, _ = flow.shape
+        H8, W8 = hw
+        wc1, bc1, wc2, bc2, wf1, bf1, wf2, bf2, wcv, bcv = self.packed()
+        call("craft_motion_encoder", corr, corr.stride(1), self.cor_planes, flow, wc1, bc1, wc2, bc2, wf1, bf1, wf2, bf2,
+             wcv, bcv, B, H8, W8, out, out.stride(1), ws, prec)
+
+
+class GMAUpdateBlock(nn.Module):
+    def __init__(self, args, hidden_dim: int = 128):
+        super().__init__()
+        self.args = args
+        self.encoder = BasicMotionEncoder(args)
+        self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=128 + hidden_dim + hidden_dim)
+        self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
+        self.mask = nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(256, 64 * 9, 1, padding=0))
+        self.use_setrans = args.use_setrans
+        if self.use_setrans:
+            self.intra_trans_config = args.intra_trans_config
+            self.aggregator = ExpandedFeatTrans(self.intra_trans_config, "Motion Aggregator")
+        else:
+            self.aggregator = Aggregate(args=args, dim=128, dim_head=128, heads=args.num_heads)
+        self._pk_mask = _PackCache()
+
+    def packed_mask(self):
+        m0, m2 = self.mask[0], self.mask[2]
+        return self._pk_mask.get([m0.weight, m0.bias, m2.weight, m2.bias],
+                                 lambda: (ops.pack_conv(m0.weight), m0.bias.detach().float().contiguous(),
+                                          m2.weight.detach().view(576, -1).float().contiguous(),
+                                          m2.bias.detach().float().contiguous()))
+
+    # -- token-level steps used by CRAFT.forward ---------------------------------------------------
+    def step_tokens(self, hx, corr, flow, attention, hw, ws, prec):
+        """One refinement step up to the new hidden state (update.py:137-156), in place on
+        hx = [net | inp | motion | motion_global] tokens [B, N, 512]."""
+        self.encoder.forward_tokens(flow, corr, hw, hx[..., 256:384], ws, prec)
+        mf = hx[..., 256:384]
+        if self.use_setrans:
+            self.aggregator(mf, attention, out=hx[..., 384:512], prec=prec)
+        else:
+            self.aggregator.forward_tokens(attention, mf, prec, out=hx[..., 384:512])
+        self.gru.forward_tokens(hx, hw, ws, prec)
+
+    def flow_head_tokens(self, hx, hw, coords1, coords0, flow, delta, ws, prec):
+        B, N, _ = hx.shape
+        w1, b1, w2, b2 = self.flow_head.packed()
+        call("craft_flow_head", hx, hx.stride(1), w1, b1, w2, b2, B, hw[0], hw[1], coords1, coords0, flow, delta, ws, prec)
+
+    def mask_tokens(self, hx, hw, ws, prec, out: Optional[torch.Tensor] = None):
+        B, N, _ = hx.shape
+        if out is None:
+            out = torch.empty(B, N, 576, device=hx.device, dtype=torch.float32)
+        w0, b0, w2, b2 = self.packed_mask()
+        call("craft_mask_head", hx, hx.stride(1), w0, b0, w2, b2, B, hw[0], hw[1], out, ws, prec)
+        return out
+
+    @staticmethod
+    def workspace(B: int, N: int, device) -> torch.Tensor:
+        """Scratch for one step: max(motion encoder 640, GRU 256, heads 256) floats per pixel."""
+        return torch.empty(B * N * 640, device=device, dtype=torch.float32)
+
+    def forward(self, net, inp, corr, flow, attention):
+        """NCHW interface of the reference (update.py:137-162) -> (net, mask, delta_flow), all NCHW.
+        ``attention`` is what ``self.att`` returned ([B, M, N, N] view of the padded P)."""
+        prec = getattr(self, "hip_prec", PREC_F32)
+        B, _, H8, W8 = net.shape
+        N = H8 * W8
+        dev = net.device
+        hx = torch.empty(B, N, 512, device=dev, dtype=torch.float32)
+        ops.tokens_from_nchw(net.float(), out=hx[..., 0:128])
+        ops.tokens_from_nchw(inp.float(), out=hx[..., 128:256])
+        corr_t = ops.tokens_from_nchw_wide(corr.float())
+        flow_t = ops.tokens_from_nchw(flow.float())
+        P = attention
+        if P.shape[-1] == N and P.stride(-2) == N:            # unpadded caller-made tensor: re-pad
+            ldp = ops.round_up(N, 32)
+            Pp = torch.zeros(*P.shape[:-1], ldp, device=dev, dtype=P.dtype)
+            Pp[..., :N] = P
+            P = Pp
+        elif P.stride(-2) != P.shape[-1]:                      # the [..., :N] view handed out by att.forward
+            P = torch.as_strided(P, (*P.shape[:-1], P.stride(-2)), P.stride())
+        ws = self.workspace(B, N, dev)
+        self.step_tokens(hx, corr_t, flow_t, P, (H8, W8), ws, prec)
+        c0, c1, fl = ops.coords_init(None, B, H8, W8, dev)
+        delta = torch.empty(B, N, 2, device=dev, dtype=torch.float32)
+        self.flow_head_tokens(hx, (H8, W8), c1, c0, fl, delta, ws, prec)
+        mask = self.mask_tokens(hx, (H8, W8), ws, prec)
+        return (ops.tokens_to_nchw(hx[..., 0:128], H8, W8), ops.tokens_to_nchw(mask, H8, W8),
+                ops.tokens_to_nchw(delta, H8, W8))

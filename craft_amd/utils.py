@@ -1,0 +1,58 @@
+"""Small host-side helpers around the model (the reference's ``core/utils/utils.py``)."""
+from __future__ import annotations
+
+import argparse
+
+import torch
+import torch.nn.functional as F
+
+
+class InputPadder:
+    """Pad images so that H and W are divisible by ``mod`` (utils.py:14-31): 'sintel' pads
+    symmetrically, anything else ('kitti') pads the bottom only; replicate padding."""
+
+    def __init__(self, dims, mode: str = "sintel", mod: int = 8):
+        self.ht, self.wd = dims[-2:]
+        ph = (mod - self.ht % mod) % mod
+        pw = (mod - self.wd % mod) % mod
+        if mode == "sintel":
+            self._pad = [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2]
+        else:
+            self._pad = [pw // 2, pw - pw // 2, 0, ph]
+
+    def pad(self, *inputs):
+        return [F.pad(x, self._pad, mode="replicate") for x in inputs]
+
+    def unpad(self, x):
+        ht, wd = x.shape[-2:]
+        return x[..., self._pad[2]: ht - self._pad[3], self._pad[0]: wd - self._pad[1]]
+
+
+def coords_grid(batch: int, ht: int, wd: int, device=None) -> torch.Tensor:
+    """[B, 2, ht, wd] with channel 0 = x (column), channel 1 = y (row)  (utils.py:82-85)."""
+    ys, xs = torch.meshgrid(torch.arange(ht, device=device, dtype=torch.float32),
+                            torch.arange(wd, device=device, dtype=torch.float32), indexing="ij")
+    return torch.stack([xs, ys], dim=0)[None].expand(batch, -1, -1, -1)
+
+
+def default_args(**overrides) -> argparse.Namespace:
+    """The Namespace ``train.py`` / ``evaluate.py`` build for the released configuration
+    (``--craft --f2 full --setrans``; train.py:311-406), for callers without an argparse front-end."""
+    a = argparse.Namespace(craft=True, use_setrans=True, f1trans="none", f2trans="full", corr_radius=4,
+                           pos_bias_radius=7, mixed_precision=False, dropout=0.0, num_heads=1, position_only=False,
+                           position_and_content=False, f2_pos_code_weight=0.5, f2_attn_mask_radius=-1,
+                           inter_num_modes=4, intra_num_modes=4, f2_num_modes=4, inter_qk_have_bias=True,
+                           inter_pos_code_type="bias", inter_pos_code_weight=0.5, intra_pos_code_type="bias",
+                           intra_pos_code_weight=1.0)
+    for k, v in overrides.items():
+        setattr(a, k, v)
+    return a
+
+
+def load_checkpoint(model: torch.nn.Module, path_or_dict, strict: bool = False):
+    """Load a reference-layout checkpoint: ``{'model': {'module.<key>': tensor}, ...}`` or a legacy bare
+    state dict, with or without the DataParallel ``module.`` prefix (evaluate.py:1540-1547, train.py:147-154)."""
+    ck = torch.load(path_or_dict, map_location="cpu") if isinstance(path_or_dict, str) else path_or_dict
+    sd = ck["model"] if isinstance(ck, dict) and "model" in ck else ck
+    sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+    return model.load_state_dict(sd, strict=strict)

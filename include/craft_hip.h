@@ -1,0 +1,154 @@
+/* libcraft_hip.so — C ABI of the MI355X-native CRAFT hot path (gfx950).
+ *
+ * The reference (askerlee/craft @ 2024-10-20) has no FFI of its own: its hot path is PyTorch op call
+ * sites inside core/{corr,setrans,gma,update,network}.py.  Each entry point below replaces one of
+ * those Python functions (cited as file:line under the reference root) and is what a maintainer of
+ * the reference would bind with ctypes (INTEGRATION.md shows the stub).  Conventions:
+ *
+ *   - plain `extern "C"`, raw DEVICE pointers + sizes, no torch types; `stream` is a hipStream_t
+ *     (NULL = default stream).  Every call only enqueues work on `stream`; no internal allocation,
+ *     no synchronisation, no global state -> re-entrant per stream and hipGraph-capturable.
+ *   - the caller owns every buffer, including workspaces (sizes documented per call);
+ *   - weights are passed on every call (no hidden copies: optimizer / load_state_dict updates are seen);
+ *   - return 0 on success, a hipError_t value, or a CRAFT_ERR_* code (craft_hip_error_string()).
+ *
+ * Data layout ("tokens"): every activation on the hot path is channels-last fp32,
+ *   T[b][n][c] at  base + (b*N + n)*ld + c,   n = y*W8 + x  (H8 = H/8, W8 = W/8, N = H8*W8);
+ * `ld` (row stride, in floats) lets a tensor be a column slice of a wider buffer, which is how the
+ * reference's torch.cat()s are made free.  Row strides and channel counts must be multiples of 4.
+ * Coordinates / flow are tokens with 2 channels in (x, y) order (utils.py:82-85).
+ *
+ * Precision codes: 0 = fp32 (v_mfma_f32_32x32x2_f32, exact fp32 products), 1 = bf16 MFMA with fp32
+ * accumulate, 2 = fp16 MFMA with fp32 accumulate (operands are converted while staged into LDS).
+ */
+#ifndef CRAFT_HIP_H
+#define CRAFT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRAFT_HIP_ABI_VERSION 1
+
+#define CRAFT_PREC_F32 0
+#define CRAFT_PREC_BF16 1
+#define CRAFT_PREC_F16 2
+
+#define CRAFT_ACT_NONE 0
+#define CRAFT_ACT_TANH 1
+#define CRAFT_ACT_RELU 2
+
+int craft_hip_abi_version(void);
+const char* craft_hip_error_string(int code);
+
+/* SETransInputFeatEncoder.forward, pos_code_type='bias' (setrans.py:763-800) and the tanh/relu split of
+ * cnet's output (network.py:209-212): channels [c_off, c_off+C) of `src` -> act -> optional LayerNorm over
+ * C (no affine, eps 1e-12) -> tokens.  src_nchw=1: src is [B, Ctot, HW]; 0: src is tokens with row stride
+ * src_ld.  C <= 256. */
+int craft_tokens(const float* src, int src_nchw, int B, int Ctot, int c_off, int C, int HW, long src_ld,
+                 int act, int do_ln, float* dst, long dst_ld, void* stream);
+
+/* tokens (first C columns) -> NCHW [B, C, HW]   (the reshape at setrans.py:617 / network.py return values) */
+int craft_tokens_to_nchw(const float* src, long ld, int B, int C, int HW, float* dst, void* stream);
+
+/* nn.Linear (setrans.py:507-508, :373):  y[r][o] = sum_c x[r][c]*w[o][c] + bias[o]   (bias may be NULL) */
+int craft_linear(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, long rows,
+                 int cin, int cout, int prec, void* stream);
+/* the same projection written transposed per sample, yT[b][o][n] with row stride ldt >= N (used for V^T,
+ * setrans.py:373-378).  The caller zero-fills columns [N, ldt) once. */
+int craft_linear_t(const float* x, long ldx, const float* w, float* yT, long ldt, int B, int N, int cin,
+                   int cout, int prec, void* stream);
+
+/* Global max of the raw scaled scores Q_m K_m^T * scale over batch, modes, i, j (the .max().item() of
+ * setrans.py:520-521) as an order-preserving uint in *max_ord; consumers clamp to [-100, 100] iff that max
+ * is > 100 (setrans.py:524-529) without a host round trip.  q,k: projected tokens [B][N][ld], mode m =
+ * columns [m*d, m*d+d). */
+int craft_score_max(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d,
+                    float scale, unsigned* max_ord, int prec, void* stream);
+
+/* TransCorrBlock.corr up to (not including) the global LayerNorm (corr.py:191-199; setrans.py:507-550):
+ * c(i,j) = sum_m s_m softmax_m(w_aggr*s_m) + pos_w*pb(i,j) with s_m = clamp?(Q_m(i).K_m(j)*scale), written
+ * to pyramid level 0 [B*N][H8][W8]; sums[b] = (sum c, sum c^2) in double for the lazy LayerNorm.
+ * pos_tab: SlidingPosBiases2D.biases [(2R+1)^2] (setrans.py:644-708), NULL = none; clamp_ord from
+ * craft_score_max (NULL = never clamp).  M=1, pos_tab=NULL, scale=1/sqrt(C) gives CorrBlock.corr
+ * (corr.py:73-81). */
+int craft_corr_build(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d,
+                     float scale, const float* pos_tab, int R, float pos_w, float w_aggr,
+                     const unsigned* clamp_ord, float* pyr0, double* sums, int prec, void* stream);
+
+/* corr.py:186-189 + :200-204: levels 1..3 by 2x2 average pooling (floor sizes; pass NULL to stop early) and
+ * mu_rstd[b] = (mean, 1/sqrt(var+1e-12)) over all N*N entries (do_norm=0: (0,1)). */
+int craft_corr_finish(const float* pyr0, float* pyr1, float* pyr2, float* pyr3, const double* sums,
+                      float* mu_rstd, int B, int H8, int W8, int do_norm, void* stream);
+
+/* CorrBlock.__call__ + bilinear_sampler (corr.py:47-71, utils.py:65-79): out[q][l*(2r+1)^2 + a*(2r+1) + b] =
+ * bilinear_zero_pad(LN(pyr_l)[q], x/2^l + a - r, y/2^l + b - r), q = b*N + n, coords tokens (x,y). */
+int craft_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3, int levels,
+                      const float* mu_rstd, const float* coords, int B, int H8, int W8, int radius,
+                      float* out, long ldo, void* stream);
+
+/* CrossAttFeatTrans up to the softmax (setrans.py:507-557): P[b][m][i][j] = softmax_j(clamp?(Q_m(i).K_m(j)*
+ * scale) + pos_w*pb(i,j) + mask), mask = -1e9 where Chebyshev distance > mask_radius (setrans.py:580-584,
+ * <=0: none).  P has row stride ldp (multiple of 32, >= N); columns [N, ldp) are written as zeros.
+ * Element type of P: float (prec 0), bf16 (1), fp16 (2). */
+int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d,
+                     float scale, const float* pos_tab, int R, float pos_w, int mask_radius,
+                     const unsigned* clamp_ord, void* P, long ldp, int prec, void* stream);
+
+/* ExpandedFeatTrans.forward, matmul part (setrans.py:384): O[b][m][i][:] = sum_j P[b][m][i][j] * V_m[j][:],
+ * with vT[b][m*Dv + c][j] (row stride ldp, zero beyond N) from craft_linear_t.  O: [B][M][N][Dv] fp32. */
+int craft_attn_apply(const void* P, long ldp, const float* vT, int B, int N, int M, int Dv, float* O, int prec,
+                     void* stream);
+
+/* ExpandedFeatTrans.forward tail (setrans.py:395-407): a_m = softmax_m(<O_m, w_agg>), out = LayerNorm(
+ * skip_coeff * x + sum_m a_m O_m).  C = Dv in {64,128,192,256}. */
+int craft_mode_pool_ln(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff,
+                       int B, int N, int M, int C, float* out, long ldo, void* stream);
+
+/* gma.Aggregate.forward tail (gma.py:138): out = mf + gamma * O */
+int craft_gma_residual(const float* mf, long ldm, const float* O, const float* gamma, int B, int N, int C,
+                       float* out, long ldo, void* stream);
+
+/* BasicMotionEncoder.forward (update.py:79-87).  corr tokens [B*N][cor_planes] (row stride ldc), flow tokens
+ * [B*N][2].  Conv weights are packed [Cout][KH][KW][Cin] (weight.permute(0,2,3,1)); wf1 is packed
+ * [7*7*2][128] (weight.permute(2,3,1,0)).  Output: 128 channels (126 conv + 2 flow) at out (row stride ldo).
+ * ws: 640 floats per pixel. */
+int craft_motion_encoder(const float* corr, long ldc, int cor_planes, const float* flow, const float* wc1,
+                         const float* bc1, const float* wc2, const float* bc2, const float* wf1,
+                         const float* bf1, const float* wf2, const float* bf2, const float* wcv,
+                         const float* bcv, int B, int H8, int W8, float* out, long ldo, float* ws, int prec,
+                         void* stream);
+
+/* SepConvGRU.forward (update.py:49-64) in place on hx = [h (128) | x (cx)] (row stride ldhx): 1x5 pass then
+ * 5x1 pass; wzr*: convz and convr stacked on the output axis and packed [256][KH][KW][128+cx], wq*:
+ * [128][KH][KW][128+cx].  ws: 256 floats per pixel (z and r*h). */
+int craft_sepconv_gru(float* hx, long ldhx, int cx, const float* wzr1, const float* bzr1, const float* wq1,
+                      const float* bq1, const float* wzr2, const float* bzr2, const float* wq2,
+                      const float* bq2, int B, int H8, int W8, float* ws, int prec, void* stream);
+
+/* FlowHead.forward (update.py:15-16) fused with coords1 += delta (network.py:247) and flow = coords1 - coords0.
+ * h: hidden state tokens (row stride ldh); w1 packed [256][3][3][128]; w2 packed [2][3][3][256];
+ * delta may be NULL.  ws: 256 floats per pixel. */
+int craft_flow_head(const float* h, long ldh, const float* w1, const float* b1, const float* w2,
+                    const float* b2, int B, int H8, int W8, float* coords1, const float* coords0, float* flow,
+                    float* delta, float* ws, int prec, void* stream);
+
+/* mask head (update.py:124-127, :161): mask = 0.25 * conv1x1(relu(conv3x3(h))) -> tokens [B*N][576].
+ * w0 packed [256][3][3][128], w2 [576][256].  ws: 256 floats per pixel. */
+int craft_mask_head(const float* h, long ldh, const float* w0, const float* b0, const float* w2,
+                    const float* b2, int B, int H8, int W8, float* mask, float* ws, int prec, void* stream);
+
+/* CRAFT.upsample_flow (network.py:151-162): mask tokens [B*N][576], flow tokens [B*N][2] -> up NCHW
+ * [B][2][8*H8][8*W8]. */
+int craft_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, void* stream);
+
+/* coords_grid + flow_init (utils.py:82-85, network.py:219-222): coords0 = grid, coords1 = grid + flow_init
+ * (NCHW [B][2][H8][W8], may be NULL), flow = coords1 - coords0; all tokens [B*N][2]. */
+int craft_coords_init(const float* flow_init_nchw, int B, int H8, int W8, float* coords0, float* coords1,
+                      float* flow, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRAFT_HIP_H */

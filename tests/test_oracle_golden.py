@@ -1,0 +1,93 @@
+"""Pin the CPU oracle (oracle/craft_oracle.py) to the reference itself.
+
+The fixtures hold samples of tensors captured by running the imported reference
+(tools/make_golden.py) at every stage boundary of the hot path; here the oracle is run on the
+same inputs (images from the fixture, weights regenerated from the recorded recipe) and must agree
+to fp32 rounding.  Both are fp32 on CPU, so the tolerances are tight.
+"""
+import pytest
+import torch
+
+from craft_amd import CRAFT, default_args
+from craft_amd.synth import synth_state_dict
+from golden_util import CASES, Golden, layout
+from oracle import craft_oracle as O
+
+RTOL, ATOL = 2e-4, 2e-5
+
+
+def oracle_inputs(g: Golden):
+    m = g.meta
+    args = default_args(**m["over"])
+    model = CRAFT(args)
+    sd = synth_state_dict(model.state_dict(), seed=m["seed"], qk_gain=m["qk_gain"])
+    cfg = O.OracleConfig(craft=args.craft, use_setrans=args.use_setrans, f2_attn_mask_radius=args.f2_attn_mask_radius)
+    return sd, cfg
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_state_dict_layout_matches_reference(case):
+    g = Golden(case)
+    ref = layout(g.meta["over"])
+    ours = {k: list(v.shape) for k, v in CRAFT(default_args(**g.meta["over"])).state_dict().items()}
+    assert sorted(ours.keys()) == sorted(ref.keys())       # the JSON fixture is key-sorted
+    assert ours == ref
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_reference_capture(case):
+    g = Golden(case)
+    sd, cfg = oracle_inputs(g)
+    im1, im2 = g.images()
+    cap = {}
+    flow_lo, preds = O.craft_forward(sd, cfg, im1, im2, iters=g.meta["iters"], flow_init=g.flow_init(), test_mode=2, capture=cap)
+    g.check("fmap1", cap["fmap1"], RTOL, ATOL)
+    g.check("fmap2", cap["fmap2"], RTOL, ATOL)
+    g.check("fmap2t", cap["fmap2t"], RTOL, ATOL)
+    g.check("attention", cap["attention"], RTOL, 1e-6)
+    g.check("net0", cap["net1"], RTOL, ATOL)
+    g.check("mask0", cap["mask1"], RTOL, ATOL)
+    g.check("dflow0", cap["dflow1"], RTOL, ATOL)
+    g.check("flow_lo", flow_lo, 1e-3, 2e-4)
+    for it, p in enumerate(preds):
+        g.check(f"up{it}", p, 1e-3, 2e-3)
+    if "flow_lo.full" in g.z.files:
+        ref = torch.from_numpy(g.z["up_last.full"])
+        assert (preds[-1] - ref).abs().max().item() < 2e-3
+        assert (flow_lo - torch.from_numpy(g.z["flow_lo.full"])).abs().max().item() < 3e-4
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_pyramid_and_lookup(case):
+    """Normalised pyramid levels and three lookups (identity grid, final coords, far out-of-bounds coords)."""
+    g = Golden(case)
+    sd, cfg = oracle_inputs(g)
+    im1, im2 = g.images()
+    cap = {}
+    flow_lo, _ = O.craft_forward(sd, cfg, im1, im2, iters=g.meta["iters"], flow_init=g.flow_init(), test_mode=2, capture=cap)
+    B, _, H8, W8 = cap["fmap1"].shape
+    c = cap["corr_raw"]
+    pyr = O.build_pyramid(c, H8, W8, 4)
+    mu, rstd = cap["mu"], cap["rstd"]
+    N = H8 * W8
+    for l, p in enumerate(pyr):
+        pn = p if mu is None else (p - mu.repeat_interleave(N)[:, None, None, None]) * rstd.repeat_interleave(N)[:, None, None, None]
+        g.check(f"pyr{l}", pn, RTOL, 5e-5)
+    c0 = O.coords_grid(B, H8, W8)
+    g.check("look_id", O.corr_lookup(pyr, c0, 4, mu, rstd), RTOL, 1e-4)
+    g.check("look_fin", O.corr_lookup(pyr, c0 + flow_lo, 4, mu, rstd), 1e-3, 2e-3)
+    wild = torch.from_numpy(g.z["wild_coords"])
+    g.check("look_wild", O.corr_lookup(pyr, wild, 4, mu, rstd), RTOL, 2e-4)
+
+
+def test_oracle_clamp_case_actually_clamps():
+    g = Golden("clamp_128x160_T2")
+    assert int(g.z["clamp_count"][0]) >= 1
+    sd, cfg = oracle_inputs(g)
+    im1, im2 = g.images()
+    cap = {}
+    O.craft_forward(sd, cfg, im1, im2, iters=1, capture=cap)
+    x1 = O.tokens_layernorm(cap["fmap1"])
+    x2 = O.tokens_layernorm(cap["fmap2t"])
+    W, b = sd["corr_fn.setrans.query.weight"], sd["corr_fn.setrans.query.bias"]
+    assert float(O.mm_scores(x1, x2, W, b, W, b, 4).max()) > 100.0
