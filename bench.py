@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: image-pairs/sec at 448x1024, 12 refinement iterations (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|fp16|fp32] [--batch 4]
+
+A "step" is one forward pass of craft_amd.CRAFT (CNN encoders on PyTorch-ROCm + the HIP hot path)
+over one batch of synthetic 448x1024 pairs already resident in HBM, test_mode=1, 12 iterations —
+BASELINE.json configs[1].  N>1 is launched by torch.distributed.run (one rank per GPU); pairs shard by
+batch with no data-path collective (weak scaling), the timed region is bracketed by barrier +
+synchronize and the max over ranks is reported.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      the dominant kernel (the aggregator's P.V GEMM, k_gemm_rows<...A16>) timed live with HIP
+                events on the launch stream: algorithmic bytes = the attention probabilities it must stream
+                (B*M*N*ldp*sizeof(P)) + V^T + O, against the 8 TB/s HBM peak (MI355X_MICROARCH.md).
+  cpu_baseline  the CPU oracle (oracle/craft_oracle.py, fp32 torch-CPU restatement of the reference's
+                forward) timed on this box's host cores on ONE 448x1024 pair, 12 iterations.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="pairs per GPU per step (configs[1]: 4)")
+    ap.add_argument("--height", type=int, default=448)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--iters", type=int, default=12)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ops", action="store_true", help="also print a per-operator timing table to stderr")
+    return ap.parse_args()
+
+
+def op_table(model, im1, im2, iters):
+    """Per-operator wall time via events around each C-ABI call (diagnostics; stderr only)."""
+    from craft_amd import hip
+    orig = hip.call
+    acc = {}
+
+    def timed(name, *a):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        orig(name, *a)
+        e.record()
+        acc.setdefault(name, []).append((s, e))
+    import craft_amd.ops as ops_mod
+    import craft_amd.update as upd_mod
+    hip.call = ops_mod.call = upd_mod.call = timed
+    try:
+        with torch.no_grad():
+            model(im1, im2, iters=iters, test_mode=1)
+        torch.cuda.synchronize()
+    finally:
+        hip.call = ops_mod.call = upd_mod.call = orig
+    rows = [(n, len(v), sum(s.elapsed_time(e) for s, e in v)) for n, v in acc.items()]
+    tot = sum(r[2] for r in rows)
+    print(f"[ops] per-operator time for one forward (B={im1.shape[0]}): total {tot:.2f} ms", file=sys.stderr)
+    for n, c, t in sorted(rows, key=lambda r: -r[2]):
+        print(f"[ops] {n:28s} calls {c:4d}  {t:9.3f} ms  {100 * t / tot:5.1f} %", file=sys.stderr)
+
+
+def roofline_pv(model, B, H8, W8, prec, reps=20):
+    """Time the aggregator's P.V GEMM alone (same shapes as in the forward) with HIP events."""
+    from craft_amd import ops
+    from craft_amd.hip import PROB_DTYPE
+    dev = torch.device("cuda")
+    N, M, Dv = H8 * W8, 4, 128
+    ldp = ops.round_up(N, 32)
+    P = torch.rand(B, M, N, ldp, device=dev, dtype=torch.float32).div_(N / 2).to(PROB_DTYPE[prec])
+    vT = torch.randn(B, M * Dv, ldp, device=dev)
+    O = torch.empty(B, M, N, Dv, device=dev)
+    for _ in range(3):
+        ops.attn_apply(P, vT, Dv, prec, out=O)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(reps):
+        ops.attn_apply(P, vT, Dv, prec, out=O)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / reps
+    bytes_alg = P.numel() * P.element_size() + vT.numel() * 4 + O.numel() * 4
+    ach = bytes_alg / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_gemm_rows (attention apply O = P.V, aggregator shape)", "achieved": round(ach, 1),
+            "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+            "bytes_per_launch": bytes_alg, "ms_per_launch": round(ms, 4)}
+
+
+def cpu_baseline(H, W, iters):
+    from craft_amd import CRAFT, default_args
+    from craft_amd.synth import synth_pair, synth_state_dict
+    from oracle import craft_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synth_state_dict(CRAFT(default_args()).state_dict(), seed=1234)
+    im1, im2, _ = synth_pair(1, H, W, seed=0)
+    t0 = time.time()
+    O.craft_forward(sd, O.OracleConfig(), im1, im2, iters=iters, test_mode=1)
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "image-pairs/sec", "cores": cores, "kind": "port",
+            "sample": f"1 pair {H}x{W}, {iters} iters, fp32 torch-CPU oracle (oracle/craft_oracle.py), {dt:.1f} s wall"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", init_method="env://")
+
+    from craft_amd import CRAFT, default_args
+    from craft_amd.hip import PREC_NAMES
+    from craft_amd.synth import synth_pair, synth_state_dict
+
+    model = CRAFT(default_args(hip_precision=a.precision, mixed_precision=a.precision != "fp32"))
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=1234), strict=True)
+    model = model.to(dev).eval()
+    im1, im2, _ = synth_pair(a.batch, a.height, a.width, seed=100 + rank)
+    im1, im2 = im1.to(dev), im2.to(dev)
+
+    def step():
+        with torch.no_grad():
+            return model(im1, im2, iters=a.iters, test_mode=1)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out[1]).all()
+
+    if rank == 0:
+        pairs = a.batch * world * a.steps
+        line = {
+            "metric": "image-pairs/sec at 448x1024, 12 iters",
+            "value": round(pairs / dt, 3), "unit": "image-pairs/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.precision if a.precision != "fp32" else "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {a.height}x{a.width} synthetic pairs, batch {a.batch}/GPU, {a.iters} iters, "
+                                   "craft-sintel architecture with synthetic weights (checkpoints absent), test_mode=1",
+                       "global_batch": a.batch * world, "parallelism": f"dp{world} (pairs sharded by batch, no collective)"},
+        }
+        if a.ops:
+            op_table(model, im1, im2, a.iters)
+        line["roofline"] = roofline_pv(model, a.batch, a.height // 8, a.width // 8, PREC_NAMES[a.precision])
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.height, a.width, a.iters)
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

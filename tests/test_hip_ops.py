@@ -1,0 +1,317 @@
+"""Per-kernel parity tests: every C-ABI entry point against the CPU oracle on seeded inputs.
+
+All tests need the GPU (``-m gpu``) and go through ``libcraft_hip.so``.  fp32 mode must match the
+oracle to fp32 rounding (rtol 1e-4 / atol 1e-5 on O(1) tensors); the 16-bit MFMA modes
+are checked against the same oracle with the tolerance their operand rounding implies
+(bf16: 2^-9 relative per operand, fp16: 2^-12), stated per test.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from craft_amd import hip, ops
+from craft_amd.hip import ACT_NONE, ACT_RELU, ACT_TANH, PREC_BF16, PREC_F16, PREC_F32
+from oracle import craft_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+PRECS = [PREC_F32, PREC_BF16, PREC_F16]
+# (rtol, atol multiplier) for a K-long dot product of O(1) operands
+TOL = {PREC_F32: (1e-4, 1e-5), PREC_BF16: (2e-2, 2e-2), PREC_F16: (3e-3, 3e-3)}
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(got, ref, rtol, atol, what):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite values in HIP output"
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        i = int(torch.argmax(err - tol))
+        idx = np.unravel_index(i, got.shape)
+        raise AssertionError(f"{what}: {int(bad.sum())}/{got.numel()} elements out of tolerance; worst at {idx}: "
+                             f"got {got.flatten()[i]:.6f} ref {ref.flatten()[i]:.6f} |d|={err.flatten()[i]:.3e} "
+                             f"(rtol={rtol}, atol={atol}; max|ref|={ref.abs().max():.3f})")
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("rows,cin,cout", [(2 * 301, 324, 256), (640, 256, 126), (130, 128, 64), (257, 64, 192), (96, 32, 576)])
+def test_linear(device, prec, rows, cin, cout):
+    """craft_linear: asymmetric operands so a transposed / permuted output can not pass."""
+    x = gen(2, rows // 2, cin, seed=1)
+    w = gen(cout, cin, seed=2) / math.sqrt(cin)
+    w[3, 5] += 2.0                                  # break any accidental symmetry
+    b = gen(cout, seed=3)
+    ref = F.linear(x, w, b)
+    y = ops.linear(x.to(device), w.to(device), b.to(device), prec)
+    rt, at = TOL[prec]
+    close(y, ref, rt, at, f"linear prec={prec}")
+    y2 = ops.linear(x.to(device), w.to(device), None, prec)
+    close(y2, F.linear(x, w), rt, at, f"linear(no bias) prec={prec}")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_linear_identity_weight_detects_transpose(device, prec):
+    x = torch.arange(2 * 70 * 64, dtype=torch.float32).reshape(2, 70, 64) / 64.0 if prec == PREC_F32 else gen(2, 70, 64, seed=4)
+    w = torch.eye(64)
+    y = ops.linear(x.to(device), w.to(device), None, prec)
+    rt, at = TOL[prec]
+    close(y, x, rt, at, "identity projection")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_linear_t_and_column_views(device, prec):
+    B, N, C, Cout = 2, 203, 128, 512
+    buf = torch.zeros(B, N, 512)
+    buf[..., 256:384] = gen(B, N, C, seed=5)
+    w = gen(Cout, C, seed=6) / math.sqrt(C)
+    ldt = ops.round_up(N, 32)
+    yT = ops.linear_t(buf.to(device)[..., 256:384], w.to(device), ldt, prec)
+    ref = F.linear(buf[..., 256:384], w).transpose(1, 2)
+    rt, at = TOL[prec]
+    close(yT[..., :N], ref, rt, at, "linear_t")
+    assert float(yT[..., N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("nchw", [True, False])
+def test_tokens(device, nchw):
+    B, C, H, W = 2, 256, 9, 13
+    x = gen(B, 300, H, W, seed=7) * 3 + 0.5
+    if nchw:
+        t = ops.tokens_from_nchw(x.to(device), c_off=20, C=C, act=ACT_RELU, ln=True)
+        ref = O.layernorm_lastdim(torch.relu(x[:, 20:20 + C]).reshape(B, C, H * W).transpose(1, 2))
+    else:
+        xt = x[:, :C].reshape(B, C, H * W).transpose(1, 2).contiguous()
+        t = ops.tokens_norm(xt.to(device))
+        ref = O.layernorm_lastdim(xt)
+    close(t, ref, 1e-4, 1e-5, "tokens LN")
+    t2 = ops.tokens_from_nchw(x.to(device), c_off=0, C=128, act=ACT_TANH, ln=False)
+    close(t2, torch.tanh(x[:, :128]).reshape(B, 128, H * W).transpose(1, 2), 1e-5, 1e-6, "tokens tanh")
+    back = ops.tokens_to_nchw(t2, H, W)
+    close(back, torch.tanh(x[:, :128]), 1e-5, 1e-6, "tokens_to_nchw")
+
+
+def _qk(B, H8, W8, C, seed, gain=2.5):
+    N = H8 * W8
+    x1 = O.layernorm_lastdim(gen(B, N, C, seed=seed))
+    x2 = O.layernorm_lastdim(gen(B, N, C, seed=seed + 1) + 0.5 * x1)
+    Wq = gen(C, C, seed=seed + 2) * math.sqrt(gain / C)
+    Wk = gen(C, C, seed=seed + 3) * math.sqrt(gain / C)
+    bq = gen(C, seed=seed + 4) * 0.3
+    return x1, x2, Wq, Wk, bq
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("gain", [2.5, 60.0])
+def test_corr_build_pyramid_lookup(device, prec, gain):
+    """craft_score_max + craft_corr_build + craft_corr_finish + craft_corr_lookup vs the oracle
+    (inter-frame attention, tied projection with bias; gain=60 triggers the global clamp)."""
+    B, H8, W8, C, M = 2, 18, 21, 256, 4       # odd sizes: ragged tiles, floor pooling
+    N = H8 * W8
+    x1, x2, Wq, _, bq = _qk(B, H8, W8, C, seed=10, gain=gain)
+    tab = gen(15, 15, seed=20) * 0.5
+    w_aggr = 0.8
+    sd = {"corr_fn.setrans.query.weight": Wq, "corr_fn.setrans.query.bias": bq,
+          "corr_fn.vispos_encoder.pos_coder.biases": tab,
+          "corr_fn.setrans.attn_softaggr.feat2score.weight": torch.tensor([[w_aggr]])}
+    S = O.mm_scores(x1, x2, Wq, bq, Wq, bq, M)
+    if gain > 10:
+        assert float(S.max()) > 100, "test input does not trigger the clamp"
+    c_ref = O.softaggr_scores(O.clamp_rule(S) + 0.5 * O.pos_bias_matrix(tab, H8, W8), sd["corr_fn.setrans.attn_softaggr.feat2score.weight"])
+    mu_ref, rstd_ref = O.global_stats(c_ref)
+    pyr_ref = O.build_pyramid(c_ref, H8, W8, 4)
+
+    q = ops.linear(x1.to(device), Wq.to(device), bq.to(device), PREC_F32)
+    k = ops.linear(x2.to(device), Wq.to(device), bq.to(device), PREC_F32)
+    scale = 1.0 / math.sqrt(C // M)
+    mx = ops.score_max(q, k, H8, W8, M, scale, prec)
+    rt, at = TOL[prec]
+    got_max = ops.decode_ord(mx)
+    assert abs(got_max - float(S.max())) <= at * 20 + rt * abs(float(S.max())), f"score max {got_max} vs {float(S.max())}"
+    pyr = ops.CorrPyramid(B, H8, W8, 4, device)
+    ops.corr_build(q, k, H8, W8, M, scale, tab.to(device), 0.5, w_aggr, mx, pyr, True, prec)
+    sc = float(c_ref.abs().max())
+    close(pyr.lv[0].reshape(B, N, N), c_ref, rt, at * max(1.0, sc), f"corr level 0 prec={prec}")
+    for l in range(1, 4):
+        close(pyr.lv[l], pyr_ref[l][:, 0], rt, at * max(1.0, sc), f"corr level {l}")
+    close(pyr.mu_rstd[:, 0], mu_ref, rt, at * max(1.0, sc), "global mean")
+    close(pyr.mu_rstd[:, 1], rstd_ref, max(rt, 1e-4), 1e-6, "global rstd")
+
+    # lookups: identity grid, smooth offsets, far out-of-bounds
+    c0 = O.coords_grid(B, H8, W8)
+    wild = c0 + gen(B, 2, H8, W8, seed=30) * torch.tensor([W8 / 2.0, H8 / 2.0]).view(1, 2, 1, 1)
+    frac = c0 + gen(B, 2, H8, W8, seed=31) * 2.0
+    for name, cc in (("identity", c0), ("frac", frac), ("wild", wild)):
+        ref = O.corr_lookup(pyr_ref, cc, 4, mu_ref, rstd_ref)
+        got = ops.corr_lookup(pyr, ops.tokens_from_nchw(cc.to(device)), 4)
+        if prec == PREC_F32:
+            close(ops.tokens_to_nchw(got, H8, W8), ref, 2e-4, 2e-4, f"lookup {name}")
+        else:
+            close(ops.tokens_to_nchw(got, H8, W8), ref, rt, at * 10, f"lookup {name} prec={prec}")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_plain_corr(device, prec):
+    """CorrBlock.corr variant: one mode over all 256 channels, no bias, no norm."""
+    B, H8, W8, C = 1, 16, 20, 256
+    f1, f2 = gen(B, C, H8, W8, seed=40), gen(B, C, H8, W8, seed=41)
+    ref = O.plain_corr_raw(f1, f2)
+    pyr = ops.CorrPyramid(B, H8, W8, 4, device)
+    ops.corr_build(ops.tokens_from_nchw(f1.to(device)), ops.tokens_from_nchw(f2.to(device)), H8, W8, 1, 1.0 / 16.0, None, 0.0,
+                   1.0, None, pyr, False, prec)
+    rt, at = TOL[prec]
+    close(pyr.lv[0].reshape(B, H8 * W8, H8 * W8), ref, rt, at * 4, "plain corr")
+    assert pyr.mu_rstd.cpu().tolist() == [[0.0, 1.0]]
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("C,M,mask_radius,gain", [(128, 4, -1, 2.5), (256, 4, 5, 2.5), (128, 4, -1, 80.0), (128, 1, -1, 2.5)])
+def test_attn_probs(device, prec, C, M, mask_radius, gain):
+    B, H8, W8 = 2, 13, 19
+    N = H8 * W8
+    x, _, Wq, Wk, _ = _qk(B, H8, W8, C, seed=50, gain=gain)
+    tab = gen(15, 15, seed=51) * 0.5
+    ref = O.self_attn_probs(x, Wq, Wk, tab, 1.0, M, H8, W8, mask_radius)
+    q = ops.linear(x.to(device), Wq.to(device), None, PREC_F32)
+    k = ops.linear(x.to(device), Wk.to(device), None, PREC_F32)
+    scale = 1.0 / math.sqrt(C // M)
+    mx = ops.score_max(q, k, H8, W8, M, scale, prec)
+    P = ops.attn_probs(q, k, H8, W8, M, scale, tab.to(device), 1.0, mask_radius, mx, prec)
+    assert P.shape == (B, M, N, ops.round_up(N, 32))
+    assert float(P[..., N:].float().abs().max()) == 0.0, "padding columns must be zero"
+    got = P[..., :N].float()
+    rsum = got.sum(-1).cpu()
+    assert (rsum - 1).abs().max() < (1e-5 if prec == PREC_F32 else 1e-2), "rows must sum to 1"
+    if prec == PREC_F32:
+        close(got, ref, 2e-4, 1e-6, "attention probs")
+    else:
+        # logits carry the operand rounding (|S| up to ~|x||y| 2^-8), probabilities are <= 1
+        close(got, ref, 0.0, 0.08 if prec == PREC_BF16 else 0.02, f"attention probs prec={prec}")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("C", [128, 256])
+def test_expanded_feat_trans(device, prec, C):
+    """craft_linear_t + craft_attn_apply + craft_mode_pool_ln vs ExpandedFeatTrans."""
+    B, H8, W8, M = 2, 11, 17, 4
+    N = H8 * W8
+    x = gen(B, N, C, seed=60)
+    Pf = torch.softmax(gen(B, M, N, N, seed=61) * 2.0, dim=-1)
+    Wv = gen(M * C, C, seed=62) / math.sqrt(C)
+    w_agg = gen(1, C, seed=63) * 0.3
+    skip = torch.tensor([0.7])
+    ldp = ops.round_up(N, 32)
+    P = torch.zeros(B, M, N, ldp, dtype=hip.PROB_DTYPE[prec])
+    P[..., :N] = Pf.to(P.dtype)
+    ref = O.expanded_feat_trans(x, P[..., :N].float(), Wv, w_agg, skip)
+    xd = x.to(device)
+    vT = ops.linear_t(xd, Wv.to(device), ldp, prec)
+    Od = ops.attn_apply(P.to(device), vT, C, prec)
+    y = ops.mode_pool_ln(Od, xd, w_agg.to(device), skip.to(device))
+    rt, at = TOL[prec]
+    Oref = torch.matmul(P[..., :N].float(), F.linear(x, Wv).reshape(B, N, M, C).permute(0, 2, 1, 3))
+    close(Od, Oref, rt, at, "P.V")
+    close(y, ref, rt * 5, at * 5, "ExpandedFeatTrans")
+
+
+def _conv_sd(seed=70):
+    from craft_amd import CRAFT, default_args
+    from craft_amd.synth import synth_state_dict
+    m = CRAFT(default_args())
+    sd = synth_state_dict(m.state_dict(), seed=seed)
+    m.load_state_dict(sd)
+    return m, sd
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_update_block_pieces(device, prec):
+    """craft_motion_encoder / craft_sepconv_gru / craft_flow_head / craft_mask_head vs update.py."""
+    m, sd = _conv_sd()
+    m = m.to(device).eval()
+    ub = m.update_block
+    B, H8, W8 = 2, 10, 14
+    N = H8 * W8
+    corr = gen(B, 324, H8, W8, seed=71)
+    flow = gen(B, 2, H8, W8, seed=72) * 3
+    net = torch.tanh(gen(B, 128, H8, W8, seed=73))
+    inp = torch.relu(gen(B, 128, H8, W8, seed=74))
+    mfg = gen(B, 128, H8, W8, seed=75)
+    rt, at = TOL[prec]
+    ws = ub.workspace(B, N, device)
+
+    mf_ref = O.motion_encoder(flow, corr, sd)
+    hx = torch.zeros(B, N, 512, device=device)
+    corr_t = ops.tokens_from_nchw_wide(corr.to(device))
+    flow_t = ops.tokens_from_nchw(flow.to(device))
+    ub.encoder.forward_tokens(flow_t, corr_t, (H8, W8), hx[..., 256:384], ws, prec)
+    close(ops.tokens_to_nchw(hx[..., 256:384], H8, W8), mf_ref, rt * 3, at * 10, f"motion encoder prec={prec}")
+    assert float(hx[..., :256].abs().max()) == 0 and float(hx[..., 384:].abs().max()) == 0, "encoder wrote outside its columns"
+
+    x_ref = torch.cat([inp, mf_ref, mfg], dim=1)
+    h_ref = O.sepconv_gru(net, x_ref, sd)
+    ops.tokens_from_nchw(net.to(device), out=hx[..., 0:128])
+    ops.tokens_from_nchw(inp.to(device), out=hx[..., 128:256])
+    ops.tokens_from_nchw(mf_ref.to(device), out=hx[..., 256:384])
+    ops.tokens_from_nchw(mfg.to(device), out=hx[..., 384:512])
+    ub.gru.forward_tokens(hx, (H8, W8), ws, prec)
+    close(ops.tokens_to_nchw(hx[..., 0:128], H8, W8), h_ref, rt * 3, at * 10, f"SepConvGRU prec={prec}")
+    close(ops.tokens_to_nchw(hx[..., 128:256], H8, W8), inp, 0, 0, "GRU must not touch x")
+
+    ops.tokens_from_nchw(h_ref.to(device), out=hx[..., 0:128])
+    c0, c1, fl = ops.coords_init(flow.to(device), B, H8, W8, device)
+    delta = torch.empty(B, N, 2, device=device)
+    ub.flow_head_tokens(hx, (H8, W8), c1, c0, fl, delta, ws, prec)
+    d_ref = O.flow_head(h_ref, sd)
+    close(ops.tokens_to_nchw(delta, H8, W8), d_ref, rt * 3, at * 10, f"flow head prec={prec}")
+    close(ops.tokens_to_nchw(fl, H8, W8), flow + d_ref, rt * 3, at * 10, "flow = coords1 - coords0")
+    close(ops.tokens_to_nchw(c1, H8, W8), O.coords_grid(B, H8, W8) + flow + d_ref, rt * 3, at * 10, "coords1 += delta")
+
+    mask = ub.mask_tokens(hx, (H8, W8), ws, prec)
+    mk_ref = O.mask_head(h_ref, sd)
+    close(ops.tokens_to_nchw(mask, H8, W8), mk_ref, rt * 3, at * 10, f"mask head prec={prec}")
+
+    up = ops.convex_upsample(ops.tokens_from_nchw_wide(mk_ref.to(device)).contiguous(), ops.tokens_from_nchw((flow + d_ref).to(device)), H8, W8)
+    close(up, O.convex_upsample(flow + d_ref, mk_ref), 1e-4, 1e-4, "convex upsample")
+
+
+def test_module_level_api_matches_reference_shapes(device):
+    """The NCHW module interfaces of the reference (SelfAttVisPosTrans / TransCorrBlock / GMAUpdateBlock)."""
+    m, sd = _conv_sd(seed=80)
+    m = m.to(device).eval()
+    cfg = O.OracleConfig()
+    B, H8, W8 = 1, 16, 24
+    N = H8 * W8
+    fmap1, fmap2 = gen(B, 256, H8, W8, seed=81), gen(B, 256, H8, W8, seed=82)
+    inp = torch.relu(gen(B, 128, H8, W8, seed=83))
+    net = torch.tanh(gen(B, 128, H8, W8, seed=84))
+    f2 = m.f2_trans(fmap2.to(device))
+    f2_ref = O.f2_transform(fmap2, sd, cfg)
+    close(f2, f2_ref, 2e-4, 5e-5, "f2_trans(fmap2)")
+    att = m.att(inp.to(device))
+    att_ref = O.intra_attention(inp, sd, cfg)
+    close(att, att_ref, 2e-4, 1e-6, "att(inp)")
+    m.corr_fn.update(fmap1.to(device), f2, None, None, None)
+    c = O.inter_corr_raw(fmap1, f2_ref, sd, cfg)
+    mu, rstd = O.global_stats(c)
+    pyr = O.build_pyramid(c, H8, W8)
+    coords = O.coords_grid(B, H8, W8) + gen(B, 2, H8, W8, seed=85) * 1.5
+    look = m.corr_fn(coords.to(device))
+    look_ref = O.corr_lookup(pyr, coords, 4, mu, rstd)
+    close(look, look_ref, 5e-4, 5e-4, "corr_fn(coords)")
+    flow = coords - O.coords_grid(B, H8, W8)
+    n2, mk, df = m.update_block(net.to(device), inp.to(device), look, flow.to(device), att)
+    n2r, mkr, dfr = O.update_block(net, inp, look_ref, flow, att_ref, sd, cfg)
+    close(n2, n2r, 1e-3, 1e-3, "update_block net")
+    close(df, dfr, 1e-3, 1e-3, "update_block delta_flow")
+    close(mk, mkr, 1e-3, 1e-3, "update_block mask")
