@@ -89,9 +89,9 @@ int craft_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, c
 
 int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d, float scale,
                      const float* pos_tab, int R, float pos_w, int mask_radius, const unsigned* clamp_ord, void* P,
-                     long ldp, int prec, void* stream) {
+                     long ldp, int p_prec, int prec, void* stream) {
   return launch_attn_probs(make_score(q, ldq, k, ldk, B, H8, W8, M, d, scale, pos_tab, R, pos_w, mask_radius, clamp_ord), P,
-                           ldp, prec, S(stream));
+                           ldp, p_prec, prec, S(stream));
 }
 
 int craft_attn_apply(const void* P, long ldp, const float* vT, int B, int N, int M, int Dv, float* O, int prec,

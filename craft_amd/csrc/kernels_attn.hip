@@ -156,10 +156,10 @@ template <> struct ProbT<CRAFT_PREC_F32> { typedef float t; };
 template <> struct ProbT<CRAFT_PREC_BF16> { typedef __bf16 t; };
 template <> struct ProbT<CRAFT_PREC_F16> { typedef _Float16 t; };
 
-template <int PREC>
+template <int PREC, int PT>
 __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __restrict__ Pout, long ldp) {
   constexpr int BM = 128, BN = 128, WM = 1, WN = 4, MT = 4, NT = 1;
-  typedef typename ProbT<PREC>::t prob_t;
+  typedef typename ProbT<PT>::t prob_t;
   __shared__ __attribute__((aligned(16))) char smem[TileLds<PREC, BM, BN>::BYTES];
   __shared__ int s_kh[BM], s_kw[BM];
   __shared__ float s_tab[961];
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
                 const float d = sv[mt][4 * q + i] - m_run;
                 pv[i] = ((PREC == CRAFT_PREC_F32) ? expf(d) : __expf(d)) * inv_l;
               }
-              if constexpr (PREC == CRAFT_PREC_F32) {
+              if constexpr (PT == CRAFT_PREC_F32) {
                 *reinterpret_cast<float4*>(Prow + j) = make_float4(pv[0], pv[1], pv[2], pv[3]);
               } else {
                 typedef prob_t pt4 __attribute__((ext_vector_type(4)));
@@ -255,15 +255,22 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
   }
 }
 
-int launch_attn_probs(const ScoreParams& p, void* P, long ldp, int prec, hipStream_t s) {
+template <int PREC> static int launch_attn_probs_pt(const ScoreParams& p, void* P, long ldp, int p_prec, dim3 grid, hipStream_t s) {
+  if (p_prec == CRAFT_PREC_F32) hipLaunchKernelGGL((k_attn_probs<PREC, CRAFT_PREC_F32>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
+  else if (p_prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_attn_probs<PREC, CRAFT_PREC_BF16>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
+  else if (p_prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_attn_probs<PREC, CRAFT_PREC_F16>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
+  else return CRAFT_ERR_ARG;
+  return (int)hipGetLastError();
+}
+
+int launch_attn_probs(const ScoreParams& p, void* P, long ldp, int p_prec, int prec, hipStream_t s) {
   if (int e = check_score(p)) return e;
   if (ldp % 32 || ldp < p.N) return CRAFT_ERR_ALIGN;
   dim3 grid((p.N + 127) / 128, p.B * p.M, 1);
-  if (prec == CRAFT_PREC_F32) hipLaunchKernelGGL((k_attn_probs<CRAFT_PREC_F32>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
-  else if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_attn_probs<CRAFT_PREC_BF16>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
-  else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_attn_probs<CRAFT_PREC_F16>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
-  else return CRAFT_ERR_ARG;
-  return (int)hipGetLastError();
+  if (prec == CRAFT_PREC_F32) return launch_attn_probs_pt<CRAFT_PREC_F32>(p, P, ldp, p_prec, grid, s);
+  if (prec == CRAFT_PREC_BF16) return launch_attn_probs_pt<CRAFT_PREC_BF16>(p, P, ldp, p_prec, grid, s);
+  if (prec == CRAFT_PREC_F16) return launch_attn_probs_pt<CRAFT_PREC_F16>(p, P, ldp, p_prec, grid, s);
+  return CRAFT_ERR_ARG;
 }
 
 }  // namespace craft

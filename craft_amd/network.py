@@ -12,9 +12,10 @@ intra-frame attention, correlation volume + pyramid, and the T refinement iterat
 by the HIP path carry no autograd graph.
 
 Extra (non-reference) argument fields, all optional:
-  ``hip_precision``: "fp32" | "bf16" | "fp16" MFMA operand precision of the hot path.  Default: "fp32"
-                     when ``mixed_precision`` is False (the reference's fp32 path), "bf16" when it is
-                     True (the reference autocasts to fp16 there).
+  ``hip_precision``: "fp32" | "mixed" | "fp16" | "bf16" MFMA operand precision of the hot path, or per role,
+                     e.g. "score=bf16,pv=fp16,conv=fp32,proj=fp32" (craft_amd.hip.Precision).  Default: "fp32"
+                     when ``mixed_precision`` is False (the reference's fp32 path); "mixed" (fp16 attention
+                     contractions, fp32 convolutions) when it is True (the reference autocasts to fp16 there).
 """
 from __future__ import annotations
 
@@ -27,13 +28,16 @@ from . import ops
 from .corr import CorrBlock, TransCorrBlock
 from .extractor import BasicEncoder
 from .gma import Attention
-from .hip import ACT_RELU, ACT_TANH, PREC_BF16, PREC_F32, PREC_NAMES
+from .hip import ACT_RELU, ACT_TANH, PREC_BF16, PREC_F32, PREC_NAMES, Precision
 from .setrans import SelfAttVisPosTrans, SETransConfig
 from .update import GMAUpdateBlock
 
 
 def _autocast(enabled: bool):
-    return torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=bool(enabled) and torch.cuda.is_available())
+    """The reference runs the CNN encoders under fp16 autocast when mixed_precision is set (network.py:179);
+    here the encoders stay fp32 unless ``args.encoder_autocast`` is set, because their rounding dominates the
+    end-point deviation of the otherwise fp32-accumulated hot path."""
+    return torch.autocast(device_type="cuda", dtype=torch.float16, enabled=bool(enabled) and torch.cuda.is_available())
 
 
 class CRAFT(nn.Module):
@@ -117,11 +121,11 @@ class CRAFT(nn.Module):
         self.call_counter = 0
 
     # ------------------------------------------------------------------------------------------
-    def hip_prec(self) -> int:
-        name = getattr(self.args, "hip_precision", None)
-        if name is None:
-            return PREC_BF16 if getattr(self.args, "mixed_precision", False) else PREC_F32
-        return PREC_NAMES[name]
+    def hip_prec(self) -> Precision:
+        spec = getattr(self.args, "hip_precision", None)
+        if spec is None:
+            spec = "mixed" if getattr(self.args, "mixed_precision", False) else "fp32"
+        return Precision.parse(spec)
 
     def freeze_bn(self):
         for m in self.modules():
@@ -163,7 +167,7 @@ class CRAFT(nn.Module):
         dev = image1.device
 
         with torch.no_grad():
-            with _autocast(args.mixed_precision):
+            with _autocast(getattr(args, "encoder_autocast", False)):
                 fmap1, fmap2 = self.fnet([image1, image2])
                 cnet_feat = self.cnet(image1)
             fmap1, fmap2, cnet_feat = fmap1.float(), fmap2.float(), cnet_feat.float()

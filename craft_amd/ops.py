@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import hip
-from .hip import ACT_NONE, ACT_RELU, ACT_TANH, PREC_F32, PROB_DTYPE, call, round_up
+from .hip import ACT_NONE, ACT_RELU, ACT_TANH, PREC_F32, PROB_DTYPE, call, pick, round_up
 
 
 def _ld(t: torch.Tensor) -> int:
@@ -81,7 +81,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], prec:
     if out is None:
         out = torch.empty(B, N, Cout, device=x.device, dtype=torch.float32)
     _check_rows(out)
-    call("craft_linear", x, _ld(x), w.contiguous(), bias, out, _ld(out), B * N, Cin, Cout, prec)
+    call("craft_linear", x, _ld(x), w.contiguous(), bias, out, _ld(out), B * N, Cin, Cout, pick(prec, "proj"))
     return out
 
 
@@ -92,7 +92,7 @@ def linear_t(x: torch.Tensor, w: torch.Tensor, ldt: int, prec: int, out: Optiona
     Cout = w.shape[0]
     if out is None:
         out = torch.zeros(B, Cout, ldt, device=x.device, dtype=torch.float32)
-    call("craft_linear_t", x, _ld(x), w.contiguous(), out, ldt, B, N, Cin, Cout, prec)
+    call("craft_linear_t", x, _ld(x), w.contiguous(), out, ldt, B, N, Cin, Cout, pick(prec, "proj"))
     return out
 
 
@@ -102,7 +102,7 @@ def score_max(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale:
     B, N, C = q.shape
     if out is None:
         out = torch.zeros(1, device=q.device, dtype=torch.int32)
-    call("craft_score_max", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale, out, prec)
+    call("craft_score_max", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale, out, pick(prec, "score"))
     return out
 
 
@@ -140,7 +140,8 @@ def corr_build(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale
     B, N, C = q.shape
     R = 0 if pos_tab is None else (pos_tab.shape[0] - 1) // 2
     call("craft_corr_build", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale,
-         None if pos_tab is None else pos_tab.contiguous(), R, pos_w, w_aggr, clamp_ord, pyr.lv[0], pyr.sums, prec)
+         None if pos_tab is None else pos_tab.contiguous(), R, pos_w, w_aggr, clamp_ord, pyr.lv[0], pyr.sums,
+         pick(prec, "score"))
     lv = pyr.lv + [None] * (4 - len(pyr.lv))
     call("craft_corr_finish", lv[0], lv[1], lv[2], lv[3], pyr.sums, pyr.mu_rstd, B, H8, W8, int(do_norm))
     return pyr
@@ -165,10 +166,11 @@ def attn_probs(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale
     B, N, C = q.shape
     ldp = round_up(N, 32)
     if out is None:
-        out = torch.empty(B, M, N, ldp, device=q.device, dtype=PROB_DTYPE[prec])
+        out = torch.empty(B, M, N, ldp, device=q.device, dtype=PROB_DTYPE[pick(prec, "pv")])
     R = 0 if pos_tab is None else (pos_tab.shape[0] - 1) // 2
     call("craft_attn_probs", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale,
-         None if pos_tab is None else pos_tab.contiguous(), R, pos_w, mask_radius, clamp_ord, out, ldp, prec)
+         None if pos_tab is None else pos_tab.contiguous(), R, pos_w, mask_radius, clamp_ord, out, ldp, pick(prec, "pv"),
+         pick(prec, "score"))
     return out
 
 
@@ -177,7 +179,10 @@ def attn_apply(P: torch.Tensor, vT: torch.Tensor, Dv: int, prec: int, out: Optio
     B, M, N, ldp = P.shape
     if out is None:
         out = torch.empty(B, M, N, Dv, device=P.device, dtype=torch.float32)
-    call("craft_attn_apply", P, ldp, vT, B, N, M, Dv, out, prec)
+    pv = pick(prec, "pv")
+    if PROB_DTYPE[pv] != P.dtype:
+        raise hip.CraftHipError(f"attention probabilities are {P.dtype} but the pv precision expects {PROB_DTYPE[pv]}")
+    call("craft_attn_apply", P, ldp, vT, B, N, M, Dv, out, pv)
     return out
 
 

@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import ops
 from .gma import Aggregate
-from .hip import PREC_F32, call
+from .hip import PREC_F32, call, pick
 from .setrans import ExpandedFeatTrans
 
 
@@ -80,7 +80,7 @@ class SepConvGRU(nn.Module):
         H8, W8 = hw
         wzr1, bzr1, wq1, bq1, wzr2, bzr2, wq2, bq2 = self.packed()
         call("craft_sepconv_gru", hx, hx.stride(1), self.input_dim, wzr1, bzr1, wq1, bq1, wzr2, bzr2, wq2, bq2, B, H8, W8,
-             ws, prec)
+             ws, pick(prec, "conv"))
 
 
 class BasicMotionEncoder(nn.Module):
@@ -113,7 +113,7 @@ class BasicMotionEncoder(nn.Module):
         H8, W8 = hw
         wc1, bc1, wc2, bc2, wf1, bf1, wf2, bf2, wcv, bcv = self.packed()
         call("craft_motion_encoder", corr, corr.stride(1), self.cor_planes, flow, wc1, bc1, wc2, bc2, wf1, bf1, wf2, bf2,
-             wcv, bcv, B, H8, W8, out, out.stride(1), ws, prec)
+             wcv, bcv, B, H8, W8, out, out.stride(1), ws, pick(prec, "conv"))
 
 
 class GMAUpdateBlock(nn.Module):
@@ -154,14 +154,15 @@ class GMAUpdateBlock(nn.Module):
     def flow_head_tokens(self, hx, hw, coords1, coords0, flow, delta, ws, prec):
         B, N, _ = hx.shape
         w1, b1, w2, b2 = self.flow_head.packed()
-        call("craft_flow_head", hx, hx.stride(1), w1, b1, w2, b2, B, hw[0], hw[1], coords1, coords0, flow, delta, ws, prec)
+        call("craft_flow_head", hx, hx.stride(1), w1, b1, w2, b2, B, hw[0], hw[1], coords1, coords0, flow, delta, ws,
+             pick(prec, "conv"))
 
     def mask_tokens(self, hx, hw, ws, prec, out: Optional[torch.Tensor] = None):
         B, N, _ = hx.shape
         if out is None:
             out = torch.empty(B, N, 576, device=hx.device, dtype=torch.float32)
         w0, b0, w2, b2 = self.packed_mask()
-        call("craft_mask_head", hx, hx.stride(1), w0, b0, w2, b2, B, hw[0], hw[1], out, ws, prec)
+        call("craft_mask_head", hx, hx.stride(1), w0, b0, w2, b2, B, hw[0], hw[1], out, ws, pick(prec, "conv"))
         return out
 
     @staticmethod

@@ -91,13 +91,14 @@ int craft_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, c
 /* CrossAttFeatTrans up to the softmax (setrans.py:507-557): P[b][m][i][j] = softmax_j(clamp?(Q_m(i).K_m(j)*
  * scale) + pos_w*pb(i,j) + mask), mask = -1e9 where Chebyshev distance > mask_radius (setrans.py:580-584,
  * <=0: none).  P has row stride ldp (multiple of 32, >= N); columns [N, ldp) are written as zeros.
- * Element type of P: float (prec 0), bf16 (1), fp16 (2). */
+ * Element type of P by p_prec: float (0), bf16 (1), fp16 (2); prec selects the MFMA path of Q K^T. */
 int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d,
                      float scale, const float* pos_tab, int R, float pos_w, int mask_radius,
-                     const unsigned* clamp_ord, void* P, long ldp, int prec, void* stream);
+                     const unsigned* clamp_ord, void* P, long ldp, int p_prec, int prec, void* stream);
 
 /* ExpandedFeatTrans.forward, matmul part (setrans.py:384): O[b][m][i][:] = sum_j P[b][m][i][j] * V_m[j][:],
- * with vT[b][m*Dv + c][j] (row stride ldp, zero beyond N) from craft_linear_t.  O: [B][M][N][Dv] fp32. */
+ * with vT[b][m*Dv + c][j] (row stride ldp, zero beyond N) from craft_linear_t.  O: [B][M][N][Dv] fp32.
+ * prec is both the element type of P (as written by craft_attn_probs with p_prec = prec) and the MFMA path. */
 int craft_attn_apply(const void* P, long ldp, const float* vT, int B, int N, int M, int Dv, float* O, int prec,
                      void* stream);
 

@@ -64,9 +64,14 @@ def test_test_modes_and_skipped_mask_head(device):
     assert isinstance(ups0, list) and len(ups0) == 4
 
 
-@pytest.mark.parametrize("precision,mean_tol,max_tol", [("bf16", 0.01, 0.25), ("fp16", 0.004, 0.1)])
+@pytest.mark.parametrize("precision,mean_tol,max_tol", [("mixed", 0.004, 0.02), ("fp16", 0.03, 0.1), ("bf16", 0.3, 0.8)])
 def test_forward_mixed_precision_modes(device, precision, mean_tol, max_tol):
-    """16-bit MFMA operands, fp32 accumulate: mean end-point difference to the fp32 reference <= 0.01 px."""
+    """16-bit MFMA operands, fp32 accumulate, against the reference's fp32 output (4 iterations).
+    "mixed" (fp16 attention contractions + fp32 convolutions) is the shipped mixed-precision policy and must
+    hold BASELINE.md's bound for 16-bit attention, mean EPE delta <= 0.01 px (measured 0.0014; 0.0042 px at
+    448x1024 / 12 iterations).  All-fp16 (what the reference's autocast does) and all-bf16 are selectable but
+    do NOT meet that bound on the synthetic weights (measured 0.012 / 0.11 px): their bounds here only guard
+    against regressions."""
     g = Golden("canon_128x256_T4")
     model = build(g, device, precision)
     im1, im2 = g.images()
@@ -106,7 +111,7 @@ def _full_model(device, precision):
     return model.to(device).eval()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "mixed"])
 def test_full_size_448x1024_properties(device, precision):
     model = _full_model(device, precision)
     im1, im2, _ = synth_pair(2, 448, 1024, seed=3)
@@ -120,7 +125,11 @@ def test_full_size_448x1024_properties(device, precision):
     # determinism and batch independence (eval-mode forward is exactly batch independent in the reference;
     # ours up to the double-precision atomics of the global-LayerNorm statistics)
     assert (up1 - up1b).abs().max().item() < 1e-4
-    assert (up2[:1] - up1).abs().max().item() < (2e-3 if precision == "fp32" else 5e-2)
+    assert (up2[:1] - up1).abs().max().item() < 2e-3
+    if precision == "mixed":
+        ref = _full_model(device, "fp32")(im1[:1], im2[:1], iters=12, test_mode=1)[1]
+        epe = (up1 - ref).pow(2).sum(1).sqrt()
+        assert epe.mean().item() < 0.01, f"mixed-precision mean EPE delta {epe.mean().item():.4f} px at 448x1024 / 12 iters"
     # the flow must be non-trivial (the synthetic pair moves by up to 12 px)
     assert up2.abs().max().item() > 0.5
 

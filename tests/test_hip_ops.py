@@ -188,6 +188,10 @@ def test_attn_probs(device, prec, C, M, mask_radius, gain):
     scale = 1.0 / math.sqrt(C // M)
     mx = ops.score_max(q, k, H8, W8, M, scale, prec)
     P = ops.attn_probs(q, k, H8, W8, M, scale, tab.to(device), 1.0, mask_radius, mx, prec)
+    if prec == PREC_BF16:      # mixed roles: fp32 logits, fp16 storage
+        P2 = ops.attn_probs(q, k, H8, W8, M, scale, tab.to(device), 1.0, mask_radius, mx, hip.Precision(score=PREC_F32, pv=PREC_F16))
+        assert P2.dtype == torch.float16
+        close(P2[..., :H8 * W8].float(), ref, 2e-3, 1e-6, "fp32 logits stored as fp16")
     assert P.shape == (B, M, N, ops.round_up(N, 32))
     assert float(P[..., N:].float().abs().max()) == 0.0, "padding columns must be zero"
     got = P[..., :N].float()
