@@ -171,7 +171,8 @@ def main():
             "metric": "image-pairs/sec at 448x1024, 12 iters",
             "value": round(pairs / dt, 3), "unit": "image-pairs/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "mixed": "f16 MFMA attention (f32 accumulate) + f32 MFMA convolutions"}.get(a.precision, a.precision),
+            "dtype": {"fp32": "f32", "mixed": "f16x3 (fp32 operands split into 2 fp16 planes, 3 fp16 MFMAs per product, f32 "
+                      "accumulate: fp32-class) for projections / Q.K^T / convolutions; f16 P.V (f32 accumulate)"}.get(a.precision, a.precision),
             "data": "synthetic",
             "config": {"workload": f"configs[1]: {a.height}x{a.width} synthetic pairs, batch {a.batch}/GPU, {a.iters} iters, "
                                    "craft-sintel architecture with synthetic weights (checkpoints absent), test_mode=1",

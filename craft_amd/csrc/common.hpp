@@ -13,6 +13,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define CRAFT_PREC_F32 0
 #define CRAFT_PREC_BF16 1
 #define CRAFT_PREC_F16 2
+#define CRAFT_PREC_F16X3 3   // split-fp16 emulation of fp32 products (gemm_engine.hpp)
 
 #define CRAFT_ACT_NONE 0
 #define CRAFT_ACT_TANH 1

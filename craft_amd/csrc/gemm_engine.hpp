@@ -31,12 +31,18 @@ template <int PREC> struct PrecT;
 template <> struct PrecT<CRAFT_PREC_F32> { typedef float lds_t; static constexpr int LD = 36; };
 template <> struct PrecT<CRAFT_PREC_BF16> { typedef __bf16 lds_t; static constexpr int LD = 40; };
 template <> struct PrecT<CRAFT_PREC_F16> { typedef _Float16 lds_t; static constexpr int LD = 40; };
+// F16X3: every fp32 operand is split into two fp16 planes x = hi + lo (hi = fp16(x), lo = fp16(x - hi), 22
+// significant bits) and a product is three fp16 MFMAs hi*hi + hi*lo + lo*hi with fp32 accumulation: fp32-class
+// results (relative error ~2^-22 per product) at 3/16 of the fp32-MFMA cost.  gfx950 has no TF32/xf32 path.
+template <> struct PrecT<CRAFT_PREC_F16X3> { typedef _Float16 lds_t; static constexpr int LD = 40; };
+
+template <int PREC> struct Planes { static constexpr int N = (PREC == CRAFT_PREC_F16X3) ? 2 : 1; };
 
 template <int PREC, int BM, int BN> struct TileLds {
   typedef typename PrecT<PREC>::lds_t lds_t;
   static constexpr int LD = PrecT<PREC>::LD;
-  static constexpr int A_ELEMS = BM * LD;
-  static constexpr int B_ELEMS = BN * LD;
+  static constexpr int A_ELEMS = Planes<PREC>::N * BM * LD;
+  static constexpr int B_ELEMS = Planes<PREC>::N * BN * LD;
   static constexpr int BYTES = 2 * (A_ELEMS + B_ELEMS) * (int)sizeof(lds_t);
 };
 
@@ -59,16 +65,23 @@ __device__ __forceinline__ void stage_store(typename PrecT<PREC>::lds_t* S, cons
       bf16x4 h;
       h[0] = (__bf16)r.v[i].x; h[1] = (__bf16)r.v[i].y; h[2] = (__bf16)r.v[i].z; h[3] = (__bf16)r.v[i].w;
       *reinterpret_cast<bf16x4*>(&S[row * LD + c4 * 4]) = h;
-    } else {
+    } else if constexpr (PREC == CRAFT_PREC_F16) {
       f16x4 h;
       h[0] = (_Float16)r.v[i].x; h[1] = (_Float16)r.v[i].y; h[2] = (_Float16)r.v[i].z; h[3] = (_Float16)r.v[i].w;
       *reinterpret_cast<f16x4*>(&S[row * LD + c4 * 4]) = h;
+    } else {   // F16X3: hi plane, then lo plane at + ROWS*LD
+      f16x4 h, l;
+      h[0] = (_Float16)r.v[i].x; h[1] = (_Float16)r.v[i].y; h[2] = (_Float16)r.v[i].z; h[3] = (_Float16)r.v[i].w;
+      l[0] = (_Float16)(r.v[i].x - (float)h[0]); l[1] = (_Float16)(r.v[i].y - (float)h[1]);
+      l[2] = (_Float16)(r.v[i].z - (float)h[2]); l[3] = (_Float16)(r.v[i].w - (float)h[3]);
+      *reinterpret_cast<f16x4*>(&S[row * LD + c4 * 4]) = h;
+      *reinterpret_cast<f16x4*>(&S[(ROWS + row) * LD + c4 * 4]) = l;
     }
   }
 }
 template <int PREC, int ROWS>
 __device__ __forceinline__ void stage_store(typename PrecT<PREC>::lds_t* S, const RegsH16<ROWS>& r, int tid) {
-  static_assert(PREC != CRAFT_PREC_F32, "16-bit operands need a 16-bit MFMA mode");
+  static_assert(PREC == CRAFT_PREC_BF16 || PREC == CRAFT_PREC_F16, "16-bit operands need a plain 16-bit MFMA mode");
   constexpr int LD = PrecT<PREC>::LD;
   const int c8 = tid & 3, r0 = tid >> 2;
 #pragma unroll
@@ -184,7 +197,7 @@ template <int ROWS> struct LoaderConvF32 {
 // ---------------------------------------------------------------------------------------------
 // LDS fragments -> MFMA
 // ---------------------------------------------------------------------------------------------
-template <int PREC, int MT, int NT>
+template <int PREC, int MT, int NT, int BM, int BN>
 __device__ __forceinline__ void mma_tile(const typename PrecT<PREC>::lds_t* As, const typename PrecT<PREC>::lds_t* Bs,
                                          int wm0, int wn0, int lane, f32x16 (&acc)[MT][NT]) {
   constexpr int LD = PrecT<PREC>::LD;
@@ -221,7 +234,7 @@ __device__ __forceinline__ void mma_tile(const typename PrecT<PREC>::lds_t* As, 
         for (int nt = 0; nt < NT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
     }
-  } else {
+  } else if constexpr (PREC == CRAFT_PREC_F16) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       f16x8 a[MT], b[NT];
@@ -234,6 +247,29 @@ __device__ __forceinline__ void mma_tile(const typename PrecT<PREC>::lds_t* As, 
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+  } else {   // F16X3
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      f16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        ah[mt] = *reinterpret_cast<const f16x8*>(&As[(wm0 + mt * 32 + r) * LD + kk * 16 + g * 8]);
+        al[mt] = *reinterpret_cast<const f16x8*>(&As[(BM + wm0 + mt * 32 + r) * LD + kk * 16 + g * 8]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        bh[nt] = *reinterpret_cast<const f16x8*>(&Bs[(wn0 + nt * 32 + r) * LD + kk * 16 + g * 8]);
+        bl[nt] = *reinterpret_cast<const f16x8*>(&Bs[(BN + wn0 + nt * 32 + r) * LD + kk * 16 + g * 8]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        }
     }
   }
 }
@@ -291,7 +327,7 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int nk
       la.fetch(kt + 1, ra);
       lb.fetch(kt + 1, rb);
     }
-    mma_tile<PREC, MT, NT>(As[cur], Bs[cur], wm0, wn0, lane, acc);
+    mma_tile<PREC, MT, NT, BM, BN>(As[cur], Bs[cur], wm0, wn0, lane, acc);
     fold(kt);
     if (kt + 1 < nk) {
       stage_store<PREC>(As[cur ^ 1], ra, tid);

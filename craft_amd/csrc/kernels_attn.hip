@@ -130,6 +130,7 @@ int launch_score_max(const ScoreParams& p, unsigned* max_ord, int prec, hipStrea
   if (prec == CRAFT_PREC_F32) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_F32, true>), grid, dim3(NTHREADS), 0, s, p, 0.f, nullptr, nullptr, max_ord);
   else if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_BF16, true>), grid, dim3(NTHREADS), 0, s, p, 0.f, nullptr, nullptr, max_ord);
   else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_F16, true>), grid, dim3(NTHREADS), 0, s, p, 0.f, nullptr, nullptr, max_ord);
+  else if (prec == CRAFT_PREC_F16X3) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_F16X3, true>), grid, dim3(NTHREADS), 0, s, p, 0.f, nullptr, nullptr, max_ord);
   else return CRAFT_ERR_ARG;
   return (int)hipGetLastError();
 }
@@ -142,6 +143,7 @@ int launch_corr_build(const ScoreParams& p, float w_aggr, float* pyr0, double* s
   if (prec == CRAFT_PREC_F32) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_F32, false>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums, nullptr);
   else if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_BF16, false>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums, nullptr);
   else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_F16, false>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums, nullptr);
+  else if (prec == CRAFT_PREC_F16X3) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_F16X3, false>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums, nullptr);
   else return CRAFT_ERR_ARG;
   return (int)hipGetLastError();
 }
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) add += (PREC == CRAFT_PREC_F32) ? expf(sv[mt][e] - m_new) : __expf(sv[mt][e] - m_new);
+            for (int e = 0; e < 16; ++e) add += (PREC == CRAFT_PREC_F32 || PREC == CRAFT_PREC_F16X3) ? expf(sv[mt][e] - m_new) : __expf(sv[mt][e] - m_new);
           l_run = l_run * ((m_run > -INFINITY) ? expf(m_run - m_new) : 0.f) + add;
           m_run = m_new;
         }
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 const float d = sv[mt][4 * q + i] - m_run;
-                pv[i] = ((PREC == CRAFT_PREC_F32) ? expf(d) : __expf(d)) * inv_l;
+                pv[i] = ((PREC == CRAFT_PREC_F32 || PREC == CRAFT_PREC_F16X3) ? expf(d) : __expf(d)) * inv_l;
               }
               if constexpr (PT == CRAFT_PREC_F32) {
                 *reinterpret_cast<float4*>(Prow + j) = make_float4(pv[0], pv[1], pv[2], pv[3]);
@@ -270,6 +272,7 @@ int launch_attn_probs(const ScoreParams& p, void* P, long ldp, int p_prec, int p
   if (prec == CRAFT_PREC_F32) return launch_attn_probs_pt<CRAFT_PREC_F32>(p, P, ldp, p_prec, grid, s);
   if (prec == CRAFT_PREC_BF16) return launch_attn_probs_pt<CRAFT_PREC_BF16>(p, P, ldp, p_prec, grid, s);
   if (prec == CRAFT_PREC_F16) return launch_attn_probs_pt<CRAFT_PREC_F16>(p, P, ldp, p_prec, grid, s);
+  if (prec == CRAFT_PREC_F16X3) return launch_attn_probs_pt<CRAFT_PREC_F16X3>(p, P, ldp, p_prec, grid, s);
   return CRAFT_ERR_ARG;
 }
 

@@ -57,7 +57,7 @@ static int pick_bn(int N) {
 int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return 0;
   if ((p.K & 3) || (p.lda & 3) || (p.ldb & 3)) return CRAFT_ERR_ALIGN;
-  if (a16 && ((p.K & 7) || (p.lda & 7) || prec == CRAFT_PREC_F32)) return CRAFT_ERR_ALIGN;
+  if (a16 && ((p.K & 7) || (p.lda & 7) || (prec != CRAFT_PREC_BF16 && prec != CRAFT_PREC_F16))) return CRAFT_ERR_ALIGN;
   const int bn = pick_bn(p.N);
 #define GO(PR, BNV, A) return launch_rows_t<PR, BNV, A>(p, s)
   if (prec == CRAFT_PREC_F32) { if (bn == 128) GO(CRAFT_PREC_F32, 128, false); else GO(CRAFT_PREC_F32, 64, false); }
@@ -69,6 +69,7 @@ int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s)
     if (a16) { if (bn == 128) GO(CRAFT_PREC_F16, 128, true); else GO(CRAFT_PREC_F16, 64, true); }
     if (bn == 128) GO(CRAFT_PREC_F16, 128, false); else GO(CRAFT_PREC_F16, 64, false);
   }
+  if (prec == CRAFT_PREC_F16X3) { if (bn == 128) GO(CRAFT_PREC_F16X3, 128, false); else GO(CRAFT_PREC_F16X3, 64, false); }
 #undef GO
   return CRAFT_ERR_ARG;
 }
@@ -152,6 +153,7 @@ int launch_gemm_conv(const ConvGemmParams& p, int prec, hipStream_t s) {
   if (prec == CRAFT_PREC_F32) GO(CRAFT_PREC_F32);
   if (prec == CRAFT_PREC_BF16) GO(CRAFT_PREC_BF16);
   if (prec == CRAFT_PREC_F16) GO(CRAFT_PREC_F16);
+  if (prec == CRAFT_PREC_F16X3) GO(CRAFT_PREC_F16X3);
 #undef GO
   return CRAFT_ERR_ARG;
 }

@@ -12,9 +12,10 @@ from ctypes import c_double, c_float, c_int, c_long, c_void_p, c_char_p
 
 import torch
 
-PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
+PREC_F32, PREC_BF16, PREC_F16, PREC_F16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
-PREC_NAMES = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16}
+PREC_NAMES = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "f16x3": PREC_F16X3,
+              "fp16x3": PREC_F16X3}
 PROB_DTYPE = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_F16: torch.float16}
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcraft_hip.so")
@@ -49,7 +50,7 @@ _SIGS = {
 # Named policies.  "mixed" is the default for mixed_precision=True: fp16 MFMA for the attention contractions
 # (projections, Q K^T, P V; fp32 accumulate) and exact-fp32 MFMA for the update-block convolutions; measured
 # mean end-point deviation from the fp32 path 0.004 px at 448x1024 / 12 iters.
-NAMED_POLICIES = {"mixed": "proj=fp16,score=fp16,pv=fp16,conv=fp32"}
+NAMED_POLICIES = {"mixed": "proj=f16x3,score=f16x3,pv=fp16,conv=f16x3", "mixed_fp32conv": "proj=fp16,score=fp16,pv=fp16,conv=fp32"}
 
 
 class CraftHipError(RuntimeError):
@@ -78,17 +79,19 @@ class Precision:
         spec = NAMED_POLICIES.get(spec.strip(), spec.strip())
         if "=" not in spec:
             v = PREC_NAMES[spec]
-            return Precision(v, v, v, v)
+            return Precision(v, v, PREC_F16 if v == PREC_F16X3 else v, v)
         p = Precision()
         for item in spec.split(","):
             k, v = item.split("=")
             if k.strip() not in Precision.__slots__:
                 raise ValueError(f"unknown precision role {k!r}")
             setattr(p, k.strip(), PREC_NAMES[v.strip()])
+        if p.pv == PREC_F16X3:
+            raise ValueError("pv (the storage type of the attention probabilities) must be fp32, bf16 or fp16")
         return p
 
     def __repr__(self):
-        inv = {0: "fp32", 1: "bf16", 2: "fp16"}
+        inv = {0: "fp32", 1: "bf16", 2: "fp16", 3: "f16x3"}
         return ",".join(f"{k}={inv[getattr(self, k)]}" for k in self.__slots__)
 
 

@@ -34,6 +34,7 @@ extern "C" {
 #define CRAFT_PREC_F32 0
 #define CRAFT_PREC_BF16 1
 #define CRAFT_PREC_F16 2
+#define CRAFT_PREC_F16X3 3 /* fp32 operands split into two fp16 planes, 3 fp16 MFMAs per product: fp32-class results */
 
 #define CRAFT_ACT_NONE 0
 #define CRAFT_ACT_TANH 1

@@ -64,11 +64,14 @@ def test_test_modes_and_skipped_mask_head(device):
     assert isinstance(ups0, list) and len(ups0) == 4
 
 
-@pytest.mark.parametrize("precision,mean_tol,max_tol", [("mixed", 0.004, 0.02), ("fp16", 0.03, 0.1), ("bf16", 0.3, 0.8)])
+@pytest.mark.parametrize("precision,mean_tol,max_tol", [("mixed", 0.001, 0.005), ("mixed_fp32conv", 0.004, 0.02), ("fp16", 0.03, 0.1),
+                                                        ("bf16", 0.3, 0.8)])
 def test_forward_mixed_precision_modes(device, precision, mean_tol, max_tol):
     """16-bit MFMA operands, fp32 accumulate, against the reference's fp32 output (4 iterations).
-    "mixed" (fp16 attention contractions + fp32 convolutions) is the shipped mixed-precision policy and must
-    hold BASELINE.md's bound for 16-bit attention, mean EPE delta <= 0.01 px (measured 0.0014; 0.0042 px at
+    "mixed" is the shipped mixed-precision policy: fp16 storage of the attention probabilities + fp16 MFMA for
+    P.V, and split-fp16 (F16X3, fp32-class) MFMA for projections, Q K^T and the convolutions; it is held to the
+    fp32 bound of BASELINE.md (mean EPE delta <= 1e-3 px).  "mixed_fp32conv" (fp16 attention contractions + exact
+    fp32 MFMA convolutions) holds the 16-bit-attention bound (<= 0.01 px; measured 0.0014, 0.0042 px at
     448x1024 / 12 iterations).  All-fp16 (what the reference's autocast does) and all-bf16 are selectable but
     do NOT meet that bound on the synthetic weights (measured 0.012 / 0.11 px): their bounds here only guard
     against regressions."""
@@ -129,7 +132,7 @@ def test_full_size_448x1024_properties(device, precision):
     if precision == "mixed":
         ref = _full_model(device, "fp32")(im1[:1], im2[:1], iters=12, test_mode=1)[1]
         epe = (up1 - ref).pow(2).sum(1).sqrt()
-        assert epe.mean().item() < 0.01, f"mixed-precision mean EPE delta {epe.mean().item():.4f} px at 448x1024 / 12 iters"
+        assert epe.mean().item() < 2e-3, f"mixed-precision mean EPE delta {epe.mean().item():.4f} px at 448x1024 / 12 iters"
     # the flow must be non-trivial (the synthetic pair moves by up to 12 px)
     assert up2.abs().max().item() > 0.5
 

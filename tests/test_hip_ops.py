@@ -13,14 +13,15 @@ import torch
 import torch.nn.functional as F
 
 from craft_amd import hip, ops
-from craft_amd.hip import ACT_NONE, ACT_RELU, ACT_TANH, PREC_BF16, PREC_F16, PREC_F32
+from craft_amd.hip import ACT_NONE, ACT_RELU, ACT_TANH, PREC_BF16, PREC_F16, PREC_F16X3, PREC_F32
 from oracle import craft_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-PRECS = [PREC_F32, PREC_BF16, PREC_F16]
-# (rtol, atol multiplier) for a K-long dot product of O(1) operands
-TOL = {PREC_F32: (1e-4, 1e-5), PREC_BF16: (2e-2, 2e-2), PREC_F16: (3e-3, 3e-3)}
+PRECS = [PREC_F32, PREC_BF16, PREC_F16, PREC_F16X3]
+# (rtol, atol multiplier) for a K-long dot product of O(1) operands.  F16X3 (split-fp16 emulation of fp32
+# products, 2^-22 per product) is held to the fp32 tolerance.
+TOL = {PREC_F32: (1e-4, 1e-5), PREC_BF16: (2e-2, 2e-2), PREC_F16: (3e-3, 3e-3), PREC_F16X3: (1e-4, 1e-5)}
 
 
 def gen(*shape, seed=0, scale=1.0):
@@ -155,7 +156,7 @@ def test_corr_build_pyramid_lookup(device, prec, gain):
     for name, cc in (("identity", c0), ("frac", frac), ("wild", wild)):
         ref = O.corr_lookup(pyr_ref, cc, 4, mu_ref, rstd_ref)
         got = ops.corr_lookup(pyr, ops.tokens_from_nchw(cc.to(device)), 4)
-        if prec == PREC_F32:
+        if prec in (PREC_F32, PREC_F16X3):
             close(ops.tokens_to_nchw(got, H8, W8), ref, 2e-4, 2e-4, f"lookup {name}")
         else:
             close(ops.tokens_to_nchw(got, H8, W8), ref, rt, at * 10, f"lookup {name} prec={prec}")
@@ -187,6 +188,8 @@ def test_attn_probs(device, prec, C, M, mask_radius, gain):
     k = ops.linear(x.to(device), Wk.to(device), None, PREC_F32)
     scale = 1.0 / math.sqrt(C // M)
     mx = ops.score_max(q, k, H8, W8, M, scale, prec)
+    if prec == PREC_F16X3:
+        prec = hip.Precision(score=PREC_F16X3, pv=PREC_F32)
     P = ops.attn_probs(q, k, H8, W8, M, scale, tab.to(device), 1.0, mask_radius, mx, prec)
     if prec == PREC_BF16:      # mixed roles: fp32 logits, fp16 storage
         P2 = ops.attn_probs(q, k, H8, W8, M, scale, tab.to(device), 1.0, mask_radius, mx, hip.Precision(score=PREC_F32, pv=PREC_F16))
@@ -196,8 +199,9 @@ def test_attn_probs(device, prec, C, M, mask_radius, gain):
     assert float(P[..., N:].float().abs().max()) == 0.0, "padding columns must be zero"
     got = P[..., :N].float()
     rsum = got.sum(-1).cpu()
-    assert (rsum - 1).abs().max() < (1e-5 if prec == PREC_F32 else 1e-2), "rows must sum to 1"
-    if prec == PREC_F32:
+    exact = prec == PREC_F32 or isinstance(prec, hip.Precision)
+    assert (rsum - 1).abs().max() < (1e-5 if exact else 1e-2), "rows must sum to 1"
+    if exact:
         close(got, ref, 2e-4, 1e-6, "attention probs")
     else:
         # logits carry the operand rounding (|S| up to ~|x||y| 2^-8), probabilities are <= 1
@@ -208,6 +212,8 @@ def test_attn_probs(device, prec, C, M, mask_radius, gain):
 @pytest.mark.parametrize("C", [128, 256])
 def test_expanded_feat_trans(device, prec, C):
     """craft_linear_t + craft_attn_apply + craft_mode_pool_ln vs ExpandedFeatTrans."""
+    if prec == PREC_F16X3:
+        pytest.skip("P is stored as fp32 / bf16 / fp16; the split mode applies to fp32 operands only")
     B, H8, W8, M = 2, 11, 17, 4
     N = H8 * W8
     x = gen(B, N, C, seed=60)
