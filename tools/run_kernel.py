@@ -25,6 +25,31 @@ def main():
         O = torch.empty(B, M, N, Dv, device=dev)
         for _ in range(5):
             ops.attn_apply(P, vT, Dv, pv, out=O)
+    elif which in ("gru", "menc", "head"):
+        from craft_amd import CRAFT, default_args
+        from craft_amd.synth import synth_state_dict
+        m = CRAFT(default_args())
+        m.load_state_dict(synth_state_dict(m.state_dict(), seed=1234))
+        ub = m.cuda().eval().update_block
+        hx = torch.randn(B, N, 512, device=dev)
+        ws = ub.workspace(B, N, dev)
+        corr = torch.randn(B, N, 324, device=dev)
+        c0, c1, fl = ops.coords_init(None, B, H8, W8, dev)
+        for _ in range(3):
+            if which == "gru":
+                ub.gru.forward_tokens(hx, (H8, W8), ws, prec)
+            elif which == "menc":
+                ub.encoder.forward_tokens(fl, corr, (H8, W8), hx[..., 256:384], ws, prec)
+            else:
+                ub.flow_head_tokens(hx, (H8, W8), c1, c0, fl, None, ws, prec)
+    elif which == "probs":
+        import math
+        C, Mm = 128, 4
+        q = torch.randn(B, N, C, device=dev)
+        k = torch.randn(B, N, C, device=dev)
+        tab = torch.randn(15, 15, device=dev)
+        for _ in range(2):
+            ops.attn_probs(q, k, H8, W8, Mm, 1 / math.sqrt(C // Mm), tab, 1.0, -1, None, prec)
     torch.cuda.synchronize()
 
 
