@@ -301,37 +301,36 @@ struct NoFold { __device__ __forceinline__ void operator()(int) const {} };
 // The K loop.  `fold(kt)` runs after K-tile kt has been accumulated (used by the correlation build to
 // close a mode every d/32 tiles).  Ends with a barrier, so it can be called repeatedly.
 template <int PREC, int BM, int BN, int WM, int WN, class LA, class LB, class FOLD>
-__device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int nk, char* smem,
+__device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int nk,
                                               f32x16 (&acc)[BM / WM / 32][BN / WN / 32], FOLD&& fold) {
   typedef typename PrecT<PREC>::lds_t lds_t;
   typedef TileLds<PREC, BM, BN> L;
   constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
-  lds_t* As[2];
-  lds_t* Bs[2];
-  As[0] = reinterpret_cast<lds_t*>(smem);
-  As[1] = As[0] + L::A_ELEMS;
-  Bs[0] = As[1] + L::A_ELEMS;
-  Bs[1] = Bs[0] + L::B_ELEMS;
+  // The tile buffers live HERE (one static LDS array, indexed by integer offsets) so that every access is
+  // provably in the LDS address space: handing the engine a generic pointer made hipcc emit flat_load
+  // instead of ds_read_b128 for the fragments.  Layout: A0 | A1 | B0 | B1.
+  __shared__ __attribute__((aligned(16))) lds_t S[2 * (L::A_ELEMS + L::B_ELEMS)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
   typename LA::Regs ra;
   typename LB::Regs rb;
   la.fetch(0, ra);
   lb.fetch(0, rb);
-  stage_store<PREC>(As[0], ra, tid);
-  stage_store<PREC>(Bs[0], rb, tid);
+  stage_store<PREC>(&S[0], ra, tid);
+  stage_store<PREC>(&S[2 * L::A_ELEMS], rb, tid);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
+    const int ao = (kt & 1) * L::A_ELEMS, bo = 2 * L::A_ELEMS + (kt & 1) * L::B_ELEMS;
+    const int an = L::A_ELEMS - ao, bn = 2 * L::A_ELEMS + L::B_ELEMS - (kt & 1) * L::B_ELEMS;
     if (kt + 1 < nk) {
       la.fetch(kt + 1, ra);
       lb.fetch(kt + 1, rb);
     }
-    mma_tile<PREC, MT, NT, BM, BN>(As[cur], Bs[cur], wm0, wn0, lane, acc);
+    mma_tile<PREC, MT, NT, BM, BN>(&S[ao], &S[bo], wm0, wn0, lane, acc);
     fold(kt);
     if (kt + 1 < nk) {
-      stage_store<PREC>(As[cur ^ 1], ra, tid);
-      stage_store<PREC>(Bs[cur ^ 1], rb, tid);
+      stage_store<PREC>(&S[an], ra, tid);
+      stage_store<PREC>(&S[bn], rb, tid);
     }
     __syncthreads();
   }

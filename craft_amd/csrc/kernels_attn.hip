@@ -17,7 +17,6 @@ template <int PREC, bool MAXONLY>
 __global__ __launch_bounds__(NTHREADS) void k_corr_build(ScoreParams p, float w_aggr, float* __restrict__ pyr0,
                                                         double* __restrict__ sums, unsigned* __restrict__ max_ord) {
   constexpr int BM = 128, BN = 64, WM = 2, WN = 2, MT = 2, NT = 1;
-  __shared__ __attribute__((aligned(16))) char smem[TileLds<PREC, BM, BN>::BYTES];
   __shared__ int s_rh[BM], s_rw[BM];
   __shared__ float s_tab[961];
   __shared__ float s_red[8];
@@ -71,7 +70,7 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build(ScoreParams p, float w_
         }
       }
   };
-  gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, smem, acc, fold);
+  gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, acc, fold);
 
   if (MAXONLY) {
     vmax = wave_max(vmax);
@@ -162,7 +161,6 @@ template <int PREC, int PT>
 __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __restrict__ Pout, long ldp) {
   constexpr int BM = 128, BN = 128, WM = 1, WN = 4, MT = 4, NT = 1;
   typedef typename ProbT<PT>::t prob_t;
-  __shared__ __attribute__((aligned(16))) char smem[TileLds<PREC, BM, BN>::BYTES];
   __shared__ int s_kh[BM], s_kw[BM];
   __shared__ float s_tab[961];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -189,7 +187,7 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
       LoaderRowsF32<BM> la;
       la.init(kbase, p.ldk, jt * BM, N, p.d, tid);
       acc_zero(acc);
-      gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, smem, acc, NoFold());
+      gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, acc, NoFold());
       // scores of this lane: key row r = mt*32 + 8*q + rh4 + i  (q = reg>>2, i = reg&3)
       float sv[MT][16];
       float tmax = -INFINITY;

@@ -12,7 +12,6 @@ namespace craft {
 template <int PREC, int BN, bool A16>
 __global__ __launch_bounds__(NTHREADS) void k_gemm_rows(RowsGemmParams p) {
   constexpr int BM = 128, WM = 2, WN = 2, MT = BM / WM / 32, NT = BN / WN / 32;
-  __shared__ __attribute__((aligned(16))) char smem[TileLds<PREC, BM, BN>::BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
   const int z0 = z / p.zdiv, z1 = z - z0 * p.zdiv;
@@ -24,11 +23,11 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_rows(RowsGemmParams p) {
   if constexpr (A16) {
     LoaderRowsH16<BM> la;
     la.init(reinterpret_cast<const uint16_t*>(p.A) + z0 * p.a_bs0 + z1 * p.a_bs1, p.lda, m0, p.M, p.K, tid);
-    gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, smem, acc, NoFold());
+    gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, acc, NoFold());
   } else {
     LoaderRowsF32<BM> la;
     la.init(reinterpret_cast<const float*>(p.A) + z0 * p.a_bs0 + z1 * p.a_bs1, p.lda, m0, p.M, p.K, tid);
-    gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, smem, acc, NoFold());
+    gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, acc, NoFold());
   }
   float* C = p.C + z0 * p.c_bs0 + z1 * p.c_bs1;
   const int rb = m0 + (wave / WN) * (BM / WM), cb = n0 + (wave % WN) * (BN / WN);
@@ -80,7 +79,6 @@ int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s)
 template <int PREC, int BN>
 __global__ __launch_bounds__(NTHREADS) void k_gemm_conv(ConvGemmParams p) {
   constexpr int BM = 128, WM = 2, WN = 2, MT = BM / WM / 32, NT = BN / WN / 32;
-  __shared__ __attribute__((aligned(16))) char smem[TileLds<PREC, BM, BN>::BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   f32x16 acc[MT][NT];
@@ -90,7 +88,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_conv(ConvGemmParams p) {
   la.init(p.g, m0, tid);
   LoaderRowsF32<BN> lb;
   lb.init(p.W, K, n0, p.cout, K, tid);
-  gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, K / BK, smem, acc, NoFold());
+  gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, K / BK, acc, NoFold());
   const int rb = m0 + (wave / WN) * (BM / WM), cb = n0 + (wave % WN) * (BN / WN);
   const int M = p.g.npix, N = p.cout;
   switch (p.epi) {
