@@ -3,8 +3,7 @@
 //                                 written straight into pyramid level 0, plus per-sample (sum, sum^2) for the
 //                                 lazy global LayerNorm (corr.py:200-204).  The 4-mode score tensor never exists.
 //   k_corr_build<MAXONLY=true>  : global max of the raw scaled scores -> clamp decision (setrans.py:520-529)
-//   k_attn_probs                : P_m = softmax_j(S_m + pw*pb (+mask)), two passes over the keys per query tile
-//                                 (row max / row sum, then normalised write); P is written once, fp32 or 16-bit.
+//   (k_attn_probs, the softmax branch, lives in attn_probs.inc.hpp)
 #include "gemm_engine.hpp"
 #include "launch.hpp"
 
@@ -147,131 +146,14 @@ int launch_corr_build(const ScoreParams& p, float w_aggr, float* pyr0, double* s
   return (int)hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------
-// attention probabilities.  grid (query tiles of 128, B*M).  "Swapped" product: keys are the MFMA row
-// operand and queries the column operand, so a lane owns ONE query (col = lane&31) and 64 of the 128
-// keys of a tile: the softmax row statistics stay lane-local (one cross-half exchange at the end).
-// ---------------------------------------------------------------------------------------------
-template <int PREC> struct ProbT;
-template <> struct ProbT<CRAFT_PREC_F32> { typedef float t; };
-template <> struct ProbT<CRAFT_PREC_BF16> { typedef __bf16 t; };
-template <> struct ProbT<CRAFT_PREC_F16> { typedef _Float16 t; };
-
-template <int PREC, int PT>
-__global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __restrict__ Pout, long ldp) {
-  constexpr int BM = 128, BN = 128, WM = 1, WN = 4, MT = 4, NT = 1;
-  typedef typename ProbT<PT>::t prob_t;
-  __shared__ int s_kh[BM], s_kw[BM];
-  __shared__ float s_tab[961];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * BN, z = blockIdx.y;
-  const int b = z / p.M, m = z - b * p.M;
-  const int N = p.N;
-  const int qcol = n0 + wave * 32 + (lane & 31);
-  const int h1 = qcol / p.W8, w1 = qcol - h1 * p.W8;
-  const int rh4 = 4 * (lane >> 5);
-  const bool clamp = p.clamp_ord != nullptr && ord2f(*p.clamp_ord) > CRAFT_ATTN_CLIP;
-  const int nkt = (N + BM - 1) / BM, nk = p.d / BK;
-  if (p.pos_tab) { const int T = (2 * p.R + 1) * (2 * p.R + 1); for (int i = tid; i < T; i += NTHREADS) s_tab[i] = p.pos_tab[i]; }
-
-  LoaderRowsF32<BN> lb;
-  lb.init(p.Q + (long)b * p.q_bs + (long)m * p.d, p.ldq, n0, N, p.d, tid);
-  const float* kbase = p.Kf + (long)b * p.k_bs + (long)m * p.d;
-  prob_t* Prow = reinterpret_cast<prob_t*>(Pout) + ((long)z * N + qcol) * ldp;
-
-  float m_run = -INFINITY, l_run = 0.f, inv_l = 0.f;
-  f32x16 acc[MT][NT];
-  for (int pass = 0; pass < 2; ++pass) {
-    for (int jt = 0; jt < nkt; ++jt) {
-      if (tid < BM) { const int j = jt * BM + tid; s_kh[tid] = j / p.W8; s_kw[tid] = j - (j / p.W8) * p.W8; }
-      LoaderRowsF32<BM> la;
-      la.init(kbase, p.ldk, jt * BM, N, p.d, tid);
-      acc_zero(acc);
-      gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, acc, NoFold());
-      // scores of this lane: key row r = mt*32 + 8*q + rh4 + i  (q = reg>>2, i = reg&3)
-      float sv[MT][16];
-      float tmax = -INFINITY;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int r = mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
-          float s = acc[mt][0][e] * p.scale;
-          if (clamp) s = fminf(fmaxf(s, -CRAFT_ATTN_CLIP), CRAFT_ATTN_CLIP);
-          const int dh = s_kh[r] - h1, dw = s_kw[r] - w1;
-          if (p.pos_tab && dh >= -p.R && dh <= p.R && dw >= -p.R && dw <= p.R)
-            s += p.pos_w * s_tab[(dh + p.R) * (2 * p.R + 1) + dw + p.R];
-          if (p.mask_radius > 0 && max(abs(dh), abs(dw)) > p.mask_radius) s += -1e9f;
-          if (jt * BM + r >= N) s = -INFINITY;
-          sv[mt][e] = s;
-          tmax = fmaxf(tmax, s);
-        }
-      if (pass == 0) {
-        const float m_new = fmaxf(m_run, tmax);
-        if (m_new > -INFINITY) {
-          float add = 0.f;
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) add += (PREC == CRAFT_PREC_F32 || PREC == CRAFT_PREC_F16X3) ? expf(sv[mt][e] - m_new) : __expf(sv[mt][e] - m_new);
-          l_run = l_run * ((m_run > -INFINITY) ? expf(m_run - m_new) : 0.f) + add;
-          m_run = m_new;
-        }
-      } else if (qcol < N) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int j = jt * BM + mt * 32 + 8 * q + rh4;
-            if (j < ldp) {
-              float pv[4];
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const float d = sv[mt][4 * q + i] - m_run;
-                pv[i] = ((PREC == CRAFT_PREC_F32 || PREC == CRAFT_PREC_F16X3) ? expf(d) : __expf(d)) * inv_l;
-              }
-              if constexpr (PT == CRAFT_PREC_F32) {
-                *reinterpret_cast<float4*>(Prow + j) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-              } else {
-                typedef prob_t pt4 __attribute__((ext_vector_type(4)));
-                pt4 h;
-                h[0] = (prob_t)pv[0]; h[1] = (prob_t)pv[1]; h[2] = (prob_t)pv[2]; h[3] = (prob_t)pv[3];
-                *reinterpret_cast<pt4*>(Prow + j) = h;
-              }
-            }
-          }
-      }
-      __syncthreads();   // s_kh / s_kw are rewritten by the next tile
-    }
-    if (pass == 0) {
-      // merge the two half-waves (same query, disjoint keys)
-      const float m_o = __shfl_xor(m_run, 32), l_o = __shfl_xor(l_run, 32);
-      const float m_f = fmaxf(m_run, m_o);
-      const float la_ = (m_run > -INFINITY) ? l_run * expf(m_run - m_f) : 0.f;
-      const float lo_ = (m_o > -INFINITY) ? l_o * expf(m_o - m_f) : 0.f;
-      m_run = m_f;
-      inv_l = 1.f / (la_ + lo_);
-    }
-  }
-}
-
-template <int PREC> static int launch_attn_probs_pt(const ScoreParams& p, void* P, long ldp, int p_prec, dim3 grid, hipStream_t s) {
-  if (p_prec == CRAFT_PREC_F32) hipLaunchKernelGGL((k_attn_probs<PREC, CRAFT_PREC_F32>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
-  else if (p_prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_attn_probs<PREC, CRAFT_PREC_BF16>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
-  else if (p_prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_attn_probs<PREC, CRAFT_PREC_F16>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
-  else return CRAFT_ERR_ARG;
-  return (int)hipGetLastError();
-}
-
+// attention probabilities: kernels live in attn_probs.inc.hpp, one translation unit per mode width d
 int launch_attn_probs(const ScoreParams& p, void* P, long ldp, int p_prec, int prec, hipStream_t s) {
   if (int e = check_score(p)) return e;
   if (ldp % 32 || ldp < p.N) return CRAFT_ERR_ALIGN;
-  dim3 grid((p.N + 127) / 128, p.B * p.M, 1);
-  if (prec == CRAFT_PREC_F32) return launch_attn_probs_pt<CRAFT_PREC_F32>(p, P, ldp, p_prec, grid, s);
-  if (prec == CRAFT_PREC_BF16) return launch_attn_probs_pt<CRAFT_PREC_BF16>(p, P, ldp, p_prec, grid, s);
-  if (prec == CRAFT_PREC_F16) return launch_attn_probs_pt<CRAFT_PREC_F16>(p, P, ldp, p_prec, grid, s);
-  if (prec == CRAFT_PREC_F16X3) return launch_attn_probs_pt<CRAFT_PREC_F16X3>(p, P, ldp, p_prec, grid, s);
-  return CRAFT_ERR_ARG;
+  if (p.d == 32) return launch_attn_probs_d<32>(p, P, ldp, p_prec, prec, s);
+  if (p.d == 64) return launch_attn_probs_d<64>(p, P, ldp, p_prec, prec, s);
+  if (p.d == 128) return launch_attn_probs_d<128>(p, P, ldp, p_prec, prec, s);
+  return CRAFT_ERR_UNSUPPORTED;
 }
 
 }  // namespace craft
