@@ -1,0 +1,236 @@
+// Halo-tile NHWC convolution on the MFMA engine (stride 1, "same" padding, KH*KW > 1).
+//
+// A block owns an 8x16 patch of output pixels (128 GEMM rows) and BN output channels.  For each chunk of
+// 32 input channels the (8+KH-1) x (16+KW-1) halo patch is staged into LDS ONCE (zero-filled outside the
+// image, converted / split as the precision requires) and all KH*KW taps run from it: the MFMA row
+// fragment of output pixel (py, px) for tap (dy, dx) is halo row (py+dy)*(16+KW-1) + (px+dx), i.e. the
+// lane's base row plus a wave-uniform offset.  Compared with the generic implicit GEMM (k_gemm_conv), which
+// re-gathers and re-converts the activation tile for every tap, activation staging drops by 5x (1x5, 5x1)
+// to 6.4x (3x3); only the weight tile [BN x 32] is staged per (chunk, tap), double-buffered with one
+// barrier per K-tile.  Epilogues are shared with k_gemm_conv (conv_epilogue.hpp).
+#include "conv_epilogue.hpp"
+
+namespace craft {
+
+constexpr int PATCH_H = 8, PATCH_W = 16;
+
+template <int PREC, int BN>
+__global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
+  typedef typename PrecT<PREC>::lds_t lds_t;
+  constexpr int LD = PrecT<PREC>::LD, PL = Planes<PREC>::N;
+  constexpr int BM = 128, WM = 2, WN = 2, MT = BM / WM / 32, NT = BN / WN / 32;
+  constexpr int HR_MAX = (PATCH_H + 4) * PATCH_W;       // 192 rows: enough for 5x1 / 1x5 / 3x3
+  constexpr int NA = HR_MAX / 32;                       // float4 per thread for one halo chunk
+  constexpr int B_ELEMS = PL * BN * LD;
+  __shared__ __attribute__((aligned(16))) lds_t As[PL * HR_MAX * LD];
+  __shared__ __attribute__((aligned(16))) lds_t Bs[2 * B_ELEMS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const ConvGeom& g = p.g;
+  const int KH = g.KH, KW = g.KW, T = KH * KW;
+  const int HWd = PATCH_W + KW - 1, HH = PATCH_H + KH - 1, HR = HH * HWd;
+  const int tiles_x = (g.W + PATCH_W - 1) / PATCH_W, tiles_y = (g.H + PATCH_H - 1) / PATCH_H;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = ty * PATCH_H, x0 = tx * PATCH_W;
+  const int n0 = blockIdx.y * BN;
+  const int ctot = g.c0 + g.c1, nchunk = ctot / BK, K = T * ctot;
+  const long img = (long)b * g.H * g.W;
+  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+  const int c4 = tid & 7, r0 = tid >> 3;
+
+  // ---- halo gather: per-thread pixel offsets (-1: outside the image / beyond the halo)
+  int hpix[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int hr = r0 + 32 * i;
+    const int hy = hr / HWd, hx = hr - hy * HWd;
+    const int y = y0 - g.padH + hy, x = x0 - g.padW + hx;
+    hpix[i] = (hr < HR && y >= 0 && y < g.H && x >= 0 && x < g.W) ? y * g.W + x : -1;
+  }
+  auto fetch_halo = [&](int chunk, float4 (&r)[NA]) {
+    const int cb = chunk * BK;
+    const float* sp; int ld, c;
+    if (cb < g.c0) { sp = g.seg0; ld = g.ld0; c = cb; } else { sp = g.seg1; ld = g.ld1; c = cb - g.c0; }
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      r[i] = (hpix[i] >= 0) ? *reinterpret_cast<const float4*>(sp + (img + hpix[i]) * ld + c + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto store_halo = [&](const float4 (&r)[NA]) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int row = r0 + 32 * i;
+      if (row >= HR) continue;
+      if constexpr (PREC == CRAFT_PREC_F32) {
+        *reinterpret_cast<float4*>(&As[row * LD + c4 * 4]) = r[i];
+      } else if constexpr (PREC == CRAFT_PREC_BF16) {
+        bf16x4 h;
+        h[0] = (__bf16)r[i].x; h[1] = (__bf16)r[i].y; h[2] = (__bf16)r[i].z; h[3] = (__bf16)r[i].w;
+        *reinterpret_cast<bf16x4*>(&As[row * LD + c4 * 4]) = h;
+      } else {
+        f16x4 h;
+        h[0] = (_Float16)r[i].x; h[1] = (_Float16)r[i].y; h[2] = (_Float16)r[i].z; h[3] = (_Float16)r[i].w;
+        *reinterpret_cast<f16x4*>(&As[row * LD + c4 * 4]) = h;
+        if constexpr (PREC == CRAFT_PREC_F16X3) {
+          f16x4 l;
+          l[0] = (_Float16)(r[i].x - (float)h[0]); l[1] = (_Float16)(r[i].y - (float)h[1]);
+          l[2] = (_Float16)(r[i].z - (float)h[2]); l[3] = (_Float16)(r[i].w - (float)h[3]);
+          *reinterpret_cast<f16x4*>(&As[(HR_MAX + row) * LD + c4 * 4]) = l;
+        }
+      }
+    }
+  };
+
+  // ---- weight tile loader: rows = output channels n0.., k = tap*ctot + chunk*32 .. +32
+  const float* wp[BN / 32];
+#pragma unroll
+  for (int i = 0; i < BN / 32; ++i) {
+    const int row = n0 + r0 + 32 * i;
+    wp[i] = (row < p.cout) ? p.W + (long)row * K + c4 * 4 : nullptr;
+  }
+  auto fetch_w = [&](int chunk, int tap, RegsF32<BN>& r) {
+    const int koff = tap * ctot + chunk * BK;
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i)
+      r.v[i] = wp[i] ? *reinterpret_cast<const float4*>(wp[i] + koff) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+
+  // lane's base halo rows for its MT output-row fragments
+  int arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int r = wm0 + mt * 32 + (lane & 31);
+    arow[mt] = (r >> 4) * HWd + (r & 15);
+  }
+  const int g8 = lane >> 5;
+
+  f32x16 acc[MT][NT];
+  acc_zero(acc);
+  float4 ra[NA];
+  RegsF32<BN> rb;
+  fetch_halo(0, ra);
+  fetch_w(0, 0, rb);
+  store_halo(ra);
+  stage_store<PREC>(&Bs[0], rb, tid);
+  __syncthreads();
+
+  const int nk = nchunk * T;
+  int chunk = 0, tap = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    int nchunk_i = chunk, ntap = tap + 1;
+    if (ntap == T) { ntap = 0; nchunk_i = chunk + 1; }
+    const bool has_next = kt + 1 < nk;
+    if (has_next) fetch_w(nchunk_i, ntap, rb);
+    if (tap == 0 && chunk + 1 < nchunk) fetch_halo(chunk + 1, ra);     // lands during this chunk's taps
+
+    // ---- MFMAs for (chunk, tap): A rows shifted by the tap
+    const int ty_ = tap / KW;
+    const int toff = ty_ * HWd + (tap - ty_ * KW);
+    const lds_t* Bc = &Bs[(kt & 1) * B_ELEMS];
+    if constexpr (PREC == CRAFT_PREC_F32) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        float4 a[MT], bq[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4*>(&As[(arow[mt] + toff) * LD + kk * 8 + g8 * 4]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bq[nt] = *reinterpret_cast<const float4*>(&Bc[(wn0 + nt * 32 + (lane & 31)) * LD + kk * 8 + g8 * 4]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bq[nt].x, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bq[nt].y, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bq[nt].z, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bq[nt].w, acc[mt][nt], 0, 0, 0);
+          }
+      }
+    } else if constexpr (PREC == CRAFT_PREC_BF16) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 a[MT], bq[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(&As[(arow[mt] + toff) * LD + kk * 16 + g8 * 8]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bq[nt] = *reinterpret_cast<const bf16x8*>(&Bc[(wn0 + nt * 32 + (lane & 31)) * LD + kk * 16 + g8 * 8]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], bq[nt], acc[mt][nt], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        f16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          ah[mt] = *reinterpret_cast<const f16x8*>(&As[(arow[mt] + toff) * LD + kk * 16 + g8 * 8]);
+          if constexpr (PREC == CRAFT_PREC_F16X3) al[mt] = *reinterpret_cast<const f16x8*>(&As[(HR_MAX + arow[mt] + toff) * LD + kk * 16 + g8 * 8]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          bh[nt] = *reinterpret_cast<const f16x8*>(&Bc[(wn0 + nt * 32 + (lane & 31)) * LD + kk * 16 + g8 * 8]);
+          if constexpr (PREC == CRAFT_PREC_F16X3) bl[nt] = *reinterpret_cast<const f16x8*>(&Bc[(BN + wn0 + nt * 32 + (lane & 31)) * LD + kk * 16 + g8 * 8]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (PREC == CRAFT_PREC_F16X3) {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+            }
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          }
+      }
+    }
+
+    if (has_next) stage_store<PREC>(&Bs[((kt + 1) & 1) * B_ELEMS], rb, tid);
+    __syncthreads();
+    if (has_next && ntap == 0) {          // chunk boundary: every wave is done with the halo tile
+      store_halo(ra);
+      __syncthreads();
+    }
+    chunk = nchunk_i; tap = ntap;
+  }
+
+  // ---- epilogue: GEMM row r of the patch -> token (y0 + r/16, x0 + r%16)
+  const int cb = n0 + wn0;
+  const int c_lane = lane & 31, rh4 = 4 * (lane >> 5);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = wm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
+        const int y = y0 + (r >> 4), x = x0 + (r & 15);
+        if (y < g.H && x < g.W) conv_epilogue(p, img + (long)y * g.W + x, cb + nt * 32 + c_lane, acc[mt][nt][e]);
+      }
+}
+
+template <int PREC, int BN> static int launch_halo_t(const ConvGemmParams& p, hipStream_t s) {
+  const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
+  const int tiles = ((p.g.W + PATCH_W - 1) / PATCH_W) * ((p.g.H + PATCH_H - 1) / PATCH_H) * (p.g.npix / (p.g.H * p.g.W));
+  dim3 grid(tiles, (ncols + BN - 1) / BN, 1);
+  hipLaunchKernelGGL((k_conv_halo<PREC, BN>), grid, dim3(NTHREADS), 0, s, p);
+  return (int)hipGetLastError();
+}
+
+int launch_conv_halo(const ConvGemmParams& p, int prec, hipStream_t s) {
+  if (p.g.KH > 5 || p.g.KW > 5 || (p.g.KH + 7) * (p.g.KW + 15) > (PATCH_H + 4) * PATCH_W) return CRAFT_ERR_UNSUPPORTED;
+  const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
+  // BN = 128 only when that still leaves >= 2 blocks per CU's worth of tiles for wide outputs
+  const int bn = (ncols % 128 == 0 && ncols >= 256) ? 128 : 64;
+#define GO(PR) do { if (bn == 128) return launch_halo_t<PR, 128>(p, s); else return launch_halo_t<PR, 64>(p, s); } while (0)
+  if (prec == CRAFT_PREC_F32) GO(CRAFT_PREC_F32);
+  if (prec == CRAFT_PREC_BF16) GO(CRAFT_PREC_BF16);
+  if (prec == CRAFT_PREC_F16) GO(CRAFT_PREC_F16);
+  if (prec == CRAFT_PREC_F16X3) GO(CRAFT_PREC_F16X3);
+#undef GO
+  return CRAFT_ERR_ARG;
+}
+
+}  // namespace craft

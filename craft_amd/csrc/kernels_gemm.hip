@@ -1,8 +1,7 @@
 // GEMM-engine instantiations with store-type epilogues:
 //   * rows x rows GEMM (nn.Linear, V^T projection, attention apply O = P V)
 //   * NHWC implicit-GEMM convolution with the update block's fused epilogues
-#include "gemm_engine.hpp"
-#include "launch.hpp"
+#include "conv_epilogue.hpp"
 
 namespace craft {
 
@@ -90,49 +89,10 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_conv(ConvGemmParams p) {
   lb.init(p.W, K, n0, p.cout, K, tid);
   gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, K / BK, acc, NoFold());
   const int rb = m0 + (wave / WN) * (BM / WM), cb = n0 + (wave % WN) * (BN / WN);
-  const int M = p.g.npix, N = p.cout;
-  switch (p.epi) {
-    case CONV_EPI_BIAS_ACT:
-      acc_foreach<MT, NT>(acc, lane, [&](int r, int c, float v, int, int, int) {
-        const int row = rb + r, col = cb + c;
-        if (row < M && col < N) {
-          v += p.bias[col];
-          if (p.act == CRAFT_ACT_RELU) v = fmaxf(v, 0.f);
-          p.out[(long)row * p.ldo + col] = v * p.scale;
-        }
-      });
-      break;
-    case CONV_EPI_GRU_ZR:   // cols [0,128): z = sigmoid -> out ; cols [128,256): r = sigmoid, rh = r*h -> aux1
-      acc_foreach<MT, NT>(acc, lane, [&](int r, int c, float v, int, int, int) {
-        const int row = rb + r, col = cb + c;
-        if (row < M && col < N) {
-          const float s = sigmoid_precise(v + p.bias[col]);
-          if (col < 128) p.out[(long)row * p.ldo + col] = s;
-          else p.aux1[(long)row * p.ld1 + (col - 128)] = s * p.aux0[(long)row * p.ld0 + (col - 128)];
-        }
-      });
-      break;
-    case CONV_EPI_GRU_Q:    // q = tanh; h' = (1-z) h + z q  (z = aux1, h = aux0; out may alias h)
-      acc_foreach<MT, NT>(acc, lane, [&](int r, int c, float v, int, int, int) {
-        const int row = rb + r, col = cb + c;
-        if (row < M && col < N) {
-          const float q = tanhf(v + p.bias[col]);
-          const float z = p.aux1[(long)row * p.ld1 + col];
-          const float h = p.aux0[(long)row * p.ld0 + col];
-          p.out[(long)row * p.ldo + col] = (1.f - z) * h + z * q;
-        }
-      });
-      break;
-    case CONV_EPI_MENC:     // cols [0,N): relu(conv) ; cols N, N+1: the 2 flow channels (update.py:86-87)
-      acc_foreach<MT, NT>(acc, lane, [&](int r, int c, float v, int, int, int) {
-        const int row = rb + r, col = cb + c;
-        if (row < M) {
-          if (col < N) p.out[(long)row * p.ldo + col] = fmaxf(v + p.bias[col], 0.f);
-          else if (col < N + 2) p.out[(long)row * p.ldo + col] = p.aux0[(long)row * p.ld0 + (col - N)];
-        }
-      });
-      break;
-  }
+  const int M = p.g.npix;
+  acc_foreach<MT, NT>(acc, lane, [&](int r, int c, float v, int, int, int) {
+    if (rb + r < M) conv_epilogue(p, (long)(rb + r), cb + c, v);
+  });
 }
 
 template <int PREC, int BN> static int launch_conv_t(const ConvGemmParams& p, hipStream_t s) {
@@ -145,6 +105,10 @@ template <int PREC, int BN> static int launch_conv_t(const ConvGemmParams& p, hi
 int launch_gemm_conv(const ConvGemmParams& p, int prec, hipStream_t s) {
   if (p.g.npix <= 0) return 0;
   if ((p.g.c0 % 32) || (p.g.c1 % 32) || (p.g.ld0 & 3) || (p.g.c1 && (p.g.ld1 & 3))) return CRAFT_ERR_ALIGN;
+  if (p.g.KH * p.g.KW > 1 && !p.force_generic) {
+    const int rc = launch_conv_halo(p, prec, s);
+    if (rc != CRAFT_ERR_UNSUPPORTED) return rc;
+  }
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   const int bn = pick_bn(ncols);
 #define GO(PR) do { if (bn == 128) return launch_conv_t<PR, 128>(p, s); else return launch_conv_t<PR, 64>(p, s); } while (0)

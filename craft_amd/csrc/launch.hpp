@@ -34,10 +34,12 @@ struct ConvGemmParams {
   float* out; int ldo;
   const float* aux0; int ld0;
   float* aux1; int ld1;
+  int force_generic;     // 1: always use the generic implicit GEMM (k_gemm_conv), for A/B tests
 };
 
 int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s);
 int launch_gemm_conv(const ConvGemmParams& p, int prec, hipStream_t s);
+int launch_conv_halo(const ConvGemmParams& p, int prec, hipStream_t s);
 
 // ---- attention / correlation (kernels_attn.hip) ----
 struct ScoreParams {
