@@ -82,7 +82,7 @@ def roofline_pv(model, B, H8, W8, prec, reps=20):
     N, M, Dv = H8 * W8, 4, 128
     ldp = ops.round_up(N, 32)
     P = torch.rand(B, M, N, ldp, device=dev, dtype=torch.float32).div_(N / 2).to(PROB_DTYPE[prec])
-    vT = torch.randn(B, M * Dv, ldp, device=dev)
+    vT = torch.randn(B, M * Dv, ldp, device=dev).to(PROB_DTYPE[prec])
     O = torch.empty(B, M, N, Dv, device=dev)
     for _ in range(3):
         ops.attn_apply(P, vT, Dv, prec, out=O)
@@ -94,7 +94,7 @@ def roofline_pv(model, B, H8, W8, prec, reps=20):
     e.record()
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / reps
-    bytes_alg = P.numel() * P.element_size() + vT.numel() * 4 + O.numel() * 4
+    bytes_alg = P.numel() * P.element_size() + vT.numel() * vT.element_size() + O.numel() * 4
     ach = bytes_alg / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "k_gemm_rows (attention apply O = P.V, aggregator shape)", "achieved": round(ach, 1),
             "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,

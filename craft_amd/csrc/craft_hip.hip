@@ -40,9 +40,11 @@ int craft_linear(const float* x, long ldx, const float* w, const float* bias, fl
   return launch_gemm_rows(p, prec, false, S(stream));
 }
 
-int craft_linear_t(const float* x, long ldx, const float* w, float* yT, long ldt, int B, int N, int cin, int cout,
-                   int prec, void* stream) {
+int craft_linear_t(const float* x, long ldx, const float* w, void* yT, long ldt, int B, int N, int cin, int cout,
+                   int out_prec, int prec, void* stream) {
+  if (out_prec < 0 || out_prec > 2) return CRAFT_ERR_ARG;
   RowsGemmParams p = {};
+  p.c_dtype = out_prec;
   p.A = w; p.lda = cin; p.B = x; p.ldb = ldx; p.b_bs0 = (long)N * ldx; p.C = yT; p.ldc = ldt; p.c_bs0 = (long)cout * ldt;
   p.zdiv = 1; p.batch = B; p.M = cout; p.N = N; p.K = cin;
   p.bias = nullptr; p.scale = 1.f; p.act = CRAFT_ACT_NONE;
@@ -94,7 +96,7 @@ int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, 
                            ldp, p_prec, prec, S(stream));
 }
 
-int craft_attn_apply(const void* P, long ldp, const float* vT, int B, int N, int M, int Dv, float* O, int prec,
+int craft_attn_apply(const void* P, long ldp, const void* vT, int B, int N, int M, int Dv, float* O, int prec,
                      void* stream) {
   RowsGemmParams p = {};
   p.A = P; p.lda = ldp; p.a_bs0 = (long)M * N * ldp; p.a_bs1 = (long)N * ldp;
@@ -102,7 +104,8 @@ int craft_attn_apply(const void* P, long ldp, const float* vT, int B, int N, int
   p.C = O; p.ldc = Dv; p.c_bs0 = (long)M * N * Dv; p.c_bs1 = (long)N * Dv;
   p.zdiv = M; p.batch = B * M; p.M = N; p.N = Dv; p.K = (int)ldp;
   p.bias = nullptr; p.scale = 1.f; p.act = CRAFT_ACT_NONE;
-  return launch_gemm_rows(p, prec, prec != CRAFT_PREC_F32, S(stream));
+  if (prec == CRAFT_PREC_F32) return launch_gemm_rows(p, prec, false, S(stream));
+  return launch_pv16(p, prec, S(stream));
 }
 
 int craft_mode_pool_ln(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff, int B, int N,

@@ -88,13 +88,15 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
 #pragma unroll
   for (int i = 0; i < BN / 32; ++i) {
     const int row = n0 + r0 + 32 * i;
-    wp[i] = (row < p.cout) ? p.W + (long)row * K + c4 * 4 : nullptr;
+    // rows beyond cout re-read the last real row: those output columns are discarded / overwritten by the
+    // epilogue, and an unconditional load keeps exec-mask branches out of the K loop
+    wp[i] = p.W + (long)min(row, p.cout - 1) * K + c4 * 4;
   }
   auto fetch_w = [&](int chunk, int tap, RegsF32<BN>& r) {
     const int koff = tap * ctot + chunk * BK;
 #pragma unroll
     for (int i = 0; i < BN / 32; ++i)
-      r.v[i] = wp[i] ? *reinterpret_cast<const float4*>(wp[i] + koff) : make_float4(0.f, 0.f, 0.f, 0.f);
+      r.v[i] = *reinterpret_cast<const float4*>(wp[i] + koff);
   };
 
   // lane's base halo rows for its MT output-row fragments

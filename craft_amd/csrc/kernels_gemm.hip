@@ -28,16 +28,118 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_rows(RowsGemmParams p) {
     la.init(reinterpret_cast<const float*>(p.A) + z0 * p.a_bs0 + z1 * p.a_bs1, p.lda, m0, p.M, p.K, tid);
     gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, acc, NoFold());
   }
-  float* C = p.C + z0 * p.c_bs0 + z1 * p.c_bs1;
+  const long cbase = z0 * p.c_bs0 + z1 * p.c_bs1;
   const int rb = m0 + (wave / WN) * (BM / WM), cb = n0 + (wave % WN) * (BN / WN);
   acc_foreach<MT, NT>(acc, lane, [&](int r, int c, float v, int, int, int) {
     const int row = rb + r, col = cb + c;
     if (row < p.M && col < p.N) {
       v *= p.scale;
       if (p.bias) v += p.bias[col];
-      C[(long)row * p.ldc + col] = act_apply(v, p.act);
+      v = act_apply(v, p.act);
+      const long o = cbase + (long)row * p.ldc + col;
+      if (p.c_dtype == CRAFT_PREC_F32) reinterpret_cast<float*>(p.C)[o] = v;
+      else if (p.c_dtype == CRAFT_PREC_BF16) reinterpret_cast<__bf16*>(p.C)[o] = (__bf16)v;
+      else reinterpret_cast<_Float16*>(p.C)[o] = (_Float16)v;
     }
   });
+}
+
+// ---------------------------------------------------------------------------------------------
+// O = P . V with BOTH operands already 16-bit in HBM (P from k_attn_probs, V^T from craft_linear_t):
+// K-tile 64, pure 16-byte copies global -> registers -> LDS (no conversion), 128 x 128 tile, fp32 out.
+// HBM-bound on P (streamed exactly once: the n-tile covers all of Dv = 128).
+// ---------------------------------------------------------------------------------------------
+template <int PREC>
+__global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
+  typedef typename PrecT<PREC>::lds_t lds_t;
+  constexpr int BM = 128, BN = 128, KT = 64, LD = 72, WN = 2, MT = 2, NT = 2;
+  constexpr int TILE = 128 * LD;
+  __shared__ __attribute__((aligned(16))) lds_t S[4 * TILE];      // A0 | A1 | B0 | B1
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
+  const int z0 = z / p.zdiv, z1 = z - z0 * p.zdiv;
+  const uint16_t* A = reinterpret_cast<const uint16_t*>(p.A) + z0 * p.a_bs0 + z1 * p.a_bs1;
+  const uint16_t* B = reinterpret_cast<const uint16_t*>(p.B) + z0 * p.b_bs0 + z1 * p.b_bs1;
+  const int c8 = tid & 7, r0 = tid >> 3;
+  const uint16_t* pa[4];
+  const uint16_t* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = m0 + r0 + 32 * i, rb_ = n0 + r0 + 32 * i;
+    pa[i] = ra < p.M ? A + (long)ra * p.lda + c8 * 8 : nullptr;
+    pb[i] = rb_ < p.N ? B + (long)rb_ * p.ldb + c8 * 8 : nullptr;
+  }
+  const int nk = (p.K + KT - 1) / KT;
+  uint4 va[4], vb[4];
+  auto fetch = [&](int kt) {
+    const bool kok = kt * KT + c8 * 8 < p.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      va[i] = (pa[i] && kok) ? *reinterpret_cast<const uint4*>(pa[i] + kt * KT) : make_uint4(0u, 0u, 0u, 0u);
+      vb[i] = (pb[i] && kok) ? *reinterpret_cast<const uint4*>(pb[i] + kt * KT) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<uint4*>(&S[buf * TILE + (r0 + 32 * i) * LD + c8 * 8]) = va[i];
+      *reinterpret_cast<uint4*>(&S[(2 + buf) * TILE + (r0 + 32 * i) * LD + c8 * 8]) = vb[i];
+    }
+  };
+  const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * 64;
+  const int r = lane & 31, g = lane >> 5;
+  f32x16 acc[MT][NT];
+  acc_zero(acc);
+  fetch(0);
+  store(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) fetch(kt + 1);
+    const lds_t* As = &S[cur * TILE];
+    const lds_t* Bs = &S[(2 + cur) * TILE];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if constexpr (PREC == CRAFT_PREC_BF16) {
+        bf16x8 a[MT], b[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(&As[(wm0 + mt * 32 + r) * LD + kk * 16 + g * 8]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const bf16x8*>(&Bs[(wn0 + nt * 32 + r) * LD + kk * 16 + g * 8]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+      } else {
+        f16x8 a[MT], b[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f16x8*>(&As[(wm0 + mt * 32 + r) * LD + kk * 16 + g * 8]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f16x8*>(&Bs[(wn0 + nt * 32 + r) * LD + kk * 16 + g * 8]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) store(cur ^ 1);
+    __syncthreads();
+  }
+  float* C = reinterpret_cast<float*>(p.C) + z0 * p.c_bs0 + z1 * p.c_bs1;
+  acc_foreach<MT, NT>(acc, lane, [&](int rr, int cc, float v, int, int, int) {
+    const int row = m0 + wm0 + rr, col = n0 + wn0 + cc;
+    if (row < p.M && col < p.N) C[(long)row * p.ldc + col] = v;
+  });
+}
+
+int launch_pv16(const RowsGemmParams& p, int prec, hipStream_t s) {
+  if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return 0;
+  if ((p.K & 7) || (p.lda & 7) || (p.ldb & 7) || p.c_dtype != CRAFT_PREC_F32) return CRAFT_ERR_ALIGN;
+  dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, p.batch);
+  if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_pv16<CRAFT_PREC_BF16>), grid, dim3(NTHREADS), 0, s, p);
+  else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_pv16<CRAFT_PREC_F16>), grid, dim3(NTHREADS), 0, s, p);
+  else return CRAFT_ERR_ARG;
+  return (int)hipGetLastError();
 }
 
 template <int PREC, int BN, bool A16> static int launch_rows_t(const RowsGemmParams& p, hipStream_t s) {

@@ -12,7 +12,8 @@
 namespace craft {
 
 struct RowsGemmParams {
-  const void* A; const void* B; float* C;
+  const void* A; const void* B; void* C;
+  int c_dtype;           // element type of C: 0 fp32, 1 bf16, 2 fp16
   long lda, ldb, ldc;
   long a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1;   // batch z -> (z / zdiv, z % zdiv) strides, in elements
   int zdiv, batch;
@@ -38,6 +39,7 @@ struct ConvGemmParams {
 };
 
 int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s);
+int launch_pv16(const RowsGemmParams& p, int prec, hipStream_t s);   // A and B both 16-bit (type = prec), C fp32
 int launch_gemm_conv(const ConvGemmParams& p, int prec, hipStream_t s);
 int launch_conv_halo(const ConvGemmParams& p, int prec, hipStream_t s);
 

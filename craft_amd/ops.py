@@ -86,13 +86,15 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], prec:
 
 
 def linear_t(x: torch.Tensor, w: torch.Tensor, ldt: int, prec: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Per-sample transposed projection: yT[b][o][n] (row stride ldt >= N, tail zero)."""
+    """Per-sample transposed projection: yT[b][o][n] (row stride ldt >= N, tail zero), stored in the
+    element type of the pv role (the type attn_apply consumes)."""
     B, N, Cin = x.shape
     _check_rows(x)
     Cout = w.shape[0]
+    pv = pick(prec, "pv")
     if out is None:
-        out = torch.zeros(B, Cout, ldt, device=x.device, dtype=torch.float32)
-    call("craft_linear_t", x, _ld(x), w.contiguous(), out, ldt, B, N, Cin, Cout, pick(prec, "proj"))
+        out = torch.zeros(B, Cout, ldt, device=x.device, dtype=PROB_DTYPE[pv])
+    call("craft_linear_t", x, _ld(x), w.contiguous(), out, ldt, B, N, Cin, Cout, pv, pick(prec, "proj"))
     return out
 
 
@@ -182,6 +184,8 @@ def attn_apply(P: torch.Tensor, vT: torch.Tensor, Dv: int, prec: int, out: Optio
     pv = pick(prec, "pv")
     if PROB_DTYPE[pv] != P.dtype:
         raise hip.CraftHipError(f"attention probabilities are {P.dtype} but the pv precision expects {PROB_DTYPE[pv]}")
+    if vT.dtype != P.dtype:
+        raise hip.CraftHipError(f"V^T is {vT.dtype} but P is {P.dtype}")
     call("craft_attn_apply", P, ldp, vT, B, N, M, Dv, out, pv)
     return out
 

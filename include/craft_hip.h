@@ -57,9 +57,10 @@ int craft_tokens_to_nchw(const float* src, long ld, int B, int C, int HW, float*
 int craft_linear(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, long rows,
                  int cin, int cout, int prec, void* stream);
 /* the same projection written transposed per sample, yT[b][o][n] with row stride ldt >= N (used for V^T,
- * setrans.py:373-378).  The caller zero-fills columns [N, ldt) once. */
-int craft_linear_t(const float* x, long ldx, const float* w, float* yT, long ldt, int B, int N, int cin,
-                   int cout, int prec, void* stream);
+ * setrans.py:373-378), stored as float (out_prec 0), bf16 (1) or fp16 (2).  The caller zero-fills columns
+ * [N, ldt) once. */
+int craft_linear_t(const float* x, long ldx, const float* w, void* yT, long ldt, int B, int N, int cin,
+                   int cout, int out_prec, int prec, void* stream);
 
 /* Global max of the raw scaled scores Q_m K_m^T * scale over batch, modes, i, j (the .max().item() of
  * setrans.py:520-521) as an order-preserving uint in *max_ord; consumers clamp to [-100, 100] iff that max
@@ -99,8 +100,9 @@ int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, 
 
 /* ExpandedFeatTrans.forward, matmul part (setrans.py:384): O[b][m][i][:] = sum_j P[b][m][i][j] * V_m[j][:],
  * with vT[b][m*Dv + c][j] (row stride ldp, zero beyond N) from craft_linear_t.  O: [B][M][N][Dv] fp32.
- * prec is both the element type of P (as written by craft_attn_probs with p_prec = prec) and the MFMA path. */
-int craft_attn_apply(const void* P, long ldp, const float* vT, int B, int N, int M, int Dv, float* O, int prec,
+ * prec (0 fp32, 1 bf16, 2 fp16) is the element type of BOTH P (craft_attn_probs with p_prec = prec) and vT
+ * (craft_linear_t with out_prec = prec), and the MFMA path. */
+int craft_attn_apply(const void* P, long ldp, const void* vT, int B, int N, int M, int Dv, float* O, int prec,
                      void* stream);
 
 /* ExpandedFeatTrans.forward tail (setrans.py:395-407): a_m = softmax_m(<O_m, w_agg>), out = LayerNorm(

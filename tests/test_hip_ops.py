@@ -78,10 +78,13 @@ def test_linear_t_and_column_views(device, prec):
     buf[..., 256:384] = gen(B, N, C, seed=5)
     w = gen(Cout, C, seed=6) / math.sqrt(C)
     ldt = ops.round_up(N, 32)
-    yT = ops.linear_t(buf.to(device)[..., 256:384], w.to(device), ldt, prec)
+    yT = ops.linear_t(buf.to(device)[..., 256:384], w.to(device), ldt, hip.Precision(proj=prec, pv=PREC_F32))
     ref = F.linear(buf[..., 256:384], w).transpose(1, 2)
     rt, at = TOL[prec]
     close(yT[..., :N], ref, rt, at, "linear_t")
+    y16 = ops.linear_t(buf.to(device)[..., 256:384], w.to(device), ldt, hip.Precision(proj=prec, pv=PREC_F16))
+    assert y16.dtype == torch.float16
+    close(y16[..., :N], ref, max(rt, 2e-3), max(at, 2e-3), "linear_t (fp16 output)")
     assert float(yT[..., N:].abs().max()) == 0.0
 
 

@@ -21,7 +21,7 @@ def main():
         ldp = ops.round_up(N, 32)
         pv = pick(prec, "pv")
         P = torch.rand(B, M, N, ldp, device=dev).div_(N / 2).to(PROB_DTYPE[pv])
-        vT = torch.randn(B, M * Dv, ldp, device=dev)
+        vT = torch.randn(B, M * Dv, ldp, device=dev).to(PROB_DTYPE[pv])
         O = torch.empty(B, M, N, Dv, device=dev)
         for _ in range(5):
             ops.attn_apply(P, vT, Dv, pv, out=O)
