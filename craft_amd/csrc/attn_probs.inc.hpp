@@ -36,8 +36,10 @@ template <int PREC, int D> struct RowTile {
     const int ch = tid % NCH, rr = tid / NCH;
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
-      const int row = row0 + rr + RPP * i;
-      r[i] = (row < nrows) ? *reinterpret_cast<const float4*>(base + (long)row * ld + ch * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      // unconditional load (rows beyond the matrix re-read the last row: such keys are masked to -inf by the
+      // caller, such queries are never written) -- a guarded load would serialise on vmcnt(0)
+      const int row = min(row0 + rr + RPP * i, nrows - 1);
+      r[i] = *reinterpret_cast<const float4*>(base + (long)row * ld + ch * 4);
     }
   }
   // registers -> LDS (convert / split as the precision requires)

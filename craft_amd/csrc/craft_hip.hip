@@ -118,6 +118,9 @@ int craft_gma_residual(const float* mf, long ldm, const float* O, const float* g
   return launch_gma_residual(mf, ldm, O, gamma, B, N, C, out, ldo, S(stream));
 }
 
+#define PREC_OF(prec) ((prec) & 0xff)
+#define PACKED_OF(prec) ((((prec) >> 8) & 1) && PREC_OF(prec) != CRAFT_PREC_F32)
+
 static ConvGemmParams conv_params(const float* in0, int ld0, int c0, const float* in1, int ld1, int c1, int B, int H8, int W8,
                                   int KH, int KW, const float* W, const float* bias, int cout, int epi, int act, float scale,
                                   float* out, int ldo) {
@@ -141,20 +144,31 @@ int craft_motion_encoder(const float* corr, long ldc, int cor_planes, const floa
     RowsGemmParams p = {};
     p.A = corr; p.lda = ldc; p.B = wc1; p.ldb = cor_planes; p.C = cor1; p.ldc = 256;
     p.zdiv = 1; p.batch = 1; p.M = (int)npix; p.N = 256; p.K = cor_planes; p.bias = bc1; p.scale = 1.f; p.act = CRAFT_ACT_RELU;
-    TRY(launch_gemm_rows(p, prec, false, s));
+    TRY(launch_gemm_rows(p, PREC_OF(prec), false, s));
   }
+  const int pk = PACKED_OF(prec);
+  prec = PREC_OF(prec);
   // cor = relu(convc2(cor))  3x3, 256 -> 192   (update.py:81)
-  TRY(launch_gemm_conv(conv_params(cor1, 256, 256, nullptr, 0, 0, B, H8, W8, 3, 3, wc2, bc2, 192, CONV_EPI_BIAS_ACT,
-                                   CRAFT_ACT_RELU, 1.f, corflo, 256), prec, s));
+  {
+    ConvGemmParams q = conv_params(cor1, 256, 256, nullptr, 0, 0, B, H8, W8, 3, 3, wc2, bc2, 192, CONV_EPI_BIAS_ACT,
+                                   CRAFT_ACT_RELU, 1.f, corflo, 256);
+    q.w_packed = pk;
+    TRY(launch_gemm_conv(q, prec, s));
+  }
   // flo = relu(convf1(flow))  7x7, 2 -> 128   (update.py:82)
   TRY(launch_convf1(flow, wf1, bf1, B, H8, W8, flo1, 128, s));
   // flo = relu(convf2(flo))  3x3, 128 -> 64   (update.py:83) -> columns 192..255 of corflo (the torch.cat of :85)
-  TRY(launch_gemm_conv(conv_params(flo1, 128, 128, nullptr, 0, 0, B, H8, W8, 3, 3, wf2, bf2, 64, CONV_EPI_BIAS_ACT,
-                                   CRAFT_ACT_RELU, 1.f, corflo + 192, 256), prec, s));
+  {
+    ConvGemmParams q = conv_params(flo1, 128, 128, nullptr, 0, 0, B, H8, W8, 3, 3, wf2, bf2, 64, CONV_EPI_BIAS_ACT,
+                                   CRAFT_ACT_RELU, 1.f, corflo + 192, 256);
+    q.w_packed = pk;
+    TRY(launch_gemm_conv(q, prec, s));
+  }
   // out = cat[relu(conv(cor_flo)) (126), flow (2)]  (update.py:86-87)
   ConvGemmParams p = conv_params(corflo, 256, 256, nullptr, 0, 0, B, H8, W8, 3, 3, wcv, bcv, 126, CONV_EPI_MENC,
                                  CRAFT_ACT_RELU, 1.f, out, (int)ldo);
   p.aux0 = flow; p.ld0 = 2;
+  p.w_packed = pk;
   return launch_gemm_conv(p, prec, s);
 }
 
@@ -169,17 +183,19 @@ int craft_sepconv_gru(float* hx, long ldhx, int cx, const float* wzr1, const flo
   const float* bzr[2] = {bzr1, bzr2};
   const float* wq[2] = {wq1, wq2};
   const float* bq[2] = {bq1, bq2};
+  const int pk = PACKED_OF(prec);
+  prec = PREC_OF(prec);
   for (int pass = 0; pass < 2; ++pass) {
     const int KH = pass == 0 ? 1 : 5, KW = pass == 0 ? 5 : 1;
     // z = sigmoid(convz(hx)), r = sigmoid(convr(hx)); rh = r*h   (update.py:51-53 / :58-60)
     ConvGemmParams a = conv_params(hx, (int)ldhx, 128 + cx, nullptr, 0, 0, B, H8, W8, KH, KW, wzr[pass], bzr[pass], 256,
                                    CONV_EPI_GRU_ZR, 0, 1.f, z, 128);
-    a.aux0 = hx; a.ld0 = (int)ldhx; a.aux1 = rh; a.ld1 = 128;
+    a.aux0 = hx; a.ld0 = (int)ldhx; a.aux1 = rh; a.ld1 = 128; a.w_packed = pk;
     TRY(launch_gemm_conv(a, prec, s));
     // q = tanh(convq(cat[r*h, x])); h = (1-z)*h + z*q   (update.py:54-55 / :61-62)
     ConvGemmParams q = conv_params(rh, 128, 128, hx + 128, (int)ldhx, cx, B, H8, W8, KH, KW, wq[pass], bq[pass], 128,
                                    CONV_EPI_GRU_Q, 0, 1.f, hx, (int)ldhx);
-    q.aux0 = hx; q.ld0 = (int)ldhx; q.aux1 = z; q.ld1 = 128;
+    q.aux0 = hx; q.ld0 = (int)ldhx; q.aux1 = z; q.ld1 = 128; q.w_packed = pk;
     TRY(launch_gemm_conv(q, prec, s));
   }
   return 0;
@@ -188,17 +204,25 @@ int craft_sepconv_gru(float* hx, long ldhx, int cx, const float* wzr1, const flo
 int craft_flow_head(const float* h, long ldh, const float* w1, const float* b1, const float* w2, const float* b2, int B,
                     int H8, int W8, float* coords1, const float* coords0, float* flow, float* delta, float* ws, int prec,
                     void* stream) {
-  TRY(launch_gemm_conv(conv_params(h, (int)ldh, 128, nullptr, 0, 0, B, H8, W8, 3, 3, w1, b1, 256, CONV_EPI_BIAS_ACT,
-                                   CRAFT_ACT_RELU, 1.f, ws, 256), prec, S(stream)));
+  ConvGemmParams q = conv_params(h, (int)ldh, 128, nullptr, 0, 0, B, H8, W8, 3, 3, w1, b1, 256, CONV_EPI_BIAS_ACT,
+                                 CRAFT_ACT_RELU, 1.f, ws, 256);
+  q.w_packed = PACKED_OF(prec);
+  TRY(launch_gemm_conv(q, PREC_OF(prec), S(stream)));
   return launch_flow_head2(ws, w2, b2, B, H8, W8, coords1, coords0, flow, delta, S(stream));
 }
 
 int craft_mask_head(const float* h, long ldh, const float* w0, const float* b0, const float* w2, const float* b2, int B,
                     int H8, int W8, float* mask, float* ws, int prec, void* stream) {
-  TRY(launch_gemm_conv(conv_params(h, (int)ldh, 128, nullptr, 0, 0, B, H8, W8, 3, 3, w0, b0, 256, CONV_EPI_BIAS_ACT,
-                                   CRAFT_ACT_RELU, 1.f, ws, 256), prec, S(stream)));
+  ConvGemmParams q = conv_params(h, (int)ldh, 128, nullptr, 0, 0, B, H8, W8, 3, 3, w0, b0, 256, CONV_EPI_BIAS_ACT,
+                                 CRAFT_ACT_RELU, 1.f, ws, 256);
+  q.w_packed = PACKED_OF(prec);
+  TRY(launch_gemm_conv(q, PREC_OF(prec), S(stream)));
   return launch_gemm_conv(conv_params(ws, 256, 256, nullptr, 0, 0, B, H8, W8, 1, 1, w2, b2, 576, CONV_EPI_BIAS_ACT,
-                                      CRAFT_ACT_NONE, 0.25f, mask, 576), prec, S(stream));
+                                      CRAFT_ACT_NONE, 0.25f, mask, 576), PREC_OF(prec), S(stream));
+}
+
+int craft_pack_weights(const float* w, long n, int prec, void* out, void* stream) {
+  return launch_pack_weights(w, n, prec, out, S(stream));
 }
 
 int craft_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, void* stream) {

@@ -49,8 +49,11 @@ template <int PREC, int BM, int BN> struct TileLds {
 // ---------------------------------------------------------------------------------------------
 // staging registers
 // ---------------------------------------------------------------------------------------------
-template <int ROWS> struct RegsF32 { float4 v[ROWS / 32]; };   // thread: k-chunk (tid&7)*4, rows (tid>>3)+32*i
-template <int ROWS> struct RegsH16 { uint4 v[ROWS / 64]; };    // thread: k-chunk (tid&3)*8, rows (tid>>2)+64*i
+// zmask: bit i set -> chunk i must be stored as zeros (K tail / conv padding).  The zeroing is applied when the
+// registers are written to LDS, NOT right after the load: a select next to the load would make the compiler
+// wait for the data immediately and lose the overlap of the global-load latency with the MFMAs.
+template <int ROWS> struct RegsF32 { float4 v[ROWS / 32]; unsigned zmask; };   // thread: k-chunk (tid&7)*4, rows (tid>>3)+32*i
+template <int ROWS> struct RegsH16 { uint4 v[ROWS / 64]; unsigned zmask; };    // thread: k-chunk (tid&3)*8, rows (tid>>2)+64*i
 
 template <int PREC, int ROWS>
 __device__ __forceinline__ void stage_store(typename PrecT<PREC>::lds_t* S, const RegsF32<ROWS>& r, int tid) {
@@ -59,21 +62,24 @@ __device__ __forceinline__ void stage_store(typename PrecT<PREC>::lds_t* S, cons
 #pragma unroll
   for (int i = 0; i < ROWS / 32; ++i) {
     const int row = r0 + 32 * i;
+    const bool z = (r.zmask >> i) & 1u;
+    float4 v;
+    v.x = z ? 0.f : r.v[i].x; v.y = z ? 0.f : r.v[i].y; v.z = z ? 0.f : r.v[i].z; v.w = z ? 0.f : r.v[i].w;
     if constexpr (PREC == CRAFT_PREC_F32) {
-      *reinterpret_cast<float4*>(&S[row * LD + c4 * 4]) = r.v[i];
+      *reinterpret_cast<float4*>(&S[row * LD + c4 * 4]) = v;
     } else if constexpr (PREC == CRAFT_PREC_BF16) {
       bf16x4 h;
-      h[0] = (__bf16)r.v[i].x; h[1] = (__bf16)r.v[i].y; h[2] = (__bf16)r.v[i].z; h[3] = (__bf16)r.v[i].w;
+      h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
       *reinterpret_cast<bf16x4*>(&S[row * LD + c4 * 4]) = h;
     } else if constexpr (PREC == CRAFT_PREC_F16) {
       f16x4 h;
-      h[0] = (_Float16)r.v[i].x; h[1] = (_Float16)r.v[i].y; h[2] = (_Float16)r.v[i].z; h[3] = (_Float16)r.v[i].w;
+      h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
       *reinterpret_cast<f16x4*>(&S[row * LD + c4 * 4]) = h;
     } else {   // F16X3: hi plane, then lo plane at + ROWS*LD
       f16x4 h, l;
-      h[0] = (_Float16)r.v[i].x; h[1] = (_Float16)r.v[i].y; h[2] = (_Float16)r.v[i].z; h[3] = (_Float16)r.v[i].w;
-      l[0] = (_Float16)(r.v[i].x - (float)h[0]); l[1] = (_Float16)(r.v[i].y - (float)h[1]);
-      l[2] = (_Float16)(r.v[i].z - (float)h[2]); l[3] = (_Float16)(r.v[i].w - (float)h[3]);
+      h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+      l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
+      l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
       *reinterpret_cast<f16x4*>(&S[row * LD + c4 * 4]) = h;
       *reinterpret_cast<f16x4*>(&S[(ROWS + row) * LD + c4 * 4]) = l;
     }
@@ -87,7 +93,10 @@ __device__ __forceinline__ void stage_store(typename PrecT<PREC>::lds_t* S, cons
 #pragma unroll
   for (int i = 0; i < ROWS / 64; ++i) {
     const int row = r0 + 64 * i;
-    *reinterpret_cast<uint4*>(&S[row * LD + c8 * 8]) = r.v[i];
+    const bool z = (r.zmask >> i) & 1u;
+    uint4 v;
+    v.x = z ? 0u : r.v[i].x; v.y = z ? 0u : r.v[i].y; v.z = z ? 0u : r.v[i].z; v.w = z ? 0u : r.v[i].w;
+    *reinterpret_cast<uint4*>(&S[row * LD + c8 * 8]) = v;
   }
 }
 
@@ -96,6 +105,11 @@ __device__ __forceinline__ void stage_store(typename PrecT<PREC>::lds_t* S, cons
 // ---------------------------------------------------------------------------------------------
 // Plain fp32 rows: element (row, k) at base[row*ld + k]; rows >= nrows and k >= K read as zero.
 // Requirements: base 16-B aligned, ld % 4 == 0, K % 4 == 0.
+// NOTE on predication: a load guarded by a per-lane condition ("valid ? *p : 0") makes hipcc branch around
+// the load and wait vmcnt(0) right behind it, serialising every load of the tile.  All loaders therefore load
+// UNCONDITIONALLY from a clamped, always-valid address; out-of-range rows re-read the last valid row (their
+// products only reach output rows / columns that the epilogues discard) and the K tail is zeroed by a value
+// select after the load.
 template <int ROWS> struct LoaderRowsF32 {
   typedef RegsF32<ROWS> Regs;
   const float* p[ROWS / 32];
@@ -105,17 +119,17 @@ template <int ROWS> struct LoaderRowsF32 {
     kcol = (tid & 7) * 4;
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
-      const int row = row0 + (tid >> 3) + 32 * i;
-      p[i] = (row < nrows) ? base + (long)row * ld + kcol : nullptr;
+      const int row = min(row0 + (tid >> 3) + 32 * i, nrows - 1);
+      p[i] = base + (long)row * ld;
     }
   }
   __device__ __forceinline__ void fetch(int kt, Regs& r) const {
-    const bool kok = kt * BK + kcol < K;
+    const int k = kt * BK + kcol;
+    const bool kok = k < K;
+    const int kc = kok ? k : K - 4;
+    r.zmask = kok ? 0u : 0xffffffffu;
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-      if (p[i] != nullptr && kok) r.v[i] = *reinterpret_cast<const float4*>(p[i] + kt * BK);
-      else r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int i = 0; i < ROWS / 32; ++i) r.v[i] = *reinterpret_cast<const float4*>(p[i] + kc);
   }
 };
 
@@ -129,17 +143,17 @@ template <int ROWS> struct LoaderRowsH16 {
     kcol = (tid & 3) * 8;
 #pragma unroll
     for (int i = 0; i < ROWS / 64; ++i) {
-      const int row = row0 + (tid >> 2) + 64 * i;
-      p[i] = (row < nrows) ? base + (long)row * ld + kcol : nullptr;
+      const int row = min(row0 + (tid >> 2) + 64 * i, nrows - 1);
+      p[i] = base + (long)row * ld;
     }
   }
   __device__ __forceinline__ void fetch(int kt, Regs& r) const {
-    const bool kok = kt * BK + kcol < K;
+    const int k = kt * BK + kcol;
+    const bool kok = k < K;
+    const int kc = kok ? k : K - 8;
+    r.zmask = kok ? 0u : 0xffffffffu;
 #pragma unroll
-    for (int i = 0; i < ROWS / 64; ++i) {
-      if (p[i] != nullptr && kok) r.v[i] = *reinterpret_cast<const uint4*>(p[i] + kt * BK);
-      else r.v[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
+    for (int i = 0; i < ROWS / 64; ++i) r.v[i] = *reinterpret_cast<const uint4*>(p[i] + kc);
   }
 };
 
@@ -183,14 +197,16 @@ template <int ROWS> struct LoaderConvF32 {
     const int dy = ty - g.padH, dx = (tap - ty * g.KW) - g.padW;
     const float* sp; int ld, c;
     if (cb < g.c0) { sp = g.seg0; ld = g.ld0; c = cb; } else { sp = g.seg1; ld = g.ld1; c = cb - g.c0; }
+    unsigned zm = 0u;
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
       const int yy = py[i] + dy, xx = px[i] + dx;
-      if (yy >= 0 && yy < g.H && xx >= 0 && xx < g.W)
-        r.v[i] = *reinterpret_cast<const float4*>(sp + (pimg[i] + (long)yy * g.W + xx) * ld + c + kcol);
-      else
-        r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+      const long pix = ok ? pimg[i] + (long)yy * g.W + xx : 0;      // unconditional load from a valid address
+      zm |= ok ? 0u : (1u << i);
+      r.v[i] = *reinterpret_cast<const float4*>(sp + pix * ld + c + kcol);
     }
+    r.zmask = zm;
   }
 };
 

@@ -14,7 +14,7 @@ namespace craft {
 
 constexpr int PATCH_H = 8, PATCH_W = 16;
 
-template <int PREC, int BN>
+template <int PREC, int BN, bool WPACK>
 __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
   typedef typename PrecT<PREC>::lds_t lds_t;
   constexpr int LD = PrecT<PREC>::LD, PL = Planes<PREC>::N;
@@ -50,53 +50,88 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
     const int y = y0 - g.padH + hy, x = x0 - g.padW + hx;
     hpix[i] = (hr < HR && y >= 0 && y < g.H && x >= 0 && x < g.W) ? y * g.W + x : -1;
   }
-  auto fetch_halo = [&](int chunk, float4 (&r)[NA]) {
+  auto fetch_halo = [&](int chunk, float4 (&r)[NA]) __attribute__((always_inline)) {
     const int cb = chunk * BK;
     const float* sp; int ld, c;
     if (cb < g.c0) { sp = g.seg0; ld = g.ld0; c = cb; } else { sp = g.seg1; ld = g.ld1; c = cb - g.c0; }
+    // unconditional loads (clamped pixel); out-of-image taps are zeroed by a value select in store_halo
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
-      r[i] = (hpix[i] >= 0) ? *reinterpret_cast<const float4*>(sp + (img + hpix[i]) * ld + c + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < NA; ++i) r[i] = *reinterpret_cast<const float4*>(sp + (img + max(hpix[i], 0)) * ld + c + c4 * 4);
   };
-  auto store_halo = [&](const float4 (&r)[NA]) {
+  auto store_halo = [&](const float4 (&r)[NA]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int row = r0 + 32 * i;
       if (row >= HR) continue;
+      const bool ok = hpix[i] >= 0;
+      float4 v;
+      v.x = ok ? r[i].x : 0.f; v.y = ok ? r[i].y : 0.f; v.z = ok ? r[i].z : 0.f; v.w = ok ? r[i].w : 0.f;
       if constexpr (PREC == CRAFT_PREC_F32) {
-        *reinterpret_cast<float4*>(&As[row * LD + c4 * 4]) = r[i];
+        *reinterpret_cast<float4*>(&As[row * LD + c4 * 4]) = v;
       } else if constexpr (PREC == CRAFT_PREC_BF16) {
         bf16x4 h;
-        h[0] = (__bf16)r[i].x; h[1] = (__bf16)r[i].y; h[2] = (__bf16)r[i].z; h[3] = (__bf16)r[i].w;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
         *reinterpret_cast<bf16x4*>(&As[row * LD + c4 * 4]) = h;
       } else {
         f16x4 h;
-        h[0] = (_Float16)r[i].x; h[1] = (_Float16)r[i].y; h[2] = (_Float16)r[i].z; h[3] = (_Float16)r[i].w;
+        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
         *reinterpret_cast<f16x4*>(&As[row * LD + c4 * 4]) = h;
         if constexpr (PREC == CRAFT_PREC_F16X3) {
           f16x4 l;
-          l[0] = (_Float16)(r[i].x - (float)h[0]); l[1] = (_Float16)(r[i].y - (float)h[1]);
-          l[2] = (_Float16)(r[i].z - (float)h[2]); l[3] = (_Float16)(r[i].w - (float)h[3]);
+          l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
+          l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
           *reinterpret_cast<f16x4*>(&As[(HR_MAX + row) * LD + c4 * 4]) = l;
         }
       }
     }
   };
 
-  // ---- weight tile loader: rows = output channels n0.., k = tap*ctot + chunk*32 .. +32
+  // ---- weight tile loader: rows = output channels n0.., k = tap*ctot + chunk*32 .. +32.  Rows beyond cout
+  // re-read the last real row: those output columns are discarded / overwritten by the epilogue, and an
+  // unconditional load keeps exec-mask branches out of the K loop.
+  constexpr int NV = WPACK ? PL * (BN / 64) : 1;      // uint4 per thread for one packed weight tile
   const float* wp[BN / 32];
+  const uint16_t* wq[PL * (BN / 64)];
+  if constexpr (WPACK) {
+    const uint16_t* W16 = reinterpret_cast<const uint16_t*>(p.W);
 #pragma unroll
-  for (int i = 0; i < BN / 32; ++i) {
-    const int row = n0 + r0 + 32 * i;
-    // rows beyond cout re-read the last real row: those output columns are discarded / overwritten by the
-    // epilogue, and an unconditional load keeps exec-mask branches out of the K loop
-    wp[i] = p.W + (long)min(row, p.cout - 1) * K + c4 * 4;
+    for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+      for (int i = 0; i < BN / 64; ++i) {
+        const int row = n0 + (tid >> 2) + 64 * i;
+        wq[pl * (BN / 64) + i] = W16 + ((long)pl * p.cout + min(row, p.cout - 1)) * K + (tid & 3) * 8;
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < BN / 32; ++i) {
+      const int row = n0 + r0 + 32 * i;
+      wp[i] = p.W + (long)min(row, p.cout - 1) * K + c4 * 4;
+    }
   }
-  auto fetch_w = [&](int chunk, int tap, RegsF32<BN>& r) {
+  RegsF32<BN> rbf;
+  rbf.zmask = 0u;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 rbv[NV];
+  auto fetch_w = [&](int chunk, int tap) __attribute__((always_inline)) {
     const int koff = tap * ctot + chunk * BK;
+    if constexpr (WPACK) {
 #pragma unroll
-    for (int i = 0; i < BN / 32; ++i)
-      r.v[i] = *reinterpret_cast<const float4*>(wp[i] + koff);
+      for (int i = 0; i < NV; ++i) rbv[i] = *reinterpret_cast<const u32x4*>(wq[i] + koff);
+    } else {
+#pragma unroll
+      for (int i = 0; i < BN / 32; ++i) rbf.v[i] = *reinterpret_cast<const float4*>(wp[i] + koff);
+    }
+  };
+  auto store_w = [&](int buf) __attribute__((always_inline)) {
+    if constexpr (WPACK) {
+#pragma unroll
+      for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+        for (int i = 0; i < BN / 64; ++i)
+          *reinterpret_cast<u32x4*>(&Bs[buf * B_ELEMS + (pl * BN + (tid >> 2) + 64 * i) * LD + (tid & 3) * 8]) = rbv[pl * (BN / 64) + i];
+    } else {
+      stage_store<PREC>(&Bs[buf * B_ELEMS], rbf, tid);
+    }
   };
 
   // lane's base halo rows for its MT output-row fragments
@@ -111,26 +146,17 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
   f32x16 acc[MT][NT];
   acc_zero(acc);
   float4 ra[NA];
-  RegsF32<BN> rb;
+  const int nk = nchunk * T;
   fetch_halo(0, ra);
-  fetch_w(0, 0, rb);
+  fetch_w(0, 0);
   store_halo(ra);
-  stage_store<PREC>(&Bs[0], rb, tid);
+  store_w(0);
   __syncthreads();
 
-  const int nk = nchunk * T;
   int chunk = 0, tap = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    int nchunk_i = chunk, ntap = tap + 1;
-    if (ntap == T) { ntap = 0; nchunk_i = chunk + 1; }
-    const bool has_next = kt + 1 < nk;
-    if (has_next) fetch_w(nchunk_i, ntap, rb);
-    if (tap == 0 && chunk + 1 < nchunk) fetch_halo(chunk + 1, ra);     // lands during this chunk's taps
-
-    // ---- MFMAs for (chunk, tap): A rows shifted by the tap
-    const int ty_ = tap / KW;
-    const int toff = ty_ * HWd + (tap - ty_ * KW);
-    const lds_t* Bc = &Bs[(kt & 1) * B_ELEMS];
+  // MFMAs of one K-tile: weight buffer `buf`, activation rows shifted by the tap offset `toff`
+  auto mma_step = [&](int buf, int toff) __attribute__((always_inline)) {
+    const lds_t* Bc = &Bs[buf * B_ELEMS];
     if constexpr (PREC == CRAFT_PREC_F32) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
@@ -176,26 +202,39 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
           bh[nt] = *reinterpret_cast<const f16x8*>(&Bc[(wn0 + nt * 32 + (lane & 31)) * LD + kk * 16 + g8 * 8]);
           if constexpr (PREC == CRAFT_PREC_F16X3) bl[nt] = *reinterpret_cast<const f16x8*>(&Bc[(BN + wn0 + nt * 32 + (lane & 31)) * LD + kk * 16 + g8 * 8]);
         }
+        // term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent chain)
+        if constexpr (PREC == CRAFT_PREC_F16X3) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            if constexpr (PREC == CRAFT_PREC_F16X3) {
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-            }
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-          }
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
       }
     }
 
-    if (has_next) stage_store<PREC>(&Bs[((kt + 1) & 1) * B_ELEMS], rb, tid);
+  };
+  for (int kt = 0; kt < nk; ++kt) {
+    int c1 = chunk, t1 = tap + 1;
+    if (t1 == T) { t1 = 0; c1 = chunk + 1; }
+    const bool has_next = kt + 1 < nk;
+    if (has_next) fetch_w(c1, t1);
+    if (tap == 0 && chunk + 1 < nchunk) fetch_halo(chunk + 1, ra);     // lands during this chunk's taps
+    { const int ty_ = tap / KW; mma_step(kt & 1, ty_ * HWd + (tap - ty_ * KW)); }
+    if (has_next) store_w((kt + 1) & 1);
     __syncthreads();
-    if (has_next && ntap == 0) {          // chunk boundary: every wave is done with the halo tile
+    if (has_next && t1 == 0) {            // chunk boundary: every wave is done with the halo tile
       store_halo(ra);
       __syncthreads();
     }
-    chunk = nchunk_i; tap = ntap;
+    chunk = c1; tap = t1;
   }
 
   // ---- epilogue: GEMM row r of the patch -> token (y0 + r/16, x0 + r%16)
@@ -213,11 +252,11 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
       }
 }
 
-template <int PREC, int BN> static int launch_halo_t(const ConvGemmParams& p, hipStream_t s) {
+template <int PREC, int BN, bool WPACK> static int launch_halo_t(const ConvGemmParams& p, hipStream_t s) {
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   const int tiles = ((p.g.W + PATCH_W - 1) / PATCH_W) * ((p.g.H + PATCH_H - 1) / PATCH_H) * (p.g.npix / (p.g.H * p.g.W));
   dim3 grid(tiles, (ncols + BN - 1) / BN, 1);
-  hipLaunchKernelGGL((k_conv_halo<PREC, BN>), grid, dim3(NTHREADS), 0, s, p);
+  hipLaunchKernelGGL((k_conv_halo<PREC, BN, WPACK>), grid, dim3(NTHREADS), 0, s, p);
   return (int)hipGetLastError();
 }
 
@@ -226,13 +265,43 @@ int launch_conv_halo(const ConvGemmParams& p, int prec, hipStream_t s) {
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   // BN = 128 only when that still leaves >= 2 blocks per CU's worth of tiles for wide outputs
   const int bn = (ncols % 128 == 0 && ncols >= 256) ? 128 : 64;
-#define GO(PR) do { if (bn == 128) return launch_halo_t<PR, 128>(p, s); else return launch_halo_t<PR, 64>(p, s); } while (0)
-  if (prec == CRAFT_PREC_F32) GO(CRAFT_PREC_F32);
-  if (prec == CRAFT_PREC_BF16) GO(CRAFT_PREC_BF16);
-  if (prec == CRAFT_PREC_F16) GO(CRAFT_PREC_F16);
-  if (prec == CRAFT_PREC_F16X3) GO(CRAFT_PREC_F16X3);
+  if (p.w_packed && ((p.g.c0 + p.g.c1) * p.g.KH * p.g.KW) % 8) return CRAFT_ERR_ALIGN;
+#define GO(PR, WP) do { if (bn == 128) return launch_halo_t<PR, 128, WP>(p, s); else return launch_halo_t<PR, 64, WP>(p, s); } while (0)
+  if (prec == CRAFT_PREC_F32) GO(CRAFT_PREC_F32, false);      // packed == raw for fp32
+  if (prec == CRAFT_PREC_BF16) { if (p.w_packed) GO(CRAFT_PREC_BF16, true); else GO(CRAFT_PREC_BF16, false); }
+  if (prec == CRAFT_PREC_F16) { if (p.w_packed) GO(CRAFT_PREC_F16, true); else GO(CRAFT_PREC_F16, false); }
+  if (prec == CRAFT_PREC_F16X3) { if (p.w_packed) GO(CRAFT_PREC_F16X3, true); else GO(CRAFT_PREC_F16X3, false); }
 #undef GO
   return CRAFT_ERR_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------
+// craft_pack_weights: fp32 [rows][K] -> the LDS element type of `prec`: bf16 / fp16 [rows][K], or for F16X3
+// two fp16 planes [2][rows][K] (hi = fp16(w), lo = fp16(w - hi)); fp32 is a plain copy.
+// ---------------------------------------------------------------------------------------------
+template <int PREC>
+__global__ void k_pack_weights(const float* __restrict__ w, long n, void* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = w[i];
+  if constexpr (PREC == CRAFT_PREC_F32) reinterpret_cast<float*>(out)[i] = v;
+  else if constexpr (PREC == CRAFT_PREC_BF16) reinterpret_cast<__bf16*>(out)[i] = (__bf16)v;
+  else {
+    const _Float16 h = (_Float16)v;
+    reinterpret_cast<_Float16*>(out)[i] = h;
+    if constexpr (PREC == CRAFT_PREC_F16X3) reinterpret_cast<_Float16*>(out)[n + i] = (_Float16)(v - (float)h);
+  }
+}
+
+int launch_pack_weights(const float* w, long n, int prec, void* out, hipStream_t s) {
+  if (n <= 0) return 0;
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (prec == CRAFT_PREC_F32) hipLaunchKernelGGL((k_pack_weights<CRAFT_PREC_F32>), grid, dim3(256), 0, s, w, n, out);
+  else if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_pack_weights<CRAFT_PREC_BF16>), grid, dim3(256), 0, s, w, n, out);
+  else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_pack_weights<CRAFT_PREC_F16>), grid, dim3(256), 0, s, w, n, out);
+  else if (prec == CRAFT_PREC_F16X3) hipLaunchKernelGGL((k_pack_weights<CRAFT_PREC_F16X3>), grid, dim3(256), 0, s, w, n, out);
+  else return CRAFT_ERR_ARG;
+  return (int)hipGetLastError();
 }
 
 }  // namespace craft

@@ -65,25 +65,30 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
   const uint16_t* pb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int ra = m0 + r0 + 32 * i, rb_ = n0 + r0 + 32 * i;
-    pa[i] = ra < p.M ? A + (long)ra * p.lda + c8 * 8 : nullptr;
-    pb[i] = rb_ < p.N ? B + (long)rb_ * p.ldb + c8 * 8 : nullptr;
+    const int ra = min(m0 + r0 + 32 * i, p.M - 1), rb_ = min(n0 + r0 + 32 * i, p.N - 1);   // clamped: unconditional loads
+    pa[i] = A + (long)ra * p.lda;
+    pb[i] = B + (long)rb_ * p.ldb;
   }
   const int nk = (p.K + KT - 1) / KT;
-  uint4 va[4], vb[4];
-  auto fetch = [&](int kt) {
-    const bool kok = kt * KT + c8 * 8 < p.K;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 va[4], vb[4];
+  bool kzero = false;
+  auto fetch = [&](int kt) __attribute__((always_inline)) {
+    const int k = kt * KT + c8 * 8;
+    const bool kok = k < p.K;
+    const int kc = kok ? k : p.K - 8;
+    kzero = !kok;                 // applied in store(): a select here would stall on the loads
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      va[i] = (pa[i] && kok) ? *reinterpret_cast<const uint4*>(pa[i] + kt * KT) : make_uint4(0u, 0u, 0u, 0u);
-      vb[i] = (pb[i] && kok) ? *reinterpret_cast<const uint4*>(pb[i] + kt * KT) : make_uint4(0u, 0u, 0u, 0u);
+      va[i] = *reinterpret_cast<const u32x4*>(pa[i] + kc);
+      vb[i] = *reinterpret_cast<const u32x4*>(pb[i] + kc);
     }
   };
-  auto store = [&](int buf) {
+  auto store = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4*>(&S[buf * TILE + (r0 + 32 * i) * LD + c8 * 8]) = va[i];
-      *reinterpret_cast<uint4*>(&S[(2 + buf) * TILE + (r0 + 32 * i) * LD + c8 * 8]) = vb[i];
+      *reinterpret_cast<u32x4*>(&S[buf * TILE + (r0 + 32 * i) * LD + c8 * 8]) = kzero ? u32x4{0u, 0u, 0u, 0u} : va[i];
+      *reinterpret_cast<u32x4*>(&S[(2 + buf) * TILE + (r0 + 32 * i) * LD + c8 * 8]) = kzero ? u32x4{0u, 0u, 0u, 0u} : vb[i];
     }
   };
   const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * 64;
@@ -211,6 +216,7 @@ int launch_gemm_conv(const ConvGemmParams& p, int prec, hipStream_t s) {
     const int rc = launch_conv_halo(p, prec, s);
     if (rc != CRAFT_ERR_UNSUPPORTED) return rc;
   }
+  if (p.w_packed) return CRAFT_ERR_UNSUPPORTED;     // the generic implicit GEMM reads raw fp32 weights
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   const int bn = pick_bn(ncols);
 #define GO(PR) do { if (bn == 128) return launch_conv_t<PR, 128>(p, s); else return launch_conv_t<PR, 64>(p, s); } while (0)

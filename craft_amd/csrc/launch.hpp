@@ -36,12 +36,14 @@ struct ConvGemmParams {
   const float* aux0; int ld0;
   float* aux1; int ld1;
   int force_generic;     // 1: always use the generic implicit GEMM (k_gemm_conv), for A/B tests
+  int w_packed;          // 1: W was produced by craft_pack_weights for this precision (halo kernel only)
 };
 
 int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s);
 int launch_pv16(const RowsGemmParams& p, int prec, hipStream_t s);   // A and B both 16-bit (type = prec), C fp32
 int launch_gemm_conv(const ConvGemmParams& p, int prec, hipStream_t s);
 int launch_conv_halo(const ConvGemmParams& p, int prec, hipStream_t s);
+int launch_pack_weights(const float* w, long n, int prec, void* out, hipStream_t s);
 
 // ---- attention / correlation (kernels_attn.hip) ----
 struct ScoreParams {

@@ -231,6 +231,18 @@ def pack_conv(w: torch.Tensor) -> torch.Tensor:
     return w.detach().permute(0, 2, 3, 1).contiguous().float()
 
 
+def pack_conv_prec(w: torch.Tensor, prec: int) -> torch.Tensor:
+    """[Cout, Cin, KH, KW] -> [Cout, KH, KW, Cin] in the MFMA operand type of ``prec`` (craft_pack_weights):
+    fp32 as is, bf16 / fp16, or two fp16 planes [2, Cout, KH, KW, Cin] for f16x3."""
+    wp = pack_conv(w)
+    if prec == PREC_F32:
+        return wp
+    planes = 2 if prec == hip.PREC_F16X3 else 1
+    out = torch.empty((planes,) + tuple(wp.shape), device=w.device, dtype=torch.bfloat16 if prec == hip.PREC_BF16 else torch.float16)
+    call("craft_pack_weights", wp, wp.numel(), prec, out)
+    return out
+
+
 def pack_convf1(w: torch.Tensor) -> torch.Tensor:
     """[128, 2, 7, 7] -> [7*7*2, 128] (tap-major, output channel contiguous)."""
     return w.detach().permute(2, 3, 1, 0).reshape(-1, w.shape[0]).contiguous().float()

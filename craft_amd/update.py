@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import ops
 from .gma import Aggregate
-from .hip import PREC_F32, call, pick
+from .hip import PREC_F32, W_PACKED, call, pick
 from .setrans import ExpandedFeatTrans
 
 
@@ -26,8 +26,8 @@ class _PackCache:
         self._key = None
         self._val = None
 
-    def get(self, params, fn):
-        key = tuple((p.data_ptr(), p._version, p.device) for p in params)
+    def get(self, params, fn, tag=0):
+        key = (tag,) + tuple((p.data_ptr(), p._version, p.device) for p in params)
         if key != self._key:
             with torch.no_grad():
                 self._val = fn()
@@ -42,10 +42,10 @@ class FlowHead(nn.Module):
         self.conv2 = nn.Conv2d(hidden_dim, 2, 3, padding=1)
         self._pk = _PackCache()
 
-    def packed(self):
+    def packed(self, prec: int = PREC_F32):
         return self._pk.get([self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias],
-                            lambda: (ops.pack_conv(self.conv1.weight), self.conv1.bias.detach().float().contiguous(),
-                                     ops.pack_conv(self.conv2.weight), self.conv2.bias.detach().float().contiguous()))
+                            lambda: (ops.pack_conv_prec(self.conv1.weight, prec), self.conv1.bias.detach().float().contiguous(),
+                                     ops.pack_conv(self.conv2.weight), self.conv2.bias.detach().float().contiguous()), tag=prec)
 
 
 class SepConvGRU(nn.Module):
@@ -61,26 +61,27 @@ class SepConvGRU(nn.Module):
         self.convq2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
         self._pk = _PackCache()
 
-    def packed(self):
+    def packed(self, prec: int = PREC_F32):
         mods = [self.convz1, self.convr1, self.convq1, self.convz2, self.convr2, self.convq2]
         params = [p for m in mods for p in (m.weight, m.bias)]
 
         def make():
             out = []
             for z, r, q in ((self.convz1, self.convr1, self.convq1), (self.convz2, self.convr2, self.convq2)):
-                out += [ops.pack_conv(torch.cat([z.weight, r.weight], 0)),
+                out += [ops.pack_conv_prec(torch.cat([z.weight, r.weight], 0), prec),
                         torch.cat([z.bias, r.bias], 0).detach().float().contiguous(),
-                        ops.pack_conv(q.weight), q.bias.detach().float().contiguous()]
+                        ops.pack_conv_prec(q.weight, prec), q.bias.detach().float().contiguous()]
             return tuple(out)
-        return self._pk.get(params, make)
+        return self._pk.get(params, make, tag=prec)
 
     def forward_tokens(self, hx: torch.Tensor, hw, ws: torch.Tensor, prec: int):
         """In place on hx = [h (128) | x (input_dim)] tokens [B, N, 128+input_dim]."""
         B, N, _ = hx.shape
         H8, W8 = hw
-        wzr1, bzr1, wq1, bq1, wzr2, bzr2, wq2, bq2 = self.packed()
+        cp = pick(prec, "conv")
+        wzr1, bzr1, wq1, bq1, wzr2, bzr2, wq2, bq2 = self.packed(cp)
         call("craft_sepconv_gru", hx, hx.stride(1), self.input_dim, wzr1, bzr1, wq1, bq1, wzr2, bzr2, wq2, bq2, B, H8, W8,
-             ws, pick(prec, "conv"))
+             ws, cp | W_PACKED)
 
 
 class BasicMotionEncoder(nn.Module):
@@ -95,25 +96,26 @@ class BasicMotionEncoder(nn.Module):
         self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
         self._pk = _PackCache()
 
-    def packed(self):
+    def packed(self, prec: int = PREC_F32):
         mods = [self.convc1, self.convc2, self.convf1, self.convf2, self.conv]
         params = [p for m in mods for p in (m.weight, m.bias)]
 
         def b(m):
             return m.bias.detach().float().contiguous()
         return self._pk.get(params, lambda: (self.convc1.weight.detach().view(256, -1).float().contiguous(), b(self.convc1),
-                                             ops.pack_conv(self.convc2.weight), b(self.convc2),
+                                             ops.pack_conv_prec(self.convc2.weight, prec), b(self.convc2),
                                              ops.pack_convf1(self.convf1.weight), b(self.convf1),
-                                             ops.pack_conv(self.convf2.weight), b(self.convf2),
-                                             ops.pack_conv(self.conv.weight), b(self.conv)))
+                                             ops.pack_conv_prec(self.convf2.weight, prec), b(self.convf2),
+                                             ops.pack_conv_prec(self.conv.weight, prec), b(self.conv)), tag=prec)
 
     def forward_tokens(self, flow: torch.Tensor, corr: torch.Tensor, hw, out: torch.Tensor, ws: torch.Tensor, prec: int):
         """flow tokens [B,N,2], corr tokens [B,N,cor_planes] -> out tokens view [B,N,128]."""
         B, N, _ = flow.shape
         H8, W8 = hw
-        wc1, bc1, wc2, bc2, wf1, bf1, wf2, bf2, wcv, bcv = self.packed()
+        cp = pick(prec, "conv")
+        wc1, bc1, wc2, bc2, wf1, bf1, wf2, bf2, wcv, bcv = self.packed(cp)
         call("craft_motion_encoder", corr, corr.stride(1), self.cor_planes, flow, wc1, bc1, wc2, bc2, wf1, bf1, wf2, bf2,
-             wcv, bcv, B, H8, W8, out, out.stride(1), ws, pick(prec, "conv"))
+             wcv, bcv, B, H8, W8, out, out.stride(1), ws, cp | W_PACKED)
 
 
 class GMAUpdateBlock(nn.Module):
@@ -132,12 +134,12 @@ class GMAUpdateBlock(nn.Module):
             self.aggregator = Aggregate(args=args, dim=128, dim_head=128, heads=args.num_heads)
         self._pk_mask = _PackCache()
 
-    def packed_mask(self):
+    def packed_mask(self, prec: int = PREC_F32):
         m0, m2 = self.mask[0], self.mask[2]
         return self._pk_mask.get([m0.weight, m0.bias, m2.weight, m2.bias],
-                                 lambda: (ops.pack_conv(m0.weight), m0.bias.detach().float().contiguous(),
+                                 lambda: (ops.pack_conv_prec(m0.weight, prec), m0.bias.detach().float().contiguous(),
                                           m2.weight.detach().view(576, -1).float().contiguous(),
-                                          m2.bias.detach().float().contiguous()))
+                                          m2.bias.detach().float().contiguous()), tag=prec)
 
     # -- token-level steps used by CRAFT.forward ---------------------------------------------------
     def step_tokens(self, hx, corr, flow, attention, hw, ws, prec):
@@ -153,16 +155,18 @@ class GMAUpdateBlock(nn.Module):
 
     def flow_head_tokens(self, hx, hw, coords1, coords0, flow, delta, ws, prec):
         B, N, _ = hx.shape
-        w1, b1, w2, b2 = self.flow_head.packed()
+        cp = pick(prec, "conv")
+        w1, b1, w2, b2 = self.flow_head.packed(cp)
         call("craft_flow_head", hx, hx.stride(1), w1, b1, w2, b2, B, hw[0], hw[1], coords1, coords0, flow, delta, ws,
-             pick(prec, "conv"))
+             cp | W_PACKED)
 
     def mask_tokens(self, hx, hw, ws, prec, out: Optional[torch.Tensor] = None):
         B, N, _ = hx.shape
         if out is None:
             out = torch.empty(B, N, 576, device=hx.device, dtype=torch.float32)
-        w0, b0, w2, b2 = self.packed_mask()
-        call("craft_mask_head", hx, hx.stride(1), w0, b0, w2, b2, B, hw[0], hw[1], out, ws, pick(prec, "conv"))
+        cp = pick(prec, "conv")
+        w0, b0, w2, b2 = self.packed_mask(cp)
+        call("craft_mask_head", hx, hx.stride(1), w0, b0, w2, b2, B, hw[0], hw[1], out, ws, cp | W_PACKED)
         return out
 
     @staticmethod

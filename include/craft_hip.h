@@ -114,6 +114,14 @@ int craft_mode_pool_ln(const float* O, const float* x, long ldx, const float* w_
 int craft_gma_residual(const float* mf, long ldm, const float* O, const float* gamma, int B, int N, int C,
                        float* out, long ldo, void* stream);
 
+/* Pre-pack a conv weight [rows][K] (already laid out [Cout][KH][KW][Cin]) into the MFMA operand type of `prec`:
+ * fp32 -> copy; bf16 / fp16 -> 16-bit [rows][K]; F16X3 -> two fp16 planes [2][rows][K] (hi, lo).  `n` = rows*K;
+ * `out` holds n * {4, 2, 2, 4} bytes.  Operators below accept such buffers for their KxK convolutions (NOT the
+ * 1x1 / tiny convs: wc1, wf1, flow-head w2, mask-head w2 stay raw fp32) when CRAFT_W_PACKED is or-ed into prec;
+ * the K loop then stages weights with pure 16-byte copies. */
+#define CRAFT_W_PACKED 0x100
+int craft_pack_weights(const float* w, long n, int prec, void* out, void* stream);
+
 /* BasicMotionEncoder.forward (update.py:79-87).  corr tokens [B*N][cor_planes] (row stride ldc), flow tokens
  * [B*N][2].  Conv weights are packed [Cout][KH][KW][Cin] (weight.permute(0,2,3,1)); wf1 is packed
  * [7*7*2][128] (weight.permute(2,3,1,0)).  Output: 128 channels (126 conv + 2 flow) at out (row stride ldo).
