@@ -146,7 +146,6 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
   f32x16 acc[MT][NT];
   acc_zero(acc);
   float4 ra[NA];
-  const int nk = nchunk * T;
   fetch_halo(0, ra);
   fetch_w(0, 0);
   store_halo(ra);
@@ -221,20 +220,24 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
     }
 
   };
-  for (int kt = 0; kt < nk; ++kt) {
-    int c1 = chunk, t1 = tap + 1;
-    if (t1 == T) { t1 = 0; c1 = chunk + 1; }
-    const bool has_next = kt + 1 < nk;
-    if (has_next) fetch_w(c1, t1);
-    if (tap == 0 && chunk + 1 < nchunk) fetch_halo(chunk + 1, ra);     // lands during this chunk's taps
-    { const int ty_ = tap / KW; mma_step(kt & 1, ty_ * HWd + (tap - ty_ * KW)); }
-    if (has_next) store_w((kt + 1) & 1);
-    __syncthreads();
-    if (has_next && t1 == 0) {            // chunk boundary: every wave is done with the halo tile
-      store_halo(ra);
+  // Straight-line loop nest (no data-dependent branch around a load: at a control-flow join hipcc equalises the
+  // outstanding-load counters of both paths by WAITING, which exposed a full memory latency per chunk):
+  // the next chunk's halo and the next weight tile are always fetched (indices clamped at the end; the
+  // duplicates are harmless) and always stored.
+  int buf = 0;
+  for (chunk = 0; chunk < nchunk; ++chunk) {
+    const int cn = min(chunk + 1, nchunk - 1);
+    fetch_halo(cn, ra);                                   // lands during this chunk's taps
+    for (tap = 0; tap < T; ++tap) {
+      const bool last_tap = tap + 1 == T;
+      fetch_w(last_tap ? cn : chunk, last_tap ? 0 : tap + 1);
+      { const int ty_ = tap / KW; mma_step(buf, ty_ * HWd + (tap - ty_ * KW)); }
+      store_w(buf ^ 1);
       __syncthreads();
+      buf ^= 1;
     }
-    chunk = c1; tap = t1;
+    store_halo(ra);                                       // every wave is past the last tap of this chunk
+    __syncthreads();
   }
 
   // ---- epilogue: GEMM row r of the patch -> token (y0 + r/16, x0 + r%16)
