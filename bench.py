@@ -10,9 +10,11 @@ batch with no data-path collective (weak scaling), the timed region is bracketed
 synchronize and the max over ranks is reported.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      the dominant kernel (the aggregator's P.V GEMM, k_gemm_rows<...A16>) timed live with HIP
-                events on the launch stream: algorithmic bytes = the attention probabilities it must stream
-                (B*M*N*ldp*sizeof(P)) + V^T + O, against the 8 TB/s HBM peak (MI355X_MICROARCH.md).
+  roofline      the dominant hand-written kernel, k_conv_halo (the SepConvGRU z|r convolution shape), timed live
+                with HIP events on the launch stream: algorithmic flops / time against the dense MFMA peak.
+  roofline_pv   the second kernel by time, k_pv16 (attention apply O = P.V of the motion aggregator): algorithmic
+                bytes = the attention probabilities it must stream (B*M*N*ldp*sizeof(P)) + V^T + O, against the
+                8 TB/s HBM peak (MI355X_MICROARCH.md).
   cpu_baseline  the CPU oracle (oracle/craft_oracle.py, fp32 torch-CPU restatement of the reference's
                 forward) timed on this box's host cores on ONE 448x1024 pair, 12 iterations.
 """
@@ -101,6 +103,39 @@ def roofline_pv(model, B, H8, W8, prec, reps=20):
             "bytes_per_launch": bytes_alg, "ms_per_launch": round(ms, 4)}
 
 
+def roofline_conv(B, H8, W8, prec, reps=20):
+    """Time the GRU's z|r convolution alone (1x5, 512 -> 256 channels: the largest K loop of the update block,
+    k_conv_halo) with HIP events; algorithmic flops = 2 * pixels * Cout * KH*KW*Cin."""
+    from craft_amd import ops
+    from craft_amd.hip import PREC_F32, pick
+    cp = pick(prec, "conv")
+    dev = torch.device("cuda")
+    N = H8 * W8
+    x = torch.randn(B, N, 512, device=dev)
+    w = torch.randn(256, 512, 1, 5, device=dev) * 0.02
+    bias = torch.zeros(256, device=dev)
+    wp = ops.pack_conv_prec(w, cp)
+    y = torch.empty(B, N, 256, device=dev)
+    for _ in range(3):
+        ops.conv2d_tokens(x, (H8, W8), wp, bias, 256, 1, 5, 0, cp, packed=cp != PREC_F32, out=y)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(reps):
+        ops.conv2d_tokens(x, (H8, W8), wp, bias, 256, 1, 5, 0, cp, packed=cp != PREC_F32, out=y)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / reps
+    flops = 2.0 * B * N * 256 * 5 * 512
+    ach = flops / (ms * 1e-3) / 1e12
+    peak = 157.3 if cp == PREC_F32 else 2500.0
+    return {"bound": "mfma", "kernel": "k_conv_halo (SepConvGRU z|r conv, 1x5, 512->256)", "achieved": round(ach, 1), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "flops_per_launch": flops,
+            "ms_per_launch": round(ms, 4),
+            "note": "algorithmic (fp32-equivalent) flops; the f16x3 scheme executes 3 fp16 MFMAs per product, so the "
+                    "matrix pipe runs at 3x this rate; peak = dense fp16 MFMA (fp32 MFMA for the fp32 policy)"}
+
+
 def cpu_baseline(H, W, iters, threads):
     """The CPU oracle on ONE pair of the same workload, in a subprocess with a wall-clock bound (a bounded
     sample: ~10 s of CPU work on 8 cores).  Returns None if it can not finish in time."""
@@ -145,31 +180,20 @@ def main():
         with torch.no_grad():
             return model(im1, im2, iters=a.iters, test_mode=1)
 
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert torch.isfinite(out[1]).all()
+    from craft_amd.dist import aggregate_throughput, timed_steps
+    last = {}
+
+    def run_step():
+        last["out"] = step()
+
+    dt_rank = timed_steps(run_step, steps=a.steps, warmup=a.warmup, sync=torch.cuda.synchronize)
+    value, dt = aggregate_throughput(pairs_per_rank_step=a.batch, steps=a.steps, dt=dt_rank)
+    assert torch.isfinite(last["out"][1]).all()
 
     if rank == 0:
-        pairs = a.batch * world * a.steps
         line = {
             "metric": "image-pairs/sec at 448x1024, 12 iters",
-            "value": round(pairs / dt, 3), "unit": "image-pairs/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": round(value, 3), "unit": "image-pairs/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "mixed": "f16x3 (fp32 operands split into 2 fp16 planes, 3 fp16 MFMAs per product, f32 "
                       "accumulate: fp32-class) for projections / Q.K^T / convolutions; f16 P.V (f32 accumulate)"}.get(a.precision, a.precision),
@@ -180,7 +204,8 @@ def main():
         }
         if a.ops:
             op_table(model, im1, im2, a.iters)
-        line["roofline"] = roofline_pv(model, a.batch, a.height // 8, a.width // 8, prec)
+        line["roofline"] = roofline_conv(a.batch, a.height // 8, a.width // 8, prec)
+        line["roofline_pv"] = roofline_pv(model, a.batch, a.height // 8, a.width // 8, prec)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.height, a.width, a.iters, a.cpu_threads)
         print(json.dumps(line), flush=True)

@@ -221,6 +221,15 @@ int craft_mask_head(const float* h, long ldh, const float* w0, const float* b0, 
                                       CRAFT_ACT_NONE, 0.25f, mask, 576), PREC_OF(prec), S(stream));
 }
 
+int craft_conv2d_nhwc(const float* x, long ldx, int cin, const float* w, const float* bias, int cout, int KH, int KW, int act,
+                      float* y, long ldy, int B, int H, int W, int prec, void* stream) {
+  if (cin % 32) return CRAFT_ERR_ALIGN;
+  ConvGemmParams q = conv_params(x, (int)ldx, cin, nullptr, 0, 0, B, H, W, KH, KW, w, bias, cout, CONV_EPI_BIAS_ACT, act, 1.f, y,
+                                 (int)ldy);
+  q.w_packed = PACKED_OF(prec);
+  return launch_gemm_conv(q, PREC_OF(prec), S(stream));
+}
+
 int craft_pack_weights(const float* w, long n, int prec, void* out, void* stream) {
   return launch_pack_weights(w, n, prec, out, S(stream));
 }

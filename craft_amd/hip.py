@@ -44,6 +44,7 @@ _SIGS = {
     "craft_flow_head": [P, L, P, P, P, P, I, I, I, P, P, P, P, P, I, P],
     "craft_mask_head": [P, L, P, P, P, P, I, I, I, P, P, I, P],
     "craft_pack_weights": [P, L, I, P, P],
+    "craft_conv2d_nhwc": [P, L, I, P, P, I, I, I, I, P, L, I, I, I, I, P],
     "craft_convex_upsample": [P, P, I, I, I, P, P],
     "craft_coords_init": [P, I, I, I, P, P, P, P],
 }

@@ -225,6 +225,18 @@ def coords_init(flow_init: Optional[torch.Tensor], B: int, H8: int, W8: int, dev
     return c0, c1, fl
 
 
+def conv2d_tokens(x: torch.Tensor, hw, w_packed: torch.Tensor, bias: torch.Tensor, cout: int, KH: int, KW: int, act: int,
+                  prec: int, packed: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Conv2d (stride 1, same padding) + bias (+ReLU) on tokens [B, N, Cin] -> [B, N, Cout]."""
+    B, N, Cin = x.shape
+    _check_rows(x)
+    if out is None:
+        out = torch.empty(B, N, cout, device=x.device, dtype=torch.float32)
+    call("craft_conv2d_nhwc", x, _ld(x), Cin, w_packed, bias, cout, KH, KW, act, out, _ld(out), B, hw[0], hw[1],
+         prec | (hip.W_PACKED if packed else 0))
+    return out
+
+
 # ---- weight packing (layout plumbing, cached by the modules) --------------------------------------
 def pack_conv(w: torch.Tensor) -> torch.Tensor:
     """[Cout, Cin, KH, KW] -> [Cout, KH, KW, Cin] contiguous."""

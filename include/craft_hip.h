@@ -122,6 +122,12 @@ int craft_gma_residual(const float* mf, long ldm, const float* O, const float* g
 #define CRAFT_W_PACKED 0x100
 int craft_pack_weights(const float* w, long n, int prec, void* out, void* stream);
 
+/* nn.Conv2d (stride 1, "same" zero padding KH/2, KW/2) + bias + optional ReLU on tokens: x [B*H*W][cin] (row
+ * stride ldx, cin % 32 == 0), w packed [cout][KH][KW][cin] (raw fp32, or craft_pack_weights output with
+ * CRAFT_W_PACKED or-ed into prec when KH*KW > 1), y [B*H*W][cout].  The building block of the operators below. */
+int craft_conv2d_nhwc(const float* x, long ldx, int cin, const float* w, const float* bias, int cout, int KH, int KW,
+                      int act, float* y, long ldy, int B, int H, int W, int prec, void* stream);
+
 /* BasicMotionEncoder.forward (update.py:79-87).  corr tokens [B*N][cor_planes] (row stride ldc), flow tokens
  * [B*N][2].  Conv weights are packed [Cout][KH][KW][Cin] (weight.permute(0,2,3,1)); wf1 is packed
  * [7*7*2][128] (weight.permute(2,3,1,0)).  Output: 128 channels (126 conv + 2 flow) at out (row stride ldo).

@@ -328,3 +328,23 @@ def test_module_level_api_matches_reference_shapes(device):
     close(n2, n2r, 1e-3, 1e-3, "update_block net")
     close(df, dfr, 1e-3, 1e-3, "update_block delta_flow")
     close(mk, mkr, 1e-3, 1e-3, "update_block mask")
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("KH,KW,cin,cout,relu", [(3, 3, 64, 192, True), (1, 5, 96, 256, False), (5, 1, 128, 126, True), (1, 1, 64, 64, True)])
+def test_conv2d_tokens(device, prec, KH, KW, cin, cout, relu):
+    """craft_conv2d_nhwc (halo-tile kernel for KxK, generic implicit GEMM for 1x1) vs F.conv2d on an image whose
+    size is not a multiple of the 8x16 patch (ragged patches, zero padding at every border)."""
+    B, H8, W8 = 2, 11, 21
+    x = gen(B, cin, H8, W8, seed=90)
+    w = gen(cout, cin, KH, KW, seed=91) / math.sqrt(cin * KH * KW)
+    b = gen(cout, seed=92)
+    ref = F.conv2d(x, w, b, padding=(KH // 2, KW // 2))
+    if relu:
+        ref = torch.relu(ref)
+    xt = ops.tokens_from_nchw(x.to(device))
+    rt, at = TOL[prec]
+    for packed in ([False, True] if KH * KW > 1 else [False]):
+        wp = ops.pack_conv_prec(w.to(device), prec) if packed else ops.pack_conv(w.to(device))
+        y = ops.conv2d_tokens(xt, (H8, W8), wp, b.to(device), cout, KH, KW, ACT_RELU if relu else ACT_NONE, prec, packed=packed)
+        close(ops.tokens_to_nchw(y, H8, W8), ref, rt * 2, at * 4, f"conv {KH}x{KW} prec={prec} packed={packed}")
