@@ -27,6 +27,13 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build(ScoreParams p, float w_
   const int c_lane = lane & 31, rh4 = 4 * (lane >> 5);
   const int col = n0 + wn0 + c_lane;
   const bool clamp = (!MAXONLY) && p.clamp_ord != nullptr && ord2f(*p.clamp_ord) > CRAFT_ATTN_CLIP;
+  if (MAXONLY) {
+    // Cauchy-Schwarz bound from k_norm_bound: max_ij q_m(i).k_m(j) <= max_i|q_m(i)| * max_j|k_m(j)|.  If even that
+    // can not exceed the clip threshold, no score can: leave max_ord = 0 ("no clamp") and skip the exact pass.
+    float bound = 0.f;
+    for (int m = 0; m < p.M; ++m) bound = fmaxf(bound, __uint_as_float(max_ord[1 + m]) * __uint_as_float(max_ord[1 + 8 + m]));
+    if (bound * p.scale * 1.0001f <= CRAFT_ATTN_CLIP) return;
+  }
 
   if (!MAXONLY) {
     if (tid < BM) { const int r = m0 + tid; s_rh[tid] = r / p.W8; s_rw[tid] = r - (r / p.W8) * p.W8; }
@@ -120,11 +127,41 @@ static int check_score(const ScoreParams& p) {
   return 0;
 }
 
+// per-mode max row norms of Q (slots 1..8) and K (slots 9..16) as float bits (non-negative floats order like uints)
+__global__ __launch_bounds__(256) void k_norm_bound(const float* __restrict__ Q, long ldq, const float* __restrict__ Kf, long ldk,
+                                                    long ntok, int M, int d, unsigned* __restrict__ ws) {
+  __shared__ unsigned s_max[16];
+  if (threadIdx.x < 16) s_max[threadIdx.x] = 0u;
+  __syncthreads();
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;    // one thread per (which, token, mode)
+  const long per = ntok * M;
+  if (i < 2 * per) {
+    const int which = i >= per;
+    const long j = which ? i - per : i;
+    const long tok = j / M;
+    const int m = (int)(j - tok * M);
+    const float* p = (which ? Kf + tok * ldk : Q + tok * ldq) + (long)m * d;
+    float ss = 0.f;
+    for (int c = 0; c < d; c += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p + c);
+      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    atomicMax(&s_max[which * 8 + m], __float_as_uint(sqrtf(ss) * 1.00001f));
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 && s_max[threadIdx.x]) atomicMax(&ws[1 + threadIdx.x], s_max[threadIdx.x]);
+}
+
 int launch_score_max(const ScoreParams& p, unsigned* max_ord, int prec, hipStream_t s) {
   if (int e = check_score(p)) return e;
+  if (p.M > 8) return CRAFT_ERR_UNSUPPORTED;
   dim3 grid((p.N + 127) / 128, (p.N + 63) / 64, p.B);
-  hipError_t me = hipMemsetAsync(max_ord, 0, sizeof(unsigned), s);
+  hipError_t me = hipMemsetAsync(max_ord, 0, 32 * sizeof(unsigned), s);
   if (me != hipSuccess) return (int)me;
+  {
+    const long ntok = (long)p.B * p.N, tot = 2 * ntok * p.M;
+    hipLaunchKernelGGL(k_norm_bound, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p.Q, p.ldq, p.Kf, p.ldk, ntok, p.M, p.d, max_ord);
+  }
   if (prec == CRAFT_PREC_F32) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_F32, true>), grid, dim3(NTHREADS), 0, s, p, 0.f, nullptr, nullptr, max_ord);
   else if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_BF16, true>), grid, dim3(NTHREADS), 0, s, p, 0.f, nullptr, nullptr, max_ord);
   else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_F16, true>), grid, dim3(NTHREADS), 0, s, p, 0.f, nullptr, nullptr, max_ord);

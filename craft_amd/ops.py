@@ -103,14 +103,14 @@ def score_max(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale:
     """Device-side global max of the raw scaled scores as an ordered uint32 (setrans.py:520-529)."""
     B, N, C = q.shape
     if out is None:
-        out = torch.zeros(1, device=q.device, dtype=torch.int32)
+        out = torch.zeros(32, device=q.device, dtype=torch.int32)
     call("craft_score_max", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale, out, pick(prec, "score"))
     return out
 
 
 def decode_ord(o: torch.Tensor) -> float:
     """Host decode of the ordered-uint max (diagnostics / tests only; forces a sync)."""
-    u = int(o.item()) & 0xFFFFFFFF
+    u = int(o[0].item()) & 0xFFFFFFFF
     import struct
     if u == 0:
         return float("nan")

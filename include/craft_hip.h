@@ -64,8 +64,10 @@ int craft_linear_t(const float* x, long ldx, const float* w, void* yT, long ldt,
 
 /* Global max of the raw scaled scores Q_m K_m^T * scale over batch, modes, i, j (the .max().item() of
  * setrans.py:520-521) as an order-preserving uint in *max_ord; consumers clamp to [-100, 100] iff that max
- * is > 100 (setrans.py:524-529) without a host round trip.  q,k: projected tokens [B][N][ld], mode m =
- * columns [m*d, m*d+d). */
+ * is > 100 (setrans.py:524-529) without a host round trip.  q,k: projected tokens [B][N][ld] (ld == the tokens'
+ * row stride for all samples), mode m = columns [m*d, m*d+d).  max_ord points to 32 unsigned words: [0] is
+ * the result (0 = "no score exceeds the threshold"), the rest is scratch for a Cauchy-Schwarz norm bound that
+ * lets the exact N^2 pass exit immediately when no score can reach 100. */
 int craft_score_max(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d,
                     float scale, unsigned* max_ord, int prec, void* stream);
 

@@ -142,7 +142,10 @@ def test_corr_build_pyramid_lookup(device, prec, gain):
     mx = ops.score_max(q, k, H8, W8, M, scale, prec)
     rt, at = TOL[prec]
     got_max = ops.decode_ord(mx)
-    assert abs(got_max - float(S.max())) <= at * 20 + rt * abs(float(S.max())), f"score max {got_max} vs {float(S.max())}"
+    if got_max != got_max:      # NaN: the Cauchy-Schwarz norm bound proved that no score reaches the clip threshold
+        assert float(S.max()) <= 100.0, "norm bound skipped the exact pass although a score exceeds the threshold"
+    else:
+        assert abs(got_max - float(S.max())) <= at * 20 + rt * abs(float(S.max())), f"score max {got_max} vs {float(S.max())}"
     pyr = ops.CorrPyramid(B, H8, W8, 4, device)
     ops.corr_build(q, k, H8, W8, M, scale, tab.to(device), 0.5, w_aggr, mx, pyr, True, prec)
     sc = float(c_ref.abs().max())
