@@ -59,15 +59,16 @@ def op_table(model, im1, im2, iters):
         orig(name, *a)
         e.record()
         acc.setdefault(name, []).append((s, e))
+    import craft_amd.hip_encoder as enc_mod
     import craft_amd.ops as ops_mod
     import craft_amd.update as upd_mod
-    hip.call = ops_mod.call = upd_mod.call = timed
+    hip.call = ops_mod.call = upd_mod.call = enc_mod.call = timed
     try:
         with torch.no_grad():
             model(im1, im2, iters=iters, test_mode=1)
         torch.cuda.synchronize()
     finally:
-        hip.call = ops_mod.call = upd_mod.call = orig
+        hip.call = ops_mod.call = upd_mod.call = enc_mod.call = orig
     rows = [(n, len(v), sum(s.elapsed_time(e) for s, e in v)) for n, v in acc.items()]
     tot = sum(r[2] for r in rows)
     print(f"[ops] per-operator time for one forward (B={im1.shape[0]}): total {tot:.2f} ms", file=sys.stderr)

@@ -38,4 +38,34 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, long row,
   }
 }
 
+// Per-(image, channel) moments of the biased conv output for a lazy InstanceNorm: column sums of this wave's
+// accumulator tile over its valid rows -> double atomics into stats[(b*cout + col)*2 + {0,1}].
+// rowmask bit (mt*16 + e) set = that accumulator row of this lane is a valid output pixel of image b.
+template <int MT, int NT>
+__device__ __forceinline__ void conv_col_stats(const ConvGemmParams& p, f32x16 (&acc)[MT][NT], int lane, int cb, long b,
+                                               unsigned rowmask_lo, unsigned rowmask_hi) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = cb + nt * 32 + (lane & 31);
+    const float bias = (col < p.cout) ? p.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int bit = mt * 16 + e;
+        const bool ok = bit < 32 ? (rowmask_lo >> bit) & 1u : (rowmask_hi >> (bit - 32)) & 1u;
+        const float v = ok ? acc[mt][nt][e] + bias : 0.f;
+        s1 += v;
+        s2 += v * v;
+      }
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (lane < 32 && col < p.cout) {
+      atomicAdd(&p.stats[(b * p.cout + col) * 2], (double)s1);
+      atomicAdd(&p.stats[(b * p.cout + col) * 2 + 1], (double)s2);
+    }
+  }
+}
+
 }  // namespace craft

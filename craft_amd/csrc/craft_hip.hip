@@ -127,6 +127,7 @@ static ConvGemmParams conv_params(const float* in0, int ld0, int c0, const float
   ConvGemmParams p = {};
   p.g.seg0 = in0; p.g.ld0 = ld0; p.g.c0 = c0; p.g.seg1 = in1; p.g.ld1 = ld1; p.g.c1 = c1;
   p.g.H = H8; p.g.W = W8; p.g.KH = KH; p.g.KW = KW; p.g.padH = KH / 2; p.g.padW = KW / 2; p.g.npix = B * H8 * W8;
+  p.g.stride = 1; p.g.Hin = H8; p.g.Win = W8; p.g.in_norm = nullptr;
   p.W = W; p.bias = bias; p.cout = cout; p.epi = epi; p.act = act; p.scale = scale; p.out = out; p.ldo = ldo;
   return p;
 }
@@ -228,6 +229,27 @@ int craft_conv2d_nhwc(const float* x, long ldx, int cin, const float* w, const f
                                  (int)ldy);
   q.w_packed = PACKED_OF(prec);
   return launch_gemm_conv(q, PREC_OF(prec), S(stream));
+}
+
+int craft_conv2d_nhwc_ex(const float* x, long ldx, int cin, int Hin, int Win, const float* in_norm, const float* w,
+                         const float* bias, int cout, int KH, int KW, int stride, int act, float* y, long ldy, int B, int Hout,
+                         int Wout, double* stats, int prec, void* stream) {
+  if (cin % 32 || (stride != 1 && stride != 2)) return CRAFT_ERR_ALIGN;
+  ConvGemmParams q = conv_params(x, (int)ldx, cin, nullptr, 0, 0, B, Hout, Wout, KH, KW, w, bias, cout, CONV_EPI_BIAS_ACT, act, 1.f,
+                                 y, (int)ldy);
+  q.g.stride = stride; q.g.Hin = Hin; q.g.Win = Win; q.g.in_norm = in_norm;
+  q.stats = stats;
+  q.w_packed = PACKED_OF(prec);
+  return launch_gemm_conv(q, PREC_OF(prec), S(stream));
+}
+
+int craft_stats_finalize(const double* sums, long n, double count, float eps, float* mean_rstd, void* stream) {
+  return launch_stats_finalize(sums, n, count, eps, mean_rstd, S(stream));
+}
+
+int craft_residual_relu(const float* x, long ldx, const float* xnorm, const float* y, long ldy, const float* ynorm, int y_relu,
+                        int B, int HW, int C, float* out, long ldo, void* stream) {
+  return launch_residual_relu(x, ldx, xnorm, y, ldy, ynorm, y_relu, B, HW, C, out, ldo, S(stream));
 }
 
 int craft_pack_weights(const float* w, long n, int prec, void* out, void* stream) {

@@ -163,8 +163,11 @@ template <int ROWS> struct LoaderRowsH16 {
 struct ConvGeom {
   const float* seg0; const float* seg1;
   int ld0, ld1, c0, c1;
-  int H, W, KH, KW, padH, padW;
-  int npix;                                  // B*H*W
+  int H, W, KH, KW, padH, padW;              // H, W: OUTPUT size
+  int npix;                                  // B*H*W (output pixels)
+  int stride, Hin, Win;                      // input size (== H, W for stride 1); stride 2 only via k_gemm_conv
+  const float* in_norm;                      // optional [B][c0][2] (mean, rstd): input is relu((x-mean)*rstd)
+                                             // (lazy InstanceNorm + ReLU of the producing conv; k_conv_halo only)
 };
 template <int ROWS> struct LoaderConvF32 {
   typedef RegsF32<ROWS> Regs;
@@ -182,9 +185,9 @@ template <int ROWS> struct LoaderConvF32 {
       const int row = row0 + (tid >> 3) + 32 * i;
       if (row < g.npix) {
         const int b = row / hw, rem = row - b * hw;
-        py[i] = rem / g.W;
-        px[i] = rem - py[i] * g.W;
-        pimg[i] = (long)b * hw;
+        py[i] = (rem / g.W) * g.stride;                      // input coordinates of the window origin
+        px[i] = (rem - (rem / g.W) * g.W) * g.stride;
+        pimg[i] = (long)b * g.Hin * g.Win;
       } else {
         py[i] = -100000; px[i] = 0; pimg[i] = 0;
       }
@@ -201,8 +204,8 @@ template <int ROWS> struct LoaderConvF32 {
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
       const int yy = py[i] + dy, xx = px[i] + dx;
-      const bool ok = yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
-      const long pix = ok ? pimg[i] + (long)yy * g.W + xx : 0;      // unconditional load from a valid address
+      const bool ok = yy >= 0 && yy < g.Hin && xx >= 0 && xx < g.Win;
+      const long pix = ok ? pimg[i] + (long)yy * g.Win + xx : 0;    // unconditional load from a valid address
       zm |= ok ? 0u : (1u << i);
       r.v[i] = *reinterpret_cast<const float4*>(sp + pix * ld + c + kcol);
     }

@@ -14,7 +14,9 @@ namespace craft {
 
 constexpr int PATCH_H = 8, PATCH_W = 16;
 
-template <int PREC, int BN, bool WPACK>
+// ENC: the encoder features (lazy InstanceNorm on the input, per-channel statistics of the output) are a
+// compile-time variant so that the update-block instantiation keeps its register budget (2 waves per SIMD).
+template <int PREC, int BN, bool WPACK, bool ENC>
 __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
   typedef typename PrecT<PREC>::lds_t lds_t;
   constexpr int LD = PrecT<PREC>::LD, PL = Planes<PREC>::N;
@@ -58,14 +60,26 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) r[i] = *reinterpret_cast<const float4*>(sp + (img + max(hpix[i], 0)) * ld + c + c4 * 4);
   };
+  int cur_chunk_stored = 0;     // channel chunk whose halo is being written (for the lazy-norm table)
   auto store_halo = [&](const float4 (&r)[NA]) __attribute__((always_inline)) {
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (ENC && g.in_norm) {     // (mean, rstd) of this thread's 4 input channels, image b
+      const float* t = g.in_norm + ((long)b * g.c0 + cur_chunk_stored * BK + c4 * 4) * 2;
+      const float4 t0 = *reinterpret_cast<const float4*>(t), t1 = *reinterpret_cast<const float4*>(t + 4);
+      mu = make_float4(t0.x, t0.z, t1.x, t1.z);
+      rs = make_float4(t0.y, t0.w, t1.y, t1.w);
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int row = r0 + 32 * i;
       if (row >= HR) continue;
       const bool ok = hpix[i] >= 0;
-      float4 v;
-      v.x = ok ? r[i].x : 0.f; v.y = ok ? r[i].y : 0.f; v.z = ok ? r[i].z : 0.f; v.w = ok ? r[i].w : 0.f;
+      float4 v = r[i];
+      if (ENC && g.in_norm) {
+        v.x = fmaxf((v.x - mu.x) * rs.x, 0.f); v.y = fmaxf((v.y - mu.y) * rs.y, 0.f);
+        v.z = fmaxf((v.z - mu.z) * rs.z, 0.f); v.w = fmaxf((v.w - mu.w) * rs.w, 0.f);
+      }
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
       if constexpr (PREC == CRAFT_PREC_F32) {
         *reinterpret_cast<float4*>(&As[row * LD + c4 * 4]) = v;
       } else if constexpr (PREC == CRAFT_PREC_BF16) {
@@ -236,6 +250,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
       __syncthreads();
       buf ^= 1;
     }
+    cur_chunk_stored = cn;
     store_halo(ra);                                       // every wave is past the last tap of this chunk
     __syncthreads();
   }
@@ -253,13 +268,28 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
         const int y = y0 + (r >> 4), x = x0 + (r & 15);
         if (y < g.H && x < g.W) conv_epilogue(p, img + (long)y * g.W + x, cb + nt * 32 + c_lane, acc[mt][nt][e]);
       }
+  if (ENC && p.stats) {
+    unsigned mlo = 0u, mhi = 0u;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = wm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
+        const bool ok = (y0 + (r >> 4)) < g.H && (x0 + (r & 15)) < g.W;
+        const int bit = mt * 16 + e;
+        if (ok) { if (bit < 32) mlo |= 1u << bit; else mhi |= 1u << (bit - 32); }
+      }
+    conv_col_stats<MT, NT>(p, acc, lane, cb, (long)b, mlo, mhi);
+  }
 }
 
 template <int PREC, int BN, bool WPACK> static int launch_halo_t(const ConvGemmParams& p, hipStream_t s) {
+  const bool enc = p.g.in_norm != nullptr || p.stats != nullptr;
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   const int tiles = ((p.g.W + PATCH_W - 1) / PATCH_W) * ((p.g.H + PATCH_H - 1) / PATCH_H) * (p.g.npix / (p.g.H * p.g.W));
   dim3 grid(tiles, (ncols + BN - 1) / BN, 1);
-  hipLaunchKernelGGL((k_conv_halo<PREC, BN, WPACK>), grid, dim3(NTHREADS), 0, s, p);
+  if (enc) hipLaunchKernelGGL((k_conv_halo<PREC, BN, WPACK, true>), grid, dim3(NTHREADS), 0, s, p);
+  else hipLaunchKernelGGL((k_conv_halo<PREC, BN, WPACK, false>), grid, dim3(NTHREADS), 0, s, p);
   return (int)hipGetLastError();
 }
 

@@ -182,7 +182,7 @@ int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s)
 // ---------------------------------------------------------------------------------------------
 // NHWC implicit-GEMM conv: out[pix, co] = epi( sum_{tap,c} in[pix+tap, c] * W[co, tap, c] + bias[co] )
 // ---------------------------------------------------------------------------------------------
-template <int PREC, int BN>
+template <int PREC, int BN, bool ENC>
 __global__ __launch_bounds__(NTHREADS) void k_gemm_conv(ConvGemmParams p) {
   constexpr int BM = 128, WM = 2, WN = 2, MT = BM / WM / 32, NT = BN / WN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -200,23 +200,40 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_conv(ConvGemmParams p) {
   acc_foreach<MT, NT>(acc, lane, [&](int r, int c, float v, int, int, int) {
     if (rb + r < M) conv_epilogue(p, (long)(rb + r), cb + c, v);
   });
+  if (ENC && p.stats) {
+    // all rows of a tile must belong to one image (checked by the launcher: H*W % 128 == 0)
+    const int hw = p.g.H * p.g.W;
+    unsigned mlo = 0u, mhi = 0u;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = rb + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int bit = mt * 16 + e;
+        if (r < M) { if (bit < 32) mlo |= 1u << bit; else mhi |= 1u << (bit - 32); }
+      }
+    conv_col_stats<MT, NT>(p, acc, lane, cb, (long)(m0 / hw), mlo, mhi);
+  }
 }
 
 template <int PREC, int BN> static int launch_conv_t(const ConvGemmParams& p, hipStream_t s) {
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   dim3 grid((p.g.npix + 127) / 128, (ncols + BN - 1) / BN, 1);
-  hipLaunchKernelGGL((k_gemm_conv<PREC, BN>), grid, dim3(NTHREADS), 0, s, p);
+  if (p.stats) hipLaunchKernelGGL((k_gemm_conv<PREC, BN, true>), grid, dim3(NTHREADS), 0, s, p);
+  else hipLaunchKernelGGL((k_gemm_conv<PREC, BN, false>), grid, dim3(NTHREADS), 0, s, p);
   return (int)hipGetLastError();
 }
 
 int launch_gemm_conv(const ConvGemmParams& p, int prec, hipStream_t s) {
   if (p.g.npix <= 0) return 0;
   if ((p.g.c0 % 32) || (p.g.c1 % 32) || (p.g.ld0 & 3) || (p.g.c1 && (p.g.ld1 & 3))) return CRAFT_ERR_ALIGN;
-  if (p.g.KH * p.g.KW > 1 && !p.force_generic) {
+  if (p.g.KH * p.g.KW > 1 && !p.force_generic && p.g.stride == 1) {
     const int rc = launch_conv_halo(p, prec, s);
     if (rc != CRAFT_ERR_UNSUPPORTED) return rc;
   }
   if (p.w_packed) return CRAFT_ERR_UNSUPPORTED;     // the generic implicit GEMM reads raw fp32 weights
+  if (p.g.in_norm) return CRAFT_ERR_UNSUPPORTED;    // lazy input normalisation is a k_conv_halo feature
+  if (p.stats && (p.g.H * p.g.W) % 128) return CRAFT_ERR_UNSUPPORTED;
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   const int bn = pick_bn(ncols);
 #define GO(PR) do { if (bn == 128) return launch_conv_t<PR, 128>(p, s); else return launch_conv_t<PR, 64>(p, s); } while (0)

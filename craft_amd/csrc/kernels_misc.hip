@@ -425,6 +425,61 @@ int launch_coords_init(const float* flow_init_nchw, int B, int H8, int W8, float
   return (int)hipGetLastError();
 }
 
+// (sum, sum^2) -> (mean, 1/sqrt(var + eps)) for n independent populations of `count` samples each
+// (lazy InstanceNorm of the HIP encoders: one population per (image, channel)).
+__global__ void k_stats_finalize(const double* __restrict__ sums, long n, double count, float eps, float* __restrict__ mr) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double mu = sums[2 * i] / count;
+  double var = sums[2 * i + 1] / count - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mr[2 * i] = (float)mu;
+  mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+int launch_stats_finalize(const double* sums, long n, double count, float eps, float* mean_rstd, hipStream_t s) {
+  hipLaunchKernelGGL(k_stats_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sums, n, count, eps, mean_rstd);
+  return (int)hipGetLastError();
+}
+
+// ResidualBlock tail (extractor.py:58-64) with lazy norms: out = relu( fx(x) + fy(y) ),
+//   fx(x) = x or (x - mean)*rstd        (downsample branch: norm3, no ReLU)
+//   fy(y) = y, relu(y) or relu((y - mean)*rstd)   (norm2 + ReLU of conv2's raw output)
+// tokens [B, HW, C]; norm tables [B][C][2].
+__global__ void k_residual_relu(const float* __restrict__ x, long ldx, const float* __restrict__ xn, const float* __restrict__ y,
+                                long ldy, const float* __restrict__ yn, int y_relu, int HW, int C4, long tot,
+                                float* __restrict__ out, long ldo) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one float4 of channels per thread
+  if (i >= tot) return;
+  const long tok = i / C4;
+  const int c = (int)(i - tok * C4) * 4;
+  const long b = tok / HW;
+  float4 vx = *reinterpret_cast<const float4*>(x + tok * ldx + c);
+  float4 vy = *reinterpret_cast<const float4*>(y + tok * ldy + c);
+  const int C = C4 * 4;
+  if (xn) {
+    const float* t = xn + (b * C + c) * 2;
+    const float4 t0 = *reinterpret_cast<const float4*>(t), t1 = *reinterpret_cast<const float4*>(t + 4);
+    vx.x = (vx.x - t0.x) * t0.y; vx.y = (vx.y - t0.z) * t0.w; vx.z = (vx.z - t1.x) * t1.y; vx.w = (vx.w - t1.z) * t1.w;
+  }
+  if (yn) {
+    const float* t = yn + (b * C + c) * 2;
+    const float4 t0 = *reinterpret_cast<const float4*>(t), t1 = *reinterpret_cast<const float4*>(t + 4);
+    vy.x = (vy.x - t0.x) * t0.y; vy.y = (vy.y - t0.z) * t0.w; vy.z = (vy.z - t1.x) * t1.y; vy.w = (vy.w - t1.z) * t1.w;
+  }
+  if (y_relu) { vy.x = fmaxf(vy.x, 0.f); vy.y = fmaxf(vy.y, 0.f); vy.z = fmaxf(vy.z, 0.f); vy.w = fmaxf(vy.w, 0.f); }
+  float4 o;
+  o.x = fmaxf(vx.x + vy.x, 0.f); o.y = fmaxf(vx.y + vy.y, 0.f); o.z = fmaxf(vx.z + vy.z, 0.f); o.w = fmaxf(vx.w + vy.w, 0.f);
+  *reinterpret_cast<float4*>(out + tok * ldo + c) = o;
+}
+int launch_residual_relu(const float* x, long ldx, const float* xnorm, const float* y, long ldy, const float* ynorm, int y_relu,
+                         int B, int HW, int C, float* out, long ldo, hipStream_t s) {
+  if (C % 4 || (ldx & 3) || (ldy & 3) || (ldo & 3)) return CRAFT_ERR_ALIGN;
+  const long tot = (long)B * HW * (C / 4);
+  hipLaunchKernelGGL(k_residual_relu, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, x, ldx, xnorm, y, ldy, ynorm, y_relu, HW,
+                     C / 4, tot, out, ldo);
+  return (int)hipGetLastError();
+}
+
 // tokens [B, HW, ld] (first C columns) -> NCHW [B, C, HW]
 __global__ void k_tokens_to_nchw(const float* __restrict__ src, long ld, int C, int HW, long tot, float* __restrict__ dst) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -37,6 +37,7 @@ struct ConvGemmParams {
   float* aux1; int ld1;
   int force_generic;     // 1: always use the generic implicit GEMM (k_gemm_conv), for A/B tests
   int w_packed;          // 1: W was produced by craft_pack_weights for this precision (halo kernel only)
+  double* stats;         // optional [B][cout][2]: += (sum, sum^2) of the biased conv output per (image, channel)
 };
 
 int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s);
@@ -44,6 +45,9 @@ int launch_pv16(const RowsGemmParams& p, int prec, hipStream_t s);   // A and B 
 int launch_gemm_conv(const ConvGemmParams& p, int prec, hipStream_t s);
 int launch_conv_halo(const ConvGemmParams& p, int prec, hipStream_t s);
 int launch_pack_weights(const float* w, long n, int prec, void* out, hipStream_t s);
+int launch_stats_finalize(const double* sums, long n, double count, float eps, float* mean_rstd, hipStream_t s);
+int launch_residual_relu(const float* x, long ldx, const float* xnorm, const float* y, long ldy, const float* ynorm, int y_relu,
+                         int B, int HW, int C, float* out, long ldo, hipStream_t s);
 
 // ---- attention / correlation (kernels_attn.hip) ----
 struct ScoreParams {

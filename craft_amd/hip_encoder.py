@@ -1,0 +1,150 @@
+"""BasicEncoder (extractor.py:124-196) on the HIP conv kernels, channels-last, eval mode.
+
+SURVEY.md §8(f) item 2: once the hot path is fused the two CNN encoders (94 of 815 GMAC per pair) are the
+next bottleneck — on MIOpen/fp32 they cost ~12 ms of a 37 ms step at configs[1].  Here every convolution
+after the 7x7 stem runs on the same MFMA engine as the update block (k_conv_halo for the stride-1 3x3 convs,
+k_gemm_conv for the stride-2 ones, the rows GEMM for the final 1x1), and the normalisations never cost a pass:
+
+* BatchNorm (cnet, eval): folded into the conv weights / bias (exact up to rounding), ReLU in the epilogue;
+* InstanceNorm (fnet): the producing conv accumulates per-(image, channel) (sum, sum^2) in its epilogue and the
+  CONSUMER applies relu((x - mean) * rstd) while it stages its input (conv halo) or in the fused residual tail;
+* ``relu(x + y)`` of a residual block is one fused kernel (craft_residual_relu) with both pending norms applied.
+
+The 7x7 / stride-2 / 3-channel stem (3.5 % of the encoder flops) stays on PyTorch-ROCm (MIOpen).  Output: tokens
+[B, (H/8)*(W/8), output_dim] — exactly the layout the hot path consumes, so no NCHW round trip exists.
+Falls back to the PyTorch module (then converted to tokens) for shapes the kernels do not support.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .extractor import BasicEncoder, ResidualBlock
+from .hip import ACT_NONE, ACT_RELU, PREC_F32, W_PACKED, call, pick
+
+IN_EPS = 1e-5   # nn.InstanceNorm2d / nn.BatchNorm2d default eps (extractor.py uses the defaults)
+
+
+def _fold_bn(conv: nn.Conv2d, bn: Optional[nn.Module]):
+    """conv followed by eval-mode BatchNorm -> equivalent (weight, bias)."""
+    w, b = conv.weight.detach().float(), conv.bias.detach().float()
+    if isinstance(bn, nn.BatchNorm2d):
+        s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+        w = w * s.view(-1, 1, 1, 1)
+        b = (b - bn.running_mean.detach().float()) * s + bn.bias.detach().float()
+    return w, b
+
+
+class _ConvPack:
+    """One conv's weights in the layout / precision its kernel wants (halo kernel: packed for `prec`;
+    strided or 1x1: raw fp32 [Cout][KH][KW][Cin])."""
+
+    def __init__(self, conv: nn.Conv2d, bn, prec: int):
+        w, b = _fold_bn(conv, bn)
+        self.cout, self.cin, self.KH, self.KW = w.shape
+        self.stride = conv.stride[0]
+        self.halo = self.stride == 1 and self.KH * self.KW > 1
+        self.packed = self.halo and prec != PREC_F32
+        self.w = ops.pack_conv_prec(w, prec) if self.packed else ops.pack_conv(w)
+        self.b = b.contiguous()
+
+
+class HipEncoder:
+    """Stateless runner around a ``BasicEncoder`` module (its parameters stay the source of truth)."""
+
+    def __init__(self, enc: BasicEncoder):
+        self.enc = enc
+        self.kind = enc.norm_fn
+        self._key = None
+        self._packs = None
+
+    def supported(self, H: int, W: int) -> bool:
+        if self.kind not in ("instance", "batch") or self.enc.training:
+            return False
+        if H % 8 or W % 8:
+            return False
+        # stride-2 convs accumulate InstanceNorm statistics per 128-row tile: each image must be a whole number of tiles
+        return self.kind == "batch" or (((H // 4) * (W // 4)) % 128 == 0 and ((H // 8) * (W // 8)) % 128 == 0)
+
+    def _blocks(self):
+        e = self.enc
+        return [e.layer1[0], e.layer1[1], e.layer2[0], e.layer2[1], e.layer3[0], e.layer3[1]]
+
+    def _get_packs(self, prec: int):
+        params = [p for p in self.enc.parameters()] + [b for b in self.enc.buffers()]
+        key = (prec,) + tuple((p.data_ptr(), p._version) for p in params)
+        if key != self._key:
+            bn = self.kind == "batch"
+            packs = []
+            with torch.no_grad():
+                for blk in self._blocks():
+                    d = {"c1": _ConvPack(blk.conv1, blk.norm1 if bn else None, prec),
+                         "c2": _ConvPack(blk.conv2, blk.norm2 if bn else None, prec)}
+                    if blk.downsample is not None:
+                        d["ds"] = _ConvPack(blk.downsample[0], blk.norm3 if bn else None, prec)
+                    packs.append(d)
+                self._final = (self.enc.conv2.weight.detach().float().view(self.enc.conv2.out_channels, -1).contiguous(),
+                               self.enc.conv2.bias.detach().float().contiguous())
+            self._packs, self._key = packs, key
+        return self._packs
+
+    # ------------------------------------------------------------------------------------------
+    def _conv(self, x, B, hw_in, pk: _ConvPack, act, prec, in_norm=None, stats=None):
+        Hin, Win = hw_in
+        Ho, Wo = (Hin // pk.stride, Win // pk.stride)
+        y = torch.empty(B, Ho * Wo, pk.cout, device=x.device, dtype=torch.float32)
+        call("craft_conv2d_nhwc_ex", x, x.stride(1), pk.cin, Hin, Win, in_norm, pk.w, pk.b, pk.cout, pk.KH, pk.KW, pk.stride, act,
+             y, y.stride(1), B, Ho, Wo, stats, prec | (W_PACKED if pk.packed else 0))
+        return y, (Ho, Wo)
+
+    def _finalize(self, stats, count):
+        B, C, _ = stats.shape
+        mr = torch.empty(B, C, 2, device=stats.device, dtype=torch.float32)
+        call("craft_stats_finalize", stats, B * C, float(count), IN_EPS, mr)
+        return mr
+
+    def forward_tokens(self, x: torch.Tensor, prec) -> torch.Tensor:
+        """x: normalised images [B, 3, H, W] -> tokens [B, (H/8)*(W/8), output_dim]."""
+        enc = self.enc
+        B, _, H, W = x.shape
+        cp = pick(prec, "conv")
+        if not self.supported(H, W):
+            return ops.tokens_from_nchw(enc(x).float())
+        packs = self._get_packs(cp)
+        inorm = self.kind == "instance"
+        with torch.no_grad():
+            stem = F.relu(enc.norm1(enc.conv1(x)))                                  # 7x7 / s2 stem on MIOpen
+        t = ops.tokens_from_nchw(stem.float())
+        hw = (H // 2, W // 2)
+        dev = x.device
+        for pk in packs:
+            if inorm:
+                s1 = torch.zeros(B, pk["c1"].cout, 2, device=dev, dtype=torch.float64)
+                c1, hw1 = self._conv(t, B, hw, pk["c1"], ACT_NONE, cp, stats=s1)
+                n1 = self._finalize(s1, hw1[0] * hw1[1])
+                s2 = torch.zeros(B, pk["c2"].cout, 2, device=dev, dtype=torch.float64)
+                c2, _ = self._conv(c1, B, hw1, pk["c2"], ACT_NONE, cp, in_norm=n1, stats=s2)
+                n2 = self._finalize(s2, hw1[0] * hw1[1])
+                if "ds" in pk:
+                    s3 = torch.zeros(B, pk["ds"].cout, 2, device=dev, dtype=torch.float64)
+                    xs, _ = self._conv(t, B, hw, pk["ds"], ACT_NONE, cp, stats=s3)
+                    n3 = self._finalize(s3, hw1[0] * hw1[1])
+                else:
+                    xs, n3 = t, None
+                out = torch.empty_like(c2)
+                call("craft_residual_relu", xs, xs.stride(1), n3, c2, c2.stride(1), n2, 1, B, hw1[0] * hw1[1], c2.shape[-1], out,
+                     out.stride(1))
+            else:
+                c1, hw1 = self._conv(t, B, hw, pk["c1"], ACT_RELU, cp)
+                c2, _ = self._conv(c1, B, hw1, pk["c2"], ACT_RELU, cp)
+                xs = self._conv(t, B, hw, pk["ds"], ACT_NONE, cp)[0] if "ds" in pk else t
+                out = torch.empty_like(c2)
+                call("craft_residual_relu", xs, xs.stride(1), None, c2, c2.stride(1), None, 0, B, hw1[0] * hw1[1], c2.shape[-1], out,
+                     out.stride(1))
+            t, hw = out, hw1
+        wf, bf = self._final
+        return ops.linear(t, wf, bf, prec)

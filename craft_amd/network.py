@@ -6,7 +6,8 @@ three ``*_trans_config`` objects back into it), same ``forward(image1, image2, i
 upsample, test_mode)`` signature / return conventions, same ``state_dict`` keys (202 in the
 canonical ``--craft --f2 full --setrans`` configuration), ``freeze_bn()``.
 
-Execution: the CNN encoders stay on PyTorch-ROCm (MIOpen); everything after them — F2 transformer,
+Execution: the CNN encoders run on the same HIP conv engine (craft_amd/hip_encoder.py; only their 7x7 stem stays
+on PyTorch-ROCm / MIOpen; ``args.hip_encoders=False`` keeps them entirely on PyTorch); everything after them — F2 transformer,
 intra-frame attention, correlation volume + pyramid, and the T refinement iterations — runs through
 ``libcraft_hip.so`` on channels-last token buffers.  Inference only in this round: tensors produced
 by the HIP path carry no autograd graph.
@@ -27,6 +28,7 @@ import torch.nn as nn
 from . import ops
 from .corr import CorrBlock, TransCorrBlock
 from .extractor import BasicEncoder
+from .hip_encoder import HipEncoder
 from .gma import Attention
 from .hip import ACT_RELU, ACT_TANH, PREC_BF16, PREC_F32, PREC_NAMES, Precision
 from .setrans import SelfAttVisPosTrans, SETransConfig
@@ -119,6 +121,10 @@ class CRAFT(nn.Module):
 
         self.update_block = GMAUpdateBlock(args, hidden_dim=hdim)
         self.call_counter = 0
+        # runners that execute the two BasicEncoders on the HIP conv kernels (eval mode; args.hip_encoders=False
+        # keeps them on PyTorch-ROCm / MIOpen)
+        self._henc_f = HipEncoder(self.fnet)
+        self._henc_c = HipEncoder(self.cnet)
 
     # ------------------------------------------------------------------------------------------
     def hip_prec(self) -> Precision:
@@ -167,19 +173,28 @@ class CRAFT(nn.Module):
         dev = image1.device
 
         with torch.no_grad():
-            with _autocast(getattr(args, "encoder_autocast", False)):
-                fmap1, fmap2 = self.fnet([image1, image2])
-                cnet_feat = self.cnet(image1)
-            fmap1, fmap2, cnet_feat = fmap1.float(), fmap2.float(), cnet_feat.float()
+            use_henc = getattr(args, "hip_encoders", True) and not self.training
+            if use_henc:
+                # CNN encoders on the HIP conv engine, channels-last end to end
+                fm = self._henc_f.forward_tokens(torch.cat([image1, image2], dim=0), prec)     # [2B, N, 256]
+                f1_tok, f2_tok = fm[:B], fm[B:]
+                cn_tok = self._henc_c.forward_tokens(image1, prec)                              # [B, N, 256]
+            else:
+                with _autocast(getattr(args, "encoder_autocast", False)):
+                    fmap1, fmap2 = self.fnet([image1, image2])
+                    cnet_feat = self.cnet(image1)
+                f1_tok = ops.tokens_from_nchw(fmap1.float())
+                f2_tok = ops.tokens_from_nchw(fmap2.float())
+                cn_tok = ops.tokens_from_nchw(cnet_feat.float())
 
             # ---- F2 transformer (network.py:185-187): tokens in, LayerNorm-ed tokens out ------------
-            x2 = ops.tokens_from_nchw(fmap2, ln=True)
+            x2 = ops.tokens_norm(f2_tok)
             fmap2_t = self.f2_trans.forward_tokens(x2, hw, prec=prec)                 # [B, N, 256]
 
             # ---- context split + intra-frame attention (network.py:206-214) -----------------------
             hx = torch.empty(B, N, 512, device=dev, dtype=torch.float32)              # [net | inp | mf | mfg]
-            ops.tokens_from_nchw(cnet_feat, c_off=0, C=128, act=ACT_TANH, out=hx[..., 0:128])
-            ops.tokens_from_nchw(cnet_feat, c_off=128, C=128, act=ACT_RELU, out=hx[..., 128:256])
+            ops.tokens_slice(cn_tok, 0, 128, act=ACT_TANH, out=hx[..., 0:128])
+            ops.tokens_slice(cn_tok, 128, 128, act=ACT_RELU, out=hx[..., 128:256])
             if args.use_setrans:
                 xc = ops.tokens_norm(hx[..., 128:256])
                 attention = self.att.forward_tokens(xc, hw, prec=prec)                # [B, 4, N, ldp]
@@ -188,7 +203,7 @@ class CRAFT(nn.Module):
 
             # ---- correlation volume + pyramid (network.py:196-197, :225-228) ---------------------
             if args.craft:
-                x1 = ops.tokens_from_nchw(fmap1, ln=True)
+                x1 = ops.tokens_norm(f1_tok)
                 x2t = ops.tokens_norm(fmap2_t)
                 self.corr_fn.update_tokens(x1, x2t, hw, prec)
                 corr_fn = self.corr_fn
@@ -197,7 +212,7 @@ class CRAFT(nn.Module):
                 corr_fn.num_levels, corr_fn.radius, corr_fn.shape = 4, args.corr_radius, (B, H8, W8)
                 corr_fn.pyramid = ops.CorrPyramid(B, H8, W8, 4, dev)
                 import math
-                ops.corr_build(ops.tokens_from_nchw(fmap1), fmap2_t, H8, W8, 1, 1.0 / math.sqrt(256), None, 0.0, 1.0, None,
+                ops.corr_build(f1_tok.contiguous(), fmap2_t, H8, W8, 1, 1.0 / math.sqrt(256), None, 0.0, 1.0, None,
                                corr_fn.pyramid, False, prec)
                 self.corr_fn = corr_fn
 

@@ -64,6 +64,18 @@ def tokens_norm(t: torch.Tensor, act: int = ACT_NONE, ln: bool = True, out: Opti
     return out
 
 
+def tokens_slice(t: torch.Tensor, c_off: int, C: int, act: int = ACT_NONE, ln: bool = False,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """tokens columns [c_off, c_off+C) -> (activation) -> (LayerNorm) -> tokens [B, N, C]."""
+    B, N, Ctot = t.shape
+    _check_rows(t)
+    if out is None:
+        out = torch.empty(B, N, C, device=t.device, dtype=torch.float32)
+    _check_rows(out)
+    call("craft_tokens", t, 0, B, Ctot, c_off, C, N, _ld(t), act, int(ln), out, _ld(out))
+    return out
+
+
 def tokens_to_nchw(t: torch.Tensor, H: int, W: int) -> torch.Tensor:
     B, N, C = t.shape
     _check_rows(t)

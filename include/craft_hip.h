@@ -130,6 +130,21 @@ int craft_pack_weights(const float* w, long n, int prec, void* out, void* stream
 int craft_conv2d_nhwc(const float* x, long ldx, int cin, const float* w, const float* bias, int cout, int KH, int KW,
                       int act, float* y, long ldy, int B, int H, int W, int prec, void* stream);
 
+/* ---- CNN encoder building blocks (BasicEncoder / ResidualBlock, extractor.py:6-64, 124-196) ----
+ * craft_conv2d_nhwc_ex: craft_conv2d_nhwc plus (a) stride 2 (x is [B*Hin*Win][cin], y [B*Hout*Wout][cout], padding
+ * KH/2); (b) in_norm [B][cin][2] = (mean, rstd): the input is read as relu((x - mean)*rstd), i.e. the InstanceNorm
+ * + ReLU of the producing conv applied lazily (stride 1, KH*KW > 1 only); (c) stats [B][cout][2] doubles: += (sum,
+ * sum^2) of the biased output per (image, channel) for the consumer's lazy InstanceNorm (zero them first).
+ * craft_stats_finalize: n populations of `count` samples: (sum, sum^2) -> (mean, 1/sqrt(var + eps)).
+ * craft_residual_relu: out = relu(fx(x) + fy(y)), fx = identity or (x-mean)*rstd (xnorm), fy = identity / relu /
+ * relu((y-mean)*rstd) (ynorm, y_relu): the tail of ResidualBlock.forward with both norms applied lazily. */
+int craft_conv2d_nhwc_ex(const float* x, long ldx, int cin, int Hin, int Win, const float* in_norm, const float* w,
+                         const float* bias, int cout, int KH, int KW, int stride, int act, float* y, long ldy, int B,
+                         int Hout, int Wout, double* stats, int prec, void* stream);
+int craft_stats_finalize(const double* sums, long n, double count, float eps, float* mean_rstd, void* stream);
+int craft_residual_relu(const float* x, long ldx, const float* xnorm, const float* y, long ldy, const float* ynorm,
+                        int y_relu, int B, int HW, int C, float* out, long ldo, void* stream);
+
 /* BasicMotionEncoder.forward (update.py:79-87).  corr tokens [B*N][cor_planes] (row stride ldc), flow tokens
  * [B*N][2].  Conv weights are packed [Cout][KH][KW][Cin] (weight.permute(0,2,3,1)); wf1 is packed
  * [7*7*2][128] (weight.permute(2,3,1,0)).  Output: 128 channels (126 conv + 2 flow) at out (row stride ldo).
