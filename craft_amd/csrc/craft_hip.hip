@@ -243,6 +243,11 @@ int craft_conv2d_nhwc_ex(const float* x, long ldx, int cin, int Hin, int Win, co
   return launch_gemm_conv(q, PREC_OF(prec), S(stream));
 }
 
+int craft_stem_conv7x7(const float* image, const float* w, const float* bias, int act, int B, int H, int W, float* out,
+                       double* stats, void* stream) {
+  return launch_stem7x7(image, w, bias, act, B, H, W, out, stats, S(stream));
+}
+
 int craft_stats_finalize(const double* sums, long n, double count, float eps, float* mean_rstd, void* stream) {
   return launch_stats_finalize(sums, n, count, eps, mean_rstd, S(stream));
 }

@@ -8,6 +8,7 @@
 // re-gathers and re-converts the activation tile for every tap, activation staging drops by 5x (1x5, 5x1)
 // to 6.4x (3x3); only the weight tile [BN x 32] is staged per (chunk, tap), double-buffered with one
 // barrier per K-tile.  Epilogues are shared with k_gemm_conv (conv_epilogue.hpp).
+#include <cstdlib>
 #include "conv_epilogue.hpp"
 
 namespace craft {
@@ -297,7 +298,8 @@ int launch_conv_halo(const ConvGemmParams& p, int prec, hipStream_t s) {
   if (p.g.KH > 5 || p.g.KW > 5 || (p.g.KH + 7) * (p.g.KW + 15) > (PATCH_H + 4) * PATCH_W) return CRAFT_ERR_UNSUPPORTED;
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   // BN = 128 only when that still leaves >= 2 blocks per CU's worth of tiles for wide outputs
-  const int bn = (ncols % 128 == 0 && ncols >= 256) ? 128 : 64;
+  int bn = (ncols % 128 == 0 && ncols >= 256) ? 128 : 64;
+  if (const char* e = getenv("CRAFT_HALO_BN")) bn = atoi(e) == 128 ? (ncols % 128 == 0 ? 128 : 64) : 64;   // tuning override
   if (p.w_packed && ((p.g.c0 + p.g.c1) * p.g.KH * p.g.KW) % 8) return CRAFT_ERR_ALIGN;
 #define GO(PR, WP) do { if (bn == 128) return launch_halo_t<PR, 128, WP>(p, s); else return launch_halo_t<PR, 64, WP>(p, s); } while (0)
   if (prec == CRAFT_PREC_F32) GO(CRAFT_PREC_F32, false);      // packed == raw for fp32

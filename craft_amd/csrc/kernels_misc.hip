@@ -442,7 +442,8 @@ int launch_stats_finalize(const double* sums, long n, double count, float eps, f
 }
 
 // ResidualBlock tail (extractor.py:58-64) with lazy norms: out = relu( fx(x) + fy(y) ),
-//   fx(x) = x or (x - mean)*rstd        (downsample branch: norm3, no ReLU)
+//   fx(x) = x, (x - mean)*rstd (downsample branch: norm3, no ReLU) or relu((x - mean)*rstd) (flag bit 1 of
+//           y_relu: the stem's norm1 + ReLU applied lazily to the identity branch of layer1.0)
 //   fy(y) = y, relu(y) or relu((y - mean)*rstd)   (norm2 + ReLU of conv2's raw output)
 // tokens [B, HW, C]; norm tables [B][C][2].
 __global__ void k_residual_relu(const float* __restrict__ x, long ldx, const float* __restrict__ xn, const float* __restrict__ y,
@@ -461,12 +462,13 @@ __global__ void k_residual_relu(const float* __restrict__ x, long ldx, const flo
     const float4 t0 = *reinterpret_cast<const float4*>(t), t1 = *reinterpret_cast<const float4*>(t + 4);
     vx.x = (vx.x - t0.x) * t0.y; vx.y = (vx.y - t0.z) * t0.w; vx.z = (vx.z - t1.x) * t1.y; vx.w = (vx.w - t1.z) * t1.w;
   }
+  if (y_relu & 2) { vx.x = fmaxf(vx.x, 0.f); vx.y = fmaxf(vx.y, 0.f); vx.z = fmaxf(vx.z, 0.f); vx.w = fmaxf(vx.w, 0.f); }
   if (yn) {
     const float* t = yn + (b * C + c) * 2;
     const float4 t0 = *reinterpret_cast<const float4*>(t), t1 = *reinterpret_cast<const float4*>(t + 4);
     vy.x = (vy.x - t0.x) * t0.y; vy.y = (vy.y - t0.z) * t0.w; vy.z = (vy.z - t1.x) * t1.y; vy.w = (vy.w - t1.z) * t1.w;
   }
-  if (y_relu) { vy.x = fmaxf(vy.x, 0.f); vy.y = fmaxf(vy.y, 0.f); vy.z = fmaxf(vy.z, 0.f); vy.w = fmaxf(vy.w, 0.f); }
+  if (y_relu & 1) { vy.x = fmaxf(vy.x, 0.f); vy.y = fmaxf(vy.y, 0.f); vy.z = fmaxf(vy.z, 0.f); vy.w = fmaxf(vy.w, 0.f); }
   float4 o;
   o.x = fmaxf(vx.x + vy.x, 0.f); o.y = fmaxf(vx.y + vy.y, 0.f); o.z = fmaxf(vx.z + vy.z, 0.f); o.w = fmaxf(vx.w + vy.w, 0.f);
   *reinterpret_cast<float4*>(out + tok * ldo + c) = o;
@@ -477,6 +479,114 @@ int launch_residual_relu(const float* x, long ldx, const float* xnorm, const flo
   const long tot = (long)B * HW * (C / 4);
   hipLaunchKernelGGL(k_residual_relu, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, x, ldx, xnorm, y, ldy, ynorm, y_relu, HW,
                      C / 4, tot, out, ldo);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Encoder stem: 7x7 / stride 2 / pad 3 convolution 3 -> 64 (extractor.py:139, :181) fused with the input
+// normalisation 2*(x/255)-1 of CRAFT.forward (network.py:169-173), bias, optional ReLU (cnet: BatchNorm folded
+// into w / bias) and optional per-(image, channel) (sum, sum^2) for a lazy InstanceNorm (fnet).
+// Direct fp32 FMA kernel (K = 147 is too ragged for the MFMA engine and the stem is 3.5 % of the encoder
+// flops): a block owns 16 x 32 output pixels, stages the 37 x 69 x 3 input patch and the [147][64] weights in
+// LDS; each thread accumulates 2 pixels x 64 channels, so every weight read from LDS feeds 2 FMAs.
+// image: NCHW [B][3][H][W] raw 0..255;  w: [147 = (ky*7+kx)*3+c][64];  out: tokens [B][(H/2)*(W/2)][64].
+// ---------------------------------------------------------------------------------------------
+#define STEM_TH 16
+#define STEM_TW 32
+#define STEM_PH (2 * STEM_TH + 5)
+#define STEM_PW (2 * STEM_TW + 5)
+#define STEM_PLD (STEM_PW + 1)
+__global__ __launch_bounds__(256) void k_stem7x7(const float* __restrict__ img, const float* __restrict__ w,
+                                                 const float* __restrict__ bias, int act, int H, int W, float* __restrict__ out,
+                                                 double* __restrict__ stats) {
+  extern __shared__ float sm[];
+  float* sw = sm;                                   // [147][64]
+  float* sp = sm + 147 * 64;                        // [3][STEM_PH][STEM_PLD]
+  float* sred = sp + 3 * STEM_PH * STEM_PLD;        // [4 waves][128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H2 = H / 2, W2 = W / 2;
+  const int tiles_x = (W2 + STEM_TW - 1) / STEM_TW, tiles_y = (H2 + STEM_TH - 1) / STEM_TH;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int oy0 = ty * STEM_TH, ox0 = tx * STEM_TW;
+  for (int i = tid; i < 147 * 64 / 4; i += 256) reinterpret_cast<float4*>(sw)[i] = reinterpret_cast<const float4*>(w)[i];
+  const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+  for (int i = tid; i < 3 * STEM_PH * STEM_PW; i += 256) {
+    const int c = i / (STEM_PH * STEM_PW), rem = i - c * (STEM_PH * STEM_PW);
+    const int r = rem / STEM_PW, q = rem - r * STEM_PW;
+    const int y = iy0 + r, x = ix0 + q;
+    float v = 0.f;
+    if (y >= 0 && y < H && x >= 0 && x < W) v = 2.f * (img[(((long)b * 3 + c) * H + y) * W + x] / 255.f) - 1.f;
+    sp[(c * STEM_PH + r) * STEM_PLD + q] = v;
+  }
+  __syncthreads();
+  const int py = tid >> 4, px = tid & 15;           // pixels (py, px) and (py, px + 16) of the tile
+  float a0[64], a1[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+  for (int ky = 0; ky < 7; ++ky)
+    for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* prow = sp + (c * STEM_PH + 2 * py + ky) * STEM_PLD + kx;
+        const float v0 = prow[2 * px], v1 = prow[2 * (px + 16)];
+        const float4* wr = reinterpret_cast<const float4*>(sw + ((ky * 7 + kx) * 3 + c) * 64);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float4 ww = wr[j];
+          a0[4 * j + 0] += v0 * ww.x; a0[4 * j + 1] += v0 * ww.y; a0[4 * j + 2] += v0 * ww.z; a0[4 * j + 3] += v0 * ww.w;
+          a1[4 * j + 0] += v1 * ww.x; a1[4 * j + 1] += v1 * ww.y; a1[4 * j + 2] += v1 * ww.z; a1[4 * j + 3] += v1 * ww.w;
+        }
+      }
+  const int oy = oy0 + py, ox_a = ox0 + px, ox_b = ox0 + px + 16;
+  const bool ok_a = oy < H2 && ox_a < W2, ok_b = oy < H2 && ox_b < W2;
+  float* o_a = out + (((long)b * H2 + oy) * W2 + ox_a) * 64;
+  float* o_b = out + (((long)b * H2 + oy) * W2 + ox_b) * 64;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float4 bb = reinterpret_cast<const float4*>(bias)[j];
+    float4 r0 = make_float4(a0[4 * j] + bb.x, a0[4 * j + 1] + bb.y, a0[4 * j + 2] + bb.z, a0[4 * j + 3] + bb.w);
+    float4 r1 = make_float4(a1[4 * j] + bb.x, a1[4 * j + 1] + bb.y, a1[4 * j + 2] + bb.z, a1[4 * j + 3] + bb.w);
+    if (act == CRAFT_ACT_RELU) {
+      r0.x = fmaxf(r0.x, 0.f); r0.y = fmaxf(r0.y, 0.f); r0.z = fmaxf(r0.z, 0.f); r0.w = fmaxf(r0.w, 0.f);
+      r1.x = fmaxf(r1.x, 0.f); r1.y = fmaxf(r1.y, 0.f); r1.z = fmaxf(r1.z, 0.f); r1.w = fmaxf(r1.w, 0.f);
+    }
+    a0[4 * j] = r0.x; a0[4 * j + 1] = r0.y; a0[4 * j + 2] = r0.z; a0[4 * j + 3] = r0.w;
+    a1[4 * j] = r1.x; a1[4 * j + 1] = r1.y; a1[4 * j + 2] = r1.z; a1[4 * j + 3] = r1.w;
+    if (ok_a) reinterpret_cast<float4*>(o_a)[j] = r0;
+    if (ok_b) reinterpret_cast<float4*>(o_b)[j] = r1;
+  }
+  if (stats) {
+    // per-channel (sum, sum^2) over the tile's valid pixels: wave reduce, then across the 4 waves through LDS
+#pragma unroll
+    for (int ch = 0; ch < 64; ++ch) {
+      const float v0 = ok_a ? a0[ch] : 0.f, v1 = ok_b ? a1[ch] : 0.f;
+      const float s1 = wave_sum(v0 + v1), s2 = wave_sum(v0 * v0 + v1 * v1);
+      if (lane == 0) { sred[wave * 128 + ch] = s1; sred[wave * 128 + 64 + ch] = s2; }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const float t = sred[tid] + sred[128 + tid] + sred[256 + tid] + sred[384 + tid];
+      const int ch = tid & 63, which = tid >> 6;
+      atomicAdd(&stats[((long)b * 64 + ch) * 2 + which], (double)t);
+    }
+  }
+}
+int launch_stem7x7(const float* img, const float* w, const float* bias, int act, int B, int H, int W, float* out, double* stats,
+                   hipStream_t s) {
+  if ((H & 1) || (W & 1)) return CRAFT_ERR_ALIGN;
+  const int H2 = H / 2, W2 = W / 2;
+  const int tiles = ((W2 + STEM_TW - 1) / STEM_TW) * ((H2 + STEM_TH - 1) / STEM_TH) * B;
+  const size_t lds = sizeof(float) * (147 * 64 + 3 * STEM_PH * STEM_PLD + 4 * 128);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stem7x7), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_stem7x7, dim3(tiles), dim3(256), lds, s, img, w, bias, act, H, W, out, stats);
   return (int)hipGetLastError();
 }
 

@@ -45,6 +45,8 @@ int launch_pv16(const RowsGemmParams& p, int prec, hipStream_t s);   // A and B 
 int launch_gemm_conv(const ConvGemmParams& p, int prec, hipStream_t s);
 int launch_conv_halo(const ConvGemmParams& p, int prec, hipStream_t s);
 int launch_pack_weights(const float* w, long n, int prec, void* out, hipStream_t s);
+int launch_stem7x7(const float* img, const float* w, const float* bias, int act, int B, int H, int W, float* out, double* stats,
+                   hipStream_t s);
 int launch_stats_finalize(const double* sums, long n, double count, float eps, float* mean_rstd, hipStream_t s);
 int launch_residual_relu(const float* x, long ldx, const float* xnorm, const float* y, long ldy, const float* ynorm, int y_relu,
                          int B, int HW, int C, float* out, long ldo, hipStream_t s);

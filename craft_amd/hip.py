@@ -46,6 +46,7 @@ _SIGS = {
     "craft_pack_weights": [P, L, I, P, P],
     "craft_conv2d_nhwc": [P, L, I, P, P, I, I, I, I, P, L, I, I, I, I, P],
     "craft_conv2d_nhwc_ex": [P, L, I, I, I, P, P, P, I, I, I, I, I, P, L, I, I, I, P, I, P],
+    "craft_stem_conv7x7": [P, P, P, I, I, I, I, P, P, P],
     "craft_stats_finalize": [P, L, c_double, F, P, P],
     "craft_residual_relu": [P, L, P, P, L, P, I, I, I, I, P, L, P],
     "craft_convex_upsample": [P, P, I, I, I, P, P],

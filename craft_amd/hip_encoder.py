@@ -10,7 +10,8 @@ k_gemm_conv for the stride-2 ones, the rows GEMM for the final 1x1), and the nor
   CONSUMER applies relu((x - mean) * rstd) while it stages its input (conv halo) or in the fused residual tail;
 * ``relu(x + y)`` of a residual block is one fused kernel (craft_residual_relu) with both pending norms applied.
 
-The 7x7 / stride-2 / 3-channel stem (3.5 % of the encoder flops) stays on PyTorch-ROCm (MIOpen).  Output: tokens
+The 7x7 / stride-2 / 3-channel stem (3.5 % of the encoder flops) is a direct fp32 kernel (craft_stem_conv7x7) fused
+with the input normalisation; no PyTorch / MIOpen compute remains in the forward pass.  Output: tokens
 [B, (H/8)*(W/8), output_dim] — exactly the layout the hot path consumes, so no NCHW round trip exists.
 Falls back to the PyTorch module (then converted to tokens) for shapes the kernels do not support.
 """
@@ -89,6 +90,8 @@ class HipEncoder:
                     packs.append(d)
                 self._final = (self.enc.conv2.weight.detach().float().view(self.enc.conv2.out_channels, -1).contiguous(),
                                self.enc.conv2.bias.detach().float().contiguous())
+                w0, b0 = _fold_bn(self.enc.conv1, self.enc.norm1 if bn else None)
+                self._stem = (w0.permute(2, 3, 1, 0).reshape(147, 64).contiguous(), b0.contiguous())
             self._packs, self._key = packs, key
         return self._packs
 
@@ -107,24 +110,32 @@ class HipEncoder:
         call("craft_stats_finalize", stats, B * C, float(count), IN_EPS, mr)
         return mr
 
-    def forward_tokens(self, x: torch.Tensor, prec) -> torch.Tensor:
-        """x: normalised images [B, 3, H, W] -> tokens [B, (H/8)*(W/8), output_dim]."""
+    def forward_tokens(self, raw: torch.Tensor, prec) -> torch.Tensor:
+        """raw: images [B, 3, H, W] in 0..255 (the normalisation 2*(x/255)-1 of network.py:169-173 is fused into the
+        stem) -> tokens [B, (H/8)*(W/8), output_dim]."""
         enc = self.enc
-        B, _, H, W = x.shape
+        B, _, H, W = raw.shape
         cp = pick(prec, "conv")
         if not self.supported(H, W):
-            return ops.tokens_from_nchw(enc(x).float())
+            return ops.tokens_from_nchw(enc((2 * (raw / 255.0) - 1.0).contiguous()).float())
         packs = self._get_packs(cp)
         inorm = self.kind == "instance"
-        with torch.no_grad():
-            stem = F.relu(enc.norm1(enc.conv1(x)))                                  # 7x7 / s2 stem on MIOpen
-        t = ops.tokens_from_nchw(stem.float())
+        dev = raw.device
         hw = (H // 2, W // 2)
-        dev = x.device
+        # ---- stem: 7x7 / s2 conv (+ folded BatchNorm + ReLU for cnet; raw output + statistics for fnet)
+        sw, sb = self._stem
+        t = torch.empty(B, hw[0] * hw[1], 64, device=dev, dtype=torch.float32)
+        t_norm = None
+        if inorm:
+            s0 = torch.zeros(B, 64, 2, device=dev, dtype=torch.float64)
+            call("craft_stem_conv7x7", raw.contiguous(), sw, sb, ACT_NONE, B, H, W, t, s0)
+            t_norm = self._finalize(s0, hw[0] * hw[1])          # norm1 + ReLU are applied lazily by layer1.0
+        else:
+            call("craft_stem_conv7x7", raw.contiguous(), sw, sb, ACT_RELU, B, H, W, t, None)
         for pk in packs:
             if inorm:
                 s1 = torch.zeros(B, pk["c1"].cout, 2, device=dev, dtype=torch.float64)
-                c1, hw1 = self._conv(t, B, hw, pk["c1"], ACT_NONE, cp, stats=s1)
+                c1, hw1 = self._conv(t, B, hw, pk["c1"], ACT_NONE, cp, in_norm=t_norm, stats=s1)
                 n1 = self._finalize(s1, hw1[0] * hw1[1])
                 s2 = torch.zeros(B, pk["c2"].cout, 2, device=dev, dtype=torch.float64)
                 c2, _ = self._conv(c1, B, hw1, pk["c2"], ACT_NONE, cp, in_norm=n1, stats=s2)
@@ -133,11 +144,14 @@ class HipEncoder:
                     s3 = torch.zeros(B, pk["ds"].cout, 2, device=dev, dtype=torch.float64)
                     xs, _ = self._conv(t, B, hw, pk["ds"], ACT_NONE, cp, stats=s3)
                     n3 = self._finalize(s3, hw1[0] * hw1[1])
+                    flags = 1
                 else:
-                    xs, n3 = t, None
+                    xs, n3 = t, t_norm                          # identity branch (with the stem's pending norm1 + ReLU)
+                    flags = 1 | (2 if t_norm is not None else 0)
                 out = torch.empty_like(c2)
-                call("craft_residual_relu", xs, xs.stride(1), n3, c2, c2.stride(1), n2, 1, B, hw1[0] * hw1[1], c2.shape[-1], out,
-                     out.stride(1))
+                call("craft_residual_relu", xs, xs.stride(1), n3, c2, c2.stride(1), n2, flags, B, hw1[0] * hw1[1], c2.shape[-1],
+                     out, out.stride(1))
+                t_norm = None
             else:
                 c1, hw1 = self._conv(t, B, hw, pk["c1"], ACT_RELU, cp)
                 c2, _ = self._conv(c1, B, hw1, pk["c2"], ACT_RELU, cp)

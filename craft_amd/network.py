@@ -6,8 +6,8 @@ three ``*_trans_config`` objects back into it), same ``forward(image1, image2, i
 upsample, test_mode)`` signature / return conventions, same ``state_dict`` keys (202 in the
 canonical ``--craft --f2 full --setrans`` configuration), ``freeze_bn()``.
 
-Execution: the CNN encoders run on the same HIP conv engine (craft_amd/hip_encoder.py; only their 7x7 stem stays
-on PyTorch-ROCm / MIOpen; ``args.hip_encoders=False`` keeps them entirely on PyTorch); everything after them — F2 transformer,
+Execution: the CNN encoders run on the same HIP conv engine (craft_amd/hip_encoder.py; ``args.hip_encoders=False``
+keeps them on PyTorch-ROCm / MIOpen); everything after them — F2 transformer,
 intra-frame attention, correlation volume + pyramid, and the T refinement iterations — runs through
 ``libcraft_hip.so`` on channels-last token buffers.  Inference only in this round: tensors produced
 by the HIP path carry no autograd graph.
@@ -163,8 +163,7 @@ class CRAFT(nn.Module):
                                       "call model.eval() / use torch.no_grad()")
         args = self.args
         prec = self.hip_prec()
-        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
-        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        raw1, raw2 = image1.float().contiguous(), image2.float().contiguous()
         B, _, H, W = image1.shape
         if H % 8 or W % 8:
             raise ValueError("image height and width must be multiples of 8 (use InputPadder)")
@@ -176,10 +175,12 @@ class CRAFT(nn.Module):
             use_henc = getattr(args, "hip_encoders", True) and not self.training
             if use_henc:
                 # CNN encoders on the HIP conv engine, channels-last end to end
-                fm = self._henc_f.forward_tokens(torch.cat([image1, image2], dim=0), prec)     # [2B, N, 256]
+                fm = self._henc_f.forward_tokens(torch.cat([raw1, raw2], dim=0), prec)         # [2B, N, 256]
                 f1_tok, f2_tok = fm[:B], fm[B:]
-                cn_tok = self._henc_c.forward_tokens(image1, prec)                              # [B, N, 256]
+                cn_tok = self._henc_c.forward_tokens(raw1, prec)                                # [B, N, 256]
             else:
+                image1 = (2 * (raw1 / 255.0) - 1.0).contiguous()
+                image2 = (2 * (raw2 / 255.0) - 1.0).contiguous()
                 with _autocast(getattr(args, "encoder_autocast", False)):
                     fmap1, fmap2 = self.fnet([image1, image2])
                     cnet_feat = self.cnet(image1)

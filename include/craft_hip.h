@@ -137,10 +137,16 @@ int craft_conv2d_nhwc(const float* x, long ldx, int cin, const float* w, const f
  * sum^2) of the biased output per (image, channel) for the consumer's lazy InstanceNorm (zero them first).
  * craft_stats_finalize: n populations of `count` samples: (sum, sum^2) -> (mean, 1/sqrt(var + eps)).
  * craft_residual_relu: out = relu(fx(x) + fy(y)), fx = identity or (x-mean)*rstd (xnorm), fy = identity / relu /
- * relu((y-mean)*rstd) (ynorm, y_relu): the tail of ResidualBlock.forward with both norms applied lazily. */
+ * relu((y-mean)*rstd) (ynorm, y_relu bit 0; bit 1 = ReLU on fx): the tail of ResidualBlock.forward with both
+ * norms applied lazily.
+ * craft_stem_conv7x7: BasicEncoder.conv1 (7x7, stride 2, pad 3, 3 -> 64; extractor.py:139,181) fused with the input
+ * normalisation 2*(x/255)-1 (network.py:169-173): image NCHW [B][3][H][W] raw 0..255, w packed [147 = (ky*7+kx)*3
+ * + c][64] (weight.permute(2,3,1,0)), out tokens [B][(H/2)*(W/2)][64] = act(conv + bias); stats as above. */
 int craft_conv2d_nhwc_ex(const float* x, long ldx, int cin, int Hin, int Win, const float* in_norm, const float* w,
                          const float* bias, int cout, int KH, int KW, int stride, int act, float* y, long ldy, int B,
                          int Hout, int Wout, double* stats, int prec, void* stream);
+int craft_stem_conv7x7(const float* image, const float* w, const float* bias, int act, int B, int H, int W,
+                       float* out, double* stats, void* stream);
 int craft_stats_finalize(const double* sums, long n, double count, float eps, float* mean_rstd, void* stream);
 int craft_residual_relu(const float* x, long ldx, const float* xnorm, const float* y, long ldy, const float* ynorm,
                         int y_relu, int B, int HW, int C, float* out, long ldo, void* stream);

@@ -182,12 +182,41 @@ def test_hip_encoder_matches_pytorch_module(device, which, precision):
     model = _full_model(device, precision)
     enc = getattr(model, which)
     im1, im2, _ = synth_pair(2, 128, 256, seed=5)
-    x = (2 * (torch.cat([im1, im2]) / 255.0) - 1).to(device)
+    raw = torch.cat([im1, im2]).to(device)
     with torch.no_grad():
-        ref = enc(x)
-        got = HipEncoder(enc).forward_tokens(x, Precision.parse(precision))
+        ref = enc(2 * (raw / 255.0) - 1)
+        got = HipEncoder(enc).forward_tokens(raw, Precision.parse(precision))
     B, C, H8, W8 = ref.shape
     got = ops.tokens_to_nchw(got, H8, W8)
     err = (got - ref).abs().max().item()
     scale = ref.abs().max().item()
     assert err < 2e-4 * max(1.0, scale), f"{which}/{precision}: max abs diff {err:.3e} (|ref| max {scale:.2f})"
+
+
+@pytest.mark.parametrize("H,W,B", [(136, 200, 2), (128, 264, 1)])
+def test_ragged_sizes_against_oracle(device, H, W, B):
+    """Image sizes whose token grid is not a multiple of any tile (17x25 = 425 tokens, 16x33 = 528): ragged MFMA
+    tiles, padded P rows, partial conv patches, floor pooling with odd sizes, and the PyTorch fallback of the
+    encoder runner (stride-2 statistics tiles do not divide the image) — compared with the CPU oracle directly."""
+    from oracle import craft_oracle as O
+    model = _full_model(device, "fp32")
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    im1, im2, _ = synth_pair(B, H, W, seed=11)
+    g = torch.Generator().manual_seed(3)
+    fi = 2.0 * torch.randn(B, 2, H // 8, W // 8, generator=g)
+    with torch.no_grad():
+        lo, ups = model(im1.to(device), im2.to(device), iters=3, flow_init=fi.to(device), test_mode=2)
+    lo_ref, ups_ref = O.craft_forward(sd, O.OracleConfig(), im1, im2, iters=3, flow_init=fi, test_mode=2)
+    assert (lo.cpu() - lo_ref).abs().max().item() < 1e-3
+    for a, b in zip(ups, ups_ref):
+        assert (a.cpu() - b).abs().max().item() < 5e-3
+
+
+def test_iters_zero_and_single(device):
+    g = Golden("canon_128x256_T4")
+    model = build(g, device)
+    im1, im2 = (t.to(device) for t in g.images())
+    with torch.no_grad():
+        lo, up = model(im1, im2, iters=1, test_mode=1)
+        preds = model(im1, im2, iters=1, test_mode=0)
+    assert torch.equal(preds[0], up) and lo.shape == (1, 2, 16, 32)
