@@ -202,6 +202,52 @@ int craft_sepconv_gru(float* hx, long ldhx, int cx, const float* wzr1, const flo
   return 0;
 }
 
+int craft_sepconv_gru_context(const float* inp, long ldi, int cc, const float* wzr1, const float* bzr1, const float* wq1,
+                              const float* bq1, const float* wzr2, const float* bzr2, const float* wq2, const float* bq2, int B,
+                              int H8, int W8, float* fields, int prec, void* stream) {
+  const int pk = PACKED_OF(prec);
+  prec = PREC_OF(prec);
+  const float* w[4] = {wzr1, wq1, wzr2, wq2};
+  const float* bb[4] = {bzr1, bq1, bzr2, bq2};
+  const int cout[4] = {256, 128, 256, 128}, off[4] = {0, 256, 384, 640};
+  for (int i = 0; i < 4; ++i) {
+    const int KH = i < 2 ? 1 : 5, KW = i < 2 ? 5 : 1;
+    ConvGemmParams q = conv_params(inp, (int)ldi, cc, nullptr, 0, 0, B, H8, W8, KH, KW, w[i], bb[i], cout[i], CONV_EPI_BIAS_ACT,
+                                   CRAFT_ACT_NONE, 1.f, fields + off[i], 768);
+    q.w_packed = pk;
+    TRY(launch_gemm_conv(q, prec, S(stream)));
+  }
+  return 0;
+}
+
+int craft_sepconv_gru_step(float* hx, long ldhx, int voff, int cv, const float* wzr1, const float* wq1, const float* wzr2,
+                           const float* wq2, const float* fields, int B, int H8, int W8, float* ws, int prec, void* stream) {
+  const long npix = (long)B * H8 * W8;
+  float* z = ws;                 // [npix][128]
+  float* rh = ws + npix * 128;   // [npix][128]
+  hipStream_t s = S(stream);
+  const float* wzr[2] = {wzr1, wzr2};
+  const float* wq[2] = {wq1, wq2};
+  const int pk = PACKED_OF(prec);
+  prec = PREC_OF(prec);
+  for (int pass = 0; pass < 2; ++pass) {
+    const int KH = pass == 0 ? 1 : 5, KW = pass == 0 ? 5 : 1;
+    // z, r from [h | v] + the hoisted context term (fields columns 0..255 / 384..639)
+    ConvGemmParams a = conv_params(hx, (int)ldhx, 128, hx + voff, (int)ldhx, cv, B, H8, W8, KH, KW, wzr[pass], nullptr, 256,
+                                   CONV_EPI_GRU_ZR, 0, 1.f, z, 128);
+    a.aux0 = hx; a.ld0 = (int)ldhx; a.aux1 = rh; a.ld1 = 128; a.w_packed = pk;
+    a.bias_field = fields + (pass == 0 ? 0 : 384); a.ld_bf = 768;
+    TRY(launch_gemm_conv(a, prec, s));
+    // q from [r*h | v] + context term (columns 256..383 / 640..767); h = (1-z)*h + z*q
+    ConvGemmParams q = conv_params(rh, 128, 128, hx + voff, (int)ldhx, cv, B, H8, W8, KH, KW, wq[pass], nullptr, 128,
+                                   CONV_EPI_GRU_Q, 0, 1.f, hx, (int)ldhx);
+    q.aux0 = hx; q.ld0 = (int)ldhx; q.aux1 = z; q.ld1 = 128; q.w_packed = pk;
+    q.bias_field = fields + (pass == 0 ? 256 : 640); q.ld_bf = 768;
+    TRY(launch_gemm_conv(q, prec, s));
+  }
+  return 0;
+}
+
 int craft_flow_head(const float* h, long ldh, const float* w1, const float* b1, const float* w2, const float* b2, int B,
                     int H8, int W8, float* coords1, const float* coords0, float* flow, float* delta, float* ws, int prec,
                     void* stream) {

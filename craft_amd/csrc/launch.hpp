@@ -38,6 +38,8 @@ struct ConvGemmParams {
   int force_generic;     // 1: always use the generic implicit GEMM (k_gemm_conv), for A/B tests
   int w_packed;          // 1: W was produced by craft_pack_weights for this precision (halo kernel only)
   double* stats;         // optional [B][cout][2]: += (sum, sum^2) of the biased conv output per (image, channel)
+  const float* bias_field; int ld_bf;   // optional per-pixel bias [npix][ld_bf] used INSTEAD of bias[col] (hoisted
+                                        // iteration-invariant part of a conv: SepConvGRU context term)
 };
 
 int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s);

@@ -41,6 +41,8 @@ _SIGS = {
     "craft_gma_residual": [P, L, P, P, I, I, I, P, L, P],
     "craft_motion_encoder": [P, L, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, L, P, I, P],
     "craft_sepconv_gru": [P, L, I, P, P, P, P, P, P, P, P, I, I, I, P, I, P],
+    "craft_sepconv_gru_context": [P, L, I, P, P, P, P, P, P, P, P, I, I, I, P, I, P],
+    "craft_sepconv_gru_step": [P, L, I, I, P, P, P, P, P, I, I, I, P, I, P],
     "craft_flow_head": [P, L, P, P, P, P, I, I, I, P, P, P, P, P, I, P],
     "craft_mask_head": [P, L, P, P, P, P, I, I, I, P, P, I, P],
     "craft_pack_weights": [P, L, I, P, P],

@@ -217,6 +217,8 @@ class CRAFT(nn.Module):
                                corr_fn.pyramid, False, prec)
                 self.corr_fn = corr_fn
 
+            # the context features are the same in every iteration: hoist their share of the GRU convolutions
+            gru_fields = self.update_block.gru.context_tokens(hx[..., 128:256], hw, prec)
             coords0, coords1, flow = ops.coords_init(flow_init, B, H8, W8, dev)
             ws = GMAUpdateBlock.workspace(B, N, dev)
             nch = corr_fn.num_levels * (2 * corr_fn.radius + 1) ** 2
@@ -227,7 +229,7 @@ class CRAFT(nn.Module):
             flow_up = None
             for itr in range(iters):
                 corr_fn.lookup_tokens(coords1, out=corr)                               # network.py:235
-                self.update_block.step_tokens(hx, corr, flow, attention, hw, ws, prec)  # :244 (to the new net)
+                self.update_block.step_tokens(hx, corr, flow, attention, hw, ws, prec, gru_fields)  # :244 (to the new net)
                 self.update_block.flow_head_tokens(hx, hw, coords1, coords0, flow, None, ws, prec)   # :244-247
                 # the mask head + convex upsampling only feed the returned predictions: in test_mode=1 only
                 # the last one is returned (network.py:262-263), so earlier ones are skipped (same result).

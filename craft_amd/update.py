@@ -60,6 +60,7 @@ class SepConvGRU(nn.Module):
         self.convr2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
         self.convq2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
         self._pk = _PackCache()
+        self._pk_split = _PackCache()
 
     def packed(self, prec: int = PREC_F32):
         mods = [self.convz1, self.convr1, self.convq1, self.convz2, self.convr2, self.convq2]
@@ -73,6 +74,39 @@ class SepConvGRU(nn.Module):
                         ops.pack_conv_prec(q.weight, prec), q.bias.detach().float().contiguous()]
             return tuple(out)
         return self._pk.get(params, make, tag=prec)
+
+    def packed_split(self, prec: int, c_lo: int, c_hi: int):
+        """Weights split for the hoisted-context form: channels [c_lo, c_hi) of the conv input are iteration
+        invariant (the context features inp); returns (varying-part weights x4, const-part weights + biases x4)."""
+        mods = [self.convz1, self.convr1, self.convq1, self.convz2, self.convr2, self.convq2]
+        params = [p for m in mods for p in (m.weight, m.bias)]
+
+        def make():
+            var, const = [], []
+            for z, r, q in ((self.convz1, self.convr1, self.convq1), (self.convz2, self.convr2, self.convq2)):
+                for w, b in ((torch.cat([z.weight, r.weight], 0), torch.cat([z.bias, r.bias], 0)), (q.weight, q.bias)):
+                    w = w.detach()
+                    var.append(ops.pack_conv_prec(torch.cat([w[:, :c_lo], w[:, c_hi:]], 1).contiguous(), prec))
+                    const += [ops.pack_conv_prec(w[:, c_lo:c_hi].contiguous(), prec), b.detach().float().contiguous()]
+            return tuple(var), tuple(const)
+        return self._pk_split.get(params, make, tag=(prec, c_lo, c_hi))
+
+    def context_tokens(self, inp: torch.Tensor, hw, prec) -> torch.Tensor:
+        """Once per forward: the contribution of the (iteration-invariant) context features to all six gate
+        convolutions, biases included -> fields [B, N, 768]."""
+        B, N, cc = inp.shape
+        cp = pick(prec, "conv")
+        _, const = self.packed_split(cp, self.hidden_dim, self.hidden_dim + cc)
+        fields = torch.empty(B, N, 768, device=inp.device, dtype=torch.float32)
+        call("craft_sepconv_gru_context", inp, inp.stride(1), cc, *const, B, hw[0], hw[1], fields, cp | W_PACKED)
+        return fields
+
+    def step_tokens(self, hx: torch.Tensor, hw, ws: torch.Tensor, prec, fields: torch.Tensor, c_lo: int, c_hi: int):
+        """One GRU update in place on hx = [h | inp | v]: only h and v enter the K loops, `fields` carries the rest."""
+        B, N, ctot = hx.shape
+        cp = pick(prec, "conv")
+        var, _ = self.packed_split(cp, c_lo, c_hi)
+        call("craft_sepconv_gru_step", hx, hx.stride(1), c_hi, ctot - c_hi, *var, fields, B, hw[0], hw[1], ws, cp | W_PACKED)
 
     def forward_tokens(self, hx: torch.Tensor, hw, ws: torch.Tensor, prec: int):
         """In place on hx = [h (128) | x (input_dim)] tokens [B, N, 128+input_dim]."""
@@ -142,16 +176,20 @@ class GMAUpdateBlock(nn.Module):
                                           m2.bias.detach().float().contiguous()), tag=prec)
 
     # -- token-level steps used by CRAFT.forward ---------------------------------------------------
-    def step_tokens(self, hx, corr, flow, attention, hw, ws, prec):
+    def step_tokens(self, hx, corr, flow, attention, hw, ws, prec, gru_fields=None):
         """One refinement step up to the new hidden state (update.py:137-156), in place on
-        hx = [net | inp | motion | motion_global] tokens [B, N, 512]."""
+        hx = [net | inp | motion | motion_global] tokens [B, N, 512].  With ``gru_fields`` (from
+        ``gru.context_tokens(inp)``) the GRU skips the iteration-invariant context channels."""
         self.encoder.forward_tokens(flow, corr, hw, hx[..., 256:384], ws, prec)
         mf = hx[..., 256:384]
         if self.use_setrans:
             self.aggregator(mf, attention, out=hx[..., 384:512], prec=prec)
         else:
             self.aggregator.forward_tokens(attention, mf, prec, out=hx[..., 384:512])
-        self.gru.forward_tokens(hx, hw, ws, prec)
+        if gru_fields is None:
+            self.gru.forward_tokens(hx, hw, ws, prec)
+        else:
+            self.gru.step_tokens(hx, hw, ws, prec, gru_fields, 128, 256)
 
     def flow_head_tokens(self, hx, hw, coords1, coords0, flow, delta, ws, prec):
         B, N, _ = hx.shape

@@ -168,6 +168,22 @@ int craft_sepconv_gru(float* hx, long ldhx, int cx, const float* wzr1, const flo
                       const float* bq1, const float* wzr2, const float* bzr2, const float* wq2,
                       const float* bq2, int B, int H8, int W8, float* ws, int prec, void* stream);
 
+/* SepConvGRU with its iteration-invariant part hoisted.  The context features `inp` (cc channels of x) are the same
+ * in every refinement iteration and a convolution is linear in its input channels, so their contribution to the six
+ * gate convolutions is computed once per forward pass by craft_sepconv_gru_context into
+ *   fields [B*N][768] = [z|r pass 1 (256) | q pass 1 (128) | z|r pass 2 (256) | q pass 2 (128)]   (biases included)
+ * from the const-channel slices of the weights ([cout][KH][KW][cc], optionally packed).  craft_sepconv_gru_step then
+ * runs one GRU update in place on hx = [h (128) | ... | v (cv channels at column voff)] with weights over the
+ * [h | v] channels only ([cout][KH][KW][128+cv]) and `fields` as per-pixel bias: 25 % fewer MACs per iteration,
+ * same result up to fp32 summation order.  ws: 256 floats per pixel. */
+int craft_sepconv_gru_context(const float* inp, long ldi, int cc, const float* wzr1, const float* bzr1,
+                              const float* wq1, const float* bq1, const float* wzr2, const float* bzr2,
+                              const float* wq2, const float* bq2, int B, int H8, int W8, float* fields, int prec,
+                              void* stream);
+int craft_sepconv_gru_step(float* hx, long ldhx, int voff, int cv, const float* wzr1, const float* wq1,
+                           const float* wzr2, const float* wq2, const float* fields, int B, int H8, int W8, float* ws,
+                           int prec, void* stream);
+
 /* FlowHead.forward (update.py:15-16) fused with coords1 += delta (network.py:247) and flow = coords1 - coords0.
  * h: hidden state tokens (row stride ldh); w1 packed [256][3][3][128]; w2 packed [2][3][3][256];
  * delta may be NULL.  ws: 256 floats per pixel. */

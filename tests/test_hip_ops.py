@@ -283,6 +283,11 @@ def test_update_block_pieces(device, prec):
     ub.gru.forward_tokens(hx, (H8, W8), ws, prec)
     close(ops.tokens_to_nchw(hx[..., 0:128], H8, W8), h_ref, rt * 3, at * 10, f"SepConvGRU prec={prec}")
     close(ops.tokens_to_nchw(hx[..., 128:256], H8, W8), inp, 0, 0, "GRU must not touch x")
+    # hoisted-context form: the inp channels enter through precomputed per-pixel bias fields
+    ops.tokens_from_nchw(net.to(device), out=hx[..., 0:128])
+    fields = ub.gru.context_tokens(hx[..., 128:256], (H8, W8), prec)
+    ub.gru.step_tokens(hx, (H8, W8), ws, prec, fields, 128, 256)
+    close(ops.tokens_to_nchw(hx[..., 0:128], H8, W8), h_ref, rt * 3, at * 10, f"SepConvGRU (hoisted context) prec={prec}")
 
     ops.tokens_from_nchw(h_ref.to(device), out=hx[..., 0:128])
     c0, c1, fl = ops.coords_init(flow.to(device), B, H8, W8, device)
