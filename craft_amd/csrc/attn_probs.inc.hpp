@@ -43,25 +43,26 @@ template <int PREC, int D> struct RowTile {
     }
   }
   // registers -> LDS (convert / split as the precision requires)
-  static __device__ __forceinline__ void store(lds_t* S, const float4 (&r)[NPASS], int tid) {
+  static __device__ __forceinline__ void store(lds_t* S, const float4 (&r)[NPASS], int tid, float mul = 1.f) {
     const int ch = tid % NCH, rr = tid / NCH;
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
       const int row = rr + RPP * i;
+      const float4 v = make_float4(r[i].x * mul, r[i].y * mul, r[i].z * mul, r[i].w * mul);
       if constexpr (PREC == CRAFT_PREC_F32) {
-        *reinterpret_cast<float4*>(&S[row * LD + ch * 4]) = r[i];
+        *reinterpret_cast<float4*>(&S[row * LD + ch * 4]) = v;
       } else if constexpr (PREC == CRAFT_PREC_BF16) {
         bf16x4 h;
-        h[0] = (__bf16)r[i].x; h[1] = (__bf16)r[i].y; h[2] = (__bf16)r[i].z; h[3] = (__bf16)r[i].w;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
         *reinterpret_cast<bf16x4*>(&S[row * LD + ch * 4]) = h;
       } else {
         f16x4 h;
-        h[0] = (_Float16)r[i].x; h[1] = (_Float16)r[i].y; h[2] = (_Float16)r[i].z; h[3] = (_Float16)r[i].w;
+        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
         *reinterpret_cast<f16x4*>(&S[row * LD + ch * 4]) = h;
         if constexpr (PREC == CRAFT_PREC_F16X3) {
           f16x4 l;
-          l[0] = (_Float16)(r[i].x - (float)h[0]); l[1] = (_Float16)(r[i].y - (float)h[1]);
-          l[2] = (_Float16)(r[i].z - (float)h[2]); l[3] = (_Float16)(r[i].w - (float)h[3]);
+          l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
+          l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
           *reinterpret_cast<f16x4*>(&S[(128 + row) * LD + ch * 4]) = l;
         }
       }
@@ -138,7 +139,12 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
   const bool clamp = p.clamp_ord != nullptr && ord2f(*p.clamp_ord) > CRAFT_ATTN_CLIP;
   const int nkt = (N + 127) / 128;
   const int q_hmin = n0 / W8, q_hmax = min(n0 + 127, N - 1) / W8;
-  if (p.pos_tab) { const int TT = (2 * R + 1) * (2 * R + 1); for (int i = tid; i < TT; i += NTHREADS) s_tab[i] = p.pos_tab[i]; }
+  // Everything runs in the base-2 log domain: the query tile is pre-multiplied by scale*log2(e) when it is staged
+  // (once per block), the positional table by pos_w*log2(e), so a logit costs no multiply and the softmax uses
+  // v_exp_f32 (2^x) directly.  P = 2^(t - max) / sum is the same number as exp(s - max) / sum.
+  constexpr float LOG2E = 1.4426950408889634f;
+  if (p.pos_tab) { const int TT = (2 * R + 1) * (2 * R + 1); for (int i = tid; i < TT; i += NTHREADS) s_tab[i] = p.pos_tab[i] * (p.pos_w * LOG2E); }
+  const float clip2 = CRAFT_ATTN_CLIP * LOG2E;
 
   const float* qbase = p.Q + (long)b * p.q_bs + (long)m * D;
   const float* kbase = p.Kf + (long)b * p.k_bs + (long)m * D;
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
 
   float4 rk[T::NPASS];
   T::fetch(rk, qbase, p.ldq, n0, N, tid);
-  T::store(Qs, rk, tid);
+  T::store(Qs, rk, tid, p.scale * LOG2E);
   T::fetch(rk, kbase, p.ldk, 0, N, tid);
   T::store(Ks, rk, tid);
   if (tid < 128) { s_kh[tid] = tid / W8; s_kw[tid] = tid - (tid / W8) * W8; }
@@ -167,28 +173,34 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
       for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
     mma_rows<PREC, D>(Ks, Qs, wave * 32, lane, acc);
 
-    // ---- logits of this lane: key row r = mt*32 + 8*(e>>2) + rh4 + (e&3)
+    // ---- logits (base-2 domain) of this lane: key row r = mt*32 + 8*(e>>2) + rh4 + (e&3).  ONE uniform branch per
+    // tile selects the full path (clamp / positional window / mask / ragged tail) or the bare fast path.
     const int j0 = jt * 128;
     const int k_hmin = j0 / W8, k_hmax = min(j0 + 127, N - 1) / W8;
     const bool has_bias = p.pos_tab != nullptr && k_hmax >= q_hmin - R && k_hmin <= q_hmax + R;
     const bool ragged = j0 + 128 > N;
     float tmax = -INFINITY;
+    if (has_bias || ragged || clamp || p.mask_radius > 0) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+      for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int r = mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
-        float s = acc[mt][e] * p.scale;
-        if (clamp) s = fminf(fmaxf(s, -CRAFT_ATTN_CLIP), CRAFT_ATTN_CLIP);
-        if (has_bias || p.mask_radius > 0) {
+        for (int e = 0; e < 16; ++e) {
+          const int r = mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
+          float s = acc[mt][e];
+          if (clamp) s = fminf(fmaxf(s, -clip2), clip2);
           const int dh = s_kh[r] - h1, dw = s_kw[r] - w1;
-          if (has_bias && dh >= -R && dh <= R && dw >= -R && dw <= R) s += p.pos_w * s_tab[(dh + R) * (2 * R + 1) + dw + R];
+          if (has_bias && dh >= -R && dh <= R && dw >= -R && dw <= R) s += s_tab[(dh + R) * (2 * R + 1) + dw + R];
           if (p.mask_radius > 0 && max(abs(dh), abs(dw)) > p.mask_radius) s += -1e9f;
+          if (ragged && j0 + r >= N) s = -INFINITY;
+          acc[mt][e] = s;
+          tmax = fmaxf(tmax, s);
         }
-        if (ragged && j0 + r >= N) s = -INFINITY;
-        acc[mt][e] = s;
-        tmax = fmaxf(tmax, s);
-      }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, acc[mt][e]);
+    }
     if (!pass1) {
       const float m_new = fmaxf(m_run, tmax);
       if (m_new > -INFINITY) {
@@ -196,15 +208,15 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) add += kExact ? expf(acc[mt][e] - m_new) : __expf(acc[mt][e] - m_new);
-        l_run = l_run * ((m_run > -INFINITY) ? expf(m_run - m_new) : 0.f) + add;
+          for (int e = 0; e < 16; ++e) add += kExact ? exp2f(acc[mt][e] - m_new) : __builtin_amdgcn_exp2f(acc[mt][e] - m_new);
+        l_run = l_run * ((m_run > -INFINITY) ? exp2f(m_run - m_new) : 0.f) + add;
         m_run = m_new;
       }
       if (t == nkt - 1) {   // merge the two half-waves (same query, disjoint keys)
         const float m_o = __shfl_xor(m_run, 32), l_o = __shfl_xor(l_run, 32);
         const float m_f = fmaxf(m_run, m_o);
-        const float la_ = (m_run > -INFINITY) ? l_run * expf(m_run - m_f) : 0.f;
-        const float lo_ = (m_o > -INFINITY) ? l_o * expf(m_o - m_f) : 0.f;
+        const float la_ = (m_run > -INFINITY) ? l_run * exp2f(m_run - m_f) : 0.f;
+        const float lo_ = (m_o > -INFINITY) ? l_o * exp2f(m_o - m_f) : 0.f;
         m_run = m_f;
         inv_l = 1.f / (la_ + lo_);
       }
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const float d = acc[mt][4 * q + i] - m_run;
-              pv[i] = (kExact ? expf(d) : __expf(d)) * inv_l;
+              pv[i] = (kExact ? exp2f(d) : __builtin_amdgcn_exp2f(d)) * inv_l;
             }
             if constexpr (PT == CRAFT_PREC_F32) {
               *reinterpret_cast<float4*>(Prow + j) = make_float4(pv[0], pv[1], pv[2], pv[3]);
