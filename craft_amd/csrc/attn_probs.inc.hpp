@@ -163,8 +163,9 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
   for (int t = 0; t < T2; ++t) {
     const bool pass1 = t >= nkt;
     const int jt = pass1 ? t - nkt : t;
-    const int jn = (t + 1 < T2) ? ((t + 1 >= nkt) ? t + 1 - nkt : t + 1) : -1;
-    if (jn >= 0) T::fetch(rk, kbase, p.ldk, jn * 128, N, tid);
+    const int jn = (t + 1 < T2) ? ((t + 1 >= nkt) ? t + 1 - nkt : t + 1) : 0;   // (after the last tile: a harmless refetch)
+    T::fetch(rk, kbase, p.ldk, jn * 128, N, tid);
+    __builtin_amdgcn_sched_barrier(0);     // loads stay above the MFMAs + epilogue they are meant to hide behind
 
     f32x16 acc[4];
 #pragma unroll
@@ -244,11 +245,10 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
           }
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                 // every wave is done with Ks / s_kh / s_kw of tile jt
-    if (jn >= 0) {
-      T::store(Ks, rk, tid);
-      if (tid < 128) { const int j = jn * 128 + tid; s_kh[tid] = j / W8; s_kw[tid] = j - (j / W8) * W8; }
-    }
+    T::store(Ks, rk, tid);
+    if (tid < 128) { const int j = jn * 128 + tid; s_kh[tid] = j / W8; s_kw[tid] = j - (j / W8) * W8; }
     __syncthreads();
   }
 }

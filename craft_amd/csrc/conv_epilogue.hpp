@@ -6,37 +6,133 @@
 
 namespace craft {
 
-__device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, long row, int col, float v) {
+// sigmoid / tanh.  FAST: v_exp_f32 + v_rcp_f32 (1 ulp each, saturating correctly at +-inf) for the 16-bit / split
+// MFMA modes; the exact fp32 mode keeps the libm-grade expf / tanhf so that it stays comparable to the oracle
+// at fp32 round-off.
+template <bool FAST> __device__ __forceinline__ float epi_sigmoid(float v) {
+  if constexpr (FAST) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+  else return sigmoid_precise(v);
+}
+template <bool FAST> __device__ __forceinline__ float epi_tanh(float v) {
+  if constexpr (FAST) return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * v));
+  else return tanhf(v);
+}
+
+// Epilogue of FOUR consecutive output pixels (tokens row0 .. row0+3, the first `nvalid` of them real) of output
+// channel `col`: v[i] is the raw accumulator of pixel i.  The epilogue kind is a template parameter -- the switch
+// on p.epi is taken ONCE per kernel (CONV_EPI_DISPATCH), not once per element -- and the full group (nvalid == 4)
+// runs without exec-mask branches so that its loads are issued back to back.
+template <int EPI, bool FAST>
+__device__ __forceinline__ void conv_epilogue4(const ConvGemmParams& p, long row0, int nvalid, int col, const float (&v)[4]) {
   const int N = p.cout;
-  const float bcol = (col < N) ? (p.bias_field ? p.bias_field[row * p.ld_bf + col] : p.bias[col]) : 0.f;
-  switch (p.epi) {
-    case CONV_EPI_BIAS_ACT:          // out = act(conv + bias) * scale
-      if (col < N) {
-        v += bcol;
-        if (p.act == CRAFT_ACT_RELU) v = fmaxf(v, 0.f);
-        p.out[row * p.ldo + col] = v * p.scale;
-      }
-      break;
-    case CONV_EPI_GRU_ZR:            // cols [0,128): z = sigmoid -> out ; cols [128,256): r = sigmoid, r*h -> aux1
-      if (col < N) {
-        const float s = sigmoid_precise(v + bcol);
-        if (col < 128) p.out[row * p.ldo + col] = s;
-        else p.aux1[row * p.ld1 + (col - 128)] = s * p.aux0[row * p.ld0 + (col - 128)];
-      }
-      break;
-    case CONV_EPI_GRU_Q:             // q = tanh; h' = (1-z) h + z q  (z = aux1, h = aux0; out may alias h)
-      if (col < N) {
-        const float q = tanhf(v + bcol);
-        const float z = p.aux1[row * p.ld1 + col];
-        const float h = p.aux0[row * p.ld0 + col];
-        p.out[row * p.ldo + col] = (1.f - z) * h + z * q;
-      }
-      break;
-    case CONV_EPI_MENC:              // cols [0,N): relu(conv) ; cols N, N+1: the 2 flow channels (update.py:86-87)
-      if (col < N) p.out[row * p.ldo + col] = fmaxf(v + bcol, 0.f);
-      else if (col < N + 2) p.out[row * p.ldo + col] = p.aux0[row * p.ld0 + (col - N)];
-      break;
+  if (nvalid <= 0 || col >= (EPI == CONV_EPI_MENC ? N + 2 : N)) return;
+  if (EPI == CONV_EPI_MENC && col >= N) {     // the 2 pass-through flow channels (update.py:86-87)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < nvalid) p.out[(row0 + i) * p.ldo + col] = p.aux0[(row0 + i) * p.ld0 + (col - N)];
+    return;
   }
+  float b[4];
+  if (p.bias_field) {
+    const float* bf = p.bias_field + row0 * p.ld_bf + col;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = bf[(long)min(i, nvalid - 1) * p.ld_bf];
+  } else {
+    const float b0 = p.bias[col];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = b0;
+  }
+  float o[4];
+  float* dst; long ldd;
+  if constexpr (EPI == CONV_EPI_BIAS_ACT) {            // out = act(conv + bias) * scale
+    const bool relu = p.act == CRAFT_ACT_RELU;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float t = v[i] + b[i]; o[i] = (relu ? fmaxf(t, 0.f) : t) * p.scale; }
+    dst = p.out + row0 * p.ldo + col; ldd = p.ldo;
+  } else if constexpr (EPI == CONV_EPI_GRU_ZR) {       // cols [0,128): z = sigmoid -> out ; cols [128,256): r*h -> aux1
+    if (col < 128) {                                   // (wave-uniform: a wave's 32 columns never straddle 128)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = epi_sigmoid<FAST>(v[i] + b[i]);
+      dst = p.out + row0 * p.ldo + col; ldd = p.ldo;
+    } else {
+      const float* hp = p.aux0 + row0 * p.ld0 + (col - 128);
+      float h[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) h[i] = hp[(long)min(i, nvalid - 1) * p.ld0];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = epi_sigmoid<FAST>(v[i] + b[i]) * h[i];
+      dst = p.aux1 + row0 * p.ld1 + (col - 128); ldd = p.ld1;
+    }
+  } else if constexpr (EPI == CONV_EPI_GRU_Q) {        // q = tanh; h' = (1-z) h + z q  (z = aux1, h = aux0; out may alias h)
+    const float* zp = p.aux1 + row0 * p.ld1 + col;
+    const float* hp = p.aux0 + row0 * p.ld0 + col;
+    float z[4], h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const long j = min(i, nvalid - 1); z[i] = zp[j * p.ld1]; h[i] = hp[j * p.ld0]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (1.f - z[i]) * h[i] + z[i] * epi_tanh<FAST>(v[i] + b[i]);
+    dst = p.out + row0 * p.ldo + col; ldd = p.ldo;
+  } else {                                             // CONV_EPI_MENC, conv columns: relu(conv + bias)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = fmaxf(v[i] + b[i], 0.f);
+    dst = p.out + row0 * p.ldo + col; ldd = p.ldo;
+  }
+  if (nvalid >= 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i * ldd] = o[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i < nvalid) dst[i * ldd] = o[i];
+  }
+}
+
+// run BODY(EPI) with the compile-time epilogue kind that matches p.epi
+#define CONV_EPI_DISPATCH(p, BODY)                                  \
+  switch ((p).epi) {                                                \
+    case CONV_EPI_BIAS_ACT: { BODY(CONV_EPI_BIAS_ACT) } break;      \
+    case CONV_EPI_GRU_ZR: { BODY(CONV_EPI_GRU_ZR) } break;          \
+    case CONV_EPI_GRU_Q: { BODY(CONV_EPI_GRU_Q) } break;            \
+    default: { BODY(CONV_EPI_MENC) } break;                         \
+  }
+
+// Epilogue of a halo-conv wave tile: accumulator rows are patch pixels, GEMM row r -> token (y0 + r/16, x0 + r%16);
+// the 4 rows of one accumulator quad (e = 4q..4q+3) are 4 consecutive pixels of one patch row.
+template <int EPI, bool FAST, int MT, int NT>
+__device__ __forceinline__ void conv_epilogue_patch(const ConvGemmParams& p, const f32x16 (&acc)[MT][NT], int wm0, int lane,
+                                                    int cb, long img, int y0, int x0) {
+  const int c_lane = lane & 31, rh4 = 4 * (lane >> 5);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = wm0 + mt * 32 + 8 * q + rh4;
+      const int y = y0 + (r >> 4), x = x0 + (r & 15);
+      const int nvalid = y < p.g.H ? min(4, p.g.W - x) : 0;
+      const long row0 = img + (long)y * p.g.W + x;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float v[4] = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+        conv_epilogue4<EPI, FAST>(p, row0, nvalid, cb + nt * 32 + c_lane, v);
+      }
+    }
+}
+
+// Epilogue of a generic implicit-GEMM wave tile: accumulator row r of the tile is token rb + r.
+template <int EPI, bool FAST, int MT, int NT>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvGemmParams& p, const f32x16 (&acc)[MT][NT], int lane, long rb, int cb, long M) {
+  const int c_lane = lane & 31, rh4 = 4 * (lane >> 5);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long row0 = rb + mt * 32 + 8 * q + rh4;
+      const int nvalid = (int)max(0L, min(4L, M - row0));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float v[4] = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+        conv_epilogue4<EPI, FAST>(p, row0, nvalid, cb + nt * 32 + c_lane, v);
+      }
+    }
 }
 
 // Per-(image, channel) moments of the biased conv output for a lazy InstanceNorm: column sums of this wave's

@@ -303,8 +303,8 @@ int craft_residual_relu(const float* x, long ldx, const float* xnorm, const floa
   return launch_residual_relu(x, ldx, xnorm, y, ldy, ynorm, y_relu, B, HW, C, out, ldo, S(stream));
 }
 
-int craft_pack_weights(const float* w, long n, int prec, void* out, void* stream) {
-  return launch_pack_weights(w, n, prec, out, S(stream));
+int craft_pack_weights(const float* w, int rows, int K, int prec, void* out, void* stream) {
+  return launch_pack_weights(w, rows, K, PREC_OF(prec), out, S(stream));
 }
 
 int craft_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, void* stream) {

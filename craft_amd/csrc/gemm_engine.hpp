@@ -341,16 +341,18 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int nk
   for (int kt = 0; kt < nk; ++kt) {
     const int ao = (kt & 1) * L::A_ELEMS, bo = 2 * L::A_ELEMS + (kt & 1) * L::B_ELEMS;
     const int an = L::A_ELEMS - ao, bn = 2 * L::A_ELEMS + L::B_ELEMS - (kt & 1) * L::B_ELEMS;
-    if (kt + 1 < nk) {
-      la.fetch(kt + 1, ra);
-      lb.fetch(kt + 1, rb);
-    }
+    // Straight-line body: the next tile is always fetched (index clamped; the duplicate of the last tile lands in
+    // the idle buffer) and the issue order is pinned -- left alone, hipcc sinks the global loads below the
+    // MFMAs to save registers and then waits on them at once, exposing an L2 round trip in every K-tile.
+    const int ktn = min(kt + 1, nk - 1);
+    la.fetch(ktn, ra);
+    lb.fetch(ktn, rb);
+    __builtin_amdgcn_sched_barrier(0);
     mma_tile<PREC, MT, NT, BM, BN>(&S[ao], &S[bo], wm0, wn0, lane, acc);
     fold(kt);
-    if (kt + 1 < nk) {
-      stage_store<PREC>(&S[an], ra, tid);
-      stage_store<PREC>(&S[bn], rb, tid);
-    }
+    __builtin_amdgcn_sched_barrier(0);
+    stage_store<PREC>(&S[an], ra, tid);
+    stage_store<PREC>(&S[bn], rb, tid);
     __syncthreads();
   }
 }

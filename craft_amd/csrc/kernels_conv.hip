@@ -7,7 +7,8 @@
 // lane's base row plus a wave-uniform offset.  Compared with the generic implicit GEMM (k_gemm_conv), which
 // re-gathers and re-converts the activation tile for every tap, activation staging drops by 5x (1x5, 5x1)
 // to 6.4x (3x3); only the weight tile [BN x 32] is staged per (chunk, tap), double-buffered with one
-// barrier per K-tile.  Epilogues are shared with k_gemm_conv (conv_epilogue.hpp).
+// barrier per K-tile.  Epilogues are shared with k_gemm_conv (conv_epilogue.hpp).  This is the RAW-weight
+// (fp32 [Cout][KH][KW][Cin]) kernel; pre-packed 16-bit weights take k_conv_halo_wf (kernels_conv_wf.hip).
 #include <cstdlib>
 #include "conv_epilogue.hpp"
 
@@ -17,7 +18,7 @@ constexpr int PATCH_H = 8, PATCH_W = 16;
 
 // ENC: the encoder features (lazy InstanceNorm on the input, per-channel statistics of the output) are a
 // compile-time variant so that the update-block instantiation keeps its register budget (2 waves per SIMD).
-template <int PREC, int BN, bool WPACK, bool ENC>
+template <int PREC, int BN, bool ENC>
 __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
   typedef typename PrecT<PREC>::lds_t lds_t;
   constexpr int LD = PrecT<PREC>::LD, PL = Planes<PREC>::N;
@@ -104,50 +105,20 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
   // ---- weight tile loader: rows = output channels n0.., k = tap*ctot + chunk*32 .. +32.  Rows beyond cout
   // re-read the last real row: those output columns are discarded / overwritten by the epilogue, and an
   // unconditional load keeps exec-mask branches out of the K loop.
-  constexpr int NV = WPACK ? PL * (BN / 64) : 1;      // uint4 per thread for one packed weight tile
   const float* wp[BN / 32];
-  const uint16_t* wq[PL * (BN / 64)];
-  if constexpr (WPACK) {
-    const uint16_t* W16 = reinterpret_cast<const uint16_t*>(p.W);
 #pragma unroll
-    for (int pl = 0; pl < PL; ++pl)
-#pragma unroll
-      for (int i = 0; i < BN / 64; ++i) {
-        const int row = n0 + (tid >> 2) + 64 * i;
-        wq[pl * (BN / 64) + i] = W16 + ((long)pl * p.cout + min(row, p.cout - 1)) * K + (tid & 3) * 8;
-      }
-  } else {
-#pragma unroll
-    for (int i = 0; i < BN / 32; ++i) {
-      const int row = n0 + r0 + 32 * i;
-      wp[i] = p.W + (long)min(row, p.cout - 1) * K + c4 * 4;
-    }
+  for (int i = 0; i < BN / 32; ++i) {
+    const int row = n0 + r0 + 32 * i;
+    wp[i] = p.W + (long)min(row, p.cout - 1) * K + c4 * 4;
   }
   RegsF32<BN> rbf;
   rbf.zmask = 0u;
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 rbv[NV];
   auto fetch_w = [&](int chunk, int tap) __attribute__((always_inline)) {
     const int koff = tap * ctot + chunk * BK;
-    if constexpr (WPACK) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) rbv[i] = *reinterpret_cast<const u32x4*>(wq[i] + koff);
-    } else {
-#pragma unroll
-      for (int i = 0; i < BN / 32; ++i) rbf.v[i] = *reinterpret_cast<const float4*>(wp[i] + koff);
-    }
+    for (int i = 0; i < BN / 32; ++i) rbf.v[i] = *reinterpret_cast<const float4*>(wp[i] + koff);
   };
-  auto store_w = [&](int buf) __attribute__((always_inline)) {
-    if constexpr (WPACK) {
-#pragma unroll
-      for (int pl = 0; pl < PL; ++pl)
-#pragma unroll
-        for (int i = 0; i < BN / 64; ++i)
-          *reinterpret_cast<u32x4*>(&Bs[buf * B_ELEMS + (pl * BN + (tid >> 2) + 64 * i) * LD + (tid & 3) * 8]) = rbv[pl * (BN / 64) + i];
-    } else {
-      stage_store<PREC>(&Bs[buf * B_ELEMS], rbf, tid);
-    }
-  };
+  auto store_w = [&](int buf) __attribute__((always_inline)) { stage_store<PREC>(&Bs[buf * B_ELEMS], rbf, tid); };
 
   // lane's base halo rows for its MT output-row fragments
   int arow[MT];
@@ -246,7 +217,11 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
     for (tap = 0; tap < T; ++tap) {
       const bool last_tap = tap + 1 == T;
       fetch_w(last_tap ? cn : chunk, last_tap ? 0 : tap + 1);
+      // pin the issue order: without the fences hipcc sinks the weight loads below the MFMAs (to save VGPRs)
+      // and then waits on them immediately, exposing an L2 round trip in every K-tile
+      __builtin_amdgcn_sched_barrier(0);
       { const int ty_ = tap / KW; mma_step(buf, ty_ * HWd + (tap - ty_ * KW)); }
+      __builtin_amdgcn_sched_barrier(0);
       store_w(buf ^ 1);
       __syncthreads();
       buf ^= 1;
@@ -258,17 +233,10 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
 
   // ---- epilogue: GEMM row r of the patch -> token (y0 + r/16, x0 + r%16)
   const int cb = n0 + wn0;
-  const int c_lane = lane & 31, rh4 = 4 * (lane >> 5);
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int r = wm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
-        const int y = y0 + (r >> 4), x = x0 + (r & 15);
-        if (y < g.H && x < g.W) conv_epilogue(p, img + (long)y * g.W + x, cb + nt * 32 + c_lane, acc[mt][nt][e]);
-      }
+  const int rh4 = 4 * (lane >> 5);
+#define BODY(E) conv_epilogue_patch<E, PREC != CRAFT_PREC_F32, MT, NT>(p, acc, wm0, lane, cb, img, y0, x0);
+  CONV_EPI_DISPATCH(p, BODY)
+#undef BODY
   if (ENC && p.stats) {
     unsigned mlo = 0u, mhi = 0u;
 #pragma unroll
@@ -284,59 +252,31 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
   }
 }
 
-template <int PREC, int BN, bool WPACK> static int launch_halo_t(const ConvGemmParams& p, hipStream_t s) {
+template <int PREC, int BN> static int launch_halo_t(const ConvGemmParams& p, hipStream_t s) {
   const bool enc = p.g.in_norm != nullptr || p.stats != nullptr;
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   const int tiles = ((p.g.W + PATCH_W - 1) / PATCH_W) * ((p.g.H + PATCH_H - 1) / PATCH_H) * (p.g.npix / (p.g.H * p.g.W));
   dim3 grid(tiles, (ncols + BN - 1) / BN, 1);
-  if (enc) hipLaunchKernelGGL((k_conv_halo<PREC, BN, WPACK, true>), grid, dim3(NTHREADS), 0, s, p);
-  else hipLaunchKernelGGL((k_conv_halo<PREC, BN, WPACK, false>), grid, dim3(NTHREADS), 0, s, p);
+  if (enc) hipLaunchKernelGGL((k_conv_halo<PREC, BN, true>), grid, dim3(NTHREADS), 0, s, p);
+  else hipLaunchKernelGGL((k_conv_halo<PREC, BN, false>), grid, dim3(NTHREADS), 0, s, p);
   return (int)hipGetLastError();
 }
 
 int launch_conv_halo(const ConvGemmParams& p, int prec, hipStream_t s) {
   if (p.g.KH > 5 || p.g.KW > 5 || (p.g.KH + 7) * (p.g.KW + 15) > (PATCH_H + 4) * PATCH_W) return CRAFT_ERR_UNSUPPORTED;
+  // packed weights (craft_pack_weights, fragment order): the weight-fragment kernel (kernels_conv_wf.hip)
+  if (p.w_packed) return prec == CRAFT_PREC_F32 ? CRAFT_ERR_ARG : launch_conv_halo_wf(p, prec, s);
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   // BN = 128 only when that still leaves >= 2 blocks per CU's worth of tiles for wide outputs
   int bn = (ncols % 128 == 0 && ncols >= 256) ? 128 : 64;
   if (const char* e = getenv("CRAFT_HALO_BN")) bn = atoi(e) == 128 ? (ncols % 128 == 0 ? 128 : 64) : 64;   // tuning override
-  if (p.w_packed && ((p.g.c0 + p.g.c1) * p.g.KH * p.g.KW) % 8) return CRAFT_ERR_ALIGN;
-#define GO(PR, WP) do { if (bn == 128) return launch_halo_t<PR, 128, WP>(p, s); else return launch_halo_t<PR, 64, WP>(p, s); } while (0)
-  if (prec == CRAFT_PREC_F32) GO(CRAFT_PREC_F32, false);      // packed == raw for fp32
-  if (prec == CRAFT_PREC_BF16) { if (p.w_packed) GO(CRAFT_PREC_BF16, true); else GO(CRAFT_PREC_BF16, false); }
-  if (prec == CRAFT_PREC_F16) { if (p.w_packed) GO(CRAFT_PREC_F16, true); else GO(CRAFT_PREC_F16, false); }
-  if (prec == CRAFT_PREC_F16X3) { if (p.w_packed) GO(CRAFT_PREC_F16X3, true); else GO(CRAFT_PREC_F16X3, false); }
+#define GO(PR) do { if (bn == 128) return launch_halo_t<PR, 128>(p, s); else return launch_halo_t<PR, 64>(p, s); } while (0)
+  if (prec == CRAFT_PREC_F32) GO(CRAFT_PREC_F32);
+  if (prec == CRAFT_PREC_BF16) GO(CRAFT_PREC_BF16);
+  if (prec == CRAFT_PREC_F16) GO(CRAFT_PREC_F16);
+  if (prec == CRAFT_PREC_F16X3) GO(CRAFT_PREC_F16X3);
 #undef GO
   return CRAFT_ERR_ARG;
-}
-
-// ---------------------------------------------------------------------------------------------
-// craft_pack_weights: fp32 [rows][K] -> the LDS element type of `prec`: bf16 / fp16 [rows][K], or for F16X3
-// two fp16 planes [2][rows][K] (hi = fp16(w), lo = fp16(w - hi)); fp32 is a plain copy.
-// ---------------------------------------------------------------------------------------------
-template <int PREC>
-__global__ void k_pack_weights(const float* __restrict__ w, long n, void* __restrict__ out) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float v = w[i];
-  if constexpr (PREC == CRAFT_PREC_F32) reinterpret_cast<float*>(out)[i] = v;
-  else if constexpr (PREC == CRAFT_PREC_BF16) reinterpret_cast<__bf16*>(out)[i] = (__bf16)v;
-  else {
-    const _Float16 h = (_Float16)v;
-    reinterpret_cast<_Float16*>(out)[i] = h;
-    if constexpr (PREC == CRAFT_PREC_F16X3) reinterpret_cast<_Float16*>(out)[n + i] = (_Float16)(v - (float)h);
-  }
-}
-
-int launch_pack_weights(const float* w, long n, int prec, void* out, hipStream_t s) {
-  if (n <= 0) return 0;
-  dim3 grid((unsigned)((n + 255) / 256));
-  if (prec == CRAFT_PREC_F32) hipLaunchKernelGGL((k_pack_weights<CRAFT_PREC_F32>), grid, dim3(256), 0, s, w, n, out);
-  else if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_pack_weights<CRAFT_PREC_BF16>), grid, dim3(256), 0, s, w, n, out);
-  else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_pack_weights<CRAFT_PREC_F16>), grid, dim3(256), 0, s, w, n, out);
-  else if (prec == CRAFT_PREC_F16X3) hipLaunchKernelGGL((k_pack_weights<CRAFT_PREC_F16X3>), grid, dim3(256), 0, s, w, n, out);
-  else return CRAFT_ERR_ARG;
-  return (int)hipGetLastError();
 }
 
 }  // namespace craft

@@ -1,0 +1,303 @@
+// Halo-tile NHWC convolution, weight-fragment variant (packed 16-bit weights: bf16 / fp16 / f16x3).
+//
+// Same tiling as k_conv_halo (kernels_conv.hip): a block owns an 8x16 patch of output pixels and BN output
+// channels, the (8+KH-1) x (16+KW-1) halo of 32 input channels is staged into LDS once per channel chunk and all
+// KH*KW taps run from it.  What differs is the weight operand: craft_pack_weights lays the weights out in MFMA
+// FRAGMENT order ([k-tile][32-column block][plane][k-half][lane][8 halves]), so a wave fetches the B operand of
+// one 32x32x16 MFMA with ONE fully coalesced 1 KiB global_load_dwordx4 straight into the registers the MFMA
+// reads.  The weights never touch LDS:
+//   * no per-K-tile weight staging (4 ds_write_b128 + 8 ds_read_b128 per wave and K-tile gone),
+//   * no per-K-tile barrier: the only block-wide synchronisation left is ONE barrier per channel chunk (the halo
+//     is double-buffered), i.e. every KH*KW K-tiles; in between the four waves run free, so one wave's LDS /
+//     global latency overlaps the other waves' MFMAs instead of stalling the whole block at a barrier.
+// The weight tile of a block (BN x K, <= 1 MB) is shared by every block of the same column block and lives in L2.
+// Each wave owns 32 output channels (NT = 1) and MT = 128 / (32 * WM) row fragments:
+//   BN = 128: WM = 1, WN = 4, MT = 4   |   BN = 64: WM = 2, WN = 2, MT = 2.
+#include <cstdlib>
+#include "conv_epilogue.hpp"
+
+namespace craft {
+
+constexpr int WF_PATCH_H = 8, WF_PATCH_W = 16;
+
+template <int PREC> struct FragT;
+template <> struct FragT<CRAFT_PREC_BF16> { typedef bf16x8 t; };
+template <> struct FragT<CRAFT_PREC_F16> { typedef f16x8 t; };
+template <> struct FragT<CRAFT_PREC_F16X3> { typedef f16x8 t; };
+
+template <int PREC>
+__device__ __forceinline__ f32x16 mfma16(typename FragT<PREC>::t a, typename FragT<PREC>::t b, f32x16 c) {
+  if constexpr (PREC == CRAFT_PREC_BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <int PREC, int WM, int WN, bool ENC, int DBG = 0>
+__global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
+  typedef typename PrecT<PREC>::lds_t lds_t;
+  typedef typename FragT<PREC>::t frag_t;
+  constexpr int LD = PrecT<PREC>::LD, PL = Planes<PREC>::N;
+  constexpr int BM = 128, MT = BM / WM / 32, BN = WN * 32;
+  static_assert(WM * WN == NTHREADS / 64, "4 waves");
+  constexpr int HR_MAX = (WF_PATCH_H + 4) * WF_PATCH_W;    // 192 halo rows: enough for 5x1 / 1x5 / 3x3
+  constexpr int NA = HR_MAX / 32;                          // float4 per thread for one halo chunk
+  constexpr int A_ELEMS = PL * HR_MAX * LD;
+  __shared__ __attribute__((aligned(16))) lds_t As[2 * A_ELEMS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const ConvGeom& g = p.g;
+  const int KH = g.KH, KW = g.KW, T = KH * KW;
+  const int HWd = WF_PATCH_W + KW - 1, HH = WF_PATCH_H + KH - 1, HR = HH * HWd;
+  const int tiles_x = (g.W + WF_PATCH_W - 1) / WF_PATCH_W, tiles_y = (g.H + WF_PATCH_H - 1) / WF_PATCH_H;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = ty * WF_PATCH_H, x0 = tx * WF_PATCH_W;
+  const int n0 = blockIdx.y * BN;
+  const int ctot = g.c0 + g.c1, nchunk = ctot / BK;
+  const long img = (long)b * g.H * g.W;
+  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * 32;
+  const int c4 = tid & 7, r0 = tid >> 3;
+
+  // ---- halo gather: per-thread pixel offsets (-1: outside the image / beyond the halo)
+  int hpix[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int hr = r0 + 32 * i;
+    const int hy = hr / HWd, hx = hr - hy * HWd;
+    const int y = y0 - g.padH + hy, x = x0 - g.padW + hx;
+    hpix[i] = (hr < HR && y >= 0 && y < g.H && x >= 0 && x < g.W) ? y * g.W + x : -1;
+  }
+  auto fetch_halo = [&](int chunk, float4 (&r)[NA]) __attribute__((always_inline)) {
+    const int cb = chunk * BK;
+    const float* sp; int ld, c;
+    if (cb < g.c0) { sp = g.seg0; ld = g.ld0; c = cb; } else { sp = g.seg1; ld = g.ld1; c = cb - g.c0; }
+    // unconditional loads (clamped pixel); out-of-image taps are zeroed by a value select in store_halo
+#pragma unroll
+    for (int i = 0; i < NA; ++i) r[i] = *reinterpret_cast<const float4*>(sp + (img + max(hpix[i], 0)) * ld + c + c4 * 4);
+  };
+  auto store_halo = [&](int hb, int chunk, const float4 (&r)[NA]) __attribute__((always_inline)) {
+    lds_t* A0 = &As[hb * A_ELEMS];
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (ENC && g.in_norm) {     // (mean, rstd) of this thread's 4 input channels, image b
+      const float* t = g.in_norm + ((long)b * g.c0 + chunk * BK + c4 * 4) * 2;
+      const float4 t0 = *reinterpret_cast<const float4*>(t), t1 = *reinterpret_cast<const float4*>(t + 4);
+      mu = make_float4(t0.x, t0.z, t1.x, t1.z);
+      rs = make_float4(t0.y, t0.w, t1.y, t1.w);
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int row = r0 + 32 * i;                // rows >= HR are written too (zeros, never read): no exec branch
+      const bool ok = hpix[i] >= 0;
+      float4 v = r[i];
+      if (ENC && g.in_norm) {
+        v.x = fmaxf((v.x - mu.x) * rs.x, 0.f); v.y = fmaxf((v.y - mu.y) * rs.y, 0.f);
+        v.z = fmaxf((v.z - mu.z) * rs.z, 0.f); v.w = fmaxf((v.w - mu.w) * rs.w, 0.f);
+      }
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      if constexpr (PREC == CRAFT_PREC_BF16) {
+        bf16x4 h;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(&A0[row * LD + c4 * 4]) = h;
+      } else {
+        f16x4 h;
+        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+        *reinterpret_cast<f16x4*>(&A0[row * LD + c4 * 4]) = h;
+        if constexpr (PREC == CRAFT_PREC_F16X3) {
+          f16x4 l;
+          l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
+          l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+          *reinterpret_cast<f16x4*>(&A0[(HR_MAX + row) * LD + c4 * 4]) = l;
+        }
+      }
+    }
+  };
+
+  // ---- weight fragments: [kt][nb][pl][kk][lane][8].  Column blocks beyond the packed width re-read the last one
+  // (those output columns are discarded / overwritten by the epilogue).
+  const int NBtot = (p.cout + 31) / 32;
+  const int nb = min((n0 + wn0) / 32, NBtot - 1);
+  const uint16_t* wb = reinterpret_cast<const uint16_t*>(p.W) + (long)nb * (PL * 1024) + lane * 8;
+  const long kt_stride = (long)NBtot * (PL * 1024);
+  frag_t bq[PL][2], bn[PL][2];
+  auto fetch_b = [&](int kt, frag_t (&dst)[PL][2]) __attribute__((always_inline)) {
+    const uint16_t* q = wb + kt * kt_stride;
+#pragma unroll
+    for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) dst[pl][kk] = *reinterpret_cast<const frag_t*>(q + (pl * 2 + kk) * 512);
+  };
+
+  // lane's base halo element offsets for its MT output-row fragments
+  int arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int r = wm0 + mt * 32 + (lane & 31);
+    arow[mt] = ((r >> 4) * HWd + (r & 15)) * LD + (lane >> 5) * 8;
+  }
+  // A fragments of one k-half: hi (and lo) plane rows of the halo buffer `hb`, shifted by the tap offset
+  auto read_a = [&](int hb, int toff, int kk, frag_t (&h)[MT], frag_t (&l)[MT]) __attribute__((always_inline)) {
+    const lds_t* A0 = &As[hb * A_ELEMS + toff + kk * 16];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      h[mt] = *reinterpret_cast<const frag_t*>(&A0[arow[mt]]);
+      if constexpr (PL == 2) l[mt] = *reinterpret_cast<const frag_t*>(&A0[HR_MAX * LD + arow[mt]]);
+    }
+  };
+
+  f32x16 acc[MT][1];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[mt][0][e] = 0.f;
+  // MFMAs of one k-half; term-major order so that consecutive MFMAs hit different accumulators
+  auto mma_half = [&](const frag_t (&h)[MT], const frag_t (&l)[MT], int kk) __attribute__((always_inline)) {
+    if constexpr (PL == 2) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(l[mt], bq[0][kk], acc[mt][0]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(h[mt], bq[1][kk], acc[mt][0]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(h[mt], bq[0][kk], acc[mt][0]);
+  };
+
+  float4 ra[NA];
+  fetch_halo(0, ra);
+  fetch_b(0, bq);
+  store_halo(0, 0, ra);
+  __syncthreads();
+
+  // K loop: chunk-outer / tap-inner; K-tile index in the packed weights = tap * nchunk + chunk.  Software pipeline,
+  // all distances in units of one k-half (MT*3 MFMAs):
+  //   * A fragments (LDS) are requested ONE k-half ahead (two register sets a0 / a1),
+  //   * B fragments (L2) a whole K-tile ahead (bn, copied into bq after the tile's MFMAs),
+  //   * the next chunk's halo (HBM/L2) a whole chunk ahead; it is written to the idle LDS buffer after the second
+  //     tap and published by the single barrier of the chunk, placed right before the first read of that buffer
+  //     (in the middle of the last tap), by which time every wave has long finished its stores.
+  frag_t a0h[MT], a0l[MT], a1h[MT], a1l[MT];
+  const int smid = min(1, T - 1);
+  int hb = 0;
+  read_a(0, 0, 0, a0h, a0l);
+  if (DBG & 4) read_a(0, 0, 1, a1h, a1l);
+  for (int chunk = 0; chunk < ((DBG & 16) ? 0 : nchunk); ++chunk) {
+    const int cn = min(chunk + 1, nchunk - 1);
+    if (!(DBG & 1)) fetch_halo(cn, ra);                   // straight-line: lands during this chunk's taps
+    for (int tap = 0; tap < T; ++tap) {
+      const bool last_tap = tap + 1 == T;
+      const int tapn = last_tap ? 0 : tap + 1;
+      const int ty_ = tap / KW, tyn = tapn / KW;
+      const int toff = (ty_ * HWd + (tap - ty_ * KW)) * LD, toffn = (tyn * HWd + (tapn - tyn * KW)) * LD;
+      if (!(DBG & 2)) fetch_b(last_tap ? cn : tapn * nchunk + chunk, bn);
+      if (!(DBG & 4)) read_a(hb, toff, 1, a1h, a1l);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a0h, a0l, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(DBG & 1) && tap == smid) store_halo(hb ^ 1, cn, ra);
+      if (!(DBG & 8) && last_tap) { __syncthreads(); hb ^= 1; }
+      if (!(DBG & 4)) read_a(hb, toffn, 0, a0h, a0l);                    // next tile (after the last chunk: a harmless re-read)
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(a1h, a1l, 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pl = 0; pl < PL; ++pl) if (!(DBG & 2)) { bq[pl][0] = bn[pl][0]; bq[pl][1] = bn[pl][1]; }
+    }
+  }
+
+  // ---- epilogue: GEMM row r of the patch -> token (y0 + r/16, x0 + r%16)
+  const int cb = n0 + wn0;
+  const int rh4 = 4 * (lane >> 5);
+#define BODY(E) conv_epilogue_patch<E, true, MT, 1>(p, acc, wm0, lane, cb, img, y0, x0);
+  CONV_EPI_DISPATCH(p, BODY)
+#undef BODY
+  if (ENC && p.stats) {
+    unsigned mlo = 0u, mhi = 0u;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = wm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
+        const bool ok = (y0 + (r >> 4)) < g.H && (x0 + (r & 15)) < g.W;
+        const int bit = mt * 16 + e;
+        if (ok) { if (bit < 32) mlo |= 1u << bit; else mhi |= 1u << (bit - 32); }
+      }
+    conv_col_stats<MT, 1>(p, acc, lane, cb, (long)b, mlo, mhi);
+  }
+}
+
+template <int PREC, int WM, int WN> static int launch_wf_t(const ConvGemmParams& p, hipStream_t s) {
+  constexpr int BN = WN * 32;
+  const bool enc = p.g.in_norm != nullptr || p.stats != nullptr;
+  const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
+  const int tiles = ((p.g.W + WF_PATCH_W - 1) / WF_PATCH_W) * ((p.g.H + WF_PATCH_H - 1) / WF_PATCH_H) * (p.g.npix / (p.g.H * p.g.W));
+  dim3 grid(tiles, (ncols + BN - 1) / BN, 1);
+  if (const char* e = getenv("CRAFT_DBG")) {
+    if constexpr (PREC == CRAFT_PREC_F16X3 && WM == 1) {
+      const int d = atoi(e);
+#define DB(D) if (d == D) { hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, false, D>), grid, dim3(NTHREADS), 0, s, p); return (int)hipGetLastError(); }
+      DB(1) DB(7) DB(16) DB(23)
+#undef DB
+    }
+  }
+  if (enc) hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, true>), grid, dim3(NTHREADS), 0, s, p);
+  else hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, false>), grid, dim3(NTHREADS), 0, s, p);
+  return (int)hipGetLastError();
+}
+
+// packed (fragment-order) weights only; called by launch_conv_halo
+int launch_conv_halo_wf(const ConvGemmParams& p, int prec, hipStream_t s) {
+  const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
+  // BN = 128 only when that still leaves >= 2 blocks per CU's worth of tiles for wide outputs
+  int bn = (ncols % 128 == 0 && ncols >= 256) ? 128 : 64;
+  if (const char* e = getenv("CRAFT_HALO_BN")) bn = atoi(e) == 128 ? 128 : 64;   // tuning override
+#define GO(PR) do { if (bn == 128) return launch_wf_t<PR, 1, 4>(p, s); else return launch_wf_t<PR, 2, 2>(p, s); } while (0)
+  if (prec == CRAFT_PREC_BF16) GO(CRAFT_PREC_BF16);
+  if (prec == CRAFT_PREC_F16) GO(CRAFT_PREC_F16);
+  if (prec == CRAFT_PREC_F16X3) GO(CRAFT_PREC_F16X3);
+#undef GO
+  return CRAFT_ERR_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------
+// craft_pack_weights: fp32 [rows][K] -> MFMA fragment order of `prec` (see the header of this file):
+//   out[((((kt * NB + nb) * PL + pl) * 2 + kk) * 64 + lane) * 8 + j] = plane_pl( w[nb*32 + (lane & 31)][kt*32 + kk*16 + (lane >> 5)*8 + j] )
+// NB = ceil(rows / 32) (rows beyond `rows` are zero), PL = 2 for F16X3 (hi = fp16(w), lo = fp16(w - hi)), else 1.
+// ---------------------------------------------------------------------------------------------
+template <int PREC>
+__global__ void k_pack_weights_wf(const float* __restrict__ w, int rows, int K, void* __restrict__ out) {
+  typedef typename PrecT<PREC>::lds_t h_t;
+  constexpr int PL = Planes<PREC>::N;
+  const int NB = (rows + 31) / 32;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (kt, nb, kk, lane)
+  const long total = (long)(K / 32) * NB * 128;
+  if (i >= total) return;
+  const int lane = (int)(i & 63), kk = (int)((i >> 6) & 1);
+  const long t = i >> 7;
+  const int nbi = (int)(t % NB);
+  const long kt = t / NB;
+  const int row = nbi * 32 + (lane & 31);
+  const long k = kt * 32 + kk * 16 + (lane >> 5) * 8;
+  h_t* o = reinterpret_cast<h_t*>(out) + (((kt * NB + nbi) * PL) * 2 + kk) * 512 + lane * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = row < rows ? w[(long)row * K + k + j] : 0.f;
+    const h_t h = (h_t)v;
+    o[j] = h;
+    if constexpr (PL == 2) o[1024 + j] = (h_t)(v - (float)h);
+  }
+}
+
+int launch_pack_weights(const float* w, int rows, int K, int prec, void* out, hipStream_t s) {
+  if (rows <= 0 || K <= 0) return 0;
+  if (prec == CRAFT_PREC_F32) return (int)hipMemcpyAsync(out, w, (size_t)rows * K * sizeof(float), hipMemcpyDeviceToDevice, s);
+  if (K % 32) return CRAFT_ERR_ALIGN;
+  const long total = (long)(K / 32) * ((rows + 31) / 32) * 128;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_pack_weights_wf<CRAFT_PREC_BF16>), grid, dim3(256), 0, s, w, rows, K, out);
+  else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_pack_weights_wf<CRAFT_PREC_F16>), grid, dim3(256), 0, s, w, rows, K, out);
+  else if (prec == CRAFT_PREC_F16X3) hipLaunchKernelGGL((k_pack_weights_wf<CRAFT_PREC_F16X3>), grid, dim3(256), 0, s, w, rows, K, out);
+  else return CRAFT_ERR_ARG;
+  return (int)hipGetLastError();
+}
+
+}  // namespace craft

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) fetch(kt + 1);
+    fetch(min(kt + 1, nk - 1));          // always (clamped duplicate at the end): no branch around the loads
+    __builtin_amdgcn_sched_barrier(0);   // keep the loads ABOVE the MFMAs (hipcc otherwise sinks them and waits at once)
     const lds_t* As = &S[cur * TILE];
     const lds_t* Bs = &S[(2 + cur) * TILE];
 #pragma unroll
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
           for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
       }
     }
-    if (kt + 1 < nk) store(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    store(cur ^ 1);
     __syncthreads();
   }
   float* C = reinterpret_cast<float*>(p.C) + z0 * p.c_bs0 + z1 * p.c_bs1;
@@ -197,9 +199,9 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_conv(ConvGemmParams p) {
   gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, K / BK, acc, NoFold());
   const int rb = m0 + (wave / WN) * (BM / WM), cb = n0 + (wave % WN) * (BN / WN);
   const int M = p.g.npix;
-  acc_foreach<MT, NT>(acc, lane, [&](int r, int c, float v, int, int, int) {
-    if (rb + r < M) conv_epilogue(p, (long)(rb + r), cb + c, v);
-  });
+#define BODY(E) conv_epilogue_rows<E, PREC != CRAFT_PREC_F32, MT, NT>(p, acc, lane, (long)rb, cb, (long)M);
+  CONV_EPI_DISPATCH(p, BODY)
+#undef BODY
   if (ENC && p.stats) {
     // all rows of a tile must belong to one image (checked by the launcher: H*W % 128 == 0)
     const int hw = p.g.H * p.g.W;

@@ -46,7 +46,8 @@ int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s)
 int launch_pv16(const RowsGemmParams& p, int prec, hipStream_t s);   // A and B both 16-bit (type = prec), C fp32
 int launch_gemm_conv(const ConvGemmParams& p, int prec, hipStream_t s);
 int launch_conv_halo(const ConvGemmParams& p, int prec, hipStream_t s);
-int launch_pack_weights(const float* w, long n, int prec, void* out, hipStream_t s);
+int launch_conv_halo_wf(const ConvGemmParams& p, int prec, hipStream_t s);
+int launch_pack_weights(const float* w, int rows, int K, int prec, void* out, hipStream_t s);
 int launch_stem7x7(const float* img, const float* w, const float* bias, int act, int B, int H, int W, float* out, double* stats,
                    hipStream_t s);
 int launch_stats_finalize(const double* sums, long n, double count, float eps, float* mean_rstd, hipStream_t s);

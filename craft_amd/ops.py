@@ -256,14 +256,15 @@ def pack_conv(w: torch.Tensor) -> torch.Tensor:
 
 
 def pack_conv_prec(w: torch.Tensor, prec: int) -> torch.Tensor:
-    """[Cout, Cin, KH, KW] -> [Cout, KH, KW, Cin] in the MFMA operand type of ``prec`` (craft_pack_weights):
-    fp32 as is, bf16 / fp16, or two fp16 planes [2, Cout, KH, KW, Cin] for f16x3."""
+    """[Cout, Cin, KH, KW] -> the weight operand the KxK conv kernels take with W_PACKED (craft_pack_weights): fp32 stays
+    [Cout, KH, KW, Cin]; bf16 / fp16 / f16x3 become MFMA fragment order [K/32][ceil(Cout/32)][planes][2][64][8] (flat)."""
     wp = pack_conv(w)
     if prec == PREC_F32:
         return wp
+    rows, K = wp.shape[0], wp[0].numel()
     planes = 2 if prec == hip.PREC_F16X3 else 1
-    out = torch.empty((planes,) + tuple(wp.shape), device=w.device, dtype=torch.bfloat16 if prec == hip.PREC_BF16 else torch.float16)
-    call("craft_pack_weights", wp, wp.numel(), prec, out)
+    out = torch.empty(planes * round_up(rows, 32) * K, device=w.device, dtype=torch.bfloat16 if prec == hip.PREC_BF16 else torch.float16)
+    call("craft_pack_weights", wp, rows, K, prec, out)
     return out
 
 

@@ -116,13 +116,15 @@ int craft_mode_pool_ln(const float* O, const float* x, long ldx, const float* w_
 int craft_gma_residual(const float* mf, long ldm, const float* O, const float* gamma, int B, int N, int C,
                        float* out, long ldo, void* stream);
 
-/* Pre-pack a conv weight [rows][K] (already laid out [Cout][KH][KW][Cin]) into the MFMA operand type of `prec`:
- * fp32 -> copy; bf16 / fp16 -> 16-bit [rows][K]; F16X3 -> two fp16 planes [2][rows][K] (hi, lo).  `n` = rows*K;
- * `out` holds n * {4, 2, 2, 4} bytes.  Operators below accept such buffers for their KxK convolutions (NOT the
- * 1x1 / tiny convs: wc1, wf1, flow-head w2, mask-head w2 stay raw fp32) when CRAFT_W_PACKED is or-ed into prec;
- * the K loop then stages weights with pure 16-byte copies. */
+/* Pre-pack a conv weight matrix w [rows][K] (rows = Cout, K = KH*KW*Cin laid out [KH][KW][Cin], K % 32 == 0) into the
+ * operand layout the KxK convolution kernels stream without any LDS staging.  fp32 -> plain copy.  bf16 / fp16 / F16X3 ->
+ * MFMA fragment order: out[((((kt*NB + nb)*PL + pl)*2 + kk)*64 + lane)*8 + j] = plane_pl(w[nb*32 + (lane&31)][kt*32 + kk*16 +
+ * (lane>>5)*8 + j]) with NB = ceil(rows/32) (missing rows zero) and PL = 2 planes for F16X3 (hi = fp16(w), lo = fp16(w - hi)),
+ * else 1; `out` holds PL * NB*32 * K 16-bit values.  Operators below accept such buffers for their KxK convolutions (NOT the
+ * 1x1 / tiny convs: wc1, wf1, flow-head w2, mask-head w2 stay raw fp32) when CRAFT_W_PACKED is or-ed into prec: a wave then
+ * fetches the B operand of each 32x32x16 MFMA with one coalesced 1 KiB load and the K loop runs without per-tile barriers. */
 #define CRAFT_W_PACKED 0x100
-int craft_pack_weights(const float* w, long n, int prec, void* out, void* stream);
+int craft_pack_weights(const float* w, int rows, int K, int prec, void* out, void* stream);
 
 /* nn.Conv2d (stride 1, "same" zero padding KH/2, KW/2) + bias + optional ReLU on tokens: x [B*H*W][cin] (row
  * stride ldx, cin % 32 == 0), w packed [cout][KH][KW][cin] (raw fp32, or craft_pack_weights output with
