@@ -41,13 +41,23 @@ int craft_linear(const float* x, long ldx, const float* w, const float* bias, fl
 }
 
 int craft_linear_t(const float* x, long ldx, const float* w, void* yT, long ldt, int B, int N, int cin, int cout,
-                   int out_prec, int prec, void* stream) {
+                   int out_prec, int frag_rows, int prec, void* stream) {
   if (out_prec < 0 || out_prec > 2) return CRAFT_ERR_ARG;
+  if (frag_rows && (out_prec == CRAFT_PREC_F32 || frag_rows % 32 || cout % frag_rows || ldt % 16)) return CRAFT_ERR_ALIGN;
   RowsGemmParams p = {};
   p.c_dtype = out_prec;
-  p.A = w; p.lda = cin; p.B = x; p.ldb = ldx; p.b_bs0 = (long)N * ldx; p.C = yT; p.ldc = ldt; p.c_bs0 = (long)cout * ldt;
-  p.zdiv = 1; p.batch = B; p.M = cout; p.N = N; p.K = cin;
+  p.zdiv = 1; p.batch = B; p.K = cin;
   p.bias = nullptr; p.scale = 1.f; p.act = CRAFT_ACT_NONE;
+  if (frag_rows) {
+    // fragment order: computed as y = x W^T (rows = keys) so that 4 consecutive keys of one V^T row -- 8 contiguous
+    // bytes of the fragment layout -- sit in one lane of the accumulator
+    p.c_frag = frag_rows;
+    p.A = x; p.lda = ldx; p.a_bs0 = (long)N * ldx; p.B = w; p.ldb = cin; p.C = yT; p.ldc = ldt; p.c_bs0 = (long)cout * ldt;
+    p.M = N; p.N = cout;
+  } else {
+    p.A = w; p.lda = cin; p.B = x; p.ldb = ldx; p.b_bs0 = (long)N * ldx; p.C = yT; p.ldc = ldt; p.c_bs0 = (long)cout * ldt;
+    p.M = cout; p.N = N;
+  }
   return launch_gemm_rows(p, prec, false, S(stream));
 }
 

@@ -1,6 +1,7 @@
 // GEMM-engine instantiations with store-type epilogues:
 //   * rows x rows GEMM (nn.Linear, V^T projection, attention apply O = P V)
 //   * NHWC implicit-GEMM convolution with the update block's fused epilogues
+#include <type_traits>
 #include "conv_epilogue.hpp"
 
 namespace craft {
@@ -30,119 +31,159 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_rows(RowsGemmParams p) {
   }
   const long cbase = z0 * p.c_bs0 + z1 * p.c_bs1;
   const int rb = m0 + (wave / WN) * (BM / WM), cb = n0 + (wave % WN) * (BN / WN);
-  acc_foreach<MT, NT>(acc, lane, [&](int r, int c, float v, int, int, int) {
-    const int row = rb + r, col = cb + c;
-    if (row < p.M && col < p.N) {
-      v *= p.scale;
-      if (p.bias) v += p.bias[col];
-      v = act_apply(v, p.act);
-      const long o = cbase + (long)row * p.ldc + col;
-      if (p.c_dtype == CRAFT_PREC_F32) reinterpret_cast<float*>(p.C)[o] = v;
-      else if (p.c_dtype == CRAFT_PREC_BF16) reinterpret_cast<__bf16*>(p.C)[o] = (__bf16)v;
-      else reinterpret_cast<_Float16*>(p.C)[o] = (_Float16)v;
+  // Epilogue in quads of 4 consecutive rows (the accumulator layout), with the element type / layout dispatch hoisted
+  // out of the element loop.  act is NONE or RELU here (checked by the launcher).
+  const bool relu = p.act == CRAFT_ACT_RELU;
+  const int c_lane = lane & 31, rh4 = 4 * (lane >> 5);
+  auto run = [&](auto dt_tag, auto frag_tag) __attribute__((always_inline)) {
+    constexpr int DT = decltype(dt_tag)::value;
+    constexpr bool FRAG = decltype(frag_tag)::value;
+    typedef typename std::conditional<DT == CRAFT_PREC_F32, float, typename std::conditional<DT == CRAFT_PREC_BF16, __bf16, _Float16>::type>::type out_t;
+    out_t* C = reinterpret_cast<out_t*>(p.C) + cbase;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = cb + nt * 32 + c_lane;
+      if (col >= p.N) continue;
+      const float bias = p.bias ? p.bias[col] : 0.f;
+      long fbase = 0;
+      if constexpr (FRAG) {      // MFMA B-fragment order per group of c_frag columns (k_pv16's V^T operand): row = key, col = V^T row
+        const int grp = col / p.c_frag, n = col - grp * p.c_frag;
+        fbase = (long)grp * p.c_frag * p.ldc + (long)(n >> 5) * 512 + (n & 31) * 8;
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row0 = rb + mt * 32 + 8 * q + rh4;
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float t = acc[mt][nt][4 * q + i] * p.scale + bias;
+            v[i] = relu ? fmaxf(t, 0.f) : t;
+          }
+          if constexpr (FRAG) {
+            // keys row0..row0+3 share (key >> 3): 4 consecutive 16-bit values, one 8-byte store (lanes l, l+32 pair up)
+            out_t* d = C + fbase + (long)(row0 >> 4) * (p.c_frag >> 5) * 512 + ((row0 >> 3) & 1) * 256 + (row0 & 7);
+            if (row0 + 3 < p.M) {
+              typedef out_t o4 __attribute__((ext_vector_type(4)));
+              o4 h;
+              h[0] = (out_t)v[0]; h[1] = (out_t)v[1]; h[2] = (out_t)v[2]; h[3] = (out_t)v[3];
+              *reinterpret_cast<o4*>(d) = h;
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) if (row0 + i < p.M) d[i] = (out_t)v[i];
+            }
+          } else {
+            out_t* d = C + (long)row0 * p.ldc + col;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (row0 + i < p.M) d[(long)i * p.ldc] = (out_t)v[i];
+          }
+        }
     }
-  });
+  };
+  typedef std::integral_constant<int, CRAFT_PREC_F32> T32;
+  typedef std::integral_constant<int, CRAFT_PREC_BF16> TBF;
+  typedef std::integral_constant<int, CRAFT_PREC_F16> TF16;
+  if (p.c_dtype == CRAFT_PREC_F32) run(T32(), std::false_type());
+  else if (p.c_dtype == CRAFT_PREC_BF16) { if (p.c_frag) run(TBF(), std::true_type()); else run(TBF(), std::false_type()); }
+  else { if (p.c_frag) run(TF16(), std::true_type()); else run(TF16(), std::false_type()); }
 }
 
 // ---------------------------------------------------------------------------------------------
-// O = P . V with BOTH operands already 16-bit in HBM (P from k_attn_probs, V^T from craft_linear_t):
-// K-tile 64, pure 16-byte copies global -> registers -> LDS (no conversion), 128 x 128 tile, fp32 out.
-// HBM-bound on P (streamed exactly once: the n-tile covers all of Dv = 128).
+// O = P . V with BOTH operands already 16-bit in HBM: P [rows][K] from k_attn_probs, V^T in MFMA FRAGMENT order
+// from craft_linear_t (CRAFT_T_FRAG): vT[((g * NB + nb) * 64 + lane) * 8 + j] = V^T[nb*32 + (lane & 31)][g*16 +
+// (lane >> 5)*8 + j], NB = Dv / 32, g = key / 16.
+//
+// The kernel is HBM-bound on P (streamed exactly once).  A block owns 128 rows of P and 128 columns of O; a wave
+// owns all 128 rows x 32 columns (MT = 4, NT = 1).  Per K-tile of 128 keys:
+//   * P: 256 B per row, global -> registers (one tile ahead) -> LDS (double buffer), pure 16-byte copies;
+//   * V^T: never in LDS -- each B operand is one coalesced 1 KiB load (L2 hit) straight into MFMA registers,
+//     re-requested for the next tile right after its last use;
+//   * one barrier per 128 keys (32 MFMAs per wave).
 // ---------------------------------------------------------------------------------------------
 template <int PREC>
 __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
   typedef typename PrecT<PREC>::lds_t lds_t;
-  constexpr int BM = 128, BN = 128, KT = 64, LD = 72, WN = 2, MT = 2, NT = 2;
-  constexpr int TILE = 128 * LD;
-  __shared__ __attribute__((aligned(16))) lds_t S[4 * TILE];      // A0 | A1 | B0 | B1
+  constexpr int BM = 128, KT = 128, LD = KT + 8, MT = 4, NA = 8;
+  constexpr int TILE = BM * LD;
+  __shared__ __attribute__((aligned(16))) lds_t S[2 * TILE];      // A0 | A1
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * 128, z = blockIdx.z;
   const int z0 = z / p.zdiv, z1 = z - z0 * p.zdiv;
   const uint16_t* A = reinterpret_cast<const uint16_t*>(p.A) + z0 * p.a_bs0 + z1 * p.a_bs1;
-  const uint16_t* B = reinterpret_cast<const uint16_t*>(p.B) + z0 * p.b_bs0 + z1 * p.b_bs1;
-  const int c8 = tid & 7, r0 = tid >> 3;
-  const uint16_t* pa[4];
-  const uint16_t* pb[4];
+  const int NB = p.N / 32, ng = p.K / 16;
+  const uint16_t* Bf = reinterpret_cast<const uint16_t*>(p.B) + z0 * p.b_bs0 + z1 * p.b_bs1 + (long)(n0 / 32 + wave) * 512 + lane * 8;
+  const long g_stride = (long)NB * 512;
+  const int c16 = tid & 15, r0 = tid >> 4;
+  const uint16_t* pa[NA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ra = min(m0 + r0 + 32 * i, p.M - 1), rb_ = min(n0 + r0 + 32 * i, p.N - 1);   // clamped: unconditional loads
-    pa[i] = A + (long)ra * p.lda;
-    pb[i] = B + (long)rb_ * p.ldb;
-  }
+  for (int i = 0; i < NA; ++i) pa[i] = A + (long)min(m0 + r0 + 16 * i, p.M - 1) * p.lda;    // clamped: unconditional loads
   const int nk = (p.K + KT - 1) / KT;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 va[4], vb[4];
-  bool kzero = false;
-  auto fetch = [&](int kt) __attribute__((always_inline)) {
-    const int k = kt * KT + c8 * 8;
-    const bool kok = k < p.K;
-    const int kc = kok ? k : p.K - 8;
-    kzero = !kok;                 // applied in store(): a select here would stall on the loads
+  typedef typename std::conditional<PREC == CRAFT_PREC_BF16, bf16x8, f16x8>::type frag_t;
+  u32x4 va[NA];
+  frag_t bq[8];
+  auto fetch_a = [&](int kt) __attribute__((always_inline)) {
+    const int k = min(kt, nk - 1) * KT + c16 * 8;
+    const int kc = k < p.K ? k : p.K - 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      va[i] = *reinterpret_cast<const u32x4*>(pa[i] + kc);
-      vb[i] = *reinterpret_cast<const u32x4*>(pb[i] + kc);
-    }
+    for (int i = 0; i < NA; ++i) va[i] = *reinterpret_cast<const u32x4*>(pa[i] + kc);
   };
-  auto store = [&](int buf) __attribute__((always_inline)) {
+  auto fetch_b = [&](int kt, int kk) __attribute__((always_inline)) {
+    const int g = min(min(kt, nk - 1) * 8 + kk, ng - 1);     // groups beyond K meet zeroed P columns
+    bq[kk] = *reinterpret_cast<const frag_t*>(Bf + g * g_stride);
+  };
+  // zeroing of the K tail happens at LDS-store time with a bitwise mask (no select next to the load, no exec branch)
+  auto store = [&](int kt) __attribute__((always_inline)) {
+    const unsigned keep = (kt * KT + c16 * 8 >= p.K) ? 0u : ~0u;
+    lds_t* D = &S[(kt & 1) * TILE];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<u32x4*>(&S[buf * TILE + (r0 + 32 * i) * LD + c8 * 8]) = kzero ? u32x4{0u, 0u, 0u, 0u} : va[i];
-      *reinterpret_cast<u32x4*>(&S[(2 + buf) * TILE + (r0 + 32 * i) * LD + c8 * 8]) = kzero ? u32x4{0u, 0u, 0u, 0u} : vb[i];
-    }
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(&D[(r0 + 16 * i) * LD + c16 * 8]) = va[i] & keep;
   };
-  const int wm0 = (wave / WN) * 64, wn0 = (wave % WN) * 64;
-  const int r = lane & 31, g = lane >> 5;
-  f32x16 acc[MT][NT];
+  const int r = lane & 31, g8 = (lane >> 5) * 8;
+  f32x16 acc[MT][1];
   acc_zero(acc);
-  fetch(0);
+  fetch_a(0);
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) fetch_b(0, kk);
   store(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    fetch(min(kt + 1, nk - 1));          // always (clamped duplicate at the end): no branch around the loads
-    __builtin_amdgcn_sched_barrier(0);   // keep the loads ABOVE the MFMAs (hipcc otherwise sinks them and waits at once)
-    const lds_t* As = &S[cur * TILE];
-    const lds_t* Bs = &S[(2 + cur) * TILE];
+    fetch_a(kt + 1);                         // unconditional (clamped duplicate after the last tile)
+    __builtin_amdgcn_sched_barrier(0);       // keep the P loads above the MFMAs they hide behind
+    const lds_t* As = &S[(kt & 1) * TILE];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      if constexpr (PREC == CRAFT_PREC_BF16) {
-        bf16x8 a[MT], b[NT];
+    for (int kk = 0; kk < 8; ++kk) {
+      frag_t a[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(&As[(wm0 + mt * 32 + r) * LD + kk * 16 + g * 8]);
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const frag_t*>(&As[(mt * 32 + r) * LD + kk * 16 + g8]);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const bf16x8*>(&Bs[(wn0 + nt * 32 + r) * LD + kk * 16 + g * 8]);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
-      } else {
-        f16x8 a[MT], b[NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f16x8*>(&As[(wm0 + mt * 32 + r) * LD + kk * 16 + g * 8]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f16x8*>(&Bs[(wn0 + nt * 32 + r) * LD + kk * 16 + g * 8]);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+      for (int mt = 0; mt < MT; ++mt) {
+        if constexpr (PREC == CRAFT_PREC_BF16) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], bq[kk], acc[mt][0], 0, 0, 0);
+        else acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bq[kk], acc[mt][0], 0, 0, 0);
       }
+      fetch_b(kt + 1, kk);                   // next tile's operand, a whole tile of MFMAs ahead of its use
     }
     __builtin_amdgcn_sched_barrier(0);
-    store(cur ^ 1);
+    store(kt + 1);
     __syncthreads();
   }
   float* C = reinterpret_cast<float*>(p.C) + z0 * p.c_bs0 + z1 * p.c_bs1;
-  acc_foreach<MT, NT>(acc, lane, [&](int rr, int cc, float v, int, int, int) {
-    const int row = m0 + wm0 + rr, col = n0 + wn0 + cc;
-    if (row < p.M && col < p.N) C[(long)row * p.ldc + col] = v;
-  });
+  const int col = n0 + wave * 32 + r;
+  const int rh4 = 4 * (lane >> 5);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
+      if (row < p.M) C[(long)row * p.ldc + col] = acc[mt][0][e];
+    }
 }
 
 int launch_pv16(const RowsGemmParams& p, int prec, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return 0;
-  if ((p.K & 7) || (p.lda & 7) || (p.ldb & 7) || p.c_dtype != CRAFT_PREC_F32) return CRAFT_ERR_ALIGN;
-  dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, p.batch);
+  if ((p.K & 15) || (p.lda & 7) || (p.N & 127) || p.c_dtype != CRAFT_PREC_F32) return CRAFT_ERR_ALIGN;
+  dim3 grid((p.M + 127) / 128, p.N / 128, p.batch);
   if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_pv16<CRAFT_PREC_BF16>), grid, dim3(NTHREADS), 0, s, p);
   else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_pv16<CRAFT_PREC_F16>), grid, dim3(NTHREADS), 0, s, p);
   else return CRAFT_ERR_ARG;
@@ -163,6 +204,8 @@ static int pick_bn(int N) {
 
 int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return 0;
+  if (p.act != CRAFT_ACT_NONE && p.act != CRAFT_ACT_RELU) return CRAFT_ERR_UNSUPPORTED;
+  if (p.c_frag && (p.c_dtype == CRAFT_PREC_F32 || p.c_frag % 32 || p.N % p.c_frag || p.ldc % 16)) return CRAFT_ERR_ALIGN;
   if ((p.K & 3) || (p.lda & 3) || (p.ldb & 3)) return CRAFT_ERR_ALIGN;
   if (a16 && ((p.K & 7) || (p.lda & 7) || (prec != CRAFT_PREC_BF16 && prec != CRAFT_PREC_F16))) return CRAFT_ERR_ALIGN;
   const int bn = pick_bn(p.N);

@@ -77,66 +77,85 @@ int launch_tokens(const float* src, int src_nchw, int B, int Ctot, int c_off, in
 // ExpandedFeatTrans tail (setrans.py:395-407): a_m = softmax_m(<O_m, w>), y = sum_m a_m O_m,
 // out = LN(c_skip * x + y).  One wave per token; C <= 256, M <= 8.
 // ---------------------------------------------------------------------------------------------
+// C / 4 lanes per token (float4 per lane and mode, everything in registers), 64 / (C/4) tokens per wave.
+template <int M, int C>
 __global__ __launch_bounds__(256) void k_mode_pool_ln(const float* __restrict__ O, const float* __restrict__ x, long ldx,
                                                       const float* __restrict__ w_agg, const float* __restrict__ skip_coeff,
-                                                      int N, int M, int C, float* __restrict__ out, long ldo, long ntok) {
-  const int lane = threadIdx.x & 63;
-  const long tok = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tok >= ntok) return;
-  const int b = (int)(tok / N), n = (int)(tok - (long)b * N);
-  const int nc = C / 64;   // 1..4
-  float o[8][4];
-  float sc[8];
-  for (int m = 0; m < M; ++m) {
-    const float* Om = O + (((long)b * M + m) * N + n) * C;
-    float s = 0.f;
-    for (int i = 0; i < nc; ++i) {
-      o[m][i] = Om[lane + 64 * i];
-      s += o[m][i] * w_agg[lane + 64 * i];
-    }
-    sc[m] = wave_sum(s);
-  }
+                                                      int N, float* __restrict__ out, long ldo, long ntok) {
+  constexpr int LPT = C / 4, TPB = 256 / LPT;     // lanes per token, tokens per block
+  const int sub = threadIdx.x % LPT;
+  const long tok = (long)blockIdx.x * TPB + threadIdx.x / LPT;
+  const bool live = tok < ntok;
+  const long tk = live ? tok : ntok - 1;          // clamped: all lanes take part in the shuffles
+  const int b = (int)(tk / N), n = (int)(tk - (long)b * N);
+  auto group_sum = [&](float v) __attribute__((always_inline)) {
+#pragma unroll
+    for (int o = LPT / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  const float4 w = *reinterpret_cast<const float4*>(w_agg + sub * 4);
+  float4 o[M];
+  float sc[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) o[m] = *reinterpret_cast<const float4*>(O + (((long)b * M + m) * N + n) * C + sub * 4);
+  const float4 xv = *reinterpret_cast<const float4*>(x + tk * ldx + sub * 4);
+#pragma unroll
+  for (int m = 0; m < M; ++m) sc[m] = group_sum(o[m].x * w.x + o[m].y * w.y + o[m].z * w.z + o[m].w * w.w);
   float mxs = sc[0];
+#pragma unroll
   for (int m = 1; m < M; ++m) mxs = fmaxf(mxs, sc[m]);
   float den = 0.f;
+#pragma unroll
   for (int m = 0; m < M; ++m) { sc[m] = expf(sc[m] - mxs); den += sc[m]; }
   const float cs = skip_coeff[0];
-  float t[4];
-  float sum = 0.f;
-  for (int i = 0; i < nc; ++i) {
-    float y = 0.f;
-    for (int m = 0; m < M; ++m) y += o[m][i] * (sc[m] / den);
-    t[i] = cs * x[tok * ldx + lane + 64 * i] + y;
-    sum += t[i];
+  float4 t = make_float4(cs * xv.x, cs * xv.y, cs * xv.z, cs * xv.w);
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const float a = sc[m] / den;
+    t.x += o[m].x * a; t.y += o[m].y * a; t.z += o[m].z * a; t.w += o[m].w * a;
   }
-  const float mean = wave_sum(sum) / (float)C;
-  float q = 0.f;
-  for (int i = 0; i < nc; ++i) { const float d = t[i] - mean; q += d * d; }
-  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)C + CRAFT_LN_EPS);
-  for (int i = 0; i < nc; ++i) out[tok * ldo + lane + 64 * i] = (t[i] - mean) * rstd;
+  const float mean = group_sum(t.x + t.y + t.z + t.w) / (float)C;
+  const float dx = t.x - mean, dy = t.y - mean, dz = t.z - mean, dw = t.w - mean;
+  const float rstd = 1.f / sqrtf(group_sum(dx * dx + dy * dy + dz * dz + dw * dw) / (float)C + CRAFT_LN_EPS);
+  if (live) *reinterpret_cast<float4*>(out + tok * ldo + sub * 4) = make_float4(dx * rstd, dy * rstd, dz * rstd, dw * rstd);
+}
+
+template <int M, int C> static void launch_mpl_t(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff,
+                                                  int N, float* out, long ldo, long ntok, hipStream_t s) {
+  constexpr int TPB = 256 / (C / 4);
+  hipLaunchKernelGGL((k_mode_pool_ln<M, C>), dim3((unsigned)((ntok + TPB - 1) / TPB)), dim3(256), 0, s, O, x, ldx, w_agg, skip_coeff, N,
+                     out, ldo, ntok);
 }
 
 int launch_mode_pool_ln(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff, int B, int N,
                         int M, int C, float* out, long ldo, hipStream_t s) {
-  if (C % 64 || C > 256 || M < 1 || M > 8) return CRAFT_ERR_UNSUPPORTED;
+  if ((C != 128 && C != 256) || M < 1 || M > 8 || (ldx & 3) || (ldo & 3)) return CRAFT_ERR_UNSUPPORTED;
   const long ntok = (long)B * N;
-  hipLaunchKernelGGL(k_mode_pool_ln, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, s, O, x, ldx, w_agg, skip_coeff, N, M, C,
-                     out, ldo, ntok);
+#define GO(MM) do { if (C == 128) launch_mpl_t<MM, 128>(O, x, ldx, w_agg, skip_coeff, N, out, ldo, ntok, s); \
+                    else launch_mpl_t<MM, 256>(O, x, ldx, w_agg, skip_coeff, N, out, ldo, ntok, s); } while (0)
+  switch (M) {
+    case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; case 4: GO(4); break;
+    case 5: GO(5); break; case 6: GO(6); break; case 7: GO(7); break; default: GO(8); break;
+  }
+#undef GO
   return (int)hipGetLastError();
 }
 
 // gma.Aggregate tail (gma.py:138): out = fmap + gamma * O
 __global__ void k_gma_residual(const float* __restrict__ mf, long ldm, const float* __restrict__ O,
                                const float* __restrict__ gamma, long ntok, int C, float* __restrict__ out, long ldo) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;      // 4 channels per thread
   if (i >= ntok * C) return;
   const long tok = i / C;
   const int c = (int)(i - tok * C);
-  out[tok * ldo + c] = mf[tok * ldm + c] + gamma[0] * O[i];
+  const float g = gamma[0];
+  const float4 a = *reinterpret_cast<const float4*>(mf + tok * ldm + c), o = *reinterpret_cast<const float4*>(O + i);
+  *reinterpret_cast<float4*>(out + tok * ldo + c) = make_float4(a.x + g * o.x, a.y + g * o.y, a.z + g * o.z, a.w + g * o.w);
 }
 int launch_gma_residual(const float* mf, long ldm, const float* O, const float* gamma, int B, int N, int C, float* out,
                         long ldo, hipStream_t s) {
-  const long tot = (long)B * N * C;
+  if ((C & 3) || (ldm & 3) || (ldo & 3)) return CRAFT_ERR_ALIGN;
+  const long tot = (long)B * N * C / 4;
   hipLaunchKernelGGL(k_gma_residual, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, mf, ldm, O, gamma, (long)B * N, C,
                      out, ldo);
   return (int)hipGetLastError();

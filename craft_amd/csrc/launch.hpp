@@ -21,6 +21,7 @@ struct RowsGemmParams {
   const float* bias;     // per output column, may be null
   float scale;
   int act;
+  int c_frag;            // > 0: C (16-bit) is stored in MFMA B-fragment order per group of c_frag rows (k_pv16's V^T operand)
 };
 
 enum { CONV_EPI_BIAS_ACT = 0, CONV_EPI_GRU_ZR = 1, CONV_EPI_GRU_Q = 2, CONV_EPI_MENC = 3 };

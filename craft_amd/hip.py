@@ -30,7 +30,7 @@ _SIGS = {
     "craft_tokens": [P, I, I, I, I, I, I, L, I, I, P, L, P],
     "craft_tokens_to_nchw": [P, L, I, I, I, P, P],
     "craft_linear": [P, L, P, P, P, L, L, I, I, I, P],
-    "craft_linear_t": [P, L, P, P, L, I, I, I, I, I, I, P],
+    "craft_linear_t": [P, L, P, P, L, I, I, I, I, I, I, I, P],
     "craft_score_max": [P, L, P, L, I, I, I, I, I, F, P, I, P],
     "craft_corr_build": [P, L, P, L, I, I, I, I, I, F, P, I, F, F, P, P, P, I, P],
     "craft_corr_finish": [P, P, P, P, P, P, I, I, I, I, P],

@@ -97,16 +97,19 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], prec:
     return out
 
 
-def linear_t(x: torch.Tensor, w: torch.Tensor, ldt: int, prec: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def linear_t(x: torch.Tensor, w: torch.Tensor, ldt: int, prec: int, out: Optional[torch.Tensor] = None,
+             Dv: int = 0) -> torch.Tensor:
     """Per-sample transposed projection: yT[b][o][n] (row stride ldt >= N, tail zero), stored in the
-    element type of the pv role (the type attn_apply consumes)."""
+    element type of the pv role (the type attn_apply consumes).  With ``Dv`` (the per-mode value width) and a 16-bit
+    pv type the result is in the MFMA fragment order craft_attn_apply requires (same shape / footprint)."""
     B, N, Cin = x.shape
     _check_rows(x)
     Cout = w.shape[0]
     pv = pick(prec, "pv")
     if out is None:
         out = torch.zeros(B, Cout, ldt, device=x.device, dtype=PROB_DTYPE[pv])
-    call("craft_linear_t", x, _ld(x), w.contiguous(), out, ldt, B, N, Cin, Cout, pv, pick(prec, "proj"))
+    frag = Dv if (Dv and pv != PREC_F32) else 0
+    call("craft_linear_t", x, _ld(x), w.contiguous(), out, ldt, B, N, Cin, Cout, pv, frag, pick(prec, "proj"))
     return out
 
 
@@ -189,7 +192,7 @@ def attn_probs(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale
 
 
 def attn_apply(P: torch.Tensor, vT: torch.Tensor, Dv: int, prec: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """O[b][m] = P[b][m] @ V_m with vT [B, M*Dv, ldp] -> O [B, M, N, Dv]."""
+    """O[b][m] = P[b][m] @ V_m with vT [B, M*Dv, ldp] (16-bit: fragment order, ``linear_t(..., Dv=Dv)``) -> O [B, M, N, Dv]."""
     B, M, N, ldp = P.shape
     if out is None:
         out = torch.empty(B, M, N, Dv, device=P.device, dtype=torch.float32)

@@ -58,9 +58,12 @@ int craft_linear(const float* x, long ldx, const float* w, const float* bias, fl
                  int cin, int cout, int prec, void* stream);
 /* the same projection written transposed per sample, yT[b][o][n] with row stride ldt >= N (used for V^T,
  * setrans.py:373-378), stored as float (out_prec 0), bf16 (1) or fp16 (2).  The caller zero-fills columns
- * [N, ldt) once. */
+ * [N, ldt) once.  frag_rows = 0: plain row-major [cout][ldt].  frag_rows = Dv > 0 (16-bit out_prec only; Dv % 32 == 0,
+ * cout % Dv == 0, ldt % 16 == 0): every group of Dv rows (one attention mode) is stored in MFMA B-fragment order,
+ * yT_group[((g*(Dv/32) + nb)*64 + lane)*8 + j] = yT[nb*32 + (lane & 31)][g*16 + (lane >> 5)*8 + j] -- the layout the
+ * 16-bit craft_attn_apply streams from L2 straight into MFMA operand registers (same footprint: Dv * ldt values). */
 int craft_linear_t(const float* x, long ldx, const float* w, void* yT, long ldt, int B, int N, int cin,
-                   int cout, int out_prec, int prec, void* stream);
+                   int cout, int out_prec, int frag_rows, int prec, void* stream);
 
 /* Global max of the raw scaled scores Q_m K_m^T * scale over batch, modes, i, j (the .max().item() of
  * setrans.py:520-521) as an order-preserving uint in *max_ord; consumers clamp to [-100, 100] iff that max
@@ -103,7 +106,8 @@ int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, 
 /* ExpandedFeatTrans.forward, matmul part (setrans.py:384): O[b][m][i][:] = sum_j P[b][m][i][j] * V_m[j][:],
  * with vT[b][m*Dv + c][j] (row stride ldp, zero beyond N) from craft_linear_t.  O: [B][M][N][Dv] fp32.
  * prec (0 fp32, 1 bf16, 2 fp16) is the element type of BOTH P (craft_attn_probs with p_prec = prec) and vT
- * (craft_linear_t with out_prec = prec), and the MFMA path. */
+ * (craft_linear_t with out_prec = prec), and the MFMA path.  For prec 1 / 2, vT must be in fragment order
+ * (craft_linear_t with frag_rows = Dv) and Dv % 128 == 0; for prec 0 it is plain row-major. */
 int craft_attn_apply(const void* P, long ldp, const void* vT, int B, int N, int M, int Dv, float* O, int prec,
                      void* stream);
 

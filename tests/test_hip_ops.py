@@ -86,6 +86,13 @@ def test_linear_t_and_column_views(device, prec):
     assert y16.dtype == torch.float16
     close(y16[..., :N], ref, max(rt, 2e-3), max(at, 2e-3), "linear_t (fp16 output)")
     assert float(yT[..., N:].abs().max()) == 0.0
+    # fragment order (the V^T operand of the 16-bit craft_attn_apply): a pure permutation of the plain layout
+    Dv = 128
+    yf = ops.linear_t(buf.to(device)[..., 256:384], w.to(device), ldt, hip.Precision(proj=prec, pv=PREC_F16), Dv=Dv)
+    un = yf.view(B, Cout // Dv, ldt // 16, Dv // 32, 2, 32, 8).permute(0, 1, 3, 5, 2, 4, 6).reshape(B, Cout, ldt)
+    # (the two layouts run the GEMM in opposite operand roles: same products, different fp32 summation order)
+    close(un.float(), y16.float(), 2e-3, 2e-3, "fragment-order V^T vs row-major")
+    close(un[..., :N], ref, max(rt, 2e-3), max(at, 2e-3), "linear_t (fragment order)")
 
 
 @pytest.mark.parametrize("nchw", [True, False])
@@ -232,7 +239,7 @@ def test_expanded_feat_trans(device, prec, C):
     P[..., :N] = Pf.to(P.dtype)
     ref = O.expanded_feat_trans(x, P[..., :N].float(), Wv, w_agg, skip)
     xd = x.to(device)
-    vT = ops.linear_t(xd, Wv.to(device), ldp, prec)
+    vT = ops.linear_t(xd, Wv.to(device), ldp, prec, Dv=C)
     Od = ops.attn_apply(P.to(device), vT, C, prec)
     y = ops.mode_pool_ln(Od, xd, w_agg.to(device), skip.to(device))
     rt, at = TOL[prec]
