@@ -49,6 +49,8 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build(ScoreParams p, float w_
   acc_zero(acc);
   float mx[MT][16], den[MT][16], num[MT][16];
   float vmax = -INFINITY;
+  constexpr bool kExact = (PREC == CRAFT_PREC_F32);
+  const float wl2 = w_aggr * 1.4426950408889634f;
 
   auto fold = [&](int kt) {
     if ((kt + 1) % tpm != 0) return;
@@ -64,11 +66,15 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build(ScoreParams p, float w_
           if (row < N && col < N) vmax = fmaxf(vmax, s);
         } else {
           if (clamp) s = fminf(fmaxf(s, -CRAFT_ATTN_CLIP), CRAFT_ATTN_CLIP);
-          const float t = w_aggr * s;
+          // online softmax over modes of t = w_aggr * s.  Non-fp32 modes track it in the base-2 domain (w2 = w_aggr *
+          // log2 e, v_exp_f32 directly): ~12 VALU per (element, mode) instead of ~50 with two libm expf -- this
+          // epilogue, not the MFMAs, bounds the kernel.
+          const float t = (kExact ? w_aggr : wl2) * s;
           if (first) { mx[mt][e] = t; den[mt][e] = 1.f; num[mt][e] = s; }
           else {
             const float nm = fmaxf(mx[mt][e], t);
-            const float e0 = expf(mx[mt][e] - nm), e1 = expf(t - nm);
+            const float e0 = kExact ? expf(mx[mt][e] - nm) : __builtin_amdgcn_exp2f(mx[mt][e] - nm);
+            const float e1 = kExact ? expf(t - nm) : __builtin_amdgcn_exp2f(t - nm);
             den[mt][e] = den[mt][e] * e0 + e1;
             num[mt][e] = num[mt][e] * e0 + s * e1;
             mx[mt][e] = nm;

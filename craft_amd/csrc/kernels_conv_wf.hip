@@ -235,7 +235,7 @@ template <int PREC, int WM, int WN> static int launch_wf_t(const ConvGemmParams&
     if constexpr (PREC == CRAFT_PREC_F16X3 && WM == 1) {
       const int d = atoi(e);
 #define DB(D) if (d == D) { hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, false, D>), grid, dim3(NTHREADS), 0, s, p); return (int)hipGetLastError(); }
-      DB(1) DB(7) DB(16) DB(23)
+      DB(1) DB(2) DB(3) DB(4) DB(5) DB(6) DB(7) DB(8) DB(16)
 #undef DB
     }
   }
