@@ -150,6 +150,15 @@ class CorrPyramid:
     def nbytes(self) -> int:
         return sum(t.numel() * 4 for t in self.lv)
 
+    def batch_slice(self, b0: int, b1: int) -> "CorrPyramid":
+        """View of samples [b0, b1) (no copy): the refinement loop of a batch slice can run on its own stream."""
+        v = CorrPyramid.__new__(CorrPyramid)
+        v.B, v.H8, v.W8, v.levels = b1 - b0, self.H8, self.W8, self.levels
+        N = self.H8 * self.W8
+        v.lv = [t[b0 * N:b1 * N] for t in self.lv]
+        v.sums, v.mu_rstd = self.sums[b0:b1], self.mu_rstd[b0:b1]
+        return v
+
 
 def corr_build(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale: float, pos_tab: Optional[torch.Tensor],
                pos_w: float, w_aggr: float, clamp_ord: Optional[torch.Tensor], pyr: CorrPyramid, do_norm: bool,
@@ -224,9 +233,9 @@ def gma_residual(mf: torch.Tensor, O: torch.Tensor, gamma: torch.Tensor, out: Op
     return out
 
 
-def convex_upsample(mask: torch.Tensor, flow: torch.Tensor, H8: int, W8: int) -> torch.Tensor:
+def convex_upsample(mask: torch.Tensor, flow: torch.Tensor, H8: int, W8: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     B = mask.shape[0]
-    up = torch.empty(B, 2, 8 * H8, 8 * W8, device=mask.device, dtype=torch.float32)
+    up = torch.empty(B, 2, 8 * H8, 8 * W8, device=mask.device, dtype=torch.float32) if out is None else out
     call("craft_convex_upsample", mask, flow, B, H8, W8, up)
     return up
 

@@ -32,6 +32,10 @@ class _PackCache:
             with torch.no_grad():
                 self._val = fn()
             self._key = key
+            # the packed copy may be consumed on other HIP streams (batch-sliced refinement loop): packing happens
+            # once per weight update, so simply finish it before anybody can see it
+            if torch.cuda.is_available():
+                torch.cuda.current_stream().synchronize()
         return self._val
 
 

@@ -220,3 +220,20 @@ def test_iters_zero_and_single(device):
         lo, up = model(im1, im2, iters=1, test_mode=1)
         preds = model(im1, im2, iters=1, test_mode=0)
     assert torch.equal(preds[0], up) and lo.shape == (1, 2, 16, 32)
+
+
+def test_batch_sliced_streams_match_single_stream(device):
+    """args.hip_streams > 1 runs the refinement loop of batch slices on separate HIP streams: same results."""
+    g = Golden("canon_b2_128x192_T3_init")
+    im1, im2 = (t.to(device) for t in g.images())
+    outs = []
+    for n in (1, 2):
+        model = build(g, device)
+        model.args.hip_streams = n
+        with torch.no_grad():
+            outs.append(model(im1, im2, iters=3, test_mode=2))
+    (lo1, ups1), (lo2, ups2) = outs
+    assert len(ups1) == len(ups2) == 3
+    assert torch.equal(lo1, lo2)
+    for a, b in zip(ups1, ups2):
+        assert torch.equal(a, b)
