@@ -234,6 +234,7 @@ def test_batch_sliced_streams_match_single_stream(device):
             outs.append(model(im1, im2, iters=3, test_mode=2))
     (lo1, ups1), (lo2, ups2) = outs
     assert len(ups1) == len(ups2) == 3
-    assert torch.equal(lo1, lo2)
+    # (two separate forwards: equal up to the summation order of the double-precision statistics atomics)
+    assert (lo1 - lo2).abs().max().item() < 1e-4
     for a, b in zip(ups1, ups2):
-        assert torch.equal(a, b)
+        assert (a - b).abs().max().item() < 1e-4
