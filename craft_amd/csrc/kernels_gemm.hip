@@ -1,6 +1,7 @@
 // GEMM-engine instantiations with store-type epilogues:
 //   * rows x rows GEMM (nn.Linear, V^T projection, attention apply O = P V)
 //   * NHWC implicit-GEMM convolution with the update block's fused epilogues
+#include <cstdlib>
 #include <type_traits>
 #include "conv_epilogue.hpp"
 
@@ -91,20 +92,23 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_rows(RowsGemmParams p) {
 
 // ---------------------------------------------------------------------------------------------
 // O = P . V with BOTH operands already 16-bit in HBM: P [rows][K] from k_attn_probs, V^T in MFMA FRAGMENT order
-// from craft_linear_t (CRAFT_T_FRAG): vT[((g * NB + nb) * 64 + lane) * 8 + j] = V^T[nb*32 + (lane & 31)][g*16 +
+// from craft_linear_t (frag_rows = Dv): vT[((g * NB + nb) * 64 + lane) * 8 + j] = V^T[nb*32 + (lane & 31)][g*16 +
 // (lane >> 5)*8 + j], NB = Dv / 32, g = key / 16.
 //
-// The kernel is HBM-bound on P (streamed exactly once).  A block owns 128 rows of P and 128 columns of O; a wave
-// owns all 128 rows x 32 columns (MT = 4, NT = 1).  Per K-tile of 128 keys:
-//   * P: 256 B per row, global -> registers (one tile ahead) -> LDS (double buffer), pure 16-byte copies;
-//   * V^T: never in LDS -- each B operand is one coalesced 1 KiB load (L2 hit) straight into MFMA registers,
-//     re-requested for the next tile right after its last use;
-//   * one barrier per 128 keys (32 MFMAs per wave).
+// The kernel is HBM-bound on P (streamed exactly once) and nothing but its own pipeline hides the HBM latency, so
+// the two things that matter are bytes in flight and an even block count:
+//   * a block owns BM = 32*MT rows of P and 128 columns of O; a wave owns all BM rows x 32 columns.  MT (4..7) is
+//     picked per launch so that the grid is a whole number of resident rounds (448x1024: N = 7168 = 32 * 224 -> MT = 7
+//     gives 512 blocks = exactly 2 per CU; with MT = 4 the 896 blocks run as 1.75 rounds and the tail costs 12 %);
+//   * P: 128 B per row and K-tile (64 keys), global -> registers TWO tiles ahead (two register sets) -> LDS (double
+//     buffer), pure 16-byte copies;
+//   * V^T never touches LDS: each B operand is one coalesced 1 KiB load (L2 hit) straight into MFMA registers,
+//     re-requested for the next tile right after its last use; one barrier per K-tile.
 // ---------------------------------------------------------------------------------------------
-template <int PREC>
+template <int PREC, int MT>
 __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
   typedef typename PrecT<PREC>::lds_t lds_t;
-  constexpr int BM = 128, KT = 128, LD = KT + 8, MT = 4, NA = 8;
+  constexpr int BM = 32 * MT, KT = 64, LD = KT + 8;
   constexpr int TILE = BM * LD;
   __shared__ __attribute__((aligned(16))) lds_t S[2 * TILE];      // A0 | A1
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -114,46 +118,43 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
   const int NB = p.N / 32, ng = p.K / 16;
   const uint16_t* Bf = reinterpret_cast<const uint16_t*>(p.B) + z0 * p.b_bs0 + z1 * p.b_bs1 + (long)(n0 / 32 + wave) * 512 + lane * 8;
   const long g_stride = (long)NB * 512;
-  const int c16 = tid & 15, r0 = tid >> 4;
-  const uint16_t* pa[NA];
+  const int c8 = tid & 7, r0 = tid >> 3;
+  const uint16_t* pa[MT];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) pa[i] = A + (long)min(m0 + r0 + 16 * i, p.M - 1) * p.lda;    // clamped: unconditional loads
+  for (int i = 0; i < MT; ++i) pa[i] = A + (long)min(m0 + r0 + 32 * i, p.M - 1) * p.lda;    // clamped: unconditional loads
   const int nk = (p.K + KT - 1) / KT;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   typedef typename std::conditional<PREC == CRAFT_PREC_BF16, bf16x8, f16x8>::type frag_t;
-  u32x4 va[NA];
-  frag_t bq[8];
-  auto fetch_a = [&](int kt) __attribute__((always_inline)) {
-    const int k = min(kt, nk - 1) * KT + c16 * 8;
+  u32x4 va0[MT], va1[MT];
+  frag_t bq[4];
+  auto fetch_a = [&](int kt, u32x4 (&va)[MT]) __attribute__((always_inline)) {
+    const int k = min(kt, nk - 1) * KT + c8 * 8;
     const int kc = k < p.K ? k : p.K - 8;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) va[i] = *reinterpret_cast<const u32x4*>(pa[i] + kc);
+    for (int i = 0; i < MT; ++i) va[i] = *reinterpret_cast<const u32x4*>(pa[i] + kc);
   };
   auto fetch_b = [&](int kt, int kk) __attribute__((always_inline)) {
-    const int g = min(min(kt, nk - 1) * 8 + kk, ng - 1);     // groups beyond K meet zeroed P columns
+    const int g = min(min(kt, nk - 1) * 4 + kk, ng - 1);     // groups beyond K meet zeroed P columns
     bq[kk] = *reinterpret_cast<const frag_t*>(Bf + g * g_stride);
   };
   // zeroing of the K tail happens at LDS-store time with a bitwise mask (no select next to the load, no exec branch)
-  auto store = [&](int kt) __attribute__((always_inline)) {
-    const unsigned keep = (kt * KT + c16 * 8 >= p.K) ? 0u : ~0u;
+  auto store = [&](int kt, const u32x4 (&va)[MT]) __attribute__((always_inline)) {
+    const unsigned keep = (kt * KT + c8 * 8 >= p.K) ? 0u : ~0u;
     lds_t* D = &S[(kt & 1) * TILE];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(&D[(r0 + 16 * i) * LD + c16 * 8]) = va[i] & keep;
+    for (int i = 0; i < MT; ++i) *reinterpret_cast<u32x4*>(&D[(r0 + 32 * i) * LD + c8 * 8]) = va[i] & keep;
   };
   const int r = lane & 31, g8 = (lane >> 5) * 8;
   f32x16 acc[MT][1];
   acc_zero(acc);
-  fetch_a(0);
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) fetch_b(0, kk);
-  store(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    fetch_a(kt + 1);                         // unconditional (clamped duplicate after the last tile)
+  // one pipeline step for tile kt: request A of tile kt+2 into `vfar`; MFMAs of tile kt (each B operand re-requested
+  // for tile kt+1 after its use); publish tile kt+1 (A already in `vnear`) to the other LDS buffer.
+  auto step = [&](int kt, u32x4 (&vnear)[MT], u32x4 (&vfar)[MT]) __attribute__((always_inline)) {
+    fetch_a(kt + 2, vfar);
     __builtin_amdgcn_sched_barrier(0);       // keep the P loads above the MFMAs they hide behind
     const lds_t* As = &S[(kt & 1) * TILE];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
+    for (int kk = 0; kk < 4; ++kk) {
       frag_t a[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const frag_t*>(&As[(mt * 32 + r) * LD + kk * 16 + g8]);
@@ -162,12 +163,24 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
         if constexpr (PREC == CRAFT_PREC_BF16) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], bq[kk], acc[mt][0], 0, 0, 0);
         else acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bq[kk], acc[mt][0], 0, 0, 0);
       }
-      fetch_b(kt + 1, kk);                   // next tile's operand, a whole tile of MFMAs ahead of its use
+      fetch_b(kt + 1, kk);
     }
     __builtin_amdgcn_sched_barrier(0);
-    store(kt + 1);
+    store(kt + 1, vnear);
     __syncthreads();
+  };
+  fetch_a(0, va0);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) fetch_b(0, kk);
+  store(0, va0);
+  fetch_a(1, va1);
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    step(kt, va1, va0);          // tile kt+1 is in va1; tile kt+2 goes to va0
+    step(kt + 1, va0, va1);
   }
+  if (kt < nk) step(kt, va1, va0);
   float* C = reinterpret_cast<float*>(p.C) + z0 * p.c_bs0 + z1 * p.c_bs1;
   const int col = n0 + wave * 32 + r;
   const int rh4 = 4 * (lane >> 5);
@@ -180,13 +193,30 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
     }
 }
 
+template <int PREC, int MT> static void launch_pv_t(const RowsGemmParams& p, hipStream_t s) {
+  dim3 grid((p.M + 32 * MT - 1) / (32 * MT), p.N / 128, p.batch);
+  hipLaunchKernelGGL((k_pv16<PREC, MT>), grid, dim3(NTHREADS), 0, s, p);
+}
+
 int launch_pv16(const RowsGemmParams& p, int prec, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return 0;
   if ((p.K & 15) || (p.lda & 7) || (p.N & 127) || p.c_dtype != CRAFT_PREC_F32) return CRAFT_ERR_ALIGN;
-  dim3 grid((p.M + 127) / 128, p.N / 128, p.batch);
-  if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_pv16<CRAFT_PREC_BF16>), grid, dim3(NTHREADS), 0, s, p);
-  else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_pv16<CRAFT_PREC_F16>), grid, dim3(NTHREADS), 0, s, p);
+  // rows per block: minimise (resident rounds) x (work per block).  Blocks per CU from the register / LDS budget of
+  // each instantiation (MT = 4: 3, MT >= 5: 2).
+  int best = 4; long best_cost = -1;
+  const int force = getenv("CRAFT_PV_MT") ? atoi(getenv("CRAFT_PV_MT")) : 0;
+  for (int mt = 4; mt <= 7; ++mt) {
+    const long blocks = (long)((p.M + 32 * mt - 1) / (32 * mt)) * (p.N / 128) * p.batch;
+    const long slots = 256L * (mt == 4 ? 3 : 2);
+    const long cost = ((blocks + slots - 1) / slots) * mt;
+    if (best_cost < 0 || cost < best_cost || mt == force) { best = mt; best_cost = cost; if (mt == force) break; }
+  }
+#define GO(PR) do { switch (best) { case 4: launch_pv_t<PR, 4>(p, s); break; case 5: launch_pv_t<PR, 5>(p, s); break; \
+                                    case 6: launch_pv_t<PR, 6>(p, s); break; default: launch_pv_t<PR, 7>(p, s); break; } } while (0)
+  if (prec == CRAFT_PREC_BF16) GO(CRAFT_PREC_BF16);
+  else if (prec == CRAFT_PREC_F16) GO(CRAFT_PREC_F16);
   else return CRAFT_ERR_ARG;
+#undef GO
   return (int)hipGetLastError();
 }
 
