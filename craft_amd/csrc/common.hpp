@@ -22,6 +22,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 #define CRAFT_ATTN_CLIP 100.0f   // setrans.py:98
 #define CRAFT_LN_EPS 1e-12f      // setrans.py:715, :362; corr.py:203
+#define CRAFT_STATS_REPLICAS 64  // == include/craft_hip.h
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -159,8 +159,11 @@ __device__ __forceinline__ void conv_col_stats(const ConvGemmParams& p, f32x16 (
     s1 += __shfl_xor(s1, 32);
     s2 += __shfl_xor(s2, 32);
     if (lane < 32 && col < p.cout) {
-      atomicAdd(&p.stats[(b * p.cout + col) * 2], (double)s1);
-      atomicAdd(&p.stats[(b * p.cout + col) * 2 + 1], (double)s2);
+      // CRAFT_STATS_REPLICAS copies of the table, picked by block id: thousands of blocks add into the same
+      // (image, channel) cell at about the same time and same-address atomics serialise in L2
+      double* st = p.stats + (long)(blockIdx.x % CRAFT_STATS_REPLICAS) * (p.g.npix / (p.g.H * p.g.W)) * p.cout * 2;
+      atomicAdd(&st[(b * p.cout + col) * 2], (double)s1);
+      atomicAdd(&st[(b * p.cout + col) * 2 + 1], (double)s2);
     }
   }
 }

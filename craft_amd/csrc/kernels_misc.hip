@@ -449,8 +449,10 @@ int launch_coords_init(const float* flow_init_nchw, int B, int H8, int W8, float
 __global__ void k_stats_finalize(const double* __restrict__ sums, long n, double count, float eps, float* __restrict__ mr) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double mu = sums[2 * i] / count;
-  double var = sums[2 * i + 1] / count - mu * mu;
+  double a = 0.0, q = 0.0;
+  for (int r = 0; r < CRAFT_STATS_REPLICAS; ++r) { a += sums[(r * n + i) * 2]; q += sums[(r * n + i) * 2 + 1]; }
+  const double mu = a / count;
+  double var = q / count - mu * mu;
   if (var < 0.0) var = 0.0;
   mr[2 * i] = (float)mu;
   mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(256) void k_stem7x7(const float* __restrict__ img, 
     if (tid < 128) {
       const float t = sred[tid] + sred[128 + tid] + sred[256 + tid] + sred[384 + tid];
       const int ch = tid & 63, which = tid >> 6;
-      atomicAdd(&stats[((long)b * 64 + ch) * 2 + which], (double)t);
+      atomicAdd(&stats[(((long)(blockIdx.x % CRAFT_STATS_REPLICAS) * (gridDim.x / (tiles_x * tiles_y)) + b) * 64 + ch) * 2 + which], (double)t);
     }
   }
 }

@@ -15,6 +15,7 @@ import torch
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 W_PACKED = 0x100
+STATS_REPLICAS = 64   # CRAFT_STATS_REPLICAS
 PREC_NAMES = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "f16x3": PREC_F16X3,
               "fp16x3": PREC_F16X3}
 PROB_DTYPE = {PREC_F32: torch.float32, PREC_BF16: torch.bfloat16, PREC_F16: torch.float16}

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .extractor import BasicEncoder, ResidualBlock
-from .hip import ACT_NONE, ACT_RELU, PREC_F32, W_PACKED, call, pick
+from .hip import ACT_NONE, ACT_RELU, PREC_F32, STATS_REPLICAS, W_PACKED, call, pick
 
 IN_EPS = 1e-5   # nn.InstanceNorm2d / nn.BatchNorm2d default eps (extractor.py uses the defaults)
 
@@ -105,7 +105,7 @@ class HipEncoder:
         return y, (Ho, Wo)
 
     def _finalize(self, stats, count):
-        B, C, _ = stats.shape
+        _, B, C, _ = stats.shape
         mr = torch.empty(B, C, 2, device=stats.device, dtype=torch.float32)
         call("craft_stats_finalize", stats, B * C, float(count), IN_EPS, mr)
         return mr
@@ -127,21 +127,21 @@ class HipEncoder:
         t = torch.empty(B, hw[0] * hw[1], 64, device=dev, dtype=torch.float32)
         t_norm = None
         if inorm:
-            s0 = torch.zeros(B, 64, 2, device=dev, dtype=torch.float64)
+            s0 = torch.zeros(STATS_REPLICAS, B, 64, 2, device=dev, dtype=torch.float64)
             call("craft_stem_conv7x7", raw.contiguous(), sw, sb, ACT_NONE, B, H, W, t, s0)
             t_norm = self._finalize(s0, hw[0] * hw[1])          # norm1 + ReLU are applied lazily by layer1.0
         else:
             call("craft_stem_conv7x7", raw.contiguous(), sw, sb, ACT_RELU, B, H, W, t, None)
         for pk in packs:
             if inorm:
-                s1 = torch.zeros(B, pk["c1"].cout, 2, device=dev, dtype=torch.float64)
+                s1 = torch.zeros(STATS_REPLICAS, B, pk["c1"].cout, 2, device=dev, dtype=torch.float64)
                 c1, hw1 = self._conv(t, B, hw, pk["c1"], ACT_NONE, cp, in_norm=t_norm, stats=s1)
                 n1 = self._finalize(s1, hw1[0] * hw1[1])
-                s2 = torch.zeros(B, pk["c2"].cout, 2, device=dev, dtype=torch.float64)
+                s2 = torch.zeros(STATS_REPLICAS, B, pk["c2"].cout, 2, device=dev, dtype=torch.float64)
                 c2, _ = self._conv(c1, B, hw1, pk["c2"], ACT_NONE, cp, in_norm=n1, stats=s2)
                 n2 = self._finalize(s2, hw1[0] * hw1[1])
                 if "ds" in pk:
-                    s3 = torch.zeros(B, pk["ds"].cout, 2, device=dev, dtype=torch.float64)
+                    s3 = torch.zeros(STATS_REPLICAS, B, pk["ds"].cout, 2, device=dev, dtype=torch.float64)
                     xs, _ = self._conv(t, B, hw, pk["ds"], ACT_NONE, cp, stats=s3)
                     n3 = self._finalize(s3, hw1[0] * hw1[1])
                     flags = 1

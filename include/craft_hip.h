@@ -128,6 +128,7 @@ int craft_gma_residual(const float* mf, long ldm, const float* O, const float* g
  * 1x1 / tiny convs: wc1, wf1, flow-head w2, mask-head w2 stay raw fp32) when CRAFT_W_PACKED is or-ed into prec: a wave then
  * fetches the B operand of each 32x32x16 MFMA with one coalesced 1 KiB load and the K loop runs without per-tile barriers. */
 #define CRAFT_W_PACKED 0x100
+#define CRAFT_STATS_REPLICAS 64
 int craft_pack_weights(const float* w, int rows, int K, int prec, void* out, void* stream);
 
 /* nn.Conv2d (stride 1, "same" zero padding KH/2, KW/2) + bias + optional ReLU on tokens: x [B*H*W][cin] (row
@@ -139,9 +140,12 @@ int craft_conv2d_nhwc(const float* x, long ldx, int cin, const float* w, const f
 /* ---- CNN encoder building blocks (BasicEncoder / ResidualBlock, extractor.py:6-64, 124-196) ----
  * craft_conv2d_nhwc_ex: craft_conv2d_nhwc plus (a) stride 2 (x is [B*Hin*Win][cin], y [B*Hout*Wout][cout], padding
  * KH/2); (b) in_norm [B][cin][2] = (mean, rstd): the input is read as relu((x - mean)*rstd), i.e. the InstanceNorm
- * + ReLU of the producing conv applied lazily (stride 1, KH*KW > 1 only); (c) stats [B][cout][2] doubles: += (sum,
- * sum^2) of the biased output per (image, channel) for the consumer's lazy InstanceNorm (zero them first).
- * craft_stats_finalize: n populations of `count` samples: (sum, sum^2) -> (mean, 1/sqrt(var + eps)).
+ * + ReLU of the producing conv applied lazily (stride 1, KH*KW > 1 only); (c) stats [CRAFT_STATS_REPLICAS][B][cout][2]
+ * doubles: += (sum, sum^2) of the biased output per (image, channel) for the consumer's lazy InstanceNorm (zero them
+ * first).  The table is replicated (a block adds into replica blockIdx % CRAFT_STATS_REPLICAS) because thousands of
+ * blocks hit the same B*cout cells at once and same-address atomics serialise in L2.
+ * craft_stats_finalize: n = B*cout populations of `count` samples: replicas summed, (sum, sum^2) -> (mean,
+ * 1/sqrt(var + eps)).
  * craft_residual_relu: out = relu(fx(x) + fy(y)), fx = identity or (x-mean)*rstd (xnorm), fy = identity / relu /
  * relu((y-mean)*rstd) (ynorm, y_relu bit 0; bit 1 = ReLU on fx): the tail of ResidualBlock.forward with both
  * norms applied lazily.

@@ -42,6 +42,17 @@ def main():
                 ub.encoder.forward_tokens(fl, corr, (H8, W8), hx[..., 256:384], ws, prec)
             else:
                 ub.flow_head_tokens(hx, (H8, W8), c1, c0, fl, None, ws, prec)
+    elif which in ("fnet", "cnet"):
+        from craft_amd import CRAFT, default_args
+        from craft_amd.synth import synth_state_dict, synth_pair
+        m = CRAFT(default_args())
+        m.load_state_dict(synth_state_dict(m.state_dict(), seed=1234))
+        m = m.cuda().eval()
+        im1, im2, _ = synth_pair(B, 448, 1024, seed=0)
+        raw = torch.cat([im1, im2]).cuda() if which == "fnet" else im1.cuda()
+        enc = m._henc_f if which == "fnet" else m._henc_c
+        for _ in range(2):
+            enc.forward_tokens(raw, prec)
     elif which == "probs":
         import math
         C, Mm = 128, 4
