@@ -31,7 +31,7 @@ __device__ __forceinline__ f32x16 mfma16(typename FragT<PREC>::t a, typename Fra
   else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-template <int PREC, int WM, int WN, bool ENC, int DBG = 0>
+template <int PREC, int WM, int WN, bool ENC>
 __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   typedef typename PrecT<PREC>::lds_t lds_t;
   typedef typename FragT<PREC>::t frag_t;
@@ -60,11 +60,12 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   const int c4 = tid & 7, r0 = tid >> 3;
 
   // ---- halo gather: per-thread pixel offsets (-1: outside the image / beyond the halo)
+  const int hwd_magic = 65536 / HWd + 1;
   int hpix[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int hr = r0 + 32 * i;
-    const int hy = hr / HWd, hx = hr - hy * HWd;
+    const int hy = (hr * hwd_magic) >> 16, hx = hr - hy * HWd;     // hr / HWd for hr < 192, HWd in 16..20 (exact)
     const int y = y0 - g.padH + hy, x = x0 - g.padW + hx;
     hpix[i] = (hr < HR && y >= 0 && y < g.H && x >= 0 && x < g.W) ? y * g.W + x : -1;
   }
@@ -105,8 +106,9 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
         *reinterpret_cast<f16x4*>(&A0[row * LD + c4 * 4]) = h;
         if constexpr (PREC == CRAFT_PREC_F16X3) {
           f16x4 l;
-          l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
-          l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+          // v - float(h) as one fma with an fp16 source operand (v_fma_mix_f32) instead of cvt + sub
+          l[0] = (_Float16)__builtin_fmaf((float)h[0], -1.f, v.x); l[1] = (_Float16)__builtin_fmaf((float)h[1], -1.f, v.y);
+          l[2] = (_Float16)__builtin_fmaf((float)h[2], -1.f, v.z); l[3] = (_Float16)__builtin_fmaf((float)h[3], -1.f, v.w);
           *reinterpret_cast<f16x4*>(&A0[(HR_MAX + row) * LD + c4 * 4]) = l;
         }
       }
@@ -119,13 +121,11 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   const int nb = min((n0 + wn0) / 32, NBtot - 1);
   const uint16_t* wb = reinterpret_cast<const uint16_t*>(p.W) + (long)nb * (PL * 1024) + lane * 8;
   const long kt_stride = (long)NBtot * (PL * 1024);
-  frag_t bq[PL][2], bn[PL][2];
-  auto fetch_b = [&](int kt, frag_t (&dst)[PL][2]) __attribute__((always_inline)) {
-    const uint16_t* q = wb + kt * kt_stride;
+  frag_t bq[PL][2];
+  auto fetch_b = [&](int kt, int kk) __attribute__((always_inline)) {
+    const uint16_t* q = wb + kt * kt_stride + kk * 512;
 #pragma unroll
-    for (int pl = 0; pl < PL; ++pl)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) dst[pl][kk] = *reinterpret_cast<const frag_t*>(q + (pl * 2 + kk) * 512);
+    for (int pl = 0; pl < PL; ++pl) bq[pl][kk] = *reinterpret_cast<const frag_t*>(q + pl * 1024);
   };
 
   // lane's base halo element offsets for its MT output-row fragments
@@ -164,43 +164,46 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
 
   float4 ra[NA];
   fetch_halo(0, ra);
-  fetch_b(0, bq);
+  fetch_b(0, 0);
+  fetch_b(0, 1);
   store_halo(0, 0, ra);
   __syncthreads();
 
   // K loop: chunk-outer / tap-inner; K-tile index in the packed weights = tap * nchunk + chunk.  Software pipeline,
   // all distances in units of one k-half (MT*3 MFMAs):
   //   * A fragments (LDS) are requested ONE k-half ahead (two register sets a0 / a1),
-  //   * B fragments (L2) a whole K-tile ahead (bn, copied into bq after the tile's MFMAs),
+  //   * the B fragments (L2) of k-half kk of the NEXT K-tile are requested into the same registers right after the
+  //     MFMAs that consumed them (two k-halves ahead of their use, no second register set, no copies),
   //   * the next chunk's halo (HBM/L2) a whole chunk ahead; it is written to the idle LDS buffer after the second
   //     tap and published by the single barrier of the chunk, placed right before the first read of that buffer
   //     (in the middle of the last tap), by which time every wave has long finished its stores.
+  // Tap offsets are tracked incrementally (tx, trow): no division in the loop.
   frag_t a0h[MT], a0l[MT], a1h[MT], a1l[MT];
   const int smid = min(1, T - 1);
   int hb = 0;
   read_a(0, 0, 0, a0h, a0l);
-  if (DBG & 4) read_a(0, 0, 1, a1h, a1l);
-  for (int chunk = 0; chunk < ((DBG & 16) ? 0 : nchunk); ++chunk) {
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
     const int cn = min(chunk + 1, nchunk - 1);
-    if (!(DBG & 1)) fetch_halo(cn, ra);                   // straight-line: lands during this chunk's taps
+    fetch_halo(cn, ra);                                   // straight-line: lands during this chunk's taps
+    int tx = 0, trow = 0;                                 // tap = (trow / HWd) * KW + tx; toff = (trow + tx) * LD
     for (int tap = 0; tap < T; ++tap) {
       const bool last_tap = tap + 1 == T;
-      const int tapn = last_tap ? 0 : tap + 1;
-      const int ty_ = tap / KW, tyn = tapn / KW;
-      const int toff = (ty_ * HWd + (tap - ty_ * KW)) * LD, toffn = (tyn * HWd + (tapn - tyn * KW)) * LD;
-      if (!(DBG & 2)) fetch_b(last_tap ? cn : tapn * nchunk + chunk, bn);
-      if (!(DBG & 4)) read_a(hb, toff, 1, a1h, a1l);
+      const int toff = (trow + tx) * LD;
+      if (++tx == KW) { tx = 0; trow += HWd; }
+      const int toffn = last_tap ? 0 : (trow + tx) * LD;
+      const int ktn = last_tap ? cn : (tap + 1) * nchunk + chunk;
+      read_a(hb, toff, 1, a1h, a1l);
       __builtin_amdgcn_sched_barrier(0);
       mma_half(a0h, a0l, 0);
+      fetch_b(ktn, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(DBG & 1) && tap == smid) store_halo(hb ^ 1, cn, ra);
-      if (!(DBG & 8) && last_tap) { __syncthreads(); hb ^= 1; }
-      if (!(DBG & 4)) read_a(hb, toffn, 0, a0h, a0l);                    // next tile (after the last chunk: a harmless re-read)
+      if (tap == smid) store_halo(hb ^ 1, cn, ra);
+      if (last_tap) { __syncthreads(); hb ^= 1; }
+      read_a(hb, toffn, 0, a0h, a0l);                    // next tile (after the last chunk: a harmless re-read)
       __builtin_amdgcn_sched_barrier(0);
       mma_half(a1h, a1l, 1);
+      fetch_b(ktn, 1);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int pl = 0; pl < PL; ++pl) if (!(DBG & 2)) { bq[pl][0] = bn[pl][0]; bq[pl][1] = bn[pl][1]; }
     }
   }
 
@@ -211,16 +214,19 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   CONV_EPI_DISPATCH(p, BODY)
 #undef BODY
   if (ENC && p.stats) {
-    unsigned mlo = 0u, mhi = 0u;
+    unsigned mlo = ~0u, mhi = ~0u;
+    if (y0 + WF_PATCH_H > g.H || x0 + WF_PATCH_W > g.W) {      // ragged patch only: per-row validity
+      mlo = 0u; mhi = 0u;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int r = wm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
-        const bool ok = (y0 + (r >> 4)) < g.H && (x0 + (r & 15)) < g.W;
-        const int bit = mt * 16 + e;
-        if (ok) { if (bit < 32) mlo |= 1u << bit; else mhi |= 1u << (bit - 32); }
-      }
+        for (int e = 0; e < 16; ++e) {
+          const int r = wm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
+          const bool ok = (y0 + (r >> 4)) < g.H && (x0 + (r & 15)) < g.W;
+          const int bit = mt * 16 + e;
+          if (ok) { if (bit < 32) mlo |= 1u << bit; else mhi |= 1u << (bit - 32); }
+        }
+    }
     conv_col_stats<MT, 1>(p, acc, lane, cb, (long)b, mlo, mhi);
   }
 }
@@ -231,14 +237,6 @@ template <int PREC, int WM, int WN> static int launch_wf_t(const ConvGemmParams&
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   const int tiles = ((p.g.W + WF_PATCH_W - 1) / WF_PATCH_W) * ((p.g.H + WF_PATCH_H - 1) / WF_PATCH_H) * (p.g.npix / (p.g.H * p.g.W));
   dim3 grid(tiles, (ncols + BN - 1) / BN, 1);
-  if (const char* e = getenv("CRAFT_DBG")) {
-    if constexpr (PREC == CRAFT_PREC_F16X3 && WM == 1) {
-      const int d = atoi(e);
-#define DB(D) if (d == D) { hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, false, D>), grid, dim3(NTHREADS), 0, s, p); return (int)hipGetLastError(); }
-      DB(1) DB(2) DB(3) DB(4) DB(5) DB(6) DB(7) DB(8) DB(16)
-#undef DB
-    }
-  }
   if (enc) hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, true>), grid, dim3(NTHREADS), 0, s, p);
   else hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, false>), grid, dim3(NTHREADS), 0, s, p);
   return (int)hipGetLastError();
