@@ -162,29 +162,30 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
     for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(h[mt], bq[0][kk], acc[mt][0]);
   };
 
-  float4 ra[NA];
+  float4 ra[NA], rb[NA];
   fetch_halo(0, ra);
   fetch_b(0, 0);
   fetch_b(0, 1);
+  fetch_halo(min(1, nchunk - 1), rb);                     // issued before ra is consumed: both HBM round trips overlap
   store_halo(0, 0, ra);
   __syncthreads();
 
-  // K loop: chunk-outer / tap-inner; K-tile index in the packed weights = tap * nchunk + chunk.  Software pipeline,
-  // all distances in units of one k-half (MT*3 MFMAs):
-  //   * A fragments (LDS) are requested ONE k-half ahead (two register sets a0 / a1),
+  // K loop: chunk-outer / tap-inner; K-tile index in the packed weights = tap * nchunk + chunk.  Software pipeline:
+  //   * A fragments (LDS) are requested ONE k-half (MT*3 MFMAs) ahead (two register sets a0 / a1),
   //   * the B fragments (L2) of k-half kk of the NEXT K-tile are requested into the same registers right after the
   //     MFMAs that consumed them (two k-halves ahead of their use, no second register set, no copies),
-  //   * the next chunk's halo (HBM/L2) a whole chunk ahead; it is written to the idle LDS buffer after the second
-  //     tap and published by the single barrier of the chunk, placed right before the first read of that buffer
-  //     (in the middle of the last tap), by which time every wave has long finished its stores.
+  //   * halos (HBM/L2) are requested TWO chunks ahead (register sets ra / rb alternate, hence the 2x unrolled chunk
+  //     loop): with few input channels a chunk is shorter than an HBM round trip.  Chunk c+1 is written to the idle
+  //     LDS buffer after the second tap of chunk c and published by the single barrier of the chunk, placed right
+  //     before the first read of that buffer (in the middle of the last tap).
   // Tap offsets are tracked incrementally (tx, trow): no division in the loop.
   frag_t a0h[MT], a0l[MT], a1h[MT], a1l[MT];
   const int smid = min(1, T - 1);
   int hb = 0;
   read_a(0, 0, 0, a0h, a0l);
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
+  auto do_chunk = [&](int chunk, float4 (&rnear)[NA], float4 (&rfar)[NA]) __attribute__((always_inline)) {
     const int cn = min(chunk + 1, nchunk - 1);
-    fetch_halo(cn, ra);                                   // straight-line: lands during this chunk's taps
+    fetch_halo(min(chunk + 2, nchunk - 1), rfar);         // rfar held this chunk's halo, already in LDS
     int tx = 0, trow = 0;                                 // tap = (trow / HWd) * KW + tx; toff = (trow + tx) * LD
     for (int tap = 0; tap < T; ++tap) {
       const bool last_tap = tap + 1 == T;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
       mma_half(a0h, a0l, 0);
       fetch_b(ktn, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (tap == smid) store_halo(hb ^ 1, cn, ra);
+      if (tap == smid) store_halo(hb ^ 1, cn, rnear);
       if (last_tap) { __syncthreads(); hb ^= 1; }
       read_a(hb, toffn, 0, a0h, a0l);                    // next tile (after the last chunk: a harmless re-read)
       __builtin_amdgcn_sched_barrier(0);
@@ -205,7 +206,13 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
       fetch_b(ktn, 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  int chunk = 0;
+  for (; chunk + 1 < nchunk; chunk += 2) {
+    do_chunk(chunk, rb, ra);
+    do_chunk(chunk + 1, ra, rb);
   }
+  if (chunk < nchunk) do_chunk(chunk, rb, ra);
 
   // ---- epilogue: GEMM row r of the patch -> token (y0 + r/16, x0 + r%16)
   const int cb = n0 + wn0;

@@ -118,10 +118,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_LIB_PATH):
-        raise CraftHipError(f"{_LIB_PATH} not found: build it with `python -m craft_amd.build` "
+    path = os.environ.get("CRAFT_HIP_LIB", _LIB_PATH)      # (override: A/B runs of two builds on one GPU box)
+    if not os.path.exists(path):
+        raise CraftHipError(f"{path} not found: build it with `python -m craft_amd.build` "
                             "(hipcc --offload-arch=gfx950). There is no fallback path.")
-    lib = ctypes.CDLL(_LIB_PATH)
+    lib = ctypes.CDLL(path)
     lib.craft_hip_abi_version.restype = c_int
     lib.craft_hip_error_string.restype = c_char_p
     lib.craft_hip_error_string.argtypes = [c_int]
