@@ -302,32 +302,54 @@ int launch_corr_lookup(const float* l0, const float* l1, const float* l2, const 
 // convf1: 7x7 conv 2 -> 128 + ReLU on the flow field (update.py:75,82).  w packed [7*7*2][128]
 // (tap-major: ((ky*7+kx)*2 + c), output channel contiguous).  block = 2 pixels x 128 channels.
 // ---------------------------------------------------------------------------------------------
+// A block owns CF1_SEG consecutive pixels of one image row; thread = (output channel, half of the segment).  The 98
+// weights of the thread's channel live in registers for the whole segment and the 7 x (CF1_SEG + 6) x 2 flow patch in
+// LDS (broadcast reads), so the weight table is read once per block instead of once per pixel.
+constexpr int CF1_SEG = 32, CF1_PW = CF1_SEG + 6;
 __global__ __launch_bounds__(256) void k_convf1(const float* __restrict__ flow, const float* __restrict__ w,
-                                                const float* __restrict__ bias, int H8, int W8, long npix,
+                                                const float* __restrict__ bias, int H8, int W8,
                                                 float* __restrict__ out, long ldo) {
-  __shared__ float pat[2][98];
-  const int tid = threadIdx.x, co = tid & 127, pl = tid >> 7;
-  const long pix = (long)blockIdx.x * 2 + pl;
-  const int hw = H8 * W8;
-  if (co < 98 && pix < npix) {
-    const int b = (int)(pix / hw), rem = (int)(pix - (long)b * hw);
-    const int y = rem / W8, x = rem - y * W8;
-    const int t = co >> 1, c = co & 1;
-    const int ky = t / 7, kx = t - ky * 7;
-    const int yy = y + ky - 3, xx = x + kx - 3;
-    pat[pl][co] = (yy >= 0 && yy < H8 && xx >= 0 && xx < W8) ? flow[((long)b * hw + yy * W8 + xx) * 2 + c] : 0.f;
+  __shared__ __attribute__((aligned(16))) float pat[7][CF1_PW * 2];
+  const int tid = threadIdx.x, co = tid & 127, half = tid >> 7;
+  const int segs = (W8 + CF1_SEG - 1) / CF1_SEG;
+  int bid = blockIdx.x;
+  const int sx = bid % segs; bid /= segs;
+  const int y = bid % H8;
+  const int b = bid / H8;
+  const int x0 = sx * CF1_SEG;
+  const long img = (long)b * H8 * W8;
+  for (int i = tid; i < 7 * CF1_PW * 2; i += 256) {
+    const int ky = i / (CF1_PW * 2), rem = i - ky * (CF1_PW * 2);
+    const int px = rem >> 1, c = rem & 1;
+    const int yy = y + ky - 3, xx = x0 + px - 3;
+    pat[ky][rem] = (yy >= 0 && yy < H8 && xx >= 0 && xx < W8) ? flow[(img + (long)yy * W8 + xx) * 2 + c] : 0.f;
   }
+  float wr[98];
+#pragma unroll
+  for (int k = 0; k < 98; ++k) wr[k] = w[k * 128 + co];
+  const float bco = bias[co];
   __syncthreads();
-  if (pix >= npix) return;
-  float acc = bias[co];
-#pragma unroll 14
-  for (int k = 0; k < 98; ++k) acc += pat[pl][k] * w[k * 128 + co];
-  out[pix * ldo + co] = fmaxf(acc, 0.f);
+  constexpr int PER = CF1_SEG / 2;
+  for (int i = 0; i < PER; ++i) {
+    const int px = half * PER + i;            // pixel within the segment (uniform per wave)
+    if (x0 + px >= W8) break;
+    float acc = bco;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      const float2* row = reinterpret_cast<const float2*>(&pat[ky][px * 2]);
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const float2 f = row[kx];
+        acc += f.x * wr[(ky * 7 + kx) * 2] + f.y * wr[(ky * 7 + kx) * 2 + 1];
+      }
+    }
+    out[(img + (long)y * W8 + x0 + px) * ldo + co] = fmaxf(acc, 0.f);
+  }
 }
 int launch_convf1(const float* flow, const float* w, const float* bias, int B, int H8, int W8, float* out, long ldo,
                   hipStream_t s) {
-  const long npix = (long)B * H8 * W8;
-  hipLaunchKernelGGL(k_convf1, dim3((unsigned)((npix + 1) / 2)), dim3(256), 0, s, flow, w, bias, H8, W8, npix, out, ldo);
+  const int segs = (W8 + CF1_SEG - 1) / CF1_SEG;
+  hipLaunchKernelGGL(k_convf1, dim3((unsigned)(B * H8 * segs)), dim3(256), 0, s, flow, w, bias, H8, W8, out, ldo);
   return (int)hipGetLastError();
 }
 
@@ -336,43 +358,77 @@ int launch_convf1(const float* flow, const float* w, const float* bias, int B, i
 // coords1 += delta (network.py:247) and flow = coords1 - coords0.  One wave per pixel; lane owns 4 channels.
 // w packed [2][3*3][256].
 // ---------------------------------------------------------------------------------------------
+// A wave owns FH2_SEG consecutive pixels of one image row; a lane owns 4 of the 256 channels.  The lane's 72 weights
+// stay in registers, and the 3x3 window slides along x: per pixel only the new column (3 float4) is loaded.
+constexpr int FH2_SEG = 16;
 __global__ __launch_bounds__(256) void k_flow_head2(const float* __restrict__ hid, const float* __restrict__ w,
-                                                    const float* __restrict__ bias, int H8, int W8, long npix,
+                                                    const float* __restrict__ bias, int H8, int W8, int nseg_total,
                                                     float* __restrict__ coords1, const float* __restrict__ coords0,
                                                     float* __restrict__ flow, float* __restrict__ delta) {
   const int lane = threadIdx.x & 63;
-  const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pix >= npix) return;
-  const int hw = H8 * W8;
-  const int b = (int)(pix / hw), rem = (int)(pix - (long)b * hw);
-  const int y = rem / W8, x = rem - y * W8;
-  float a0 = 0.f, a1 = 0.f;
+  const int seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (seg >= nseg_total) return;
+  const int segs = (W8 + FH2_SEG - 1) / FH2_SEG;
+  int t = seg;
+  const int sx = t % segs; t /= segs;
+  const int y = t % H8;
+  const int b = t / H8;
+  const int x0 = sx * FH2_SEG;
+  const long img = (long)b * H8 * W8;
+  float4 w0[9], w1[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-    if (yy < 0 || yy >= H8 || xx < 0 || xx >= W8) continue;
-    const float4 h = *reinterpret_cast<const float4*>(hid + ((long)b * hw + yy * W8 + xx) * 256 + lane * 4);
-    const float4 w0 = *reinterpret_cast<const float4*>(w + (0 * 9 + t) * 256 + lane * 4);
-    const float4 w1 = *reinterpret_cast<const float4*>(w + (1 * 9 + t) * 256 + lane * 4);
-    a0 += h.x * w0.x + h.y * w0.y + h.z * w0.z + h.w * w0.w;
-    a1 += h.x * w1.x + h.y * w1.y + h.z * w1.z + h.w * w1.w;
+  for (int k = 0; k < 9; ++k) {
+    w0[k] = *reinterpret_cast<const float4*>(w + (0 * 9 + k) * 256 + lane * 4);
+    w1[k] = *reinterpret_cast<const float4*>(w + (1 * 9 + k) * 256 + lane * 4);
   }
-  a0 = wave_sum(a0);
-  a1 = wave_sum(a1);
-  if (lane == 0) {
-    const float dx = a0 + bias[0], dy = a1 + bias[1];
-    const float nx = coords1[2 * pix] + dx, ny = coords1[2 * pix + 1] + dy;
-    coords1[2 * pix] = nx;
-    coords1[2 * pix + 1] = ny;
-    flow[2 * pix] = nx - coords0[2 * pix];
-    flow[2 * pix + 1] = ny - coords0[2 * pix + 1];
-    if (delta) { delta[2 * pix] = dx; delta[2 * pix + 1] = dy; }
+  const float b0 = bias[0], b1 = bias[1];
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto col = [&](int xx, float4 (&c)[3]) __attribute__((always_inline)) {     // column xx of the 3 rows (zero padding)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int yy = y + r - 1;
+      const bool ok = yy >= 0 && yy < H8 && xx >= 0 && xx < W8;
+      const float4 v = *reinterpret_cast<const float4*>(hid + (img + (long)min(max(yy, 0), H8 - 1) * W8 + min(max(xx, 0), W8 - 1)) * 256 + lane * 4);
+      c[r] = ok ? v : zero;
+    }
+  };
+  float4 cl[3], cm[3], cr[3];
+  col(x0 - 1, cl);
+  col(x0, cm);
+  const int n = min(FH2_SEG, W8 - x0);
+  for (int i = 0; i < n; ++i) {
+    col(x0 + i + 1, cr);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float4 h0 = cl[r], h1 = cm[r], h2 = cr[r];
+      const float4 u0 = w0[r * 3], u1 = w0[r * 3 + 1], u2 = w0[r * 3 + 2];
+      const float4 v0 = w1[r * 3], v1 = w1[r * 3 + 1], v2 = w1[r * 3 + 2];
+      a0 += h0.x * u0.x + h0.y * u0.y + h0.z * u0.z + h0.w * u0.w + h1.x * u1.x + h1.y * u1.y + h1.z * u1.z + h1.w * u1.w +
+            h2.x * u2.x + h2.y * u2.y + h2.z * u2.z + h2.w * u2.w;
+      a1 += h0.x * v0.x + h0.y * v0.y + h0.z * v0.z + h0.w * v0.w + h1.x * v1.x + h1.y * v1.y + h1.z * v1.z + h1.w * v1.w +
+            h2.x * v2.x + h2.y * v2.y + h2.z * v2.z + h2.w * v2.w;
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if (lane == 0) {
+      const long pix = img + (long)y * W8 + x0 + i;
+      const float dx = a0 + b0, dy = a1 + b1;
+      const float nx = coords1[2 * pix] + dx, ny = coords1[2 * pix + 1] + dy;
+      coords1[2 * pix] = nx;
+      coords1[2 * pix + 1] = ny;
+      flow[2 * pix] = nx - coords0[2 * pix];
+      flow[2 * pix + 1] = ny - coords0[2 * pix + 1];
+      if (delta) { delta[2 * pix] = dx; delta[2 * pix + 1] = dy; }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { cl[r] = cm[r]; cm[r] = cr[r]; }
   }
 }
 int launch_flow_head2(const float* hid, const float* w, const float* bias, int B, int H8, int W8, float* coords1,
                       const float* coords0, float* flow, float* delta, hipStream_t s) {
-  const long npix = (long)B * H8 * W8;
-  hipLaunchKernelGGL(k_flow_head2, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, hid, w, bias, H8, W8, npix, coords1,
+  const int nseg = B * H8 * ((W8 + FH2_SEG - 1) / FH2_SEG);
+  hipLaunchKernelGGL(k_flow_head2, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, s, hid, w, bias, H8, W8, nseg, coords1,
                      coords0, flow, delta);
   return (int)hipGetLastError();
 }
