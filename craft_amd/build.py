@@ -40,7 +40,10 @@ def _compile(src: str, extra) -> str:
     obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]
     if _stale(obj, deps):
+        # -amdgpu-mfma-vgpr-form: MFMA accumulators in VGPRs (every kernel here fits 256 unified registers), so the
+        # epilogues read them directly instead of through one v_accvgpr_read per value
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+               "-mllvm", "-amdgpu-mfma-vgpr-form",
                "-c", os.path.join(CSRC, src), "-o", obj] + list(extra)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
