@@ -119,7 +119,10 @@ __device__ __forceinline__ void mma_rows(const typename PrecT<PREC>::lds_t* Ks, 
   }
 }
 
-template <int PREC, int PT, int D>
+// DEFER: the probabilities are stored UN-normalised, P'[i][j] = 2^(t_ij - max_i) in (0, 1], together with the row sums
+// l_i (p.rowsum); the consumer (craft_attn_apply) divides its output rows by l_i.  Pass 1 then only needs the row
+// maxima -- no exponentials -- which removes ~40 % of the VALU work that bounds this kernel.
+template <int PREC, int PT, int D, bool DEFER>
 __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __restrict__ Pout, long ldp) {
   typedef RowTile<PREC, D> T;
   typedef typename T::lds_t lds_t;
@@ -202,7 +205,10 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
 #pragma unroll
         for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, acc[mt][e]);
     }
-    if (!pass1) {
+    if (!pass1 && DEFER) {
+      m_run = fmaxf(m_run, tmax);
+      if (t == nkt - 1) { m_run = fmaxf(m_run, __shfl_xor(m_run, 32)); inv_l = 1.f; l_run = 0.f; }
+    } else if (!pass1) {
       const float m_new = fmaxf(m_run, tmax);
       if (m_new > -INFINITY) {
         float add = 0.f;
@@ -232,7 +238,8 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const float d = acc[mt][4 * q + i] - m_run;
-              pv[i] = (kExact ? exp2f(d) : __builtin_amdgcn_exp2f(d)) * inv_l;
+              const float ex = kExact ? exp2f(d) : __builtin_amdgcn_exp2f(d);
+              if constexpr (DEFER) { pv[i] = ex; l_run += ex; } else pv[i] = ex * inv_l;
             }
             if constexpr (PT == CRAFT_PREC_F32) {
               *reinterpret_cast<float4*>(Prow + j) = make_float4(pv[0], pv[1], pv[2], pv[3]);
@@ -251,13 +258,20 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
     if (tid < 128) { const int j = jn * 128 + tid; s_kh[tid] = j / W8; s_kw[tid] = j - (j / W8) * W8; }
     __syncthreads();
   }
+  if constexpr (DEFER) {
+    const float l = l_run + __shfl_xor(l_run, 32);      // the two half-waves hold disjoint keys of the same query
+    if (lane < 32 && qcol < N) p.rowsum[(long)z * N + qcol] = l;
+  }
 }
 
 template <int PREC, int D> static int launch_pt(const ScoreParams& p, void* P, long ldp, int p_prec, dim3 grid, hipStream_t s) {
-  if (p_prec == CRAFT_PREC_F32) hipLaunchKernelGGL((k_attn_probs<PREC, CRAFT_PREC_F32, D>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
-  else if (p_prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_attn_probs<PREC, CRAFT_PREC_BF16, D>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
-  else if (p_prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_attn_probs<PREC, CRAFT_PREC_F16, D>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
+#define GO(PTV) do { if (p.rowsum) hipLaunchKernelGGL((k_attn_probs<PREC, PTV, D, true>), grid, dim3(NTHREADS), 0, s, p, P, ldp); \
+                     else hipLaunchKernelGGL((k_attn_probs<PREC, PTV, D, false>), grid, dim3(NTHREADS), 0, s, p, P, ldp); } while (0)
+  if (p_prec == CRAFT_PREC_F32) GO(CRAFT_PREC_F32);
+  else if (p_prec == CRAFT_PREC_BF16) GO(CRAFT_PREC_BF16);
+  else if (p_prec == CRAFT_PREC_F16) GO(CRAFT_PREC_F16);
   else return CRAFT_ERR_ARG;
+#undef GO
   return (int)hipGetLastError();
 }
 

@@ -101,14 +101,16 @@ int craft_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, c
 
 int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d, float scale,
                      const float* pos_tab, int R, float pos_w, int mask_radius, const unsigned* clamp_ord, void* P,
-                     long ldp, int p_prec, int prec, void* stream) {
-  return launch_attn_probs(make_score(q, ldq, k, ldk, B, H8, W8, M, d, scale, pos_tab, R, pos_w, mask_radius, clamp_ord), P,
-                           ldp, p_prec, prec, S(stream));
+                     long ldp, float* rowsum, int p_prec, int prec, void* stream) {
+  ScoreParams sp = make_score(q, ldq, k, ldk, B, H8, W8, M, d, scale, pos_tab, R, pos_w, mask_radius, clamp_ord);
+  sp.rowsum = rowsum;
+  return launch_attn_probs(sp, P, ldp, p_prec, prec, S(stream));
 }
 
-int craft_attn_apply(const void* P, long ldp, const void* vT, int B, int N, int M, int Dv, float* O, int prec,
-                     void* stream) {
+int craft_attn_apply(const void* P, long ldp, const float* rowsum, const void* vT, int B, int N, int M, int Dv, float* O,
+                     int prec, void* stream) {
   RowsGemmParams p = {};
+  p.row_div = rowsum; p.rd_bs = N;
   p.A = P; p.lda = ldp; p.a_bs0 = (long)M * N * ldp; p.a_bs1 = (long)N * ldp;
   p.B = vT; p.ldb = ldp; p.b_bs0 = (long)M * Dv * ldp; p.b_bs1 = (long)Dv * ldp;
   p.C = O; p.ldc = Dv; p.c_bs0 = (long)M * N * Dv; p.c_bs1 = (long)N * Dv;

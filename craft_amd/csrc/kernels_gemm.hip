@@ -59,7 +59,9 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_rows(RowsGemmParams p) {
           float v[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float t = acc[mt][nt][4 * q + i] * p.scale + bias;
+            float t = acc[mt][nt][4 * q + i] * p.scale;
+            if (p.row_div) t /= p.row_div[(long)z * p.rd_bs + min(row0 + i, p.M - 1)];
+            t += bias;
             v[i] = relu ? fmaxf(t, 0.f) : t;
           }
           if constexpr (FRAG) {
@@ -184,12 +186,17 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
   float* C = reinterpret_cast<float*>(p.C) + z0 * p.c_bs0 + z1 * p.c_bs1;
   const int col = n0 + wave * 32 + r;
   const int rh4 = 4 * (lane >> 5);
+  const float* rdiv = p.row_div ? p.row_div + (long)z * p.rd_bs : nullptr;     // deferred softmax normalisation
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = m0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
-      if (row < p.M) C[(long)row * p.ldc + col] = acc[mt][0][e];
+      if (row < p.M) {
+        float v = acc[mt][0][e];
+        if (rdiv) v /= rdiv[row];
+        C[(long)row * p.ldc + col] = v;
+      }
     }
 }
 

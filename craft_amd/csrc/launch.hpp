@@ -21,6 +21,7 @@ struct RowsGemmParams {
   const float* bias;     // per output column, may be null
   float scale;
   int act;
+  const float* row_div; long rd_bs;   // non-null: C row r of batch z is divided by row_div[z * rd_bs + r] (deferred softmax sums)
   int c_frag;            // > 0: C (16-bit) is stored in MFMA B-fragment order per group of c_frag rows (k_pv16's V^T operand)
 };
 
@@ -65,6 +66,7 @@ struct ScoreParams {
   const float* pos_tab; int R; float pos_w;   // sliding bias table [(2R+1)^2] (null: no bias)
   int mask_radius;                    // Chebyshev mask radius (<=0: none)
   const unsigned* clamp_ord;          // ordered-uint global max of the raw scores (null: never clamp)
+  float* rowsum;                      // k_attn_probs: non-null = deferred normalisation, row sums [B][M][N] out
 };
 
 int launch_score_max(const ScoreParams& p, unsigned* max_ord, int prec, hipStream_t s);

@@ -35,14 +35,14 @@ class Attention(nn.Module):
         self.to_qk = nn.Conv2d(dim, heads * dim_head * 2, 1, bias=False)
         self.pos_emb = RelPosEmb(max_pos_size, dim_head)
 
-    def forward_tokens(self, x: torch.Tensor, hw, prec: int) -> torch.Tensor:
+    def forward_tokens(self, x: torch.Tensor, hw, prec: int, defer: bool = False) -> torch.Tensor:
         """x: tokens [B, N, dim] (not normalised) -> P [B, heads, N, ldp]."""
         H8, W8 = hw
         inner = self.heads * self.dim_head
         w = self.to_qk.weight.view(2 * inner, -1)
         q = ops.linear(x, w[:inner], None, prec)
         k = ops.linear(x, w[inner:], None, prec)
-        return ops.attn_probs(q, k, H8, W8, self.heads, self.scale, None, 0.0, -1, None, prec)
+        return ops.attn_probs(q, k, H8, W8, self.heads, self.scale, None, 0.0, -1, None, prec, defer=defer)
 
     def forward(self, fmap: torch.Tensor) -> torch.Tensor:
         B, C, H8, W8 = fmap.shape

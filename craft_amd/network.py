@@ -205,9 +205,9 @@ class CRAFT(nn.Module):
             ops.tokens_slice(cn_tok, 128, 128, act=ACT_RELU, out=hx[..., 128:256])
             if args.use_setrans:
                 xc = ops.tokens_norm(hx[..., 128:256])
-                attention = self.att.forward_tokens(xc, hw, prec=prec)                # [B, 4, N, ldp]
+                attention = self.att.forward_tokens(xc, hw, prec=prec, defer=True)    # [B, 4, N, ldp] (+ row sums)
             else:
-                attention = self.att.forward_tokens(hx[..., 128:256], hw, prec)
+                attention = self.att.forward_tokens(hx[..., 128:256], hw, prec, defer=True)
 
             # ---- correlation volume + pyramid (network.py:196-197, :225-228) ---------------------
             if args.craft:
@@ -246,7 +246,7 @@ class CRAFT(nn.Module):
             parts = []
             for i in range(nstr):
                 b0, b1 = cuts[i], cuts[i + 1]
-                parts.append(dict(b=(b0, b1), hx=hx[b0:b1], corr=corr[b0:b1], flow=flow[b0:b1], att=attention[b0:b1],
+                parts.append(dict(b=(b0, b1), hx=hx[b0:b1], corr=corr[b0:b1], flow=flow[b0:b1], att=ops.probs_slice(attention, b0, b1),
                                   c0=coords0[b0:b1], c1=coords1[b0:b1], mask=mask[b0:b1], fields=gru_fields[b0:b1],
                                   pyr=corr_fn.pyramid.batch_slice(b0, b1), ws=None))
             main = torch.cuda.current_stream()

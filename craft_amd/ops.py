@@ -187,17 +187,31 @@ def corr_lookup(pyr: CorrPyramid, coords: torch.Tensor, radius: int, out: Option
 
 def attn_probs(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale: float, pos_tab: Optional[torch.Tensor],
                pos_w: float, mask_radius: int, clamp_ord: Optional[torch.Tensor], prec: int,
-               out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """P [B, M, N, ldp] (ldp = N rounded up to 32; the tail columns are zero)."""
+               out: Optional[torch.Tensor] = None, defer: bool = False) -> torch.Tensor:
+    """P [B, M, N, ldp] (ldp = N rounded up to 32; the tail columns are zero).  ``defer=True``: P is left un-normalised
+    (exp(logit - rowmax)) and carries its row sums as ``P.craft_rowsum`` [B, M, N]; ``attn_apply`` divides by them.
+    Only for P that goes straight to ``attn_apply`` -- anything handed to a caller is normalised."""
     B, N, C = q.shape
     ldp = round_up(N, 32)
     if out is None:
         out = torch.empty(B, M, N, ldp, device=q.device, dtype=PROB_DTYPE[pick(prec, "pv")])
     R = 0 if pos_tab is None else (pos_tab.shape[0] - 1) // 2
+    rowsum = torch.empty(B, M, N, device=q.device, dtype=torch.float32) if defer else None
     call("craft_attn_probs", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale,
-         None if pos_tab is None else pos_tab.contiguous(), R, pos_w, mask_radius, clamp_ord, out, ldp, pick(prec, "pv"),
+         None if pos_tab is None else pos_tab.contiguous(), R, pos_w, mask_radius, clamp_ord, out, ldp, rowsum, pick(prec, "pv"),
          pick(prec, "score"))
+    if defer:
+        out.craft_rowsum = rowsum
     return out
+
+
+def probs_slice(P: torch.Tensor, b0: int, b1: int) -> torch.Tensor:
+    """Batch slice of an ``attn_probs`` result that keeps the deferred row sums attached."""
+    v = P[b0:b1]
+    rs = getattr(P, "craft_rowsum", None)
+    if rs is not None:
+        v.craft_rowsum = rs[b0:b1]
+    return v
 
 
 def attn_apply(P: torch.Tensor, vT: torch.Tensor, Dv: int, prec: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -210,7 +224,7 @@ def attn_apply(P: torch.Tensor, vT: torch.Tensor, Dv: int, prec: int, out: Optio
         raise hip.CraftHipError(f"attention probabilities are {P.dtype} but the pv precision expects {PROB_DTYPE[pv]}")
     if vT.dtype != P.dtype:
         raise hip.CraftHipError(f"V^T is {vT.dtype} but P is {P.dtype}")
-    call("craft_attn_apply", P, ldp, vT, B, N, M, Dv, out, pv)
+    call("craft_attn_apply", P, ldp, getattr(P, "craft_rowsum", None), vT, B, N, M, Dv, out, pv)
     return out
 
 

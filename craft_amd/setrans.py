@@ -198,7 +198,7 @@ class CrossAttFeatTrans(nn.Module):
         return q, k
 
     def forward(self, query_feat, key_feat=None, pos_biases=None, attention_mask_radius: int = -1, hw=None,
-                prec: Optional[int] = None):
+                prec: Optional[int] = None, defer: bool = False):
         """query_feat/key_feat: LayerNorm-ed tokens; pos_biases: the [2R+1,2R+1] table (not the N x N
         expansion); hw = (H8, W8).  Returns attention probabilities [B, M, N, ldp] (out_attn_probs_only) or
         transformed tokens.  The scores-only variant lives in ``corr.TransCorrBlock`` because its output
@@ -210,8 +210,9 @@ class CrossAttFeatTrans(nn.Module):
         q, k = self.project(query_feat, key_feat, prec)
         scale = 1.0 / math.sqrt(self.attention_mode_dim)
         mx = ops.score_max(q, k, H8, W8, self.num_modes, scale, prec)
+        # P that is consumed right here (or by a caller that asked for it, `defer`) skips the normalisation pass
         P = ops.attn_probs(q, k, H8, W8, self.num_modes, scale, pos_biases, float(self.pos_code_weight),
-                           attention_mask_radius, mx, prec)
+                           attention_mask_radius, mx, prec, defer=defer or not self.out_attn_probs_only)
         if self.out_attn_probs_only:
             return P
         kf = query_feat if key_feat is None else key_feat
@@ -228,9 +229,9 @@ class SelfAttVisPosTrans(nn.Module):
         self.setrans = CrossAttFeatTrans(self.config, name)
         self.vispos_encoder = SETransInputFeatEncoder(self.config)
 
-    def forward_tokens(self, x_tokens_ln: torch.Tensor, hw, prec: Optional[int] = None):
+    def forward_tokens(self, x_tokens_ln: torch.Tensor, hw, prec: Optional[int] = None, defer: bool = False):
         return self.setrans(x_tokens_ln, pos_biases=self.vispos_encoder.pos_coder.biases,
-                            attention_mask_radius=self.attn_mask_radius, hw=hw, prec=prec)
+                            attention_mask_radius=self.attn_mask_radius, hw=hw, prec=prec, defer=defer)
 
     def forward(self, x: torch.Tensor):
         """NCHW in; NCHW out (feature transformer) or [B, M, N, N] probabilities (setrans.py:578-619)."""

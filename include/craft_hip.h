@@ -98,18 +98,22 @@ int craft_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, c
 /* CrossAttFeatTrans up to the softmax (setrans.py:507-557): P[b][m][i][j] = softmax_j(clamp?(Q_m(i).K_m(j)*
  * scale) + pos_w*pb(i,j) + mask), mask = -1e9 where Chebyshev distance > mask_radius (setrans.py:580-584,
  * <=0: none).  P has row stride ldp (multiple of 32, >= N); columns [N, ldp) are written as zeros.
- * Element type of P by p_prec: float (0), bf16 (1), fp16 (2); prec selects the MFMA path of Q K^T. */
+ * Element type of P by p_prec: float (0), bf16 (1), fp16 (2); prec selects the MFMA path of Q K^T.
+ * rowsum = NULL: P is the normalised softmax.  rowsum != NULL ([B][M][N] floats out): DEFERRED normalisation -- P holds
+ * exp(logit - rowmax) in (0, 1] and rowsum the row sums; craft_attn_apply given the same rowsum divides its output rows
+ * by them, which is the same O.  The first pass of the kernel then needs no exponentials (it is VALU-bound). */
 int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d,
                      float scale, const float* pos_tab, int R, float pos_w, int mask_radius,
-                     const unsigned* clamp_ord, void* P, long ldp, int p_prec, int prec, void* stream);
+                     const unsigned* clamp_ord, void* P, long ldp, float* rowsum, int p_prec, int prec, void* stream);
 
 /* ExpandedFeatTrans.forward, matmul part (setrans.py:384): O[b][m][i][:] = sum_j P[b][m][i][j] * V_m[j][:],
  * with vT[b][m*Dv + c][j] (row stride ldp, zero beyond N) from craft_linear_t.  O: [B][M][N][Dv] fp32.
  * prec (0 fp32, 1 bf16, 2 fp16) is the element type of BOTH P (craft_attn_probs with p_prec = prec) and vT
  * (craft_linear_t with out_prec = prec), and the MFMA path.  For prec 1 / 2, vT must be in fragment order
- * (craft_linear_t with frag_rows = Dv) and Dv % 128 == 0; for prec 0 it is plain row-major. */
-int craft_attn_apply(const void* P, long ldp, const void* vT, int B, int N, int M, int Dv, float* O, int prec,
-                     void* stream);
+ * (craft_linear_t with frag_rows = Dv) and Dv % 128 == 0; for prec 0 it is plain row-major.  rowsum: NULL for a
+ * normalised P, else the row sums craft_attn_probs produced with it (O rows are divided by them). */
+int craft_attn_apply(const void* P, long ldp, const float* rowsum, const void* vT, int B, int N, int M, int Dv, float* O,
+                     int prec, void* stream);
 
 /* ExpandedFeatTrans.forward tail (setrans.py:395-407): a_m = softmax_m(<O_m, w_agg>), out = LayerNorm(
  * skip_coeff * x + sum_m a_m O_m).  C = Dv in {64,128,192,256}. */

@@ -219,6 +219,13 @@ def test_attn_probs(device, prec, C, M, mask_radius, gain):
     else:
         # logits carry the operand rounding (|S| up to ~|x||y| 2^-8), probabilities are <= 1
         close(got, ref, 0.0, 0.08 if prec == PREC_BF16 else 0.02, f"attention probs prec={prec}")
+    # deferred normalisation: exp(logit - rowmax) in (0, 1] plus row sums; P' / rowsum is the same softmax
+    Pd = ops.attn_probs(q, k, H8, W8, M, scale, tab.to(device), 1.0, mask_radius, mx, prec, defer=True)
+    rs = Pd.craft_rowsum
+    assert rs.shape == (B, M, N) and float(Pd.float().max()) <= 1.0 and float(Pd[..., :N].float().amax(-1).min()) > 0.99
+    store_tol = 1e-6 if Pd.dtype == torch.float32 else (8e-3 if Pd.dtype == torch.bfloat16 else 1e-3)
+    close(Pd[..., :N].float() / rs[..., None], got, store_tol, store_tol, "deferred vs normalised probabilities")
+    assert float(Pd[..., N:].float().abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("prec", PRECS)
@@ -241,10 +248,16 @@ def test_expanded_feat_trans(device, prec, C):
     xd = x.to(device)
     vT = ops.linear_t(xd, Wv.to(device), ldp, prec, Dv=C)
     Od = ops.attn_apply(P.to(device), vT, C, prec)
+    # the same product from un-normalised rows + row sums (deferred softmax normalisation)
+    scl = torch.rand(B, M, N) * 3 + 0.5
+    Pun = (P.float() * scl[..., None]).to(P.dtype).to(device)
+    Pun.craft_rowsum = scl.to(device)
+    Od2 = ops.attn_apply(Pun, vT, C, prec)
     y = ops.mode_pool_ln(Od, xd, w_agg.to(device), skip.to(device))
     rt, at = TOL[prec]
     Oref = torch.matmul(P[..., :N].float(), F.linear(x, Wv).reshape(B, N, M, C).permute(0, 2, 1, 3))
     close(Od, Oref, rt, at, "P.V")
+    close(Od2, Oref, max(rt, 1e-2 if prec != PREC_F32 else rt), max(at, 1e-2 if prec != PREC_F32 else at), "P.V with deferred row sums")
     close(y, ref, rt * 5, at * 5, "ExpandedFeatTrans")
 
 
