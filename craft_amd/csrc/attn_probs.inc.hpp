@@ -119,19 +119,34 @@ __device__ __forceinline__ void mma_rows(const typename PrecT<PREC>::lds_t* Ks, 
   }
 }
 
-// DEFER: the probabilities are stored UN-normalised, P'[i][j] = 2^(t_ij - max_i) in (0, 1], together with the row sums
-// l_i (p.rowsum); the consumer (craft_attn_apply) divides its output rows by l_i.  Pass 1 then only needs the row
-// maxima -- no exponentials -- which removes ~40 % of the VALU work that bounds this kernel.
-template <int PREC, int PT, int D, bool DEFER>
+// MODE 0: classic two-pass softmax of one 128-query tile over all keys -> normalised P.
+// Deferred normalisation (p.rowsum != NULL): P'[i][j] = 2^(t_ij - max_i) in (0, 1] plus the row sums l_i; the consumer
+// (craft_attn_apply) divides its output rows by l_i.  Finding max_i needs no exponentials, and the two steps have no
+// sequential dependency inside a block any more, so they run as two launches over (query tile, batch*mode, KEY CHUNK):
+//   MODE 1: row maxima of the chunk -> atomicMax into p.rowmax (ordered uints),
+//   MODE 2: P' of the chunk -> global, partial row sums -> p.rowsum[2 + chunk] (summed by k_rowsum_reduce).
+// The finer work items matter as much as the saved exponentials: at 448x1024 the classic grid is 896 blocks for 768
+// resident slots (1.17 rounds: the second round runs 17 % full), the chunked grids have thousands of blocks.
+constexpr int ATTN_KC = 8;             // key tiles (of 128 keys) per work item in MODE 1 / 2
+constexpr int ATTN_TABW = 33;          // bias table width: 2 * 15 + 3
+
+template <int PREC, int PT, int D, int MODE>
 __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __restrict__ Pout, long ldp) {
   typedef RowTile<PREC, D> T;
   typedef typename T::lds_t lds_t;
   typedef typename ProbT<PT>::t prob_t;
   constexpr bool kExact = (PREC == CRAFT_PREC_F32);
+  constexpr bool DEFER = MODE != 0;
   __shared__ __attribute__((aligned(16))) lds_t Qs[T::ELEMS];
   __shared__ __attribute__((aligned(16))) lds_t Ks[T::ELEMS];
   __shared__ int s_kh[128], s_kw[128];
-  __shared__ float s_tab[961];
+  __shared__ float s_tab[ATTN_TABW * ATTN_TABW];
+  // 16-bit P: each wave transposes its 32-query x 128-key tile through LDS so that the global stores are whole
+  // 256-byte row segments.  In the accumulator layout a store instruction touches 32 rows x 16 bytes, and the
+  // kernel that writes P is bound by exactly that request stream (1.6 GB of P went out at 1.8 TB/s).
+  constexpr int PLD = 128 + 8;
+  constexpr bool kStage = MODE != 1 && PT != CRAFT_PREC_F32 && (2 * T::ELEMS * (int)sizeof(lds_t) + 4 * 32 * PLD * 2 <= 150 * 1024);
+  __shared__ __attribute__((aligned(16))) uint16_t Pst[kStage ? 4 * 32 * PLD : 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * 128, z = blockIdx.y;
   const int b = z / p.M, m = z - b * p.M;
@@ -141,13 +156,27 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
   const int rh4 = 4 * (lane >> 5);
   const bool clamp = p.clamp_ord != nullptr && ord2f(*p.clamp_ord) > CRAFT_ATTN_CLIP;
   const int nkt = (N + 127) / 128;
+  const int kt0 = MODE == 0 ? 0 : blockIdx.z * ATTN_KC, kt1 = MODE == 0 ? nkt : min(nkt, kt0 + ATTN_KC);
+  const int ntile = kt1 - kt0;
   const int q_hmin = n0 / W8, q_hmax = min(n0 + 127, N - 1) / W8;
   // Everything runs in the base-2 log domain: the query tile is pre-multiplied by scale*log2(e) when it is staged
-  // (once per block), the positional table by pos_w*log2(e), so a logit costs no multiply and the softmax uses
-  // v_exp_f32 (2^x) directly.  P = 2^(t - max) / sum is the same number as exp(s - max) / sum.
+  // (once per block), so a logit costs no multiply and the softmax uses v_exp_f32 (2^x) directly.
+  // Positional bias and Chebyshev mask come from ONE table over (dh, dw) in [-Re-1, Re+1]^2, Re = max(R, mask_radius):
+  // bias * pos_w * log2(e) inside the bias window, -1e9 outside the mask radius, and a border ring that stands for
+  // "anything farther" (0, or -1e9 with a mask).  Per element: two unsigned clamps, one mad, one LDS read, one add.
   constexpr float LOG2E = 1.4426950408889634f;
-  if (p.pos_tab) { const int TT = (2 * R + 1) * (2 * R + 1); for (int i = tid; i < TT; i += NTHREADS) s_tab[i] = p.pos_tab[i] * (p.pos_w * LOG2E); }
-  const float clip2 = CRAFT_ATTN_CLIP * LOG2E;
+  const int mr = p.mask_radius > 0 ? p.mask_radius : 0;
+  const int Re = max(p.pos_tab ? R : 0, mr), TW = 2 * Re + 3;
+  for (int i = tid; i < TW * TW; i += NTHREADS) {
+    const int dh = i / TW - Re - 1, dw = i - (i / TW) * TW - Re - 1;
+    float v = 0.f;
+    if (p.pos_tab && abs(dh) <= R && abs(dw) <= R) v = p.pos_tab[(dh + R) * (2 * R + 1) + dw + R] * (p.pos_w * LOG2E);
+    if (mr > 0 && max(abs(dh), abs(dw)) > mr) v += -1e9f;
+    s_tab[i] = v;
+  }
+  const float clipv = clamp ? CRAFT_ATTN_CLIP * LOG2E : 3.0e38f;
+  const int ch = Re + 1 - h1, cw = Re + 1 - w1;       // (unsigned)(kh + ch) = dh + Re + 1, clamped to [0, 2Re+2]
+  const unsigned umax = 2 * Re + 2;
 
   const float* qbase = p.Q + (long)b * p.q_bs + (long)m * D;
   const float* kbase = p.Kf + (long)b * p.k_bs + (long)m * D;
@@ -156,17 +185,19 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
   float4 rk[T::NPASS];
   T::fetch(rk, qbase, p.ldq, n0, N, tid);
   T::store(Qs, rk, tid, p.scale * LOG2E);
-  T::fetch(rk, kbase, p.ldk, 0, N, tid);
+  T::fetch(rk, kbase, p.ldk, kt0 * 128, N, tid);
   T::store(Ks, rk, tid);
-  if (tid < 128) { s_kh[tid] = tid / W8; s_kw[tid] = tid - (tid / W8) * W8; }
+  if (tid < 128) { const int j = kt0 * 128 + tid; s_kh[tid] = j / W8; s_kw[tid] = j - (j / W8) * W8; }
   __syncthreads();
 
-  float m_run = -INFINITY, l_run = 0.f, inv_l = 0.f;
-  const int T2 = 2 * nkt;
+  float m_run = -INFINITY, l_run = 0.f, inv_l = 1.f;
+  if constexpr (MODE == 2) m_run = ord2f(p.rowmax[(long)z * N + min(qcol, N - 1)]);
+  const int T2 = MODE == 0 ? 2 * ntile : ntile;
   for (int t = 0; t < T2; ++t) {
-    const bool pass1 = t >= nkt;
-    const int jt = pass1 ? t - nkt : t;
-    const int jn = (t + 1 < T2) ? ((t + 1 >= nkt) ? t + 1 - nkt : t + 1) : 0;   // (after the last tile: a harmless refetch)
+    const bool pass1 = MODE == 2 || (MODE == 0 && t >= ntile);       // true: the tile is written out
+    const int jt = kt0 + ((MODE == 0 && t >= ntile) ? t - ntile : t);
+    const int tn = t + 1 < T2 ? t + 1 : 0;                          // (after the last tile: a harmless refetch)
+    const int jn = kt0 + ((MODE == 0 && tn >= ntile) ? tn - ntile : tn);
     T::fetch(rk, kbase, p.ldk, jn * 128, N, tid);
     __builtin_amdgcn_sched_barrier(0);     // loads stay above the MFMAs + epilogue they are meant to hide behind
 
@@ -178,24 +209,32 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
     mma_rows<PREC, D>(Ks, Qs, wave * 32, lane, acc);
 
     // ---- logits (base-2 domain) of this lane: key row r = mt*32 + 8*(e>>2) + rh4 + (e&3).  ONE uniform branch per
-    // tile selects the full path (clamp / positional window / mask / ragged tail) or the bare fast path.
+    // tile picks the path: bare (no bias window / mask / clamp), table (branch-free), or generic (ragged last tile).
     const int j0 = jt * 128;
     const int k_hmin = j0 / W8, k_hmax = min(j0 + 127, N - 1) / W8;
-    const bool has_bias = p.pos_tab != nullptr && k_hmax >= q_hmin - R && k_hmin <= q_hmax + R;
+    const bool need_tab = clamp || mr > 0 || (p.pos_tab != nullptr && k_hmax >= q_hmin - R && k_hmin <= q_hmax + R);
     const bool ragged = j0 + 128 > N;
     float tmax = -INFINITY;
-    if (has_bias || ragged || clamp || p.mask_radius > 0) {
+    if (ragged) {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int r = mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
-          float s = acc[mt][e];
-          if (clamp) s = fminf(fmaxf(s, -clip2), clip2);
-          const int dh = s_kh[r] - h1, dw = s_kw[r] - w1;
-          if (has_bias && dh >= -R && dh <= R && dw >= -R && dw <= R) s += s_tab[(dh + R) * (2 * R + 1) + dw + R];
-          if (p.mask_radius > 0 && max(abs(dh), abs(dw)) > p.mask_radius) s += -1e9f;
-          if (ragged && j0 + r >= N) s = -INFINITY;
+          const unsigned u = min((unsigned)(s_kh[r] + ch), umax), v = min((unsigned)(s_kw[r] + cw), umax);
+          float s = __builtin_amdgcn_fmed3f(acc[mt][e], -clipv, clipv) + s_tab[u * TW + v];
+          if (j0 + r >= N) s = -INFINITY;
+          acc[mt][e] = s;
+          tmax = fmaxf(tmax, s);
+        }
+    } else if (need_tab) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
+          const unsigned u = min((unsigned)(s_kh[r] + ch), umax), v = min((unsigned)(s_kw[r] + cw), umax);
+          const float s = __builtin_amdgcn_fmed3f(acc[mt][e], -clipv, clipv) + s_tab[u * TW + v];
           acc[mt][e] = s;
           tmax = fmaxf(tmax, s);
         }
@@ -207,7 +246,6 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
     }
     if (!pass1 && DEFER) {
       m_run = fmaxf(m_run, tmax);
-      if (t == nkt - 1) { m_run = fmaxf(m_run, __shfl_xor(m_run, 32)); inv_l = 1.f; l_run = 0.f; }
     } else if (!pass1) {
       const float m_new = fmaxf(m_run, tmax);
       if (m_new > -INFINITY) {
@@ -219,13 +257,39 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
         l_run = l_run * ((m_run > -INFINITY) ? exp2f(m_run - m_new) : 0.f) + add;
         m_run = m_new;
       }
-      if (t == nkt - 1) {   // merge the two half-waves (same query, disjoint keys)
+      if (t == ntile - 1) {   // merge the two half-waves (same query, disjoint keys)
         const float m_o = __shfl_xor(m_run, 32), l_o = __shfl_xor(l_run, 32);
         const float m_f = fmaxf(m_run, m_o);
         const float la_ = (m_run > -INFINITY) ? l_run * exp2f(m_run - m_f) : 0.f;
         const float lo_ = (m_o > -INFINITY) ? l_o * exp2f(m_o - m_f) : 0.f;
         m_run = m_f;
         inv_l = 1.f / (la_ + lo_);
+      }
+    } else if constexpr (kStage) {
+      uint16_t* Tw = &Pst[wave * 32 * PLD];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          typedef prob_t pt4 __attribute__((ext_vector_type(4)));
+          pt4 h;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float ex = __builtin_amdgcn_exp2f(acc[mt][4 * q + i] - m_run);
+            if constexpr (DEFER) { h[i] = (prob_t)ex; l_run += ex; } else h[i] = (prob_t)(ex * inv_l);
+          }
+          *reinterpret_cast<pt4*>(&Tw[(lane & 31) * PLD + mt * 32 + 8 * q + rh4]) = h;
+        }
+      // rows of the staged tile -> global: lane = (row within a group of 4, 16-byte chunk of the 256-byte segment)
+      const int ch16 = lane & 15, rsub = lane >> 4;
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      prob_t* Pw = reinterpret_cast<prob_t*>(Pout) + ((long)z * N + n0 + wave * 32) * ldp + j0 + ch16 * 8;
+      const bool jok = j0 + ch16 * 8 < ldp;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + rsub;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&Tw[row * PLD + ch16 * 8]);
+        if (jok && n0 + wave * 32 + row < N) *reinterpret_cast<u32x4*>(Pw + (long)row * ldp) = v;
       }
     } else if (qcol < N) {
 #pragma unroll
@@ -258,20 +322,47 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
     if (tid < 128) { const int j = jn * 128 + tid; s_kh[tid] = j / W8; s_kw[tid] = j - (j / W8) * W8; }
     __syncthreads();
   }
-  if constexpr (DEFER) {
-    const float l = l_run + __shfl_xor(l_run, 32);      // the two half-waves hold disjoint keys of the same query
-    if (lane < 32 && qcol < N) p.rowsum[(long)z * N + qcol] = l;
+  if constexpr (MODE == 1) {
+    const float mm = fmaxf(m_run, __shfl_xor(m_run, 32));       // the two half-waves hold disjoint keys of the same query
+    if (lane < 32 && qcol < N) atomicMax(&p.rowmax[(long)z * N + qcol], f2ord(mm));
+  }
+  if constexpr (MODE == 2) {
+    // per-chunk partial sums, added up in a fixed order by k_rowsum_reduce: run-to-run deterministic (no float atomics)
+    const float l = l_run + __shfl_xor(l_run, 32);
+    if (lane < 32 && qcol < N) p.rowsum[((long)(2 + blockIdx.z) * gridDim.y + z) * N + qcol] = l;
   }
 }
 
+// row sums = sum over key chunks of the partial sums (fixed order)
+static __global__ void k_rowsum_reduce(float* __restrict__ rs, long n, int nchunk) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int c = 0; c < nchunk; ++c) a += rs[(2 + c) * n + i];
+  rs[i] = a;
+}
+
 template <int PREC, int D> static int launch_pt(const ScoreParams& p, void* P, long ldp, int p_prec, dim3 grid, hipStream_t s) {
-#define GO(PTV) do { if (p.rowsum) hipLaunchKernelGGL((k_attn_probs<PREC, PTV, D, true>), grid, dim3(NTHREADS), 0, s, p, P, ldp); \
-                     else hipLaunchKernelGGL((k_attn_probs<PREC, PTV, D, false>), grid, dim3(NTHREADS), 0, s, p, P, ldp); } while (0)
-  if (p_prec == CRAFT_PREC_F32) GO(CRAFT_PREC_F32);
-  else if (p_prec == CRAFT_PREC_BF16) GO(CRAFT_PREC_BF16);
-  else if (p_prec == CRAFT_PREC_F16) GO(CRAFT_PREC_F16);
+  if (p.rowsum) {       // deferred normalisation: maxima, then P' + row sums, both over key chunks
+    const int nkt = (p.N + 127) / 128;
+    dim3 g3(grid.x, grid.y, (nkt + ATTN_KC - 1) / ATTN_KC);
+    const long bmn = (long)p.B * p.M * p.N;
+    hipError_t me = hipMemsetAsync(p.rowmax, 0, sizeof(unsigned) * (size_t)bmn, s);     // ordered-uint maxima: 0 < everything
+    if (me != hipSuccess) return (int)me;
+#define GO2(PTV) do { hipLaunchKernelGGL((k_attn_probs<PREC, PTV, D, 1>), g3, dim3(NTHREADS), 0, s, p, P, ldp); \
+                      hipLaunchKernelGGL((k_attn_probs<PREC, PTV, D, 2>), g3, dim3(NTHREADS), 0, s, p, P, ldp); } while (0)
+    if (p_prec == CRAFT_PREC_F32) GO2(CRAFT_PREC_F32);
+    else if (p_prec == CRAFT_PREC_BF16) GO2(CRAFT_PREC_BF16);
+    else if (p_prec == CRAFT_PREC_F16) GO2(CRAFT_PREC_F16);
+    else return CRAFT_ERR_ARG;
+#undef GO2
+    hipLaunchKernelGGL(k_rowsum_reduce, dim3((unsigned)((bmn + 255) / 256)), dim3(256), 0, s, p.rowsum, bmn, (int)g3.z);
+    return (int)hipGetLastError();
+  }
+  if (p_prec == CRAFT_PREC_F32) hipLaunchKernelGGL((k_attn_probs<PREC, CRAFT_PREC_F32, D, 0>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
+  else if (p_prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_attn_probs<PREC, CRAFT_PREC_BF16, D, 0>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
+  else if (p_prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_attn_probs<PREC, CRAFT_PREC_F16, D, 0>), grid, dim3(NTHREADS), 0, s, p, P, ldp);
   else return CRAFT_ERR_ARG;
-#undef GO
   return (int)hipGetLastError();
 }
 

@@ -104,6 +104,8 @@ int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, 
                      long ldp, float* rowsum, int p_prec, int prec, void* stream) {
   ScoreParams sp = make_score(q, ldq, k, ldk, B, H8, W8, M, d, scale, pos_tab, R, pos_w, mask_radius, clamp_ord);
   sp.rowsum = rowsum;
+  sp.rowmax = rowsum ? reinterpret_cast<unsigned*>(rowsum + (long)B * M * H8 * W8) : nullptr;
+  if (mask_radius > 15 || (pos_tab && R > 15)) return CRAFT_ERR_UNSUPPORTED;
   return launch_attn_probs(sp, P, ldp, p_prec, prec, S(stream));
 }
 

@@ -66,7 +66,8 @@ struct ScoreParams {
   const float* pos_tab; int R; float pos_w;   // sliding bias table [(2R+1)^2] (null: no bias)
   int mask_radius;                    // Chebyshev mask radius (<=0: none)
   const unsigned* clamp_ord;          // ordered-uint global max of the raw scores (null: never clamp)
-  float* rowsum;                      // k_attn_probs: non-null = deferred normalisation, row sums [B][M][N] out
+  float* rowsum;                      // k_attn_probs: non-null = deferred normalisation, row sums [B][M][N] out ...
+  unsigned* rowmax;                   // ... followed by [B][M][N] ordered-uint row maxima (scratch): rowsum + B*M*N
 };
 
 int launch_score_max(const ScoreParams& p, unsigned* max_ord, int prec, hipStream_t s);

@@ -196,12 +196,13 @@ def attn_probs(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale
     if out is None:
         out = torch.empty(B, M, N, ldp, device=q.device, dtype=PROB_DTYPE[pick(prec, "pv")])
     R = 0 if pos_tab is None else (pos_tab.shape[0] - 1) // 2
-    rowsum = torch.empty(B, M, N, device=q.device, dtype=torch.float32) if defer else None
+    # row sums | scratch: row maxima, per-key-chunk partial sums (CRAFT_ATTN_CHUNK_KEYS = 1024)
+    rowsum = torch.empty(2 + (N + 1023) // 1024, B, M, N, device=q.device, dtype=torch.float32) if defer else None
     call("craft_attn_probs", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale,
          None if pos_tab is None else pos_tab.contiguous(), R, pos_w, mask_radius, clamp_ord, out, ldp, rowsum, pick(prec, "pv"),
          pick(prec, "score"))
     if defer:
-        out.craft_rowsum = rowsum
+        out.craft_rowsum = rowsum[0]
     return out
 
 

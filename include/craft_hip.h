@@ -99,7 +99,8 @@ int craft_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, c
  * scale) + pos_w*pb(i,j) + mask), mask = -1e9 where Chebyshev distance > mask_radius (setrans.py:580-584,
  * <=0: none).  P has row stride ldp (multiple of 32, >= N); columns [N, ldp) are written as zeros.
  * Element type of P by p_prec: float (0), bf16 (1), fp16 (2); prec selects the MFMA path of Q K^T.
- * rowsum = NULL: P is the normalised softmax.  rowsum != NULL ([B][M][N] floats out): DEFERRED normalisation -- P holds
+ * rowsum = NULL: P is the normalised softmax.  rowsum != NULL ((2 + ceil(N / CRAFT_ATTN_CHUNK_KEYS)) * B*M*N floats:
+ * [B][M][N] row sums out, then scratch for the row maxima and the per-key-chunk partial sums): DEFERRED normalisation -- P holds
  * exp(logit - rowmax) in (0, 1] and rowsum the row sums; craft_attn_apply given the same rowsum divides its output rows
  * by them, which is the same O.  The first pass of the kernel then needs no exponentials (it is VALU-bound). */
 int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d,
@@ -133,6 +134,7 @@ int craft_gma_residual(const float* mf, long ldm, const float* O, const float* g
  * fetches the B operand of each 32x32x16 MFMA with one coalesced 1 KiB load and the K loop runs without per-tile barriers. */
 #define CRAFT_W_PACKED 0x100
 #define CRAFT_STATS_REPLICAS 64
+#define CRAFT_ATTN_CHUNK_KEYS 1024
 int craft_pack_weights(const float* w, int rows, int K, int prec, void* out, void* stream);
 
 /* nn.Conv2d (stride 1, "same" zero padding KH/2, KW/2) + bias + optional ReLU on tokens: x [B*H*W][cin] (row

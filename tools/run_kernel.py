@@ -53,14 +53,16 @@ def main():
         enc = m._henc_f if which == "fnet" else m._henc_c
         for _ in range(2):
             enc.forward_tokens(raw, prec)
-    elif which == "probs":
+    elif which in ("probs", "probs_norm"):
         import math
         C, Mm = 128, 4
         q = torch.randn(B, N, C, device=dev)
         k = torch.randn(B, N, C, device=dev)
         tab = torch.randn(15, 15, device=dev)
         for _ in range(2):
-            ops.attn_probs(q, k, H8, W8, Mm, 1 / math.sqrt(C // Mm), tab, 1.0, -1, None, prec)
+            ops.attn_probs(q, k, H8, W8, Mm, 1 / math.sqrt(C // Mm), tab, 1.0, -1, None, prec, defer=which == "probs")
+    elif which == "probsn":
+        pass
     torch.cuda.synchronize()
 
 
