@@ -10,11 +10,12 @@ batch with no data-path collective (weak scaling), the timed region is bracketed
 synchronize and the max over ranks is reported.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      the dominant hand-written kernel, k_conv_halo (the SepConvGRU z|r convolution shape), timed live
-                with HIP events on the launch stream: algorithmic flops / time against the dense MFMA peak.
-  roofline_pv   the second kernel by time, k_pv16 (attention apply O = P.V of the motion aggregator): algorithmic
-                bytes = the attention probabilities it must stream (B*M*N*ldp*sizeof(P)) + V^T + O, against the
-                8 TB/s HBM peak (MI355X_MICROARCH.md).
+  roofline      the dominant kernel by time, k_pv16 (attention apply O = P.V of the motion aggregator, ~19 % of a
+                forward), timed live with HIP events on the launch stream: algorithmic bytes = the attention
+                probabilities it must stream (B*M*N*ldp*sizeof(P)) + V^T + O, against the 8 TB/s HBM peak
+                (MI355X_MICROARCH.md).
+  roofline_conv the conv engine on its largest K loop, k_conv_halo_wf (SepConvGRU z|r convolution of a refinement
+                step): algorithmic flops / time against the dense MFMA peak.
   cpu_baseline  the CPU oracle (oracle/craft_oracle.py, fp32 torch-CPU restatement of the reference's
                 forward) timed on this box's host cores on ONE 448x1024 pair, 12 iterations.
 """
@@ -99,21 +100,24 @@ def roofline_pv(model, B, H8, W8, prec, reps=20):
     ms = s.elapsed_time(e) / reps
     bytes_alg = P.numel() * P.element_size() + vT.numel() * vT.element_size() + O.numel() * 4
     ach = bytes_alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "k_gemm_rows (attention apply O = P.V, aggregator shape)", "achieved": round(ach, 1),
-            "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
-            "bytes_per_launch": bytes_alg, "ms_per_launch": round(ms, 4)}
+    return {"bound": "hbm", "kernel": "k_pv16 (attention apply O = P.V of the motion aggregator, 13 launches per forward)",
+            "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+            "bytes_per_launch": bytes_alg, "ms_per_launch": round(ms, 4),
+            "note": "algorithmic bytes = P (fp16, read once) + V^T + O; measured read-only ceiling of this access pattern on "
+                    "the same chip: 6.1 TB/s (tools/ubench/hbm_rows.hip); PMC traffic: profiles/"}
 
 
 def roofline_conv(B, H8, W8, prec, reps=20):
-    """Time the GRU's z|r convolution alone (1x5, 512 -> 256 channels: the largest K loop of the update block,
-    k_conv_halo) with HIP events; algorithmic flops = 2 * pixels * Cout * KH*KW*Cin."""
+    """Time the GRU's z|r convolution alone (1x5, 384 -> 256 channels -- [h | motion | aggregated] after the context
+    hoist: the largest K loop of the update block, k_conv_halo_wf) with HIP events; algorithmic flops = 2 * pixels *
+    Cout * KH*KW*Cin."""
     from craft_amd import ops
     from craft_amd.hip import PREC_F32, pick
     cp = pick(prec, "conv")
     dev = torch.device("cuda")
     N = H8 * W8
-    x = torch.randn(B, N, 512, device=dev)
-    w = torch.randn(256, 512, 1, 5, device=dev) * 0.02
+    x = torch.randn(B, N, 384, device=dev)
+    w = torch.randn(256, 384, 1, 5, device=dev) * 0.02
     bias = torch.zeros(256, device=dev)
     wp = ops.pack_conv_prec(w, cp)
     y = torch.empty(B, N, 256, device=dev)
@@ -127,10 +131,10 @@ def roofline_conv(B, H8, W8, prec, reps=20):
     e.record()
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / reps
-    flops = 2.0 * B * N * 256 * 5 * 512
+    flops = 2.0 * B * N * 256 * 5 * 384
     ach = flops / (ms * 1e-3) / 1e12
     peak = 157.3 if cp == PREC_F32 else 2500.0
-    return {"bound": "mfma", "kernel": "k_conv_halo (SepConvGRU z|r conv, 1x5, 512->256)", "achieved": round(ach, 1), "peak": peak,
+    return {"bound": "mfma", "kernel": "k_conv_halo_wf (SepConvGRU z|r conv, 1x5, 384->256, 24 launches per forward)", "achieved": round(ach, 1), "peak": peak,
             "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "flops_per_launch": flops,
             "ms_per_launch": round(ms, 4),
             "note": "algorithmic (fp32-equivalent) flops; the f16x3 scheme executes 3 fp16 MFMAs per product, so the "
@@ -205,8 +209,8 @@ def main():
         }
         if a.ops:
             op_table(model, im1, im2, a.iters)
-        line["roofline"] = roofline_conv(a.batch, a.height // 8, a.width // 8, prec)
-        line["roofline_pv"] = roofline_pv(model, a.batch, a.height // 8, a.width // 8, prec)
+        line["roofline"] = roofline_pv(model, a.batch, a.height // 8, a.width // 8, prec)
+        line["roofline_conv"] = roofline_conv(a.batch, a.height // 8, a.width // 8, prec)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.height, a.width, a.iters, a.cpu_threads)
         print(json.dumps(line), flush=True)

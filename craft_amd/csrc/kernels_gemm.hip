@@ -194,7 +194,7 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
       const int row = m0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
       if (row < p.M) {
         float v = acc[mt][0][e];
-        if (rdiv) v /= rdiv[row];
+        if (rdiv) v *= __builtin_amdgcn_rcpf(rdiv[row]);      // (16-bit P: a 1-ulp reciprocal is far below its rounding)
         C[(long)row * p.ldc + col] = v;
       }
     }
