@@ -321,6 +321,11 @@ int craft_pack_weights(const float* w, int rows, int K, int prec, void* out, voi
   return launch_pack_weights(w, rows, K, PREC_OF(prec), out, S(stream));
 }
 
+int craft_flow_metrics(const float* pred, const float* gt, const float* valid, int B, int H, int W, float gt_off_x,
+                       float gt_off_y, double* out16, void* stream) {
+  return launch_flow_metrics(pred, gt, valid, B, H, W, gt_off_x, gt_off_y, out16, S(stream));
+}
+
 int craft_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, void* stream) {
   return launch_convex_upsample(mask, flow, B, H8, W8, up, S(stream));
 }

@@ -683,4 +683,53 @@ int launch_tokens_to_nchw(const float* src, long ld, int B, int C, int HW, float
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Evaluation metrics of the harness (evaluate.py:529, :578-598, :833-841, :911): per valid pixel
+//   epe = |pred - gt|_2, mag = |gt + gt_offset|_2;  out[16] (doubles, += : zero them first):
+//   [0] sum epe  [1] #valid  [2..4] #(epe < 1, 3, 5)  [5] #(epe > 3 and epe / mag > 0.05)   (KITTI Fl outliers)
+//   [6..10] sum epe by magnitude bin [0,1) [1,10) [10,20) [20,30) [30,inf)   [11..15] pixel counts of the bins
+// pred / gt NCHW [B][2][H][W]; valid [B][H][W] (>= 0.5 counts) or null (all pixels).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flow_metrics(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                      const float* __restrict__ valid, long hw, long tot, float offx, float offy,
+                                                      double* __restrict__ out) {
+  __shared__ double s_acc[4][16];
+  float a[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a[i] = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    if (valid && valid[i] < 0.5f) continue;
+    const long b = i / hw, p = i - b * hw;
+    const float gx = gt[(2 * b) * hw + p], gy = gt[(2 * b + 1) * hw + p];
+    const float dx = pred[(2 * b) * hw + p] - gx, dy = pred[(2 * b + 1) * hw + p] - gy;
+    const float epe = sqrtf(dx * dx + dy * dy);
+    const float mx = gx + offx, my = gy + offy;
+    const float mag = sqrtf(mx * mx + my * my);
+    a[0] += epe; a[1] += 1.f;
+    a[2] += epe < 1.f; a[3] += epe < 3.f; a[4] += epe < 5.f;
+    a[5] += (epe > 3.f && epe / mag > 0.05f);
+    const int bin = mag < 1.f ? 0 : mag < 10.f ? 1 : mag < 20.f ? 2 : mag < 30.f ? 3 : 4;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { a[6 + k] += bin == k ? epe : 0.f; a[11 + k] += bin == k; }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float v = wave_sum(a[i]);
+    if (lane == 0) s_acc[wave][i] = (double)v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) atomicAdd(&out[threadIdx.x], s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]);
+}
+int launch_flow_metrics(const float* pred, const float* gt, const float* valid, int B, int H, int W, float offx, float offy,
+                        double* out, hipStream_t s) {
+  const long hw = (long)H * W, tot = hw * B;
+  if (tot <= 0) return 0;
+  // <= 4096 pixels per thread keeps the fp32 per-thread partial sums exact enough (counts exact below 2^24)
+  const long nb = (tot + 255) / 256;
+  const unsigned blocks = (unsigned)(nb < 4096 ? nb : 4096);
+  hipLaunchKernelGGL(k_flow_metrics, dim3(blocks), dim3(256), 0, s, pred, gt, valid, hw, tot, offx, offy, out);
+  return (int)hipGetLastError();
+}
+
 }  // namespace craft

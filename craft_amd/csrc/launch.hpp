@@ -90,6 +90,8 @@ int launch_convf1(const float* flow, const float* w, const float* bias, int B, i
 int launch_flow_head2(const float* hid, const float* w, const float* bias, int B, int H8, int W8, float* coords1,
                       const float* coords0, float* flow, float* delta, hipStream_t s);
 int launch_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, hipStream_t s);
+int launch_flow_metrics(const float* pred, const float* gt, const float* valid, int B, int H, int W, float offx, float offy,
+                        double* out, hipStream_t s);
 int launch_coords_init(const float* flow_init_nchw, int B, int H8, int W8, float* coords0, float* coords1, float* flow,
                        hipStream_t s);
 int launch_tokens_to_nchw(const float* src, long ld, int B, int C, int HW, float* dst, hipStream_t s);

@@ -212,6 +212,14 @@ int craft_flow_head(const float* h, long ldh, const float* w1, const float* b1, 
 int craft_mask_head(const float* h, long ldh, const float* w0, const float* b0, const float* w2,
                     const float* b2, int B, int H8, int W8, float* mask, float* ws, int prec, void* stream);
 
+/* Evaluation metrics of the harness (evaluate.py:529 EPE, :578-598 1/3/5 px and magnitude bins, :833-841 KITTI Fl
+ * outliers): pred, gt NCHW [B][2][H][W] fp32; valid [B][H][W] (>= 0.5 counts) or NULL; (gt_off_x, gt_off_y) is added to
+ * gt only for the magnitude (the shift experiments, evaluate.py:534).  out16 += { sum epe, #valid, #epe<1, #epe<3,
+ * #epe<5, #(epe>3 && epe/mag>0.05), sum epe per magnitude bin [0,1) [1,10) [10,20) [20,30) [30,inf), counts per bin }
+ * as doubles (zero it first; accumulates over calls). */
+int craft_flow_metrics(const float* pred, const float* gt, const float* valid, int B, int H, int W, float gt_off_x,
+                       float gt_off_y, double* out16, void* stream);
+
 /* CRAFT.upsample_flow (network.py:151-162): mask tokens [B*N][576], flow tokens [B*N][2] -> up NCHW
  * [B][2][8*H8][8*W8]. */
 int craft_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, void* stream);
