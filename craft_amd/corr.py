@@ -33,8 +33,12 @@ class CorrBlock:
         self.pyramid = ops.CorrPyramid(B, H8, W8, num_levels, fmap1.device)
         ops.corr_build(t1, t2, H8, W8, 1, 1.0 / math.sqrt(C), None, 0.0, 1.0, None, self.pyramid, do_corr_global_norm, prec)
 
+    def all_pyramids(self):
+        """[CorrPyramid] -- two of them for the two-way correlation of ``--f1`` (TransCorrBlock)."""
+        return getattr(self, "pyramids", None) or [self.pyramid]
+
     def lookup_tokens(self, coords_tokens: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        return ops.corr_lookup(self.pyramid, coords_tokens, self.radius, out=out)
+        return ops.corr_lookup(self.all_pyramids(), coords_tokens, self.radius, out=out)
 
     def __call__(self, coords: torch.Tensor) -> torch.Tensor:
         """coords NCHW [B, 2, H8, W8] (x, y) -> [B, L*(2r+1)^2, H8, W8]   (corr.py:47-71)."""
@@ -52,10 +56,10 @@ class TransCorrBlock(CorrBlock, nn.Module):
         self.vispos_encoder = SETransInputFeatEncoder(config)
         self.do_corr_global_norm = do_corr_global_norm
         self.pyramid = None
+        self.pyramids = []
         self.shape = None
 
-    def update_tokens(self, x1_ln: torch.Tensor, x2_ln: torch.Tensor, hw, prec: int):
-        """x1_ln / x2_ln: LayerNorm-ed tokens of frame-1 conv features and frame-2 (transformed) features."""
+    def _build(self, x1_ln: torch.Tensor, x2_ln: torch.Tensor, hw, prec: int, slot: int):
         H8, W8 = hw
         B = x1_ln.shape[0]
         st = self.setrans
@@ -63,18 +67,36 @@ class TransCorrBlock(CorrBlock, nn.Module):
         k = ops.linear(x2_ln, st.key.weight, st.key.bias, prec)
         scale = 1.0 / math.sqrt(st.attention_mode_dim)
         mx = ops.score_max(q, k, H8, W8, st.num_modes, scale, prec)
-        if self.pyramid is None or self.shape != (B, H8, W8) or self.pyramid.lv[0].device != q.device:
-            self.pyramid = ops.CorrPyramid(B, H8, W8, self.num_levels, q.device)
-            self.shape = (B, H8, W8)
+        while len(self.pyramids) <= slot:
+            self.pyramids.append(None)
+        pyr = self.pyramids[slot]
+        if pyr is None or (pyr.B, pyr.H8, pyr.W8) != (B, H8, W8) or pyr.lv[0].device != q.device:
+            pyr = self.pyramids[slot] = ops.CorrPyramid(B, H8, W8, self.num_levels, q.device)
         w_aggr = float(st.attn_softaggr.feat2score.weight.item()) if st.num_modes > 1 else 1.0
         ops.corr_build(q, k, H8, W8, st.num_modes, scale, self.vispos_encoder.pos_coder.biases, float(st.pos_code_weight),
-                       w_aggr, mx, self.pyramid, self.do_corr_global_norm, prec)
+                       w_aggr, mx, pyr, self.do_corr_global_norm, prec)
+
+    def update_tokens(self, x1_ln: torch.Tensor, x2_ln: torch.Tensor, hw, prec: int, x1o_ln=None, x2o_ln=None):
+        """x1_ln / x2_ln: LayerNorm-ed tokens of the two frames' features (transformed where a transformer exists).
+        With ``x1o_ln`` / ``x2o_ln`` (the conv features, ``--f1 shared|private``) the correlation is two-way
+        (corr.py:164-171): volume 0 = (transformed 1, conv 2), volume 1 = (conv 1, transformed 2)."""
+        B = x1_ln.shape[0]
+        if x1o_ln is not None and x2o_ln is not None:
+            self._build(x1_ln, x2o_ln, hw, prec, 0)
+            self._build(x1o_ln, x2_ln, hw, prec, 1)
+            del self.pyramids[2:]
+        else:
+            self._build(x1_ln, x2_ln, hw, prec, 0)
+            del self.pyramids[1:]
+        self.pyramid = self.pyramids[0]
+        self.shape = (B, hw[0], hw[1])
 
     def update(self, fmap1, fmap2, fmap1o=None, fmap2o=None, coords1=None, coords2=None):
-        """corr.py:148-189.  Single-way correlation only (fmap1o must be None: ``--f1 none``)."""
-        if fmap1o is not None:
-            raise NotImplementedError("two-way correlation (--f1 shared|private) is outside the HIP path")
+        """corr.py:148-189: single-way, or two-way when both fmap1o and fmap2o (the conv features) are given."""
         B, C, H8, W8 = fmap1.shape
         x1 = ops.tokens_from_nchw(fmap1.float(), ln=True)
         x2 = ops.tokens_from_nchw(fmap2.float(), ln=True)
-        self.update_tokens(x1, x2, (H8, W8), getattr(self, "hip_prec", PREC_F32))
+        two = fmap1o is not None and fmap2o is not None
+        x1o = ops.tokens_from_nchw(fmap1o.float(), ln=True) if two else None
+        x2o = ops.tokens_from_nchw(fmap2o.float(), ln=True) if two else None
+        self.update_tokens(x1, x2, (H8, W8), getattr(self, "hip_prec", PREC_F32), x1o, x2o)

@@ -95,8 +95,9 @@ int craft_corr_finish(const float* pyr0, float* pyr1, float* pyr2, float* pyr3, 
 
 int craft_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3, int levels,
                       const float* mu_rstd, const float* coords, int B, int H8, int W8, int radius, float* out, long ldo,
-                      void* stream) {
-  return launch_corr_lookup(pyr0, pyr1, pyr2, pyr3, levels, mu_rstd, coords, B, H8, W8, radius, out, ldo, S(stream));
+                      int lvl_stride, int col_off, void* stream) {
+  return launch_corr_lookup(pyr0, pyr1, pyr2, pyr3, levels, mu_rstd, coords, B, H8, W8, radius, out, ldo, lvl_stride, col_off,
+                            S(stream));
 }
 
 int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d, float scale,

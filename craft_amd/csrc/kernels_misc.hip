@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ l
                                                      const float* __restrict__ l2, const float* __restrict__ l3, int levels,
                                                      const float* __restrict__ mu_rstd, const float* __restrict__ coords,
                                                      int N, int H8, int W8, int radius, float* __restrict__ out, long ldo,
-                                                     long nq) {
+                                                     int lvl_stride, int col_off, long nq) {
   __shared__ float patch[4][4][LOOKUP_MAXP * LOOKUP_MAXP];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long q0 = (long)blockIdx.x * 4 + wv;
@@ -285,16 +285,20 @@ __global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ l
     const float fx = fxs[l], fy = fys[l];
     const float* P = &patch[wv][l][bb * LOOKUP_MAXP + a];
     const float nw = (1.f - fx) * (1.f - fy), ne = fx * (1.f - fy), sw = (1.f - fx) * fy, se = fx * fy;
-    o[k] = ((P[0] * nw + P[1] * ne) + P[LOOKUP_MAXP] * sw) + P[LOOKUP_MAXP + 1] * se;
+    o[l * lvl_stride + col_off + rem] = ((P[0] * nw + P[1] * ne) + P[LOOKUP_MAXP] * sw) + P[LOOKUP_MAXP + 1] * se;
   }
 }
 
 int launch_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3, int levels, const float* mu_rstd,
-                       const float* coords, int B, int H8, int W8, int radius, float* out, long ldo, hipStream_t s) {
+                       const float* coords, int B, int H8, int W8, int radius, float* out, long ldo, int lvl_stride, int col_off,
+                       hipStream_t s) {
   if (levels < 1 || levels > 4 || radius < 0 || 2 * radius + 2 > LOOKUP_MAXP) return CRAFT_ERR_UNSUPPORTED;
+  const int win2 = (2 * radius + 1) * (2 * radius + 1);
+  if (lvl_stride <= 0) lvl_stride = win2;            // default: one volume, levels back to back
+  if (lvl_stride < win2 || col_off < 0 || col_off + win2 > lvl_stride) return CRAFT_ERR_ARG;
   const long nq = (long)B * H8 * W8;
   hipLaunchKernelGGL(k_corr_lookup, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, l0, l1, l2, l3, levels, mu_rstd, coords,
-                     H8 * W8, H8, W8, radius, out, ldo, nq);
+                     H8 * W8, H8, W8, radius, out, ldo, lvl_stride, col_off, nq);
   return (int)hipGetLastError();
 }
 

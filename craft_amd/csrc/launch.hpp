@@ -84,7 +84,8 @@ int launch_corr_pyramid(const float* l0, float* l1, float* l2, float* l3, long n
 int launch_corr_stats(const double* sums, float* mu_rstd, int B, double count, int do_norm, hipStream_t s);
 int launch_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3, int levels,
                        const float* mu_rstd, const float* coords, int B, int H8, int W8, int radius,
-                       float* out, long ldo, hipStream_t s);
+                       float* out, long ldo, int lvl_stride, int col_off,
+                       hipStream_t s);
 int launch_convf1(const float* flow, const float* w, const float* bias, int B, int H8, int W8, float* out, long ldo,
                   hipStream_t s);
 int launch_flow_head2(const float* hid, const float* w, const float* bias, int B, int H8, int W8, float* coords1,

@@ -61,8 +61,11 @@ class CRAFT(nn.Module):
                               ("intra_pos_code_type", "bias"), ("intra_pos_code_weight", 1.0)):
             if not hasattr(args, name):
                 setattr(args, name, default)
-        if args.f1trans != "none":
-            raise NotImplementedError("--f1 shared|private (two-way correlation) is outside the HIP path")
+        if args.f1trans not in ("none", "shared", "private"):
+            raise ValueError(f"--f1 {args.f1trans!r}: expected none | shared | private (network.py:94-103)")
+        if args.f1trans != "none" and not args.craft:
+            raise NotImplementedError("--f1 needs the cross-attention correlation (--craft): with the plain CorrBlock the "
+                                      "reference builds a 324-plane volume for a 648-plane motion encoder and fails")
         if args.f2trans == "none":
             # the reference itself raises AttributeError here (corr_multiplier is never set)
             raise NotImplementedError("--f2 none is not supported (the reference crashes on it as well)")
@@ -98,8 +101,15 @@ class CRAFT(nn.Module):
         cfg.pos_code_weight = args.f2_pos_code_weight
         self.f2_trans_config = args.f2_trans_config = cfg
         self.f2_trans = SelfAttVisPosTrans(cfg, "F2 transformer")
-        self.f1_trans = None
-        args.corr_multiplier = 1
+        # --f1 (network.py:94-103): frame 1 gets the same ("shared": one module under two names, so the state dict
+        # carries its tensors twice) or its own ("private") transformer, and the correlation becomes two-way
+        if args.f1trans == "shared":
+            self.f1_trans = self.f2_trans
+        elif args.f1trans == "private":
+            self.f1_trans = SelfAttVisPosTrans(cfg, "F1 transformer")
+        else:
+            self.f1_trans = None
+        args.corr_multiplier = 2 if self.f1_trans is not None else 1
 
         if args.use_setrans:
             cfg = SETransConfig()
@@ -213,7 +223,11 @@ class CRAFT(nn.Module):
             if args.craft:
                 x1 = ops.tokens_norm(f1_tok)
                 x2t = ops.tokens_norm(fmap2_t)
-                self.corr_fn.update_tokens(x1, x2t, hw, prec)
+                if self.f1_trans is not None:       # two-way: (transformed 1, conv 2) and (conv 1, transformed 2)
+                    fmap1_t = self.f1_trans.forward_tokens(x1, hw, prec=prec)
+                    self.corr_fn.update_tokens(ops.tokens_norm(fmap1_t), x2t, hw, prec, x1, x2)
+                else:
+                    self.corr_fn.update_tokens(x1, x2t, hw, prec)
                 corr_fn = self.corr_fn
             else:
                 corr_fn = CorrBlock.__new__(CorrBlock)
@@ -227,7 +241,8 @@ class CRAFT(nn.Module):
             # the context features are the same in every iteration: hoist their share of the GRU convolutions
             gru_fields = self.update_block.gru.context_tokens(hx[..., 128:256], hw, prec)
             coords0, coords1, flow = ops.coords_init(flow_init, B, H8, W8, dev)
-            nch = corr_fn.num_levels * (2 * corr_fn.radius + 1) ** 2
+            pyramids = corr_fn.all_pyramids()
+            nch = corr_fn.num_levels * (2 * corr_fn.radius + 1) ** 2 * len(pyramids)
             corr = torch.empty(B, N, nch, device=dev, dtype=torch.float32)
             mask = torch.empty(B, N, 576, device=dev, dtype=torch.float32)
             need_all = test_mode != 1
@@ -248,7 +263,7 @@ class CRAFT(nn.Module):
                 b0, b1 = cuts[i], cuts[i + 1]
                 parts.append(dict(b=(b0, b1), hx=hx[b0:b1], corr=corr[b0:b1], flow=flow[b0:b1], att=ops.probs_slice(attention, b0, b1),
                                   c0=coords0[b0:b1], c1=coords1[b0:b1], mask=mask[b0:b1], fields=gru_fields[b0:b1],
-                                  pyr=corr_fn.pyramid.batch_slice(b0, b1), ws=None))
+                                  pyr=[pv.batch_slice(b0, b1) for pv in pyramids], ws=None))
             main = torch.cuda.current_stream()
             streams = [main] if nstr == 1 else self._streams(nstr, dev)
             if nstr > 1:

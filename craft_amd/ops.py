@@ -173,15 +173,21 @@ def corr_build(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale
     return pyr
 
 
-def corr_lookup(pyr: CorrPyramid, coords: torch.Tensor, radius: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """coords tokens [B, N, 2] -> tokens [B, N, levels*(2r+1)^2]."""
+def corr_lookup(pyr, coords: torch.Tensor, radius: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """coords tokens [B, N, 2] -> tokens [B, N, V*levels*(2r+1)^2].  ``pyr`` is one CorrPyramid or, for the two-way
+    correlation of ``--f1`` (corr.py:164-171), a list of V of them: level l then holds [volume 0 | volume 1 | ...]."""
+    pyrs = list(pyr) if isinstance(pyr, (list, tuple)) else [pyr]
     B, N, _ = coords.shape
-    nch = pyr.levels * (2 * radius + 1) ** 2
+    win2 = (2 * radius + 1) ** 2
+    V = len(pyrs)
+    nch = pyrs[0].levels * win2 * V
     if out is None:
         out = torch.empty(B, N, nch, device=coords.device, dtype=torch.float32)
-    lv = pyr.lv + [None] * (4 - len(pyr.lv))
-    call("craft_corr_lookup", lv[0], lv[1], lv[2], lv[3], pyr.levels, pyr.mu_rstd, coords.contiguous(), B, pyr.H8, pyr.W8,
-         radius, out, _ld(out))
+    co = coords.contiguous()
+    for v, pv in enumerate(pyrs):
+        lv = pv.lv + [None] * (4 - len(pv.lv))
+        call("craft_corr_lookup", lv[0], lv[1], lv[2], lv[3], pv.levels, pv.mu_rstd, co, B, pv.H8, pv.W8,
+             radius, out, _ld(out), win2 * V, win2 * v)
     return out
 
 

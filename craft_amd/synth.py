@@ -82,7 +82,14 @@ def _fill(key: str, shape, dtype, seed: int, qk_gain: float) -> torch.Tensor:
 def synth_state_dict(template, seed: int = 1234, qk_gain: float = 2.5) -> "OrderedDict[str, torch.Tensor]":
     """Fill ``template`` (a ``state_dict()``-like mapping name -> tensor) deterministically."""
     out = OrderedDict()
-    for k, v in template.items():
+    owner = {}          # storage -> first key that owns it: modules registered under two names (``--f1 shared`` makes
+    for k, v in template.items():      # f1_trans the SAME module as f2_trans, network.py:94-98) get identical values
+        ident = (v.data_ptr(), tuple(v.shape)) if isinstance(v, torch.Tensor) and v.numel() > 0 else None
+        if ident is not None and ident in owner and k.startswith("f1_trans."):
+            out[k] = out[owner[ident]].clone()
+            continue
+        if ident is not None:
+            owner[ident] = k
         out[k] = _fill(k, v.shape, v.dtype, seed, qk_gain)
     # tied inter-frame projection: corr_fn.setrans.key is the same Parameter as .query (setrans.py:475-478)
     for k in list(out.keys()):

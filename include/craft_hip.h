@@ -89,11 +89,13 @@ int craft_corr_build(const float* q, long ldq, const float* k, long ldk, int B, 
 int craft_corr_finish(const float* pyr0, float* pyr1, float* pyr2, float* pyr3, const double* sums,
                       float* mu_rstd, int B, int H8, int W8, int do_norm, void* stream);
 
-/* CorrBlock.__call__ + bilinear_sampler (corr.py:47-71, utils.py:65-79): out[q][l*(2r+1)^2 + a*(2r+1) + b] =
- * bilinear_zero_pad(LN(pyr_l)[q], x/2^l + a - r, y/2^l + b - r), q = b*N + n, coords tokens (x,y). */
+/* CorrBlock.__call__ + bilinear_sampler (corr.py:47-71, utils.py:65-79): out[q][l*lvl_stride + col_off + a*(2r+1) + b] =
+ * bilinear_zero_pad(LN(pyr_l)[q], x/2^l + a - r, y/2^l + b - r), q = b*N + n, coords tokens (x,y).  lvl_stride = 0 means
+ * (2r+1)^2 (one volume).  The two-way correlation of --f1 (corr.py:164-171: two volumes concatenated on the channel axis
+ * of every level) is two calls with lvl_stride = 2*(2r+1)^2 and col_off = 0 / (2r+1)^2. */
 int craft_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3, int levels,
                       const float* mu_rstd, const float* coords, int B, int H8, int W8, int radius,
-                      float* out, long ldo, void* stream);
+                      float* out, long ldo, int lvl_stride, int col_off, void* stream);
 
 /* CrossAttFeatTrans up to the softmax (setrans.py:507-557): P[b][m][i][j] = softmax_j(clamp?(Q_m(i).K_m(j)*
  * scale) + pos_w*pb(i,j) + mask), mask = -1e9 where Chebyshev distance > mask_radius (setrans.py:580-584,

@@ -233,6 +233,15 @@ def corr_lookup(pyr: List[Tensor], coords: Tensor, radius: int,
     return torch.cat(out, dim=-1).permute(0, 3, 1, 2).contiguous()
 
 
+def corr_lookup2(pyrs: List[List[Tensor]], coords: Tensor, radius: int, mus, rstds) -> Tensor:
+    """Lookup on the two-way volume (corr.py:164-171: the two correlations are concatenated on the channel axis of every
+    pyramid level, so each level contributes [volume 0 window | volume 1 window]).  -> [B, L*2*(2r+1)^2, H8, W8]"""
+    B, _, H8, W8 = coords.shape
+    win2 = (2 * radius + 1) ** 2
+    parts = [corr_lookup(p, coords, radius, m, s).reshape(B, len(p), win2, H8, W8) for p, m, s in zip(pyrs, mus, rstds)]
+    return torch.stack(parts, dim=2).reshape(B, -1, H8, W8)
+
+
 # ------------------------------------------------------------------------------------------------
 # ExpandedFeatTrans (setrans.py:364-410) and the two self-attentions built on it
 # ------------------------------------------------------------------------------------------------
@@ -421,29 +430,37 @@ def hot_path(fmap1: Tensor, fmap2: Tensor, net: Tensor, inp: Tensor, sd, cfg: Or
     """Everything in CRAFT.forward after the CNN encoders: fmap1/fmap2 are fnet outputs, net/inp the
     tanh/relu halves of cnet's output (network.py:185-267)."""
     B, C, H8, W8 = fmap1.shape
-    if cfg.craft and cfg.f1trans != "none":
-        raise NotImplementedError("two-way correlation (--f1) is outside the canonical configuration")
     fmap2t = f2_transform(fmap2, sd, cfg) if cfg.f2trans != "none" else fmap2
+    two_way = cfg.craft and cfg.f1trans != "none"
+    # --f1 shared|private (network.py:94-103, :180-183): frame 1 goes through its own (or the shared) transformer and
+    # the correlation becomes two-way: (transformed 1, conv 2) and (conv 1, transformed 2), concatenated (corr.py:164-171)
+    fmap1t = f2_transform(fmap1, sd, cfg, prefix="f1_trans") if two_way else None
     if cfg.use_setrans:
         attention = intra_attention(inp, sd, cfg)
     else:
         attention = gma_attention(inp, sd, cfg.num_heads)
-    if cfg.craft:
+    if two_way:
+        c = [inter_corr_raw(fmap1t, fmap2, sd, cfg), inter_corr_raw(fmap1, fmap2t, sd, cfg)]
+        stats = [global_stats(ci) for ci in c]
+        mu, rstd = [st[0] for st in stats], [st[1] for st in stats]
+        pyr = [build_pyramid(ci, H8, W8, cfg.corr_levels) for ci in c]
+    elif cfg.craft:
         c = inter_corr_raw(fmap1, fmap2t, sd, cfg)
         mu, rstd = global_stats(c)
+        pyr = build_pyramid(c, H8, W8, cfg.corr_levels)
     else:
         c = plain_corr_raw(fmap1, fmap2t)
         mu, rstd = None, None
-    pyr = build_pyramid(c, H8, W8, cfg.corr_levels)
+        pyr = build_pyramid(c, H8, W8, cfg.corr_levels)
     coords0 = coords_grid(B, H8, W8)
     coords1 = coords0.clone()
     if flow_init is not None:
         coords1 = coords1 + flow_init
     if capture is not None:
-        capture.update(fmap2t=fmap2t, attention=attention, corr_raw=c, mu=mu, rstd=rstd)
+        capture.update(fmap2t=fmap2t, fmap1t=fmap1t, attention=attention, corr_raw=c, mu=mu, rstd=rstd)
     preds = []
     for it in range(iters):
-        corr = corr_lookup(pyr, coords1, cfg.corr_radius, mu, rstd)
+        corr = corr_lookup2(pyr, coords1, cfg.corr_radius, mu, rstd) if two_way else corr_lookup(pyr, coords1, cfg.corr_radius, mu, rstd)
         flow = coords1 - coords0
         net, mask, dflow = update_block(net, inp, corr, flow, attention, sd, cfg)
         coords1 = coords1 + dflow

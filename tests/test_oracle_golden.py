@@ -21,7 +21,8 @@ def oracle_inputs(g: Golden):
     args = default_args(**m["over"])
     model = CRAFT(args)
     sd = synth_state_dict(model.state_dict(), seed=m["seed"], qk_gain=m["qk_gain"])
-    cfg = O.OracleConfig(craft=args.craft, use_setrans=args.use_setrans, f2_attn_mask_radius=args.f2_attn_mask_radius)
+    cfg = O.OracleConfig(craft=args.craft, use_setrans=args.use_setrans, f2_attn_mask_radius=args.f2_attn_mask_radius,
+                         f1trans=args.f1trans)
     return sd, cfg
 
 
@@ -67,17 +68,26 @@ def test_oracle_pyramid_and_lookup(case):
     flow_lo, _ = O.craft_forward(sd, cfg, im1, im2, iters=g.meta["iters"], flow_init=g.flow_init(), test_mode=2, capture=cap)
     B, _, H8, W8 = cap["fmap1"].shape
     c = cap["corr_raw"]
-    pyr = O.build_pyramid(c, H8, W8, 4)
     mu, rstd = cap["mu"], cap["rstd"]
     N = H8 * W8
-    for l, p in enumerate(pyr):
-        pn = p if mu is None else (p - mu.repeat_interleave(N)[:, None, None, None]) * rstd.repeat_interleave(N)[:, None, None, None]
-        g.check(f"pyr{l}", pn, RTOL, 5e-5)
     c0 = O.coords_grid(B, H8, W8)
-    g.check("look_id", O.corr_lookup(pyr, c0, 4, mu, rstd), RTOL, 1e-4)
-    g.check("look_fin", O.corr_lookup(pyr, c0 + flow_lo, 4, mu, rstd), 1e-3, 2e-3)
     wild = torch.from_numpy(g.z["wild_coords"])
-    g.check("look_wild", O.corr_lookup(pyr, wild, 4, mu, rstd), RTOL, 2e-4)
+    if isinstance(c, list):          # two-way volume (--f1): the reference keeps both as 2 channels of every level
+        pyrs = [O.build_pyramid(ci, H8, W8, 4) for ci in c]
+        for l in range(4):
+            pn = [(p[l] - m.repeat_interleave(N)[:, None, None, None]) * s.repeat_interleave(N)[:, None, None, None]
+                  for p, m, s in zip(pyrs, mu, rstd)]
+            g.check(f"pyr{l}", torch.cat(pn, dim=1), RTOL, 5e-5)
+        look = lambda co: O.corr_lookup2(pyrs, co, 4, mu, rstd)
+    else:
+        pyr = O.build_pyramid(c, H8, W8, 4)
+        for l, p in enumerate(pyr):
+            pn = p if mu is None else (p - mu.repeat_interleave(N)[:, None, None, None]) * rstd.repeat_interleave(N)[:, None, None, None]
+            g.check(f"pyr{l}", pn, RTOL, 5e-5)
+        look = lambda co: O.corr_lookup(pyr, co, 4, mu, rstd)
+    g.check("look_id", look(c0), RTOL, 1e-4)
+    g.check("look_fin", look(c0 + flow_lo), 1e-3, 2e-3)
+    g.check("look_wild", look(wild), RTOL, 2e-4)
 
 
 def test_oracle_clamp_case_actually_clamps():
