@@ -127,6 +127,91 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build(ScoreParams p, float w_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// correlation build, M = 4 modes (the released configuration): every mode keeps its own accumulator tile, so the
+// K loop carries no per-mode fold and the softmax-over-modes pooling c = sum_m s_m softmax_m(w s_m) is computed once
+// per element from the four scores (max, 4 x exp2, one reciprocal: ~28 VALU per element instead of 4 x 12 for
+// the online form plus its state).  The positional bias comes from a clamped (dh, dw) table with a zero border.
+// ---------------------------------------------------------------------------------------------
+template <int PREC>
+__global__ __launch_bounds__(NTHREADS) void k_corr_build4(ScoreParams p, float w_aggr, float* __restrict__ pyr0,
+                                                         double* __restrict__ sums) {
+  constexpr int BM = 128, BN = 64, WM = 2, WN = 2, MT = 2, NT = 1;
+  constexpr bool kExact = (PREC == CRAFT_PREC_F32);
+  __shared__ int s_rh[BM], s_rw[BM];
+  __shared__ float s_tab[33 * 33];
+  __shared__ float s_red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, b = blockIdx.z;
+  const int N = p.N, d = p.d;
+  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+  const int c_lane = lane & 31, rh4 = 4 * (lane >> 5);
+  const int col = n0 + wn0 + c_lane;
+  const bool clamp = p.clamp_ord != nullptr && ord2f(*p.clamp_ord) > CRAFT_ATTN_CLIP;
+  const int R = p.pos_tab ? p.R : 0, TW = 2 * R + 3;
+  if (tid < BM) { const int r = m0 + tid; s_rh[tid] = r / p.W8; s_rw[tid] = r - (r / p.W8) * p.W8; }
+  for (int i = tid; i < TW * TW; i += NTHREADS) {
+    const int dh = i / TW - R - 1, dw = i - (i / TW) * TW - R - 1;
+    s_tab[i] = (p.pos_tab && abs(dh) <= R && abs(dw) <= R) ? p.pos_w * p.pos_tab[(dh + R) * (2 * R + 1) + dw + R] : 0.f;
+  }
+  f32x16 acc[4][MT][NT];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    acc_zero(acc[m]);
+    LoaderRowsF32<BM> la;
+    la.init(p.Q + (long)b * p.q_bs + m * d, p.ldq, m0, N, d, tid);
+    LoaderRowsF32<BN> lb;
+    lb.init(p.Kf + (long)b * p.k_bs + m * d, p.ldk, n0, N, d, tid);
+    gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, d / BK, acc[m], NoFold());     // ends with a barrier
+  }
+  const float clipv = clamp ? CRAFT_ATTN_CLIP : 3.0e38f;
+  const float wl = kExact ? w_aggr : w_aggr * 1.4426950408889634f;
+  const int h2 = col / p.W8, w2 = col - h2 * p.W8;
+  const int ch = R + 1 + h2, cw = R + 1 + w2;           // (unsigned)(ch - rh) = dh + R + 1, clamped to [0, 2R+2]
+  const unsigned umax = 2 * R + 2;
+  float s1 = 0.f, s2 = 0.f;
+  float* out = pyr0 + (long)b * N * N;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rl = wm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
+      const int row = m0 + rl;
+      float sv[4], tv[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        sv[m] = __builtin_amdgcn_fmed3f(acc[m][mt][0][e] * p.scale, -clipv, clipv);
+        tv[m] = wl * sv[m];
+      }
+      const float mx = fmaxf(fmaxf(tv[0], tv[1]), fmaxf(tv[2], tv[3]));
+      float den = 0.f, num = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float ex = kExact ? expf(tv[m] - mx) : __builtin_amdgcn_exp2f(tv[m] - mx);
+        den += ex;
+        num += sv[m] * ex;
+      }
+      float c = kExact ? num / den : num * __builtin_amdgcn_rcpf(den);
+      const unsigned u = min((unsigned)(ch - s_rh[rl]), umax), v = min((unsigned)(cw - s_rw[rl]), umax);
+      c += s_tab[u * TW + v];
+      if (row < N && col < N) {
+        out[(long)row * N + col] = c;
+        s1 += c;
+        s2 += c * c;
+      }
+    }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) { s_red[wave] = s1; s_red[4 + wave] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    const double a = (double)s_red[0] + (double)s_red[1] + (double)s_red[2] + (double)s_red[3];
+    const double q = (double)s_red[4] + (double)s_red[5] + (double)s_red[6] + (double)s_red[7];
+    atomicAdd(&sums[2 * b], a);
+    atomicAdd(&sums[2 * b + 1], q);
+  }
+}
+
 static int check_score(const ScoreParams& p) {
   if (p.d % BK || p.M < 1 || (p.ldq & 3) || (p.ldk & 3) || (p.q_bs & 3) || (p.k_bs & 3)) return CRAFT_ERR_ALIGN;
   if (p.pos_tab && p.R > 15) return CRAFT_ERR_UNSUPPORTED;
@@ -181,6 +266,14 @@ int launch_corr_build(const ScoreParams& p, float w_aggr, float* pyr0, double* s
   dim3 grid((p.N + 127) / 128, (p.N + 63) / 64, p.B);
   hipError_t me = hipMemsetAsync(sums, 0, sizeof(double) * 2 * p.B, s);
   if (me != hipSuccess) return (int)me;
+  if (p.M == 4) {
+    if (prec == CRAFT_PREC_F32) hipLaunchKernelGGL((k_corr_build4<CRAFT_PREC_F32>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums);
+    else if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_corr_build4<CRAFT_PREC_BF16>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums);
+    else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_corr_build4<CRAFT_PREC_F16>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums);
+    else if (prec == CRAFT_PREC_F16X3) hipLaunchKernelGGL((k_corr_build4<CRAFT_PREC_F16X3>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums);
+    else return CRAFT_ERR_ARG;
+    return (int)hipGetLastError();
+  }
   if (prec == CRAFT_PREC_F32) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_F32, false>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums, nullptr);
   else if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_BF16, false>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums, nullptr);
   else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_F16, false>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums, nullptr);

@@ -74,12 +74,14 @@ class Precision:
     proj  : nn.Linear projections (Q, K, V)            score : Q K^T (correlation build, attention logits)
     pv    : attention apply O = P V (also the storage type of the probabilities P)
     conv  : update-block convolutions (motion encoder, SepConvGRU, flow / mask heads)
+    enc   : the two CNN encoders' convolutions (defaults to ``conv`` when not given)
     Spec strings: "fp32" | "bf16" | "fp16" (all roles) or e.g. "score=bf16,pv=fp16,conv=fp32,proj=fp32"
     (unnamed roles default to fp32)."""
-    __slots__ = ("proj", "score", "pv", "conv")
+    __slots__ = ("proj", "score", "pv", "conv", "enc")
 
-    def __init__(self, proj=PREC_F32, score=PREC_F32, pv=PREC_F32, conv=PREC_F32):
+    def __init__(self, proj=PREC_F32, score=PREC_F32, pv=PREC_F32, conv=PREC_F32, enc=None):
         self.proj, self.score, self.pv, self.conv = proj, score, pv, conv
+        self.enc = conv if enc is None else enc
 
     @staticmethod
     def parse(spec) -> "Precision":
@@ -92,11 +94,15 @@ class Precision:
             v = PREC_NAMES[spec]
             return Precision(v, v, PREC_F16 if v == PREC_F16X3 else v, v)
         p = Precision()
+        seen = set()
         for item in spec.split(","):
             k, v = item.split("=")
             if k.strip() not in Precision.__slots__:
                 raise ValueError(f"unknown precision role {k!r}")
             setattr(p, k.strip(), PREC_NAMES[v.strip()])
+            seen.add(k.strip())
+        if "enc" not in seen:
+            p.enc = p.conv
         if p.pv == PREC_F16X3:
             raise ValueError("pv (the storage type of the attention probabilities) must be fp32, bf16 or fp16")
         return p

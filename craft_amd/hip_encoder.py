@@ -115,7 +115,7 @@ class HipEncoder:
         stem) -> tokens [B, (H/8)*(W/8), output_dim]."""
         enc = self.enc
         B, _, H, W = raw.shape
-        cp = pick(prec, "conv")
+        cp = pick(prec, "enc")
         if not self.supported(H, W):
             return ops.tokens_from_nchw(enc((2 * (raw / 255.0) - 1.0).contiguous()).float())
         packs = self._get_packs(cp)

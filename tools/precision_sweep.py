@@ -12,7 +12,8 @@ import torch  # noqa: E402
 from craft_amd import CRAFT, default_args  # noqa: E402
 from craft_amd.synth import synth_pair, synth_state_dict  # noqa: E402
 
-POLICIES = ["fp32", "mixed", "mixed_fp32conv", "f16x3", "conv=f16x3", "proj=f16x3,score=f16x3", "fp16", "bf16",
+POLICIES = ["fp32", "mixed", "proj=f16x3,score=f16x3,pv=fp16,conv=fp16,enc=f16x3", "proj=f16x3,score=f16x3,pv=fp16,conv=bf16,enc=f16x3",
+            "proj=f16x3,score=f16x3,pv=fp16,conv=f16x3,enc=fp16", "mixed_fp32conv", "f16x3", "conv=f16x3", "proj=f16x3,score=f16x3", "fp16", "bf16",
             "score=fp16,pv=fp16", "score=bf16,pv=bf16", "score=bf16,pv=fp16",
             "proj=fp16,score=fp16,pv=fp16", "conv=fp16", "conv=bf16",
             "score=fp16,pv=fp16,conv=fp16", "pv=fp16", "score=fp16", "proj=fp16"]
