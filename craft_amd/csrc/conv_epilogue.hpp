@@ -6,6 +6,19 @@
 
 namespace craft {
 
+// 16-bit MFMA operand fragment (8 values per lane) and the 32x32x16 MFMA of a precision code
+template <int PREC> struct FragT;
+template <> struct FragT<CRAFT_PREC_BF16> { typedef bf16x8 t; };
+template <> struct FragT<CRAFT_PREC_F16> { typedef f16x8 t; };
+template <> struct FragT<CRAFT_PREC_F16X3> { typedef f16x8 t; };
+
+template <int PREC>
+__device__ __forceinline__ f32x16 mfma16(typename FragT<PREC>::t a, typename FragT<PREC>::t b, f32x16 c) {
+  if constexpr (PREC == CRAFT_PREC_BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+
 // sigmoid / tanh.  FAST: v_exp_f32 + v_rcp_f32 (1 ulp each, saturating correctly at +-inf) for the 16-bit / split
 // MFMA modes; the exact fp32 mode keeps the libm-grade expf / tanhf so that it stays comparable to the oracle
 // at fp32 round-off.

@@ -20,17 +20,6 @@ namespace craft {
 
 constexpr int WF_PATCH_H = 8, WF_PATCH_W = 16;
 
-template <int PREC> struct FragT;
-template <> struct FragT<CRAFT_PREC_BF16> { typedef bf16x8 t; };
-template <> struct FragT<CRAFT_PREC_F16> { typedef f16x8 t; };
-template <> struct FragT<CRAFT_PREC_F16X3> { typedef f16x8 t; };
-
-template <int PREC>
-__device__ __forceinline__ f32x16 mfma16(typename FragT<PREC>::t a, typename FragT<PREC>::t b, f32x16 c) {
-  if constexpr (PREC == CRAFT_PREC_BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
 template <int PREC, int WM, int WN, bool ENC>
 __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   typedef typename PrecT<PREC>::lds_t lds_t;
@@ -251,6 +240,7 @@ template <int PREC, int WM, int WN> static int launch_wf_t(const ConvGemmParams&
 
 // packed (fragment-order) weights only; called by launch_conv_halo
 int launch_conv_halo_wf(const ConvGemmParams& p, int prec, hipStream_t s) {
+  if (conv3x3_c64_applies(p) && !getenv("CRAFT_NO_C64")) return launch_conv3x3_c64(p, prec, s);     // encoder layer1 shape
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   // BN = 128 only when that still leaves >= 2 blocks per CU's worth of tiles for wide outputs
   int bn = (ncols % 128 == 0 && ncols >= 256) ? 128 : 64;

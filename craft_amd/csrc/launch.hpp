@@ -49,6 +49,8 @@ int launch_pv16(const RowsGemmParams& p, int prec, hipStream_t s);   // A and B 
 int launch_gemm_conv(const ConvGemmParams& p, int prec, hipStream_t s);
 int launch_conv_halo(const ConvGemmParams& p, int prec, hipStream_t s);
 int launch_conv_halo_wf(const ConvGemmParams& p, int prec, hipStream_t s);
+bool conv3x3_c64_applies(const ConvGemmParams& p);
+int launch_conv3x3_c64(const ConvGemmParams& p, int prec, hipStream_t s);
 int launch_pack_weights(const float* w, int rows, int K, int prec, void* out, hipStream_t s);
 int launch_stem7x7(const float* img, const float* w, const float* bias, int act, int B, int H, int W, float* out, double* stats,
                    hipStream_t s);
