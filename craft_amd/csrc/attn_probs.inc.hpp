@@ -178,6 +178,13 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
   const int ch = Re + 1 - h1, cw = Re + 1 - w1;       // (unsigned)(kh + ch) = dh + Re + 1, clamped to [0, 2Re+2]
   const unsigned umax = 2 * Re + 2;
 
+  // relative-position rows of this lane's query (gma.RelPosEmb): base-2 domain like everything else
+  const bool has_rb = p.rb_h != nullptr;
+  const long qrow = (long)z * N + min(qcol, N - 1);
+  const float* rbh = has_rb ? p.rb_h + qrow * p.ld_rbh + (p.H8 - 1 - h1) : nullptr;      // indexed by the key's row kh
+  const float* rbw = has_rb ? p.rb_wd + qrow * p.ld_rbw + (W8 - 1 - w1) : nullptr;       // indexed by the key's column kw
+  const float rbs = p.rb_w * LOG2E;
+
   const float* qbase = p.Q + (long)b * p.q_bs + (long)m * D;
   const float* kbase = p.Kf + (long)b * p.k_bs + (long)m * D;
   prob_t* Prow = reinterpret_cast<prob_t*>(Pout) + ((long)z * N + qcol) * ldp;
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
     // tile picks the path: bare (no bias window / mask / clamp), table (branch-free), or generic (ragged last tile).
     const int j0 = jt * 128;
     const int k_hmin = j0 / W8, k_hmax = min(j0 + 127, N - 1) / W8;
-    const bool need_tab = clamp || mr > 0 || (p.pos_tab != nullptr && k_hmax >= q_hmin - R && k_hmin <= q_hmax + R);
+    const bool need_tab = has_rb || clamp || mr > 0 || (p.pos_tab != nullptr && k_hmax >= q_hmin - R && k_hmin <= q_hmax + R);
     const bool ragged = j0 + 128 > N;
     float tmax = -INFINITY;
     if (ragged) {
@@ -223,6 +230,7 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
           const int r = mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
           const unsigned u = min((unsigned)(s_kh[r] + ch), umax), v = min((unsigned)(s_kw[r] + cw), umax);
           float s = __builtin_amdgcn_fmed3f(acc[mt][e], -clipv, clipv) + s_tab[u * TW + v];
+          if (has_rb && j0 + r < N) s += rbs * (rbh[s_kh[r]] + rbw[s_kw[r]]);
           if (j0 + r >= N) s = -INFINITY;
           acc[mt][e] = s;
           tmax = fmaxf(tmax, s);
@@ -234,7 +242,8 @@ __global__ __launch_bounds__(NTHREADS) void k_attn_probs(ScoreParams p, void* __
         for (int e = 0; e < 16; ++e) {
           const int r = mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
           const unsigned u = min((unsigned)(s_kh[r] + ch), umax), v = min((unsigned)(s_kw[r] + cw), umax);
-          const float s = __builtin_amdgcn_fmed3f(acc[mt][e], -clipv, clipv) + s_tab[u * TW + v];
+          float s = __builtin_amdgcn_fmed3f(acc[mt][e], -clipv, clipv) + s_tab[u * TW + v];
+          if (has_rb) s += rbs * (rbh[s_kh[r]] + rbw[s_kw[r]]);
           acc[mt][e] = s;
           tmax = fmaxf(tmax, s);
         }

@@ -101,9 +101,12 @@ int craft_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, c
 }
 
 int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d, float scale,
-                     const float* pos_tab, int R, float pos_w, int mask_radius, const unsigned* clamp_ord, void* P,
+                     const float* pos_tab, int R, float pos_w, int mask_radius, const unsigned* clamp_ord,
+                     const float* relpos_h, const float* relpos_w, float relpos_weight, void* P,
                      long ldp, float* rowsum, int p_prec, int prec, void* stream) {
   ScoreParams sp = make_score(q, ldq, k, ldk, B, H8, W8, M, d, scale, pos_tab, R, pos_w, mask_radius, clamp_ord);
+  if ((relpos_h == nullptr) != (relpos_w == nullptr)) return CRAFT_ERR_ARG;
+  sp.rb_h = relpos_h; sp.rb_wd = relpos_w; sp.ld_rbh = 2 * H8 - 1; sp.ld_rbw = 2 * W8 - 1; sp.rb_w = relpos_weight;
   sp.rowsum = rowsum;
   sp.rowmax = rowsum ? reinterpret_cast<unsigned*>(rowsum + (long)B * M * H8 * W8) : nullptr;
   if (mask_radius > 15 || (pos_tab && R > 15)) return CRAFT_ERR_UNSUPPORTED;

@@ -68,6 +68,9 @@ struct ScoreParams {
   const float* pos_tab; int R; float pos_w;   // sliding bias table [(2R+1)^2] (null: no bias)
   int mask_radius;                    // Chebyshev mask radius (<=0: none)
   const unsigned* clamp_ord;          // ordered-uint global max of the raw scores (null: never clamp)
+  // per-QUERY relative-position scores (gma.RelPosEmb, gma.py:21-50): logit += rb_w * (rb_h[q][kh - qh + H8 - 1] +
+  // rb_w_[q][kw - qw + W8 - 1]), q = (b*M + m)*N + query; null: none
+  const float* rb_h; const float* rb_wd; long ld_rbh, ld_rbw; float rb_w;
   float* rowsum;                      // k_attn_probs: non-null = deferred normalisation, row sums [B][M][N] out ...
   unsigned* rowmax;                   // ... followed by [B][M][N] ordered-uint row maxima (scratch): rowsum + B*M*N
 };

@@ -1,9 +1,8 @@
 """GMA attention / aggregation (the ``use_setrans=False`` variant) on HIP kernels.
 
-Reference: ``core/gma.py`` — ``Attention`` :53-102 (content-only scores softmax(scale*q.k); the
-position_only / position_and_content flags are off by default and not implemented here),
-``Aggregate`` :105-142 (fmap + gamma * attn . to_v(fmap)).  ``RelPosEmb`` parameters are declared
-so checkpoints load, but are unused by the content-only path (exactly as in the reference).
+Reference: ``core/gma.py`` — ``Attention`` :53-102 (softmax of the content scores scale*q.k, of the relative-position
+scores of ``RelPosEmb`` :6-50 -- ``position_only`` -- or of their sum -- ``position_and_content``),
+``Aggregate`` :105-142 (fmap + gamma * attn . to_v(fmap)).
 """
 from __future__ import annotations
 
@@ -28,9 +27,9 @@ class RelPosEmb(nn.Module):
 class Attention(nn.Module):
     def __init__(self, *, args, dim: int, max_pos_size: int = 100, heads: int = 4, dim_head: int = 128):
         super().__init__()
-        if getattr(args, "position_only", False) or getattr(args, "position_and_content", False):
-            raise NotImplementedError("GMA positional scores (gma.py:34-50) are outside the HIP path")
         self.args, self.heads, self.dim_head = args, heads, dim_head
+        self.max_pos_size = max_pos_size
+        self.pos_embed_weight = 1.0
         self.scale = dim_head ** -0.5
         self.to_qk = nn.Conv2d(dim, heads * dim_head * 2, 1, bias=False)
         self.pos_emb = RelPosEmb(max_pos_size, dim_head)
@@ -42,7 +41,23 @@ class Attention(nn.Module):
         w = self.to_qk.weight.view(2 * inner, -1)
         q = ops.linear(x, w[:inner], None, prec)
         k = ops.linear(x, w[inner:], None, prec)
-        return ops.attn_probs(q, k, H8, W8, self.heads, self.scale, None, 0.0, -1, None, prec, defer=defer)
+        pos_only = bool(getattr(self.args, "position_only", False))
+        relpos = None
+        if pos_only or getattr(self.args, "position_and_content", False):
+            # RelPosEmb (gma.py:21-50): (scale*q)(x,y).E_h[u - x] + (scale*q)(x,y).E_w[v - y]: per query a row of 2*H8-1 and
+            # one of 2*W8-1 scores -- two small GEMMs against the embedding rows of the offsets that can occur
+            if max(H8, W8) > self.max_pos_size:
+                raise ValueError(f"feature map {H8}x{W8} exceeds RelPosEmb max_pos_size {self.max_pos_size}")
+            B, N, _ = x.shape
+            P0 = self.max_pos_size - 1
+            Eh = self.pos_emb.rel_height.weight[P0 - (H8 - 1): P0 + H8]
+            Ew = self.pos_emb.rel_width.weight[P0 - (W8 - 1): P0 + W8]
+            qh = q.view(B, N, self.heads, self.dim_head).permute(0, 2, 1, 3).reshape(B * self.heads, N, self.dim_head)
+            Hs = ops.linear(qh, Eh, None, prec).view(B, self.heads, N, 2 * H8 - 1)
+            Ws = ops.linear(qh, Ew, None, prec).view(B, self.heads, N, 2 * W8 - 1)
+            relpos = (Hs, Ws, self.scale * (1.0 if pos_only else self.pos_embed_weight))
+        return ops.attn_probs(q, k, H8, W8, self.heads, 0.0 if pos_only else self.scale, None, 0.0, -1, None, prec, defer=defer,
+                              relpos=relpos)
 
     def forward(self, fmap: torch.Tensor) -> torch.Tensor:
         B, C, H8, W8 = fmap.shape

@@ -193,10 +193,11 @@ def corr_lookup(pyr, coords: torch.Tensor, radius: int, out: Optional[torch.Tens
 
 def attn_probs(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale: float, pos_tab: Optional[torch.Tensor],
                pos_w: float, mask_radius: int, clamp_ord: Optional[torch.Tensor], prec: int,
-               out: Optional[torch.Tensor] = None, defer: bool = False) -> torch.Tensor:
+               out: Optional[torch.Tensor] = None, defer: bool = False, relpos=None) -> torch.Tensor:
     """P [B, M, N, ldp] (ldp = N rounded up to 32; the tail columns are zero).  ``defer=True``: P is left un-normalised
     (exp(logit - rowmax)) and carries its row sums as ``P.craft_rowsum`` [B, M, N]; ``attn_apply`` divides by them.
-    Only for P that goes straight to ``attn_apply`` -- anything handed to a caller is normalised."""
+    Only for P that goes straight to ``attn_apply`` -- anything handed to a caller is normalised.
+    ``relpos = (Hs [B, M, N, 2*H8-1], Ws [B, M, N, 2*W8-1], weight)``: per-query relative-position scores (gma.RelPosEmb)."""
     B, N, C = q.shape
     ldp = round_up(N, 32)
     if out is None:
@@ -204,9 +205,12 @@ def attn_probs(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale
     R = 0 if pos_tab is None else (pos_tab.shape[0] - 1) // 2
     # row sums | scratch: row maxima, per-key-chunk partial sums (CRAFT_ATTN_CHUNK_KEYS = 1024)
     rowsum = torch.empty(2 + (N + 1023) // 1024, B, M, N, device=q.device, dtype=torch.float32) if defer else None
+    rph, rpw, rpwt = (None, None, 0.0) if relpos is None else (relpos[0].contiguous(), relpos[1].contiguous(), float(relpos[2]))
+    if relpos is not None and (tuple(rph.shape) != (B, M, N, 2 * H8 - 1) or tuple(rpw.shape) != (B, M, N, 2 * W8 - 1)):
+        raise hip.CraftHipError("relpos tables must be [B, M, N, 2*H8-1] and [B, M, N, 2*W8-1]")
     call("craft_attn_probs", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale,
-         None if pos_tab is None else pos_tab.contiguous(), R, pos_w, mask_radius, clamp_ord, out, ldp, rowsum, pick(prec, "pv"),
-         pick(prec, "score"))
+         None if pos_tab is None else pos_tab.contiguous(), R, pos_w, mask_radius, clamp_ord, rph, rpw, rpwt, out, ldp, rowsum,
+         pick(prec, "pv"), pick(prec, "score"))
     if defer:
         out.craft_rowsum = rowsum[0]
     return out

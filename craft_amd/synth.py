@@ -41,6 +41,9 @@ def _fill(key: str, shape, dtype, seed: int, qk_gain: float) -> torch.Tensor:
     leaf = key.split(".")[-1]
     if leaf == "num_batches_tracked":
         return torch.zeros(shape, dtype=torch.int64)
+    if leaf == "rel_ind":                     # gma.RelPosEmb index table (a persistent buffer): rel_ind[i, j] = j - i + P - 1
+        P = shape[0]
+        return (torch.arange(P).view(1, -1) - torch.arange(P).view(-1, 1) + P - 1).to(torch.int64)
     if leaf == "running_var":
         return uniform(0.5, 1.5)
     if leaf == "running_mean":

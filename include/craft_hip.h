@@ -101,13 +101,17 @@ int craft_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, c
  * scale) + pos_w*pb(i,j) + mask), mask = -1e9 where Chebyshev distance > mask_radius (setrans.py:580-584,
  * <=0: none).  P has row stride ldp (multiple of 32, >= N); columns [N, ldp) are written as zeros.
  * Element type of P by p_prec: float (0), bf16 (1), fp16 (2); prec selects the MFMA path of Q K^T.
+ * relpos_h [B*M*N][2*H8-1], relpos_w [B*M*N][2*W8-1] (or both NULL): per-query relative-position scores of gma.RelPosEmb
+ * (gma.py:21-50), logit += relpos_weight * (relpos_h[q][kh - qh + H8 - 1] + relpos_w[q][kw - qw + W8 - 1]); they are two
+ * small GEMMs of the query against the embedding rows (craft_linear); scale = 0 gives the position_only variant.
  * rowsum = NULL: P is the normalised softmax.  rowsum != NULL ((2 + ceil(N / CRAFT_ATTN_CHUNK_KEYS)) * B*M*N floats:
  * [B][M][N] row sums out, then scratch for the row maxima and the per-key-chunk partial sums): DEFERRED normalisation -- P holds
  * exp(logit - rowmax) in (0, 1] and rowsum the row sums; craft_attn_apply given the same rowsum divides its output rows
  * by them, which is the same O.  The first pass of the kernel then needs no exponentials (it is VALU-bound). */
 int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d,
                      float scale, const float* pos_tab, int R, float pos_w, int mask_radius,
-                     const unsigned* clamp_ord, void* P, long ldp, float* rowsum, int p_prec, int prec, void* stream);
+                     const unsigned* clamp_ord, const float* relpos_h, const float* relpos_w, float relpos_weight, void* P,
+                     long ldp, float* rowsum, int p_prec, int prec, void* stream);
 
 /* ExpandedFeatTrans.forward, matmul part (setrans.py:384): O[b][m][i][:] = sum_j P[b][m][i][j] * V_m[j][:],
  * with vT[b][m*Dv + c][j] (row stride ldp, zero beyond N) from craft_linear_t.  O: [B][M][N][Dv] fp32.

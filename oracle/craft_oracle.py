@@ -52,6 +52,8 @@ class OracleConfig:
     f2_pos_code_weight: float = 0.5
     f2_attn_mask_radius: int = -1
     num_heads: int = 1
+    position_only: bool = False
+    position_and_content: bool = False
     extra: dict = field(default_factory=dict)
 
 
@@ -293,15 +295,28 @@ def intra_attention(inp_feat: Tensor, sd: Dict[str, Tensor], cfg: OracleConfig) 
                            cfg.intra_num_modes, H8, W8, -1)
 
 
-def gma_attention(inp_feat: Tensor, sd: Dict[str, Tensor], heads: int) -> Tensor:
-    """gma.Attention.forward, content-only (gma.py:78-100): softmax_j(scale * q.k).  [B,heads,N,N]"""
+def gma_attention(inp_feat: Tensor, sd: Dict[str, Tensor], heads: int, position_only: bool = False,
+                  position_and_content: bool = False) -> Tensor:
+    """gma.Attention.forward (gma.py:78-100): softmax_j of the content scores scale*q.k, of the relative-position scores
+    (RelPosEmb, gma.py:21-50: q(x,y).E_h[u-x] + q(x,y).E_w[v-y] with the scaled q), or of their sum.  [B,heads,N,N]"""
     B, C, H8, W8 = inp_feat.shape
     qk = F.conv2d(inp_feat, sd["att.to_qk.weight"])
     q, k = qk.chunk(2, dim=1)
     dh = q.shape[1] // heads
     q = q.reshape(B, heads, dh, H8 * W8).transpose(2, 3) * (dh ** -0.5)
     k = k.reshape(B, heads, dh, H8 * W8).transpose(2, 3)
-    return torch.softmax(torch.matmul(q, k.transpose(-1, -2)), dim=-1)
+    sim = torch.matmul(q, k.transpose(-1, -2))
+    if position_only or position_and_content:
+        Eh, Ew = sd["att.pos_emb.rel_height.weight"], sd["att.pos_emb.rel_width.weight"]
+        P = (Eh.shape[0] + 1) // 2                                        # max_pos_size; rel_ind[i, j] = j - i + P - 1
+        ih = torch.arange(H8)[None, :] - torch.arange(H8)[:, None] + P - 1     # [x, u]
+        iw = torch.arange(W8)[None, :] - torch.arange(W8)[:, None] + P - 1     # [y, v]
+        q5 = q.reshape(B, heads, H8, W8, dh)
+        hs = torch.einsum("bhxyd,xud->bhxyu", q5, Eh[ih])                 # [B,h,H8,W8,H8]
+        ws = torch.einsum("bhxyd,yvd->bhxyv", q5, Ew[iw])                 # [B,h,H8,W8,W8]
+        pos = (hs[..., :, None] + ws[..., None, :]).reshape(B, heads, H8 * W8, H8 * W8)
+        sim = pos if position_only else sim + pos
+    return torch.softmax(sim, dim=-1)
 
 
 def gma_aggregate(attn: Tensor, mf: Tensor, sd: Dict[str, Tensor], heads: int) -> Tensor:
@@ -438,7 +453,7 @@ def hot_path(fmap1: Tensor, fmap2: Tensor, net: Tensor, inp: Tensor, sd, cfg: Or
     if cfg.use_setrans:
         attention = intra_attention(inp, sd, cfg)
     else:
-        attention = gma_attention(inp, sd, cfg.num_heads)
+        attention = gma_attention(inp, sd, cfg.num_heads, cfg.position_only, cfg.position_and_content)
     if two_way:
         c = [inter_corr_raw(fmap1t, fmap2, sd, cfg), inter_corr_raw(fmap1, fmap2t, sd, cfg)]
         stats = [global_stats(ci) for ci in c]

@@ -9,7 +9,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 K_SAMPLE = 4096
 STRIDE = 7919
 CASES = ["canon_128x256_T4", "canon_b2_128x192_T3_init", "clamp_128x160_T2", "gma_128x160_T2", "nocraft_128x160_T2",
-         "f2mask_128x160_T2", "f1shared_128x160_T2", "f1private_b2_128x160_T2"]
+         "f2mask_128x160_T2", "f1shared_128x160_T2", "f1private_b2_128x160_T2", "gmapos_128x160_T2", "gmaposonly_128x160_T2"]
 
 
 def sample_idx(numel: int) -> np.ndarray:

@@ -22,7 +22,8 @@ def oracle_inputs(g: Golden):
     model = CRAFT(args)
     sd = synth_state_dict(model.state_dict(), seed=m["seed"], qk_gain=m["qk_gain"])
     cfg = O.OracleConfig(craft=args.craft, use_setrans=args.use_setrans, f2_attn_mask_radius=args.f2_attn_mask_radius,
-                         f1trans=args.f1trans)
+                         f1trans=args.f1trans, position_only=args.position_only,
+                         position_and_content=args.position_and_content)
     return sd, cfg
 
 
