@@ -326,8 +326,22 @@ int craft_pack_weights(const float* w, int rows, int K, int prec, void* out, voi
 }
 
 int craft_flow_metrics(const float* pred, const float* gt, const float* valid, int B, int H, int W, float gt_off_x,
-                       float gt_off_y, double* out16, void* stream) {
-  return launch_flow_metrics(pred, gt, valid, B, H, W, gt_off_x, gt_off_y, out16, S(stream));
+                       float gt_off_y, float max_gt_mag, double* out16, void* stream) {
+  return launch_flow_metrics(pred, gt, valid, B, H, W, gt_off_x, gt_off_y, max_gt_mag, out16, S(stream));
+}
+
+int craft_flow_l1_loss(const float* pred, const float* gt, const float* valid, int B, int H, int W, float weight, float max_flow,
+                       double* loss, float* grad_pred, void* stream) {
+  return launch_flow_l1(pred, gt, valid, B, H, W, weight, max_flow, loss, grad_pred, S(stream));
+}
+
+int craft_sumsq(const float* x, long n, double* out, void* stream) { return launch_sumsq(x, n, out, S(stream)); }
+
+int craft_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, float grad_mul, const double* grad_sumsq,
+                     float max_norm, void* stream) {
+  return launch_adamw(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_mul, grad_sumsq,
+                      max_norm, S(stream));
 }
 
 int craft_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, void* stream) {

@@ -696,7 +696,7 @@ int launch_tokens_to_nchw(const float* src, long ld, int B, int C, int HW, float
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_flow_metrics(const float* __restrict__ pred, const float* __restrict__ gt,
                                                       const float* __restrict__ valid, long hw, long tot, float offx, float offy,
-                                                      double* __restrict__ out) {
+                                                      float max_mag, double* __restrict__ out) {
   __shared__ double s_acc[4][16];
   float a[16];
 #pragma unroll
@@ -705,6 +705,7 @@ __global__ __launch_bounds__(256) void k_flow_metrics(const float* __restrict__ 
     if (valid && valid[i] < 0.5f) continue;
     const long b = i / hw, p = i - b * hw;
     const float gx = gt[(2 * b) * hw + p], gy = gt[(2 * b + 1) * hw + p];
+    if (max_mag > 0.f && !(sqrtf(gx * gx + gy * gy) < max_mag)) continue;        // train.py:53 (MAX_FLOW)
     const float dx = pred[(2 * b) * hw + p] - gx, dy = pred[(2 * b + 1) * hw + p] - gy;
     const float epe = sqrtf(dx * dx + dy * dy);
     const float mx = gx + offx, my = gy + offy;
@@ -726,13 +727,100 @@ __global__ __launch_bounds__(256) void k_flow_metrics(const float* __restrict__ 
   if (threadIdx.x < 16) atomicAdd(&out[threadIdx.x], s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x]);
 }
 int launch_flow_metrics(const float* pred, const float* gt, const float* valid, int B, int H, int W, float offx, float offy,
-                        double* out, hipStream_t s) {
+                        float max_mag, double* out, hipStream_t s) {
   const long hw = (long)H * W, tot = hw * B;
   if (tot <= 0) return 0;
   // <= 4096 pixels per thread keeps the fp32 per-thread partial sums exact enough (counts exact below 2^24)
   const long nb = (tot + 255) / 256;
   const unsigned blocks = (unsigned)(nb < 4096 ? nb : 4096);
-  hipLaunchKernelGGL(k_flow_metrics, dim3(blocks), dim3(256), 0, s, pred, gt, valid, hw, tot, offx, offy, out);
+  hipLaunchKernelGGL(k_flow_metrics, dim3(blocks), dim3(256), 0, s, pred, gt, valid, hw, tot, offx, offy, max_mag, out);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Training-step pieces around the path.
+// k_flow_l1: one term of sequence_loss (train.py:44-61): loss += weight * sum(valid * |pred - gt|) / (B*2*H*W), valid =
+//   (valid >= 0.5) & (|gt| < max_flow); optional gradient d loss / d pred = weight * valid * sign(pred - gt) / (B*2*H*W).
+// k_sumsq: sum of squares (the global gradient norm of clip_grad_norm_, train.py:234).
+// k_adamw: torch.optim.AdamW (decoupled weight decay) over a flat buffer, with the clip coefficient min(1, max_norm /
+//   (norm + 1e-6)) and the 1/world_size of a summed all-reduce folded in.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flow_l1(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                 const float* __restrict__ valid, long hw, long tot, float weight, float max_flow,
+                                                 double* __restrict__ loss, float* __restrict__ grad) {
+  __shared__ double s_acc[4];
+  const float inv = weight / (float)(2 * tot);
+  float a = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+    const long b = i / hw, p = i - b * hw;
+    const float gx = gt[(2 * b) * hw + p], gy = gt[(2 * b + 1) * hw + p];
+    const bool ok = (valid == nullptr || valid[i] >= 0.5f) && sqrtf(gx * gx + gy * gy) < max_flow;
+    const float dx = pred[(2 * b) * hw + p] - gx, dy = pred[(2 * b + 1) * hw + p] - gy;
+    if (ok) a += fabsf(dx) + fabsf(dy);
+    if (grad) {
+      grad[(2 * b) * hw + p] = ok ? (dx > 0.f ? inv : dx < 0.f ? -inv : 0.f) : 0.f;
+      grad[(2 * b + 1) * hw + p] = ok ? (dy > 0.f ? inv : dy < 0.f ? -inv : 0.f) : 0.f;
+    }
+  }
+  const float v = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6] = (double)v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (s_acc[0] + s_acc[1] + s_acc[2] + s_acc[3]) * (double)weight / (double)(2 * tot));
+}
+int launch_flow_l1(const float* pred, const float* gt, const float* valid, int B, int H, int W, float weight, float max_flow,
+                   double* loss, float* grad, hipStream_t s) {
+  const long hw = (long)H * W, tot = hw * B;
+  if (tot <= 0) return 0;
+  const long nb = (tot + 255) / 256;
+  hipLaunchKernelGGL(k_flow_l1, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, s, pred, gt, valid, hw, tot, weight, max_flow,
+                     loss, grad);
+  return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ x, long n, double* __restrict__ out) {
+  __shared__ double s_acc[4];
+  double a = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { const double v = x[i]; a += v * v; }
+  // wave reduction in double (two 32-bit shuffles per step)
+  for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+  if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, s_acc[0] + s_acc[1] + s_acc[2] + s_acc[3]);
+}
+int launch_sumsq(const float* x, long n, double* out, hipStream_t s) {
+  if (n <= 0) return 0;
+  const long nb = (n + 255) / 256;
+  hipLaunchKernelGGL(k_sumsq, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), 0, s, x, n, out);
+  return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
+                                               float wd, float bc1, float bc2_sqrt, float grad_mul, const double* __restrict__ sumsq,
+                                               float max_norm) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float gm = grad_mul;
+  if (sumsq != nullptr && max_norm > 0.f) {        // clip_grad_norm_: the norm is that of the (already averaged) gradient
+    const float norm = (float)sqrt(*sumsq) * grad_mul;
+    gm *= fminf(1.f, max_norm / (norm + 1e-6f));
+  }
+  const float gi = g[i] * gm;
+  float pi = p[i] * (1.f - lr * wd);
+  const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+  const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = pi - (lr / bc1) * (mi / denom);
+}
+int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
+                 int step, float grad_mul, const double* sumsq, float max_norm, hipStream_t s) {
+  if (n <= 0) return 0;
+  if (step < 1) return CRAFT_ERR_ARG;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(k_adamw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1,
+                     bc2_sqrt, grad_mul, sumsq, max_norm);
   return (int)hipGetLastError();
 }
 

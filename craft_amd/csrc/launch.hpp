@@ -97,7 +97,12 @@ int launch_flow_head2(const float* hid, const float* w, const float* bias, int B
                       const float* coords0, float* flow, float* delta, hipStream_t s);
 int launch_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, hipStream_t s);
 int launch_flow_metrics(const float* pred, const float* gt, const float* valid, int B, int H, int W, float offx, float offy,
-                        double* out, hipStream_t s);
+                        float max_mag, double* out, hipStream_t s);
+int launch_flow_l1(const float* pred, const float* gt, const float* valid, int B, int H, int W, float weight, float max_flow,
+                   double* loss, float* grad, hipStream_t s);
+int launch_sumsq(const float* x, long n, double* out, hipStream_t s);
+int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
+                 int step, float grad_mul, const double* sumsq, float max_norm, hipStream_t s);
 int launch_coords_init(const float* flow_init_nchw, int B, int H8, int W8, float* coords0, float* coords1, float* flow,
                        hipStream_t s);
 int launch_tokens_to_nchw(const float* src, long ld, int B, int C, int HW, float* dst, hipStream_t s);

@@ -28,8 +28,9 @@ MAG_ENDPOINTS = (1, 10, 20, 30, float("inf"))      # evaluate.py:452
 class FlowMetrics:
     """Accumulates the harness metrics over batches on the device (one 16-double table, see craft_hip.h)."""
 
-    def __init__(self, device):
+    def __init__(self, device, max_mag: float = 0.0):
         self.acc = torch.zeros(16, device=device, dtype=torch.float64)
+        self.max_mag = max_mag           # > 0: also drop |gt| >= max_mag (training metrics, train.py:53)
 
     def update(self, flow_pr: torch.Tensor, flow_gt: torch.Tensor, valid: Optional[torch.Tensor] = None, gt_offset=(0.0, 0.0)):
         """flow_pr, flow_gt [B, 2, H, W]; valid [B, H, W] (>= 0.5 counts) or None."""
@@ -37,7 +38,7 @@ class FlowMetrics:
         pr = flow_pr.float().contiguous()
         gt = flow_gt.to(pr.device).float().contiguous()
         va = None if valid is None else valid.to(pr.device).float().contiguous()
-        call("craft_flow_metrics", pr, gt, va, B, H, W, float(gt_offset[0]), float(gt_offset[1]), self.acc)
+        call("craft_flow_metrics", pr, gt, va, B, H, W, float(gt_offset[0]), float(gt_offset[1]), float(self.max_mag), self.acc)
 
     def result(self) -> Dict[str, float]:
         a = self.acc.cpu().numpy()

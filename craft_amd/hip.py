@@ -52,7 +52,10 @@ _SIGS = {
     "craft_stem_conv7x7": [P, P, P, I, I, I, I, P, P, P],
     "craft_stats_finalize": [P, L, c_double, F, P, P],
     "craft_residual_relu": [P, L, P, P, L, P, I, I, I, I, P, L, P],
-    "craft_flow_metrics": [P, P, P, I, I, I, F, F, P, P],
+    "craft_flow_metrics": [P, P, P, I, I, I, F, F, F, P, P],
+    "craft_flow_l1_loss": [P, P, P, I, I, I, F, F, P, P, P],
+    "craft_sumsq": [P, L, P, P],
+    "craft_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, F, P, F, P],
     "craft_convex_upsample": [P, P, I, I, I, P, P],
     "craft_coords_init": [P, I, I, I, P, P, P, P],
 }

@@ -222,9 +222,25 @@ int craft_mask_head(const float* h, long ldh, const float* w0, const float* b0, 
  * outliers): pred, gt NCHW [B][2][H][W] fp32; valid [B][H][W] (>= 0.5 counts) or NULL; (gt_off_x, gt_off_y) is added to
  * gt only for the magnitude (the shift experiments, evaluate.py:534).  out16 += { sum epe, #valid, #epe<1, #epe<3,
  * #epe<5, #(epe>3 && epe/mag>0.05), sum epe per magnitude bin [0,1) [1,10) [10,20) [20,30) [30,inf), counts per bin }
- * as doubles (zero it first; accumulates over calls). */
+ * as doubles (zero it first; accumulates over calls).  max_gt_mag > 0 also drops pixels with |gt| >= max_gt_mag (the
+ * MAX_FLOW rule of the training metrics, train.py:53). */
 int craft_flow_metrics(const float* pred, const float* gt, const float* valid, int B, int H, int W, float gt_off_x,
-                       float gt_off_y, double* out16, void* stream);
+                       float gt_off_y, float max_gt_mag, double* out16, void* stream);
+
+/* ---- training step around the path (the backward kernels of the model itself do not exist yet) ----
+ * craft_flow_l1_loss: one term of sequence_loss (train.py:44-61): *loss += weight * mean(valid * |pred - gt|) over all
+ *   B*2*H*W elements, valid = (valid >= 0.5) & (|gt| < max_flow); grad_pred (or NULL) = d(term)/d(pred).  The caller
+ *   loops over the T predictions with weight = gamma^(T-1-i).
+ * craft_sumsq: *out += sum x^2 (double): the global gradient norm of clip_grad_norm_ (train.py:234).
+ * craft_adamw_step: torch.optim.AdamW semantics (decoupled decay, bias correction with `step` >= 1) over flat buffers:
+ *   g = grad * grad_mul (e.g. 1/world_size after a summed all-reduce), then if grad_sumsq != NULL and max_norm > 0:
+ *   g *= min(1, max_norm / (sqrt(*grad_sumsq) * grad_mul + 1e-6)) -- the clip coefficient, computed on the device. */
+int craft_flow_l1_loss(const float* pred, const float* gt, const float* valid, int B, int H, int W, float weight, float max_flow,
+                       double* loss, float* grad_pred, void* stream);
+int craft_sumsq(const float* x, long n, double* out, void* stream);
+int craft_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, float grad_mul, const double* grad_sumsq,
+                     float max_norm, void* stream);
 
 /* CRAFT.upsample_flow (network.py:151-162): mask tokens [B*N][576], flow tokens [B*N][2] -> up NCHW
  * [B][2][8*H8][8*W8]. */

@@ -1,0 +1,98 @@
+"""Training-step kernels on the GPU: sequence_loss + its gradient vs the reference formula under
+torch autograd, fused AdamW + clip_grad_norm_ vs torch.optim.AdamW, checkpoint save / resume in the reference's layout."""
+import numpy as np
+import pytest
+import torch
+
+from craft_amd import train as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_sequence_loss(flow_preds, flow_gt, valid, gamma, max_flow=400.0):
+    """train.py:44-73 verbatim in behaviour."""
+    n = len(flow_preds)
+    valid = (valid >= 0.5) & ((flow_gt ** 2).sum(dim=1).sqrt() < max_flow)
+    loss = 0.0
+    for i in range(n):
+        loss = loss + gamma ** (n - i - 1) * (valid[:, None] * (flow_preds[i] - flow_gt).abs()).mean()
+    epe = torch.sum((flow_preds[-1] - flow_gt) ** 2, dim=1).sqrt().view(-1)[valid.view(-1)]
+    return loss, {"epe": epe.mean().item(), "1px": (epe < 1).float().mean().item(), "3px": (epe < 3).float().mean().item(),
+                  "5px": (epe < 5).float().mean().item()}
+
+
+def test_sequence_loss_and_gradient(device):
+    g = torch.Generator().manual_seed(3)
+    B, H, W, n = 2, 37, 45, 4
+    gt = torch.randn(B, 2, H, W, generator=g) * 30
+    gt[0, :, :5, :5] = 500.0                                           # beyond MAX_FLOW: excluded
+    valid = (torch.rand(B, H, W, generator=g) > 0.2).float()
+    preds = [(gt + torch.randn(B, 2, H, W, generator=g) * (n - i)).requires_grad_(True) for i in range(n)]
+    ref_loss, ref_m = _ref_sequence_loss(preds, gt, valid, 0.8)
+    ref_loss.backward()
+    loss, m, grads = T.sequence_loss([p.detach().to(device) for p in preds], gt, valid, gamma=0.8, want_grad=True)
+    assert float(loss) == pytest.approx(float(ref_loss.detach()), rel=1e-5)
+    for k in ref_m:
+        assert m[k] == pytest.approx(ref_m[k], rel=1e-5, abs=1e-7), k
+    for gr, p in zip(grads, preds):
+        assert torch.allclose(gr.cpu(), p.grad, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("max_norm", [0.0, 1.0])
+def test_fused_adamw_matches_torch(device, max_norm):
+    torch.manual_seed(1)
+    def make():
+        torch.manual_seed(1)
+        return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.ReLU(), torch.nn.Conv2d(8, 2, 3)).to(device)
+    a, b = make(), make()
+    ref = torch.optim.AdamW(a.parameters(), lr=2e-3, weight_decay=1e-2, eps=1e-8)
+    ours = T.FlatAdamW(b.parameters(), lr=2e-3, weight_decay=1e-2, eps=1e-8)
+    sched = T.OneCycleLR(2e-3, 50, pct_start=0.2)
+    rs = torch.optim.lr_scheduler.OneCycleLR(ref, max_lr=2e-3, total_steps=50, pct_start=0.2, cycle_momentum=False,
+                                             anneal_strategy="linear")
+    x = torch.randn(4, 3, 12, 12, device=device)
+    for it in range(12):
+        ref.zero_grad(); ours.zero_grad()
+        (a(x) ** 2).sum().mul(3.0).backward()
+        (b(x) ** 2).sum().mul(3.0).backward()
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(a.parameters(), max_norm)
+        ref.step(); rs.step()
+        ours.step(lr=sched.get_last_lr()[0], max_norm=max_norm); sched.step()
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert torch.allclose(pa, pb, rtol=2e-5, atol=2e-7), f"iteration {it}"
+    # a gradient summed over 2 ranks and averaged in the update == the single-rank gradient
+    ours2 = T.FlatAdamW(make().parameters(), lr=2e-3, weight_decay=1e-2, eps=1e-8)
+    ours3 = T.FlatAdamW(make().parameters(), lr=2e-3, weight_decay=1e-2, eps=1e-8)
+    gsrc = torch.randn(ours2.numel, device=device)
+    ours2.flat_grad.copy_(gsrc); ours3.flat_grad.copy_(gsrc * 2)
+    ours2.step(max_norm=1.0); ours3.step(max_norm=1.0, grad_mul=0.5)
+    assert torch.allclose(ours2.flat, ours3.flat, rtol=1e-6, atol=1e-8)
+
+
+def test_checkpoint_save_resume(device, tmp_path):
+    from craft_amd import CRAFT, default_args
+    from craft_amd.synth import synth_state_dict
+    m = CRAFT(default_args())
+    m.load_state_dict(synth_state_dict(m.state_dict(), seed=5), strict=True)
+    m = m.to(device)
+    opt, sched = T.fetch_optimizer(m, lr=1.25e-4, wdecay=1e-5, epsilon=1e-8, num_steps=200)
+    assert opt.numel == sum(p.numel() for p in m.parameters())          # one 25 MB buffer
+    opt.flat_grad.normal_()
+    opt.step(lr=sched.get_last_lr()[0], max_norm=1.0); sched.step()
+    path = str(tmp_path / "ck.pth")
+    T.save_checkpoint(path, m, opt, sched, logger={"total_steps": 1})
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck.keys()) == {"model", "optimizer", "lr_scheduler", "logger"} and all(k.startswith("module.") for k in ck["model"])
+    m2 = CRAFT(default_args()).to(device)
+    opt2, sched2 = T.fetch_optimizer(m2, lr=1.25e-4, wdecay=1e-5, epsilon=1e-8, num_steps=200)
+    _, logger = T.load_checkpoint(path, m2, opt2, sched2, load_optimizer_state=True, load_scheduler_state=True)
+    assert logger == {"total_steps": 1} and sched2.last_epoch == 1 and opt2.step_count == 1
+    for (k, v), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k == k2 and torch.equal(v.cpu(), v2.cpu()), k
+    assert torch.equal(opt.exp_avg, opt2.exp_avg)
+    # the resumed model's parameters are still views of its flat buffer: a step moves them
+    w0 = m2.update_block.flow_head.conv2.weight.detach().clone()
+    opt2.flat_grad.fill_(1.0)
+    opt2.step()
+    assert not torch.equal(w0, m2.update_block.flow_head.conv2.weight.detach())

@@ -1,0 +1,91 @@
+"""Host-side pieces of the training step -- CPU: the OneCycle schedule against torch's own
+scheduler, the flat parameter / gradient views, the AdamW state layout, and the one-collective gradient exchange under
+gloo with two ranks."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+import torch
+
+from craft_amd.train import FlatAdamW, OneCycleLR
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("num_steps,lr", [(1000, 4e-4), (120, 1.25e-4)])
+def test_onecycle_matches_torch(num_steps, lr):
+    # exactly what fetch_optimizer builds (train.py:76-85)
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.AdamW([p], lr=lr, weight_decay=1e-5, eps=1e-8)
+    ref = torch.optim.lr_scheduler.OneCycleLR(optimizer=opt, max_lr=lr, total_steps=num_steps + 100, pct_start=0.05,
+                                              cycle_momentum=False, anneal_strategy="linear")
+    ours = OneCycleLR(lr, num_steps + 100, pct_start=0.05)
+    for _ in range(num_steps + 99):
+        assert ours.get_last_lr()[0] == pytest.approx(ref.get_last_lr()[0], rel=1e-12, abs=1e-18)
+        opt.step()
+        ref.step()
+        ours.step()
+    sd = ours.state_dict()
+    again = OneCycleLR(lr, num_steps + 100)
+    again.load_state_dict(sd)
+    assert again.get_last_lr() == ours.get_last_lr()
+
+
+def test_flat_views_and_state_layout():
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Linear(5, 2))
+    before = [p.detach().clone() for p in net.parameters()]
+    opt = FlatAdamW(net.parameters(), lr=1e-3, weight_decay=1e-4, eps=1e-8)
+    assert opt.numel == sum(p.numel() for p in net.parameters())
+    off = 0
+    for p, b in zip(net.parameters(), before):
+        assert torch.equal(p.detach(), b)                                       # values survive the re-pointing
+        assert p.data.data_ptr() == opt.flat[off:].data_ptr()                   # parameters are views of the flat buffer
+        assert p.grad.data_ptr() == opt.flat_grad[off:].data_ptr()              # and so are their gradients
+        off += p.numel()
+    # autograd accumulates straight into the flat gradient buffer
+    net(torch.randn(1, 3, 7, 7)).sum().backward()
+    assert opt.flat_grad.abs().sum() > 0
+    # the optimizer state has torch.optim.AdamW's layout (what the reference's checkpoints store, train.py:139)
+    ref = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=1e-4, eps=1e-8)
+    ref.step()
+    sd, rsd = opt.state_dict(), ref.state_dict()
+    assert set(sd.keys()) == set(rsd.keys()) and sd["param_groups"][0]["params"] == rsd["param_groups"][0]["params"]
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and sd["state"][0]["exp_avg"].shape == before[0].shape
+    opt.load_state_dict(rsd)                                                     # a torch AdamW state loads into ours
+    assert opt.step_count == 1 and torch.equal(opt.state_dict()["state"][1]["exp_avg"], rsd["state"][1]["exp_avg"])
+
+
+WORKER = textwrap.dedent("""
+    import sys
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    from craft_amd.train import FlatAdamW
+    dist.init_process_group("gloo", init_method="env://")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.manual_seed(0)
+    net = torch.nn.Linear(6, 3)
+    opt = FlatAdamW(net.parameters())
+    opt.flat_grad.copy_(torch.arange(opt.numel, dtype=torch.float32) * (rank + 1))
+    mul = opt.allreduce_grads()
+    # ONE collective over the whole flat buffer: sum over ranks, 1/world returned for the update
+    assert mul == 1.0 / world
+    assert torch.equal(opt.flat_grad, torch.arange(opt.numel, dtype=torch.float32) * 3), opt.flat_grad
+    assert torch.equal(net.weight.grad.reshape(-1), opt.flat_grad[:18])
+    dist.barrier()
+    dist.destroy_process_group()
+    print("ok", rank)
+""")
+
+
+def test_gradient_allreduce_two_ranks(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count("ok") == 2
