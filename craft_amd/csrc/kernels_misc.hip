@@ -255,49 +255,26 @@ __global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ l
   const int PS = 2 * radius + 2, win = 2 * radius + 1;
   float fxs[4], fys[4];
   const float* lv[4] = {l0, l1, l2, l3};
-  // All levels' taps are requested BEFORE any of them is consumed (one memory round trip per query instead of one per
-  // level: the kernel is latency-bound), out-of-bounds taps read a clamped address and are zeroed afterwards.
-  constexpr int NLD = (LOOKUP_MAXP * LOOKUP_MAXP + 63) / 64;       // taps per lane and level (PS*PS <= 256)
-  float tv[4][NLD];
-  bool tok[4][NLD];
-  {
-    int h = H8, w = W8;
-    float sc = 1.f;
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-      if (l < levels) {
-        const float X = cx * sc, Y = cy * sc;
-        const float x0f = floorf(X), y0f = floorf(Y);
-        fxs[l] = X - x0f;
-        fys[l] = Y - y0f;
-        // clamp the integer base far outside the image so int conversion can not overflow
-        const int x0 = (int)fminf(fmaxf(x0f, -100000.f), 100000.f) - radius;
-        const int y0 = (int)fminf(fmaxf(y0f, -100000.f), 100000.f) - radius;
-        const float* img = lv[l] + q * (long)h * w;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-          const int idx = lane + 64 * i;
-          const int py = idx / PS, px = idx - py * PS;
-          const int y = y0 + py, x = x0 + px;
-          tok[l][i] = idx < PS * PS && y >= 0 && y < h && x >= 0 && x < w;
-          tv[l][i] = (h > 0 && w > 0) ? img[min(max(y, 0), h - 1) * w + min(max(x, 0), w - 1)] : 0.f;   // (empty level: tiny maps)
-        }
-      }
-      h >>= 1; w >>= 1; sc *= 0.5f;
+  int h = H8, w = W8;
+  float sc = 1.f;
+  for (int l = 0; l < levels; ++l) {
+    const float X = cx * sc, Y = cy * sc;
+    const float x0f = floorf(X), y0f = floorf(Y);
+    fxs[l] = X - x0f;
+    fys[l] = Y - y0f;
+    // clamp the integer base far outside the image so int conversion can not overflow
+    const int x0 = (int)fminf(fmaxf(x0f, -100000.f), 100000.f) - radius;
+    const int y0 = (int)fminf(fmaxf(y0f, -100000.f), 100000.f) - radius;
+    const float* img = lv[l] + q * (long)h * w;
+    for (int idx = lane; idx < PS * PS; idx += 64) {
+      const int py = idx / PS, px = idx - py * PS;
+      const int y = y0 + py, x = x0 + px;
+      float v = 0.f;
+      if (y >= 0 && y < h && x >= 0 && x < w) v = (img[y * w + x] - mu) * rstd;
+      patch[wv][l][py * LOOKUP_MAXP + px] = v;
     }
+    h >>= 1; w >>= 1; sc *= 0.5f;
   }
-#pragma unroll
-  for (int l = 0; l < 4; ++l)
-    if (l < levels) {
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int idx = lane + 64 * i;
-        if (idx < PS * PS) {
-          const int py = idx / PS, px = idx - py * PS;
-          patch[wv][l][py * LOOKUP_MAXP + px] = tok[l][i] ? (tv[l][i] - mu) * rstd : 0.f;
-        }
-      }
-    }
   __syncthreads();
   if (!valid) return;
   const int nch = levels * win * win;
