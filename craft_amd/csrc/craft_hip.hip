@@ -312,6 +312,11 @@ int craft_stem_conv7x7(const float* image, const float* w, const float* bias, in
   return launch_stem7x7(image, w, bias, act, B, H, W, out, stats, S(stream));
 }
 
+int craft_stem_conv7x7_mfma(const float* image, const void* w_packed, const float* bias, int act, int B, int H, int W,
+                            float* out, double* stats, int prec, void* stream) {
+  return launch_stem_mfma(image, w_packed, bias, act, B, H, W, out, stats, PREC_OF(prec), S(stream));
+}
+
 int craft_stats_finalize(const double* sums, long n, double count, float eps, float* mean_rstd, void* stream) {
   return launch_stats_finalize(sums, n, count, eps, mean_rstd, S(stream));
 }

@@ -92,6 +92,17 @@ class HipEncoder:
                                self.enc.conv2.bias.detach().float().contiguous())
                 w0, b0 = _fold_bn(self.enc.conv1, self.enc.norm1 if bn else None)
                 self._stem = (w0.permute(2, 3, 1, 0).reshape(147, 64).contiguous(), b0.contiguous())
+                self._stem_mfma = None
+                if prec != PREC_F32:
+                    # MFMA stem: K ordered (ky, c, kx) with kx padded 7 -> 8 and K padded 168 -> 192 (craft_stem_conv7x7_mfma)
+                    wk = torch.zeros(64, 7, 3, 8, device=w0.device, dtype=torch.float32)
+                    wk[..., :7] = w0.permute(0, 2, 1, 3)
+                    wm = torch.zeros(64, 192, device=w0.device, dtype=torch.float32)
+                    wm[:, :168] = wk.reshape(64, 168)
+                    planes = 2 if prec == 3 else 1
+                    packed = torch.empty(planes * 64 * 192, device=w0.device, dtype=torch.bfloat16 if prec == 1 else torch.float16)
+                    call("craft_pack_weights", wm, 64, 192, prec, packed)
+                    self._stem_mfma = packed
             self._packs, self._key = packs, key
         return self._packs
 
@@ -126,12 +137,17 @@ class HipEncoder:
         sw, sb = self._stem
         t = torch.empty(B, hw[0] * hw[1], 64, device=dev, dtype=torch.float32)
         t_norm = None
+        def stem(act, stats):
+            if self._stem_mfma is not None:
+                call("craft_stem_conv7x7_mfma", raw.contiguous(), self._stem_mfma, sb, act, B, H, W, t, stats, cp)
+            else:
+                call("craft_stem_conv7x7", raw.contiguous(), sw, sb, act, B, H, W, t, stats)
         if inorm:
             s0 = torch.zeros(STATS_REPLICAS, B, 64, 2, device=dev, dtype=torch.float64)
-            call("craft_stem_conv7x7", raw.contiguous(), sw, sb, ACT_NONE, B, H, W, t, s0)
+            stem(ACT_NONE, s0)
             t_norm = self._finalize(s0, hw[0] * hw[1])          # norm1 + ReLU are applied lazily by layer1.0
         else:
-            call("craft_stem_conv7x7", raw.contiguous(), sw, sb, ACT_RELU, B, H, W, t, None)
+            stem(ACT_RELU, None)
         for pk in packs:
             if inorm:
                 s1 = torch.zeros(STATS_REPLICAS, B, pk["c1"].cout, 2, device=dev, dtype=torch.float64)

@@ -169,6 +169,11 @@ int craft_conv2d_nhwc_ex(const float* x, long ldx, int cin, int Hin, int Win, co
                          int Hout, int Wout, double* stats, int prec, void* stream);
 int craft_stem_conv7x7(const float* image, const float* w, const float* bias, int act, int B, int H, int W,
                        float* out, double* stats, void* stream);
+/* The same stem on the matrix cores (bf16 / fp16 / F16X3): w_packed = craft_pack_weights(rows 64, K 192, prec) of the
+ * weight matrix re-ordered to k = (ky*3 + c)*8 + kx (kx = 7 and k >= 168 zero), so that a k-group of 8 is one run of
+ * 8 consecutive pixels of an input row.  Same outputs / statistics as craft_stem_conv7x7. */
+int craft_stem_conv7x7_mfma(const float* image, const void* w_packed, const float* bias, int act, int B, int H, int W,
+                            float* out, double* stats, int prec, void* stream);
 int craft_stats_finalize(const double* sums, long n, double count, float eps, float* mean_rstd, void* stream);
 int craft_residual_relu(const float* x, long ldx, const float* xnorm, const float* y, long ldy, const float* ynorm,
                         int y_relu, int B, int HW, int C, float* out, long ldo, void* stream);
