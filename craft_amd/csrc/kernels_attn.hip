@@ -212,6 +212,183 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build4(ScoreParams p, float w
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pre-split operands for the f16x3 correlation build: x fp32 [rows][ld] (first C columns) * mul -> two fp16 planes
+// [2][rows][C] (hi = fp16(v), lo = fp16(v - hi)).  Q and K tiles are re-read by ~100 blocks each; splitting them once
+// takes the fp32 -> hi/lo conversion (a third of that kernel's VALU work) out of its K loop.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_split_planes(const float* __restrict__ x, long ld, long rows, int C, float mul,
+                                                      _Float16* __restrict__ out) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= rows * C) return;
+  const long r = i / C;
+  const int c = (int)(i - r * C);
+  const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+  f16x4 h, l;
+  const float a[4] = {v.x * mul, v.y * mul, v.z * mul, v.w * mul};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { h[j] = (_Float16)a[j]; l[j] = (_Float16)(a[j] - (float)h[j]); }
+  *reinterpret_cast<f16x4*>(out + i) = h;
+  *reinterpret_cast<f16x4*>(out + rows * C + i) = l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// correlation build, f16x3, M = 4 modes of width d = 64, operands pre-split by k_split_planes (Q already multiplied by
+// the score scale).  One K-tile per mode (64 wide): the next mode's tiles are requested into registers before the
+// current mode's 24 MFMAs, staged with pure 16-byte copies, two barriers per mode.  The epilogue is specialised on the
+// two tile-uniform conditions (clamp active; tile inside the positional window).
+// ---------------------------------------------------------------------------------------------
+template <bool CLAMP, bool BIAS>
+__device__ __forceinline__ void corr4_epilogue(const ScoreParams& p, const f32x16 (&acc)[4][2], float wl, int m0, int wm0, int col,
+                                               int lane, const int* s_rh, const int* s_rw, const float* s_tab, int R, int TW,
+                                               float* __restrict__ out, float& s1, float& s2) {
+  const int N = p.N, rh4 = 4 * (lane >> 5);
+  const int h2 = col / p.W8, w2 = col - h2 * p.W8;
+  const int ch = R + 1 + h2, cw = R + 1 + w2;
+  const unsigned umax = 2 * R + 2;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rl = wm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
+      const int row = m0 + rl;
+      float sv[4], tv[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        sv[m] = CLAMP ? __builtin_amdgcn_fmed3f(acc[m][mt][e], -CRAFT_ATTN_CLIP, CRAFT_ATTN_CLIP) : acc[m][mt][e];
+        tv[m] = wl * sv[m];
+      }
+      const float mx = fmaxf(fmaxf(tv[0], tv[1]), fmaxf(tv[2], tv[3]));
+      float den = 0.f, num = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float ex = __builtin_amdgcn_exp2f(tv[m] - mx);
+        den += ex;
+        num += sv[m] * ex;
+      }
+      float c = num * __builtin_amdgcn_rcpf(den);
+      if (BIAS) {
+        const unsigned u = min((unsigned)(ch - s_rh[rl]), umax), v = min((unsigned)(cw - s_rw[rl]), umax);
+        c += s_tab[u * TW + v];
+      }
+      if (row < N && col < N) {
+        out[(long)row * N + col] = c;
+        s1 += c;
+        s2 += c * c;
+      }
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS) void k_corr_build4s(ScoreParams p, const _Float16* __restrict__ Qs, const _Float16* __restrict__ Ks,
+                                                          float w_aggr, float* __restrict__ pyr0, double* __restrict__ sums) {
+  constexpr int BM = 128, BN = 64, D = 64, LD = D + 8, MT = 2;
+  __shared__ __attribute__((aligned(16))) _Float16 As[2 * BM * LD];       // planes hi | lo
+  __shared__ __attribute__((aligned(16))) _Float16 Bs[2 * BN * LD];
+  __shared__ int s_rh[BM], s_rw[BM];
+  __shared__ float s_tab[33 * 33];
+  __shared__ float s_red[8];
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, b = blockIdx.z;
+  const int N = p.N, C = 4 * D;
+  const long rows_tot = (long)p.B * N;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 32;
+  const int col = n0 + wn0 + (lane & 31);
+  const bool clamp = p.clamp_ord != nullptr && ord2f(*p.clamp_ord) > CRAFT_ATTN_CLIP;
+  const int R = p.pos_tab ? p.R : 0, TW = 2 * R + 3;
+  if (tid < BM) { const int r = m0 + tid; s_rh[tid] = r / p.W8; s_rw[tid] = r - (r / p.W8) * p.W8; }
+  for (int i = tid; i < TW * TW; i += NTHREADS) {
+    const int dh = i / TW - R - 1, dw = i - (i / TW) * TW - R - 1;
+    s_tab[i] = (p.pos_tab && abs(dh) <= R && abs(dw) <= R) ? p.pos_w * p.pos_tab[(dh + R) * (2 * R + 1) + dw + R] : 0.f;
+  }
+  // staging: thread -> (row r8 + 32 i, 16-byte chunk c8 of the 128-byte mode row); rows clamped (results discarded)
+  const int c8 = tid & 7, r8 = tid >> 3;
+  const _Float16* qp[4];
+  const _Float16* kp[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) qp[i] = Qs + ((long)b * N + min(m0 + r8 + 32 * i, N - 1)) * C + c8 * 8;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) kp[i] = Ks + ((long)b * N + min(n0 + r8 + 32 * i, N - 1)) * C + c8 * 8;
+  u32x4 ra[2][4], rb[2][2];
+  auto fetch = [&](int m) __attribute__((always_inline)) {
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra[pl][i] = *reinterpret_cast<const u32x4*>(qp[i] + pl * rows_tot * C + m * D);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) rb[pl][i] = *reinterpret_cast<const u32x4*>(kp[i] + pl * rows_tot * C + m * D);
+    }
+  };
+  auto store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&As[(pl * BM + r8 + 32 * i) * LD + c8 * 8]) = ra[pl][i];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(&Bs[(pl * BN + r8 + 32 * i) * LD + c8 * 8]) = rb[pl][i];
+    }
+  };
+  f32x16 acc[4][MT];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][mt][e] = 0.f;
+  const int r = lane & 31, g8 = (lane >> 5) * 8;
+  fetch(0);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    __syncthreads();                       // every wave is done with the previous mode's tiles
+    store();
+    __syncthreads();
+    if (m + 1 < 4) fetch(m + 1);           // lands behind this mode's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f16x8 ah[MT], al[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        ah[mt] = *reinterpret_cast<const f16x8*>(&As[(wm0 + mt * 32 + r) * LD + kk * 16 + g8]);
+        al[mt] = *reinterpret_cast<const f16x8*>(&As[(BM + wm0 + mt * 32 + r) * LD + kk * 16 + g8]);
+      }
+      const f16x8 bh = *reinterpret_cast<const f16x8*>(&Bs[(wn0 + r) * LD + kk * 16 + g8]);
+      const f16x8 bl = *reinterpret_cast<const f16x8*>(&Bs[(BN + wn0 + r) * LD + kk * 16 + g8]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[m][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[m][mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[m][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[m][mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[m][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[m][mt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const float wl = w_aggr * 1.4426950408889634f;
+  // positional window: rows of the key tile vs rows of the query tile (block-uniform)
+  const int q_hmin = m0 / p.W8, q_hmax = min(m0 + BM - 1, N - 1) / p.W8;
+  const int k_hmin = n0 / p.W8, k_hmax = min(n0 + BN - 1, N - 1) / p.W8;
+  const bool has_bias = p.pos_tab != nullptr && k_hmax >= q_hmin - R && k_hmin <= q_hmax + R;
+  float s1 = 0.f, s2 = 0.f;
+  float* out = pyr0 + (long)b * N * N;
+  if (clamp) {
+    if (has_bias) corr4_epilogue<true, true>(p, acc, wl, m0, wm0, col, lane, s_rh, s_rw, s_tab, R, TW, out, s1, s2);
+    else corr4_epilogue<true, false>(p, acc, wl, m0, wm0, col, lane, s_rh, s_rw, s_tab, R, TW, out, s1, s2);
+  } else {
+    if (has_bias) corr4_epilogue<false, true>(p, acc, wl, m0, wm0, col, lane, s_rh, s_rw, s_tab, R, TW, out, s1, s2);
+    else corr4_epilogue<false, false>(p, acc, wl, m0, wm0, col, lane, s_rh, s_rw, s_tab, R, TW, out, s1, s2);
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) { s_red[wave] = s1; s_red[4 + wave] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    const double a = (double)s_red[0] + (double)s_red[1] + (double)s_red[2] + (double)s_red[3];
+    const double q = (double)s_red[4] + (double)s_red[5] + (double)s_red[6] + (double)s_red[7];
+    atomicAdd(&sums[2 * b], a);
+    atomicAdd(&sums[2 * b + 1], q);
+  }
+}
+
 static int check_score(const ScoreParams& p) {
   if (p.d % BK || p.M < 1 || (p.ldq & 3) || (p.ldk & 3) || (p.q_bs & 3) || (p.k_bs & 3)) return CRAFT_ERR_ALIGN;
   if (p.pos_tab && p.R > 15) return CRAFT_ERR_UNSUPPORTED;
@@ -261,11 +438,22 @@ int launch_score_max(const ScoreParams& p, unsigned* max_ord, int prec, hipStrea
   return (int)hipGetLastError();
 }
 
-int launch_corr_build(const ScoreParams& p, float w_aggr, float* pyr0, double* sums, int prec, hipStream_t s) {
+int launch_corr_build(const ScoreParams& p, float w_aggr, float* pyr0, double* sums, void* ws, int prec, hipStream_t s) {
   if (int e = check_score(p)) return e;
   dim3 grid((p.N + 127) / 128, (p.N + 63) / 64, p.B);
   hipError_t me = hipMemsetAsync(sums, 0, sizeof(double) * 2 * p.B, s);
   if (me != hipSuccess) return (int)me;
+  if (ws != nullptr && prec == CRAFT_PREC_F16X3 && p.M == 4 && p.d == 64 && p.ldq % 4 == 0 && p.ldk % 4 == 0) {
+    // pre-split path: ws holds the hi/lo planes of Q (x scale) and K: 2 x (2 * B*N*256) fp16
+    const long rows = (long)p.B * p.N, n4 = rows * 256 / 4;
+    _Float16* Qs = reinterpret_cast<_Float16*>(ws);
+    _Float16* Ks = Qs + 2 * rows * 256;
+    dim3 g1((unsigned)((n4 + 255) / 256));
+    hipLaunchKernelGGL(k_split_planes, g1, dim3(256), 0, s, p.Q, p.ldq, rows, 256, p.scale, Qs);
+    hipLaunchKernelGGL(k_split_planes, g1, dim3(256), 0, s, p.Kf, p.ldk, rows, 256, 1.f, Ks);
+    hipLaunchKernelGGL(k_corr_build4s, grid, dim3(NTHREADS), 0, s, p, Qs, Ks, w_aggr, pyr0, sums);
+    return (int)hipGetLastError();
+  }
   if (p.M == 4) {
     if (prec == CRAFT_PREC_F32) hipLaunchKernelGGL((k_corr_build4<CRAFT_PREC_F32>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums);
     else if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_corr_build4<CRAFT_PREC_BF16>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums);

@@ -76,7 +76,7 @@ struct ScoreParams {
 };
 
 int launch_score_max(const ScoreParams& p, unsigned* max_ord, int prec, hipStream_t s);
-int launch_corr_build(const ScoreParams& p, float w_aggr, float* pyr0, double* sums, int prec, hipStream_t s);
+int launch_corr_build(const ScoreParams& p, float w_aggr, float* pyr0, double* sums, void* ws, int prec, hipStream_t s);
 int launch_attn_probs(const ScoreParams& p, void* P, long ldp, int p_prec, int prec, hipStream_t s);
 template <int D> int launch_attn_probs_d(const ScoreParams& p, void* P, long ldp, int p_prec, int prec, hipStream_t s);
 

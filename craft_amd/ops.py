@@ -165,9 +165,11 @@ def corr_build(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale
                prec: int) -> CorrPyramid:
     B, N, C = q.shape
     R = 0 if pos_tab is None else (pos_tab.shape[0] - 1) // 2
+    sp = pick(prec, "score")
+    # f16x3, 4 modes of 64: scratch for the pre-split (hi / lo fp16) copies of Q and K
+    ws = torch.empty(4 * B * N * C, device=q.device, dtype=torch.float16) if (sp == hip.PREC_F16X3 and M == 4 and C == 256) else None
     call("craft_corr_build", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale,
-         None if pos_tab is None else pos_tab.contiguous(), R, pos_w, w_aggr, clamp_ord, pyr.lv[0], pyr.sums,
-         pick(prec, "score"))
+         None if pos_tab is None else pos_tab.contiguous(), R, pos_w, w_aggr, clamp_ord, pyr.lv[0], pyr.sums, ws, sp)
     lv = pyr.lv + [None] * (4 - len(pyr.lv))
     call("craft_corr_finish", lv[0], lv[1], lv[2], lv[3], pyr.sums, pyr.mu_rstd, B, H8, W8, int(do_norm))
     return pyr

@@ -79,10 +79,13 @@ int craft_score_max(const float* q, long ldq, const float* k, long ldk, int B, i
  * to pyramid level 0 [B*N][H8][W8]; sums[b] = (sum c, sum c^2) in double for the lazy LayerNorm.
  * pos_tab: SlidingPosBiases2D.biases [(2R+1)^2] (setrans.py:644-708), NULL = none; clamp_ord from
  * craft_score_max (NULL = never clamp).  M=1, pos_tab=NULL, scale=1/sqrt(C) gives CorrBlock.corr
- * (corr.py:73-81). */
+ * (corr.py:73-81).
+ * ws (or NULL): scratch of 2 * (2 * B*N*M*d) 16-bit values.  With it, prec = F16X3, M = 4 and d = 64 the operands are split
+ * into fp16 hi/lo planes ONCE (Q pre-multiplied by scale) and the build streams them with pure copies -- the fp32 -> hi/lo
+ * conversion inside the K loop was a third of the kernel's instructions.  Same result up to fp32 rounding order. */
 int craft_corr_build(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d,
                      float scale, const float* pos_tab, int R, float pos_w, float w_aggr,
-                     const unsigned* clamp_ord, float* pyr0, double* sums, int prec, void* stream);
+                     const unsigned* clamp_ord, float* pyr0, double* sums, void* ws, int prec, void* stream);
 
 /* corr.py:186-189 + :200-204: levels 1..3 by 2x2 average pooling (floor sizes; pass NULL to stop early) and
  * mu_rstd[b] = (mean, 1/sqrt(var+1e-12)) over all N*N entries (do_norm=0: (0,1)). */

@@ -53,6 +53,15 @@ def main():
         enc = m._henc_f if which == "fnet" else m._henc_c
         for _ in range(2):
             enc.forward_tokens(raw, prec)
+    elif which == "corr":
+        import math
+        C, Mm = 256, 4
+        q = torch.randn(B, N, C, device=dev)
+        k = torch.randn(B, N, C, device=dev)
+        tab = torch.randn(15, 15, device=dev)
+        pyr = ops.CorrPyramid(B, H8, W8, 4, dev)
+        for _ in range(2):
+            ops.corr_build(q, k, H8, W8, Mm, 1 / math.sqrt(C // Mm), tab, 0.5, 0.7, None, pyr, True, prec)
     elif which in ("probs", "probs_norm"):
         import math
         C, Mm = 128, 4
