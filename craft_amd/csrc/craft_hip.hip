@@ -1,5 +1,6 @@
 // C ABI of libcraft_hip.so (declared in include/craft_hip.h): thin argument marshalling over the kernel
 // launchers; operator-level entry points (motion encoder, GRU, heads) compose several launches.
+#include <cstdlib>
 #include "launch.hpp"
 #include "../../include/craft_hip.h"
 
@@ -7,6 +8,39 @@ using namespace craft;
 
 #define S(stream) reinterpret_cast<hipStream_t>(stream)
 #define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+namespace {
+// Fork / join of a side stream around independent launches inside one operator-level entry point.  The side stream and
+// the two events are created once per host thread and device (the library is called from one thread per GPU).
+struct AuxFork {
+  hipStream_t main, aux = nullptr;
+  hipEvent_t e_join = nullptr;
+  bool on;
+  AuxFork(hipStream_t s, bool enable) : main(s), on(false) {
+    if (!enable) return;
+    struct Res { hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; int dev = -1; };
+    static thread_local Res r;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    if (r.dev != dev) {
+      if (hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking) != hipSuccess) return;
+      if (hipEventCreateWithFlags(&r.e0, hipEventDisableTiming) != hipSuccess) return;
+      if (hipEventCreateWithFlags(&r.e1, hipEventDisableTiming) != hipSuccess) return;
+      r.dev = dev;
+    }
+    if (hipEventRecord(r.e0, s) != hipSuccess || hipStreamWaitEvent(r.st, r.e0, 0) != hipSuccess) return;
+    aux = r.st; e_join = r.e1; on = true;
+  }
+  hipStream_t side() const { return on ? aux : main; }
+  int join() {
+    if (!on) return 0;
+    on = false;
+    hipError_t e = hipEventRecord(e_join, aux);
+    if (e == hipSuccess) e = hipStreamWaitEvent(main, e_join, 0);
+    return (int)e;
+  }
+};
+}  // namespace
 
 extern "C" {
 
@@ -159,6 +193,10 @@ int craft_motion_encoder(const float* corr, long ldc, int cor_planes, const floa
   float* corflo = ws + npix * 256;     // [npix][256] = [cor (192) | flo (64)]
   float* flo1 = ws + npix * 512;       // [npix][128]
   hipStream_t s = S(stream);
+  // The flow branch (convf1 -> convf2) and the correlation branch (convc1 -> convc2) are independent until `conv`:
+  // the flow branch runs on a side stream of the library, forked from / joined into the caller's stream by events.
+  AuxFork fork(s, getenv("CRAFT_NO_FORK") == nullptr);
+  hipStream_t sf = fork.side();
   {  // cor = relu(convc1(corr))  1x1, cor_planes -> 256   (update.py:80)
     RowsGemmParams p = {};
     p.A = corr; p.lda = ldc; p.B = wc1; p.ldb = cor_planes; p.C = cor1; p.ldc = 256;
@@ -175,14 +213,15 @@ int craft_motion_encoder(const float* corr, long ldc, int cor_planes, const floa
     TRY(launch_gemm_conv(q, prec, s));
   }
   // flo = relu(convf1(flow))  7x7, 2 -> 128   (update.py:82)
-  TRY(launch_convf1(flow, wf1, bf1, B, H8, W8, flo1, 128, s));
+  TRY(launch_convf1(flow, wf1, bf1, B, H8, W8, flo1, 128, sf));
   // flo = relu(convf2(flo))  3x3, 128 -> 64   (update.py:83) -> columns 192..255 of corflo (the torch.cat of :85)
   {
     ConvGemmParams q = conv_params(flo1, 128, 128, nullptr, 0, 0, B, H8, W8, 3, 3, wf2, bf2, 64, CONV_EPI_BIAS_ACT,
                                    CRAFT_ACT_RELU, 1.f, corflo + 192, 256);
     q.w_packed = pk;
-    TRY(launch_gemm_conv(q, prec, s));
+    TRY(launch_gemm_conv(q, prec, sf));
   }
+  TRY(fork.join());
   // out = cat[relu(conv(cor_flo)) (126), flow (2)]  (update.py:86-87)
   ConvGemmParams p = conv_params(corflo, 256, 256, nullptr, 0, 0, B, H8, W8, 3, 3, wcv, bcv, 126, CONV_EPI_MENC,
                                  CRAFT_ACT_RELU, 1.f, out, (int)ldo);

@@ -20,6 +20,8 @@ Extra (non-reference) argument fields, all optional:
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -164,11 +166,25 @@ class CRAFT(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _streams(self, n: int, dev):
-        """Side streams for the batch-sliced refinement loop (created once per device)."""
+        """Side streams (context chain, batch-sliced refinement loop), created once per device and count."""
+        cache = self.__dict__.setdefault("_stream_cache", {})
         key = (dev.index, n)
-        if getattr(self, "_stream_cache", None) is None or self._stream_cache[0] != key:
-            self._stream_cache = (key, [torch.cuda.Stream(device=dev) for _ in range(n)])
-        return self._stream_cache[1]
+        if key not in cache:
+            cache[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        return cache[key]
+
+    def _context_chain(self, cn_tok, hx, hw, prec):
+        """Context split + intra-frame attention (network.py:206-214) + the GRU's context fields: fills hx[..., 0:256],
+        returns (attention, gru_fields)."""
+        ops.tokens_slice(cn_tok, 0, 128, act=ACT_TANH, out=hx[..., 0:128])
+        ops.tokens_slice(cn_tok, 128, 128, act=ACT_RELU, out=hx[..., 128:256])
+        if self.args.use_setrans:
+            xc = ops.tokens_norm(hx[..., 128:256])
+            attention = self.att.forward_tokens(xc, hw, prec=prec, defer=True)    # [B, 4, N, ldp] (+ row sums)
+        else:
+            attention = self.att.forward_tokens(hx[..., 128:256], hw, prec, defer=True)
+        # the context features are the same in every iteration: hoist their share of the GRU convolutions
+        return attention, self.update_block.gru.context_tokens(hx[..., 128:256], hw, prec)
 
     def forward(self, image1, image2, iters=12, flow_init=None, upsample=True, test_mode=0):
         """Estimate optical flow between a pair of frames (network.py:164-267)."""
@@ -190,11 +206,24 @@ class CRAFT(nn.Module):
 
         with torch.no_grad():
             use_henc = getattr(args, "hip_encoders", True) and not self.training
+            # The context chain (cnet -> net / inp -> intra-frame attention -> GRU context fields) and the feature
+            # chain (fnet -> F2 transformer -> correlation volume) are independent until the refinement loop: the
+            # context chain is enqueued on a side stream (fork / join by events; every side-stream tensor is consumed
+            # on the main stream only after the join, and the side stream always starts by waiting for the main one,
+            # so the caching allocator's per-stream reuse stays ordered).
+            main = torch.cuda.current_stream()
+            fork = use_henc and getattr(args, "hip_fork", True) and not os.environ.get("CRAFT_NO_FORK")
+            side = self._streams(1, dev)[0] if fork else main
+            hx = torch.empty(B, N, 512, device=dev, dtype=torch.float32)              # [net | inp | mf | mfg]
             if use_henc:
                 # CNN encoders on the HIP conv engine, channels-last end to end
+                if side is not main:
+                    side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    cn_tok = self._henc_c.forward_tokens(raw1, prec)                            # [B, N, 256]
+                    attention, gru_fields = self._context_chain(cn_tok, hx, hw, prec)
                 fm = self._henc_f.forward_tokens(torch.cat([raw1, raw2], dim=0), prec)         # [2B, N, 256]
                 f1_tok, f2_tok = fm[:B], fm[B:]
-                cn_tok = self._henc_c.forward_tokens(raw1, prec)                                # [B, N, 256]
             else:
                 image1 = (2 * (raw1 / 255.0) - 1.0).contiguous()
                 image2 = (2 * (raw2 / 255.0) - 1.0).contiguous()
@@ -204,20 +233,11 @@ class CRAFT(nn.Module):
                 f1_tok = ops.tokens_from_nchw(fmap1.float())
                 f2_tok = ops.tokens_from_nchw(fmap2.float())
                 cn_tok = ops.tokens_from_nchw(cnet_feat.float())
+                attention, gru_fields = self._context_chain(cn_tok, hx, hw, prec)
 
             # ---- F2 transformer (network.py:185-187): tokens in, LayerNorm-ed tokens out ------------
             x2 = ops.tokens_norm(f2_tok)
             fmap2_t = self.f2_trans.forward_tokens(x2, hw, prec=prec)                 # [B, N, 256]
-
-            # ---- context split + intra-frame attention (network.py:206-214) -----------------------
-            hx = torch.empty(B, N, 512, device=dev, dtype=torch.float32)              # [net | inp | mf | mfg]
-            ops.tokens_slice(cn_tok, 0, 128, act=ACT_TANH, out=hx[..., 0:128])
-            ops.tokens_slice(cn_tok, 128, 128, act=ACT_RELU, out=hx[..., 128:256])
-            if args.use_setrans:
-                xc = ops.tokens_norm(hx[..., 128:256])
-                attention = self.att.forward_tokens(xc, hw, prec=prec, defer=True)    # [B, 4, N, ldp] (+ row sums)
-            else:
-                attention = self.att.forward_tokens(hx[..., 128:256], hw, prec, defer=True)
 
             # ---- correlation volume + pyramid (network.py:196-197, :225-228) ---------------------
             if args.craft:
@@ -238,8 +258,8 @@ class CRAFT(nn.Module):
                                corr_fn.pyramid, False, prec)
                 self.corr_fn = corr_fn
 
-            # the context features are the same in every iteration: hoist their share of the GRU convolutions
-            gru_fields = self.update_block.gru.context_tokens(hx[..., 128:256], hw, prec)
+            if side is not main:
+                main.wait_stream(side)
             coords0, coords1, flow = ops.coords_init(flow_init, B, H8, W8, dev)
             pyramids = corr_fn.all_pyramids()
             nch = corr_fn.num_levels * (2 * corr_fn.radius + 1) ** 2 * len(pyramids)
@@ -264,7 +284,6 @@ class CRAFT(nn.Module):
                 parts.append(dict(b=(b0, b1), hx=hx[b0:b1], corr=corr[b0:b1], flow=flow[b0:b1], att=ops.probs_slice(attention, b0, b1),
                                   c0=coords0[b0:b1], c1=coords1[b0:b1], mask=mask[b0:b1], fields=gru_fields[b0:b1],
                                   pyr=[pv.batch_slice(b0, b1) for pv in pyramids], ws=None))
-            main = torch.cuda.current_stream()
             streams = [main] if nstr == 1 else self._streams(nstr, dev)
             if nstr > 1:
                 fork = torch.cuda.Event()

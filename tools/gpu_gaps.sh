@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # GPU idle-gap analysis of the bench step: kernel-trace of bench.py, then per-step busy time vs wall span.
 REPO=$(pwd); export TMPDIR=/tmp; cd /tmp; rm -rf /tmp/tr_bench
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_bench -o k -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_bench -o k -- python $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline $BENCH_ARGS > /dev/null 2>&1
 f=$(find /tmp/tr_bench -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
 import csv, re, sys
@@ -9,7 +9,7 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # find step boundaries: k_stem7x7 with the fnet grid marks the start of a forward (two stems per forward: fnet first)
-starts = [i for i, r in enumerate(rows) if "k_stem7x7" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "k_stem" in r["Kernel_Name"]]
 starts = starts[0::2]
 print("forwards found:", len(starts))
 for a, b in zip(starts[-4:-1], starts[-3:]):
