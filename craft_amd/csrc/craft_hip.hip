@@ -77,8 +77,12 @@ int craft_linear(const float* x, long ldx, const float* w, const float* bias, fl
 int craft_linear_t(const float* x, long ldx, const float* w, void* yT, long ldt, int B, int N, int cin, int cout,
                    int out_prec, int frag_rows, int prec, void* stream) {
   if (out_prec < 0 || out_prec > 2) return CRAFT_ERR_ARG;
+  const int frag_acc = (frag_rows & CRAFT_FRAG_ACC_ORDER) ? 1 : 0;
+  frag_rows &= ~CRAFT_FRAG_ACC_ORDER;
+  if (frag_acc && !frag_rows) return CRAFT_ERR_ARG;
   if (frag_rows && (out_prec == CRAFT_PREC_F32 || frag_rows % 32 || cout % frag_rows || ldt % 16)) return CRAFT_ERR_ALIGN;
   RowsGemmParams p = {};
+  p.c_frag_acc = frag_acc;
   p.c_dtype = out_prec;
   p.zdiv = 1; p.batch = B; p.K = cin;
   p.bias = nullptr; p.scale = 1.f; p.act = CRAFT_ACT_NONE;
@@ -145,6 +149,13 @@ int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, 
   sp.rowmax = rowsum ? reinterpret_cast<unsigned*>(rowsum + (long)B * M * H8 * W8) : nullptr;
   if (mask_radius > 15 || (pos_tab && R > 15)) return CRAFT_ERR_UNSUPPORTED;
   return launch_attn_probs(sp, P, ldp, p_prec, prec, S(stream));
+}
+
+int craft_flash_attention(const float* q, long ldq, const float* k, long ldk, const void* vT, long ldt, int B, int H8, int W8,
+                          int M, int d, int Dv, float scale, const float* pos_tab, int R, float pos_w, int mask_radius,
+                          const unsigned* clamp_ord, float* O, void* ws, int score_prec, int pv_prec, void* stream) {
+  ScoreParams sp = make_score(q, ldq, k, ldk, B, H8, W8, M, d, scale, pos_tab, R, pos_w, mask_radius, clamp_ord);
+  return launch_flash_attn(sp, vT, ldt, Dv, O, ws, score_prec, pv_prec, S(stream));
 }
 
 int craft_attn_apply(const void* P, long ldp, const float* rowsum, const void* vT, int B, int N, int M, int Dv, float* O,

@@ -1,0 +1,295 @@
+// Flash-style fused attention of a feature transformer (CrossAttFeatTrans + ExpandedFeatTrans up to the mode pooling,
+// setrans.py:507-557 and :364-410):
+//     O[b][m][i][:] = sum_j softmax_j( clamp?(Q_m(i).K_m(j) * scale) + pw*pb(i,j) + mask ) * V_m[j][:]
+// The N x N probabilities of such a layer are used exactly once, so they never exist in memory: per 32-key tile a wave
+// computes the scores of its 32 queries (f16x3 or fp16 MFMAs), updates the running row maximum / sum, and feeds the
+// un-normalised probabilities straight back into the MFMAs of P.V as a 16-bit operand (online softmax).
+//
+// Layouts (all produced on the device, see below):
+//   * Q and K are pre-split into fp16 planes and stored in MFMA FRAGMENT order by k_pack_qk:
+//       [z = b*M + m][32-row block][k-step][plane][lane][8]   (lane -> row = lane & 31, k = 16*kstep + 8*(lane >> 5) + j)
+//     Q is pre-multiplied by scale*log2(e): the softmax runs in the base-2 domain like k_attn_probs.
+//   * "Swapped" score product S^T = K.Q^T: a lane owns ONE query (column lane & 31) and 16 of the 32 keys of the tile,
+//     accumulator register i <-> key 8*(i >> 2) + 4*(lane >> 5) + (i & 3).  Registers 8*h .. 8*h+7 converted to fp16 are
+//     directly the B operand of MFMA h of O^T += V^T.P^T, PROVIDED the A operand (V^T) enumerates the keys of a
+//     16-key group in the same order: craft_linear_t(frag_rows = Dv | CRAFT_FRAG_ACC_ORDER) stores V^T that way.
+//     No shuffle, no LDS round trip for P.
+//   * K / V^T tiles (8 + 16 KB at d = 64, Dv = 256) are shared by the 8 waves of a block through LDS (double buffer,
+//     fragment order = conflict-free ds_read_b128); global -> registers one tile ahead, registers -> LDS after the
+//     MFMAs, one barrier per tile.
+// grid (ceil(N / 256), B*M), 512 threads: wave w owns queries [256*bx + 32*w, +32).
+#include "launch.hpp"
+
+namespace craft {
+
+__device__ __forceinline__ float xhalf_max(float v) {       // max over the two half-waves (lanes l and l ^ 32)
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+constexpr int FLASH_TABW = 33;          // bias / mask table width: 2 * 15 + 3
+constexpr float FLASH_RESCALE_THR = 8.f;
+
+template <int D, int DV, int PL>
+__global__ __launch_bounds__(512) void k_flash_attn(FlashParams p) {
+  constexpr int KS = D / 16;                  // k-steps of the score product
+  constexpr int NB = DV / 32;                 // 32-row blocks of O^T
+  constexpr int KT_H = KS * PL * 512;         // 16-bit elements per K tile
+  constexpr int VT_H = NB * 2 * 512;          // ... per V^T tile (two 16-key groups)
+  constexpr int TILE_H = KT_H + VT_H;
+  constexpr int NL = (TILE_H + 4095) / 4096;  // 16-byte pieces per thread and tile
+  static_assert(TILE_H % 8 == 0, "tile");
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) uint16_t St[2 * TILE_H];
+  __shared__ float s_tab[FLASH_TABW * FLASH_TABW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int z = blockIdx.y, b = z / p.M, m = z - b * p.M;
+  const int N = p.N, W8 = p.W8, R = p.R;
+  const int q0 = blockIdx.x * 256;
+  const int qb = blockIdx.x * 8 + wave;
+  const int qidx = qb * 32 + (lane & 31);
+  const int hh = lane >> 5;
+
+  // ---- bias / mask table (same construction as k_attn_probs)
+  constexpr float LOG2E = 1.4426950408889634f;
+  const bool clamp = p.clamp_ord != nullptr && ord2f(*p.clamp_ord) > CRAFT_ATTN_CLIP;
+  const int mr = p.mask_radius > 0 ? p.mask_radius : 0;
+  const int Re = max(p.pos_tab ? R : 0, mr), TW = 2 * Re + 3;
+  for (int i = tid; i < TW * TW; i += 512) {
+    const int dh = i / TW - Re - 1, dw = i - (i / TW) * TW - Re - 1;
+    float v = 0.f;
+    if (p.pos_tab && abs(dh) <= R && abs(dw) <= R) v = p.pos_tab[(dh + R) * (2 * R + 1) + dw + R] * (p.pos_w * LOG2E);
+    if (mr > 0 && max(abs(dh), abs(dw)) > mr) v += -1e9f;
+    s_tab[i] = v;
+  }
+  const float clipv = clamp ? CRAFT_ATTN_CLIP * LOG2E : 3.0e38f;
+  const int qc = min(qidx, N - 1);
+  const int h1 = qc / W8, w1 = qc - h1 * W8;
+  const int ch = Re + 1 - h1, cw = Re + 1 - w1;
+  const unsigned umax = 2 * Re + 2;
+  const int q_hmin = q0 / W8, q_hmax = min(q0 + 255, N - 1) / W8;
+  const bool always_tab = clamp || mr > 0;
+
+  // ---- Q fragments of this wave (resident)
+  f16x8 qf[KS][PL];
+  {
+    const uint16_t* qs = p.Qf + ((long)z * p.nqb + qb) * (KS * PL * 512) + lane * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < PL; ++pl) qf[ks][pl] = *reinterpret_cast<const f16x8*>(qs + (ks * PL + pl) * 512);
+  }
+
+  // ---- tile staging: piece i of thread tid = 16 bytes at element offset i*4096 + tid*8 of [K tile | V^T tile]
+  const uint16_t* kbase = p.Kf + (long)z * p.nkb * KT_H;
+  const uint16_t* vbase = p.Vf + (long)b * p.v_bs + (long)m * p.v_ms;
+  u32x4 rs[NL];
+  auto fetch = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int off = i * 4096 + tid * 8;
+      if (off < KT_H) rs[i] = *reinterpret_cast<const u32x4*>(kbase + (long)t * KT_H + off);
+      else if (off < TILE_H) rs[i] = *reinterpret_cast<const u32x4*>(vbase + (long)t * VT_H + (off - KT_H));
+    }
+  };
+  auto stash = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int off = i * 4096 + tid * 8;
+      if (off < TILE_H) *reinterpret_cast<u32x4*>(&St[buf * TILE_H + off]) = rs[i];
+    }
+  };
+
+  const int nkt = p.nkt;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+
+  f32x16 o[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[nb][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int t = 0; t < nkt; ++t) {
+    const int buf = t & 1;
+    fetch(min(t + 1, nkt - 1));
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- S^T = K . Q^T (32 keys x 32 queries), base-2 logits
+    const uint16_t* Kt = &St[buf * TILE_H + lane * 8];
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const f16x8 ah = *reinterpret_cast<const f16x8*>(Kt + (ks * PL) * 512);
+      if constexpr (PL == 2) {
+        const f16x8 al = *reinterpret_cast<const f16x8*>(Kt + (ks * PL + 1) * 512);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qf[ks][0], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qf[ks][1], s, 0, 0, 0);
+      }
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qf[ks][0], s, 0, 0, 0);
+    }
+
+    // ---- bias window / mask / clamp / ragged last tile: one block-uniform branch per tile
+    const int j0 = t * 32;
+    const int k_hmin = j0 / W8, k_hmax = min(j0 + 31, N - 1) / W8;
+    const bool ragged = j0 + 32 > N;
+    const bool need_tab = always_tab || (p.pos_tab != nullptr && k_hmax >= q_hmin - R && k_hmin <= q_hmax + R);
+    if (need_tab || ragged) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = j0 + 8 * (e >> 2) + 4 * hh + (e & 3);
+        const int kh = (int)__umulhi((unsigned)key, p.w8_magic), kw = key - kh * W8;
+        const unsigned u = min((unsigned)(kh + ch), umax), v = min((unsigned)(kw + cw), umax);
+        float sv = __builtin_amdgcn_fmed3f(s[e], -clipv, clipv) + s_tab[u * TW + v];
+        if (key >= N) sv = -INFINITY;
+        s[e] = sv;
+      }
+    }
+
+    // ---- online softmax.  The running maximum is only raised when some row's tile maximum exceeds it by more than
+    // 2^THR (P' then stays <= 2^THR, exact in fp16's range; the final division by the row sum uses the same stale max).
+    float tm = s[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) tm = fmaxf(tm, s[e]);
+    tm = xhalf_max(tm);
+    if (__any(tm > m_run + FLASH_RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, tm);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);       // m_run = -inf (first tile): 0
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[nb][e] *= alpha;
+      l_run *= alpha;
+      m_run = m_new;
+    }
+    f16x8 pb[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float ex = __builtin_amdgcn_exp2f(s[e] - m_run);
+      l_run += ex;
+      pb[e >> 3][e & 7] = (_Float16)ex;
+    }
+
+    // ---- O^T += V^T . P^T
+    const uint16_t* Vt = &St[buf * TILE_H + KT_H + lane * 8];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const f16x8 a0 = *reinterpret_cast<const f16x8*>(Vt + nb * 512);
+      const f16x8 a1 = *reinterpret_cast<const f16x8*>(Vt + (NB + nb) * 512);
+      o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, pb[0], o[nb], 0, 0, 0);
+      o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, pb[1], o[nb], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stash(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: O[z][q][nb*32 + 8*(e >> 2) + 4*hh + (e & 3)]
+  const float inv = 1.f / xhalf_sum(l_run);
+  if (qidx < N) {
+    float* orow = p.O + ((long)z * N + qidx) * DV + 4 * hh;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(orow + nb * 32 + 8 * g) =
+            make_float4(o[nb][4 * g] * inv, o[nb][4 * g + 1] * inv, o[nb][4 * g + 2] * inv, o[nb][4 * g + 3] * inv);
+  }
+}
+
+// Q / K -> pre-split fragment order (see the header).  One thread per (z, block, k-step, lane): 8 consecutive floats in,
+// 16 (+16) bytes out.  Rows >= N are zero.
+template <int PL>
+__global__ void k_pack_qk(const float* __restrict__ X, long ld, long bs, int N, int M, int D, int nblk, float mul,
+                          uint16_t* __restrict__ out, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int KS = D / 16;
+  const int lane = (int)(i & 63);
+  long t = i >> 6;
+  const int ks = (int)(t % KS); t /= KS;
+  const int blk = (int)(t % nblk);
+  const int z = (int)(t / nblk);
+  const int b = z / M, m = z - b * M;
+  const int row = blk * 32 + (lane & 31);
+  float v[8];
+  if (row < N) {
+    const float* src = X + (long)b * bs + (long)row * ld + m * D + ks * 16 + (lane >> 5) * 8;
+    const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  }
+  f16x8 h, l;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = v[j] * mul;
+    h[j] = (_Float16)x;
+    l[j] = (_Float16)(x - (float)h[j]);
+  }
+  uint16_t* o = out + ((((long)z * nblk + blk) * KS + ks) * PL) * 512 + lane * 8;
+  *reinterpret_cast<f16x8*>(o) = h;
+  if constexpr (PL == 2) *reinterpret_cast<f16x8*>(o + 512) = l;
+}
+
+size_t flash_ws_bytes(int B, int M, int N, int d, int score_prec) {
+  const int PL = score_prec == CRAFT_PREC_F16X3 ? 2 : 1;
+  const long nqb = (long)((N + 255) / 256) * 8, nkb = (N + 31) / 32;
+  return (size_t)B * M * (nqb + nkb) * (d / 16) * PL * 512 * 2;
+}
+
+int launch_flash_attn(const ScoreParams& sp, const void* vT, long ldt, int Dv, float* O, void* ws, int score_prec, int pv_prec,
+                      hipStream_t s) {
+  if (sp.d != 64 || Dv != 256 || pv_prec != CRAFT_PREC_F16 || sp.rb_h != nullptr) return CRAFT_ERR_UNSUPPORTED;
+  if (score_prec != CRAFT_PREC_F16X3 && score_prec != CRAFT_PREC_F16) return CRAFT_ERR_UNSUPPORTED;
+  if (sp.N >= 65536 || sp.W8 < 2 || sp.N < 1) return CRAFT_ERR_UNSUPPORTED;
+  if ((sp.ldq & 3) || (sp.ldk & 3) || ldt % 32 || ldt < sp.N) return CRAFT_ERR_ALIGN;
+  if (sp.pos_tab && sp.R > 15) return CRAFT_ERR_UNSUPPORTED;
+  if (sp.mask_radius > 15) return CRAFT_ERR_UNSUPPORTED;
+  const int PL = score_prec == CRAFT_PREC_F16X3 ? 2 : 1;
+  const int Z = sp.B * sp.M, KS = sp.d / 16;
+  const int nqb = ((sp.N + 255) / 256) * 8, nkb = (sp.N + 31) / 32;
+  uint16_t* Qf = reinterpret_cast<uint16_t*>(ws);
+  uint16_t* Kf = Qf + (long)Z * nqb * KS * PL * 512;
+  constexpr float LOG2E = 1.4426950408889634f;
+  {
+    const long tq = (long)Z * nqb * KS * 64, tk = (long)Z * nkb * KS * 64;
+    if (PL == 2) {
+      hipLaunchKernelGGL((k_pack_qk<2>), dim3((unsigned)((tq + 255) / 256)), dim3(256), 0, s, sp.Q, sp.ldq, sp.q_bs, sp.N, sp.M,
+                         sp.d, nqb, sp.scale * LOG2E, Qf, tq);
+      hipLaunchKernelGGL((k_pack_qk<2>), dim3((unsigned)((tk + 255) / 256)), dim3(256), 0, s, sp.Kf, sp.ldk, sp.k_bs, sp.N, sp.M,
+                         sp.d, nkb, 1.f, Kf, tk);
+    } else {
+      hipLaunchKernelGGL((k_pack_qk<1>), dim3((unsigned)((tq + 255) / 256)), dim3(256), 0, s, sp.Q, sp.ldq, sp.q_bs, sp.N, sp.M,
+                         sp.d, nqb, sp.scale * LOG2E, Qf, tq);
+      hipLaunchKernelGGL((k_pack_qk<1>), dim3((unsigned)((tk + 255) / 256)), dim3(256), 0, s, sp.Kf, sp.ldk, sp.k_bs, sp.N, sp.M,
+                         sp.d, nkb, 1.f, Kf, tk);
+    }
+  }
+  FlashParams p = {};
+  p.Qf = Qf; p.Kf = Kf; p.Vf = reinterpret_cast<const uint16_t*>(vT);
+  p.v_bs = (long)sp.M * Dv * ldt; p.v_ms = (long)Dv * ldt;
+  p.O = O;
+  p.B = sp.B; p.M = sp.M; p.N = sp.N; p.H8 = sp.H8; p.W8 = sp.W8;
+  p.nkt = nkb; p.nqb = nqb; p.nkb = nkb;
+  p.w8_magic = (unsigned)((0x100000000ULL + (unsigned)sp.W8 - 1) / (unsigned)sp.W8);
+  p.pos_tab = sp.pos_tab; p.R = sp.R; p.pos_w = sp.pos_w; p.mask_radius = sp.mask_radius; p.clamp_ord = sp.clamp_ord;
+  dim3 grid((sp.N + 255) / 256, Z);
+  if (PL == 2) hipLaunchKernelGGL((k_flash_attn<64, 256, 2>), grid, dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((k_flash_attn<64, 256, 1>), grid, dim3(512), 0, s, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace craft

@@ -66,7 +66,9 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_rows(RowsGemmParams p) {
           }
           if constexpr (FRAG) {
             // keys row0..row0+3 share (key >> 3): 4 consecutive 16-bit values, one 8-byte store (lanes l, l+32 pair up)
-            out_t* d = C + fbase + (long)(row0 >> 4) * (p.c_frag >> 5) * 512 + ((row0 >> 3) & 1) * 256 + (row0 & 7);
+            // (accumulator key order: half = bit 2 of the key, position within the lane = 4 * bit 3 + low two bits)
+            out_t* d = C + fbase + (long)(row0 >> 4) * (p.c_frag >> 5) * 512 +
+                       (p.c_frag_acc ? ((row0 >> 2) & 1) * 256 + ((row0 >> 3) & 1) * 4 : ((row0 >> 3) & 1) * 256 + (row0 & 7));
             if (row0 + 3 < p.M) {
               typedef out_t o4 __attribute__((ext_vector_type(4)));
               o4 h;

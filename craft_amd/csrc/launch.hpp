@@ -23,6 +23,8 @@ struct RowsGemmParams {
   int act;
   const float* row_div; long rd_bs;   // non-null: C row r of batch z is divided by row_div[z * rd_bs + r] (deferred softmax sums)
   int c_frag;            // > 0: C (16-bit) is stored in MFMA B-fragment order per group of c_frag rows (k_pv16's V^T operand)
+  int c_frag_acc;        // with c_frag: the 16 rows (keys) of a k-group are enumerated in MFMA ACCUMULATOR order
+                         // (position 8*h + j <-> key 8*(j >> 2) + 4*h + (j & 3)): k_flash_attn's V^T operand
 };
 
 enum { CONV_EPI_BIAS_ACT = 0, CONV_EPI_GRU_ZR = 1, CONV_EPI_GRU_Q = 2, CONV_EPI_MENC = 3 };
@@ -74,6 +76,20 @@ struct ScoreParams {
   float* rowsum;                      // k_attn_probs: non-null = deferred normalisation, row sums [B][M][N] out ...
   unsigned* rowmax;                   // ... followed by [B][M][N] ordered-uint row maxima (scratch): rowsum + B*M*N
 };
+
+// ---- flash-fused attention (kernels_flash.hip) ----
+struct FlashParams {
+  const uint16_t* Qf; const uint16_t* Kf;   // pre-split fragment order [z][32-row block][k-step][plane][lane][8]
+  const uint16_t* Vf; long v_bs, v_ms;      // V^T fragments (accumulator key order): per-sample / per-mode strides (elements)
+  float* O;                                 // [B][M][N][Dv]
+  int B, M, N, H8, W8;
+  int nkt, nqb, nkb;                        // key tiles; 32-row blocks allocated per z for Q (multiple of 8) and K
+  unsigned w8_magic;                        // ceil(2^32 / W8): key / W8 = umulhi(key, magic) for key < 2^16
+  const float* pos_tab; int R; float pos_w; int mask_radius; const unsigned* clamp_ord;
+};
+size_t flash_ws_bytes(int B, int M, int N, int d, int score_prec);
+int launch_flash_attn(const ScoreParams& sp, const void* vT, long ldt, int Dv, float* O, void* ws, int score_prec, int pv_prec,
+                      hipStream_t s);
 
 int launch_score_max(const ScoreParams& p, unsigned* max_ord, int prec, hipStream_t s);
 int launch_corr_build(const ScoreParams& p, float w_aggr, float* pyr0, double* sums, void* ws, int prec, hipStream_t s);

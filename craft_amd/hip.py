@@ -15,6 +15,7 @@ import torch
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 W_PACKED = 0x100
+FRAG_ACC_ORDER = 0x10000      # == CRAFT_FRAG_ACC_ORDER
 STATS_REPLICAS = 64   # CRAFT_STATS_REPLICAS
 PREC_NAMES = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "f16x3": PREC_F16X3,
               "fp16x3": PREC_F16X3}
@@ -38,6 +39,7 @@ _SIGS = {
     "craft_corr_lookup": [P, P, P, P, I, P, P, I, I, I, I, P, L, I, I, P],
     "craft_attn_probs": [P, L, P, L, I, I, I, I, I, F, P, I, F, I, P, P, P, F, P, L, P, I, I, P],
     "craft_attn_apply": [P, L, P, P, I, I, I, I, P, I, P],
+    "craft_flash_attention": [P, L, P, L, P, L, I, I, I, I, I, I, F, P, I, F, I, P, P, P, I, I, P],
     "craft_mode_pool_ln": [P, P, L, P, P, I, I, I, I, P, L, P],
     "craft_gma_residual": [P, L, P, P, I, I, I, P, L, P],
     "craft_motion_encoder": [P, L, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, L, P, I, P],

@@ -98,10 +98,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], prec:
 
 
 def linear_t(x: torch.Tensor, w: torch.Tensor, ldt: int, prec: int, out: Optional[torch.Tensor] = None,
-             Dv: int = 0) -> torch.Tensor:
+             Dv: int = 0, acc_order: bool = False) -> torch.Tensor:
     """Per-sample transposed projection: yT[b][o][n] (row stride ldt >= N, tail zero), stored in the
     element type of the pv role (the type attn_apply consumes).  With ``Dv`` (the per-mode value width) and a 16-bit
-    pv type the result is in the MFMA fragment order craft_attn_apply requires (same shape / footprint)."""
+    pv type the result is in the MFMA fragment order craft_attn_apply requires (same shape / footprint);
+    ``acc_order``: the key order ``flash_attention`` requires instead."""
     B, N, Cin = x.shape
     _check_rows(x)
     Cout = w.shape[0]
@@ -109,6 +110,10 @@ def linear_t(x: torch.Tensor, w: torch.Tensor, ldt: int, prec: int, out: Optiona
     if out is None:
         out = torch.zeros(B, Cout, ldt, device=x.device, dtype=PROB_DTYPE[pv])
     frag = Dv if (Dv and pv != PREC_F32) else 0
+    if acc_order:
+        if not frag:
+            raise hip.CraftHipError("acc_order needs a 16-bit pv type and Dv")
+        frag |= hip.FRAG_ACC_ORDER
     call("craft_linear_t", x, _ld(x), w.contiguous(), out, ldt, B, N, Cin, Cout, pv, frag, pick(prec, "proj"))
     return out
 
@@ -215,6 +220,31 @@ def attn_probs(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale
          pick(prec, "pv"), pick(prec, "score"))
     if defer:
         out.craft_rowsum = rowsum[0]
+    return out
+
+
+def flash_supported(N: int, W8: int, d: int, Dv: int, prec: int) -> bool:
+    """Shapes / precisions craft_flash_attention implements (anything else: attn_probs + attn_apply)."""
+    return (d == 64 and Dv == 256 and pick(prec, "pv") == hip.PREC_F16 and pick(prec, "score") in (hip.PREC_F16, hip.PREC_F16X3)
+            and N < 65536 and W8 >= 2)
+
+
+def flash_attention(q: torch.Tensor, k: torch.Tensor, vT: torch.Tensor, H8: int, W8: int, M: int, Dv: int, scale: float,
+                    pos_tab: Optional[torch.Tensor], pos_w: float, mask_radius: int, clamp_ord: Optional[torch.Tensor], prec: int,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """O [B, M, N, Dv] = softmax(scores) @ V in one pass (the probabilities never reach memory).  ``vT`` from
+    ``linear_t(..., Dv=Dv, acc_order=True)`` with ldt = N rounded up to 32."""
+    B, N, C = q.shape
+    d = C // M
+    ldt = vT.shape[-1]
+    sp = pick(prec, "score")
+    planes = 2 if sp == hip.PREC_F16X3 else 1
+    ws = torch.empty(B * M * (8 * ((N + 255) // 256) + (N + 31) // 32) * (d // 16) * planes * 1024, device=q.device, dtype=torch.uint8)
+    if out is None:
+        out = torch.empty(B, M, N, Dv, device=q.device, dtype=torch.float32)
+    R = 0 if pos_tab is None else (pos_tab.shape[0] - 1) // 2
+    call("craft_flash_attention", q, _ld(q), k, _ld(k), vT, ldt, B, H8, W8, M, d, Dv, scale,
+         None if pos_tab is None else pos_tab.contiguous(), R, pos_w, mask_radius, clamp_ord, out, ws, sp, pick(prec, "pv"))
     return out
 
 

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import copy
 import math
+import os
 from typing import Optional
 
 import torch
@@ -142,6 +143,16 @@ class ExpandedFeatTrans(nn.Module):
         return ops.mode_pool_ln(O, input_feat, self.feat_softaggr.feat2score.weight, self.input_skip_coeff, out=out)
 
 
+    def forward_flash(self, input_feat: torch.Tensor, q: torch.Tensor, k: torch.Tensor, hw, scale: float, pos_biases, pos_w: float,
+                      mask_radius: int, clamp_ord, prec: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The same layer with the attention fused in (``ops.flash_attention``): q, k projected tokens [B, N, C]."""
+        H8, W8 = hw
+        ldt = ops.round_up(H8 * W8, 32)
+        vT = ops.linear_t(input_feat, self.first_linear.weight, ldt, prec, Dv=self.feat_dim, acc_order=True)
+        O = ops.flash_attention(q, k, vT, H8, W8, self.num_modes, self.feat_dim, scale, pos_biases, pos_w, mask_radius, clamp_ord, prec)
+        return ops.mode_pool_ln(O, input_feat, self.feat_softaggr.feat2score.weight, self.input_skip_coeff, out=out)
+
+
 class CrossAttFeatTrans(nn.Module):
     def __init__(self, config: SETransConfig, name: str):
         super().__init__()
@@ -210,12 +221,17 @@ class CrossAttFeatTrans(nn.Module):
         q, k = self.project(query_feat, key_feat, prec)
         scale = 1.0 / math.sqrt(self.attention_mode_dim)
         mx = ops.score_max(q, k, H8, W8, self.num_modes, scale, prec)
+        kf = query_feat if key_feat is None else key_feat
+        if (self.out_trans is not None and not defer and not os.environ.get("CRAFT_NO_FLASH")
+                and ops.flash_supported(H8 * W8, W8, self.attention_mode_dim, self.out_trans.feat_dim, prec)):
+            # probabilities used once: fused scores -> online softmax -> P.V, nothing N x N in memory
+            return self.out_trans.forward_flash(kf, q, k, hw, scale, pos_biases, float(self.pos_code_weight),
+                                                attention_mask_radius, mx, prec)
         # P that is consumed right here (or by a caller that asked for it, `defer`) skips the normalisation pass
         P = ops.attn_probs(q, k, H8, W8, self.num_modes, scale, pos_biases, float(self.pos_code_weight),
                            attention_mask_radius, mx, prec, defer=defer or not self.out_attn_probs_only)
         if self.out_attn_probs_only:
             return P
-        kf = query_feat if key_feat is None else key_feat
         return self.out_trans(kf, P, prec=prec)
 
 

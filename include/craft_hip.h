@@ -64,6 +64,9 @@ int craft_linear(const float* x, long ldx, const float* w, const float* bias, fl
  * 16-bit craft_attn_apply streams from L2 straight into MFMA operand registers (same footprint: Dv * ldt values). */
 int craft_linear_t(const float* x, long ldx, const float* w, void* yT, long ldt, int B, int N, int cin,
                    int cout, int out_prec, int frag_rows, int prec, void* stream);
+/* or-ed into frag_rows: the 16 keys of a k-group are enumerated in MFMA ACCUMULATOR order (position 8*h + j holds key
+ * 8*(j >> 2) + 4*h + (j & 3)) -- the V^T operand of craft_flash_attention, whose P operand is a score accumulator. */
+#define CRAFT_FRAG_ACC_ORDER 0x10000
 
 /* Global max of the raw scaled scores Q_m K_m^T * scale over batch, modes, i, j (the .max().item() of
  * setrans.py:520-521) as an order-preserving uint in *max_ord; consumers clamp to [-100, 100] iff that max
@@ -124,6 +127,17 @@ int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, 
  * normalised P, else the row sums craft_attn_probs produced with it (O rows are divided by them). */
 int craft_attn_apply(const void* P, long ldp, const float* rowsum, const void* vT, int B, int N, int M, int Dv, float* O,
                      int prec, void* stream);
+
+/* CrossAttFeatTrans + the matmul of ExpandedFeatTrans in one pass (setrans.py:507-557 + :384) for a layer whose
+ * probabilities are used once (the F2 feature transformer): O[b][m][i][:] = sum_j softmax_j(clamp?(Q_m(i).K_m(j)*scale) +
+ * pos_w*pb(i,j) + mask) V_m[j][:] with an online softmax -- the N x N probabilities never exist in memory.  Arguments as
+ * craft_attn_probs (no relative-position scores) and craft_attn_apply; vT from craft_linear_t(out_prec = pv_prec,
+ * frag_rows = Dv | CRAFT_FRAG_ACC_ORDER), row stride ldt = N rounded up to 32.  ws: scratch for the pre-split Q / K
+ * fragments, B*M * (8*ceil(N/256) + ceil(N/32)) * (d/16) * planes * 1024 bytes (planes = 2 for score_prec 3, else 1).  Supported: d = 64, Dv = 256, score_prec 2 (fp16) or 3 (f16x3), pv_prec 2, N < 65536;
+ * anything else returns CRAFT_ERR_UNSUPPORTED (10003) and the caller uses craft_attn_probs + craft_attn_apply. */
+int craft_flash_attention(const float* q, long ldq, const float* k, long ldk, const void* vT, long ldt, int B, int H8, int W8,
+                          int M, int d, int Dv, float scale, const float* pos_tab, int R, float pos_w, int mask_radius,
+                          const unsigned* clamp_ord, float* O, void* ws, int score_prec, int pv_prec, void* stream);
 
 /* ExpandedFeatTrans.forward tail (setrans.py:395-407): a_m = softmax_m(<O_m, w_agg>), out = LayerNorm(
  * skip_coeff * x + sum_m a_m O_m).  C = Dv in {64,128,192,256}. */

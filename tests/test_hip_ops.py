@@ -261,6 +261,40 @@ def test_expanded_feat_trans(device, prec, C):
     close(y, ref, rt * 5, at * 5, "ExpandedFeatTrans")
 
 
+@pytest.mark.parametrize("score", [PREC_F16X3, PREC_F16])
+@pytest.mark.parametrize("H8,W8,mask_radius,gain", [(13, 19, -1, 2.5), (16, 32, 5, 2.5), (9, 40, -1, 80.0), (5, 6, -1, 2.5)])
+def test_flash_attention(device, score, H8, W8, mask_radius, gain):
+    """craft_flash_attention (scores -> online softmax -> P.V in one pass) vs the oracle's probabilities times V, and vs
+    the two-kernel path (craft_attn_probs + craft_attn_apply) it replaces.  Ragged N, the positional window, the
+    Chebyshev mask, and (gain 80) the score clamp are all exercised."""
+    B, C, M, Dv = 2, 256, 4, 256
+    N = H8 * W8
+    x, _, Wq, Wk, _ = _qk(B, H8, W8, C, seed=150, gain=gain)
+    tab = gen(15, 15, seed=151) * 0.5
+    Wv = gen(M * Dv, C, seed=152) / math.sqrt(C)
+    Pref = O.self_attn_probs(x, Wq, Wk, tab, 1.0, M, H8, W8, mask_radius)                       # [B, M, N, N]
+    V = F.linear(x, Wv).reshape(B, N, M, Dv).permute(0, 2, 1, 3)
+    Oref = torch.matmul(Pref, V)
+    prec = hip.Precision(proj=PREC_F32, score=score, pv=PREC_F16)
+    xd = x.to(device)
+    q = ops.linear(xd, Wq.to(device), None, PREC_F32)
+    k = ops.linear(xd, Wk.to(device), None, PREC_F32)
+    scale = 1.0 / math.sqrt(C // M)
+    mx = ops.score_max(q, k, H8, W8, M, scale, prec)
+    assert ops.flash_supported(N, W8, C // M, Dv, prec)
+    ldt = ops.round_up(N, 32)
+    vT = ops.linear_t(xd, Wv.to(device), ldt, prec, Dv=Dv, acc_order=True)
+    Of = ops.flash_attention(q, k, vT, H8, W8, M, Dv, scale, tab.to(device), 1.0, mask_radius, mx, prec)
+    assert Of.shape == (B, M, N, Dv)
+    # two-kernel path with the same roles
+    P = ops.attn_probs(q, k, H8, W8, M, scale, tab.to(device), 1.0, mask_radius, mx, prec, defer=True)
+    O2 = ops.attn_apply(P, ops.linear_t(xd, Wv.to(device), ldt, prec, Dv=Dv), Dv, prec)
+    # fp16 P and V: 2^-11 relative per operand of a convex combination of O(1) values
+    tol = 2e-3 if score == PREC_F16X3 else 2e-2
+    close(Of, Oref, tol, tol, "flash attention vs oracle")
+    close(Of, O2, tol, tol, "flash attention vs attn_probs + attn_apply")
+
+
 def _conv_sd(seed=70):
     from craft_amd import CRAFT, default_args
     from craft_amd.synth import synth_state_dict
