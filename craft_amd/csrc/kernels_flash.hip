@@ -17,7 +17,7 @@
 //   * K / V^T tiles (8 + 16 KB at d = 64, Dv = 256) are shared by the 8 waves of a block through LDS (double buffer,
 //     fragment order = conflict-free ds_read_b128); global -> registers one tile ahead, registers -> LDS after the
 //     MFMAs, one barrier per tile.
-// grid (ceil(N / 256), B*M), 512 threads: wave w owns queries [256*bx + 32*w, +32).
+// grid ceil(N / 256) * B*M (XCD-aware mapping, see the kernel), 512 threads: wave w owns queries [256*bx + 32*w, +32).
 #include "launch.hpp"
 
 namespace craft {
@@ -50,10 +50,16 @@ __global__ __launch_bounds__(512) void k_flash_attn(FlashParams p) {
   __shared__ float s_tab[FLASH_TABW * FLASH_TABW];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int z = blockIdx.y, b = z / p.M, m = z - b * p.M;
+  // XCD-aware work mapping: the hardware deals consecutive block ids round-robin over the 8 XCDs (each with its own L2).
+  // Every block of one z streams the same K / V^T (5.5 MB at 448x1024), so the blocks of a z are given to ONE XCD:
+  // virtual id v = (blocks of lower XCDs) + (id / 8), z = v / nqx, query block = v % nqx  (bijective for any count).
+  const int nqx = (p.N + 255) / 256, total = nqx * p.B * p.M;
+  const int xcd = blockIdx.x & 7, qn = total >> 3, rn = total & 7;
+  const int v = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
+  const int z = v / nqx, bx = v - z * nqx, b = z / p.M, m = z - b * p.M;
   const int N = p.N, W8 = p.W8, R = p.R;
-  const int q0 = blockIdx.x * 256;
-  const int qb = blockIdx.x * 8 + wave;
+  const int q0 = bx * 256;
+  const int qb = bx * 8 + wave;
   const int qidx = qb * 32 + (lane & 31);
   const int hh = lane >> 5;
 
@@ -124,21 +130,35 @@ __global__ __launch_bounds__(512) void k_flash_attn(FlashParams p) {
     fetch(min(t + 1, nkt - 1));
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- S^T = K . Q^T (32 keys x 32 queries), base-2 logits
+    // ---- S^T = K . Q^T (32 keys x 32 queries), base-2 logits.  All K fragments are requested up front (counted waits).
     const uint16_t* Kt = &St[buf * TILE_H + lane * 8];
+    const uint16_t* Vt = &St[buf * TILE_H + KT_H + lane * 8];
+    f16x8 kf[KS][PL];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < PL; ++pl) kf[ks][pl] = *reinterpret_cast<const f16x8*>(Kt + (ks * PL + pl) * 512);
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 s;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const f16x8 ah = *reinterpret_cast<const f16x8*>(Kt + (ks * PL) * 512);
       if constexpr (PL == 2) {
-        const f16x8 al = *reinterpret_cast<const f16x8*>(Kt + (ks * PL + 1) * 512);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qf[ks][0], s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qf[ks][1], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][1], qf[ks][0], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], qf[ks][1], s, 0, 0, 0);
       }
-      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qf[ks][0], s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], qf[ks][0], s, 0, 0, 0);
     }
+    // the first V^T fragments travel while the softmax runs (they take the registers of the K fragments)
+    constexpr int VPF = NB < 2 ? NB : 2;
+    f16x8 va[VPF][2];
+#pragma unroll
+    for (int nb = 0; nb < VPF; ++nb) {
+      va[nb][0] = *reinterpret_cast<const f16x8*>(Vt + nb * 512);
+      va[nb][1] = *reinterpret_cast<const f16x8*>(Vt + (NB + nb) * 512);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- bias window / mask / clamp / ragged last tile: one block-uniform branch per tile
     const int j0 = t * 32;
@@ -181,14 +201,17 @@ __global__ __launch_bounds__(512) void k_flash_attn(FlashParams p) {
       pb[e >> 3][e & 7] = (_Float16)ex;
     }
 
-    // ---- O^T += V^T . P^T
-    const uint16_t* Vt = &St[buf * TILE_H + KT_H + lane * 8];
+    // ---- O^T += V^T . P^T; a fragment pair is re-requested (4 blocks ahead) right after the MFMAs that consumed it
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      const f16x8 a0 = *reinterpret_cast<const f16x8*>(Vt + nb * 512);
-      const f16x8 a1 = *reinterpret_cast<const f16x8*>(Vt + (NB + nb) * 512);
-      o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, pb[0], o[nb], 0, 0, 0);
-      o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, pb[1], o[nb], 0, 0, 0);
+      o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[nb % VPF][0], pb[0], o[nb], 0, 0, 0);
+      o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[nb % VPF][1], pb[1], o[nb], 0, 0, 0);
+      if (nb + VPF < NB) {
+        va[nb % VPF][0] = *reinterpret_cast<const f16x8*>(Vt + (nb + VPF) * 512);
+        va[nb % VPF][1] = *reinterpret_cast<const f16x8*>(Vt + (NB + nb + VPF) * 512);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
     stash(buf ^ 1);
@@ -286,7 +309,7 @@ int launch_flash_attn(const ScoreParams& sp, const void* vT, long ldt, int Dv, f
   p.nkt = nkb; p.nqb = nqb; p.nkb = nkb;
   p.w8_magic = (unsigned)((0x100000000ULL + (unsigned)sp.W8 - 1) / (unsigned)sp.W8);
   p.pos_tab = sp.pos_tab; p.R = sp.R; p.pos_w = sp.pos_w; p.mask_radius = sp.mask_radius; p.clamp_ord = sp.clamp_ord;
-  dim3 grid((sp.N + 255) / 256, Z);
+  dim3 grid(((sp.N + 255) / 256) * Z);
   if (PL == 2) hipLaunchKernelGGL((k_flash_attn<64, 256, 2>), grid, dim3(512), 0, s, p);
   else hipLaunchKernelGGL((k_flash_attn<64, 256, 1>), grid, dim3(512), 0, s, p);
   return (int)hipGetLastError();

@@ -13,6 +13,6 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   i=$((i+1))
   rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -o k -- python $REPO/tools/run_kernel.py $W $POL > /dev/null 2> $OUT/pmc$i.err
   f=$(find $OUT/pmc$i -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then python $REPO/tools/kstats.py $f | grep -A12 -E "k_gemm|k_attn|k_corr|k_conv|k_pv" | head -40; else tail -3 $OUT/pmc$i.err; fi
+  if [ -n "$f" ]; then python $REPO/tools/kstats.py $f | grep -A12 -E "k_gemm|k_attn|k_corr|k_conv|k_pv|k_flash" | head -40; else tail -3 $OUT/pmc$i.err; fi
 done
 rm -rf $OUT/trace $OUT/pmc*/ 2>/dev/null

@@ -70,8 +70,28 @@ def main():
         tab = torch.randn(15, 15, device=dev)
         for _ in range(2):
             ops.attn_probs(q, k, H8, W8, Mm, 1 / math.sqrt(C // Mm), tab, 1.0, -1, None, prec, defer=which == "probs")
-    elif which == "probsn":
-        pass
+    elif which == "flash":
+        import math
+        C, Mm, Dvf = 256, 4, 256
+        q = torch.randn(B, N, C, device=dev)
+        k = torch.randn(B, N, C, device=dev)
+        x = torch.randn(B, N, C, device=dev)
+        Wv = torch.randn(Mm * Dvf, C, device=dev) / 16
+        tab = torch.randn(15, 15, device=dev)
+        ldt = ops.round_up(N, 32)
+        vT = ops.linear_t(x, Wv, ldt, prec, Dv=Dvf, acc_order=True)
+        O = torch.empty(B, Mm, N, Dvf, device=dev)
+        reps = int(os.environ.get("REPS", 5))
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ops.flash_attention(q, k, vT, H8, W8, Mm, Dvf, 1 / math.sqrt(C // Mm), tab, 0.5, -1, None, prec, out=O)
+        s.record()
+        for _ in range(reps):
+            ops.flash_attention(q, k, vT, H8, W8, Mm, Dvf, 1 / math.sqrt(C // Mm), tab, 0.5, -1, None, prec, out=O)
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / reps
+        flop = 2.0 * B * Mm * N * N * (3 * 64 + Dvf)
+        print(f"flash attention (pack + kernel): {ms:.3f} ms  = {flop / ms / 1e9:.0f} TFLOP/s executed (f16x3 scores)")
     torch.cuda.synchronize()
 
 
