@@ -80,7 +80,7 @@ def op_table(model, im1, im2, iters):
 def roofline_pv(model, B, H8, W8, prec, reps=20):
     """Time the aggregator's P.V GEMM alone (same shapes as in the forward) with HIP events."""
     from craft_amd import ops
-    from craft_amd.hip import PROB_DTYPE, pick
+    from craft_amd.hip import PREC_F16, PROB_DTYPE, pick
     prec = pick(prec, "pv")
     dev = torch.device("cuda")
     N, M, Dv = H8 * W8, 4, 128
@@ -100,11 +100,24 @@ def roofline_pv(model, B, H8, W8, prec, reps=20):
     ms = s.elapsed_time(e) / reps
     bytes_alg = P.numel() * P.element_size() + vT.numel() * vT.element_size() + O.numel() * 4
     ach = bytes_alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "k_pv16 (attention apply O = P.V of the motion aggregator, 13 launches per forward)",
-            "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+    # HBM bytes per launch from the committed PMC passes of this kernel at this shape (rocprofv3 --pmc FETCH_SIZE and
+    # --pmc WRITE_SIZE in separate runs, gfx950 x2 correction on FETCH_SIZE: profiles/r1/pmc_traffic_pv16.json);
+    # only quoted when the live shape is the profiled one
+    traffic = None
+    try:
+        import json as _json
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1", "pmc_traffic_pv16.json")) as fh:
+            pmc = _json.load(fh)
+        if (B, H8, W8) == (4, 56, 128) and prec == PREC_F16:
+            traffic = int(pmc["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return {"bound": "hbm", "kernel": "k_pv16 (attention apply O = P.V of the motion aggregator, 12 launches per forward)",
+            "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
             "bytes_per_launch": bytes_alg, "ms_per_launch": round(ms, 4),
-            "note": "algorithmic bytes = P (fp16, read once) + V^T + O; measured read-only ceiling of this access pattern on "
-                    "the same chip: 6.1 TB/s (tools/ubench/hbm_rows.hip); PMC traffic: profiles/"}
+            "note": "algorithmic bytes = P (fp16, read once) + V^T + O; traffic = HBM bytes per launch from the PMC passes "
+                    "committed under profiles/r1 (FETCH_SIZE x2 on gfx950 + WRITE_SIZE); measured read-only ceiling of this "
+                    "access pattern on the same chip: 6.1 TB/s (tools/ubench/hbm_rows.hip)"}
 
 
 def roofline_conv(B, H8, W8, prec, reps=20):

@@ -18,6 +18,7 @@ def cls(t):
     if op == "s_waitcnt": return "[" + t.split(None, 1)[1].replace(" ", "") + "]"
     if op == "s_barrier": return "|"
     if op.startswith(("s_cbranch", "s_branch")): return "b"
+    if op.startswith("v_exp"): return "x"
     if op.startswith("s_"): return "s"
     if op.startswith("v_"): return "v"
     return "?"
