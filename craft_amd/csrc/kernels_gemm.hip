@@ -285,18 +285,22 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_conv(ConvGemmParams p) {
   CONV_EPI_DISPATCH(p, BODY)
 #undef BODY
   if (ENC && p.stats) {
-    // all rows of a tile must belong to one image (checked by the launcher: H*W % 128 == 0)
+    // a 128-row tile may straddle images (H*W not a multiple of 128): one masked pass per image it touches
     const int hw = p.g.H * p.g.W;
-    unsigned mlo = 0u, mhi = 0u;
+    const int b_first = m0 / hw, b_last = min(m0 + BM - 1, M - 1) / hw;
+    for (int b = b_first; b <= b_last; ++b) {
+      const long lo = (long)b * hw, hi = min(lo + hw, (long)M);
+      unsigned mlo = 0u, mhi = 0u;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int r = rb + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const int bit = mt * 16 + e;
-        if (r < M) { if (bit < 32) mlo |= 1u << bit; else mhi |= 1u << (bit - 32); }
-      }
-    conv_col_stats<MT, NT>(p, acc, lane, cb, (long)(m0 / hw), mlo, mhi);
+        for (int e = 0; e < 16; ++e) {
+          const int r = rb + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          const int bit = mt * 16 + e;
+          if (r >= lo && r < hi) { if (bit < 32) mlo |= 1u << bit; else mhi |= 1u << (bit - 32); }
+        }
+      conv_col_stats<MT, NT>(p, acc, lane, cb, (long)b, mlo, mhi);
+    }
   }
 }
 
@@ -317,7 +321,6 @@ int launch_gemm_conv(const ConvGemmParams& p, int prec, hipStream_t s) {
   }
   if (p.w_packed) return CRAFT_ERR_UNSUPPORTED;     // the generic implicit GEMM reads raw fp32 weights
   if (p.g.in_norm) return CRAFT_ERR_UNSUPPORTED;    // lazy input normalisation is a k_conv_halo feature
-  if (p.stats && (p.g.H * p.g.W) % 128) return CRAFT_ERR_UNSUPPORTED;
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   const int bn = pick_bn(ncols);
 #define GO(PR) do { if (bn == 128) return launch_conv_t<PR, 128>(p, s); else return launch_conv_t<PR, 64>(p, s); } while (0)

@@ -66,10 +66,7 @@ class HipEncoder:
     def supported(self, H: int, W: int) -> bool:
         if self.kind not in ("instance", "batch") or self.enc.training:
             return False
-        if H % 8 or W % 8:
-            return False
-        # stride-2 convs accumulate InstanceNorm statistics per 128-row tile: each image must be a whole number of tiles
-        return self.kind == "batch" or (((H // 4) * (W // 4)) % 128 == 0 and ((H // 8) * (W // 8)) % 128 == 0)
+        return not (H % 8 or W % 8)
 
     def _blocks(self):
         e = self.enc

@@ -174,15 +174,16 @@ def test_full_size_attention_and_volume_statistics(device):
 
 @pytest.mark.parametrize("which", ["fnet", "cnet"])
 @pytest.mark.parametrize("precision", ["fp32", "mixed"])
-def test_hip_encoder_matches_pytorch_module(device, which, precision):
+@pytest.mark.parametrize("H,W", [(128, 256), (376, 1248), (136, 200)])      # (KITTI-padded and small: statistics tiles straddle images)
+def test_hip_encoder_matches_pytorch_module(device, which, precision, H, W):
     """craft_amd.hip_encoder.HipEncoder (lazy InstanceNorm / folded BatchNorm, fused residual tails) against the
     PyTorch BasicEncoder module it wraps, same weights, on the GPU (extractor.py:124-196)."""
     from craft_amd.hip import Precision
     from craft_amd.hip_encoder import HipEncoder
     model = _full_model(device, precision)
     enc = getattr(model, which)
-    im1, im2, _ = synth_pair(2, 128, 256, seed=5)
-    raw = torch.cat([im1, im2]).to(device)
+    im1, im2, _ = synth_pair(2 if H * W < 200000 else 1, H, W, seed=5)
+    raw = torch.cat([im1, im2, im1[:1]]).to(device)            # odd batch: tiles straddle more often
     with torch.no_grad():
         ref = enc(2 * (raw / 255.0) - 1)
         got = HipEncoder(enc).forward_tokens(raw, Precision.parse(precision))
@@ -238,3 +239,27 @@ def test_batch_sliced_streams_match_single_stream(device):
     assert (lo1 - lo2).abs().max().item() < 1e-4
     for a, b in zip(ups1, ups2):
         assert (a - b).abs().max().item() < 1e-4
+
+
+def test_side_streams_and_fused_attention_do_not_change_results(device, monkeypatch):
+    """The context chain / flow branch on side streams (args.hip_fork, CRAFT_NO_FORK) only reorder independent work, and the
+    flash-fused F2 attention (CRAFT_NO_FLASH -> attn_probs + attn_apply) is the same layer with an online softmax: the
+    predictions agree to the fp16 rounding of P (mixed policy: fp16 P.V in both paths)."""
+    g = Golden("canon_b2_128x192_T3_init")
+    im1, im2 = (t.to(device) for t in g.images())
+
+    def run(env):
+        for k in ("CRAFT_NO_FORK", "CRAFT_NO_FLASH"):
+            monkeypatch.delenv(k, raising=False)
+        for k in env:
+            monkeypatch.setenv(k, "1")
+        model = build(g, device, precision="mixed")
+        with torch.no_grad():
+            out = model(im1, im2, iters=3, test_mode=1)
+        torch.cuda.synchronize()
+        return out
+    lo, up = run(())
+    lo_nf, up_nf = run(("CRAFT_NO_FORK",))
+    lo_nl, up_nl = run(("CRAFT_NO_FLASH",))
+    assert (up - up_nf).abs().max().item() < 1e-4, "side streams changed the result"
+    assert (up - up_nl).abs().max().item() < 5e-3 and (lo - lo_nl).abs().max().item() < 1e-3, "fused attention deviates"
