@@ -171,6 +171,10 @@ int craft_attn_apply(const void* P, long ldp, const float* rowsum, const void* v
   return launch_pv16(p, prec, S(stream));
 }
 
+int craft_forward_interpolate(const float* flow, int B, int H, int W, float* out, void* stream) {
+  return launch_forward_interpolate(flow, B, H, W, out, S(stream));
+}
+
 int craft_mode_pool_ln(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff, int B, int N,
                        int M, int C, float* out, long ldo, void* stream) {
   return launch_mode_pool_ln(O, x, ldx, w_agg, skip_coeff, B, N, M, C, out, ldo, S(stream));

@@ -824,4 +824,54 @@ int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr,
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Warm start: forward_interpolate (core/utils/utils.py:34-62).  out[:, y0, x0] = flow of the source pixel whose warped
+// position (x + dx, y + dy) is nearest to (x0, y0), among the sources that land strictly inside (0, W) x (0, H).
+// Brute force in float64 (the reference's griddata works on float64 coordinates): one thread per target pixel, the
+// sources of the image stream through LDS in chunks; an invalid source is parked at +inf.  Ties: lowest source index.
+// ---------------------------------------------------------------------------------------------
+constexpr int FI_CHUNK = 1024;
+__global__ __launch_bounds__(256) void k_forward_interpolate(const float* __restrict__ flow, int H, int W, float* __restrict__ out) {
+  __shared__ double sx[FI_CHUNK], sy[FI_CHUNK];
+  const int b = blockIdx.y, HW = H * W;
+  const float* fx = flow + (long)b * 2 * HW;
+  const float* fy = fx + HW;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int ty = t / W, tx = t - ty * W;
+  const double gx = tx, gy = ty;
+  double best = INFINITY;
+  int bi = -1;
+  for (int c0 = 0; c0 < HW; c0 += FI_CHUNK) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < FI_CHUNK; i += 256) {
+      const int j = c0 + i;
+      double x1 = INFINITY, y1 = INFINITY;
+      if (j < HW) {
+        const int y = j / W, x = j - y * W;
+        const double ax = (double)x + (double)fx[j], ay = (double)y + (double)fy[j];
+        if (ax > 0.0 && ax < (double)W && ay > 0.0 && ay < (double)H) { x1 = ax; y1 = ay; }
+      }
+      sx[i] = x1; sy[i] = y1;
+    }
+    __syncthreads();
+    const int n = min(FI_CHUNK, HW - c0);
+    for (int i = 0; i < n; ++i) {
+      const double ex = sx[i] - gx, ey = sy[i] - gy;
+      const double d2 = ex * ex + ey * ey;          // (inf for parked sources: never < best)
+      if (d2 < best) { best = d2; bi = c0 + i; }
+    }
+  }
+  if (t < HW) {
+    out[(long)b * 2 * HW + t] = bi >= 0 ? fx[bi] : 0.f;
+    out[(long)b * 2 * HW + HW + t] = bi >= 0 ? fy[bi] : 0.f;
+  }
+}
+
+int launch_forward_interpolate(const float* flow, int B, int H, int W, float* out, hipStream_t s) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  dim3 grid((H * W + 255) / 256, B);
+  hipLaunchKernelGGL(k_forward_interpolate, grid, dim3(256), 0, s, flow, H, W, out);
+  return (int)hipGetLastError();
+}
+
 }  // namespace craft

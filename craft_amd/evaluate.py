@@ -51,12 +51,12 @@ class FlowMetrics:
         return out
 
 
-def _predict(model, image1, image2, iters, pad_mode, device):
+def _predict(model, image1, image2, iters, pad_mode, device, flow_init=None):
     """pad -> forward (test_mode=1) -> unpad; images [B, 3, H, W] float 0..255 on any device."""
     image1, image2 = image1.to(device), image2.to(device)
     padder = InputPadder(image1.shape, mode=pad_mode, mod=8)
     image1, image2 = padder.pad(image1, image2)
-    flow_low, flow_up = model(image1, image2, iters=iters, test_mode=1)
+    flow_low, flow_up = model(image1, image2, iters=iters, flow_init=flow_init, test_mode=1)
     return flow_low, padder.unpad(flow_up)
 
 
@@ -123,15 +123,26 @@ def validate_kitti(model, root="datasets/KITTI", iters=6, batch_size=1, max_val_
 
 @torch.no_grad()
 def create_sintel_submission(model, root="datasets/Sintel", output_path="sintel_submission", iters=32, split="test",
-                             device="cuda"):
-    """One ``frameXXXX.flo`` per pair under <output_path>/<clean|final>/<scene>/ (evaluate.py:106-150)."""
+                             device="cuda", warm_start=False):
+    """One ``frameXXXX.flo`` per pair under <output_path>/<clean|final>/<scene>/ (evaluate.py:106-150).
+    ``warm_start``: the low-resolution flow of a frame, forward-interpolated on the GPU (``utils.forward_interpolate``),
+    initialises the next frame of the same scene (RAFT's warm start).  The reference computes that field
+    (evaluate.py:146-147) but never passes it to the model, so its submissions equal
+    ``warm_start=False``, the default here."""
+    from .utils import forward_interpolate
     model.eval()
     for dst in ("clean", "final"):
         ds = MpiSintel(split=split, root=root, dstype=dst)
         ds.is_test = True
+        flow_prev, scene_prev = None, None
         for i in range(len(ds)):
             image1, image2, (scene, frame_id) = ds[i]
-            _, flow = _predict(model, image1[None], image2[None], iters, "sintel", device)
+            if scene != scene_prev:
+                flow_prev = None
+            scene_prev = scene
+            flow_low, flow = _predict(model, image1[None], image2[None], iters, "sintel", device, flow_init=flow_prev)
+            if warm_start:
+                flow_prev = forward_interpolate(flow_low[0])[None]
             out_dir = os.path.join(output_path, dst, scene)
             os.makedirs(out_dir, exist_ok=True)
             flow_io.write_flo(os.path.join(out_dir, "frame%04d.flo" % (frame_id + 1)), flow[0].permute(1, 2, 0).cpu().numpy())
@@ -172,6 +183,7 @@ def main(argv=None):
     ap.add_argument("--output", default=None, help="output directory of the submission writers")
     ap.add_argument("--fullprec", dest="mixed_precision", action="store_false", help="exact fp32 MFMA path (evaluate.py:1455)")
     ap.add_argument("--hip_precision", default=None)
+    ap.add_argument("--warm_start", action="store_true", help="sintel_submission: initialise each frame with the previous flow")
     ns = ap.parse_args(argv)
     ns.mixed_precision = bool(ns.mixed_precision)
     model = build_model(ns)
@@ -183,7 +195,8 @@ def main(argv=None):
     if ns.dataset == "kitti":
         return validate_kitti(model, ns.root or "datasets/KITTI", ns.iters or 24, ns.batch_size, ns.max_val_count)
     if ns.dataset == "sintel_submission":
-        return create_sintel_submission(model, ns.root or "datasets/Sintel", ns.output or "sintel_submission", ns.iters or 32)
+        return create_sintel_submission(model, ns.root or "datasets/Sintel", ns.output or "sintel_submission", ns.iters or 32,
+                                        warm_start=ns.warm_start)
     return create_kitti_submission(model, ns.root or "datasets/KITTI", ns.output or "kitti_submission", ns.iters or 24)
 
 

@@ -28,6 +28,23 @@ class InputPadder:
         return x[..., self._pad[2]: ht - self._pad[3], self._pad[0]: wd - self._pad[1]]
 
 
+def forward_interpolate(flow: torch.Tensor) -> torch.Tensor:
+    """Warm-start helper (utils.py:34-62): map the flow of each pixel to the location it points to (nearest forward-
+    warped source per pixel).  flow [2, H, W] or [B, 2, H, W] on the GPU -> same shape, on the GPU (``craft_forward_interpolate``;
+    the reference round-trips through numpy / scipy on the CPU)."""
+    from .hip import call
+    if not flow.is_cuda:
+        raise RuntimeError("forward_interpolate runs as a HIP kernel: the flow must be on the GPU (no CPU fallback)")
+    f = flow.detach().float().contiguous()
+    f4 = f[None] if f.dim() == 3 else f
+    B, two, H, W = f4.shape
+    if two != 2:
+        raise ValueError("flow must be [2, H, W] or [B, 2, H, W]")
+    out = torch.empty_like(f4)
+    call("craft_forward_interpolate", f4, B, H, W, out)
+    return out[0] if f.dim() == 3 else out
+
+
 def coords_grid(batch: int, ht: int, wd: int, device=None) -> torch.Tensor:
     """[B, 2, ht, wd] with channel 0 = x (column), channel 1 = y (row)  (utils.py:82-85)."""
     ys, xs = torch.meshgrid(torch.arange(ht, device=device, dtype=torch.float32),

@@ -139,6 +139,11 @@ int craft_flash_attention(const float* q, long ldq, const float* k, long ldk, co
                           int M, int d, int Dv, float scale, const float* pos_tab, int R, float pos_w, int mask_radius,
                           const unsigned* clamp_ord, float* O, void* ws, int score_prec, int pv_prec, void* stream);
 
+/* Warm start, forward_interpolate (core/utils/utils.py:34-62): flow, out [B][2][H][W] (NCHW, dx then dy).  Every pixel takes
+ * the flow of the source pixel whose forward-warped position is nearest (float64 distances, like the reference's
+ * griddata(..., 'nearest') on float64 coordinates), among sources landing strictly inside (0, W) x (0, H); none: zeros. */
+int craft_forward_interpolate(const float* flow, int B, int H, int W, float* out, void* stream);
+
 /* ExpandedFeatTrans.forward tail (setrans.py:395-407): a_m = softmax_m(<O_m, w_agg>), out = LayerNorm(
  * skip_coeff * x + sum_m a_m O_m).  C = Dv in {64,128,192,256}. */
 int craft_mode_pool_ln(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff,

@@ -504,3 +504,32 @@ def craft_forward(sd, cfg: OracleConfig, image1: Tensor, image2: Tensor, iters: 
         if capture is not None:
             capture.update(fmap1=fmap1, fmap2=fmap2, net0=net, inp=inp)
         return hot_path(fmap1, fmap2, net, inp, sd, cfg, iters, flow_init, test_mode, capture)
+
+
+# ------------------------------------------------------------------------------------------------
+# warm start
+# ------------------------------------------------------------------------------------------------
+def forward_interpolate(flow: Tensor) -> Tensor:
+    """core/utils/utils.py:34-62 restated without scipy: every pixel (x0, y0) of the grid takes the flow of the NEAREST
+    forward-warped source point (x0' + dx, y0' + dy) among those that land strictly inside (0, W) x (0, H); distances in
+    float64 like griddata('nearest') on the float64 coordinates the reference builds (int64 grid + float32 flow).  Exact
+    ties (measure zero for real flows) go to the lowest source index here; a k-d tree may pick another of the tied points.
+    flow [2, H, W] -> [2, H, W] float32; no valid source point at all: zeros (the reference's fill value)."""
+    import numpy as np
+    f = flow.detach().cpu().numpy().astype(np.float32)
+    dx, dy = f[0], f[1]
+    H, W = dx.shape
+    x0, y0 = np.meshgrid(np.arange(W), np.arange(H))
+    x1 = (x0 + dx.astype(np.float64)).reshape(-1)
+    y1 = (y0 + dy.astype(np.float64)).reshape(-1)
+    valid = (x1 > 0) & (x1 < W) & (y1 > 0) & (y1 < H)
+    if not valid.any():
+        return torch.zeros(2, H, W)
+    xs, ys, vx, vy = x1[valid], y1[valid], dx.reshape(-1)[valid], dy.reshape(-1)[valid]
+    out = np.zeros((2, H * W), dtype=np.float32)
+    gx, gy = x0.reshape(-1).astype(np.float64), y0.reshape(-1).astype(np.float64)
+    for s in range(0, H * W, 2048):                                   # blocks of targets: [2048, n_valid] distances
+        d2 = (gx[s:s + 2048, None] - xs[None]) ** 2 + (gy[s:s + 2048, None] - ys[None]) ** 2
+        j = np.argmin(d2, axis=1)
+        out[0, s:s + 2048], out[1, s:s + 2048] = vx[j], vy[j]
+    return torch.from_numpy(out.reshape(2, H, W))

@@ -100,3 +100,15 @@ def test_validate_drivers_on_miniature_datasets(device, tmp_path):
     with torch.no_grad():
         _, up0 = evaluate._predict(model, im1[:1], im2[:1], 3, "sintel", device)
     assert np.abs(sub - up0[0].permute(1, 2, 0).cpu().numpy()).max() < 1e-4
+    # ---- warm start: the second pair of a scene starts from the forward-interpolated low-res flow of the first
+    from craft_amd.utils import forward_interpolate
+    flow_io.write_image(str(root / "test" / "clean" / "s0" / "frame_0003.png"), u8(im1[0]))
+    flow_io.write_image(str(root / "test" / "final" / "s0" / "frame_0003.png"), u8(im1[0]))
+    out2 = tmp_path / "sub_ws"
+    evaluate.create_sintel_submission(model, root=str(root), output_path=str(out2), iters=3, device=device, warm_start=True)
+    with torch.no_grad():
+        lo0, _ = evaluate._predict(model, im1[:1], im2[:1], 3, "sintel", device)
+        _, up1 = evaluate._predict(model, im2[:1], im1[:1], 3, "sintel", device, flow_init=forward_interpolate(lo0[0])[None])
+    sub1 = flow_io.read_flo(str(out2 / "clean" / "s0" / "frame0002.flo"))
+    assert np.abs(sub1 - up1[0].permute(1, 2, 0).cpu().numpy()).max() < 1e-4
+    assert np.abs(flow_io.read_flo(str(out2 / "clean" / "s0" / "frame0001.flo")) - sub).max() < 1e-4   # first frame: no init

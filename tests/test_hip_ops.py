@@ -410,3 +410,20 @@ def test_conv2d_tokens(device, prec, KH, KW, cin, cout, relu):
         wp = ops.pack_conv_prec(w.to(device), prec) if packed else ops.pack_conv(w.to(device))
         y = ops.conv2d_tokens(xt, (H8, W8), wp, b.to(device), cout, KH, KW, ACT_RELU if relu else ACT_NONE, prec, packed=packed)
         close(ops.tokens_to_nchw(y, H8, W8), ref, rt * 2, at * 4, f"conv {KH}x{KW} prec={prec} packed={packed}")
+
+
+def test_forward_interpolate(device):
+    """craft_forward_interpolate vs the reference's outputs (tests/golden/forward_interpolate.npz, generated by running
+    utils.py:34-62) and vs the oracle on a batch of fresh flows, including one with no valid source."""
+    import os
+    from craft_amd.utils import forward_interpolate
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "forward_interpolate.npz"))
+    for n in sorted(k[:-3] for k in z.files if k.endswith(".in")):
+        got = forward_interpolate(torch.from_numpy(z[n + ".in"]).to(device)).cpu().numpy()
+        assert np.array_equal(got, z[n + ".out"]), f"{n}: {int((got != z[n + '.out']).any(0).sum())} pixels differ"
+    f = gen(3, 2, 21, 37, seed=300) * 4.0
+    f[2] = 1000.0                                       # every source leaves the frame: zeros
+    got = forward_interpolate(f.to(device)).cpu()
+    for b in range(3):
+        assert torch.equal(got[b], O.forward_interpolate(f[b])), f"sample {b}"
+    assert float(got[2].abs().max()) == 0.0
