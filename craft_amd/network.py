@@ -201,6 +201,9 @@ class CRAFT(nn.Module):
         if H % 8 or W % 8:
             raise ValueError("image height and width must be multiples of 8 (use InputPadder)")
         H8, W8, N = H // 8, W // 8, (H // 8) * (W // 8)
+        if min(H8, W8) < 2 ** (args.corr_levels - 1):
+            raise ValueError(f"image {H}x{W} is too small: level {args.corr_levels - 1} of the correlation pyramid would be empty "
+                             "(the reference's avg_pool2d fails the same way)")
         hw = (H8, W8)
         dev = image1.device
 
