@@ -14,3 +14,11 @@ def test_random_shapes_against_oracle(device):
     import fuzz_parity
     bad, worst = fuzz_parity.sweep(10, seed0=1000, verbose=False)
     assert bad == 0, f"{bad} of 10 random draws exceed the tolerance (worst error / tolerance {worst:.2f})"
+
+
+def test_random_shapes_and_model_variants_against_oracle(device):
+    """The same sweep also drawing the model variant (score clamp, GMA attention kinds, plain correlation, F2 mask, shared /
+    private F1 transformer)."""
+    import fuzz_parity
+    bad, worst = fuzz_parity.sweep(14, seed0=2000, verbose=False, variants=True)
+    assert bad == 0, f"{bad} of 14 random draws exceed the tolerance (worst error / tolerance {worst:.2f})"

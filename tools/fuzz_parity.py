@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Random-shape parity sweep: craft_amd.CRAFT (HIP) vs the CPU oracle on seeded random (H, W, B, iters, flow_init,
 policy) draws at sizes the oracle finishes in about a second.  Prints one line per draw and a summary; exit code 1 if a
-draw exceeds the tolerance.  GPU box only (gpurun -- 'python tools/fuzz_parity.py 40').
+draw exceeds the tolerance.  GPU box only (gpurun -- 'python tools/fuzz_parity.py 40 [seed0 [variants]]'; a third argument also
+draws the model variant: score clamp, GMA attention kinds, plain correlation, F2 mask, shared / private F1 transformer).
 """
 import os
 import sys
@@ -16,7 +17,13 @@ from craft_amd.synth import synth_pair, synth_state_dict  # noqa: E402
 from oracle import craft_oracle as O  # noqa: E402
 
 
-def sweep(n: int, seed0: int = 0, verbose: bool = True):
+# (model overrides, Q/K weight gain): the canonical model, the score clamp, and the reference's option variants
+VARIANTS = [({}, 2.5), ({}, 40.0), (dict(use_setrans=False), 2.5), (dict(craft=False), 2.5), (dict(f2_attn_mask_radius=5), 2.5),
+            (dict(use_setrans=False, position_and_content=True), 2.5), (dict(use_setrans=False, position_only=True), 2.5),
+            (dict(f1trans="shared"), 2.5), (dict(f1trans="private"), 2.5)]
+
+
+def sweep(n: int, seed0: int = 0, verbose: bool = True, variants: bool = False):
     """-> (failures, worst error / tolerance)."""
     dev = torch.device("cuda")
     models = {}
@@ -28,18 +35,25 @@ def sweep(n: int, seed0: int = 0, verbose: bool = True):
         B, iters = int(rng.randint(1, 4)), int(rng.randint(1, 4))
         policy = ["fp32", "mixed"][int(rng.randint(0, 2))]
         use_init = bool(rng.randint(0, 2))
-        if policy not in models:
-            m = CRAFT(default_args(hip_precision=policy))
-            m.load_state_dict(synth_state_dict(m.state_dict(), seed=1234))
-            models[policy] = m.to(dev).eval()
-        model = models[policy]
+        vi = int(rng.randint(0, len(VARIANTS))) if variants else 0
+        over, qk_gain = VARIANTS[vi]
+        key = (policy, vi)
+        if key not in models:
+            args = default_args(hip_precision=policy, **over)
+            m = CRAFT(args)
+            m.load_state_dict(synth_state_dict(m.state_dict(), seed=1234 + vi, qk_gain=qk_gain))
+            cfg = O.OracleConfig(craft=args.craft, use_setrans=args.use_setrans, f2_attn_mask_radius=args.f2_attn_mask_radius,
+                                 f1trans=args.f1trans, position_only=args.position_only,
+                                 position_and_content=args.position_and_content)
+            models[key] = (m.to(dev).eval(), cfg)
+        model, cfg = models[key]
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         H, W = 8 * H8, 8 * W8
         im1, im2, _ = synth_pair(B, H, W, seed=100 + i)
         fi = (2.0 * torch.randn(B, 2, H8, W8, generator=torch.Generator().manual_seed(i))) if use_init else None
         with torch.no_grad():
             lo, up = model(im1.to(dev), im2.to(dev), iters=iters, flow_init=None if fi is None else fi.to(dev), test_mode=1)
-        lo_ref, up_ref = O.craft_forward(sd, O.OracleConfig(), im1, im2, iters=iters, flow_init=fi, test_mode=1)
+        lo_ref, up_ref = O.craft_forward(sd, cfg, im1, im2, iters=iters, flow_init=fi, test_mode=1)
         e_lo = (lo.cpu() - lo_ref).abs().max().item()
         e_up = (up.cpu() - up_ref).abs().max().item()
         tol = 5e-3 if policy == "fp32" else 2e-2
@@ -47,7 +61,7 @@ def sweep(n: int, seed0: int = 0, verbose: bool = True):
         worst = max(worst, e_up / tol)
         bad += not ok
         if verbose or not ok:
-            print(f"[{i:3d}] {H:4d}x{W:<4d} B{B} T{iters} init={int(use_init)} {policy:5s}  |d lo| {e_lo:.2e}  |d up| {e_up:.2e}  "
+            print(f"[{i:3d}] {H:4d}x{W:<4d} B{B} T{iters} init={int(use_init)} {policy:5s} v{vi}  |d lo| {e_lo:.2e}  |d up| {e_up:.2e}  "
                   f"{'ok' if ok else 'FAIL'}", flush=True)
     return bad, worst
 
@@ -55,7 +69,7 @@ def sweep(n: int, seed0: int = 0, verbose: bool = True):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    bad, worst = sweep(n, seed0)
+    bad, worst = sweep(n, seed0, variants=len(sys.argv) > 3)
     print(f"{n} draws, {bad} failures, worst error / tolerance = {worst:.3f}")
     sys.exit(1 if bad else 0)
 
