@@ -20,7 +20,21 @@ namespace craft {
 
 constexpr int WF_PATCH_H = 8, WF_PATCH_W = 16;
 
-template <int PREC, int WM, int WN, bool ENC>
+// scheduling pipeline of one k-half: N x { 1 MFMA, 1 LDS op, up to 5 VALU, 1 VMEM read }
+template <int N> __device__ __forceinline__ void wf_interleave() {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+  }
+}
+
+// TT: number of taps when known at compile time (5: 1x5 / 5x1, 9: 3x3; 0: run-time KH*KW).  With static taps the tap loop
+// is unrolled and the fp32 -> fp16-plane conversion of the next chunk's halo is cut into one piece per k-half, each in
+// the same scheduling region as that k-half's MFMAs (VALU work only hides behind MFMAs of the same wave).
+template <int PREC, int WM, int WN, bool ENC, int TT>
 __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   typedef typename PrecT<PREC>::lds_t lds_t;
   typedef typename FragT<PREC>::t frag_t;
@@ -34,7 +48,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const ConvGeom& g = p.g;
-  const int KH = g.KH, KW = g.KW, T = KH * KW;
+  const int KH = g.KH, KW = g.KW, T = TT ? TT : KH * KW;
   const int HWd = WF_PATCH_W + KW - 1, HH = WF_PATCH_H + KH - 1, HR = HH * HWd;
   const int tiles_x = (g.W + WF_PATCH_W - 1) / WF_PATCH_W, tiles_y = (g.H + WF_PATCH_H - 1) / WF_PATCH_H;
   int bid = blockIdx.x;
@@ -66,42 +80,49 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) r[i] = *reinterpret_cast<const float4*>(sp + (img + max(hpix[i], 0)) * ld + c + c4 * 4);
   };
-  auto store_halo = [&](int hb, int chunk, const float4 (&r)[NA]) __attribute__((always_inline)) {
-    lds_t* A0 = &As[hb * A_ELEMS];
-    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (ENC && g.in_norm) {     // (mean, rstd) of this thread's 4 input channels, image b
+  // (mean, rstd) of this thread's 4 input channels for the lazy input normalisation of chunk `chunk`, image b
+  auto load_norm = [&](int chunk, float4& mu, float4& rs) __attribute__((always_inline)) {
+    mu = make_float4(0.f, 0.f, 0.f, 0.f); rs = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (ENC && g.in_norm) {
       const float* t = g.in_norm + ((long)b * g.c0 + chunk * BK + c4 * 4) * 2;
       const float4 t0 = *reinterpret_cast<const float4*>(t), t1 = *reinterpret_cast<const float4*>(t + 4);
       mu = make_float4(t0.x, t0.z, t1.x, t1.z);
       rs = make_float4(t0.y, t0.w, t1.y, t1.w);
     }
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int row = r0 + 32 * i;                // rows >= HR are written too (zeros, never read): no exec branch
-      const bool ok = hpix[i] >= 0;
-      float4 v = r[i];
-      if (ENC && g.in_norm) {
-        v.x = fmaxf((v.x - mu.x) * rs.x, 0.f); v.y = fmaxf((v.y - mu.y) * rs.y, 0.f);
-        v.z = fmaxf((v.z - mu.z) * rs.z, 0.f); v.w = fmaxf((v.w - mu.w) * rs.w, 0.f);
-      }
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      if constexpr (PREC == CRAFT_PREC_BF16) {
-        bf16x4 h;
-        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-        *reinterpret_cast<bf16x4*>(&A0[row * LD + c4 * 4]) = h;
-      } else {
-        f16x4 h;
-        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-        *reinterpret_cast<f16x4*>(&A0[row * LD + c4 * 4]) = h;
-        if constexpr (PREC == CRAFT_PREC_F16X3) {
-          f16x4 l;
-          // v - float(h) as one fma with an fp16 source operand (v_fma_mix_f32) instead of cvt + sub
-          l[0] = (_Float16)__builtin_fmaf((float)h[0], -1.f, v.x); l[1] = (_Float16)__builtin_fmaf((float)h[1], -1.f, v.y);
-          l[2] = (_Float16)__builtin_fmaf((float)h[2], -1.f, v.z); l[3] = (_Float16)__builtin_fmaf((float)h[3], -1.f, v.w);
-          *reinterpret_cast<f16x4*>(&A0[(HR_MAX + row) * LD + c4 * 4]) = l;
-        }
+  };
+  // one float4 of the halo (row r0 + 32 i): normalise / zero / split -> LDS buffer hb
+  auto store_piece = [&](int hb, const float4 (&r)[NA], int i, const float4& mu, const float4& rs) __attribute__((always_inline)) {
+    lds_t* A0 = &As[hb * A_ELEMS];
+    const int row = r0 + 32 * i;                // rows >= HR are written too (zeros, never read): no exec branch
+    const bool ok = hpix[i] >= 0;
+    float4 v = r[i];
+    if (ENC && g.in_norm) {
+      v.x = fmaxf((v.x - mu.x) * rs.x, 0.f); v.y = fmaxf((v.y - mu.y) * rs.y, 0.f);
+      v.z = fmaxf((v.z - mu.z) * rs.z, 0.f); v.w = fmaxf((v.w - mu.w) * rs.w, 0.f);
+    }
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    if constexpr (PREC == CRAFT_PREC_BF16) {
+      bf16x4 h;
+      h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+      *reinterpret_cast<bf16x4*>(&A0[row * LD + c4 * 4]) = h;
+    } else {
+      f16x4 h;
+      h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+      *reinterpret_cast<f16x4*>(&A0[row * LD + c4 * 4]) = h;
+      if constexpr (PREC == CRAFT_PREC_F16X3) {
+        f16x4 l;
+        // v - float(h) as one fma with an fp16 source operand (v_fma_mix_f32) instead of cvt + sub
+        l[0] = (_Float16)__builtin_fmaf((float)h[0], -1.f, v.x); l[1] = (_Float16)__builtin_fmaf((float)h[1], -1.f, v.y);
+        l[2] = (_Float16)__builtin_fmaf((float)h[2], -1.f, v.z); l[3] = (_Float16)__builtin_fmaf((float)h[3], -1.f, v.w);
+        *reinterpret_cast<f16x4*>(&A0[(HR_MAX + row) * LD + c4 * 4]) = l;
       }
     }
+  };
+  auto store_halo = [&](int hb, int chunk, const float4 (&r)[NA]) __attribute__((always_inline)) {
+    float4 mu, rs;
+    load_norm(chunk, mu, rs);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) store_piece(hb, r, i, mu, rs);
   };
 
   // ---- weight fragments: [kt][nb][pl][kk][lane][8].  Column blocks beyond the packed width re-read the last one
@@ -176,6 +197,36 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
     const int cn = min(chunk + 1, nchunk - 1);
     fetch_halo(min(chunk + 2, nchunk - 1), rfar);         // rfar held this chunk's halo, already in LDS
     int tx = 0, trow = 0;                                 // tap = (trow / HWd) * KW + tx; toff = (trow + tx) * LD
+    if constexpr (TT > 0) {
+      // static taps: k-half h = 2 * tap + kk converts halo piece (h - 1) / PSTEP of the next chunk, if any
+      constexpr int PSTEP = (2 * TT - 2) / NA > 1 ? 2 : 1;
+      float4 mu, rs;
+      load_norm(cn, mu, rs);
+#pragma unroll
+      for (int tap = 0; tap < TT; ++tap) {
+        constexpr bool kLastDummy = false; (void)kLastDummy;
+        const bool last_tap = tap + 1 == TT;
+        const int toff = (trow + tx) * LD;
+        if (++tx == KW) { tx = 0; trow += HWd; }
+        const int toffn = last_tap ? 0 : (trow + tx) * LD;
+        const int ktn = last_tap ? cn : (tap + 1) * nchunk + chunk;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int h = 2 * tap + kk;
+          if (kk == 0) read_a(hb, toff, 1, a1h, a1l);
+          else {
+            if (last_tap) { __syncthreads(); hb ^= 1; }
+            read_a(hb, toffn, 0, a0h, a0l);               // next tile (after the last chunk: a harmless re-read)
+          }
+          if (kk == 0) mma_half(a0h, a0l, 0); else mma_half(a1h, a1l, 1);
+          fetch_b(ktn, kk);
+          if (h >= 1 && (h - 1) % PSTEP == 0 && (h - 1) / PSTEP < NA && !(last_tap && kk == 1))
+            store_piece(hb ^ 1, rnear, (h - 1) / PSTEP, mu, rs);
+          wf_interleave<MT * (PL == 2 ? 3 : 1)>();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
     for (int tap = 0; tap < T; ++tap) {
       const bool last_tap = tap + 1 == T;
       const int toff = (trow + tx) * LD;
@@ -183,17 +234,18 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
       const int toffn = last_tap ? 0 : (trow + tx) * LD;
       const int ktn = last_tap ? cn : (tap + 1) * nchunk + chunk;
       read_a(hb, toff, 1, a1h, a1l);
-      __builtin_amdgcn_sched_barrier(0);
       mma_half(a0h, a0l, 0);
       fetch_b(ktn, 0);
-      __builtin_amdgcn_sched_barrier(0);
       if (tap == smid) store_halo(hb ^ 1, cn, rnear);
+      wf_interleave<MT * (PL == 2 ? 3 : 1)>();
+      __builtin_amdgcn_sched_barrier(0);
       if (last_tap) { __syncthreads(); hb ^= 1; }
       read_a(hb, toffn, 0, a0h, a0l);                    // next tile (after the last chunk: a harmless re-read)
-      __builtin_amdgcn_sched_barrier(0);
       mma_half(a1h, a1l, 1);
       fetch_b(ktn, 1);
+      wf_interleave<MT * (PL == 2 ? 3 : 1)>();
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
   };
   int chunk = 0;
@@ -227,15 +279,22 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   }
 }
 
-template <int PREC, int WM, int WN> static int launch_wf_t(const ConvGemmParams& p, hipStream_t s) {
+template <int PREC, int WM, int WN, int TT> static int launch_wf_tt(const ConvGemmParams& p, hipStream_t s) {
   constexpr int BN = WN * 32;
   const bool enc = p.g.in_norm != nullptr || p.stats != nullptr;
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   const int tiles = ((p.g.W + WF_PATCH_W - 1) / WF_PATCH_W) * ((p.g.H + WF_PATCH_H - 1) / WF_PATCH_H) * (p.g.npix / (p.g.H * p.g.W));
   dim3 grid(tiles, (ncols + BN - 1) / BN, 1);
-  if (enc) hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, true>), grid, dim3(NTHREADS), 0, s, p);
-  else hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, false>), grid, dim3(NTHREADS), 0, s, p);
+  if (enc) hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, true, TT>), grid, dim3(NTHREADS), 0, s, p);
+  else hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, false, TT>), grid, dim3(NTHREADS), 0, s, p);
   return (int)hipGetLastError();
+}
+template <int PREC, int WM, int WN> static int launch_wf_t(const ConvGemmParams& p, hipStream_t s) {
+  static const bool dyn = getenv("CRAFT_WF_DYNAMIC_TAPS") != nullptr;       // A/B: always the run-time tap loop
+  const int T = p.g.KH * p.g.KW;
+  if (T == 5 && !dyn) return launch_wf_tt<PREC, WM, WN, 5>(p, s);
+  if (T == 9 && !dyn) return launch_wf_tt<PREC, WM, WN, 9>(p, s);
+  return launch_wf_tt<PREC, WM, WN, 0>(p, s);
 }
 
 // packed (fragment-order) weights only; called by launch_conv_halo
