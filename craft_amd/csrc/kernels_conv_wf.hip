@@ -195,7 +195,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   read_a(0, 0, 0, a0h, a0l);
   auto do_chunk = [&](int chunk, float4 (&rnear)[NA], float4 (&rfar)[NA]) __attribute__((always_inline)) {
     const int cn = min(chunk + 1, nchunk - 1);
-    fetch_halo(min(chunk + 2, nchunk - 1), rfar);         // rfar held this chunk's halo, already in LDS
+    if constexpr (TT == 0) fetch_halo(min(chunk + 2, nchunk - 1), rfar);     // rfar held this chunk's halo, already in LDS
     int tx = 0, trow = 0;                                 // tap = (trow / HWd) * KW + tx; toff = (trow + tx) * LD
     if constexpr (TT > 0) {
       // static taps: k-half h = 2 * tap + kk converts halo piece (h - 1) / PSTEP of the next chunk, if any
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
           }
           if (kk == 0) mma_half(a0h, a0l, 0); else mma_half(a1h, a1l, 1);
           fetch_b(ktn, kk);
+          if (h == 0) fetch_halo(min(chunk + 2, nchunk - 1), rfar);   // (address arithmetic behind the first MFMAs)
           if (h >= 1 && (h - 1) % PSTEP == 0 && (h - 1) / PSTEP < NA && !(last_tap && kk == 1))
             store_piece(hb ^ 1, rnear, (h - 1) / PSTEP, mu, rs);
           wf_interleave<MT * (PL == 2 ? 3 : 1)>();
