@@ -55,12 +55,12 @@ template <int PREC, int BM, int BN> struct TileLds {
 template <int ROWS> struct RegsF32 { float4 v[ROWS / 32]; unsigned zmask; };   // thread: k-chunk (tid&7)*4, rows (tid>>3)+32*i
 template <int ROWS> struct RegsH16 { uint4 v[ROWS / 64]; unsigned zmask; };    // thread: k-chunk (tid&3)*8, rows (tid>>2)+64*i
 
+// one register (float4 / uint4) of a staged tile -> LDS; stage_store = all pieces
 template <int PREC, int ROWS>
-__device__ __forceinline__ void stage_store(typename PrecT<PREC>::lds_t* S, const RegsF32<ROWS>& r, int tid) {
+__device__ __forceinline__ void stage_store_piece(typename PrecT<PREC>::lds_t* S, const RegsF32<ROWS>& r, int tid, int i) {
   constexpr int LD = PrecT<PREC>::LD;
   const int c4 = tid & 7, r0 = tid >> 3;
-#pragma unroll
-  for (int i = 0; i < ROWS / 32; ++i) {
+  {
     const int row = r0 + 32 * i;
     const bool z = (r.zmask >> i) & 1u;
     float4 v;
@@ -85,19 +85,30 @@ __device__ __forceinline__ void stage_store(typename PrecT<PREC>::lds_t* S, cons
     }
   }
 }
+template <int ROWS> __device__ __forceinline__ constexpr int stage_pieces(const RegsF32<ROWS>&) { return ROWS / 32; }
+template <int ROWS> __device__ __forceinline__ constexpr int stage_pieces(const RegsH16<ROWS>&) { return ROWS / 64; }
 template <int PREC, int ROWS>
-__device__ __forceinline__ void stage_store(typename PrecT<PREC>::lds_t* S, const RegsH16<ROWS>& r, int tid) {
+__device__ __forceinline__ void stage_store(typename PrecT<PREC>::lds_t* S, const RegsF32<ROWS>& r, int tid) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 32; ++i) stage_store_piece<PREC, ROWS>(S, r, tid, i);
+}
+template <int PREC, int ROWS>
+__device__ __forceinline__ void stage_store_piece(typename PrecT<PREC>::lds_t* S, const RegsH16<ROWS>& r, int tid, int i) {
   static_assert(PREC == CRAFT_PREC_BF16 || PREC == CRAFT_PREC_F16, "16-bit operands need a plain 16-bit MFMA mode");
   constexpr int LD = PrecT<PREC>::LD;
   const int c8 = tid & 3, r0 = tid >> 2;
-#pragma unroll
-  for (int i = 0; i < ROWS / 64; ++i) {
+  {
     const int row = r0 + 64 * i;
     const bool z = (r.zmask >> i) & 1u;
     uint4 v;
     v.x = z ? 0u : r.v[i].x; v.y = z ? 0u : r.v[i].y; v.z = z ? 0u : r.v[i].z; v.w = z ? 0u : r.v[i].w;
     *reinterpret_cast<uint4*>(&S[row * LD + c8 * 8]) = v;
   }
+}
+template <int PREC, int ROWS>
+__device__ __forceinline__ void stage_store(typename PrecT<PREC>::lds_t* S, const RegsH16<ROWS>& r, int tid) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 64; ++i) stage_store_piece<PREC, ROWS>(S, r, tid, i);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -216,9 +227,12 @@ template <int ROWS> struct LoaderConvF32 {
 // ---------------------------------------------------------------------------------------------
 // LDS fragments -> MFMA
 // ---------------------------------------------------------------------------------------------
-template <int PREC, int MT, int NT, int BM, int BN>
+struct NoSlot { __device__ __forceinline__ void operator()(int) const {} };
+// `slot(i)`, i = 0 .. 2*MT*NT-1, runs after the MFMAs of accumulator tile (kk, mt, nt) in the 16-bit modes: the caller
+// places slices of other work there, each pinned behind those MFMAs (VALU hides only behind MFMAs of the same wave).
+template <int PREC, int MT, int NT, int BM, int BN, class SLOT = NoSlot>
 __device__ __forceinline__ void mma_tile(const typename PrecT<PREC>::lds_t* As, const typename PrecT<PREC>::lds_t* Bs,
-                                         int wm0, int wn0, int lane, f32x16 (&acc)[MT][NT]) {
+                                         int wm0, int wn0, int lane, f32x16 (&acc)[MT][NT], SLOT&& slot = NoSlot()) {
   constexpr int LD = PrecT<PREC>::LD;
   const int r = lane & 31, g = lane >> 5;
   if constexpr (PREC == CRAFT_PREC_F32) {
@@ -251,7 +265,10 @@ __device__ __forceinline__ void mma_tile(const typename PrecT<PREC>::lds_t* As, 
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
+        {
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+          slot((kk * MT + mt) * NT + nt);
+        }
     }
   } else if constexpr (PREC == CRAFT_PREC_F16) {
 #pragma unroll
@@ -265,7 +282,10 @@ __device__ __forceinline__ void mma_tile(const typename PrecT<PREC>::lds_t* As, 
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
+        {
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+          slot((kk * MT + mt) * NT + nt);
+        }
     }
   } else {   // F16X3
 #pragma unroll
@@ -288,6 +308,7 @@ __device__ __forceinline__ void mma_tile(const typename PrecT<PREC>::lds_t* As, 
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          slot((kk * MT + mt) * NT + nt);
         }
     }
   }
@@ -348,11 +369,29 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int nk
     la.fetch(ktn, ra);
     lb.fetch(ktn, rb);
     __builtin_amdgcn_sched_barrier(0);
-    mma_tile<PREC, MT, NT, BM, BN>(&S[ao], &S[bo], wm0, wn0, lane, acc);
-    fold(kt);
-    __builtin_amdgcn_sched_barrier(0);
-    stage_store<PREC>(&S[an], ra, tid);
-    stage_store<PREC>(&S[bn], rb, tid);
+    if constexpr (PREC == CRAFT_PREC_F32) {
+      mma_tile<PREC, MT, NT, BM, BN>(&S[ao], &S[bo], wm0, wn0, lane, acc);
+      fold(kt);
+      __builtin_amdgcn_sched_barrier(0);
+      stage_store<PREC>(&S[an], ra, tid);
+      stage_store<PREC>(&S[bn], rb, tid);
+    } else {
+      // the conversion / split of the next tile is cut into pieces (one staged register each) placed behind the MFMAs of
+      // this tile, starting after the first third (the fetch is still in flight); what does not fit follows the last MFMA
+      constexpr int NSLOT = 2 * MT * NT, S0 = NSLOT / 3;
+      constexpr int NPA = stage_pieces(typename LA::Regs()), NPB = stage_pieces(typename LB::Regs());
+      auto piece = [&](int j) __attribute__((always_inline)) {
+        if (j < NPA) stage_store_piece<PREC>(&S[an], ra, tid, j);
+        else if (j < NPA + NPB) stage_store_piece<PREC>(&S[bn], rb, tid, j - NPA);
+      };
+      mma_tile<PREC, MT, NT, BM, BN>(&S[ao], &S[bo], wm0, wn0, lane, acc, [&](int i) __attribute__((always_inline)) {
+        if (i >= S0) piece(i - S0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      fold(kt);
+#pragma unroll
+      for (int j = NSLOT - S0; j < NPA + NPB; ++j) piece(j);
+    }
     __syncthreads();
   }
 }
