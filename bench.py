@@ -176,12 +176,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # one rank per GPU; CRAFT_BENCH_BACKEND=gloo lets several ranks share a device to exercise this path on a 1-GPU box
+    backend = os.environ.get("CRAFT_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and local >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {ndev} GPU(s) visible")
+    local_dev = local % ndev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", init_method="env://")
+        dist.init_process_group(backend, init_method="env://")
 
     from craft_amd import CRAFT, default_args
     from craft_amd.hip import Precision

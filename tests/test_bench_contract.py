@@ -1,0 +1,47 @@
+"""bench.py's output contract on the GPU box: one JSON line with the driver's keys plus roofline / roofline_conv /
+cpu_baseline at N = 1, and the N > 1 launch path (torch.distributed.run, barrier + max-over-ranks timing, rank 0
+prints) exercised with two ranks that share the one GPU over gloo (CRAFT_BENCH_BACKEND=gloo; the driver's real runs use
+RCCL with one rank per GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline"}
+
+
+def _json_line(out: str) -> dict:
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"expected exactly one JSON line, got {len(lines)}:\n{out[-2000:]}"
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line(device):
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "1", "--height", "128", "--width", "256",
+                        "--iters", "2"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "workload" in d["config"]
+
+
+def test_two_rank_launch_path(device):
+    env = dict(os.environ, CRAFT_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1", "--height", "128",
+           "--width", "256", "--iters", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and d["value"] > 0 and "cpu_baseline" not in d
+    # value = pairs of ALL ranks / slowest rank's time
+    assert abs(d["value"] - 2 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 0.02
