@@ -274,12 +274,15 @@ class CRAFT(nn.Module):
             flow_ups = [torch.empty(B, 2, H, W, device=dev, dtype=torch.float32) for _ in range(n_pred)]
 
             # ---- iterative refinement (network.py:230-260).  Every per-sample tensor is batch-major, so the loop of a
-            # batch slice touches only its own rows: the batch is cut into `hip_streams` slices whose loops are enqueued
-            # interleaved on separate HIP streams.  No kernel of the loop couples samples, so the results are the
-            # same; the HBM-bound kernels (P.V, lookup) of one slice can overlap the MFMA-bound convolutions of the
-            # other.  Measured at configs[1] (B = 4): 2 streams 161.8 vs 1 stream 165.0 pairs/s -- the half-size
-            # kernels lose more than the overlap wins -- so the default is 1; the knob stays for larger batches.
-            nstr = max(1, min(int(getattr(args, "hip_streams", 1)), B))
+            # batch slice touches only its own rows: the batch can be cut into `hip_streams` slices whose loops are enqueued
+            # interleaved on separate HIP streams.  No kernel of the loop couples samples, so the results are the same; the
+            # HBM-bound kernels (P.V, lookup, conv epilogues) of one slice overlap the MFMA-bound convolutions of the other.
+            # Measured pairs/s (1 stream / 2 streams): batch 4: 206 / 200 (half-size kernels lose more than the overlap
+            # wins), batch 6: 208 / 216, batch 8: 216 / 223 (4 streams: 211), batch 16: 225 / 225 -- hence the auto rule.
+            nstr = int(os.environ.get("CRAFT_HIP_STREAMS", getattr(args, "hip_streams", 0)))
+            if nstr <= 0:                      # auto: two slices of 3..6 samples each (measured below); else one stream
+                nstr = 2 if 6 <= B <= 12 else 1
+            nstr = max(1, min(nstr, B))
             cuts = [B * i // nstr for i in range(nstr + 1)]
             parts = []
             for i in range(nstr):
