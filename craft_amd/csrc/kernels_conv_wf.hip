@@ -14,6 +14,7 @@
 // Each wave owns 32 output channels (NT = 1) and MT = 128 / (32 * WM) row fragments:
 //   BN = 128: WM = 1, WN = 4, MT = 4   |   BN = 64: WM = 2, WN = 2, MT = 2.
 #include <cstdlib>
+#include <type_traits>
 #include "conv_epilogue.hpp"
 
 namespace craft {
@@ -131,11 +132,15 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   const int nb = min((n0 + wn0) / 32, NBtot - 1);
   const uint16_t* wb = reinterpret_cast<const uint16_t*>(p.W) + (long)nb * (PL * 1024) + lane * 8;
   const long kt_stride = (long)NBtot * (PL * 1024);
-  frag_t bq[PL][2];
-  auto fetch_b = [&](int kt, int kk) __attribute__((always_inline)) {
+  // B ring: BD k-halves in flight (static taps: 4, so that an L2 round trip under load is covered; else 2).  Slot of
+  // k-half number g (counted from the start of the K loop) = g % BD; 2*TT*2 is a multiple of 4, so the slots are
+  // compile-time constants inside the 2x unrolled chunk loop.
+  constexpr int BD = (TT > 0 && !(ENC && MT == 4 && TT == 9)) ? 4 : 2;
+  frag_t bq[PL][BD];
+  auto fetch_b = [&](int kt, int kk, int slot) __attribute__((always_inline)) {
     const uint16_t* q = wb + kt * kt_stride + kk * 512;
 #pragma unroll
-    for (int pl = 0; pl < PL; ++pl) bq[pl][kk] = *reinterpret_cast<const frag_t*>(q + pl * 1024);
+    for (int pl = 0; pl < PL; ++pl) bq[pl][slot] = *reinterpret_cast<const frag_t*>(q + pl * 1024);
   };
 
   // lane's base halo element offsets for its MT output-row fragments
@@ -161,21 +166,24 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[mt][0][e] = 0.f;
   // MFMAs of one k-half; term-major order so that consecutive MFMAs hit different accumulators
-  auto mma_half = [&](const frag_t (&h)[MT], const frag_t (&l)[MT], int kk) __attribute__((always_inline)) {
+  auto mma_half = [&](const frag_t (&h)[MT], const frag_t (&l)[MT], int slot) __attribute__((always_inline)) {
     if constexpr (PL == 2) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(l[mt], bq[0][kk], acc[mt][0]);
+      for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(l[mt], bq[0][slot], acc[mt][0]);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(h[mt], bq[1][kk], acc[mt][0]);
+      for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(h[mt], bq[1][slot], acc[mt][0]);
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(h[mt], bq[0][kk], acc[mt][0]);
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(h[mt], bq[0][slot], acc[mt][0]);
   };
 
   float4 ra[NA], rb[NA];
   fetch_halo(0, ra);
-  fetch_b(0, 0);
-  fetch_b(0, 1);
+#pragma unroll
+  for (int g = 0; g < BD; ++g) {          // k-halves 0 .. BD-1 of chunk 0: tap g / 2, half g % 2
+    const int tp = min(g / 2, T - 1);
+    fetch_b(tp * nchunk, g & 1, g);
+  }
   fetch_halo(min(1, nchunk - 1), rb);                     // issued before ra is consumed: both HBM round trips overlap
   store_halo(0, 0, ra);
   __syncthreads();
@@ -193,7 +201,8 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   const int smid = min(1, T - 1);
   int hb = 0;
   read_a(0, 0, 0, a0h, a0l);
-  auto do_chunk = [&](int chunk, float4 (&rnear)[NA], float4 (&rfar)[NA]) __attribute__((always_inline)) {
+  auto do_chunk = [&](int chunk, float4 (&rnear)[NA], float4 (&rfar)[NA], auto phase_c) __attribute__((always_inline)) {
+    constexpr int PHASE = decltype(phase_c)::value;      // ring slot of this chunk's first k-half
     const int cn = min(chunk + 1, nchunk - 1);
     if constexpr (TT == 0) fetch_halo(min(chunk + 2, nchunk - 1), rfar);     // rfar held this chunk's halo, already in LDS
     int tx = 0, trow = 0;                                 // tap = (trow / HWd) * KW + tx; toff = (trow + tx) * LD
@@ -218,8 +227,14 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
             if (last_tap) { __syncthreads(); hb ^= 1; }
             read_a(hb, toffn, 0, a0h, a0l);               // next tile (after the last chunk: a harmless re-read)
           }
-          if (kk == 0) mma_half(a0h, a0l, 0); else mma_half(a1h, a1l, 1);
-          fetch_b(ktn, kk);
+          constexpr int kDummy = 0; (void)kDummy;
+          const int slot = (PHASE + h) % BD;
+          if (kk == 0) mma_half(a0h, a0l, slot); else mma_half(a1h, a1l, slot);
+          {   // B fragments of k-half h + BD (this chunk, or the head of the next one)
+            const int hf = h + BD;
+            const int ktf = hf < 2 * TT ? (hf / 2) * nchunk + chunk : ((hf - 2 * TT) / 2) * nchunk + cn;
+            fetch_b(ktf, hf & 1, slot);
+          }
           if (h == 0) fetch_halo(min(chunk + 2, nchunk - 1), rfar);   // (address arithmetic behind the first MFMAs)
           if (h >= 1 && (h - 1) % PSTEP == 0 && (h - 1) / PSTEP < NA && !(last_tap && kk == 1))
             store_piece(hb ^ 1, rnear, (h - 1) / PSTEP, mu, rs);
@@ -236,25 +251,27 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
       const int ktn = last_tap ? cn : (tap + 1) * nchunk + chunk;
       read_a(hb, toff, 1, a1h, a1l);
       mma_half(a0h, a0l, 0);
-      fetch_b(ktn, 0);
+      fetch_b(ktn, 0, 0);
       if (tap == smid) store_halo(hb ^ 1, cn, rnear);
       wf_interleave<MT * (PL == 2 ? 3 : 1)>();
       __builtin_amdgcn_sched_barrier(0);
       if (last_tap) { __syncthreads(); hb ^= 1; }
       read_a(hb, toffn, 0, a0h, a0l);                    // next tile (after the last chunk: a harmless re-read)
       mma_half(a1h, a1l, 1);
-      fetch_b(ktn, 1);
+      fetch_b(ktn, 1, 1);
       wf_interleave<MT * (PL == 2 ? 3 : 1)>();
       __builtin_amdgcn_sched_barrier(0);
     }
     }
   };
   int chunk = 0;
+  typedef std::integral_constant<int, 0> P0;
+  typedef std::integral_constant<int, (2 * TT) % BD> P1;
   for (; chunk + 1 < nchunk; chunk += 2) {
-    do_chunk(chunk, rb, ra);
-    do_chunk(chunk + 1, ra, rb);
+    do_chunk(chunk, rb, ra, P0());
+    do_chunk(chunk + 1, ra, rb, P1());
   }
-  if (chunk < nchunk) do_chunk(chunk, rb, ra);
+  if (chunk < nchunk) do_chunk(chunk, rb, ra, P0());
 
   // ---- epilogue: GEMM row r of the patch -> token (y0 + r/16, x0 + r%16)
   const int cb = n0 + wn0;
