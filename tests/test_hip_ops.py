@@ -393,10 +393,12 @@ def test_module_level_api_matches_reference_shapes(device):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("KH,KW,cin,cout,relu", [(3, 3, 64, 192, True), (1, 5, 96, 256, False), (5, 1, 128, 126, True), (1, 1, 64, 64, True)])
+@pytest.mark.parametrize("KH,KW,cin,cout,relu", [(3, 3, 64, 192, True), (1, 5, 96, 256, False), (5, 1, 128, 126, True), (1, 1, 64, 64, True),
+                                                 (1, 3, 64, 128, False), (3, 1, 96, 64, True)])
 def test_conv2d_tokens(device, prec, KH, KW, cin, cout, relu):
     """craft_conv2d_nhwc (halo-tile kernel for KxK, generic implicit GEMM for 1x1) vs F.conv2d on an image whose
-    size is not a multiple of the 8x16 patch (ragged patches, zero padding at every border)."""
+    size is not a multiple of the 8x16 patch (ragged patches, zero padding at every border).  3x3 / 1x5 / 5x1 take the
+    static-tap variants of the packed-weight kernel, 1x3 / 3x1 its run-time tap loop."""
     B, H8, W8 = 2, 11, 21
     x = gen(B, cin, H8, W8, seed=90)
     w = gen(cout, cin, KH, KW, seed=91) / math.sqrt(cin * KH * KW)
