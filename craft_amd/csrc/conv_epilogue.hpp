@@ -110,7 +110,19 @@ __device__ __forceinline__ void conv_epilogue4(const ConvGemmParams& p, long row
 
 // Epilogue of a halo-conv wave tile: accumulator rows are patch pixels, GEMM row r -> token (y0 + r/16, x0 + r%16);
 // the 4 rows of one accumulator quad (e = 4q..4q+3) are 4 consecutive pixels of one patch row.
-template <int EPI, bool FAST, int MT, int NT>
+// PERM: the 32 GEMM rows of a fragment are assigned to the two 16-pixel patch rows by patch_row_perm (below) instead
+// of linearly (quads stay quads, so the 4 rows of an accumulator quad are still 4 consecutive pixels).
+//
+// patch_row_perm: ds_read_b128 is serviced in lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32 for the upper
+// half-wave).  With the linear assignment a group reads 8 pixels of one patch row and 8 of the next, whose LDS
+// addresses are HWd halo rows apart -- 2-way bank conflicts unless HWd is a multiple of 16 (PMC: 36 % of the LDS cycles
+// of k_conv_halo_wf).  Assigning quad qi = l >> 2 to patch row parity(qi) and pixel quad qi >> 1 makes every lane group
+// read 16 consecutive pixels of ONE patch row: conflict-free for every tap and halo width.
+__device__ __forceinline__ int patch_row_perm(int l) {          // l in 0..31 -> 16 * row + x
+  const int qi = l >> 2;
+  return (((qi ^ (qi >> 1) ^ (qi >> 2)) & 1) << 4) | ((qi >> 1) << 2) | (l & 3);
+}
+template <int EPI, bool FAST, int MT, int NT, bool PERM = false>
 __device__ __forceinline__ void conv_epilogue_patch(const ConvGemmParams& p, const f32x16 (&acc)[MT][NT], int wm0, int lane,
                                                     int cb, long img, int y0, int x0) {
   const int c_lane = lane & 31, rh4 = 4 * (lane >> 5);
@@ -118,7 +130,7 @@ __device__ __forceinline__ void conv_epilogue_patch(const ConvGemmParams& p, con
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int r = wm0 + mt * 32 + 8 * q + rh4;
+      const int r = wm0 + mt * 32 + (PERM ? patch_row_perm(8 * q + rh4) : 8 * q + rh4);
       const int y = y0 + (r >> 4), x = x0 + (r & 15);
       const int nvalid = y < p.g.H ? min(4, p.g.W - x) : 0;
       const long row0 = img + (long)y * p.g.W + x;

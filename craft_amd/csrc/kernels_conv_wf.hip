@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   int arow[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int r = wm0 + mt * 32 + (lane & 31);
+    const int r = wm0 + mt * 32 + patch_row_perm(lane & 31);       // (conflict-free LDS lane groups, conv_epilogue.hpp)
     arow[mt] = ((r >> 4) * HWd + (r & 15)) * LD + (lane >> 5) * 8;
   }
   // A fragments of one k-half: hi (and lo) plane rows of the halo buffer `hb`, shifted by the tap offset
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   // ---- epilogue: GEMM row r of the patch -> token (y0 + r/16, x0 + r%16)
   const int cb = n0 + wn0;
   const int rh4 = 4 * (lane >> 5);
-#define BODY(E) conv_epilogue_patch<E, true, MT, 1>(p, acc, wm0, lane, cb, img, y0, x0);
+#define BODY(E) conv_epilogue_patch<E, true, MT, 1, true>(p, acc, wm0, lane, cb, img, y0, x0);
   CONV_EPI_DISPATCH(p, BODY)
 #undef BODY
   if (ENC && p.stats) {
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int r = wm0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
+          const int r = wm0 + mt * 32 + patch_row_perm((e & 3) + 8 * (e >> 2) + rh4);
           const bool ok = (y0 + (r >> 4)) < g.H && (x0 + (r & 15)) < g.W;
           const int bit = mt * 16 + e;
           if (ok) { if (bit < 32) mlo |= 1u << bit; else mhi |= 1u << (bit - 32); }
