@@ -77,28 +77,43 @@ def op_table(model, im1, im2, iters):
         print(f"[ops] {n:28s} calls {c:4d}  {t:9.3f} ms  {100 * t / tot:5.1f} %", file=sys.stderr)
 
 
-def roofline_pv(model, B, H8, W8, prec, reps=20):
-    """Time the aggregator's P.V GEMM alone (same shapes as in the forward) with HIP events."""
-    from craft_amd import ops
+def roofline_pv(model, im1, im2, iters, prec, forwards=3):
+    """The aggregator's P.V kernel timed LIVE: HIP events around every craft_attn_apply call of `forwards` real forward
+    passes (the kernel runs on the main stream, the events are recorded on it), so the figure is what rocprof's kernel
+    trace of the same command reports (profiles/r1/bench_kernel_stats_short.txt)."""
+    from craft_amd import hip
     from craft_amd.hip import PREC_F16, PROB_DTYPE, pick
-    prec = pick(prec, "pv")
-    dev = torch.device("cuda")
+    import craft_amd.ops as ops_mod
+    pv = pick(prec, "pv")
+    B, _, H, W = im1.shape
+    H8, W8 = H // 8, W // 8
     N, M, Dv = H8 * W8, 4, 128
-    ldp = ops.round_up(N, 32)
-    P = torch.rand(B, M, N, ldp, device=dev, dtype=torch.float32).div_(N / 2).to(PROB_DTYPE[prec])
-    vT = torch.randn(B, M * Dv, ldp, device=dev).to(PROB_DTYPE[prec])
-    O = torch.empty(B, M, N, Dv, device=dev)
-    for _ in range(3):
-        ops.attn_apply(P, vT, Dv, prec, out=O)
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    s.record()
-    for _ in range(reps):
-        ops.attn_apply(P, vT, Dv, prec, out=O)
-    e.record()
-    torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / reps
-    bytes_alg = P.numel() * P.element_size() + vT.numel() * vT.element_size() + O.numel() * 4
+    ldp = (N + 31) // 32 * 32
+    orig = ops_mod.call
+    evs = []
+
+    def timed(name, *a):
+        if name != "craft_attn_apply":
+            return orig(name, *a)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        orig(name, *a)
+        e.record()
+        evs.append((s, e))
+    ops_mod.call = timed
+    try:
+        with torch.no_grad():
+            for _ in range(forwards):
+                model(im1, im2, iters=iters, test_mode=1)
+        torch.cuda.synchronize()
+    finally:
+        ops_mod.call = orig
+    if not evs:
+        return {"bound": "hbm", "kernel": "k_pv16", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
+                "note": "no refinement iteration ran: the kernel was not launched"}
+    ms = sum(s.elapsed_time(e) for s, e in evs) / len(evs)
+    esz = torch.empty(0, dtype=PROB_DTYPE[pv]).element_size()
+    bytes_alg = B * M * N * ldp * esz + B * M * Dv * ldp * esz + B * M * N * Dv * 4
     ach = bytes_alg / (ms * 1e-3) / 1e9
     # HBM bytes per launch from the committed PMC passes of this kernel at this shape (rocprofv3 --pmc FETCH_SIZE and
     # --pmc WRITE_SIZE in separate runs, gfx950 x2 correction on FETCH_SIZE: profiles/r1/pmc_traffic_pv16.json);
@@ -108,16 +123,17 @@ def roofline_pv(model, B, H8, W8, prec, reps=20):
         import json as _json
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1", "pmc_traffic_pv16.json")) as fh:
             pmc = _json.load(fh)
-        if (B, H8, W8) == (4, 56, 128) and prec == PREC_F16:
+        if (B, H8, W8) == (4, 56, 128) and pv == PREC_F16:
             traffic = int(pmc["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         pass
-    return {"bound": "hbm", "kernel": "k_pv16 (attention apply O = P.V of the motion aggregator, 12 launches per forward)",
+    return {"bound": "hbm", "kernel": f"k_pv16 (attention apply O = P.V of the motion aggregator, {iters} launches per forward)",
             "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
-            "bytes_per_launch": bytes_alg, "ms_per_launch": round(ms, 4),
-            "note": "algorithmic bytes = P (fp16, read once) + V^T + O; traffic = HBM bytes per launch from the PMC passes "
-                    "committed under profiles/r1 (FETCH_SIZE x2 on gfx950 + WRITE_SIZE); measured read-only ceiling of this "
-                    "access pattern on the same chip: 6.1 TB/s (tools/ubench/hbm_rows.hip)"}
+            "bytes_per_launch": bytes_alg, "ms_per_launch": round(ms, 4), "launches_timed": len(evs),
+            "note": "timed live around every launch of real forward passes (HIP events on the launch stream); algorithmic bytes "
+                    "= P (fp16, read once) + V^T + O; traffic = HBM bytes per launch from the PMC passes committed under "
+                    "profiles/r1 (FETCH_SIZE x2 on gfx950 + WRITE_SIZE); measured read-only ceiling of this access pattern "
+                    "on the same chip: 6.1 TB/s (tools/ubench/hbm_rows.hip)"}
 
 
 def roofline_conv(B, H8, W8, prec, reps=20):
@@ -228,7 +244,7 @@ def main():
         }
         if a.ops:
             op_table(model, im1, im2, a.iters)
-        line["roofline"] = roofline_pv(model, a.batch, a.height // 8, a.width // 8, prec)
+        line["roofline"] = roofline_pv(model, im1, im2, a.iters, prec)
         line["roofline_conv"] = roofline_conv(a.batch, a.height // 8, a.width // 8, prec)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.height, a.width, a.iters, a.cpu_threads)
