@@ -213,12 +213,10 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
       load_norm(cn, mu, rs);
 #pragma unroll
       for (int tap = 0; tap < TT; ++tap) {
-        constexpr bool kLastDummy = false; (void)kLastDummy;
         const bool last_tap = tap + 1 == TT;
         const int toff = (trow + tx) * LD;
         if (++tx == KW) { tx = 0; trow += HWd; }
         const int toffn = last_tap ? 0 : (trow + tx) * LD;
-        const int ktn = last_tap ? cn : (tap + 1) * nchunk + chunk;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           const int h = 2 * tap + kk;
@@ -227,7 +225,6 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
             if (last_tap) { __syncthreads(); hb ^= 1; }
             read_a(hb, toffn, 0, a0h, a0l);               // next tile (after the last chunk: a harmless re-read)
           }
-          constexpr int kDummy = 0; (void)kDummy;
           const int slot = (PHASE + h) % BD;
           if (kk == 0) mma_half(a0h, a0l, slot); else mma_half(a1h, a1l, slot);
           {   // B fragments of k-half h + BD (this chunk, or the head of the next one)
