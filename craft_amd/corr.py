@@ -59,6 +59,15 @@ class TransCorrBlock(CorrBlock, nn.Module):
         self.pyramids = []
         self.shape = None
 
+    def _w_aggr(self, st) -> float:
+        """The scalar weight of the softmax-over-modes pooling (a 1x1 nn.Linear) as a host float, read back once per
+        parameter version: a per-forward ``.item()`` is a host sync on the hot path (and cannot be graph-captured)."""
+        w = st.attn_softaggr.feat2score.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if getattr(self, "_w_aggr_key", None) != key:
+            self._w_aggr_val, self._w_aggr_key = float(w.detach().float().item()), key
+        return self._w_aggr_val
+
     def _build(self, x1_ln: torch.Tensor, x2_ln: torch.Tensor, hw, prec: int, slot: int):
         H8, W8 = hw
         B = x1_ln.shape[0]
@@ -72,7 +81,7 @@ class TransCorrBlock(CorrBlock, nn.Module):
         pyr = self.pyramids[slot]
         if pyr is None or (pyr.B, pyr.H8, pyr.W8) != (B, H8, W8) or pyr.lv[0].device != q.device:
             pyr = self.pyramids[slot] = ops.CorrPyramid(B, H8, W8, self.num_levels, q.device)
-        w_aggr = float(st.attn_softaggr.feat2score.weight.item()) if st.num_modes > 1 else 1.0
+        w_aggr = self._w_aggr(st) if st.num_modes > 1 else 1.0
         ops.corr_build(q, k, H8, W8, st.num_modes, scale, self.vispos_encoder.pos_coder.biases, float(st.pos_code_weight),
                        w_aggr, mx, pyr, self.do_corr_global_norm, prec)
 
