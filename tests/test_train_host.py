@@ -83,9 +83,13 @@ WORKER = textwrap.dedent("""
 def test_gradient_allreduce_two_ranks(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="1")
+    import socket
+    with socket.socket() as sk:                      # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
