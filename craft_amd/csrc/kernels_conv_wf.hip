@@ -73,13 +73,18 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
     const int y = y0 - g.padH + hy, x = x0 - g.padW + hx;
     hpix[i] = (hr < HR && y >= 0 && y < g.H && x >= 0 && x < g.W) ? y * g.W + x : -1;
   }
+  int hoff[NA];                                  // clamped pixel index within the whole tensor
+#pragma unroll
+  for (int i = 0; i < NA; ++i) hoff[i] = (int)img + max(hpix[i], 0);
   auto fetch_halo = [&](int chunk, float4 (&r)[NA]) __attribute__((always_inline)) {
     const int cb = chunk * BK;
     const float* sp; int ld, c;
     if (cb < g.c0) { sp = g.seg0; ld = g.ld0; c = cb; } else { sp = g.seg1; ld = g.ld1; c = cb - g.c0; }
-    // unconditional loads (clamped pixel); out-of-image taps are zeroed by a value select in store_halo
+    // unconditional loads (clamped pixel); out-of-image taps are zeroed by a value select in store_halo.  Address =
+    // wave-uniform base + 32-bit lane offset (the launcher routes tensors beyond 2^31 elements elsewhere): 2 VALU per load
+    const float* spc = sp + c;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) r[i] = *reinterpret_cast<const float4*>(sp + (img + max(hpix[i], 0)) * ld + c + c4 * 4);
+    for (int i = 0; i < NA; ++i) r[i] = *reinterpret_cast<const float4*>(spc + (unsigned)(hoff[i] * ld + c4 * 4));
   };
   // (mean, rstd) of this thread's 4 input channels for the lazy input normalisation of chunk `chunk`, image b
   auto load_norm = [&](int chunk, float4& mu, float4& rs) __attribute__((always_inline)) {
@@ -305,6 +310,7 @@ template <int PREC, int WM, int WN, int TT> static int launch_wf_tt(const ConvGe
   return (int)hipGetLastError();
 }
 template <int PREC, int WM, int WN> static int launch_wf_t(const ConvGemmParams& p, hipStream_t s) {
+  if ((long)p.g.npix * (long)max(p.g.ld0, p.g.c1 ? p.g.ld1 : 0) >= (1L << 31)) return CRAFT_ERR_UNSUPPORTED;   // 32-bit lane offsets
   static const bool dyn = getenv("CRAFT_WF_DYNAMIC_TAPS") != nullptr;       // A/B: always the run-time tap loop
   const int T = p.g.KH * p.g.KW;
   if (T == 5 && !dyn) return launch_wf_tt<PREC, WM, WN, 5>(p, s);
