@@ -61,6 +61,23 @@ __device__ __forceinline__ float pos_bias_at(const float* __restrict__ tab, int 
   return tab[(dh + R) * (2 * R + 1) + (dw + R)];
 }
 
+// fp32 -> two fp16 planes (hi = fp16(v), lo = fp16(v - hi)) of the f16x3 scheme, 4 values: 2 v_cvt_pk_f16_f32 (RNE) +
+// 4 v_fma_mix_f32 (float(hi) * -1 + v with the fp16 operand read straight from a half of the packed register, one rounding:
+// the same value as v - (float)hi) + 2 v_cvt_pk_f16_f32 = 8 VALU instead of 20 for cvt / cvt-back / sub per element.
+__device__ __forceinline__ void split_f16x3(const float4& v, f16x4& h, f16x4& l) {
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  f16x2 h0, h1;
+  h0[0] = (_Float16)v.x; h0[1] = (_Float16)v.y; h1[0] = (_Float16)v.z; h1[1] = (_Float16)v.w;
+  const unsigned u0 = __builtin_bit_cast(unsigned, h0), u1 = __builtin_bit_cast(unsigned, h1);
+  float lx, ly, lz, lw;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lx) : "v"(u0), "v"(v.x));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ly) : "v"(u0), "v"(v.y));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lz) : "v"(u1), "v"(v.z));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lw) : "v"(u1), "v"(v.w));
+  h[0] = h0[0]; h[1] = h0[1]; h[2] = h1[0]; h[3] = h1[1];
+  l[0] = (_Float16)lx; l[1] = (_Float16)ly; l[2] = (_Float16)lz; l[3] = (_Float16)lw;
+}
+
 #define HIP_CHECK_RET(expr)                 \
   do {                                      \
     hipError_t _e = (expr);                 \

@@ -77,9 +77,7 @@ __device__ __forceinline__ void stage_store_piece(typename PrecT<PREC>::lds_t* S
       *reinterpret_cast<f16x4*>(&S[row * LD + c4 * 4]) = h;
     } else {   // F16X3: hi plane, then lo plane at + ROWS*LD
       f16x4 h, l;
-      h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-      l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
-      l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+      split_f16x3(v, h, l);
       *reinterpret_cast<f16x4*>(&S[row * LD + c4 * 4]) = h;
       *reinterpret_cast<f16x4*>(&S[(ROWS + row) * LD + c4 * 4]) = l;
     }

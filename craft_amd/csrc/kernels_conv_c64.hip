@@ -117,14 +117,15 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_c64(ConvGemmParams p) {
           h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
           *reinterpret_cast<bf16x4*>(d) = h;
         } else {
-          f16x4 h;
-          h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-          *reinterpret_cast<f16x4*>(d) = h;
           if constexpr (PREC == CRAFT_PREC_F16X3) {
-            f16x4 l;
-            l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
-            l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+            f16x4 h, l;
+            split_f16x3(v, h, l);
+            *reinterpret_cast<f16x4*>(d) = h;
             *reinterpret_cast<f16x4*>(d + HRP * LD) = l;
+          } else {
+            f16x4 h;
+            h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+            *reinterpret_cast<f16x4*>(d) = h;
           }
         }
       }

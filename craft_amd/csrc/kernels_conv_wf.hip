@@ -112,15 +112,15 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
       h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
       *reinterpret_cast<bf16x4*>(&A0[row * LD + c4 * 4]) = h;
     } else {
-      f16x4 h;
-      h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-      *reinterpret_cast<f16x4*>(&A0[row * LD + c4 * 4]) = h;
       if constexpr (PREC == CRAFT_PREC_F16X3) {
-        f16x4 l;
-        // v - float(h) as one fma with an fp16 source operand (v_fma_mix_f32) instead of cvt + sub
-        l[0] = (_Float16)__builtin_fmaf((float)h[0], -1.f, v.x); l[1] = (_Float16)__builtin_fmaf((float)h[1], -1.f, v.y);
-        l[2] = (_Float16)__builtin_fmaf((float)h[2], -1.f, v.z); l[3] = (_Float16)__builtin_fmaf((float)h[3], -1.f, v.w);
+        f16x4 h, l;
+        split_f16x3(v, h, l);
+        *reinterpret_cast<f16x4*>(&A0[row * LD + c4 * 4]) = h;
         *reinterpret_cast<f16x4*>(&A0[(HR_MAX + row) * LD + c4 * 4]) = l;
+      } else {
+        f16x4 h;
+        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+        *reinterpret_cast<f16x4*>(&A0[row * LD + c4 * 4]) = h;
       }
     }
   };
