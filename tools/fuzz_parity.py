@@ -31,7 +31,8 @@ def sweep(n: int, seed0: int = 0, verbose: bool = True, variants: bool = False):
     for i in range(n):
         rng = np.random.RandomState(seed0 + i)
         i = seed0 + i
-        H8, W8 = int(rng.randint(8, 22)), int(rng.randint(8, 40))
+        hmax, wmax = int(os.environ.get("FUZZ_H8_MAX", 22)), int(os.environ.get("FUZZ_W8_MAX", 40))
+        H8, W8 = int(rng.randint(8, hmax)), int(rng.randint(8, wmax))
         B, iters = int(rng.randint(1, 4)), int(rng.randint(1, 4))
         policy = ["fp32", "mixed"][int(rng.randint(0, 2))]
         use_init = bool(rng.randint(0, 2))
