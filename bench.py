@@ -3,11 +3,13 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|fp16|fp32] [--batch 4]
 
-A "step" is one forward pass of craft_amd.CRAFT (CNN encoders on PyTorch-ROCm + the HIP hot path)
-over one batch of synthetic 448x1024 pairs already resident in HBM, test_mode=1, 12 iterations —
-BASELINE.json configs[1].  N>1 is launched by torch.distributed.run (one rank per GPU); pairs shard by
-batch with no data-path collective (weak scaling), the timed region is bracketed by barrier +
-synchronize and the max over ranks is reported.  Rank 0 prints ONE JSON line.
+A "step" is one forward pass of craft_amd.CRAFT (CNN encoders and the hot path both on the HIP kernels of
+libcraft_hip.so) over one batch of synthetic 448x1024 pairs already resident in HBM, test_mode=1, 12 iterations —
+BASELINE.json configs[1].  N>1: one rank per GPU over RCCL.  Either the caller starts the ranks
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: RANK / WORLD_SIZE in the environment), or
+plain `python bench.py --gpus N` re-executes itself under torch.distributed.run with N ranks (and refuses to run when
+fewer than N GPUs are visible).  Pairs shard by batch with no data-path collective (weak scaling), the timed region is
+bracketed by barrier + synchronize and the max over ranks is reported.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
   roofline      the dominant kernel by time, k_pv16 (attention apply O = P.V of the motion aggregator, ~19 % of a
@@ -185,13 +187,38 @@ def cpu_baseline(H, W, iters, threads):
         return None
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run
+    (127.0.0.1 rendezvous on a free port), pass their output through, return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL across processes needs dmabuf IPC on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and a.gpus > 1:
+        shared = os.environ.get("CRAFT_BENCH_BACKEND", "nccl") != "nccl"     # gloo: ranks may share a device (tests)
+        if not shared and torch.cuda.device_count() < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+        raise SystemExit(self_launch(a.gpus))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # one rank per GPU; CRAFT_BENCH_BACKEND=gloo lets several ranks share a device to exercise this path on a 1-GPU box
     backend = os.environ.get("CRAFT_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
