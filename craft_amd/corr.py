@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .hip import PREC_F32
+from .hip import PREC_F32, weights_epoch
 from .setrans import CrossAttFeatTrans, SETransConfig, SETransInputFeatEncoder
 
 
@@ -63,7 +63,7 @@ class TransCorrBlock(CorrBlock, nn.Module):
         """The scalar weight of the softmax-over-modes pooling (a 1x1 nn.Linear) as a host float, read back once per
         parameter version: a per-forward ``.item()`` is a host sync on the hot path (and cannot be graph-captured)."""
         w = st.attn_softaggr.feat2score.weight
-        key = (w.data_ptr(), w._version, w.device)
+        key = (weights_epoch(), w.data_ptr(), w._version, w.device)
         if getattr(self, "_w_aggr_key", None) != key:
             self._w_aggr_val, self._w_aggr_key = float(w.detach().float().item()), key
         return self._w_aggr_val

@@ -9,38 +9,19 @@ using namespace craft;
 #define S(stream) reinterpret_cast<hipStream_t>(stream)
 #define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
-namespace {
-// Fork / join of a side stream around independent launches inside one operator-level entry point.  The side stream and
-// the two events are created once per host thread and device (the library is called from one thread per GPU).
-struct AuxFork {
-  hipStream_t main, aux = nullptr;
-  hipEvent_t e_join = nullptr;
-  bool on;
-  AuxFork(hipStream_t s, bool enable) : main(s), on(false) {
-    if (!enable) return;
-    struct Res { hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; int dev = -1; };
-    static thread_local Res r;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return;
-    if (r.dev != dev) {
-      if (hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking) != hipSuccess) return;
-      if (hipEventCreateWithFlags(&r.e0, hipEventDisableTiming) != hipSuccess) return;
-      if (hipEventCreateWithFlags(&r.e1, hipEventDisableTiming) != hipSuccess) return;
-      r.dev = dev;
-    }
-    if (hipEventRecord(r.e0, s) != hipSuccess || hipStreamWaitEvent(r.st, r.e0, 0) != hipSuccess) return;
-    aux = r.st; e_join = r.e1; on = true;
-  }
-  hipStream_t side() const { return on ? aux : main; }
-  int join() {
-    if (!on) return 0;
-    on = false;
-    hipError_t e = hipEventRecord(e_join, aux);
-    if (e == hipSuccess) e = hipStreamWaitEvent(main, e_join, 0);
-    return (int)e;
-  }
-};
-}  // namespace
+namespace craft {
+const Tuning& tuning() {
+  static const Tuning t = [] {
+    Tuning v = {};
+    if (const char* e = getenv("CRAFT_HALO_BN")) v.halo_bn = atoi(e);
+    v.no_c64 = getenv("CRAFT_NO_C64") != nullptr;
+    v.wf_dynamic_taps = getenv("CRAFT_WF_DYNAMIC_TAPS") != nullptr;
+    return v;
+  }();
+  return t;
+}
+}  // namespace craft
+static const craft::Tuning& g_tuning_at_load = craft::tuning();     // evaluated by the dynamic loader, not by a launch
 
 extern "C" {
 
@@ -167,8 +148,10 @@ int craft_attn_apply(const void* P, long ldp, const float* rowsum, const void* v
   p.C = O; p.ldc = Dv; p.c_bs0 = (long)M * N * Dv; p.c_bs1 = (long)N * Dv;
   p.zdiv = M; p.batch = B * M; p.M = N; p.N = Dv; p.K = (int)ldp;
   p.bias = nullptr; p.scale = 1.f; p.act = CRAFT_ACT_NONE;
+  const int rows32 = (prec >> CRAFT_PV_ROWS_SHIFT) & 15;
+  prec &= (1 << CRAFT_PV_ROWS_SHIFT) - 1;
   if (prec == CRAFT_PREC_F32) return launch_gemm_rows(p, prec, false, S(stream));
-  return launch_pv16(p, prec, S(stream));
+  return launch_pv16(p, prec, rows32, S(stream));
 }
 
 int craft_forward_interpolate(const float* flow, int B, int H, int W, float* out, void* stream) {
@@ -202,16 +185,17 @@ static ConvGemmParams conv_params(const float* in0, int ld0, int c0, const float
 int craft_motion_encoder(const float* corr, long ldc, int cor_planes, const float* flow, const float* wc1, const float* bc1,
                          const float* wc2, const float* bc2, const float* wf1, const float* bf1, const float* wf2,
                          const float* bf2, const float* wcv, const float* bcv, int B, int H8, int W8, float* out, long ldo,
-                         float* ws, int prec, void* stream) {
+                         float* ws, int prec, void* flow_stream, void* flow_done, void* stream) {
   const long npix = (long)B * H8 * W8;
   float* cor1 = ws;                    // [npix][256]
   float* corflo = ws + npix * 256;     // [npix][256] = [cor (192) | flo (64)]
   float* flo1 = ws + npix * 512;       // [npix][128]
   hipStream_t s = S(stream);
   // The flow branch (convf1 -> convf2) and the correlation branch (convc1 -> convc2) are independent until `conv`:
-  // the flow branch runs on a side stream of the library, forked from / joined into the caller's stream by events.
-  AuxFork fork(s, getenv("CRAFT_NO_FORK") == nullptr);
-  hipStream_t sf = fork.side();
+  // with a caller-owned side stream + event the flow branch is enqueued there (the caller has already made flow_stream
+  // wait for whatever produced `flow` and `ws`), the event is recorded behind it and `stream` waits for it before `conv`.
+  const bool forked = flow_stream != nullptr && flow_done != nullptr && flow_stream != stream;
+  hipStream_t sf = forked ? S(flow_stream) : s;
   {  // cor = relu(convc1(corr))  1x1, cor_planes -> 256   (update.py:80)
     RowsGemmParams p = {};
     p.A = corr; p.lda = ldc; p.B = wc1; p.ldb = cor_planes; p.C = cor1; p.ldc = 256;
@@ -236,7 +220,10 @@ int craft_motion_encoder(const float* corr, long ldc, int cor_planes, const floa
     q.w_packed = pk;
     TRY(launch_gemm_conv(q, prec, sf));
   }
-  TRY(fork.join());
+  if (forked) {
+    TRY((int)hipEventRecord(reinterpret_cast<hipEvent_t>(flow_done), sf));
+    TRY((int)hipStreamWaitEvent(s, reinterpret_cast<hipEvent_t>(flow_done), 0));
+  }
   // out = cat[relu(conv(cor_flo)) (126), flow (2)]  (update.py:86-87)
   ConvGemmParams p = conv_params(corflo, 256, 256, nullptr, 0, 0, B, H8, W8, 3, 3, wcv, bcv, 126, CONV_EPI_MENC,
                                  CRAFT_ACT_RELU, 1.f, out, (int)ldo);

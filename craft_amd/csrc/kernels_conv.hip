@@ -269,7 +269,7 @@ int launch_conv_halo(const ConvGemmParams& p, int prec, hipStream_t s) {
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   // BN = 128 only when that still leaves >= 2 blocks per CU's worth of tiles for wide outputs
   int bn = (ncols % 128 == 0 && ncols >= 256) ? 128 : 64;
-  if (const char* e = getenv("CRAFT_HALO_BN")) bn = atoi(e) == 128 ? (ncols % 128 == 0 ? 128 : 64) : 64;   // tuning override
+  if (tuning().halo_bn) bn = tuning().halo_bn == 128 ? (ncols % 128 == 0 ? 128 : 64) : 64;   // developer A/B override
 #define GO(PR) do { if (bn == 128) return launch_halo_t<PR, 128>(p, s); else return launch_halo_t<PR, 64>(p, s); } while (0)
   if (prec == CRAFT_PREC_F32) GO(CRAFT_PREC_F32);
   if (prec == CRAFT_PREC_BF16) GO(CRAFT_PREC_BF16);

@@ -311,7 +311,7 @@ template <int PREC, int WM, int WN, int TT> static int launch_wf_tt(const ConvGe
 }
 template <int PREC, int WM, int WN> static int launch_wf_t(const ConvGemmParams& p, hipStream_t s) {
   if ((long)p.g.npix * (long)max(p.g.ld0, p.g.c1 ? p.g.ld1 : 0) >= (1L << 31)) return CRAFT_ERR_UNSUPPORTED;   // 32-bit lane offsets
-  static const bool dyn = getenv("CRAFT_WF_DYNAMIC_TAPS") != nullptr;       // A/B: always the run-time tap loop
+  const bool dyn = tuning().wf_dynamic_taps;       // A/B: always the run-time tap loop
   const int T = p.g.KH * p.g.KW;
   if (T == 5 && !dyn) return launch_wf_tt<PREC, WM, WN, 5>(p, s);
   if (T == 9 && !dyn) return launch_wf_tt<PREC, WM, WN, 9>(p, s);
@@ -320,11 +320,11 @@ template <int PREC, int WM, int WN> static int launch_wf_t(const ConvGemmParams&
 
 // packed (fragment-order) weights only; called by launch_conv_halo
 int launch_conv_halo_wf(const ConvGemmParams& p, int prec, hipStream_t s) {
-  if (conv3x3_c64_applies(p) && !getenv("CRAFT_NO_C64")) return launch_conv3x3_c64(p, prec, s);     // encoder layer1 shape
+  if (conv3x3_c64_applies(p) && !tuning().no_c64) return launch_conv3x3_c64(p, prec, s);     // encoder layer1 shape
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   // BN = 128 only when that still leaves >= 2 blocks per CU's worth of tiles for wide outputs
   int bn = (ncols % 128 == 0 && ncols >= 256) ? 128 : 64;
-  if (const char* e = getenv("CRAFT_HALO_BN")) bn = atoi(e) == 128 ? 128 : 64;   // tuning override
+  if (tuning().halo_bn) bn = tuning().halo_bn == 128 ? 128 : 64;   // developer A/B override
 #define GO(PR) do { if (bn == 128) return launch_wf_t<PR, 1, 4>(p, s); else return launch_wf_t<PR, 2, 2>(p, s); } while (0)
   if (prec == CRAFT_PREC_BF16) GO(CRAFT_PREC_BF16);
   if (prec == CRAFT_PREC_F16) GO(CRAFT_PREC_F16);

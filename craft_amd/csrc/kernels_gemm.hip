@@ -207,13 +207,14 @@ template <int PREC, int MT> static void launch_pv_t(const RowsGemmParams& p, hip
   hipLaunchKernelGGL((k_pv16<PREC, MT>), grid, dim3(NTHREADS), 0, s, p);
 }
 
-int launch_pv16(const RowsGemmParams& p, int prec, hipStream_t s) {
+int launch_pv16(const RowsGemmParams& p, int prec, int rows32, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return 0;
   if ((p.K & 15) || (p.lda & 7) || (p.N & 127) || p.c_dtype != CRAFT_PREC_F32) return CRAFT_ERR_ALIGN;
   // rows per block: minimise (resident rounds) x (work per block).  Blocks per CU from the register / LDS budget of
   // each instantiation (MT = 4: 3, MT >= 5: 2).
   int best = 4; long best_cost = -1;
-  const int force = getenv("CRAFT_PV_MT") ? atoi(getenv("CRAFT_PV_MT")) : 0;
+  if (rows32 && (rows32 < 4 || rows32 > 7)) return CRAFT_ERR_ARG;
+  const int force = rows32;
   for (int mt = 4; mt <= 7; ++mt) {
     const long blocks = (long)((p.M + 32 * mt - 1) / (32 * mt)) * (p.N / 128) * p.batch;
     const long slots = 256L * (mt == 4 ? 3 : 2);

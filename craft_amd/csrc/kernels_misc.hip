@@ -1,6 +1,7 @@
 // HBM-bound kernels of the hot path: token LayerNorm, mode pooling + skip + LayerNorm, pyramid pooling,
 // correlation lookup (radius-r bilinear gather), the two tiny convolutions that are not worth a GEMM,
 // convex upsampling and coordinate bookkeeping.  All activations are channels-last ("tokens": [B, N, C]).
+#include <atomic>
 #include "launch.hpp"
 
 namespace craft {
@@ -661,11 +662,15 @@ int launch_stem7x7(const float* img, const float* w, const float* bias, int act,
   const int H2 = H / 2, W2 = W / 2;
   const int tiles = ((W2 + STEM_TW - 1) / STEM_TW) * ((H2 + STEM_TH - 1) / STEM_TH) * B;
   const size_t lds = sizeof(float) * (147 * 64 + 3 * STEM_PH * STEM_PLD + 4 * 128);
-  static bool attr_done = false;
-  if (!attr_done) {
+  // the attribute is per device: one bit per device ordinal (set once each; a benign race sets it twice)
+  static std::atomic<unsigned long long> attr_done{0ull};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_relaxed) & bit)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stem7x7), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    attr_done.fetch_or(bit, std::memory_order_relaxed);
   }
   hipLaunchKernelGGL(k_stem7x7, dim3(tiles), dim3(256), lds, s, img, w, bias, act, H, W, out, stats);
   return (int)hipGetLastError();

@@ -11,6 +11,12 @@
 
 namespace craft {
 
+// Developer A/B overrides from the environment, read ONCE when the library is loaded (never in a launch path):
+// CRAFT_HALO_BN (64 | 128), CRAFT_NO_C64, CRAFT_WF_DYNAMIC_TAPS.  Everything a caller may legitimately vary per call is an
+// argument of the C ABI instead (e.g. CRAFT_PV_ROWS in craft_attn_apply's prec).
+struct Tuning { int halo_bn; bool no_c64, wf_dynamic_taps; };
+const Tuning& tuning();
+
 struct RowsGemmParams {
   const void* A; const void* B; void* C;
   int c_dtype;           // element type of C: 0 fp32, 1 bf16, 2 fp16
@@ -47,7 +53,8 @@ struct ConvGemmParams {
 };
 
 int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s);
-int launch_pv16(const RowsGemmParams& p, int prec, hipStream_t s);   // A and B both 16-bit (type = prec), C fp32
+int launch_pv16(const RowsGemmParams& p, int prec, int rows32, hipStream_t s);   // A and B both 16-bit (type = prec), C fp32;
+                                                                                  // rows32: 32-row groups per block (4..7), 0 = auto
 int launch_gemm_conv(const ConvGemmParams& p, int prec, hipStream_t s);
 int launch_conv_halo(const ConvGemmParams& p, int prec, hipStream_t s);
 int launch_conv_halo_wf(const ConvGemmParams& p, int prec, hipStream_t s);

@@ -167,7 +167,7 @@ def build_model(ns: argparse.Namespace, device="cuda"):
     over = {k: v for k, v in vars(ns).items() if (k in vars(default_args()) or k == "hip_precision") and v is not None}
     model = CRAFT(default_args(**over))
     if ns.model:
-        load_checkpoint(model, ns.model)
+        load_checkpoint(model, ns.model, trusted=getattr(ns, "trust_checkpoint", False))
     return model.to(device).eval()
 
 
@@ -183,6 +183,8 @@ def main(argv=None):
     ap.add_argument("--output", default=None, help="output directory of the submission writers")
     ap.add_argument("--fullprec", dest="mixed_precision", action="store_false", help="exact fp32 MFMA path (evaluate.py:1455)")
     ap.add_argument("--hip_precision", default=None)
+    ap.add_argument("--trust-checkpoint", dest="trust_checkpoint", action="store_true",
+                    help="allow the full unpickler if the safe one (tensors + numpy scalars) cannot read the file")
     ap.add_argument("--warm_start", action="store_true", help="sintel_submission: initialise each frame with the previous flow")
     ns = ap.parse_args(argv)
     ns.mixed_precision = bool(ns.mixed_precision)

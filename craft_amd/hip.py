@@ -15,6 +15,7 @@ import torch
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 W_PACKED = 0x100
+PV_ROWS_SHIFT = 20            # CRAFT_PV_ROWS(r) = r << 20, or-ed into craft_attn_apply's prec
 FRAG_ACC_ORDER = 0x10000      # == CRAFT_FRAG_ACC_ORDER
 STATS_REPLICAS = 64   # CRAFT_STATS_REPLICAS
 PREC_NAMES = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16, "f16x3": PREC_F16X3,
@@ -43,7 +44,7 @@ _SIGS = {
     "craft_forward_interpolate": [P, I, I, I, P, P],
     "craft_mode_pool_ln": [P, P, L, P, P, I, I, I, I, P, L, P],
     "craft_gma_residual": [P, L, P, P, I, I, I, P, L, P],
-    "craft_motion_encoder": [P, L, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, L, P, I, P],
+    "craft_motion_encoder": [P, L, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, L, P, I, P, P, P],
     "craft_sepconv_gru": [P, L, I, P, P, P, P, P, P, P, P, I, I, I, P, I, P],
     "craft_sepconv_gru_context": [P, L, I, P, P, P, P, P, P, P, P, I, I, I, P, I, P],
     "craft_sepconv_gru_step": [P, L, I, I, P, P, P, P, P, I, I, I, P, I, P],
@@ -65,14 +66,30 @@ _SIGS = {
 }
 
 
-# Named policies.  "mixed" is the default for mixed_precision=True: fp16 MFMA for the attention contractions
-# (projections, Q K^T, P V; fp32 accumulate) and exact-fp32 MFMA for the update-block convolutions; measured
-# mean end-point deviation from the fp32 path 0.004 px at 448x1024 / 12 iters.
+# Named policies.  "mixed" is the default for mixed_precision=True: split-fp16 (F16X3: fp32 operands as hi + lo fp16 planes,
+# 3 fp16 MFMAs per product, fp32 accumulate -- fp32-class results) for the projections, Q K^T and every convolution, and
+# plain fp16 storage + fp16 MFMA for the attention probabilities (P V); measured mean end-point deviation from the fp32
+# path < 1e-3 px at 448x1024 / 12 iters.  "mixed_fp32conv": fp16 attention contractions + exact
+# fp32 MFMA convolutions.
 NAMED_POLICIES = {"mixed": "proj=f16x3,score=f16x3,pv=fp16,conv=f16x3", "mixed_fp32conv": "proj=fp16,score=fp16,pv=fp16,conv=fp32"}
 
 
 class CraftHipError(RuntimeError):
     pass
+
+
+# Re-laid-out weight caches (packed conv weights, BatchNorm-folded encoder weights, host copies of scalars) are keyed on
+# (data_ptr, _version) of their source parameters AND on this counter: an optimizer that updates parameters through raw
+# pointers (train.FlatAdamW's fused kernel) changes neither, so it bumps the epoch instead.
+_weights_epoch = [0]
+
+
+def weights_epoch() -> int:
+    return _weights_epoch[0]
+
+
+def bump_weights_epoch() -> None:
+    _weights_epoch[0] += 1
 
 
 class Precision:

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .extractor import BasicEncoder, ResidualBlock
-from .hip import ACT_NONE, ACT_RELU, PREC_F32, STATS_REPLICAS, W_PACKED, call, pick
+from .hip import ACT_NONE, ACT_RELU, PREC_F32, STATS_REPLICAS, W_PACKED, call, pick, weights_epoch
 
 IN_EPS = 1e-5   # nn.InstanceNorm2d / nn.BatchNorm2d default eps (extractor.py uses the defaults)
 
@@ -74,7 +74,7 @@ class HipEncoder:
 
     def _get_packs(self, prec: int):
         params = [p for p in self.enc.parameters()] + [b for b in self.enc.buffers()]
-        key = (prec,) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (prec, weights_epoch()) + tuple((p.data_ptr(), p._version) for p in params)
         if key != self._key:
             bn = self.kind == "batch"
             packs = []

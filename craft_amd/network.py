@@ -9,14 +9,16 @@ canonical ``--craft --f2 full --setrans`` configuration), ``freeze_bn()``.
 Execution: the CNN encoders run on the same HIP conv engine (craft_amd/hip_encoder.py; ``args.hip_encoders=False``
 keeps them on PyTorch-ROCm / MIOpen); everything after them — F2 transformer,
 intra-frame attention, correlation volume + pyramid, and the T refinement iterations — runs through
-``libcraft_hip.so`` on channels-last token buffers.  Inference only in this round: tensors produced
-by the HIP path carry no autograd graph.
+``libcraft_hip.so`` on channels-last token buffers.  ``model.eval()`` / ``torch.no_grad()`` takes the fused inference
+path (no autograd graph); ``model.train()`` with gradients enabled takes the training path (craft_amd/autograd.py:
+every hot-path op is an ``autograd.Function`` whose forward AND backward are HIP kernels).
 
 Extra (non-reference) argument fields, all optional:
   ``hip_precision``: "fp32" | "mixed" | "fp16" | "bf16" MFMA operand precision of the hot path, or per role,
                      e.g. "score=bf16,pv=fp16,conv=fp32,proj=fp32" (craft_amd.hip.Precision).  Default: "fp32"
-                     when ``mixed_precision`` is False (the reference's fp32 path); "mixed" (fp16 attention
-                     contractions, fp32 convolutions) when it is True (the reference autocasts to fp16 there).
+                     when ``mixed_precision`` is False (the reference's fp32 path); "mixed" when it is True (the reference
+                     autocasts to fp16 there) = "proj=f16x3,score=f16x3,pv=fp16,conv=f16x3": split-fp16 MFMA (3 fp16
+                     MFMAs per product, fp32-class) for projections, Q K^T and all convolutions, fp16 P.V.
 """
 from __future__ import annotations
 

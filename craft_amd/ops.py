@@ -257,8 +257,10 @@ def probs_slice(P: torch.Tensor, b0: int, b1: int) -> torch.Tensor:
     return v
 
 
-def attn_apply(P: torch.Tensor, vT: torch.Tensor, Dv: int, prec: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """O[b][m] = P[b][m] @ V_m with vT [B, M*Dv, ldp] (16-bit: fragment order, ``linear_t(..., Dv=Dv)``) -> O [B, M, N, Dv]."""
+def attn_apply(P: torch.Tensor, vT: torch.Tensor, Dv: int, prec: int, out: Optional[torch.Tensor] = None,
+               rows32: int = 0) -> torch.Tensor:
+    """O[b][m] = P[b][m] @ V_m with vT [B, M*Dv, ldp] (16-bit: fragment order, ``linear_t(..., Dv=Dv)``) -> O [B, M, N, Dv].
+    ``rows32`` (4..7, 0 = chosen from the grid size): 32-row groups per block of the 16-bit kernel (CRAFT_PV_ROWS)."""
     B, M, N, ldp = P.shape
     if out is None:
         out = torch.empty(B, M, N, Dv, device=P.device, dtype=torch.float32)
@@ -267,7 +269,7 @@ def attn_apply(P: torch.Tensor, vT: torch.Tensor, Dv: int, prec: int, out: Optio
         raise hip.CraftHipError(f"attention probabilities are {P.dtype} but the pv precision expects {PROB_DTYPE[pv]}")
     if vT.dtype != P.dtype:
         raise hip.CraftHipError(f"V^T is {vT.dtype} but P is {P.dtype}")
-    call("craft_attn_apply", P, ldp, getattr(P, "craft_rowsum", None), vT, B, N, M, Dv, out, pv)
+    call("craft_attn_apply", P, ldp, getattr(P, "craft_rowsum", None), vT, B, N, M, Dv, out, pv | (rows32 << hip.PV_ROWS_SHIFT))
     return out
 
 
@@ -299,6 +301,13 @@ def convex_upsample(mask: torch.Tensor, flow: torch.Tensor, H8: int, W8: int, ou
 
 def coords_init(flow_init: Optional[torch.Tensor], B: int, H8: int, W8: int, device):
     N = H8 * W8
+    if flow_init is not None:
+        if not flow_init.is_cuda:
+            raise ValueError("flow_init must be on the GPU")
+        if tuple(flow_init.shape) == (1, 2, H8, W8) and B > 1:
+            flow_init = flow_init.expand(B, -1, -1, -1)        # the reference's `coords1 + flow_init` broadcasts a batch of 1
+        if tuple(flow_init.shape) != (B, 2, H8, W8):
+            raise ValueError(f"flow_init must be [{B}, 2, {H8}, {W8}] (1/8 resolution), got {tuple(flow_init.shape)}")
     c0 = torch.empty(B, N, 2, device=device, dtype=torch.float32)
     c1 = torch.empty_like(c0)
     fl = torch.empty_like(c0)

@@ -99,9 +99,13 @@ class FlatAdamW:
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 1e-2):
-        self.params = [p for p in params if p.requires_grad]
+        self.params = list(params)
         if not self.params:
-            raise ValueError("FlatAdamW: no trainable parameters")
+            raise ValueError("FlatAdamW: no parameters")
+        if any(not p.requires_grad for p in self.params):
+            # the state dict is indexed like torch.optim.AdamW(model.parameters()) (train.py:78): a frozen parameter would
+            # shift every later index, and the reference trainers freeze nothing
+            raise ValueError("FlatAdamW: every parameter must require grad (state-dict indices follow model.parameters())")
         dev = self.params[0].device
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.empty(self.numel, device=dev, dtype=torch.float32)
@@ -133,6 +137,7 @@ class FlatAdamW:
 
     def step(self, lr: Optional[float] = None, max_norm: float = 0.0, grad_mul: float = 1.0):
         """One update; ``max_norm`` > 0 applies clip_grad_norm_(params, max_norm) (train.py:234) without a host sync."""
+        self._check_views()
         self.step_count += 1
         sumsq = None
         if max_norm > 0:
@@ -142,6 +147,23 @@ class FlatAdamW:
         call("craft_adamw_step", self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.numel,
              float(self.lr if lr is None else lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
              float(self.weight_decay), self.step_count, float(grad_mul), sumsq, float(max_norm))
+        # the kernel wrote through raw pointers: p._version / data_ptr() did not move, so tell the packed-weight caches
+        from .hip import bump_weights_epoch
+        bump_weights_epoch()
+
+    def _check_views(self):
+        """model.zero_grad(set_to_none=True), model.to(...) or p.grad = ... silently detach parameters / gradients from the
+        flat buffers; the fused kernel would then update stale memory.  Cheap host check (145 pointer compares)."""
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.data_ptr() != self.flat.data_ptr() + 4 * off:
+                raise RuntimeError("FlatAdamW: a parameter no longer lives in the flat buffer (model.to() / load with "
+                                   "assign=True after the optimizer was built?)")
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                raise RuntimeError("FlatAdamW: a .grad no longer aliases the flat gradient buffer "
+                                   "(use optimizer.zero_grad(), not model.zero_grad(set_to_none=True))")
+            off += n
 
     # ---- torch.optim.AdamW-compatible state (the 'optimizer' entry of the reference's checkpoints, train.py:139)
     def state_dict(self) -> Dict:
@@ -192,11 +214,12 @@ def save_checkpoint(path: str, model: torch.nn.Module, optimizer: FlatAdamW, lr_
 
 
 def load_checkpoint(path: str, model: torch.nn.Module, optimizer: Optional[FlatAdamW] = None,
-                    lr_scheduler: Optional[OneCycleLR] = None, load_optimizer_state: bool = False, load_scheduler_state: bool = False):
+                    lr_scheduler: Optional[OneCycleLR] = None, load_optimizer_state: bool = False, load_scheduler_state: bool = False,
+                    trusted: bool = False):
     """New dict layout or legacy bare state dict, strict=False; optimizer / scheduler only on request (train.py:147-175,
     --loadopt / --loadsched)."""
-    from .utils import load_checkpoint as load_model
-    ck = torch.load(path, map_location="cpu", weights_only=False)
+    from .utils import load_checkpoint as load_model, read_checkpoint
+    ck = read_checkpoint(path, trusted=trusted)
     msg = load_model(model, ck)
     if optimizer is not None:                      # load_state_dict re-pointed nothing: the flat views stay valid, but refresh
         off = 0                                    # the flat copy in case a parameter was replaced rather than copied into

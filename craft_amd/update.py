@@ -8,6 +8,7 @@ r*h, GRU blend, 0.25 mask scale); every ``torch.cat`` of the reference is a colu
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -15,7 +16,7 @@ import torch.nn as nn
 
 from . import ops
 from .gma import Aggregate
-from .hip import PREC_F32, W_PACKED, call, pick
+from .hip import PREC_F32, W_PACKED, call, pick, weights_epoch
 from .setrans import ExpandedFeatTrans
 
 
@@ -27,7 +28,7 @@ class _PackCache:
         self._val = None
 
     def get(self, params, fn, tag=0):
-        key = (tag,) + tuple((p.data_ptr(), p._version, p.device) for p in params)
+        key = (tag, weights_epoch()) + tuple((p.data_ptr(), p._version, p.device) for p in params)
         if key != self._key:
             with torch.no_grad():
                 self._val = fn()
@@ -146,14 +147,32 @@ class BasicMotionEncoder(nn.Module):
                                              ops.pack_conv_prec(self.convf2.weight, prec), b(self.convf2),
                                              ops.pack_conv_prec(self.conv.weight, prec), b(self.conv)), tag=prec)
 
-    def forward_tokens(self, flow: torch.Tensor, corr: torch.Tensor, hw, out: torch.Tensor, ws: torch.Tensor, prec: int):
-        """flow tokens [B,N,2], corr tokens [B,N,cor_planes] -> out tokens view [B,N,128]."""
+    def _flow_side(self, device):
+        """(side stream, event) for the flow branch, one pair per calling stream: the C ABI owns no stream or event
+        (include/craft_hip.h), the caller hands them in."""
+        cache = self.__dict__.setdefault("_side", {})
+        key = (device.index, torch.cuda.current_stream().cuda_stream)
+        if key not in cache:
+            st, ev = torch.cuda.Stream(device=device), torch.cuda.Event()
+            ev.record(st)                       # torch creates the hipEvent_t lazily: materialise the handle
+            cache[key] = (st, ev)
+        return cache[key]
+
+    def forward_tokens(self, flow: torch.Tensor, corr: torch.Tensor, hw, out: torch.Tensor, ws: torch.Tensor, prec: int,
+                       fork: bool = True):
+        """flow tokens [B,N,2], corr tokens [B,N,cor_planes] -> out tokens view [B,N,128].  ``fork``: the flow branch
+        (convf1 -> convf2) runs on a side stream next to the correlation branch."""
         B, N, _ = flow.shape
         H8, W8 = hw
         cp = pick(prec, "conv")
         wc1, bc1, wc2, bc2, wf1, bf1, wf2, bf2, wcv, bcv = self.packed(cp)
+        st = ev = None
+        if fork and not os.environ.get("CRAFT_NO_FORK"):
+            side, event = self._flow_side(flow.device)
+            side.wait_stream(torch.cuda.current_stream())       # the side stream sees `flow` / `ws` as the caller left them
+            st, ev = side.cuda_stream, event.cuda_event
         call("craft_motion_encoder", corr, corr.stride(1), self.cor_planes, flow, wc1, bc1, wc2, bc2, wf1, bf1, wf2, bf2,
-             wcv, bcv, B, H8, W8, out, out.stride(1), ws, cp | W_PACKED)
+             wcv, bcv, B, H8, W8, out, out.stride(1), ws, cp | W_PACKED, st, ev)
 
 
 class GMAUpdateBlock(nn.Module):

@@ -66,10 +66,37 @@ def default_args(**overrides) -> argparse.Namespace:
     return a
 
 
-def load_checkpoint(model: torch.nn.Module, path_or_dict, strict: bool = False):
+def read_checkpoint(path: str, trusted: bool = False):
+    """torch.load for a reference-layout checkpoint file.  The reference's trainers store {'model', 'optimizer',
+    'lr_scheduler', 'logger'} (train.py:132-145); 'logger' holds numpy scalars and 'lr_scheduler' the OneCycleLR state, which
+    the safe unpickler (weights_only=True, the default since torch 2.6) rejects.  First try the safe load with the numpy
+    scalar globals allow-listed; only if that still fails AND the caller says the file is ``trusted`` fall back to the
+    full unpickler."""
+    import pickle
+    try:
+        import numpy as np
+        safe = [np.dtype, np.ndarray]
+        for name in ("_core.multiarray.scalar", "core.multiarray.scalar", "_core.multiarray._reconstruct", "core.multiarray._reconstruct"):
+            mod, _, attr = name.rpartition(".")
+            try:
+                safe.append(getattr(__import__("numpy." + mod, fromlist=[attr]), attr))
+            except (ImportError, AttributeError):
+                pass
+        safe += [type(np.dtype(t)) for t in ("float64", "float32", "int64", "int32")]
+        with torch.serialization.safe_globals(safe):
+            return torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        if not trusted:
+            raise pickle.UnpicklingError(f"{path}: not loadable with the safe unpickler ({str(e).splitlines()[0]}); pass trusted=True "
+                                         "(evaluate: --trust-checkpoint) for a checkpoint from a source you trust") from e
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
+def load_checkpoint(model: torch.nn.Module, path_or_dict, strict: bool = False, trusted: bool = False):
     """Load a reference-layout checkpoint: ``{'model': {'module.<key>': tensor}, ...}`` or a legacy bare
-    state dict, with or without the DataParallel ``module.`` prefix (evaluate.py:1540-1547, train.py:147-154)."""
-    ck = torch.load(path_or_dict, map_location="cpu") if isinstance(path_or_dict, str) else path_or_dict
+    state dict, with or without the DataParallel ``module.`` prefix (evaluate.py:1540-1547, train.py:147-154).
+    Only ``ck['model']`` is read."""
+    ck = read_checkpoint(path_or_dict, trusted) if isinstance(path_or_dict, str) else path_or_dict
     sd = ck["model"] if isinstance(ck, dict) and "model" in ck else ck
     sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
     return model.load_state_dict(sd, strict=strict)

@@ -124,7 +124,11 @@ int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, 
  * prec (0 fp32, 1 bf16, 2 fp16) is the element type of BOTH P (craft_attn_probs with p_prec = prec) and vT
  * (craft_linear_t with out_prec = prec), and the MFMA path.  For prec 1 / 2, vT must be in fragment order
  * (craft_linear_t with frag_rows = Dv) and Dv % 128 == 0; for prec 0 it is plain row-major.  rowsum: NULL for a
- * normalised P, else the row sums craft_attn_probs produced with it (O rows are divided by them). */
+ * normalised P, else the row sums craft_attn_probs produced with it (O rows are divided by them).
+ * 16-bit path: a block owns 32*r query rows x 128 value columns; r (4..7) is chosen from the grid size unless the caller
+ * or-s CRAFT_PV_ROWS(r) into prec (tests pin every instantiation that way). */
+#define CRAFT_PV_ROWS_SHIFT 20
+#define CRAFT_PV_ROWS(r) ((r) << CRAFT_PV_ROWS_SHIFT)
 int craft_attn_apply(const void* P, long ldp, const float* rowsum, const void* vT, int B, int N, int M, int Dv, float* O,
                      int prec, void* stream);
 
@@ -203,12 +207,17 @@ int craft_residual_relu(const float* x, long ldx, const float* xnorm, const floa
 /* BasicMotionEncoder.forward (update.py:79-87).  corr tokens [B*N][cor_planes] (row stride ldc), flow tokens
  * [B*N][2].  Conv weights are packed [Cout][KH][KW][Cin] (weight.permute(0,2,3,1)); wf1 is packed
  * [7*7*2][128] (weight.permute(2,3,1,0)).  Output: 128 channels (126 conv + 2 flow) at out (row stride ldo).
- * ws: 640 floats per pixel. */
+ * ws: 640 floats per pixel.
+ * flow_stream / flow_done (both NULL: everything runs in order on `stream`): a caller-owned hipStream_t and hipEvent_t.  The
+ * flow branch (convf1 -> convf2) is independent of the correlation branch (convc1 -> convc2) until the last convolution, so
+ * it is enqueued on flow_stream, flow_done is recorded behind it and `stream` waits for that event before the last
+ * convolution.  The CALLER orders flow_stream behind the producers of `flow` and `ws` (an event wait on its own stream) --
+ * the library creates no stream, event or other state of its own. */
 int craft_motion_encoder(const float* corr, long ldc, int cor_planes, const float* flow, const float* wc1,
                          const float* bc1, const float* wc2, const float* bc2, const float* wf1,
                          const float* bf1, const float* wf2, const float* bf2, const float* wcv,
                          const float* bcv, int B, int H8, int W8, float* out, long ldo, float* ws, int prec,
-                         void* stream);
+                         void* flow_stream, void* flow_done, void* stream);
 
 /* SepConvGRU.forward (update.py:49-64) in place on hx = [h (128) | x (cx)] (row stride ldhx): 1x5 pass then
  * 5x1 pass; wzr*: convz and convr stacked on the output axis and packed [256][KH][KW][128+cx], wq*:

@@ -93,3 +93,30 @@ def test_gradient_allreduce_two_ranks(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_reference_style_full_checkpoint_loads(tmp_path):
+    """A checkpoint as the reference's trainer writes it (train.py:132-145): numpy scalars in 'logger', OneCycleLR state in
+    'lr_scheduler'.  The safe unpickler with numpy globals allow-listed must read it; an arbitrary pickled
+    object is refused unless trusted=True."""
+    import pickle
+    import numpy as np
+    from craft_amd import CRAFT, default_args
+    from craft_amd.utils import load_checkpoint, read_checkpoint
+    model = CRAFT(default_args())
+    sd = {"module." + k: v for k, v in model.state_dict().items()}
+    ck = {"model": sd, "optimizer": {"state": {}, "param_groups": [{"lr": 1e-4, "params": [0]}]},
+          "lr_scheduler": {"total_steps": 100, "last_epoch": 3, "_last_lr": [1e-4], "anneal_func": "linear"},
+          "logger": {"train_epe_list": [np.float64(1.5), np.mean(np.array([1.0, 2.0], dtype=np.float32))], "total_steps": 3}}
+    path = str(tmp_path / "ref_style.pth")
+    torch.save(ck, path)
+    res = load_checkpoint(CRAFT(default_args()), path, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert read_checkpoint(path)["logger"]["total_steps"] == 3
+
+    import argparse
+    ck["logger"]["odd"] = argparse.Namespace(a=1)            # something the safe unpickler must refuse
+    torch.save(ck, path)
+    with pytest.raises(pickle.UnpicklingError):
+        read_checkpoint(path)
+    assert "odd" in read_checkpoint(path, trusted=True)["logger"]
