@@ -1,7 +1,7 @@
 """CPU oracle for CRAFT's hot path — TEST INFRASTRUCTURE, NOT THE PRODUCT.
 
-A functional fp32 restatement (torch-CPU / numpy, no nn.Module, no autograd) of the reference's
-inner-loop algorithm, written from SURVEY.md Appendix A and the cited reference lines.  Only
+A functional fp32 restatement (torch-CPU / numpy, no nn.Module; differentiable by torch autograd, which is how the
+gradient tests use it: ``craft_train_forward``) of the reference's inner-loop algorithm, written from SURVEY.md Appendix A and the cited reference lines.  Only
 ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it; the
 product path (``craft_amd``) never does and fails loudly when ``libcraft_hip.so`` is missing.
 
@@ -406,28 +406,36 @@ def convex_upsample(flow: Tensor, mask: Tensor) -> Tensor:
 # ------------------------------------------------------------------------------------------------
 # CNN encoders (extractor.py:124-196) — not hot path, needed for an end-to-end forward
 # ------------------------------------------------------------------------------------------------
-def _norm(x, sd, name, kind):
+def _norm(x, sd, name, kind, bn_stats=None):
+    """norm_fn of BasicEncoder / ResidualBlock (extractor.py:21-47, :131-137).  ``bn_stats`` (a dict) selects nn.BatchNorm2d's
+    TRAINING behaviour: normalise with the batch statistics and record the momentum-0.1 update of the running statistics
+    (unbiased variance) under the buffer names -- what model.train() does to cnet unless freeze_bn() was called."""
     if kind == "instance":
         return F.instance_norm(x, eps=1e-5)
+    if bn_stats is not None:
+        rm, rv = sd[name + ".running_mean"].detach().clone(), sd[name + ".running_var"].detach().clone()
+        y = F.batch_norm(x, rm, rv, sd[name + ".weight"], sd[name + ".bias"], training=True, momentum=0.1, eps=1e-5)
+        bn_stats[name + ".running_mean"], bn_stats[name + ".running_var"] = rm, rv
+        return y
     return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"],
                         sd[name + ".weight"], sd[name + ".bias"], training=False, eps=1e-5)
 
 
-def _resblock(x, sd, p, kind, stride):
+def _resblock(x, sd, p, kind, stride, bn_stats=None):
     """ResidualBlock.forward (extractor.py:56-64)."""
-    y = F.relu(_norm(F.conv2d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], stride=stride, padding=1), sd, p + ".norm1", kind))
-    y = F.relu(_norm(F.conv2d(y, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1), sd, p + ".norm2", kind))
+    y = F.relu(_norm(F.conv2d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], stride=stride, padding=1), sd, p + ".norm1", kind, bn_stats))
+    y = F.relu(_norm(F.conv2d(y, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1), sd, p + ".norm2", kind, bn_stats))
     if stride != 1:
-        x = _norm(F.conv2d(x, sd[p + ".downsample.0.weight"], sd[p + ".downsample.0.bias"], stride=stride), sd, p + ".norm3", kind)
+        x = _norm(F.conv2d(x, sd[p + ".downsample.0.weight"], sd[p + ".downsample.0.bias"], stride=stride), sd, p + ".norm3", kind, bn_stats)
     return F.relu(x + y)
 
 
-def basic_encoder(x: Tensor, sd, p: str, kind: str) -> Tensor:
-    """BasicEncoder.forward in eval mode (extractor.py:173-196)."""
-    x = F.relu(_norm(F.conv2d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], stride=2, padding=3), sd, p + ".norm1", kind))
+def basic_encoder(x: Tensor, sd, p: str, kind: str, bn_stats=None) -> Tensor:
+    """BasicEncoder.forward (extractor.py:173-196); eval mode unless ``bn_stats`` is given (see _norm)."""
+    x = F.relu(_norm(F.conv2d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], stride=2, padding=3), sd, p + ".norm1", kind, bn_stats))
     for li, stride in ((1, 1), (2, 2), (3, 2)):
-        x = _resblock(x, sd, f"{p}.layer{li}.0", kind, stride)
-        x = _resblock(x, sd, f"{p}.layer{li}.1", kind, 1)
+        x = _resblock(x, sd, f"{p}.layer{li}.0", kind, stride, bn_stats)
+        x = _resblock(x, sd, f"{p}.layer{li}.1", kind, 1, bn_stats)
     return F.conv2d(x, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"])
 
 
@@ -475,6 +483,7 @@ def hot_path(fmap1: Tensor, fmap2: Tensor, net: Tensor, inp: Tensor, sd, cfg: Or
         capture.update(fmap2t=fmap2t, fmap1t=fmap1t, attention=attention, corr_raw=c, mu=mu, rstd=rstd)
     preds = []
     for it in range(iters):
+        coords1 = coords1.detach()                                     # network.py:232 (a no-op without autograd)
         corr = corr_lookup2(pyr, coords1, cfg.corr_radius, mu, rstd) if two_way else corr_lookup(pyr, coords1, cfg.corr_radius, mu, rstd)
         flow = coords1 - coords0
         net, mask, dflow = update_block(net, inp, corr, flow, attention, sd, cfg)
@@ -504,6 +513,39 @@ def craft_forward(sd, cfg: OracleConfig, image1: Tensor, image2: Tensor, iters: 
         if capture is not None:
             capture.update(fmap1=fmap1, fmap2=fmap2, net0=net, inp=inp)
         return hot_path(fmap1, fmap2, net, inp, sd, cfg, iters, flow_init, test_mode, capture)
+
+
+# ------------------------------------------------------------------------------------------------
+# training step (train.py:44-73, :228-236): the same forward with autograd on, model.train() semantics
+# ------------------------------------------------------------------------------------------------
+MAX_FLOW = 400.0         # train.py:30
+
+
+def sequence_loss(flow_preds: List[Tensor], flow_gt: Tensor, valid: Tensor, gamma: float):
+    """train.py:44-73: sum_i gamma^(T-1-i) * mean(valid * |pred_i - gt|) over ALL B*2*H*W elements, valid = (valid >= 0.5) &
+    (|gt| < MAX_FLOW); metrics of the last prediction over the valid pixels."""
+    T = len(flow_preds)
+    v = (valid >= 0.5) & ((flow_gt ** 2).sum(dim=1).sqrt() < MAX_FLOW)
+    loss = 0.0
+    for i, p in enumerate(flow_preds):
+        loss = loss + gamma ** (T - i - 1) * (v[:, None] * (p - flow_gt).abs()).mean()
+    epe = ((flow_preds[-1] - flow_gt) ** 2).sum(dim=1).sqrt().reshape(-1)[v.reshape(-1)]
+    return loss, {"epe": epe.mean().item(), "1px": (epe < 1).float().mean().item(), "3px": (epe < 3).float().mean().item(),
+                  "5px": (epe < 5).float().mean().item()}
+
+
+def craft_train_forward(sd, cfg: OracleConfig, image1: Tensor, image2: Tensor, iters: int = 12, freeze_bn: bool = False):
+    """CRAFT.forward under model.train() with every dropout at p = 0 (network.py:164-267): differentiable w.r.t. the tensors
+    of ``sd`` that require grad; cnet's BatchNorm uses batch statistics unless ``freeze_bn`` (network.py:136-140).
+    -> (flow_predictions, {buffer name: updated running statistic})."""
+    im1 = 2 * (image1 / 255.0) - 1.0
+    im2 = 2 * (image2 / 255.0) - 1.0
+    B = im1.shape[0]
+    fm = basic_encoder(torch.cat([im1, im2], dim=0), sd, "fnet", "instance")
+    bn_stats = None if freeze_bn else {}
+    cn = basic_encoder(im1, sd, "cnet", "batch", bn_stats)
+    preds = hot_path(fm[:B], fm[B:], torch.tanh(cn[:, :128]), torch.relu(cn[:, 128:]), sd, cfg, iters, None, test_mode=0)
+    return preds, (bn_stats or {})
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Training-side goldens (SURVEY.md §8(a) row H'): loss and parameter gradients of the REFERENCE
+(`core.network.CRAFT` imported from /root/reference, `model.train()`, every nn.Dropout forced to p = 0 so the step is
+deterministic) under the reference's own `sequence_loss` (compiled from train.py's AST, as in make_golden_harness.py).
+
+Only runs in the build container.  Committed: tests/golden/train_*.npz = inputs (uint8 images, flow ground truth, valid
+mask), the weight recipe, the loss, a strided sample + (sum, sum^2) of EVERY parameter's gradient, the names of parameters
+the reference leaves without a gradient (DDP's find_unused_parameters case), and the BatchNorm running statistics after the
+step (cnet runs on batch statistics in training mode unless freeze_bn).
+
+    python tools/make_golden_train.py
+"""
+import ast
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, "/root/reference/core")
+
+from craft_amd.synth import synth_pair, synth_state_dict  # noqa: E402
+from make_golden import ref_args, sample  # noqa: E402
+
+CASES = [
+    dict(name="train_b2_128x192_T3", B=2, H=128, W=192, iters=3, seed=1234, qk_gain=2.5, freeze_bn=False, gamma=0.8),
+    dict(name="train_freezebn_b2_128x160_T2", B=2, H=128, W=160, iters=2, seed=41, qk_gain=2.5, freeze_bn=True, gamma=0.85),
+]
+
+
+def ref_sequence_loss():
+    path = "/root/reference/train.py"
+    tree = ast.parse(open(path).read(), path)
+    ns = {"torch": torch}
+    for n in tree.body:
+        if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", None) == "MAX_FLOW":
+            ns["MAX_FLOW"] = ast.literal_eval(n.value)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "sequence_loss"]
+    exec(compile(ast.Module(body=fn, type_ignores=[]), path, "exec"), ns)
+    return ns["sequence_loss"]
+
+
+def run(c, seq_loss):
+    from network import CRAFT  # the reference
+    torch.manual_seed(0)
+    m = CRAFT(ref_args())
+    sd = synth_state_dict(m.state_dict(), seed=c["seed"], qk_gain=c["qk_gain"])
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    if c["freeze_bn"]:
+        m.freeze_bn()
+    n_drop = 0
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+            n_drop += 1
+    B, H, W = c["B"], c["H"], c["W"]
+    im1, im2, flow = synth_pair(B, H, W, seed=c["seed"])
+    g = torch.Generator().manual_seed(c["seed"] + 77)
+    gt = (flow + 0.5 * torch.randn(B, 2, H, W, generator=g)).float()
+    valid = (torch.rand(B, H, W, generator=g) > 0.2).float()
+    preds = m(im1, im2, iters=c["iters"])
+    assert isinstance(preds, list) and len(preds) == c["iters"]
+    loss, metrics = seq_loss(preds, gt, valid, c["gamma"])
+    loss.backward()
+    out = {"meta": json.dumps(dict(name=c["name"], B=B, H=H, W=W, iters=c["iters"], seed=c["seed"], qk_gain=c["qk_gain"],
+                                   freeze_bn=c["freeze_bn"], gamma=c["gamma"], dropouts_zeroed=n_drop, torch=torch.__version__)),
+           "image1": im1.numpy().astype(np.uint8), "image2": im2.numpy().astype(np.uint8), "flow_gt": gt.numpy(),
+           "valid": valid.numpy(), "loss": np.float64(loss.item()),
+           "metrics": np.array([metrics["epe"], metrics["1px"], metrics["3px"], metrics["5px"]])}
+    unused = []
+    seen = set()
+    for k, p in m.named_parameters():
+        if id(p) in seen:
+            continue
+        seen.add(id(p))
+        if p.grad is None:
+            unused.append(k)
+            continue
+        for kk, v in sample(p.grad).items():
+            out[f"grad.{k}.{kk}"] = v
+    out["unused"] = np.array(json.dumps(unused))
+    for k, v in m.state_dict().items():
+        if k.startswith("cnet.") and (k.endswith("running_mean") or k.endswith("running_var")):
+            out[f"bn.{k}"] = v.numpy()
+    for it, p in enumerate(preds):
+        for kk, v in sample(p).items():
+            out[f"up{it}.{kk}"] = v
+    return out, unused
+
+
+def main():
+    seq_loss = ref_sequence_loss()
+    for c in CASES:
+        out, unused = run(c, seq_loss)
+        path = os.path.join(ROOT, "tests", "golden", c["name"] + ".npz")
+        np.savez_compressed(path, **out)
+        ng = sum(1 for k in out if k.startswith("grad.") and k.endswith(".v"))
+        print(c["name"], "->", path, f"{os.path.getsize(path) / 1024:.0f} KiB loss {float(out['loss']):.6f} grads {ng} unused {unused}")
+
+
+if __name__ == "__main__":
+    main()
