@@ -1,0 +1,542 @@
+"""Training path: every hot-path operator as a ``torch.autograd.Function`` whose forward AND backward are HIP kernels.
+
+The reference trains through PyTorch autograd over ATen ops (train.py:228-236, network.py:164-267).  Here autograd only
+records the graph (plumbing: views, ``torch.cat`` of token columns, gradient accumulation); all arithmetic is
+``libcraft_hip.so`` through the C ABI of ``include/craft_hip.h`` ("training" section):
+
+* dense contractions: ``craft_gemm`` (one general strided batched GEMM on the MFMA engine: dX = dY W, dW = dY^T X with
+  split-K, Q K^T, P V, dP = dO V^T, dV = P^T dO, dQ = dS K, dK = dS^T Q), ``craft_conv2d_wgrad``; convolution input
+  gradients are the forward convolution with flipped / transposed weights;
+* row-wise and element-wise operators and their gradients: LayerNorm tokens, softmax with positional bias / clamp / mask,
+  mode pooling, correlation pooling + global LayerNorm + pyramid, bilinear lookup (scatter), GRU gates, convex upsampling,
+  dropout (counter-based mask regenerated in the backward), the sequence loss.
+
+Tensors are channels-last fp32 "tokens" ``[B, N, C]`` as in inference.  There is no fallback: a missing extension raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+from torch.autograd import Function
+
+from . import hip, ops
+from .hip import ACT_NONE, ACT_RELU, ACT_TANH, STATS_REPLICAS, call, pick, round_up
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """A tokens tensor usable as a flat [rows, C] matrix: unit channel stride, uniform row stride, 16-byte aligned rows."""
+    if t.stride(-1) != 1 or (t.dim() == 3 and t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1)) or (t.stride(-2) & 3) \
+            or (t.data_ptr() & 15):
+        return t.contiguous()
+    return t
+
+
+def gemm(A, a_sm, a_sk, a_bs0, a_bs1, B, b_sn, b_sk, b_bs0, b_bs1, C, ldc, c_bs0, c_bs1, zdiv, batch, M, N, K, alpha=1.0,
+         accumulate=False, ksplit=1, prec=hip.PREC_F32):
+    call("craft_gemm", A, a_sm, a_sk, a_bs0, a_bs1, B, b_sn, b_sk, b_bs0, b_bs1, C, ldc, c_bs0, c_bs1, zdiv, batch, M, N, K,
+         float(alpha), int(accumulate), int(ksplit), prec)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# layout / normalisation / dropout
+# ------------------------------------------------------------------------------------------------------------------
+class NchwToTokens(Function):
+    """NCHW [B, C, H, W] -> tokens [B, H*W, C] (the view/transpose of setrans.py:789); backward: craft_tokens_to_nchw."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = x.shape[-2:]
+        return ops.tokens_from_nchw_wide(_c(x.float())).contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.tokens_to_nchw(_rows(dy), *ctx.hw)
+
+
+class TokensNorm(Function):
+    """y = LayerNorm?(act(x)) per token (setrans.py:791-793 comb_norm_layer; network.py:209-212 tanh / relu of the context
+    halves).  x may be a column slice of a wider tokens tensor."""
+
+    @staticmethod
+    def forward(ctx, x, act, ln):
+        x = _rows(x)
+        ctx.save_for_backward(x)
+        ctx.act, ctx.ln = act, ln
+        return ops.tokens_norm(x, act=act, ln=ln)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _rows(dy)
+        B, N, C = x.shape
+        dx = torch.empty(B, N, C, device=x.device, dtype=torch.float32)
+        call("craft_tokens_bwd", x, x.stride(-2), dy, dy.stride(-2), dx, C, B * N, C, ctx.act, int(ctx.ln))
+        return dx, None, None
+
+
+class Dropout(Function):
+    """nn.Dropout in training mode with a counter-based mask (craft_dropout): backward = the same call on the gradient."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        x = _c(x)
+        y = torch.empty_like(x)
+        call("craft_dropout", x, y, x.numel(), float(p), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        call("craft_dropout", dy, dx, dy.numel(), float(ctx.p), int(ctx.seed))
+        return dx, None, None
+
+
+def dropout(x, p: float, seed: int):
+    return x if p <= 0.0 else Dropout.apply(x, p, seed)
+
+
+class Act(Function):
+    """y = scale * act(x) on tokens (ReLU after the 1x1 convolutions; the 0.25 of the mask head, update.py:161)."""
+
+    @staticmethod
+    def forward(ctx, x, act, scale):
+        if act not in (ACT_NONE, ACT_RELU) and scale != 1.0:
+            raise ValueError("a scaled activation is only defined for none / relu here")
+        x = _rows(x)
+        y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+        rows, C = x.numel() // x.shape[-1], x.shape[-1]
+        call("craft_act_fwd", x, x.stride(-2), y, C, rows, C, act, float(scale))
+        ctx.save_for_backward(y if act != ACT_NONE else None)        # relu: sign(y) == sign(act(x)) for scale > 0
+        ctx.act, ctx.scale, ctx.shape = act, scale, tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _rows(dy)
+        C = ctx.shape[-1]
+        rows = dy.numel() // C
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=torch.float32)
+        call("craft_act_bwd", dy, dy.stride(-2), y, C, dx, C, rows, C, ctx.act, float(ctx.scale))
+        return dx, None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# nn.Linear on tokens
+# ------------------------------------------------------------------------------------------------------------------
+class Linear(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, prec):
+        x = _rows(x)
+        w = _c(w)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias, ctx.prec = b is not None, prec
+        return ops.linear(x, w, b, prec)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _rows(dy)
+        B, N, Cin = x.shape
+        Cout = w.shape[0]
+        rows = B * N
+        pp = pick(ctx.prec, "proj")
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(B, N, Cin, device=x.device, dtype=torch.float32)
+            # dX = dY . W : A = dY rows (k = cout contiguous), B(n = ci, k = co) = W[co][ci] k-major
+            gemm(dy, dy.stride(-2), 1, 0, 0, w, 1, Cin, 0, 0, dx, Cin, 0, 0, 1, 1, rows, Cin, Cout, prec=pp)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros(Cout, Cin, device=x.device, dtype=torch.float32)
+            # dW = dY^T . X : both operands k-major over the rows, split-K
+            gemm(dy, 1, dy.stride(-2), 0, 0, x, 1, x.stride(-2), 0, 0, dw, Cin, 0, 0, 1, 1, Cout, Cin, rows, accumulate=True, ksplit=0, prec=pp)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(Cout, device=x.device, dtype=torch.float32)
+            call("craft_colsum", dy, dy.stride(-2), rows, Cout, db)
+        return dx, dw, db, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# attention: scores, softmax, apply, mode pooling
+# ------------------------------------------------------------------------------------------------------------------
+class Scores(Function):
+    """S[b][m] = scale * Q_m K_m^T (setrans.py:507-515), materialised fp32 [B, M, N, ld] (ld = N rounded up to 32)."""
+
+    @staticmethod
+    def forward(ctx, q, k, M, scale, prec):
+        q, k = _rows(q), _rows(k)
+        B, N, C = q.shape
+        d = C // M
+        ld = round_up(N, 32)
+        S = torch.empty(B, M, N, ld, device=q.device, dtype=torch.float32)
+        sp = pick(prec, "score")
+        gemm(q, q.stride(-2), 1, N * q.stride(-2), d, k, k.stride(-2), 1, N * k.stride(-2), d, S, ld, M * N * ld, N * ld, M, B * M,
+             N, N, d, alpha=scale, prec=sp)
+        ctx.save_for_backward(q, k)
+        ctx.M, ctx.scale, ctx.prec = M, scale, sp
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        q, k = ctx.saved_tensors
+        dS = _c(dS)
+        B, N, C = q.shape
+        M, d = ctx.M, C // ctx.M
+        ld = dS.shape[-1]
+        dq = torch.empty(B, N, C, device=q.device, dtype=torch.float32)
+        dk = torch.empty(B, N, C, device=q.device, dtype=torch.float32)
+        # dQ_m = scale * dS_m . K_m : A = dS rows (k = key j), B(n = c, k = j) = K[b][j][m*d + c] k-major
+        gemm(dS, ld, 1, M * N * ld, N * ld, k, 1, k.stride(-2), N * k.stride(-2), d, dq, C, N * C, d, M, B * M, N, d, N, alpha=ctx.scale,
+             prec=ctx.prec)
+        # dK_m = scale * dS_m^T . Q_m : A(m = j, k = i) = dS[i][j] k-major, B(n = c, k = i) = Q[b][i][m*d + c] k-major
+        gemm(dS, 1, ld, M * N * ld, N * ld, q, 1, q.stride(-2), N * q.stride(-2), d, dk, C, N * C, d, M, B * M, N, d, N, alpha=ctx.scale,
+             prec=ctx.prec)
+        return dq, dk, None, None, None
+
+
+class AttnSoftmax(Function):
+    """P = softmax_j(clamp?(S) + pos_w pb + mask) in place on S (setrans.py:520-551)."""
+
+    @staticmethod
+    def forward(ctx, S, pos_tab, pos_w, mask_radius, clamp_ord, hw):
+        B, M, N, ld = S.shape
+        R = (pos_tab.shape[0] - 1) // 2
+        bits = torch.empty(B * M * N * (ld // 32), device=S.device, dtype=torch.int32)
+        tab = _c(pos_tab.detach())
+        call("craft_attn_softmax_fwd", S, ld, B, M, hw[0], hw[1], tab, R, float(pos_w), int(mask_radius), clamp_ord, bits)
+        ctx.mark_dirty(S)
+        ctx.save_for_backward(S, bits, clamp_ord)
+        ctx.hw, ctx.R, ctx.pos_w = hw, R, pos_w
+        return S
+
+    @staticmethod
+    def backward(ctx, dP):
+        P, bits, clamp_ord = ctx.saved_tensors
+        B, M, N, ld = P.shape
+        dS = dP.contiguous().clone()
+        T = 2 * ctx.R + 1
+        rep = torch.zeros(STATS_REPLICAS, T * T, device=P.device, dtype=torch.float32)
+        call("craft_attn_softmax_bwd", P, dS, ld, B, M, ctx.hw[0], ctx.hw[1], ctx.R, float(ctx.pos_w), clamp_ord, bits, rep)
+        dtab = torch.zeros(T, T, device=P.device, dtype=torch.float32)
+        call("craft_reduce_replicas", rep, STATS_REPLICAS, T * T, dtab)
+        return dS, dtab, None, None, None, None
+
+
+class AttnApply(Function):
+    """O[b][m] = P[b][m] V_m with V = first_linear(x) [B, N, M*C] in its natural layout (setrans.py:373-384)."""
+
+    @staticmethod
+    def forward(ctx, P, v, prec):
+        v = _rows(v)
+        B, M, N, ld = P.shape
+        C = v.shape[-1] // M
+        O = torch.empty(B, M, N, C, device=P.device, dtype=torch.float32)
+        pv = pick(prec, "pv")
+        ldv = v.stride(-2)
+        gemm(P, ld, 1, M * N * ld, N * ld, v, 1, ldv, N * ldv, C, O, C, M * N * C, N * C, M, B * M, N, C, N, prec=pv)
+        ctx.save_for_backward(P, v)
+        ctx.prec = pv
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        P, v = ctx.saved_tensors
+        dO = _c(dO)
+        B, M, N, ld = P.shape
+        C = v.shape[-1] // M
+        ldv = v.stride(-2)
+        dP = dv = None
+        if ctx.needs_input_grad[0]:
+            dP = torch.zeros(B, M, N, ld, device=P.device, dtype=torch.float32) if ld != N else torch.empty(B, M, N, ld, device=P.device)
+            # dP_m = dO_m . V_m^T : A = dO rows (k = c), B(n = j, k = c) = V[b][j][m*C + c] rows
+            gemm(dO, C, 1, M * N * C, N * C, v, ldv, 1, N * ldv, C, dP, ld, M * N * ld, N * ld, M, B * M, N, N, C, prec=ctx.prec)
+        if ctx.needs_input_grad[1]:
+            dv = torch.empty(B, N, M * C, device=P.device, dtype=torch.float32)
+            # dV_m = P_m^T . dO_m : A(m = j, k = i) = P[i][j] k-major, B(n = c, k = i) = dO[i][c] k-major
+            gemm(P, 1, ld, M * N * ld, N * ld, dO, 1, C, M * N * C, N * C, dv, M * C, N * M * C, C, M, B * M, N, C, N, prec=ctx.prec)
+        return dP, dv, None
+
+
+class ModePoolLN(Function):
+    """y = LayerNorm(skip * x + sum_m softmax_m(<O_m, w>) O_m)  (setrans.py:395-407)."""
+
+    @staticmethod
+    def forward(ctx, O, x, w_agg, skip):
+        O, x = _c(O), _rows(x)
+        ctx.save_for_backward(O, x, w_agg, skip)
+        return ops.mode_pool_ln(O, x, w_agg.detach(), skip.detach())
+
+    @staticmethod
+    def backward(ctx, dy):
+        O, x, w_agg, skip = ctx.saved_tensors
+        dy = _rows(dy)
+        B, M, N, C = O.shape
+        dO = torch.empty_like(O)
+        dx = torch.empty(B, N, C, device=O.device, dtype=torch.float32)
+        rep = torch.zeros(STATS_REPLICAS, C + 1, device=O.device, dtype=torch.float32)
+        call("craft_mode_pool_ln_bwd", O, x, x.stride(-2), _c(w_agg.detach()).view(-1), skip.detach(), dy, dy.stride(-2), B, N, M, C,
+             dO, dx, C, rep)
+        red = torch.zeros(C + 1, device=O.device, dtype=torch.float32)
+        call("craft_reduce_replicas", rep, STATS_REPLICAS, C + 1, red)
+        return dO, dx, red[:C].reshape(w_agg.shape), red[C:].reshape(skip.shape)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# correlation volume, pyramid, lookup
+# ------------------------------------------------------------------------------------------------------------------
+class TrainPyramid:
+    """The pyramid of one forward pass plus the shared gradient buffers its lookups scatter into."""
+
+    def __init__(self, pyr: ops.CorrPyramid):
+        self.pyr = pyr
+        self.G: Optional[List[torch.Tensor]] = None
+
+    def grads(self):
+        if self.G is None:
+            self.G = [torch.zeros_like(t) for t in self.pyr.lv]
+        return self.G
+
+
+class CorrVolume(Function):
+    """Scores [B, M, N, ld] -> pooled, globally normalised 4-level pyramid (corr.py:186-204; setrans.py:520-550).  Returns the
+    (mean, rstd) tensor as the autograd handle of the pyramid: every lookup takes it as an input, so this backward runs
+    after all of them and finds their scattered gradients in ``holder.grads()``."""
+
+    @staticmethod
+    def forward(ctx, S, pos_tab, w_aggr, pos_w, clamp_ord, hw, holder_box, do_norm):
+        B, M, N, ld = S.shape
+        H8, W8 = hw
+        R = (pos_tab.shape[0] - 1) // 2
+        pyr = ops.CorrPyramid(B, H8, W8, 4, S.device)
+        tab = _c(pos_tab.detach())
+        wv = _c(w_aggr.detach()).view(-1)
+        call("craft_corr_pool_fwd", S, ld, B, M, H8, W8, tab, R, float(pos_w), wv, clamp_ord, pyr.lv[0], pyr.sums)
+        call("craft_corr_finish", pyr.lv[0], pyr.lv[1], pyr.lv[2], pyr.lv[3], pyr.sums, pyr.mu_rstd, B, H8, W8, int(do_norm))
+        holder = TrainPyramid(pyr)
+        holder_box.append(holder)
+        ctx.holder, ctx.hw, ctx.R, ctx.pos_w, ctx.do_norm = holder, hw, R, pos_w, do_norm
+        ctx.save_for_backward(S, tab, wv, clamp_ord)
+        ctx.w_shape = w_aggr.shape
+        return pyr.mu_rstd
+
+    @staticmethod
+    def backward(ctx, _dtoken):
+        S, tab, wv, clamp_ord = ctx.saved_tensors
+        B, M, N, ld = S.shape
+        H8, W8 = ctx.hw
+        pyr = ctx.holder.pyr
+        G = ctx.holder.grads()
+        gstats = torch.zeros(B, 2, device=S.device, dtype=torch.float64)
+        call("craft_corr_pyramid_bwd", G[0], G[1], G[2], G[3], pyr.lv[0], pyr.mu_rstd, B, H8, W8, gstats)
+        T = 2 * ctx.R + 1
+        rep = torch.zeros(STATS_REPLICAS, T * T, device=S.device, dtype=torch.float32)
+        dw = torch.zeros(1, device=S.device, dtype=torch.float64)
+        dS = S                                                    # the scores are dead after this: overwritten with dS
+        call("craft_corr_pool_bwd", dS, ld, B, M, H8, W8, tab, ctx.R, float(ctx.pos_w), wv, clamp_ord, pyr.lv[0], G[0], pyr.mu_rstd, gstats,
+             int(ctx.do_norm), rep, dw)
+        dtab = torch.zeros(T, T, device=S.device, dtype=torch.float32)
+        call("craft_reduce_replicas", rep, STATS_REPLICAS, T * T, dtab)
+        ctx.holder.G = None
+        return dS, dtab, dw.float().reshape(ctx.w_shape), None, None, None, None, None
+
+
+class CorrLookup(Function):
+    """corr tokens [B, N, 4*81] = bilinear samples of the normalised pyramid around coords (corr.py:47-71).  coords carry no
+    gradient (network.py:232 detaches them); the volume's gradient is scattered into the holder's buffers."""
+
+    @staticmethod
+    def forward(ctx, token, coords, holder, radius):
+        ctx.holder, ctx.radius = holder, radius
+        coords = _c(coords.detach())
+        ctx.save_for_backward(coords)
+        return ops.corr_lookup(holder.pyr, coords, radius)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (coords,) = ctx.saved_tensors
+        pyr = ctx.holder.pyr
+        G = ctx.holder.grads()
+        dout = _rows(dout)
+        call("craft_corr_lookup_bwd", dout, dout.stride(-2), coords, G[0], G[1], G[2], G[3], pyr.levels, pyr.B, pyr.H8, pyr.W8, ctx.radius, 0, 0)
+        return torch.zeros(pyr.B, 2, device=dout.device, dtype=torch.float32), None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# convolutions (stride 1, same padding) on tokens
+# ------------------------------------------------------------------------------------------------------------------
+def _pad_cols(x: torch.Tensor, c: int) -> torch.Tensor:
+    """tokens [B, N, C] -> [B, N, c] with zero columns appended (channel counts of the conv engine are multiples of 32)."""
+    if x.shape[-1] == c:
+        return _rows(x)
+    y = torch.zeros(*x.shape[:-1], c, device=x.device, dtype=torch.float32)
+    y[..., : x.shape[-1]] = x
+    return y
+
+
+class Conv(Function):
+    """nn.Conv2d (stride 1, padding K//2) + bias (+ReLU) on tokens; w in PyTorch layout [Cout, Cin, KH, KW].
+    Backward: input gradient = the same forward kernel with flipped / transposed weights, weight gradient =
+    craft_conv2d_wgrad, bias gradient = column sums."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, hw, act, prec):
+        B, N, Cin = x.shape
+        Cout, _, KH, KW = w.shape
+        cp = pick(prec, "conv")
+        cin_p, cout_p = round_up(Cin, 32), round_up(Cout, 32)
+        xp = _pad_cols(x, cin_p)
+        wp = torch.zeros(cout_p, KH, KW, cin_p, device=x.device, dtype=torch.float32)
+        wp[:Cout, :, :, :Cin] = w.detach().permute(0, 2, 3, 1)
+        bp = torch.zeros(cout_p, device=x.device, dtype=torch.float32)
+        if b is not None:
+            bp[:Cout] = b.detach()
+        y = torch.empty(B, N, cout_p, device=x.device, dtype=torch.float32)
+        call("craft_conv2d_nhwc", xp, xp.stride(-2), cin_p, wp, bp, cout_p, KH, KW, act, y, cout_p, B, hw[0], hw[1], cp)
+        ctx.save_for_backward(xp, wp, y if act != ACT_NONE else None)
+        ctx.dims = (B, N, Cin, Cout, KH, KW, cin_p, cout_p)
+        ctx.hw, ctx.act, ctx.prec, ctx.has_bias = hw, act, cp, b is not None
+        return y[..., :Cout] if cout_p != Cout else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, wp, y = ctx.saved_tensors
+        B, N, Cin, Cout, KH, KW, cin_p, cout_p = ctx.dims
+        H8, W8 = ctx.hw
+        dev = xp.device
+        g = _pad_cols(dy, cout_p)
+        if ctx.act != ACT_NONE:
+            ga = torch.empty(B, N, cout_p, device=dev, dtype=torch.float32)
+            call("craft_act_bwd", g, g.stride(-2), y, cout_p, ga, cout_p, B * N, cout_p, ctx.act, 1.0)
+            g = ga
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dX = conv(dY, W') with W'[ci][KH-1-ky][KW-1-kx][co] = W[co][ky][kx][ci]
+            wt = wp.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+            zb = torch.zeros(cin_p, device=dev, dtype=torch.float32)
+            dxp = torch.empty(B, N, cin_p, device=dev, dtype=torch.float32)
+            call("craft_conv2d_nhwc", g, g.stride(-2), cout_p, wt, zb, cin_p, KH, KW, ACT_NONE, dxp, cin_p, B, H8, W8, ctx.prec)
+            dx = dxp[..., :Cin] if cin_p != Cin else dxp
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros(cout_p, KH, KW, cin_p, device=dev, dtype=torch.float32)
+            call("craft_conv2d_wgrad", xp, xp.stride(-2), cin_p, g, g.stride(-2), cout_p, KH, KW, B, H8, W8, dwp, ctx.prec)
+            dw = dwp[:Cout, :, :, :Cin].permute(0, 3, 1, 2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dbp = torch.zeros(cout_p, device=dev, dtype=torch.float32)
+            call("craft_colsum", g, g.stride(-2), B * N, cout_p, dbp)
+            db = dbp[:Cout]
+        return dx, dw, db, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SepConvGRU gates, convex upsampling, loss
+# ------------------------------------------------------------------------------------------------------------------
+class GruZR(Function):
+    """(zr_pre [B,N,2C], h [B,N,C]) -> (z, r*h)  (update.py:55-57 / :60-62)."""
+
+    @staticmethod
+    def forward(ctx, zr_pre, h):
+        zr_pre, h = _rows(zr_pre), _rows(h)
+        B, N, C = h.shape
+        z, r, rh = (torch.empty(B, N, C, device=h.device, dtype=torch.float32) for _ in range(3))
+        call("craft_gru_zr_fwd", zr_pre, zr_pre.stride(-2), h, h.stride(-2), z, r, rh, B * N, C)
+        ctx.save_for_backward(z, r, h)
+        return z, rh
+
+    @staticmethod
+    def backward(ctx, dz, drh):
+        z, r, h = ctx.saved_tensors
+        B, N, C = h.shape
+        dz = _c(dz) if dz is not None else torch.zeros_like(z)
+        drh = _rows(drh) if drh is not None else torch.zeros_like(z)
+        dzr = torch.empty(B, N, 2 * C, device=h.device, dtype=torch.float32)
+        dh = torch.zeros(B, N, C, device=h.device, dtype=torch.float32)
+        call("craft_gru_zr_bwd", dz, drh, drh.stride(-2), z, r, h, h.stride(-2), dzr, dh, B * N, C)
+        return dzr, dh
+
+
+class GruOut(Function):
+    """(q_pre, z, h) -> h' = (1 - z) h + z tanh(q_pre)  (update.py:57-58 / :62-63)."""
+
+    @staticmethod
+    def forward(ctx, q_pre, z, h):
+        q_pre, z, h = _rows(q_pre), _c(z), _rows(h)
+        B, N, C = h.shape
+        q = torch.empty(B, N, C, device=h.device, dtype=torch.float32)
+        hn = torch.empty(B, N, C, device=h.device, dtype=torch.float32)
+        call("craft_gru_out_fwd", q_pre, q_pre.stride(-2), z, h, h.stride(-2), q, hn, C, B * N, C)
+        ctx.save_for_backward(z, q, h)
+        return hn
+
+    @staticmethod
+    def backward(ctx, dhn):
+        z, q, h = ctx.saved_tensors
+        dhn = _rows(dhn)
+        B, N, C = h.shape
+        dqp, dz, dh = (torch.empty(B, N, C, device=h.device, dtype=torch.float32) for _ in range(3))
+        call("craft_gru_out_bwd", dhn, dhn.stride(-2), z, q, h, h.stride(-2), dqp, dz, dh, B * N, C)
+        return dqp, dz, dh
+
+
+class ConvexUpsample(Function):
+    """CRAFT.upsample_flow (network.py:151-162): mask tokens [B,N,576], flow tokens [B,N,2] -> [B,2,8*H8,8*W8]."""
+
+    @staticmethod
+    def forward(ctx, mask, flow, hw):
+        mask, flow = _rows(mask), _c(flow)
+        ctx.save_for_backward(mask, flow)
+        ctx.hw = hw
+        if mask.stride(-2) != 576:
+            mask = mask.contiguous()
+        return ops.convex_upsample(mask, flow, hw[0], hw[1])
+
+    @staticmethod
+    def backward(ctx, dup):
+        mask, flow = ctx.saved_tensors
+        B, N, _ = flow.shape
+        dup = _c(dup)
+        dmask = torch.empty(B, N, 576, device=flow.device, dtype=torch.float32)
+        dflow = torch.zeros(B, N, 2, device=flow.device, dtype=torch.float32)
+        call("craft_convex_upsample_bwd", mask, mask.stride(-2), flow, dup, B, ctx.hw[0], ctx.hw[1], dmask, 576, dflow)
+        return dmask, dflow, None
+
+
+class SequenceLoss(Function):
+    """train.py:44-61: sum_i gamma^(T-1-i) mean(valid |pred_i - gt|) with its gradient from craft_flow_l1_loss."""
+
+    @staticmethod
+    def forward(ctx, gt, valid, gamma, max_flow, *preds):
+        T = len(preds)
+        B, _, H, W = gt.shape
+        dev = preds[0].device
+        gt, va = _c(gt.to(dev).float()), _c(valid.to(dev).float())
+        loss = torch.zeros((), device=dev, dtype=torch.float64)
+        grads = []
+        for i, p in enumerate(preds):
+            g = torch.empty(B, 2, H, W, device=dev, dtype=torch.float32)
+            call("craft_flow_l1_loss", _c(p.float()), gt, va, B, H, W, float(gamma ** (T - i - 1)), float(max_flow), loss, g)
+            grads.append(g)
+        ctx.grads = grads
+        return loss.float()
+
+    @staticmethod
+    def backward(ctx, dl):
+        s = dl.reshape(())
+        return (None, None, None, None) + tuple(g * s for g in ctx.grads)
+
+
+def sequence_loss(flow_preds, flow_gt, valid, gamma: float = 0.8, max_flow: float = 400.0):
+    """Differentiable loss (0-dim tensor) and the metrics dict of train.py:63-71 (computed on the device)."""
+    from .evaluate import FlowMetrics
+    loss = SequenceLoss.apply(flow_gt, valid, gamma, max_flow, *flow_preds)
+    m = FlowMetrics(flow_preds[-1].device, max_mag=max_flow)
+    m.update(flow_preds[-1].detach(), flow_gt, valid)
+    r = m.result()
+    return loss, {"epe": r["epe"], "1px": r["px1"], "3px": r["px3"], "5px": r["px5"]}

@@ -399,4 +399,83 @@ int craft_coords_init(const float* flow_init_nchw, int B, int H8, int W8, float*
   return launch_coords_init(flow_init_nchw, B, H8, W8, coords0, coords1, flow, S(stream));
 }
 
+// ---- training (include/craft_hip.h, "training" section) -------------------------------------------------------------------
+int craft_gemm(const float* A, long a_sm, long a_sk, long a_bs0, long a_bs1, const float* B, long b_sn, long b_sk, long b_bs0,
+               long b_bs1, float* C, long ldc, long c_bs0, long c_bs1, int zdiv, int batch, int M, int N, int K, float alpha,
+               int accumulate, int ksplit, int prec, void* stream) {
+  return launch_gemm_gen(A, a_sm, a_sk, a_bs0, a_bs1, B, b_sn, b_sk, b_bs0, b_bs1, C, ldc, c_bs0, c_bs1, zdiv, batch, M, N, K, alpha,
+                         accumulate, ksplit, prec, S(stream));
+}
+int craft_conv2d_wgrad(const float* x, long ldx, int cin, const float* dy, long ldy, int cout, int KH, int KW, int B, int H, int W,
+                       float* dW, int prec, void* stream) {
+  return launch_conv_wgrad(x, ldx, cin, dy, ldy, cout, KH, KW, B, H, W, dW, prec, S(stream));
+}
+int craft_colsum(const float* x, long ld, long rows, int C, float* out, void* stream) { return launch_colsum(x, ld, rows, C, out, S(stream)); }
+int craft_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, void* stream) {
+  return launch_act_fwd(x, ldx, y, ldy, rows, C, act, scale, S(stream));
+}
+int craft_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,
+                  void* stream) {
+  return launch_act_bwd(dy, lddy, y, ldy, dx, lddx, rows, C, act, scale, S(stream));
+}
+int craft_dropout(const float* x, float* y, long n, float p, unsigned long long seed, void* stream) {
+  return launch_dropout(x, y, n, p, seed, S(stream));
+}
+int craft_tokens_bwd(const float* x, long ldx, const float* dy, long lddy, float* dx, long lddx, long rows, int C, int act, int do_ln,
+                     void* stream) {
+  return launch_tokens_bwd(x, ldx, dy, lddy, dx, lddx, rows, C, act, do_ln, S(stream));
+}
+int craft_attn_softmax_fwd(float* Sc, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, int mask_radius,
+                           const unsigned* clamp_ord, unsigned* clampbits, void* stream) {
+  return launch_attn_softmax_fwd(Sc, ld, B, M, H8, W8, pos_tab, R, pos_w, mask_radius, clamp_ord, clampbits, S(stream));
+}
+int craft_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, int H8, int W8, int R, float pos_w,
+                           const unsigned* clamp_ord, const unsigned* clampbits, float* dtab_rep, void* stream) {
+  return launch_attn_softmax_bwd(P, dP, ld, B, M, H8, W8, R, pos_w, clamp_ord, clampbits, dtab_rep, S(stream));
+}
+int craft_reduce_replicas(const float* rep, int nrep, int n, float* out, void* stream) {
+  return launch_reduce_replicas(rep, nrep, n, out, S(stream));
+}
+int craft_corr_pool_fwd(const float* Sc, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, const float* w,
+                        const unsigned* clamp_ord, float* c0, double* sums, void* stream) {
+  return launch_corr_pool_fwd(Sc, ld, B, M, H8, W8, pos_tab, R, pos_w, w, clamp_ord, c0, sums, S(stream));
+}
+int craft_corr_lookup_bwd(const float* dout, long ldo, const float* coords, float* G0, float* G1, float* G2, float* G3, int levels, int B,
+                          int H8, int W8, int radius, int lvl_stride, int col_off, void* stream) {
+  return launch_corr_lookup_bwd(dout, ldo, coords, G0, G1, G2, G3, levels, B, H8, W8, radius, lvl_stride, col_off, S(stream));
+}
+int craft_corr_pyramid_bwd(float* G0, const float* G1, const float* G2, const float* G3, const float* c0, const float* mu_rstd, int B,
+                           int H8, int W8, double* gstats, void* stream) {
+  return launch_corr_pyramid_bwd(G0, G1, G2, G3, c0, mu_rstd, B, H8, W8, gstats, S(stream));
+}
+int craft_corr_pool_bwd(float* Sc, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, const float* w,
+                        const unsigned* clamp_ord, const float* c0, const float* G0, const float* mu_rstd, const double* gstats,
+                        int do_norm, float* dtab_rep, double* dw, void* stream) {
+  return launch_corr_pool_bwd(Sc, ld, B, M, H8, W8, pos_tab, R, pos_w, w, clamp_ord, c0, G0, mu_rstd, gstats, do_norm, dtab_rep, dw,
+                              S(stream));
+}
+int craft_mode_pool_ln_bwd(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff, const float* dy,
+                           long lddy, int B, int N, int M, int C, float* dO, float* dx, long lddx, float* dw_rep, void* stream) {
+  return launch_mode_pool_ln_bwd(O, x, ldx, w_agg, skip_coeff, dy, lddy, B, N, M, C, dO, dx, lddx, dw_rep, S(stream));
+}
+int craft_convex_upsample_bwd(const float* mask, long ldm, const float* flow, const float* dup, int B, int H8, int W8, float* dmask,
+                              long lddm, float* dflow, void* stream) {
+  return launch_convex_upsample_bwd(mask, ldm, flow, dup, B, H8, W8, dmask, lddm, dflow, S(stream));
+}
+int craft_gru_zr_fwd(const float* zr_pre, long ldzr, const float* h, long ldh, float* z, float* r, float* rh, long rows, int C, void* stream) {
+  return launch_gru_zr_fwd(zr_pre, ldzr, h, ldh, z, r, rh, rows, C, S(stream));
+}
+int craft_gru_out_fwd(const float* q_pre, long ldq, const float* z, const float* h, long ldh, float* q, float* h_new, long ldhn, long rows,
+                      int C, void* stream) {
+  return launch_gru_out_fwd(q_pre, ldq, z, h, ldh, q, h_new, ldhn, rows, C, S(stream));
+}
+int craft_gru_out_bwd(const float* dh_new, long lddhn, const float* z, const float* q, const float* h, long ldh, float* dq_pre, float* dz,
+                      float* dh, long rows, int C, void* stream) {
+  return launch_gru_out_bwd(dh_new, lddhn, z, q, h, ldh, dq_pre, dz, dh, rows, C, S(stream));
+}
+int craft_gru_zr_bwd(const float* dz, const float* drh, long lddrh, const float* z, const float* r, const float* h, long ldh, float* dzr_pre,
+                     float* dh, long rows, int C, void* stream) {
+  return launch_gru_zr_bwd(dz, drh, lddrh, z, r, h, ldh, dzr_pre, dh, rows, C, S(stream));
+}
+
 }  // extern "C"

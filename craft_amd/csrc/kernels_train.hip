@@ -1,0 +1,771 @@
+// Training-side kernels of the hot path (include/craft_hip.h, "training" section): the element-wise / row-wise forward
+// pieces that only exist in training form (softmax from materialised scores, mode pooling of the correlation scores,
+// GRU gates as separate stages, dropout) and the backward of every non-GEMM operator.  All of them are HBM-bound streams:
+// 16-byte accesses where the layout allows, one wave per token / query row for the row-wise reductions, replicated
+// accumulation tables where thousands of blocks reduce into a handful of cells.
+#include "launch.hpp"
+
+namespace craft {
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {        // sh: >= 4 floats; all 256 threads call
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float block_max_256(float v, float* sh) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__device__ __forceinline__ bool clamp_active(const unsigned* clamp_ord) {
+  // craft_score_max leaves 0 when no score can exceed the clip threshold, else the ordered-uint global max
+  if (!clamp_ord) return false;
+  const unsigned u = *clamp_ord;
+  return u != 0u && ord2f(u) > CRAFT_ATTN_CLIP;
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums: out[c] += sum_r x[r][c]   (bias gradients)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, long ld, long rows, int C, int rows_per_block,
+                                                float* __restrict__ out) {
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += x[r * ld + c];
+    unsafeAtomicAdd(out + c, s);
+  }
+}
+int launch_colsum(const float* x, long ld, long rows, int C, float* out, hipStream_t s) {
+  if (rows <= 0 || C <= 0) return 0;
+  const int rpb = 128;
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, ld, rows, C, rpb, out);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// activations: forward in place-capable, backward from the OUTPUT (relu: y > 0, tanh: 1 - y^2, sigmoid: y (1 - y))
+// ---------------------------------------------------------------------------------------------
+__global__ void k_act_fwd(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy, long rows, int C, int act, float scale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C >> 2;
+  if (i >= rows * c4) return;
+  const long r = i / c4;
+  const int c = (int)(i - r * c4) * 4;
+  float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+  if (act == CRAFT_ACT_SIGMOID) { v.x = sigmoid_precise(v.x); v.y = sigmoid_precise(v.y); v.z = sigmoid_precise(v.z); v.w = sigmoid_precise(v.w); }
+  else { v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act); }
+  v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+  *reinterpret_cast<float4*>(y + r * ldy + c) = v;
+}
+__global__ void k_act_bwd(const float* __restrict__ dy, long lddy, const float* __restrict__ y, long ldy, float* __restrict__ dx,
+                          long lddx, long rows, int C, int act, float scale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C >> 2;
+  if (i >= rows * c4) return;
+  const long r = i / c4;
+  const int c = (int)(i - r * c4) * 4;
+  const float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+  float4 o = {g.x * scale, g.y * scale, g.z * scale, g.w * scale};
+  if (act != CRAFT_ACT_NONE) {
+    const float4 v = *reinterpret_cast<const float4*>(y + r * ldy + c);
+    auto d = [act](float yy) { return act == CRAFT_ACT_RELU ? (yy > 0.f ? 1.f : 0.f) : act == CRAFT_ACT_TANH ? 1.f - yy * yy : yy * (1.f - yy); };
+    o.x *= d(v.x); o.y *= d(v.y); o.z *= d(v.z); o.w *= d(v.w);
+  }
+  *reinterpret_cast<float4*>(dx + r * lddx + c) = o;
+}
+int launch_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, hipStream_t s) {
+  if (rows <= 0 || C <= 0) return 0;
+  if ((C & 3) || (ldx & 3) || (ldy & 3)) return CRAFT_ERR_ALIGN;
+  const long n = rows * (C >> 2);
+  hipLaunchKernelGGL(k_act_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, ldx, y, ldy, rows, C, act, scale);
+  return (int)hipGetLastError();
+}
+int launch_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,
+                   hipStream_t s) {
+  if (rows <= 0 || C <= 0) return 0;
+  if ((C & 3) || (lddy & 3) || (ldy & 3) || (lddx & 3)) return CRAFT_ERR_ALIGN;
+  const long n = rows * (C >> 2);
+  hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, lddy, y, ldy, dx, lddx, rows, C, act, scale);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// dropout (setrans.py:553-557 att_dropout, :791-795 vispos dropout): y = x * keep / (1 - p), keep = hash(seed, index) >= p.
+// Counter-based, so the backward regenerates the mask by running the same kernel on the gradient.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mix32(unsigned long long k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+  return (unsigned)k;
+}
+__global__ void k_dropout(const float* __restrict__ x, float* __restrict__ y, long n, float p, unsigned long long seed) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned thr = (unsigned)fminf(p * 4294967296.f, 4294967040.f);
+  const float inv = 1.f / (1.f - p);
+  y[i] = mix32(seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)i) >= thr ? x[i] * inv : 0.f;
+}
+int launch_dropout(const float* x, float* y, long n, float p, unsigned long long seed, hipStream_t s) {
+  if (n <= 0) return 0;
+  if (p < 0.f || p >= 1.f) return CRAFT_ERR_ARG;
+  hipLaunchKernelGGL(k_dropout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n, p, seed);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of craft_tokens (token-major source): y = LN(act(x[c_off : c_off+C])) -> dx.  One wave per token, C <= 256.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tokens_bwd(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long lddy,
+                                                    float* __restrict__ dx, long lddx, long rows, int C, int act, int do_ln) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float a[4], g[4];
+  float s1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    a[i] = c < C ? act_apply(x[r * ldx + c], act) : 0.f;
+    g[i] = c < C ? dy[r * lddy + c] : 0.f;
+    s1 += a[i];
+  }
+  float da[4];
+  if (do_ln) {
+    const float mean = wave_sum(s1) / C;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; const float d = c < C ? a[i] - mean : 0.f; s2 += d * d; }
+    const float rstd = rsqrtf(wave_sum(s2) / C + CRAFT_LN_EPS);
+    float sg = 0.f, sgy = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float yv = (a[i] - mean) * rstd; sg += g[i]; sgy += g[i] * yv; }
+    const float mg = wave_sum(sg) / C, mgy = wave_sum(sgy) / C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) da[i] = rstd * (g[i] - mg - (a[i] - mean) * rstd * mgy);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) da[i] = g[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < C) {
+      const float d = act == CRAFT_ACT_RELU ? (a[i] > 0.f ? 1.f : 0.f) : act == CRAFT_ACT_TANH ? 1.f - a[i] * a[i] : 1.f;
+      dx[r * lddx + c] = da[i] * d;
+    }
+  }
+}
+int launch_tokens_bwd(const float* x, long ldx, const float* dy, long lddy, float* dx, long lddx, long rows, int C, int act, int do_ln,
+                      hipStream_t s) {
+  if (rows <= 0) return 0;
+  if (C <= 0 || C > 256 || act == CRAFT_ACT_SIGMOID) return CRAFT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_tokens_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ldx, dy, lddy, dx, lddx, rows, C, act, do_ln);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax over keys from materialised scores (CrossAttFeatTrans, setrans.py:520-551), in place:
+//   P[z][i][j] = softmax_j( clamp?(S[z][i][j]) + pos_w * pb(i, j) + mask(i, j) ),   z = b*M + m, columns [N, ld) = 0.
+// One block per query row; the row lives in LDS between the passes.  clampbits (optional, [rows][ld/32] words): bit j of row
+// = "this score was clamped" (its gradient is zero), written only when the clamp is active.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_attn_softmax_fwd(float* __restrict__ S, long ld, int N, int H8, int W8,
+                                                          const float* __restrict__ pos_tab, int R, float pos_w, int mask_radius,
+                                                          const unsigned* __restrict__ clamp_ord, unsigned* __restrict__ clampbits) {
+  extern __shared__ __attribute__((aligned(16))) float row[];
+  __shared__ float red[4];
+  const long rr = blockIdx.x;                   // (z, i)
+  const int i = (int)(rr % N);
+  const int hi = i / W8, wi = i - hi * W8;
+  float* Sr = S + rr * ld;
+  const bool clamp = clamp_active(clamp_ord);
+  float mx = -3.0e38f;
+  for (int j0 = 0; j0 < N; j0 += 256) {
+    const int j = j0 + threadIdx.x;
+    float v = -3.0e38f;
+    bool hit = false;
+    if (j < N) {
+      v = Sr[j];
+      if (clamp) { hit = v > CRAFT_ATTN_CLIP || v < -CRAFT_ATTN_CLIP; v = fminf(fmaxf(v, -CRAFT_ATTN_CLIP), CRAFT_ATTN_CLIP); }
+      const int hj = j / W8, wj = j - hj * W8;
+      if (pos_tab) v += pos_w * pos_bias_at(pos_tab, R, hi, wi, hj, wj);
+      if (mask_radius > 0 && max(abs(hj - hi), abs(wj - wi)) > mask_radius) v += -1e9f;
+      row[j] = v;
+    }
+    if (clampbits && clamp) {
+      const unsigned long long m = __ballot(hit);
+      const int w0 = (j0 + (threadIdx.x & ~63)) >> 5;
+      if ((threadIdx.x & 63) == 0) {
+        unsigned* cb = clampbits + rr * (ld >> 5);
+        if (w0 < (ld >> 5)) cb[w0] = (unsigned)m;
+        if (w0 + 1 < (ld >> 5)) cb[w0 + 1] = (unsigned)(m >> 32);
+      }
+    }
+    mx = fmaxf(mx, v);
+  }
+  mx = block_max_256(mx, red);
+  float sum = 0.f;
+  for (int j = threadIdx.x; j < N; j += 256) { const float e = expf(row[j] - mx); row[j] = e; sum += e; }
+  sum = block_sum_256(sum, red);
+  const float inv = 1.f / sum;
+  for (int j = threadIdx.x; j < ld; j += 256) Sr[j] = j < N ? row[j] * inv : 0.f;
+}
+int launch_attn_softmax_fwd(float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, int mask_radius,
+                            const unsigned* clamp_ord, unsigned* clampbits, hipStream_t s) {
+  const int N = H8 * W8;
+  if (N <= 0 || B <= 0) return 0;
+  if (N > 16000 || (ld & 31) || ld < N) return CRAFT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_attn_softmax_fwd, dim3((unsigned)((long)B * M * N)), dim3(256), (size_t)N * sizeof(float), s, S, ld, N, H8, W8,
+                     pos_tab, R, pos_w, mask_radius, clamp_ord, clampbits);
+  return (int)hipGetLastError();
+}
+
+// backward: dS = P * (dP - sum_j dP*P), zero where the score was clamped; dtab[rep][(dh+R)*(2R+1)+(dw+R)] += pos_w * dS' over
+// the window (dS' = before the clamp mask: the bias is added after the clamp).  dP is overwritten with dS.
+constexpr int SM_ROWS_PER_BLOCK = 8;
+__global__ __launch_bounds__(256) void k_attn_softmax_bwd(const float* __restrict__ P, float* __restrict__ dP, long ld, int N, int H8,
+                                                          int W8, int R, float pos_w, const unsigned* __restrict__ clamp_ord,
+                                                          const unsigned* __restrict__ clampbits, float* __restrict__ dtab, long nrows) {
+  __shared__ float red[4];
+  __shared__ float tab[32 * 32];
+  const int T = 2 * R + 1;
+  const bool want_tab = dtab != nullptr && R >= 0;
+  if (want_tab) for (int t = threadIdx.x; t < T * T; t += 256) tab[t] = 0.f;
+  const bool clamp = clamp_active(clamp_ord) && clampbits != nullptr;
+  const long r0 = (long)blockIdx.x * SM_ROWS_PER_BLOCK;
+  for (long rr = r0; rr < min(nrows, r0 + SM_ROWS_PER_BLOCK); ++rr) {
+    const int i = (int)(rr % N);
+    const int hi = i / W8, wi = i - hi * W8;
+    const float* Pr = P + rr * ld;
+    float* Gr = dP + rr * ld;
+    float dot = 0.f;
+    for (int j = threadIdx.x; j < N; j += 256) dot += Pr[j] * Gr[j];
+    dot = block_sum_256(dot, red);
+    for (int j = threadIdx.x; j < ld; j += 256) {
+      float ds = 0.f;
+      if (j < N) {
+        ds = Pr[j] * (Gr[j] - dot);
+        if (want_tab) {
+          const int hj = j / W8, wj = j - hj * W8;
+          const int dh = hj - hi, dw = wj - wi;
+          if (dh >= -R && dh <= R && dw >= -R && dw <= R) atomicAdd(&tab[(dh + R) * T + dw + R], ds);
+        }
+        if (clamp && ((clampbits[rr * (ld >> 5) + (j >> 5)] >> (j & 31)) & 1u)) ds = 0.f;
+      }
+      Gr[j] = ds;
+    }
+  }
+  if (want_tab) {
+    __syncthreads();
+    float* rep = dtab + (long)(blockIdx.x % CRAFT_STATS_REPLICAS) * T * T;
+    for (int t = threadIdx.x; t < T * T; t += 256) if (tab[t] != 0.f) unsafeAtomicAdd(rep + t, tab[t] * pos_w);
+  }
+}
+int launch_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, int H8, int W8, int R, float pos_w,
+                            const unsigned* clamp_ord, const unsigned* clampbits, float* dtab, hipStream_t s) {
+  const int N = H8 * W8;
+  if (N <= 0 || B <= 0) return 0;
+  if (R > 15 || (ld & 31)) return CRAFT_ERR_UNSUPPORTED;
+  const long nrows = (long)B * M * N;
+  hipLaunchKernelGGL(k_attn_softmax_bwd, dim3((unsigned)((nrows + SM_ROWS_PER_BLOCK - 1) / SM_ROWS_PER_BLOCK)), dim3(256), 0, s, P, dP, ld,
+                     N, H8, W8, R, pos_w, clamp_ord, clampbits, dtab, nrows);
+  return (int)hipGetLastError();
+}
+
+// sum the replicas of an accumulation table: out[t] += sum_r rep[r][t]
+__global__ void k_reduce_replicas(const float* __restrict__ rep, int nrep, int n, float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  float s = 0.f;
+  for (int r = 0; r < nrep; ++r) s += rep[(long)r * n + t];
+  out[t] += s;
+}
+int launch_reduce_replicas(const float* rep, int nrep, int n, float* out, hipStream_t s) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_reduce_replicas, dim3((n + 255) / 256), dim3(256), 0, s, rep, nrep, n, out);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// correlation scores -> pooled volume (TransCorrBlock.corr, corr.py:191-199; setrans.py:520-550) from materialised scores
+// S [B][M][N][ld]:  s_m = clamp?(S_m) + pos_w*pb,  c = sum_m s_m softmax_m(w s_m)  -> level 0 [B*N][N] (row stride N),
+// sums[b] += (sum c, sum c^2).  w: device pointer to attn_softaggr.feat2score.weight (one float).
+// ---------------------------------------------------------------------------------------------
+template <int M>
+__device__ __forceinline__ float pool_modes(const float (&sm)[M], float w, float (&a)[M]) {
+  float mx = w * sm[0];
+#pragma unroll
+  for (int m = 1; m < M; ++m) mx = fmaxf(mx, w * sm[m]);
+  float den = 0.f;
+#pragma unroll
+  for (int m = 0; m < M; ++m) { a[m] = expf(w * sm[m] - mx); den += a[m]; }
+  float c = 0.f;
+  const float inv = 1.f / den;
+#pragma unroll
+  for (int m = 0; m < M; ++m) { a[m] *= inv; c += a[m] * sm[m]; }
+  return c;
+}
+template <int M>
+__global__ __launch_bounds__(256) void k_corr_pool_fwd(const float* __restrict__ S, long ld, int N, int H8, int W8,
+                                                       const float* __restrict__ pos_tab, int R, float pos_w, const float* __restrict__ wp,
+                                                       const unsigned* __restrict__ clamp_ord, float* __restrict__ c0,
+                                                       double* __restrict__ sums) {
+  __shared__ float red[4];
+  const long q = blockIdx.x;                    // (b, i)
+  const int b = (int)(q / N), i = (int)(q - (long)b * N);
+  const int hi = i / W8, wi = i - hi * W8;
+  const bool clamp = clamp_active(clamp_ord);
+  const float w = M > 1 ? *wp : 1.f;
+  float s1 = 0.f, s2 = 0.f;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    const int hj = j / W8, wj = j - hj * W8;
+    const float pb = pos_tab ? pos_w * pos_bias_at(pos_tab, R, hi, wi, hj, wj) : 0.f;
+    float sm[M], a[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      float v = S[(((long)b * M + m) * N + i) * ld + j];
+      if (clamp) v = fminf(fmaxf(v, -CRAFT_ATTN_CLIP), CRAFT_ATTN_CLIP);
+      sm[m] = v + pb;
+    }
+    const float c = M > 1 ? pool_modes<M>(sm, w, a) : sm[0];
+    c0[q * N + j] = c;
+    s1 += c; s2 += c * c;
+  }
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red);
+  if (threadIdx.x == 0) { atomicAdd(&sums[2 * b], (double)s1); atomicAdd(&sums[2 * b + 1], (double)s2); }
+}
+int launch_corr_pool_fwd(const float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, const float* w,
+                         const unsigned* clamp_ord, float* c0, double* sums, hipStream_t s) {
+  const int N = H8 * W8;
+  if (B <= 0 || N <= 0) return 0;
+  dim3 grid((unsigned)((long)B * N));
+  if (M == 4) hipLaunchKernelGGL((k_corr_pool_fwd<4>), grid, dim3(256), 0, s, S, ld, N, H8, W8, pos_tab, R, pos_w, w, clamp_ord, c0, sums);
+  else if (M == 1) hipLaunchKernelGGL((k_corr_pool_fwd<1>), grid, dim3(256), 0, s, S, ld, N, H8, W8, pos_tab, R, pos_w, w, clamp_ord, c0, sums);
+  else if (M == 2) hipLaunchKernelGGL((k_corr_pool_fwd<2>), grid, dim3(256), 0, s, S, ld, N, H8, W8, pos_tab, R, pos_w, w, clamp_ord, c0, sums);
+  else return CRAFT_ERR_UNSUPPORTED;
+  return (int)hipGetLastError();
+}
+
+// backward: G [B*N][N] = gradient w.r.t. the NORMALISED level 0 (all pyramid levels folded in, k_corr_pyramid_bwd), gstats[b] =
+// (sum G, sum G*c_hat).  dc = rstd (G - mean G - c_hat mean(G c_hat));  dS'_m = dc a_m (1 + w (s_m - c));  dw += dc sum_m a_m s_m
+// (s_m - c);  dtab += pos_w sum_m dS'_m;  dS_m = clamped ? 0 : dS'_m  (written over S).
+template <int M>
+__global__ __launch_bounds__(256) void k_corr_pool_bwd(float* __restrict__ S, long ld, int N, int H8, int W8,
+                                                       const float* __restrict__ pos_tab, int R, float pos_w, const float* __restrict__ wp,
+                                                       const unsigned* __restrict__ clamp_ord, const float* __restrict__ c0,
+                                                       const float* __restrict__ G, const float* __restrict__ mu_rstd,
+                                                       const double* __restrict__ gstats, int do_norm, float* __restrict__ dtab,
+                                                       double* __restrict__ dw) {
+  __shared__ float red[4];
+  __shared__ float tab[32 * 32];
+  const int T = 2 * R + 1;
+  const bool want_tab = dtab != nullptr && pos_tab != nullptr;
+  if (want_tab) for (int t = threadIdx.x; t < T * T; t += 256) tab[t] = 0.f;
+  __syncthreads();
+  const long q = blockIdx.x;
+  const int b = (int)(q / N), i = (int)(q - (long)b * N);
+  const int hi = i / W8, wi = i - hi * W8;
+  const bool clamp = clamp_active(clamp_ord);
+  const float w = M > 1 ? *wp : 1.f;
+  const float mu = mu_rstd[2 * b], rstd = mu_rstd[2 * b + 1];
+  const double cnt = (double)N * N;
+  const float mg = do_norm ? (float)(gstats[2 * b] / cnt) : 0.f, mgc = do_norm ? (float)(gstats[2 * b + 1] / cnt) : 0.f;
+  float dwl = 0.f;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    const int hj = j / W8, wj = j - hj * W8;
+    const int dh = hj - hi, dwd = wj - wi;
+    const bool inwin = pos_tab && dh >= -R && dh <= R && dwd >= -R && dwd <= R;
+    const float pb = inwin ? pos_w * pos_tab[(dh + R) * T + dwd + R] : 0.f;
+    float sm[M], a[M];
+    bool hit[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      float v = S[(((long)b * M + m) * N + i) * ld + j];
+      hit[m] = clamp && (v > CRAFT_ATTN_CLIP || v < -CRAFT_ATTN_CLIP);
+      if (clamp) v = fminf(fmaxf(v, -CRAFT_ATTN_CLIP), CRAFT_ATTN_CLIP);
+      sm[m] = v + pb;
+    }
+    const float g = G[q * N + j];
+    const float chat = (c0[q * N + j] - mu) * rstd;
+    const float dc = do_norm ? rstd * (g - mg - chat * mgc) : g;
+    float tsum = 0.f;
+    if (M > 1) {
+      const float c = pool_modes<M>(sm, w, a);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const float ds = dc * a[m] * (1.f + w * (sm[m] - c));
+        dwl += dc * a[m] * sm[m] * (sm[m] - c);
+        tsum += ds;
+        S[(((long)b * M + m) * N + i) * ld + j] = hit[m] ? 0.f : ds;
+      }
+    } else {
+      tsum = dc;
+      S[((long)b * N + i) * ld + j] = hit[0] ? 0.f : dc;
+    }
+    if (inwin && want_tab) atomicAdd(&tab[(dh + R) * T + dwd + R], tsum);
+  }
+  dwl = block_sum_256(dwl, red);
+  if (threadIdx.x == 0 && dw && M > 1) atomicAdd(dw, (double)dwl);
+  if (want_tab) {
+    __syncthreads();
+    float* rep = dtab + (long)(blockIdx.x % CRAFT_STATS_REPLICAS) * T * T;
+    for (int t = threadIdx.x; t < T * T; t += 256) if (tab[t] != 0.f) unsafeAtomicAdd(rep + t, tab[t] * pos_w);
+  }
+}
+int launch_corr_pool_bwd(float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, const float* w,
+                         const unsigned* clamp_ord, const float* c0, const float* G, const float* mu_rstd, const double* gstats,
+                         int do_norm, float* dtab, double* dw, hipStream_t s) {
+  const int N = H8 * W8;
+  if (B <= 0 || N <= 0) return 0;
+  if (R > 15) return CRAFT_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)((long)B * N));
+#define GO(MM) hipLaunchKernelGGL((k_corr_pool_bwd<MM>), grid, dim3(256), 0, s, S, ld, N, H8, W8, pos_tab, R, pos_w, w, clamp_ord, c0, G, \
+                                  mu_rstd, gstats, do_norm, dtab, dw)
+  if (M == 4) GO(4); else if (M == 1) GO(1); else if (M == 2) GO(2); else return CRAFT_ERR_UNSUPPORTED;
+#undef GO
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// pyramid backward: fold the gradients of levels 1..3 into level 0 (avg_pool2d 2x2, floor sizes: corr.py:186-189) and reduce
+// the two sums the global-LayerNorm backward needs.  G0[q][y][x] += G1[q][y/2][x/2]/4 + G2[..]/16 + G3[..]/64 where the cell
+// exists.  gstats[b] += (sum G0, sum G0 * c_hat).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_corr_pyramid_bwd(float* __restrict__ G0, const float* __restrict__ G1, const float* __restrict__ G2,
+                                                          const float* __restrict__ G3, const float* __restrict__ c0,
+                                                          const float* __restrict__ mu_rstd, int N, int H8, int W8,
+                                                          double* __restrict__ gstats) {
+  __shared__ float red[4];
+  const long q = blockIdx.x;
+  const int b = (int)(q / N);
+  const float mu = mu_rstd[2 * b], rstd = mu_rstd[2 * b + 1];
+  const int h1 = H8 >> 1, w1 = W8 >> 1, h2 = h1 >> 1, w2 = w1 >> 1, h3 = h2 >> 1, w3 = w2 >> 1;
+  float s1 = 0.f, s2 = 0.f;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    const int y = j / W8, x = j - y * W8;
+    float g = G0[q * N + j];
+    if (G1 && (y >> 1) < h1 && (x >> 1) < w1) g += 0.25f * G1[q * h1 * w1 + (y >> 1) * w1 + (x >> 1)];
+    if (G2 && (y >> 2) < h2 && (x >> 2) < w2 && (y >> 1) < 2 * h2 && (x >> 1) < 2 * w2) g += 0.0625f * G2[q * h2 * w2 + (y >> 2) * w2 + (x >> 2)];
+    if (G3 && (y >> 3) < h3 && (x >> 3) < w3 && (y >> 2) < 2 * h3 && (x >> 2) < 2 * w3 && (y >> 1) < 2 * h2 && (x >> 1) < 2 * w2)
+      g += 0.015625f * G3[q * h3 * w3 + (y >> 3) * w3 + (x >> 3)];
+    G0[q * N + j] = g;
+    s1 += g;
+    s2 += g * (c0[q * N + j] - mu) * rstd;
+  }
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red);
+  if (threadIdx.x == 0) { atomicAdd(&gstats[2 * b], (double)s1); atomicAdd(&gstats[2 * b + 1], (double)s2); }
+}
+int launch_corr_pyramid_bwd(float* G0, const float* G1, const float* G2, const float* G3, const float* c0, const float* mu_rstd, int B,
+                            int H8, int W8, double* gstats, hipStream_t s) {
+  const int N = H8 * W8;
+  if (B <= 0 || N <= 0) return 0;
+  hipLaunchKernelGGL(k_corr_pyramid_bwd, dim3((unsigned)((long)B * N)), dim3(256), 0, s, G0, G1, G2, G3, c0, mu_rstd, N, H8, W8, gstats);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// lookup backward (CorrBlock.__call__, corr.py:47-71): scatter w * g of every bilinear tap into the gradient of the
+// NORMALISED pyramid level it sampled (zero padding: out-of-image taps have no gradient).  One wave per query.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_corr_lookup_bwd(const float* __restrict__ dout, long ldo, const float* __restrict__ coords,
+                                                         float* __restrict__ G0, float* __restrict__ G1, float* __restrict__ G2,
+                                                         float* __restrict__ G3, int levels, int H8, int W8, int radius, int lvl_stride,
+                                                         int col_off, long nq) {
+  const int lane = threadIdx.x & 63;
+  const long q = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq) return;
+  const float cx = coords[2 * q], cy = coords[2 * q + 1];
+  const int win = 2 * radius + 1;
+  float* Gl[4] = {G0, G1, G2, G3};
+  int h = H8, w = W8;
+  float sc = 1.f;
+  for (int l = 0; l < levels; ++l) {
+    const float X = cx * sc, Y = cy * sc;
+    const float x0f = floorf(X), y0f = floorf(Y);
+    const float fx = X - x0f, fy = Y - y0f;
+    const int x0 = (int)fminf(fmaxf(x0f, -100000.f), 100000.f) - radius;
+    const int y0 = (int)fminf(fmaxf(y0f, -100000.f), 100000.f) - radius;
+    float* img = Gl[l] + q * (long)h * w;
+    const float wt[4] = {(1.f - fx) * (1.f - fy), fx * (1.f - fy), (1.f - fx) * fy, fx * fy};
+    for (int k = lane; k < win * win; k += 64) {
+      const int a = k / win, bb = k - a * win;          // x offset a, y offset bb (the x offset runs along the first window axis)
+      const float g = dout[q * ldo + l * lvl_stride + col_off + k];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int x = x0 + a + (t & 1), y = y0 + bb + (t >> 1);
+        if (x >= 0 && x < w && y >= 0 && y < h) unsafeAtomicAdd(img + y * w + x, wt[t] * g);
+      }
+    }
+    h >>= 1; w >>= 1; sc *= 0.5f;
+  }
+}
+int launch_corr_lookup_bwd(const float* dout, long ldo, const float* coords, float* G0, float* G1, float* G2, float* G3, int levels, int B,
+                           int H8, int W8, int radius, int lvl_stride, int col_off, hipStream_t s) {
+  if (levels < 1 || levels > 4 || radius < 0) return CRAFT_ERR_UNSUPPORTED;
+  const int win2 = (2 * radius + 1) * (2 * radius + 1);
+  if (lvl_stride <= 0) lvl_stride = win2;
+  const long nq = (long)B * H8 * W8;
+  if (nq <= 0) return 0;
+  hipLaunchKernelGGL(k_corr_lookup_bwd, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, dout, ldo, coords, G0, G1, G2, G3, levels, H8, W8,
+                     radius, lvl_stride, col_off, nq);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of craft_mode_pool_ln (ExpandedFeatTrans tail, setrans.py:395-407).  One wave per token, C <= 256.
+// dw_agg / dskip: per-block partials -> replicated tables [CRAFT_STATS_REPLICAS][C + 1] (last cell: dskip).
+// ---------------------------------------------------------------------------------------------
+constexpr int MPL_TOK_PER_WAVE = 8;
+__global__ __launch_bounds__(256) void k_mode_pool_ln_bwd(const float* __restrict__ O, const float* __restrict__ x, long ldx,
+                                                          const float* __restrict__ w_agg, const float* __restrict__ skip_coeff,
+                                                          const float* __restrict__ dy, long lddy, int N, int M, int C, long ntok,
+                                                          float* __restrict__ dO, float* __restrict__ dx, long lddx,
+                                                          float* __restrict__ dw_rep) {
+  __shared__ float acc_w[4][257];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float wl[4], dwl[4] = {0.f, 0.f, 0.f, 0.f};
+  float dskip = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; wl[i] = c < C ? w_agg[c] : 0.f; }
+  const float skip = *skip_coeff;
+  const long t0 = ((long)blockIdx.x * 4 + wv) * MPL_TOK_PER_WAVE;
+  for (long tok = t0; tok < min(ntok, t0 + MPL_TOK_PER_WAVE); ++tok) {
+    const long b = tok / N, n = tok - b * N;
+    float o[4][4], t[4];                        // [mode][channel slot]; M <= 4
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) if (m < M) {
+      const float* Om = O + ((b * M + m) * N + n) * C;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; o[m][i] = c < C ? Om[c] : 0.f; s += o[m][i] * wl[i]; }
+      t[m] = wave_sum(s);
+    }
+    float mx = t[0];
+    _Pragma("unroll") for (int m = 1; m < 4; ++m) if (m < M) mx = fmaxf(mx, t[m]);
+    float a[4], den = 0.f;
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) if (m < M) { a[m] = expf(t[m] - mx); den += a[m]; }
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) if (m < M) a[m] /= den;
+    float u[4], xv[4], g[4], s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      xv[i] = c < C ? x[tok * ldx + c] : 0.f;
+      g[i] = c < C ? dy[tok * lddy + c] : 0.f;
+      float p = 0.f;
+      _Pragma("unroll") for (int m = 0; m < 4; ++m) if (m < M) p += a[m] * o[m][i];
+      u[i] = c < C ? skip * xv[i] + p : 0.f;
+      s1 += u[i];
+    }
+    const float mean = wave_sum(s1) / C;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; const float d = c < C ? u[i] - mean : 0.f; s2 += d * d; }
+    const float rstd = rsqrtf(wave_sum(s2) / C + CRAFT_LN_EPS);
+    float sg = 0.f, sgy = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; if (c < C) { sg += g[i]; sgy += g[i] * (u[i] - mean) * rstd; } }
+    const float mg = wave_sum(sg) / C, mgy = wave_sum(sgy) / C;
+    float du[4], sx = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      du[i] = c < C ? rstd * (g[i] - mg - (u[i] - mean) * rstd * mgy) : 0.f;
+      sx += du[i] * xv[i];
+      if (c < C) dx[tok * lddx + c] = skip * du[i];
+    }
+    dskip += sx;                                 // (lane partial; reduced at the end)
+    float da[4], dsum = 0.f;
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) if (m < M) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s += du[i] * o[m][i];
+      da[m] = wave_sum(s);
+      dsum += a[m] * da[m];
+    }
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) if (m < M) {
+      const float dt = a[m] * (da[m] - dsum);
+      float* dOm = dO + ((b * M + m) * N + n) * C;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) dOm[c] = a[m] * du[i] + dt * wl[i];
+        dwl[i] += dt * o[m][i];
+      }
+    }
+  }
+  dskip = wave_sum(dskip);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc_w[wv][lane + 64 * i] = dwl[i];
+  if (lane == 0) acc_w[wv][256] = dskip;
+  __syncthreads();
+  float* rep = dw_rep + (long)(blockIdx.x % CRAFT_STATS_REPLICAS) * (C + 1);
+  for (int c = threadIdx.x; c < 257; c += 256) {
+    const float v = acc_w[0][c] + acc_w[1][c] + acc_w[2][c] + acc_w[3][c];
+    if (c < C) unsafeAtomicAdd(rep + c, v);
+    else if (c == 256) unsafeAtomicAdd(rep + C, v);
+  }
+}
+int launch_mode_pool_ln_bwd(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff, const float* dy, long lddy,
+                            int B, int N, int M, int C, float* dO, float* dx, long lddx, float* dw_rep, hipStream_t s) {
+  if (B <= 0 || N <= 0) return 0;
+  if (C > 256 || M > 4 || M < 1) return CRAFT_ERR_UNSUPPORTED;
+  const long ntok = (long)B * N;
+  const long nblk = (ntok + 4 * MPL_TOK_PER_WAVE - 1) / (4 * MPL_TOK_PER_WAVE);
+  hipLaunchKernelGGL(k_mode_pool_ln_bwd, dim3((unsigned)nblk), dim3(256), 0, s, O, x, ldx, w_agg, skip_coeff, dy, lddy, N, M, C, ntok, dO, dx,
+                     lddx, dw_rep);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of craft_convex_upsample (network.py:151-162).  One wave per low-resolution pixel, lane = sub-position (i, j).
+// dmask [B*N][576] written; dflow [B*N][2] accumulated with atomics (zero it first).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_convex_upsample_bwd(const float* __restrict__ mask, long ldm, const float* __restrict__ flow,
+                                                             const float* __restrict__ dup, int H8, int W8, long npix,
+                                                             float* __restrict__ dmask, long lddm, float* __restrict__ dflow) {
+  const int lane = threadIdx.x & 63;
+  const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= npix) return;
+  const int N = H8 * W8;
+  const long b = p / N;
+  const int n = (int)(p - b * N), y = n / W8, x = n - y * W8;
+  const int si = lane >> 3, sj = lane & 7;
+  const int H = 8 * H8, W = 8 * W8;
+  const float g0 = dup[((b * 2 + 0) * H + 8 * y + si) * W + 8 * x + sj];
+  const float g1 = dup[((b * 2 + 1) * H + 8 * y + si) * W + 8 * x + sj];
+  float mk[9], mx = -3.0e38f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { mk[k] = mask[p * ldm + k * 64 + lane]; mx = fmaxf(mx, mk[k]); }
+  float den = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { mk[k] = expf(mk[k] - mx); den += mk[k]; }
+  float dm[9], dsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    mk[k] /= den;
+    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+    const bool ok = yy >= 0 && yy < H8 && xx >= 0 && xx < W8;
+    const long nb = b * N + (ok ? yy * W8 + xx : 0);
+    const float f0 = ok ? 8.f * flow[2 * nb] : 0.f, f1 = ok ? 8.f * flow[2 * nb + 1] : 0.f;
+    dm[k] = g0 * f0 + g1 * f1;
+    dsum += mk[k] * dm[k];
+    const float d0 = wave_sum(8.f * mk[k] * g0), d1 = wave_sum(8.f * mk[k] * g1);
+    if (lane == 0 && ok) { unsafeAtomicAdd(dflow + 2 * nb, d0); unsafeAtomicAdd(dflow + 2 * nb + 1, d1); }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dmask[p * lddm + k * 64 + lane] = mk[k] * (dm[k] - dsum);
+}
+int launch_convex_upsample_bwd(const float* mask, long ldm, const float* flow, const float* dup, int B, int H8, int W8, float* dmask,
+                               long lddm, float* dflow, hipStream_t s) {
+  const long npix = (long)B * H8 * W8;
+  if (npix <= 0) return 0;
+  hipLaunchKernelGGL(k_convex_upsample_bwd, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, mask, ldm, flow, dup, H8, W8, npix, dmask,
+                     lddm, dflow);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// SepConvGRU gates as separate stages (update.py:49-64), C = 128 hidden channels, float4 streams.
+//   zr stage : z = sigmoid(zr_pre[:, :C]), r = sigmoid(zr_pre[:, C:]), rh = r * h
+//   out stage: q = tanh(q_pre), h' = (1 - z) h + z q
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+#define F4_MAP1(out, a, expr) { float A; A = a.x; out.x = (expr); A = a.y; out.y = (expr); A = a.z; out.z = (expr); A = a.w; out.w = (expr); }
+
+__global__ void k_gru_zr_fwd(const float* __restrict__ zr, long ldzr, const float* __restrict__ h, long ldh, float* __restrict__ z,
+                             float* __restrict__ r, float* __restrict__ rh, long rows, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C >> 2;
+  if (i >= rows * c4) return;
+  const long row = i / c4;
+  const int c = (int)(i - row * c4) * 4;
+  const float4 zp = ld4(zr + row * ldzr + c), rp = ld4(zr + row * ldzr + C + c), hv = ld4(h + row * ldh + c);
+  float4 zo, ro, rho;
+  F4_MAP1(zo, zp, sigmoid_precise(A));
+  F4_MAP1(ro, rp, sigmoid_precise(A));
+  rho.x = ro.x * hv.x; rho.y = ro.y * hv.y; rho.z = ro.z * hv.z; rho.w = ro.w * hv.w;
+  st4(z + row * C + c, zo); st4(r + row * C + c, ro); st4(rh + row * C + c, rho);
+}
+__global__ void k_gru_out_fwd(const float* __restrict__ qp, long ldq, const float* __restrict__ z, const float* __restrict__ h, long ldh,
+                              float* __restrict__ q, float* __restrict__ hn, long ldhn, long rows, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C >> 2;
+  if (i >= rows * c4) return;
+  const long row = i / c4;
+  const int c = (int)(i - row * c4) * 4;
+  const float4 qv = ld4(qp + row * ldq + c), zv = ld4(z + row * C + c), hv = ld4(h + row * ldh + c);
+  float4 qo, ho;
+  F4_MAP1(qo, qv, tanhf(A));
+  ho.x = (1.f - zv.x) * hv.x + zv.x * qo.x; ho.y = (1.f - zv.y) * hv.y + zv.y * qo.y;
+  ho.z = (1.f - zv.z) * hv.z + zv.z * qo.z; ho.w = (1.f - zv.w) * hv.w + zv.w * qo.w;
+  st4(q + row * C + c, qo); st4(hn + row * ldhn + c, ho);
+}
+// dh' -> dq_pre = dh' z (1 - q^2), dz = dh' (q - h), dh = dh' (1 - z)
+__global__ void k_gru_out_bwd(const float* __restrict__ dhn, long lddhn, const float* __restrict__ z, const float* __restrict__ q,
+                              const float* __restrict__ h, long ldh, float* __restrict__ dqp, float* __restrict__ dz, float* __restrict__ dh,
+                              long rows, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C >> 2;
+  if (i >= rows * c4) return;
+  const long row = i / c4;
+  const int c = (int)(i - row * c4) * 4;
+  const float4 g = ld4(dhn + row * lddhn + c), zv = ld4(z + row * C + c), qv = ld4(q + row * C + c), hv = ld4(h + row * ldh + c);
+  float4 a, b2, d;
+  a.x = g.x * zv.x * (1.f - qv.x * qv.x); a.y = g.y * zv.y * (1.f - qv.y * qv.y); a.z = g.z * zv.z * (1.f - qv.z * qv.z); a.w = g.w * zv.w * (1.f - qv.w * qv.w);
+  b2.x = g.x * (qv.x - hv.x); b2.y = g.y * (qv.y - hv.y); b2.z = g.z * (qv.z - hv.z); b2.w = g.w * (qv.w - hv.w);
+  d.x = g.x * (1.f - zv.x); d.y = g.y * (1.f - zv.y); d.z = g.z * (1.f - zv.z); d.w = g.w * (1.f - zv.w);
+  st4(dqp + row * C + c, a); st4(dz + row * C + c, b2); st4(dh + row * C + c, d);
+}
+// (dz, d(rh)) -> dzr_pre = [dz z (1-z) | d(rh) h r (1-r)], dh += d(rh) r
+__global__ void k_gru_zr_bwd(const float* __restrict__ dz, const float* __restrict__ drh, long lddrh, const float* __restrict__ z,
+                             const float* __restrict__ r, const float* __restrict__ h, long ldh, float* __restrict__ dzr,
+                             float* __restrict__ dh, long rows, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C >> 2;
+  if (i >= rows * c4) return;
+  const long row = i / c4;
+  const int c = (int)(i - row * c4) * 4;
+  const float4 gz = ld4(dz + row * C + c), gr = ld4(drh + row * lddrh + c), zv = ld4(z + row * C + c), rv = ld4(r + row * C + c),
+               hv = ld4(h + row * ldh + c);
+  float4 a, b2, d = ld4(dh + row * C + c);
+  a.x = gz.x * zv.x * (1.f - zv.x); a.y = gz.y * zv.y * (1.f - zv.y); a.z = gz.z * zv.z * (1.f - zv.z); a.w = gz.w * zv.w * (1.f - zv.w);
+  b2.x = gr.x * hv.x * rv.x * (1.f - rv.x); b2.y = gr.y * hv.y * rv.y * (1.f - rv.y); b2.z = gr.z * hv.z * rv.z * (1.f - rv.z); b2.w = gr.w * hv.w * rv.w * (1.f - rv.w);
+  d.x += gr.x * rv.x; d.y += gr.y * rv.y; d.z += gr.z * rv.z; d.w += gr.w * rv.w;
+  st4(dzr + row * 2 * C + c, a); st4(dzr + row * 2 * C + C + c, b2); st4(dh + row * C + c, d);
+}
+#define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, s
+int launch_gru_zr_fwd(const float* zr, long ldzr, const float* h, long ldh, float* z, float* r, float* rh, long rows, int C, hipStream_t s) {
+  if (rows <= 0) return 0;
+  if ((C & 3) || (ldzr & 3) || (ldh & 3)) return CRAFT_ERR_ALIGN;
+  hipLaunchKernelGGL(k_gru_zr_fwd, GRID1(rows * (C >> 2)), zr, ldzr, h, ldh, z, r, rh, rows, C);
+  return (int)hipGetLastError();
+}
+int launch_gru_out_fwd(const float* qp, long ldq, const float* z, const float* h, long ldh, float* q, float* hn, long ldhn, long rows, int C,
+                       hipStream_t s) {
+  if (rows <= 0) return 0;
+  if ((C & 3) || (ldq & 3) || (ldh & 3) || (ldhn & 3)) return CRAFT_ERR_ALIGN;
+  hipLaunchKernelGGL(k_gru_out_fwd, GRID1(rows * (C >> 2)), qp, ldq, z, h, ldh, q, hn, ldhn, rows, C);
+  return (int)hipGetLastError();
+}
+int launch_gru_out_bwd(const float* dhn, long lddhn, const float* z, const float* q, const float* h, long ldh, float* dqp, float* dz, float* dh,
+                       long rows, int C, hipStream_t s) {
+  if (rows <= 0) return 0;
+  if ((C & 3) || (lddhn & 3) || (ldh & 3)) return CRAFT_ERR_ALIGN;
+  hipLaunchKernelGGL(k_gru_out_bwd, GRID1(rows * (C >> 2)), dhn, lddhn, z, q, h, ldh, dqp, dz, dh, rows, C);
+  return (int)hipGetLastError();
+}
+int launch_gru_zr_bwd(const float* dz, const float* drh, long lddrh, const float* z, const float* r, const float* h, long ldh, float* dzr,
+                      float* dh, long rows, int C, hipStream_t s) {
+  if (rows <= 0) return 0;
+  if ((C & 3) || (lddrh & 3) || (ldh & 3)) return CRAFT_ERR_ALIGN;
+  hipLaunchKernelGGL(k_gru_zr_bwd, GRID1(rows * (C >> 2)), dz, drh, lddrh, z, r, h, ldh, dzr, dh, rows, C);
+  return (int)hipGetLastError();
+}
+
+}  // namespace craft

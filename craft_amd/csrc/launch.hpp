@@ -135,4 +135,43 @@ int launch_tokens_to_nchw(const float* src, long ld, int B, int C, int HW, float
 int launch_gma_residual(const float* mf, long ldm, const float* O, const float* gamma, int B, int N, int C, float* out,
                         long ldo, hipStream_t s);
 
+// ---- training: general GEMM / weight gradient (kernels_gemm_gen.hip), element-wise and row-wise backward (kernels_train.hip) ----
+int launch_gemm_gen(const float* A, long a_sm, long a_sk, long a_bs0, long a_bs1, const float* B, long b_sn, long b_sk, long b_bs0,
+                    long b_bs1, float* C, long ldc, long c_bs0, long c_bs1, int zdiv, int batch, int M, int N, int K, float alpha,
+                    int accumulate, int ksplit, int prec, hipStream_t s);
+int launch_conv_wgrad(const float* x, long ldx, int cin, const float* dy, long ldy, int cout, int KH, int KW, int B, int H, int W,
+                      float* dW, int prec, hipStream_t s);
+int launch_colsum(const float* x, long ld, long rows, int C, float* out, hipStream_t s);
+int launch_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, hipStream_t s);
+int launch_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,
+                   hipStream_t s);
+int launch_dropout(const float* x, float* y, long n, float p, unsigned long long seed, hipStream_t s);
+int launch_tokens_bwd(const float* x, long ldx, const float* dy, long lddy, float* dx, long lddx, long rows, int C, int act, int do_ln,
+                      hipStream_t s);
+int launch_attn_softmax_fwd(float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, int mask_radius,
+                            const unsigned* clamp_ord, unsigned* clampbits, hipStream_t s);
+int launch_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, int H8, int W8, int R, float pos_w,
+                            const unsigned* clamp_ord, const unsigned* clampbits, float* dtab, hipStream_t s);
+int launch_reduce_replicas(const float* rep, int nrep, int n, float* out, hipStream_t s);
+int launch_corr_pool_fwd(const float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, const float* w,
+                         const unsigned* clamp_ord, float* c0, double* sums, hipStream_t s);
+int launch_corr_pool_bwd(float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, const float* w,
+                         const unsigned* clamp_ord, const float* c0, const float* G, const float* mu_rstd, const double* gstats,
+                         int do_norm, float* dtab, double* dw, hipStream_t s);
+int launch_corr_pyramid_bwd(float* G0, const float* G1, const float* G2, const float* G3, const float* c0, const float* mu_rstd, int B,
+                            int H8, int W8, double* gstats, hipStream_t s);
+int launch_corr_lookup_bwd(const float* dout, long ldo, const float* coords, float* G0, float* G1, float* G2, float* G3, int levels, int B,
+                           int H8, int W8, int radius, int lvl_stride, int col_off, hipStream_t s);
+int launch_mode_pool_ln_bwd(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff, const float* dy, long lddy,
+                            int B, int N, int M, int C, float* dO, float* dx, long lddx, float* dw_rep, hipStream_t s);
+int launch_convex_upsample_bwd(const float* mask, long ldm, const float* flow, const float* dup, int B, int H8, int W8, float* dmask,
+                               long lddm, float* dflow, hipStream_t s);
+int launch_gru_zr_fwd(const float* zr, long ldzr, const float* h, long ldh, float* z, float* r, float* rh, long rows, int C, hipStream_t s);
+int launch_gru_out_fwd(const float* qp, long ldq, const float* z, const float* h, long ldh, float* q, float* hn, long ldhn, long rows, int C,
+                       hipStream_t s);
+int launch_gru_out_bwd(const float* dhn, long lddhn, const float* z, const float* q, const float* h, long ldh, float* dqp, float* dz, float* dh,
+                       long rows, int C, hipStream_t s);
+int launch_gru_zr_bwd(const float* dz, const float* drh, long lddrh, const float* z, const float* r, const float* h, long ldh, float* dzr,
+                      float* dh, long rows, int C, hipStream_t s);
+
 }  // namespace craft

@@ -13,7 +13,7 @@ from ctypes import c_double, c_float, c_int, c_long, c_void_p, c_char_p
 import torch
 
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16X3 = 0, 1, 2, 3
-ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 W_PACKED = 0x100
 PV_ROWS_SHIFT = 20            # CRAFT_PV_ROWS(r) = r << 20, or-ed into craft_attn_apply's prec
 FRAG_ACC_ORDER = 0x10000      # == CRAFT_FRAG_ACC_ORDER
@@ -62,6 +62,27 @@ _SIGS = {
     "craft_sumsq": [P, L, P, P],
     "craft_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, F, P, F, P],
     "craft_convex_upsample": [P, P, I, I, I, P, P],
+    # ---- training
+    "craft_gemm": [P, L, L, L, L, P, L, L, L, L, P, L, L, L, I, I, I, I, I, F, I, I, I, P],
+    "craft_conv2d_wgrad": [P, L, I, P, L, I, I, I, I, I, I, P, I, P],
+    "craft_colsum": [P, L, L, I, P, P],
+    "craft_act_fwd": [P, L, P, L, L, I, I, F, P],
+    "craft_act_bwd": [P, L, P, L, P, L, L, I, I, F, P],
+    "craft_dropout": [P, P, L, F, ctypes.c_ulonglong, P],
+    "craft_tokens_bwd": [P, L, P, L, P, L, L, I, I, I, P],
+    "craft_attn_softmax_fwd": [P, L, I, I, I, I, P, I, F, I, P, P, P],
+    "craft_attn_softmax_bwd": [P, P, L, I, I, I, I, I, F, P, P, P, P],
+    "craft_reduce_replicas": [P, I, I, P, P],
+    "craft_corr_pool_fwd": [P, L, I, I, I, I, P, I, F, P, P, P, P, P],
+    "craft_corr_lookup_bwd": [P, L, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "craft_corr_pyramid_bwd": [P, P, P, P, P, P, I, I, I, P, P],
+    "craft_corr_pool_bwd": [P, L, I, I, I, I, P, I, F, P, P, P, P, P, P, I, P, P, P],
+    "craft_mode_pool_ln_bwd": [P, P, L, P, P, P, L, I, I, I, I, P, P, L, P, P],
+    "craft_convex_upsample_bwd": [P, L, P, P, I, I, I, P, L, P, P],
+    "craft_gru_zr_fwd": [P, L, P, L, P, P, P, L, I, P],
+    "craft_gru_out_fwd": [P, L, P, P, L, P, P, L, L, I, P],
+    "craft_gru_out_bwd": [P, L, P, P, P, L, P, P, P, L, I, P],
+    "craft_gru_zr_bwd": [P, P, L, P, P, P, L, P, P, L, I, P],
     "craft_coords_init": [P, I, I, I, P, P, P, P],
 }
 

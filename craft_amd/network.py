@@ -193,9 +193,16 @@ class CRAFT(nn.Module):
         if not image1.is_cuda:
             raise RuntimeError("craft_amd.CRAFT runs its hot path on HIP kernels: inputs must be on the GPU "
                                "(there is no CPU fallback)")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.update_block.parameters()) and self.training:
-            raise NotImplementedError("training (backward kernels) is not implemented in this round: "
-                                      "call model.eval() / use torch.no_grad()")
+        if torch.is_grad_enabled() and self.training:
+            # model.train() with autograd on: the differentiable composition of the same operators (craft_amd/train_forward.py,
+            # backward kernels in craft_amd/autograd.py); returns what the reference returns for the requested test_mode
+            from .train_forward import forward_train
+            preds = forward_train(self, image1, image2, iters=iters, flow_init=flow_init)
+            self.call_counter += 1
+            if test_mode != 0:
+                raise NotImplementedError("model.train() with gradients enabled returns the list of predictions (test_mode=0), the "
+                                          "way train.py:228 calls it; use model.eval() / torch.no_grad() for test_mode 1 / 2")
+            return preds
         args = self.args
         prec = self.hip_prec()
         raw1, raw2 = image1.float().contiguous(), image2.float().contiguous()

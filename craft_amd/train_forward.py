@@ -1,0 +1,149 @@
+"""``CRAFT.forward`` under ``model.train()`` (network.py:164-267 with autograd on): the same algorithm as the inference path,
+composed from the differentiable HIP operators of ``craft_amd.autograd`` -- materialised scores instead of fused attention,
+GRU gates as separate stages -- so that ``loss.backward()`` runs the hand-written backward kernels.
+
+Training-mode semantics of the reference that are reproduced: BatchNorm batch statistics in ``cnet`` unless ``freeze_bn()``
+(extractor.py norm_fn='batch'; network.py:136-140), dropout 0.1 on the LayerNorm-ed tokens of every vispos encoder
+(setrans.py:791-795) and 0.2 on the attention probabilities of the F2 transformer and the intra-frame attention
+(setrans.py:553-557; not on the inter-frame scores, :544-550), ``coords1.detach()`` at the top of every iteration
+(network.py:232), all T upsampled predictions returned (test_mode=0).  The two CNN encoders run as PyTorch-ROCm modules
+under torch autograd (BASELINE.json north_star: "Host code stays Python on PyTorch-ROCm for the CNN feature/context
+extractors").  Only the released configuration trains here (``--craft --f2 full --setrans``, no ``--f1``).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import autograd as AG
+from . import ops
+from .hip import ACT_NONE, ACT_RELU, ACT_TANH
+
+
+def _attention_probs(module, x_ln, hw, prec, p_attn: float, seed: int):
+    """CrossAttFeatTrans up to (and including) the dropout of the probabilities (setrans.py:507-557) -> P [B, M, N, ld]."""
+    st = module.setrans
+    q = AG.Linear.apply(x_ln, st.query.weight, st.query.bias, prec)
+    k = AG.Linear.apply(x_ln, st.key.weight, st.key.bias, prec)
+    M = st.num_modes
+    scale = 1.0 / math.sqrt(st.attention_mode_dim)
+    mx = ops.score_max(q.detach(), k.detach(), hw[0], hw[1], M, scale, prec)
+    S = AG.Scores.apply(q, k, M, scale, prec)
+    P = AG.AttnSoftmax.apply(S, module.vispos_encoder.pos_coder.biases, float(st.pos_code_weight), int(module.attn_mask_radius), mx, hw)
+    return AG.dropout(P, p_attn, seed)
+
+
+def _conv(x, conv, hw, act, prec):
+    return AG.Conv.apply(x, conv.weight, conv.bias, hw, act, prec)
+
+
+def forward_train(model, image1, image2, iters=12, flow_init=None):
+    args = model.args
+    if not (args.craft and args.use_setrans and args.f2trans != "none" and model.f1_trans is None):
+        raise NotImplementedError("training is implemented for the released configuration (--craft --f2 full --setrans, no --f1)")
+    prec = model.hip_prec()
+    B, _, H, W = image1.shape
+    if H % 8 or W % 8:
+        raise ValueError("image height and width must be multiples of 8")
+    H8, W8 = H // 8, W // 8
+    N = H8 * W8
+    if N % 4:
+        raise ValueError(f"training needs (H/8)*(W/8) to be a multiple of 4 (got {H8}x{W8}): the backward GEMMs read 16-byte vectors")
+    hw = (H8, W8)
+    dev = image1.device
+    step = model.__dict__.setdefault("_train_calls", 0)
+    model.__dict__["_train_calls"] = step + 1
+    base_seed = (torch.initial_seed() * 1000003 + step * 64) & 0x7FFFFFFFFFFFFFF
+
+    def p_hidden(cfg):
+        return float(getattr(args, "dropout_prob", -1)) if getattr(args, "dropout_prob", -1) >= 0 else float(cfg.hidden_dropout_prob)
+
+    def p_attn(cfg):
+        return float(getattr(args, "dropout_prob", -1)) if getattr(args, "dropout_prob", -1) >= 0 else float(cfg.attention_probs_dropout_prob)
+
+    # ---- CNN encoders: PyTorch-ROCm modules under autograd (network.py:169-183, :203) ---------------------------------
+    im1 = (2 * (image1.float() / 255.0) - 1.0).contiguous()
+    im2 = (2 * (image2.float() / 255.0) - 1.0).contiguous()
+    fmap1, fmap2 = model.fnet([im1, im2])
+    cnet_feat = model.cnet(im1)
+    f1_tok = AG.NchwToTokens.apply(fmap1.float())
+    f2_tok = AG.NchwToTokens.apply(fmap2.float())
+    cn_tok = AG.NchwToTokens.apply(cnet_feat.float())
+    net = AG.TokensNorm.apply(cn_tok[..., 0:128], ACT_TANH, False)              # network.py:209-211
+    inp = AG.TokensNorm.apply(cn_tok[..., 128:256], ACT_RELU, False)
+
+    # ---- F2 transformer (network.py:185-187; setrans.py:578-619, 364-410) ---------------------------------------------
+    f2 = model.f2_trans
+    c2 = f2.config
+    x2 = AG.dropout(AG.TokensNorm.apply(f2_tok, ACT_NONE, True), p_hidden(c2), base_seed + 1)
+    P2 = _attention_probs(f2, x2, hw, prec, p_attn(c2), base_seed + 2)
+    ot = f2.setrans.out_trans
+    v2 = AG.Linear.apply(x2, ot.first_linear.weight, None, prec)
+    O2 = AG.AttnApply.apply(P2, v2, prec)
+    fmap2_t = AG.ModePoolLN.apply(O2, x2, ot.feat_softaggr.feat2score.weight, ot.input_skip_coeff)
+
+    # ---- inter-frame correlation volume + pyramid (network.py:225-228; corr.py:148-207) -------------------------------
+    cf = model.corr_fn
+    cc = cf.config
+    x1 = AG.dropout(AG.TokensNorm.apply(f1_tok, ACT_NONE, True), p_hidden(cc), base_seed + 3)
+    x2t = AG.dropout(AG.TokensNorm.apply(fmap2_t, ACT_NONE, True), p_hidden(cc), base_seed + 4)
+    st = cf.setrans
+    q = AG.Linear.apply(x1, st.query.weight, st.query.bias, prec)
+    k = AG.Linear.apply(x2t, st.key.weight, st.key.bias, prec)
+    scale = 1.0 / math.sqrt(st.attention_mode_dim)
+    mx = ops.score_max(q.detach(), k.detach(), H8, W8, st.num_modes, scale, prec)
+    Sc = AG.Scores.apply(q, k, st.num_modes, scale, prec)
+    box = []
+    w_aggr = st.attn_softaggr.feat2score.weight if st.num_modes > 1 else torch.ones(1, 1, device=dev)
+    token = AG.CorrVolume.apply(Sc, cf.vispos_encoder.pos_coder.biases, w_aggr, float(st.pos_code_weight), mx, hw, box,
+                                bool(cf.do_corr_global_norm))
+    holder = box[0]
+
+    # ---- intra-frame attention (network.py:214): computed once, used by every iteration ------------------------------
+    att = model.att
+    ca = att.config
+    xc = AG.dropout(AG.TokensNorm.apply(inp, ACT_NONE, True), p_hidden(ca), base_seed + 5)
+    Patt = _attention_probs(att, xc, hw, prec, p_attn(ca), base_seed + 6)
+
+    # ---- iterative refinement (network.py:230-260; update.py:137-162) -------------------------------------------------
+    ub = model.update_block
+    enc, gru, fh, agg = ub.encoder, ub.gru, ub.flow_head, ub.aggregator
+    coords0, coords1, _ = ops.coords_init(flow_init, B, H8, W8, dev)
+    preds = []
+    wzr = [torch.cat([gru.convz1.weight, gru.convr1.weight], 0), torch.cat([gru.convz2.weight, gru.convr2.weight], 0)]
+    bzr = [torch.cat([gru.convz1.bias, gru.convr1.bias], 0), torch.cat([gru.convz2.bias, gru.convr2.bias], 0)]
+    convq = [gru.convq1, gru.convq2]
+    wc1 = enc.convc1.weight.view(256, -1)
+    wm2 = ub.mask[2].weight.view(576, -1)
+    for _ in range(iters):
+        coords1 = coords1.detach()                                              # network.py:232
+        corr = AG.CorrLookup.apply(token, coords1, holder, cf.radius)           # :235
+        flow = coords1 - coords0
+        # BasicMotionEncoder (update.py:79-87)
+        cor = AG.Act.apply(AG.Linear.apply(corr, wc1, enc.convc1.bias, prec.conv), ACT_RELU, 1.0)
+        cor = _conv(cor, enc.convc2, hw, ACT_RELU, prec)
+        flo = _conv(flow, enc.convf1, hw, ACT_RELU, prec)
+        flo = _conv(flo, enc.convf2, hw, ACT_RELU, prec)
+        out = _conv(torch.cat([cor, flo], dim=-1), enc.conv, hw, ACT_RELU, prec)
+        mf = torch.cat([out, flow], dim=-1)                                     # [B, N, 128]
+        # motion aggregator (update.py:143-149): ExpandedFeatTrans on the raw motion features
+        va = AG.Linear.apply(mf, agg.first_linear.weight, None, prec)
+        Oa = AG.AttnApply.apply(Patt, va, prec)
+        mfg = AG.ModePoolLN.apply(Oa, mf, agg.feat_softaggr.feat2score.weight, agg.input_skip_coeff)
+        # SepConvGRU (update.py:49-64)
+        x = torch.cat([inp, mf, mfg], dim=-1)                                   # [B, N, 384]
+        h = net
+        for ps, (kh, kw) in enumerate(((1, 5), (5, 1))):
+            zr_pre = AG.Conv.apply(torch.cat([h, x], dim=-1), wzr[ps], bzr[ps], hw, ACT_NONE, prec)
+            z, rh = AG.GruZR.apply(zr_pre, h)
+            q_pre = _conv(torch.cat([rh, x], dim=-1), convq[ps], hw, ACT_NONE, prec)
+            h = AG.GruOut.apply(q_pre, z, h)
+        net = h
+        # heads (update.py:15-16, :124-127, :161)
+        delta = _conv(_conv(net, fh.conv1, hw, ACT_RELU, prec), fh.conv2, hw, ACT_NONE, prec)
+        mh = _conv(net, ub.mask[0], hw, ACT_RELU, prec)
+        mask = AG.Act.apply(AG.Linear.apply(mh, wm2, ub.mask[2].bias, prec.conv), ACT_NONE, 0.25)
+        coords1 = coords1 + delta                                               # network.py:247
+        preds.append(AG.ConvexUpsample.apply(mask, coords1 - coords0, hw))      # :258
+    return preds

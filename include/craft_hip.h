@@ -278,6 +278,95 @@ int craft_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
                      float beta2, float eps, float weight_decay, int step, float grad_mul, const double* grad_sumsq,
                      float max_norm, void* stream);
 
+/* ==== training: backward of the hot path (train.py:228-236 `loss.backward()` through network.py:164-267) =================
+ * The reference gets its backward from autograd over PyTorch ops; here every operator's gradient is a kernel, bound as the
+ * backward of an autograd.Function by craft_amd/autograd.py.  The dense contractions are ONE general strided batched GEMM
+ * (dX = dY W, dW = dY^T X, dP = dO V^T, dV = P^T dO, dQ = dS K, dK = dS^T Q are all instances), the convolution weight
+ * gradient is its sibling with the tap shift in the loader, and the convolution input gradient is the FORWARD convolution
+ * (craft_conv2d_nhwc) with flipped, transposed weights.  Everything else is element-wise / row-wise and HBM-bound.
+ *
+ * craft_gemm:  C[z][m][n] = alpha * sum_k A(z,m,k) * B(z,n,k)  (+ C[z][m][n] when accumulate), z = z0*zdiv + z1 < batch,
+ *   A(z,m,k) at A + z0*a_bs0 + z1*a_bs1 + m*a_sm + k*a_sk with a_sk == 1 (k contiguous: rows operand) or a_sm == 1 (k-major:
+ *   a transposed operand read in place); likewise B with (b_sn, b_sk).  C row-major with row stride ldc.  Leading dimensions
+ *   and batch strides are multiples of 4 floats, bases 16-byte aligned; M, N, K arbitrary.  ksplit: K is cut into that many
+ *   ranges whose partial products are added with atomics (needs accumulate = 1 and a zero-filled or running C); 0 = choose
+ *   so that the grid fills the chip (weight gradients: M x N is tiny, K = all rows).  prec as craft_linear.
+ * craft_conv2d_wgrad: dW[co][ky][kx][ci] += sum_pix dY[pix][co] * X[pix + (ky-KH/2, kx-KW/2)][ci]  (stride 1, zero padding;
+ *   x [B*H*W][cin] row stride ldx, dy [B*H*W][cout] row stride ldy; dW in the packed [cout][KH][KW][cin] layout, ACCUMULATED).
+ * craft_colsum: out[c] += sum_r x[r][c]   (bias gradients).
+ * craft_act_fwd / craft_act_bwd: y = scale * act(x);  dx = scale * dy * act'(.) evaluated from the UNSCALED output y / scale the
+ *   caller kept (relu: y > 0, tanh: 1 - y^2, sigmoid (CRAFT_ACT_SIGMOID = 3): y (1 - y)); C % 4 == 0.
+ * craft_dropout: y[i] = x[i] * keep_i / (1 - p), keep_i = (hash(seed, i) >= p): nn.Dropout in training mode (setrans.py:553-557,
+ *   :791-795) with a counter-based generator, so the backward is the same call on the gradient. */
+#define CRAFT_ACT_SIGMOID 3
+int craft_gemm(const float* A, long a_sm, long a_sk, long a_bs0, long a_bs1, const float* B, long b_sn, long b_sk, long b_bs0,
+               long b_bs1, float* C, long ldc, long c_bs0, long c_bs1, int zdiv, int batch, int M, int N, int K, float alpha,
+               int accumulate, int ksplit, int prec, void* stream);
+int craft_conv2d_wgrad(const float* x, long ldx, int cin, const float* dy, long ldy, int cout, int KH, int KW, int B, int H, int W,
+                       float* dW, int prec, void* stream);
+int craft_colsum(const float* x, long ld, long rows, int C, float* out, void* stream);
+int craft_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, void* stream);
+int craft_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,
+                  void* stream);
+int craft_dropout(const float* x, float* y, long n, float p, unsigned long long seed, void* stream);
+
+/* backward of craft_tokens with a token-major source: y = LayerNorm?(act(x)), x / dy / dx rows of C <= 256 channels. */
+int craft_tokens_bwd(const float* x, long ldx, const float* dy, long lddy, float* dx, long lddx, long rows, int C, int act, int do_ln,
+                     void* stream);
+
+/* Attention probabilities from MATERIALISED scores (training form of craft_attn_probs; setrans.py:520-551), in place:
+ *   S [B][M][N][ld] (scaled Q K^T from craft_gemm; ld % 32 == 0) -> P = softmax_j(clamp?(S) + pos_w*pb + mask), columns [N, ld) = 0.
+ *   clampbits (or NULL): [B*M*N][ld/32] words, bit j = "score (i, j) was clamped" -- written only when the clamp is active.
+ * craft_attn_softmax_bwd: dP (gradient w.r.t. P, overwritten with dS) -> dS = P (dP - sum_j dP P), zero where clamped;
+ *   dtab_rep [CRAFT_STATS_REPLICAS][(2R+1)^2] += pos_w * dS over the positional window (zero it first; craft_reduce_replicas
+ *   folds the replicas into the table's gradient). */
+int craft_attn_softmax_fwd(float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, int mask_radius,
+                           const unsigned* clamp_ord, unsigned* clampbits, void* stream);
+int craft_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, int H8, int W8, int R, float pos_w,
+                           const unsigned* clamp_ord, const unsigned* clampbits, float* dtab_rep, void* stream);
+int craft_reduce_replicas(const float* rep, int nrep, int n, float* out, void* stream);
+
+/* Correlation volume from MATERIALISED scores (training form of craft_corr_build; corr.py:191-199, setrans.py:520-550):
+ *   S [B][M][N][ld] -> c0 [B*N][N] = sum_m s_m softmax_m(w s_m), s_m = clamp?(S_m) + pos_w*pb; sums[b] += (sum c, sum c^2).
+ *   w: DEVICE pointer to attn_softaggr.feat2score.weight (no host read-back).  craft_corr_finish then builds the pyramid and
+ *   (mean, rstd) exactly as in inference, and craft_corr_lookup samples it.
+ * craft_corr_lookup_bwd: gradient of the lookup output (tokens, same column layout as craft_corr_lookup) scattered into
+ *   G0..G3, the gradients of the NORMALISED pyramid levels (same shapes as the pyramid, zero them first; atomics).
+ * craft_corr_pyramid_bwd: folds G1..G3 into G0 (2x2 average pooling backward, floor sizes) and reduces gstats[b] += (sum G0,
+ *   sum G0 * c_hat) for the global-LayerNorm backward (zero gstats first).
+ * craft_corr_pool_bwd: (G0, gstats) -> dS written over S (LayerNorm backward over all N*N entries, mode-pooling backward, clamp
+ *   mask); dtab_rep as above; *dw += gradient of the pooling weight (double). */
+int craft_corr_pool_fwd(const float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, const float* w,
+                        const unsigned* clamp_ord, float* c0, double* sums, void* stream);
+int craft_corr_lookup_bwd(const float* dout, long ldo, const float* coords, float* G0, float* G1, float* G2, float* G3, int levels, int B,
+                          int H8, int W8, int radius, int lvl_stride, int col_off, void* stream);
+int craft_corr_pyramid_bwd(float* G0, const float* G1, const float* G2, const float* G3, const float* c0, const float* mu_rstd, int B,
+                           int H8, int W8, double* gstats, void* stream);
+int craft_corr_pool_bwd(float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, const float* w,
+                        const unsigned* clamp_ord, const float* c0, const float* G0, const float* mu_rstd, const double* gstats,
+                        int do_norm, float* dtab_rep, double* dw, void* stream);
+
+/* backward of craft_mode_pool_ln: dy -> dO [B][M][N][C], dx [B*N][C] (row stride lddx), and dw_rep [CRAFT_STATS_REPLICAS][C+1] +=
+ * (d w_agg [C], d skip_coeff) (zero it first; craft_reduce_replicas). */
+int craft_mode_pool_ln_bwd(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff, const float* dy,
+                           long lddy, int B, int N, int M, int C, float* dO, float* dx, long lddx, float* dw_rep, void* stream);
+
+/* backward of craft_convex_upsample: dup NCHW [B][2][8*H8][8*W8] -> dmask [B*N][576] (row stride lddm) and dflow [B*N][2] +=. */
+int craft_convex_upsample_bwd(const float* mask, long ldm, const float* flow, const float* dup, int B, int H8, int W8, float* dmask,
+                              long lddm, float* dflow, void* stream);
+
+/* SepConvGRU gates as separate stages (update.py:55-63), C hidden channels (C % 4 == 0); z, r, rh, q, dz, dq_pre, dh are dense
+ * [rows][C], zr_pre / dzr_pre dense [rows][2C]:
+ *   zr_fwd : z = sigmoid(zr_pre[:, :C]), r = sigmoid(zr_pre[:, C:]), rh = r*h       out_fwd: q = tanh(q_pre), h' = (1-z) h + z q
+ *   out_bwd: dq_pre = dh' z (1-q^2), dz = dh' (q-h), dh = dh' (1-z)                 zr_bwd : dzr_pre = [dz z(1-z) | drh h r(1-r)], dh += drh r */
+int craft_gru_zr_fwd(const float* zr_pre, long ldzr, const float* h, long ldh, float* z, float* r, float* rh, long rows, int C, void* stream);
+int craft_gru_out_fwd(const float* q_pre, long ldq, const float* z, const float* h, long ldh, float* q, float* h_new, long ldhn, long rows,
+                      int C, void* stream);
+int craft_gru_out_bwd(const float* dh_new, long lddhn, const float* z, const float* q, const float* h, long ldh, float* dq_pre, float* dz,
+                      float* dh, long rows, int C, void* stream);
+int craft_gru_zr_bwd(const float* dz, const float* drh, long lddrh, const float* z, const float* r, const float* h, long ldh, float* dzr_pre,
+                     float* dh, long rows, int C, void* stream);
+
 /* CRAFT.upsample_flow (network.py:151-162): mask tokens [B*N][576], flow tokens [B*N][2] -> up NCHW
  * [B][2][8*H8][8*W8]. */
 int craft_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, void* stream);

@@ -1,0 +1,356 @@
+"""Backward kernels of the hot path (SURVEY.md §8(a) H', §8(e), §8(f)3).
+
+1. ``craft_gemm`` / ``craft_conv2d_wgrad`` against torch on the CPU: every operand layout (rows / k-major), ragged sizes,
+   split-K, all four precisions.
+2. Every ``craft_amd.autograd`` Function: forward value AND input gradients against torch autograd over the CPU oracle's
+   formulation of the same operator (oracle/craft_oracle.py functions are differentiable torch code).
+3. End to end: ``model.train()`` forward + ``sequence_loss`` + ``backward()`` against the loss and ALL parameter gradients
+   captured from the imported reference (tests/golden/train_*.npz, tools/make_golden_train.py; dropout forced to 0 there and
+   here): fp32 policy: relative L2 error of every gradient <= 1e-2 (measured: update block 2e-4 .. 1e-3, attention / correlation
+   parameters <= 3e-3, the encoders -- whose backward is MIOpen's, fed by our d fmap -- <= 5.6e-3) and the loss to 3e-5
+   (SURVEY H': "loss value & selected grads"); mixed policy (fp16 P.V): <= 8e-2.
+4. Dropout: keep rate, scaling, determinism per seed, identical mask in forward and backward.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from craft_amd import CRAFT, default_args, hip, ops
+from craft_amd import autograd as AG
+from craft_amd.hip import ACT_NONE, ACT_RELU, ACT_TANH, PREC_BF16, PREC_F16, PREC_F16X3, PREC_F32
+from craft_amd.synth import synth_state_dict
+from golden_util import GOLDEN_DIR
+from oracle import craft_oracle as O
+from golden_util import sample_idx
+from test_oracle_train_golden import TRAIN_CASES, grad_scale
+
+pytestmark = pytest.mark.gpu
+TOL = {PREC_F32: 2e-5, PREC_F16X3: 2e-5, PREC_F16: 4e-3, PREC_BF16: 3e-2}
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-20)).item()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# 1. general GEMM, weight gradient
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", [PREC_F32, PREC_F16X3, PREC_F16, PREC_BF16])
+@pytest.mark.parametrize("at,bt", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K,ksplit", [(300, 200, 64, 1), (129, 70, 1000, 4), (37, 324, 2852, 0), (256, 128, 96, 1)])
+def test_gemm_layouts(device, prec, at, bt, M, N, K, ksplit):
+    if not (at and bt) and K % 4:
+        pytest.skip("k-contiguous operands are read 4 k at a time")
+    batch, zdiv = 3, 1
+    A = rnd(batch, M, K, seed=1)
+    Bm = rnd(batch, N, K, seed=2)
+    ref = 0.7 * torch.matmul(A, Bm.transpose(1, 2))
+    ldm = lambda n: (n + 3) // 4 * 4
+    if at:      # stored [K][ldM]
+        As = torch.zeros(batch, K, ldm(M)); As[..., :M] = A.transpose(1, 2); a_sm, a_sk, a_bs = 1, ldm(M), K * ldm(M)
+    else:
+        As = A.contiguous(); a_sm, a_sk, a_bs = K, 1, M * K
+    if bt:
+        Bs = torch.zeros(batch, K, ldm(N)); Bs[..., :N] = Bm.transpose(1, 2); b_sn, b_sk, b_bs = 1, ldm(N), K * ldm(N)
+    else:
+        Bs = Bm.contiguous(); b_sn, b_sk, b_bs = K, 1, N * K
+    Ad, Bd = As.to(device), Bs.to(device)
+    C = torch.zeros(batch, M, N, device=device) if ksplit != 1 else torch.full((batch, M, N), 7.0, device=device)
+    AG.gemm(Ad, a_sm, a_sk, a_bs, 0, Bd, b_sn, b_sk, b_bs, 0, C, N, M * N, 0, zdiv, batch, M, N, K, alpha=0.7,
+            accumulate=ksplit != 1, ksplit=ksplit, prec=prec)
+    assert rel_err(C, ref) < TOL[prec] * math.sqrt(K / 64 + 1), (at, bt)
+    if ksplit == 1:       # accumulate without split-K: C += on top of a known value
+        C2 = torch.full((batch, M, N), 2.0, device=device)
+        AG.gemm(Ad, a_sm, a_sk, a_bs, 0, Bd, b_sn, b_sk, b_bs, 0, C2, N, M * N, 0, zdiv, batch, M, N, K, alpha=0.7, accumulate=True, prec=prec)
+        assert rel_err(C2 - 2.0, ref) < TOL[prec] * math.sqrt(K / 64 + 1) + 1e-6
+
+
+@pytest.mark.parametrize("prec", [PREC_F32, PREC_F16X3])
+@pytest.mark.parametrize("KH,KW,cin,cout,H,W", [(3, 3, 64, 96, 11, 13), (1, 5, 160, 256, 9, 20), (5, 1, 32, 32, 12, 7), (7, 7, 32, 128, 10, 9),
+                                                (1, 1, 96, 64, 8, 8)])
+def test_conv_wgrad(device, prec, KH, KW, cin, cout, H, W):
+    B = 2
+    x = rnd(B, cin, H, W, seed=3)
+    dy = rnd(B, cout, H, W, seed=4)
+    w = torch.zeros(cout, cin, KH, KW, requires_grad=True)
+    F.conv2d(x, w, padding=(KH // 2, KW // 2)).backward(dy)
+    xt = x.permute(0, 2, 3, 1).reshape(B, H * W, cin).contiguous().to(device)
+    dyt = dy.permute(0, 2, 3, 1).reshape(B, H * W, cout).contiguous().to(device)
+    dw = torch.zeros(cout, KH, KW, cin, device=device)
+    hip.call("craft_conv2d_wgrad", xt, cin, cin, dyt, cout, cout, KH, KW, B, H, W, dw, prec)
+    assert rel_err(dw.permute(0, 3, 1, 2), w.grad) < 3e-5
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# 2. operators: value and gradients vs torch autograd on the CPU
+# ------------------------------------------------------------------------------------------------------------------
+def _leaf(t, device):
+    return t.clone().to(device).requires_grad_(True)
+
+
+def _check_grads(outs_dev, outs_ref, leaves_dev, leaves_ref, tol=3e-5, names=None, leaf_tol=None):
+    """Same random cotangents pushed through both graphs; values and every leaf gradient must agree."""
+    outs_dev = outs_dev if isinstance(outs_dev, (tuple, list)) else [outs_dev]
+    outs_ref = outs_ref if isinstance(outs_ref, (tuple, list)) else [outs_ref]
+    for i, (a, b) in enumerate(zip(outs_dev, outs_ref)):
+        assert rel_err(a, b) < tol, f"forward output {i}"
+    cots = [rnd(*b.shape, seed=90 + i) for i, b in enumerate(outs_ref)]
+    torch.autograd.backward(outs_ref, cots)
+    torch.autograd.backward(outs_dev, [c.to(a.device) for c, a in zip(cots, outs_dev)])
+    for i, (a, b) in enumerate(zip(leaves_dev, leaves_ref)):
+        assert a.grad is not None, f"no gradient for leaf {i if names is None else names[i]}"
+        t = (leaf_tol or {}).get(names[i] if names else i, tol)
+        assert rel_err(a.grad, b.grad) < t, f"gradient of leaf {i if names is None else names[i]}: {rel_err(a.grad, b.grad):.2e}"
+
+
+@pytest.mark.parametrize("act,ln", [(ACT_NONE, True), (ACT_TANH, False), (ACT_RELU, False), (ACT_RELU, True)])
+def test_tokens_norm_backward(device, act, ln):
+    x = rnd(2, 37, 256, seed=5)
+    xd, xr = _leaf(x, device), x.clone().requires_grad_(True)
+    yd = AG.TokensNorm.apply(xd[..., 64:192], act, ln)
+    a = xr[..., 64:192]
+    a = torch.tanh(a) if act == ACT_TANH else torch.relu(a) if act == ACT_RELU else a
+    yr = O.layernorm_lastdim(a) if ln else a
+    _check_grads(yd, yr, [xd], [xr])
+
+
+def test_nchw_tokens_and_act(device):
+    x = rnd(2, 256, 5, 7, seed=6)
+    xd, xr = _leaf(x, device), x.clone().requires_grad_(True)
+    yd = AG.Act.apply(AG.NchwToTokens.apply(xd), ACT_RELU, 1.0)
+    yd2 = AG.Act.apply(yd, ACT_NONE, 0.25)
+    yr = torch.relu(xr.reshape(2, 256, 35).transpose(1, 2))
+    _check_grads([yd, yd2], [yr, 0.25 * yr], [xd], [xr])
+
+
+@pytest.mark.parametrize("prec", [PREC_F32, PREC_F16X3])
+@pytest.mark.parametrize("rows,cin,cout,bias", [(2 * 300, 324, 256, True), (2 * 52, 128, 512, False), (2 * 100, 256, 576, True)])
+def test_linear_backward(device, prec, rows, cin, cout, bias):
+    x, w, b = rnd(2, rows // 2, cin, seed=7), rnd(cout, cin, seed=8) / math.sqrt(cin), rnd(cout, seed=9)
+    ld, lr = [_leaf(t, device) for t in (x, w, b)], [t.clone().requires_grad_(True) for t in (x, w, b)]
+    yd = AG.Linear.apply(ld[0], ld[1], ld[2] if bias else None, prec)
+    yr = F.linear(lr[0], lr[1], lr[2] if bias else None)
+    n = 3 if bias else 2
+    _check_grads(yd, yr, ld[:n], lr[:n], names=["x", "w", "b"])
+
+
+@pytest.mark.parametrize("H8,W8,C,M,mask_radius,gain", [(6, 10, 128, 4, -1, 2.5), (8, 9, 256, 4, 3, 2.5), (6, 10, 128, 4, -1, 90.0)])
+def test_attention_chain_backward(device, H8, W8, C, M, mask_radius, gain):
+    """Linear -> Scores -> AttnSoftmax (positional bias, Chebyshev mask, clamp) -> AttnApply -> ModePoolLN vs the oracle's
+    self_attn_probs + expanded_feat_trans under torch autograd (gain 90 triggers the clamp: clamped scores get no gradient)."""
+    B, N = 2, H8 * W8
+    x = O.layernorm_lastdim(rnd(B, N, C, seed=10))
+    Wq, Wk = rnd(C, C, seed=11) * math.sqrt(gain / C), rnd(C, C, seed=12) * math.sqrt(gain / C)
+    Wv = rnd(M * C, C, seed=13) / math.sqrt(C)
+    tab, w_agg, skip = rnd(15, 15, seed=14) * 0.5, rnd(1, C, seed=15) * 0.3, torch.tensor([0.7])
+    base = (x, Wq, Wk, Wv, tab, w_agg, skip)
+    ld, lr = [_leaf(t, device) for t in base], [t.clone().requires_grad_(True) for t in base]
+    xd, Wqd, Wkd, Wvd, tabd, wad, skd = ld
+    q, k = AG.Linear.apply(xd, Wqd, None, PREC_F32), AG.Linear.apply(xd, Wkd, None, PREC_F32)
+    scale = 1 / math.sqrt(C // M)
+    mx = ops.score_max(q.detach(), k.detach(), H8, W8, M, scale, PREC_F32)
+    S = AG.Scores.apply(q, k, M, scale, PREC_F32)
+    P = AG.AttnSoftmax.apply(S, tabd, 0.5, mask_radius, mx, (H8, W8))
+    Od = AG.AttnApply.apply(P, AG.Linear.apply(xd, Wvd, None, PREC_F32), PREC_F32)
+    yd = AG.ModePoolLN.apply(Od, xd, wad, skd)
+    xr, Wqr, Wkr, Wvr, tabr, war, skr = lr
+    Sr = O.mm_scores(xr, xr, Wqr, None, Wkr, None, M)
+    if gain > 50:
+        assert float(Sr.max()) > 100
+    Pr = O.self_attn_probs(xr, Wqr, Wkr, tabr, 0.5, M, H8, W8, mask_radius)
+    yr = O.expanded_feat_trans(xr, Pr, Wvr, war, skr)
+    assert rel_err(P[..., :N], Pr) < 3e-5
+    _check_grads(yd, yr, ld, lr, tol=2e-4, names=["x", "Wq", "Wk", "Wv", "pos table", "w_agg", "skip"])
+
+
+@pytest.mark.parametrize("gain", [2.5, 70.0])
+def test_corr_volume_and_lookup_backward(device, gain):
+    """Scores -> CorrVolume (mode pooling, global LayerNorm, pyramid) -> three CorrLookups at different coordinates (their
+    gradients accumulate in the shared pyramid-gradient buffers) vs the oracle's explicit formulation."""
+    B, H8, W8, C, M = 2, 10, 12, 256, 4
+    N = H8 * W8
+    x1 = O.layernorm_lastdim(rnd(B, N, C, seed=20))
+    x2 = O.layernorm_lastdim(rnd(B, N, C, seed=21) + 0.5 * x1)
+    W, b = rnd(C, C, seed=22) * math.sqrt(gain / C), rnd(C, seed=23) * 0.3
+    tab, wag = rnd(15, 15, seed=24) * 0.5, torch.tensor([[0.8]])
+    base = (x1, x2, W, b, tab, wag)
+    ld, lr = [_leaf(t, device) for t in base], [t.clone().requires_grad_(True) for t in base]
+    c0 = O.coords_grid(B, H8, W8)
+    coords = [c0, c0 + rnd(B, 2, H8, W8, seed=25) * 2.0, c0 + rnd(B, 2, H8, W8, seed=26) * torch.tensor([W8 / 2.0, H8 / 2.0]).view(1, 2, 1, 1)]
+    x1d, x2d, Wd, bd, tabd, wagd = ld
+    q, k = AG.Linear.apply(x1d, Wd, bd, PREC_F32), AG.Linear.apply(x2d, Wd, bd, PREC_F32)
+    scale = 1 / math.sqrt(C // M)
+    mx = ops.score_max(q.detach(), k.detach(), H8, W8, M, scale, PREC_F32)
+    box = []
+    token = AG.CorrVolume.apply(AG.Scores.apply(q, k, M, scale, PREC_F32), tabd, wagd, 0.5, mx, (H8, W8), box, True)
+    outs_d = [AG.CorrLookup.apply(token, ops.tokens_from_nchw(c.to(device)), box[0], 4) for c in coords]
+    x1r, x2r, Wr, br, tabr, wagr = lr
+    S = O.mm_scores(x1r, x2r, Wr, br, Wr, br, M)
+    if gain > 50:
+        assert float(S.max()) > 100
+    c = O.softaggr_scores(O.clamp_rule(S) + 0.5 * O.pos_bias_matrix(tabr, H8, W8), wagr)
+    mu, rstd = O.global_stats(c)
+    pyr = O.build_pyramid(c, H8, W8, 4)
+    outs_r = [O.corr_lookup(pyr, cc, 4, mu, rstd).reshape(B, 324, N).transpose(1, 2) for cc in coords]
+    # the pooling weight's gradient is ONE scalar summed over B*N*N*M terms of size ~|s|^2 with mixed signs: with clamped
+    # scores (|s| = 100) its fp32 rounding noise relative to the result is ~1e-3 in either implementation
+    _check_grads(outs_d, outs_r, ld, lr, tol=3e-4, names=["x1", "x2", "W", "b", "pos table", "w_aggr"],
+                 leaf_tol={"w_aggr": 5e-3} if gain > 50 else None)
+
+
+@pytest.mark.parametrize("prec", [PREC_F32, PREC_F16X3])
+@pytest.mark.parametrize("KH,KW,cin,cout,act", [(3, 3, 256, 192, ACT_RELU), (1, 5, 512, 256, ACT_NONE), (5, 1, 512, 128, ACT_NONE), (7, 7, 2, 128, ACT_RELU),
+                                                (3, 3, 256, 126, ACT_RELU), (3, 3, 256, 2, ACT_NONE), (3, 3, 128, 64, ACT_RELU)])
+def test_conv_backward(device, prec, KH, KW, cin, cout, act):
+    B, H8, W8 = 2, 9, 14
+    x = rnd(B, cin, H8, W8, seed=30)
+    w = rnd(cout, cin, KH, KW, seed=31) / math.sqrt(cin * KH * KW)
+    b = rnd(cout, seed=32) * 0.1
+    xt = x.permute(0, 2, 3, 1).reshape(B, H8 * W8, cin).contiguous()
+    ld, lr = [_leaf(t, device) for t in (xt, w, b)], [t.clone().requires_grad_(True) for t in (x, w, b)]
+    yd = AG.Conv.apply(ld[0], ld[1], ld[2], (H8, W8), act, prec)
+    yr = F.conv2d(lr[0], lr[1], lr[2], padding=(KH // 2, KW // 2))
+    yr = torch.relu(yr) if act == ACT_RELU else yr
+    yr_t = yr.permute(0, 2, 3, 1).reshape(B, H8 * W8, cout)
+    assert rel_err(yd, yr_t) < 3e-5
+    cot = rnd(B, H8 * W8, cout, seed=33)
+    yr_t.backward(cot)
+    yd.backward(cot.to(device))
+    assert rel_err(ld[0].grad, lr[0].grad.permute(0, 2, 3, 1).reshape(B, H8 * W8, cin)) < 5e-5, "dx"
+    assert rel_err(ld[1].grad, lr[1].grad) < 5e-5, "dw"
+    assert rel_err(ld[2].grad, lr[2].grad) < 5e-5, "db"
+
+
+def test_gru_gates_and_upsample_backward(device):
+    B, H8, W8, C = 2, 7, 9, 128
+    N = H8 * W8
+    base = (rnd(B, N, 2 * C, seed=40), rnd(B, N, C, seed=41), rnd(B, N, C, seed=42), rnd(B, N, 576, seed=43), rnd(B, N, 2, seed=44) * 3)
+    ld, lr = [_leaf(t, device) for t in base], [t.clone().requires_grad_(True) for t in base]
+    zr, h, qp, mask, flow = ld
+    z, rh = AG.GruZR.apply(zr, h)
+    hn = AG.GruOut.apply(qp + rh, z, h)
+    up = AG.ConvexUpsample.apply(mask, flow, (H8, W8))
+    zrr, hr, qpr, maskr, flowr = lr
+    zr_ = torch.sigmoid(zrr[..., :C]); rr = torch.sigmoid(zrr[..., C:])
+    hnr = (1 - zr_) * hr + zr_ * torch.tanh(qpr + rr * hr)
+    nchw = lambda t, c: t.transpose(1, 2).reshape(B, c, H8, W8)
+    upr = O.convex_upsample(nchw(flowr, 2), nchw(maskr, 576))
+    _check_grads([hn, up], [hnr, upr], ld, lr, names=["zr_pre", "h", "q_pre", "mask", "flow"])
+
+
+def test_dropout(device):
+    x = torch.ones(1 << 20, device=device).requires_grad_(True)
+    for p in (0.1, 0.2, 0.5):
+        y = AG.Dropout.apply(x, p, 1234)
+        keep = (y != 0).float().mean().item()
+        assert abs(keep - (1 - p)) < 3e-3, (p, keep)
+        assert abs(y.max().item() - 1 / (1 - p)) < 1e-6
+        y2 = AG.Dropout.apply(x, p, 1234)
+        assert torch.equal(y, y2)                                     # counter-based: same seed, same mask
+        assert not torch.equal(y, AG.Dropout.apply(x, p, 1235))
+        x.grad = None
+        y.backward(torch.full_like(y, 3.0))
+        assert torch.equal(x.grad != 0, y != 0) and abs(x.grad.max().item() - 3 / (1 - p)) < 1e-5   # same mask in the backward
+    assert AG.dropout(x, 0.0, 1) is x
+
+
+def test_sequence_loss_autograd(device):
+    z = np.load(os.path.join(GOLDEN_DIR, "harness.npz"))
+    preds = [torch.from_numpy(p).to(device).requires_grad_(True) for p in z["loss.preds"]]
+    loss, metrics = AG.sequence_loss(preds, torch.from_numpy(z["loss.gt"]), torch.from_numpy(z["loss.valid"]), 0.8, float(z["loss.max_flow"]))
+    (2.0 * loss).backward()
+    assert float(loss) == pytest.approx(float(z["loss.value"]), rel=2e-6)
+    for i, p in enumerate(preds):
+        assert np.allclose(p.grad.cpu().numpy(), 2.0 * z["loss.grads"][i], rtol=1e-6, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# 3. end to end against the reference's loss and parameter gradients
+# ------------------------------------------------------------------------------------------------------------------
+def grad_check_l2(z, key, g, l2_tol, elem_tol):
+    """Gradient `key` of a fixture against g: relative L2 error over the strided sample <= l2_tol and every sampled element within
+    elem_tol * (RMS of the gradient) + 2e-3 |ref|.  (The sample holds 4096 elements; the fp32 HIP step differs from the
+    reference's CPU step by summation order -- atomics, split-K, MIOpen's encoder backward -- which shows up as ~1e-3 relative
+    L2 and a few 1e-2 of the RMS on single small elements.)  Gradients that vanish mathematically only have to vanish."""
+    ref_v, ref_s = z[f"grad.{key}.v"], z[f"grad.{key}.s"]
+    a = g.detach().float().cpu().contiguous().numpy().reshape(-1)
+    assert tuple(z[f"grad.{key}.shape"]) == tuple(g.shape), key
+    rms = float(np.sqrt(ref_s[1] / a.size))
+    scale = grad_scale(z)
+    if rms < 1e-4 * scale:
+        assert float(np.sqrt((a.astype(np.float64) ** 2).mean())) < 1e-3 * scale, f"{key}: should vanish"
+        return 0.0
+    d = a[sample_idx(a.size)] - ref_v
+    l2 = float(np.linalg.norm(d) / max(np.linalg.norm(ref_v), 1e-30))
+    assert l2 <= l2_tol, f"{key}: relative L2 error {l2:.2e} > {l2_tol}"
+    worst = np.abs(d) - (elem_tol * rms + 2e-3 * np.abs(ref_v))
+    assert worst.max() <= 0, f"{key}: element {int(np.argmax(worst))} off by {np.abs(d).max():.3e} (rms {rms:.3e})"
+    return l2
+
+
+def _train_model(device, meta, precision="fp32"):
+    model = CRAFT(default_args(hip_precision=precision, dropout_prob=0.0))
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=meta["seed"], qk_gain=meta["qk_gain"]), strict=True)
+    model = model.to(device).train()
+    if meta["freeze_bn"]:
+        model.freeze_bn()
+    return model
+
+
+@pytest.mark.parametrize("precision", ["fp32", "mixed"])
+@pytest.mark.parametrize("case", TRAIN_CASES)
+def test_training_step_matches_reference_gradients(device, case, precision):
+    z = np.load(os.path.join(GOLDEN_DIR, case + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    model = _train_model(device, meta, precision)
+    im1 = torch.from_numpy(z["image1"].astype(np.float32)).to(device)
+    im2 = torch.from_numpy(z["image2"].astype(np.float32)).to(device)
+    preds = model(im1, im2, iters=meta["iters"])
+    assert isinstance(preds, list) and len(preds) == meta["iters"]
+    loss, metrics = AG.sequence_loss(preds, torch.from_numpy(z["flow_gt"]), torch.from_numpy(z["valid"]), meta["gamma"])
+    loss.backward()
+    tight = precision == "fp32"
+    assert float(loss) == pytest.approx(float(z["loss"]), rel=3e-5 if tight else 3e-4)
+    assert [metrics["epe"], metrics["1px"], metrics["3px"], metrics["5px"]] == pytest.approx(z["metrics"].tolist(), rel=1e-3, abs=1e-4)
+    unused = set(json.loads(str(z["unused"])))
+    seen, checked, worst = set(), 0, 0.0
+    for k, p in model.named_parameters():
+        if id(p) in seen or k.startswith("corr_fn.setrans.key."):
+            continue
+        seen.add(id(p))
+        if k in unused:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{k}: unused in the reference"
+            continue
+        if p.grad is None:
+            assert k.endswith("feat2score.bias") and z[f"grad.{k}.s"][1] < 1e-10, k      # cancels inside its softmax
+            checked += 1
+            continue
+        # a scalar parameter (pooling weight, skip coefficient) is one number: its "L2" is its own relative error
+        worst = max(worst, grad_check_l2(z, k, p.grad, l2_tol=(1e-2 if tight else 8e-2), elem_tol=(5e-2 if tight else 0.5)))
+        checked += 1
+    assert checked == 143
+    print(f"[train parity] {case} {precision}: loss {float(loss):.6f} (reference {float(z['loss']):.6f}), worst relative L2 gradient error {worst:.2e}")
+    for k in [f for f in z.files if f.startswith("bn.")]:
+        got = model.state_dict()[k[3:]].cpu().numpy()
+        assert np.allclose(got, z[k], rtol=1e-3, atol=1e-5), k
+
+
+def test_train_mode_rejects_other_configs_and_sizes(device):
+    model = CRAFT(default_args(hip_precision="fp32")).to(device).train()
+    with pytest.raises(ValueError, match="multiple of 4"):
+        model(torch.zeros(1, 3, 136, 200, device=device), torch.zeros(1, 3, 136, 200, device=device), iters=1)
+    gma = CRAFT(default_args(use_setrans=False)).to(device).train()
+    with pytest.raises(NotImplementedError):
+        gma(torch.zeros(1, 3, 128, 128, device=device), torch.zeros(1, 3, 128, 128, device=device), iters=1)
