@@ -1,11 +1,12 @@
 """Training-step pieces around the hot path.
 
-What exists: the loss (``sequence_loss``, train.py:44-73) with its gradient w.r.t. the predictions, the OneCycle schedule
-of ``fetch_optimizer`` (train.py:76-85), a fused AdamW with global-norm clipping over ONE flat parameter / gradient buffer
+The loss (``sequence_loss``, train.py:44-73) with its gradient w.r.t. the predictions, the OneCycle schedule of
+``fetch_optimizer`` (train.py:76-85), a fused AdamW with global-norm clipping over ONE flat parameter / gradient buffer
 (train.py:234 + torch.optim.AdamW semantics), the gradient exchange of train_ddp.py (one all-reduce of that flat buffer per
-step: RCCL over xGMI under the "nccl" backend, gloo in the CPU tests), and checkpoint save / resume in the reference's
-layout (train.py:132-175).  What does NOT exist yet: the backward kernels of the model itself -- so the gradients these
-pieces consume are whatever the caller provides, and ``CRAFT.forward`` still refuses to run in training mode.
+step: RCCL over xGMI under the "nccl" backend, gloo in the tests), checkpoint save / resume in the reference's layout
+(train.py:132-175), and ``Trainer.step`` = one iteration of train.py:215-236 / train_ddp.py:230-262: zero_grad -> forward
+(model.train(): craft_amd/train_forward.py) -> sequence_loss -> backward (HIP kernels, craft_amd/autograd.py) -> all-reduce ->
+clip -> AdamW -> scheduler.
 """
 from __future__ import annotations
 
@@ -98,8 +99,12 @@ class FlatAdamW:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 1e-2):
+                 weight_decay: float = 1e-2, unused: Iterable[torch.nn.Parameter] = ()):
+        """``unused``: parameters that never receive a gradient (the reference's DDP runs with find_unused_parameters=True,
+        train_ddp.py:196-198; their .grad stays None there, so torch.optim.AdamW skips them entirely -- no weight decay, no
+        state).  They stay in the flat buffers (index layout of model.parameters()) but the update kernel skips their ranges."""
         self.params = list(params)
+        unused_ids = {id(p) for p in unused}
         if not self.params:
             raise ValueError("FlatAdamW: no parameters")
         if any(not p.requires_grad for p in self.params):
@@ -107,18 +112,33 @@ class FlatAdamW:
             # shift every later index, and the reference trainers freeze nothing
             raise ValueError("FlatAdamW: every parameter must require grad (state-dict indices follow model.parameters())")
         dev = self.params[0].device
-        self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.empty(self.numel, device=dev, dtype=torch.float32)
+        # every parameter starts on a 128-byte boundary of the flat buffers (the kernels read weights with 16-byte vector
+        # loads; the padding elements stay zero: zero gradient, zero value, no effect on the norm or the update)
+        ALIGN = 32
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.numel = off                                   # elements of the flat buffers (padding included)
+        self.n_params = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, device=dev, dtype=torch.float32)
         self.flat_grad = torch.zeros(self.numel, device=dev, dtype=torch.float32)
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
-        off = 0
-        for p in self.params:
+        self.unused_index, segs, start = [], [], 0
+        for i, (p, off) in enumerate(zip(self.params, self.offsets)):
             n = p.numel()
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view_as(p.data)
             p.grad = self.flat_grad[off:off + n].view_as(p.data)
-            off += n
+            if id(p) in unused_ids:
+                self.unused_index.append(i)
+                if off > start:
+                    segs.append((start, off))
+                start = off + n
+        if self.numel > start:
+            segs.append((start, self.numel))
+        self.segments = segs                     # [begin, end) ranges of the flat buffers that the optimizer updates
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         self._sumsq = torch.zeros((), device=dev, dtype=torch.float64)
@@ -132,7 +152,13 @@ class FlatAdamW:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return 1.0
-        dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
+        if dist.get_backend(group) == "gloo" and self.flat_grad.is_cuda:
+            # test configuration (several ranks sharing one GPU over gloo): stage through the host; RCCL ("nccl") reduces in place
+            host = self.flat_grad.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            self.flat_grad.copy_(host)
+        else:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
         return 1.0 / dist.get_world_size(group)
 
     def step(self, lr: Optional[float] = None, max_norm: float = 0.0, grad_mul: float = 1.0):
@@ -144,9 +170,10 @@ class FlatAdamW:
             self._sumsq.zero_()
             call("craft_sumsq", self.flat_grad, self.numel, self._sumsq)
             sumsq = self._sumsq
-        call("craft_adamw_step", self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.numel,
-             float(self.lr if lr is None else lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-             float(self.weight_decay), self.step_count, float(grad_mul), sumsq, float(max_norm))
+        for a, b in self.segments:
+            call("craft_adamw_step", self.flat[a:b], self.flat_grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], b - a,
+                 float(self.lr if lr is None else lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                 float(self.weight_decay), self.step_count, float(grad_mul), sumsq, float(max_norm))
         # the kernel wrote through raw pointers: p._version / data_ptr() did not move, so tell the packed-weight caches
         from .hip import bump_weights_epoch
         bump_weights_epoch()
@@ -154,49 +181,117 @@ class FlatAdamW:
     def _check_views(self):
         """model.zero_grad(set_to_none=True), model.to(...) or p.grad = ... silently detach parameters / gradients from the
         flat buffers; the fused kernel would then update stale memory.  Cheap host check (145 pointer compares)."""
-        off = 0
-        for p in self.params:
-            n = p.numel()
+        for p, off in zip(self.params, self.offsets):
             if p.data_ptr() != self.flat.data_ptr() + 4 * off:
                 raise RuntimeError("FlatAdamW: a parameter no longer lives in the flat buffer (model.to() / load with "
                                    "assign=True after the optimizer was built?)")
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
                 raise RuntimeError("FlatAdamW: a .grad no longer aliases the flat gradient buffer "
                                    "(use optimizer.zero_grad(), not model.zero_grad(set_to_none=True))")
-            off += n
 
     # ---- torch.optim.AdamW-compatible state (the 'optimizer' entry of the reference's checkpoints, train.py:139)
     def state_dict(self) -> Dict:
-        state, off = {}, 0
-        for i, p in enumerate(self.params):
+        state = {}
+        for i, (p, off) in enumerate(zip(self.params, self.offsets)):
             n = p.numel()
+            if i in self.unused_index:          # torch.optim.AdamW keeps no state for a parameter without a gradient
+                continue
             state[i] = {"step": torch.tensor(float(self.step_count)),
                         "exp_avg": self.exp_avg[off:off + n].view_as(p.data).clone(),
                         "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p.data).clone()}
-            off += n
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
                  "params": list(range(len(self.params)))}
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd: Dict):
-        off = 0
-        for i, p in enumerate(self.params):
+        for i, (p, off) in enumerate(zip(self.params, self.offsets)):
             n = p.numel()
             st = sd["state"].get(i)
             if st is not None:
                 self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
                 self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
                 self.step_count = int(float(st["step"]))
-            off += n
         g = sd["param_groups"][0]
         self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+
+
+def unused_parameters(model: torch.nn.Module) -> List[torch.nn.Parameter]:
+    """Parameters that exist for state-dict parity but never enter the forward pass: the attn_softaggr of an attention that
+    returns probabilities (the intra-frame attention ``att``: setrans.py:455-458 creates it whenever num_modes > 1, the
+    out_attn_probs_only branch never calls it).  The reference capture (tests/golden/train_*.npz 'unused') lists the same."""
+    out = []
+    att = getattr(model, "att", None)
+    st = getattr(att, "setrans", None)
+    if st is not None and getattr(st, "out_attn_probs_only", False) and hasattr(st, "attn_softaggr"):
+        out += list(st.attn_softaggr.parameters())
+    return out
 
 
 def fetch_optimizer(model: torch.nn.Module, lr: float, wdecay: float, epsilon: float, num_steps: int):
     """train.py:76-85: AdamW(lr, weight_decay, eps) + OneCycleLR(max_lr=lr, total_steps=num_steps+100, pct_start=0.05,
     linear anneal, no momentum cycling)."""
-    opt = FlatAdamW(model.parameters(), lr=lr, weight_decay=wdecay, eps=epsilon)
+    opt = FlatAdamW(model.parameters(), lr=lr, weight_decay=wdecay, eps=epsilon, unused=unused_parameters(model))
     return opt, OneCycleLR(lr, num_steps + 100, pct_start=0.05)
+
+
+class Trainer:
+    """One process of train.py / train_ddp.py around a ``craft_amd.CRAFT`` on one GPU.
+
+    ``step`` = train.py:215-236: optional input noise (:220-223), ``optimizer.zero_grad()``, forward in training mode, the
+    sequence loss, backward, gradient clipping at ``clip``, AdamW, OneCycle.  Data-parallel (train_ddp.py:187-200): every rank
+    holds a full replica and its own pairs; the ONLY data-path collective is one all-reduce (sum) of the flat 25 MB gradient
+    buffer per step -- RCCL over xGMI with the "nccl" backend -- folded into the update as a 1/world factor (DDP's gradient
+    averaging), plus a 2-double all-reduce for the logged loss / EPE.  ``reference_loss_scaling``: train_ddp.py:60,84-88
+    back-propagates the all-reduced loss divided by the world size, so its gradients carry a second 1/world on top of DDP's
+    average; True reproduces that, False (default) is the plain data-parallel mean."""
+
+    def __init__(self, model: torch.nn.Module, lr: float = 4e-4, wdecay: float = 1e-4, epsilon: float = 1e-8, num_steps: int = 100000,
+                 clip: float = 1.0, gamma: float = 0.8, iters: int = 12, add_noise: bool = False, freeze_bn: bool = False, group=None,
+                 reference_loss_scaling: bool = False):
+        self.model = model
+        self.optimizer, self.scheduler = fetch_optimizer(model, lr, wdecay, epsilon, num_steps)
+        self.clip, self.gamma, self.iters, self.add_noise, self.freeze_bn, self.group = clip, gamma, iters, add_noise, freeze_bn, group
+        self.reference_loss_scaling = reference_loss_scaling
+        self.total_steps = 0
+        model.train()
+        if freeze_bn:
+            model.freeze_bn()
+
+    def _world(self) -> int:
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def step(self, image1, image2, flow, valid) -> Dict[str, float]:
+        from .autograd import sequence_loss as seq_loss
+        model, opt = self.model, self.optimizer
+        dev = next(model.parameters()).device
+        image1, image2 = image1.to(dev).float(), image2.to(dev).float()
+        if self.add_noise:                                             # train.py:220-223
+            stdv = float(torch.empty(1).uniform_(0.0, 5.0))
+            image1 = (image1 + stdv * torch.randn_like(image1)).clamp(0.0, 255.0)
+            image2 = (image2 + stdv * torch.randn_like(image2)).clamp(0.0, 255.0)
+        if not model.training:
+            model.train()
+            if self.freeze_bn:
+                model.freeze_bn()
+        opt.zero_grad()
+        preds = model(image1, image2, iters=self.iters)
+        loss, metrics = seq_loss(preds, flow, valid, self.gamma)
+        loss.backward()
+        mul = opt.allreduce_grads(self.group)                          # ONE collective over the flat gradient buffer
+        if self.reference_loss_scaling:
+            mul = mul / self._world()
+        opt.step(lr=self.scheduler.get_last_lr()[0], max_norm=self.clip, grad_mul=mul)
+        self.scheduler.step()
+        self.total_steps += 1
+        metrics = dict(metrics, loss=float(loss.detach()))
+        if self._world() > 1:                                          # logged numbers: mean over ranks (train_ddp.py:84-94)
+            import torch.distributed as dist
+            backend = dist.get_backend(self.group)
+            t = torch.tensor([metrics["loss"], metrics["epe"]], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, group=self.group)
+            metrics["loss"], metrics["epe"] = float(t[0]) / self._world(), float(t[1]) / self._world()
+        return metrics
 
 
 # ------------------------------------------------------------------------------------------------
@@ -222,13 +317,11 @@ def load_checkpoint(path: str, model: torch.nn.Module, optimizer: Optional[FlatA
     ck = read_checkpoint(path, trusted=trusted)
     msg = load_model(model, ck)
     if optimizer is not None:                      # load_state_dict re-pointed nothing: the flat views stay valid, but refresh
-        off = 0                                    # the flat copy in case a parameter was replaced rather than copied into
-        for p in optimizer.params:
+        for p, off in zip(optimizer.params, optimizer.offsets):      # the flat copy in case a parameter was replaced
             n = p.numel()
             if p.data.data_ptr() != optimizer.flat[off:off + n].data_ptr():
                 optimizer.flat[off:off + n].copy_(p.data.reshape(-1))
                 p.data = optimizer.flat[off:off + n].view_as(p.data)
-            off += n
     if load_optimizer_state and optimizer is not None and isinstance(ck, dict) and "optimizer" in ck:
         optimizer.load_state_dict(ck["optimizer"])
     logger = None

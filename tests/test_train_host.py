@@ -38,13 +38,12 @@ def test_flat_views_and_state_layout():
     net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Linear(5, 2))
     before = [p.detach().clone() for p in net.parameters()]
     opt = FlatAdamW(net.parameters(), lr=1e-3, weight_decay=1e-4, eps=1e-8)
-    assert opt.numel == sum(p.numel() for p in net.parameters())
-    off = 0
-    for p, b in zip(net.parameters(), before):
+    assert opt.n_params == sum(p.numel() for p in net.parameters()) and opt.n_params <= opt.numel < opt.n_params + 32 * 4
+    for p, b, off in zip(net.parameters(), before, opt.offsets):
+        assert off % 32 == 0                                                     # 128-byte aligned starts (16-byte vector loads)
         assert torch.equal(p.detach(), b)                                       # values survive the re-pointing
         assert p.data.data_ptr() == opt.flat[off:].data_ptr()                   # parameters are views of the flat buffer
         assert p.grad.data_ptr() == opt.flat_grad[off:].data_ptr()              # and so are their gradients
-        off += p.numel()
     # autograd accumulates straight into the flat gradient buffer
     net(torch.randn(1, 3, 7, 7)).sum().backward()
     assert opt.flat_grad.abs().sum() > 0

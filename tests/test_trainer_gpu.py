@@ -1,0 +1,153 @@
+"""The training step as a whole on the GPU: Trainer.step = forward (model.train()) -> sequence loss ->
+HIP backward -> ONE all-reduce of the flat gradient -> clip -> fused AdamW -> OneCycle.
+
+* weights really move and the inference path sees them (packed-weight caches are invalidated: ADVICE r1);
+* parameters the reference never touches (find_unused_parameters) are not decayed and carry no optimizer state;
+* against torch.optim.AdamW + clip_grad_norm_ fed with the same gradients;
+* data parallel: two ranks (gloo, sharing the one GPU of the box; the driver's 8-GPU runs use RCCL) with one pair each end
+  up with exactly the parameters of one process that trains on both pairs."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+import torch
+
+from craft_amd import CRAFT, default_args
+from craft_amd.synth import synth_pair, synth_state_dict
+from craft_amd.train import Trainer, unused_parameters
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(device, seed=1234, **over):
+    model = CRAFT(default_args(hip_precision="fp32", dropout_prob=0.0, **over))
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=seed), strict=True)
+    return model.to(device)
+
+
+def _batch(B, H, W, seed):
+    im1, im2, flow = synth_pair(B, H, W, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    valid = (torch.rand(B, H, W, generator=g) > 0.1).float()
+    return im1, im2, flow, valid
+
+
+def test_steps_move_weights_and_inference_sees_them(device):
+    model = _model(device)
+    tr = Trainer(model, lr=2e-4, num_steps=50, iters=3, clip=1.0)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    im1, im2, flow, valid = _batch(2, 128, 192, 3)
+    model.eval()
+    with torch.no_grad():
+        up_before = model(im1.to(device), im2.to(device), iters=3, test_mode=1)[1].clone()     # packs weights into the caches
+    losses = [tr.step(im1, im2, flow, valid)["loss"] for _ in range(4)]
+    assert all(l == l and l < 1e4 for l in losses), losses
+    assert losses[-1] < losses[0], f"four steps on one batch should reduce its loss: {losses}"
+    moved = [k for k, v in model.state_dict().items() if v.dtype.is_floating_point and not torch.equal(v, before[k])]
+    assert len(moved) > 170                       # (conv biases in front of a normalisation layer have a zero gradient)
+    # inference after training: same result as a fresh model that loads the trained weights (no stale packed copies)
+    model.eval()
+    fresh = CRAFT(default_args(hip_precision="fp32"))
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}, strict=True)
+    fresh = fresh.to(device).eval()
+    with torch.no_grad():
+        a = model(im1.to(device), im2.to(device), iters=3, test_mode=1)[1]
+        b = fresh(im1.to(device), im2.to(device), iters=3, test_mode=1)[1]
+    assert (a - b).abs().max().item() < 1e-4
+    assert (a - up_before).abs().max().item() > 1e-3, "training did not change the prediction"
+
+
+def test_unused_parameters_are_skipped_like_torch_adamw(device):
+    model = _model(device)
+    un = unused_parameters(model)
+    assert len(un) == 2
+    snap = [p.detach().clone() for p in un]
+    tr = Trainer(model, lr=1e-3, wdecay=0.1, num_steps=20, iters=2)
+    im1, im2, flow, valid = _batch(1, 128, 128, 5)
+    tr.step(im1, im2, flow, valid)
+    tr.step(im1, im2, flow, valid)
+    for p, s in zip(un, snap):
+        assert torch.equal(p.detach(), s), "a parameter without gradient was decayed"
+    sd = tr.optimizer.state_dict()
+    idx = {i for i, p in enumerate(model.parameters()) if any(p is u for u in un)}
+    assert idx and not (idx & set(sd["state"].keys())) and len(sd["state"]) == len(list(model.parameters())) - len(idx)
+
+
+def test_step_matches_torch_adamw_on_the_same_gradients(device):
+    """One Trainer.step vs torch.optim.AdamW + clip_grad_norm_ applied to a copy of the model with the gradients our backward
+    produced (isolates clip + optimizer + scheduler from the backward, which test_train_backward.py pins to the reference)."""
+    model = _model(device)
+    ref = _model(device)
+    tr = Trainer(model, lr=3e-4, wdecay=1e-4, epsilon=1e-8, num_steps=100, iters=2, clip=0.5)
+    im1, im2, flow, valid = _batch(2, 128, 160, 7)
+    lr0 = tr.scheduler.get_last_lr()[0]
+    tr.step(im1, im2, flow, valid)
+    un = {id(p) for p in unused_parameters(ref)}
+    params = [p for p in ref.parameters() if id(p) not in un]
+    opt = torch.optim.AdamW(params, lr=lr0, weight_decay=1e-4, eps=1e-8)
+    for p, g in zip(ref.parameters(), [q.grad for q in model.parameters()]):
+        p.grad = g.detach().clone()
+    torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+    opt.step()
+    for (k, a), b in zip(model.named_parameters(), ref.parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), k
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    from craft_amd import CRAFT, default_args
+    from craft_amd.synth import synth_pair, synth_state_dict
+    from craft_amd.train import Trainer
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    if world > 1:
+        dist.init_process_group("gloo", init_method="env://")
+    dev = torch.device("cuda:0")
+    model = CRAFT(default_args(hip_precision="fp32", dropout_prob=0.0))
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=1234), strict=True)
+    model = model.to(dev)
+    tr = Trainer(model, lr=2e-4, num_steps=50, iters=2, clip=1.0, freeze_bn=True)
+    im1, im2, flow = synth_pair(2, 128, 160, seed=9)
+    valid = torch.ones(2, 128, 160)
+    sl = slice(rank, rank + 1) if world > 1 else slice(0, 2)
+    m = tr.step(im1[sl], im2[sl], flow[sl], valid[sl])
+    grad = (tr.optimizer.flat_grad / world).cpu()            # the all-reduced (summed) gradient, averaged
+    m = tr.step(im1[sl], im2[sl], flow[sl], valid[sl])
+    if rank == 0:
+        torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "loss": m["loss"], "grad": grad}, sys.argv[1])
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+""")
+
+
+def test_two_rank_data_parallel_equals_one_process_on_both_pairs(device, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", port, str(script), str(tmp_path / "dp.pt")], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([sys.executable, str(script), str(tmp_path / "single.pt")], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    dp, single = torch.load(tmp_path / "dp.pt"), torch.load(tmp_path / "single.pt")
+    assert abs(dp["loss"] - single["loss"]) < 1e-4 * abs(single["loss"])
+    rel = ((dp["grad"] - single["grad"]).norm() / single["grad"].norm()).item()
+    assert rel < 2e-3, f"averaged data-parallel gradient differs from the two-pair gradient: relative L2 {rel:.2e}"
+    worst = 0.0
+    for k, v in single["sd"].items():
+        if v.dtype.is_floating_point:
+            worst = max(worst, (dp["sd"][k] - v).abs().max().item())
+    # (AdamW's first steps move every weight by ~lr regardless of the gradient's size, so rounding-level gradient differences
+    # between the two reduction orders can flip tiny updates: bound = a fraction of lr)
+    assert worst < 2e-4, f"data-parallel and single-process parameters differ by {worst:.2e}"
