@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0: min(32, logical CPUs))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ops", action="store_true", help="also print a per-operator timing table to stderr")
+    ap.add_argument("--train", type=int, default=0, choices=[0, 3, 4],
+                    help="3 / 4: time the TRAINING step of BASELINE.json configs[3] (FlyingChairs 368x496, batch 8/GPU) / configs[4] "
+                         "(Sintel 368x768 crops, batch 4/GPU, bf16 MFMA attention) instead of the inference headline: forward + "
+                         "HIP backward + one RCCL gradient all-reduce + clip + fused AdamW per step")
     return ap.parse_args()
 
 
@@ -203,6 +207,57 @@ def self_launch(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def train_bench(a, rank, world, dev, dist):
+    """BASELINE.json configs[3] / configs[4]: whole training steps (train.py:215-236 / train_ddp.py:230-262) on synthetic
+    pairs resident in HBM.  One rank per GPU, full replica, its own pairs; the one data-path collective is the all-reduce of
+    the flat gradient buffer (RCCL over xGMI)."""
+    from craft_amd import CRAFT, default_args
+    from craft_amd.dist import aggregate_throughput, timed_steps
+    from craft_amd.synth import synth_pair, synth_state_dict
+    from craft_amd.train import Trainer
+    H, W, B, policy, name = {3: (368, 496, 8, "train_f16x3", "configs[3]: FlyingChairs-size 368x496, batch 8/GPU"),
+                             4: (368, 768, 4, "train_bf16attn", "configs[4]: Sintel-crop 368x768, batch 4/GPU, bf16 MFMA attention")}[a.train]
+    argv = " ".join(sys.argv[1:])
+    if "--batch" in argv:
+        B = a.batch
+    if "--height" in argv:
+        H = a.height
+    if "--width" in argv:
+        W = a.width
+    if "--precision" in argv:
+        policy = a.precision
+    model = CRAFT(default_args(hip_precision=policy))
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=1234), strict=True)
+    model = model.to(dev)
+    tr = Trainer(model, lr=4e-4 if a.train == 3 else 1.25e-4, wdecay=1e-4 if a.train == 3 else 1e-5, num_steps=100000, iters=a.iters,
+                 clip=1.0, freeze_bn=a.train != 3)
+    im1, im2, flow = synth_pair(B, H, W, seed=100 + rank)
+    im1, im2, flow = im1.to(dev), im2.to(dev), flow.to(dev)
+    valid = torch.ones(B, H, W, device=dev)
+    last = {}
+
+    def step():
+        last["m"] = tr.step(im1, im2, flow, valid)
+
+    dt_rank = timed_steps(step, steps=a.steps, warmup=a.warmup, sync=torch.cuda.synchronize)
+    value, dt = aggregate_throughput(pairs_per_rank_step=B, steps=a.steps, dt=dt_rank)
+    assert last["m"]["loss"] == last["m"]["loss"]
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"training image-pairs/sec at {H}x{W}, {a.iters} iters (forward + backward + gradient all-reduce + AdamW)",
+            "value": round(value, 3), "unit": "image-pairs/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": policy + " (fp32 activations / probabilities in HBM; MFMA operand mode per role, fp32 accumulate)", "data": "synthetic",
+            "config": {"workload": name + f", {a.iters} iters, model.train(): dropout 0.1 / 0.2, "
+                                          + ("BatchNorm batch statistics" if a.train == 3 else "frozen BatchNorm")
+                                          + ", synthetic weights and pairs", "global_batch": B * world,
+                       "parallelism": f"dp{world} (one all-reduce of the {tr.optimizer.numel * 4 / 1e6:.1f} MB flat gradient per step)"},
+            "loss": round(last["m"]["loss"], 4), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)}), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     if not torch.cuda.is_available():
@@ -236,6 +291,8 @@ def main():
     from craft_amd.hip import Precision
     from craft_amd.synth import synth_pair, synth_state_dict
 
+    if a.train:
+        return train_bench(a, rank, world, dev, dist)
     prec = Precision.parse(a.precision)
     model = CRAFT(default_args(hip_precision=a.precision))
     model.load_state_dict(synth_state_dict(model.state_dict(), seed=1234), strict=True)

@@ -92,7 +92,12 @@ _SIGS = {
 # plain fp16 storage + fp16 MFMA for the attention probabilities (P V); measured mean end-point deviation from the fp32
 # path < 1e-3 px at 448x1024 / 12 iters.  "mixed_fp32conv": fp16 attention contractions + exact
 # fp32 MFMA convolutions.
-NAMED_POLICIES = {"mixed": "proj=f16x3,score=f16x3,pv=fp16,conv=f16x3", "mixed_fp32conv": "proj=fp16,score=fp16,pv=fp16,conv=fp32"}
+NAMED_POLICIES = {"mixed": "proj=f16x3,score=f16x3,pv=fp16,conv=f16x3", "mixed_fp32conv": "proj=fp16,score=fp16,pv=fp16,conv=fp32",
+                  # training (activations and probabilities stay fp32 in memory; the roles select the MFMA operand mode of the
+                  # forward AND backward contractions): everything fp32-class / bf16 MFMA for the cross- and self-attention
+                  # contractions (BASELINE.json configs[4]: "bf16 MFMA cross-attention")
+                  "train_f16x3": "proj=f16x3,score=f16x3,pv=f16x3,conv=f16x3",
+                  "train_bf16attn": "proj=f16x3,score=bf16,pv=bf16,conv=f16x3"}
 
 
 class CraftHipError(RuntimeError):
@@ -137,7 +142,7 @@ class Precision:
         spec = NAMED_POLICIES.get(spec.strip(), spec.strip())
         if "=" not in spec:
             v = PREC_NAMES[spec]
-            return Precision(v, v, PREC_F16 if v == PREC_F16X3 else v, v)
+            return Precision(v, v, PREC_F16 if v == PREC_F16X3 else v, v)      # (inference stores P in the pv type: fp16 here)
         p = Precision()
         seen = set()
         for item in spec.split(","):
@@ -148,8 +153,6 @@ class Precision:
             seen.add(k.strip())
         if "enc" not in seen:
             p.enc = p.conv
-        if p.pv == PREC_F16X3:
-            raise ValueError("pv (the storage type of the attention probabilities) must be fp32, bf16 or fp16")
         return p
 
     def __repr__(self):

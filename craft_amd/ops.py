@@ -207,6 +207,9 @@ def attn_probs(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale
     ``relpos = (Hs [B, M, N, 2*H8-1], Ws [B, M, N, 2*W8-1], weight)``: per-query relative-position scores (gma.RelPosEmb)."""
     B, N, C = q.shape
     ldp = round_up(N, 32)
+    if pick(prec, "pv") not in PROB_DTYPE:
+        raise hip.CraftHipError("inference stores the attention probabilities in the pv type: fp32, bf16 or fp16 (f16x3 is a "
+                                "training-only pv mode)")
     if out is None:
         out = torch.empty(B, M, N, ldp, device=q.device, dtype=PROB_DTYPE[pick(prec, "pv")])
     R = 0 if pos_tab is None else (pos_tab.shape[0] - 1) // 2
