@@ -212,7 +212,8 @@ int craft_motion_encoder(const float* corr, long ldc, int cor_planes, const floa
     TRY(launch_gemm_conv(q, prec, s));
   }
   // flo = relu(convf1(flow))  7x7, 2 -> 128   (update.py:82)
-  TRY(launch_convf1(flow, wf1, bf1, B, H8, W8, flo1, 128, sf));
+  if (pk && prec != CRAFT_PREC_F32) TRY(launch_convf1_mfma(flow, wf1, bf1, B, H8, W8, flo1, 128, prec, sf));
+  else TRY(launch_convf1(flow, wf1, bf1, B, H8, W8, flo1, 128, sf));
   // flo = relu(convf2(flo))  3x3, 128 -> 64   (update.py:83) -> columns 192..255 of corflo (the torch.cat of :85)
   {
     ConvGemmParams q = conv_params(flo1, 128, 128, nullptr, 0, 0, B, H8, W8, 3, 3, wf2, bf2, 64, CONV_EPI_BIAS_ACT,

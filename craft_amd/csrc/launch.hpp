@@ -116,6 +116,8 @@ int launch_corr_lookup(const float* l0, const float* l1, const float* l2, const 
                        hipStream_t s);
 int launch_convf1(const float* flow, const float* w, const float* bias, int B, int H8, int W8, float* out, long ldo,
                   hipStream_t s);
+int launch_convf1_mfma(const float* flow, const void* w_packed, const float* bias, int B, int H8, int W8, float* out, long ldo, int prec,
+                       hipStream_t s);
 int launch_flow_head2(const float* hid, const float* w, const float* bias, int B, int H8, int W8, float* coords1,
                       const float* coords0, float* flow, float* delta, hipStream_t s);
 int launch_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, hipStream_t s);

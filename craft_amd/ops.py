@@ -352,3 +352,16 @@ def pack_conv_prec(w: torch.Tensor, prec: int) -> torch.Tensor:
 def pack_convf1(w: torch.Tensor) -> torch.Tensor:
     """[128, 2, 7, 7] -> [7*7*2, 128] (tap-major, output channel contiguous)."""
     return w.detach().permute(2, 3, 1, 0).reshape(-1, w.shape[0]).contiguous().float()
+
+
+def pack_convf1_mfma(w: torch.Tensor, prec: int) -> torch.Tensor:
+    """[128, 2, 7, 7] -> the matrix-core operand of convf1: rows = output channels, k = ky*16 + kx*2 + c (kx = 7 and k >= 112
+    zero), K = 128, in craft_pack_weights' fragment order for ``prec`` (bf16 / fp16 / f16x3)."""
+    co = w.shape[0]
+    m = torch.zeros(co, 7, 8, 2, device=w.device, dtype=torch.float32)
+    m[:, :, :7, :] = w.detach().float().permute(0, 2, 3, 1)
+    m = torch.cat([m.reshape(co, 112), torch.zeros(co, 16, device=w.device)], dim=1).contiguous()
+    planes = 2 if prec == hip.PREC_F16X3 else 1
+    out = torch.empty(planes * round_up(co, 32) * 128, device=w.device, dtype=torch.bfloat16 if prec == hip.PREC_BF16 else torch.float16)
+    call("craft_pack_weights", m, co, 128, prec, out)
+    return out

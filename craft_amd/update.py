@@ -143,7 +143,8 @@ class BasicMotionEncoder(nn.Module):
             return m.bias.detach().float().contiguous()
         return self._pk.get(params, lambda: (self.convc1.weight.detach().view(256, -1).float().contiguous(), b(self.convc1),
                                              ops.pack_conv_prec(self.convc2.weight, prec), b(self.convc2),
-                                             ops.pack_convf1(self.convf1.weight), b(self.convf1),
+                                             ops.pack_convf1(self.convf1.weight) if prec == PREC_F32 else ops.pack_convf1_mfma(self.convf1.weight, prec),
+                                             b(self.convf1),
                                              ops.pack_conv_prec(self.convf2.weight, prec), b(self.convf2),
                                              ops.pack_conv_prec(self.conv.weight, prec), b(self.conv)), tag=prec)
 

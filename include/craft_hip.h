@@ -206,8 +206,10 @@ int craft_residual_relu(const float* x, long ldx, const float* xnorm, const floa
 
 /* BasicMotionEncoder.forward (update.py:79-87).  corr tokens [B*N][cor_planes] (row stride ldc), flow tokens
  * [B*N][2].  Conv weights are packed [Cout][KH][KW][Cin] (weight.permute(0,2,3,1)); wf1 is packed
- * [7*7*2][128] (weight.permute(2,3,1,0)).  Output: 128 channels (126 conv + 2 flow) at out (row stride ldo).
- * ws: 640 floats per pixel.
+ * [7*7*2][128] (weight.permute(2,3,1,0)) -- or, with CRAFT_W_PACKED and a 16-bit / F16X3 precision, craft_pack_weights(rows 128,
+ * K 128, prec) of the matrix re-ordered to k = ky*16 + kx*2 + c (kx = 7 and k >= 112 zero), which runs the layer on the matrix
+ * cores (a k-group of 8 is then one run of 8 consecutive floats of a flow-patch row).  Output: 128 channels (126 conv + 2 flow)
+ * at out (row stride ldo).  ws: 640 floats per pixel.
  * flow_stream / flow_done (both NULL: everything runs in order on `stream`): a caller-owned hipStream_t and hipEvent_t.  The
  * flow branch (convf1 -> convf2) is independent of the correlation branch (convc1 -> convc2) until the last convolution, so
  * it is enqueued on flow_stream, flow_done is recorded behind it and `stream` waits for that event before the last
