@@ -265,6 +265,78 @@ class AttnApply(Function):
         return dP, dv, None
 
 
+class SharedProbs:
+    """Attention probabilities that several AttnApplyShared calls consume (the intra-frame attention: computed once, applied in
+    every refinement iteration, network.py:214 / update.py:143-149) and what their backward passes leave behind for the ONE
+    gradient product of P."""
+
+    def __init__(self, P: torch.Tensor):
+        self.P = P.detach()
+        self.pending: List = []            # (dO_t [B, M, N, C], v_t [B, N, M*C]) of every use, in backward order
+
+
+class ProbsToken(Function):
+    """P -> a one-element handle.  Every AttnApplyShared takes the handle as an input, so this backward runs after all of them.
+    dP = sum_t dO_t V_t^T is then ONE product with the T uses concatenated along K ([dO_1 .. dO_T] . [V_1 .. V_T]^T, K = T*C):
+    the 1 GB gradient of P is written once instead of being produced, zero-filled and accumulated T times."""
+
+    @staticmethod
+    def forward(ctx, P, box, prec):
+        holder = SharedProbs(P)
+        box.append(holder)
+        ctx.holder, ctx.prec = holder, pick(prec, "pv")
+        return torch.zeros(1, device=P.device, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, _dtoken):
+        holder = ctx.holder
+        P = holder.P
+        B, M, N, ld = P.shape
+        dP = torch.zeros(B, M, N, ld, device=P.device, dtype=torch.float32) if ld != N else torch.empty_like(P)
+        if holder.pending:
+            T = len(holder.pending)
+            C = holder.pending[0][0].shape[-1]
+            dO = torch.cat([d for d, _ in holder.pending], dim=-1)                                   # [B, M, N, T*C]
+            V = torch.cat([v.view(B, N, M, C).permute(0, 2, 1, 3) for _, v in holder.pending], dim=-1)   # [B, M, N, T*C]
+            K = T * C
+            gemm(dO, K, 1, M * N * K, N * K, V, K, 1, M * N * K, N * K, dP, ld, M * N * ld, N * ld, M, B * M, N, N, K, prec=ctx.prec)
+            holder.pending = []
+        elif ld == N:
+            dP.zero_()
+        return dP, None, None
+
+
+class AttnApplyShared(Function):
+    """O[b][m] = P[b][m] V_m for a shared P (see ProbsToken): its dO / V pair is queued for the deferred dP product."""
+
+    @staticmethod
+    def forward(ctx, token, v, holder, prec):
+        v = _rows(v)
+        P = holder.P
+        B, M, N, ld = P.shape
+        C = v.shape[-1] // M
+        O = torch.empty(B, M, N, C, device=P.device, dtype=torch.float32)
+        pv = pick(prec, "pv")
+        ldv = v.stride(-2)
+        gemm(P, ld, 1, M * N * ld, N * ld, v, 1, ldv, N * ldv, C, O, C, M * N * C, N * C, M, B * M, N, C, N, prec=pv)
+        ctx.save_for_backward(v)
+        ctx.holder, ctx.prec = holder, pv
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        (v,) = ctx.saved_tensors
+        holder = ctx.holder
+        P = holder.P
+        dO = _c(dO)
+        B, M, N, ld = P.shape
+        C = v.shape[-1] // M
+        holder.pending.append((dO, v if v.is_contiguous() else v.contiguous()))
+        dv = torch.empty(B, N, M * C, device=P.device, dtype=torch.float32)
+        gemm(P, 1, ld, M * N * ld, N * ld, dO, 1, C, M * N * C, N * C, dv, M * C, N * M * C, C, M, B * M, N, C, N, prec=ctx.prec)
+        return torch.zeros(1, device=P.device, dtype=torch.float32), dv, None, None
+
+
 class ModePoolLN(Function):
     """y = LayerNorm(skip * x + sum_m softmax_m(<O_m, w>) O_m)  (setrans.py:395-407)."""
 
@@ -381,33 +453,69 @@ def _pad_cols(x: torch.Tensor, c: int) -> torch.Tensor:
     return y
 
 
+def _conv_weights(w, b, cp, cache, transposed: bool):
+    """Operands of the conv kernels for one weight tensor, built once per forward pass (``cache``: a dict that lives as long as
+    the pass' graph -- the refinement loop calls every layer 12 times with the same weights, forward and backward):
+    raw [cout_p][KH][KW][cin_p] (channel counts padded to multiples of 32), the padded bias, and for 16-bit / f16x3 precisions
+    and kernels up to 5x5 the MFMA fragment-order packing the halo kernel streams (craft_pack_weights).
+    ``transposed``: the operand of the INPUT-gradient convolution, W'[ci][KH-1-ky][KW-1-kx][co] = W[co][ky][kx][ci]."""
+    key = (id(w), cp, transposed)
+    hit = cache.get(key) if cache is not None else None
+    if hit is not None:
+        return hit
+    Cout, Cin, KH, KW = w.shape
+    cin_p, cout_p = round_up(Cin, 32), round_up(Cout, 32)
+    raw = cache.get((id(w), "raw")) if cache is not None else None
+    if raw is None:
+        raw = torch.zeros(cout_p, KH, KW, cin_p, device=w.device, dtype=torch.float32)
+        raw[:Cout, :, :, :Cin] = w.detach().permute(0, 2, 3, 1)
+        if cache is not None:
+            cache[(id(w), "raw")] = raw
+    if transposed:
+        wt = raw.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+        rows, bias = cin_p, torch.zeros(cin_p, device=w.device, dtype=torch.float32)
+    else:
+        wt = raw
+        rows, bias = cout_p, torch.zeros(cout_p, device=w.device, dtype=torch.float32)
+        if b is not None:
+            bias[:Cout] = b.detach()
+    flag = 0
+    if cp != hip.PREC_F32 and KH * KW > 1 and KH <= 5 and KW <= 5:
+        planes = 2 if cp == hip.PREC_F16X3 else 1
+        K = wt[0].numel()
+        packed = torch.empty(planes * rows * K, device=w.device, dtype=torch.bfloat16 if cp == hip.PREC_BF16 else torch.float16)
+        call("craft_pack_weights", wt, rows, K, cp, packed)
+        wt, flag = packed, hip.W_PACKED
+    out = (wt, bias, flag, raw)
+    if cache is not None:
+        cache[key] = out
+    return out
+
+
 class Conv(Function):
     """nn.Conv2d (stride 1, padding K//2) + bias (+ReLU) on tokens; w in PyTorch layout [Cout, Cin, KH, KW].
     Backward: input gradient = the same forward kernel with flipped / transposed weights, weight gradient =
     craft_conv2d_wgrad, bias gradient = column sums."""
 
     @staticmethod
-    def forward(ctx, x, w, b, hw, act, prec):
+    def forward(ctx, x, w, b, hw, act, prec, cache=None):
         B, N, Cin = x.shape
         Cout, _, KH, KW = w.shape
         cp = pick(prec, "conv")
         cin_p, cout_p = round_up(Cin, 32), round_up(Cout, 32)
         xp = _pad_cols(x, cin_p)
-        wp = torch.zeros(cout_p, KH, KW, cin_p, device=x.device, dtype=torch.float32)
-        wp[:Cout, :, :, :Cin] = w.detach().permute(0, 2, 3, 1)
-        bp = torch.zeros(cout_p, device=x.device, dtype=torch.float32)
-        if b is not None:
-            bp[:Cout] = b.detach()
+        wt, bp, flag, _ = _conv_weights(w, b, cp, cache, False)
         y = torch.empty(B, N, cout_p, device=x.device, dtype=torch.float32)
-        call("craft_conv2d_nhwc", xp, xp.stride(-2), cin_p, wp, bp, cout_p, KH, KW, act, y, cout_p, B, hw[0], hw[1], cp)
-        ctx.save_for_backward(xp, wp, y if act != ACT_NONE else None)
+        call("craft_conv2d_nhwc", xp, xp.stride(-2), cin_p, wt, bp, cout_p, KH, KW, act, y, cout_p, B, hw[0], hw[1], cp | flag)
+        ctx.save_for_backward(xp, y if act != ACT_NONE else None)
+        ctx.w, ctx.cache = w, cache
         ctx.dims = (B, N, Cin, Cout, KH, KW, cin_p, cout_p)
         ctx.hw, ctx.act, ctx.prec, ctx.has_bias = hw, act, cp, b is not None
         return y[..., :Cout] if cout_p != Cout else y
 
     @staticmethod
     def backward(ctx, dy):
-        xp, wp, y = ctx.saved_tensors
+        xp, y = ctx.saved_tensors
         B, N, Cin, Cout, KH, KW, cin_p, cout_p = ctx.dims
         H8, W8 = ctx.hw
         dev = xp.device
@@ -418,11 +526,9 @@ class Conv(Function):
             g = ga
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            # dX = conv(dY, W') with W'[ci][KH-1-ky][KW-1-kx][co] = W[co][ky][kx][ci]
-            wt = wp.flip(1, 2).permute(3, 1, 2, 0).contiguous()
-            zb = torch.zeros(cin_p, device=dev, dtype=torch.float32)
+            wt, zb, flag, _ = _conv_weights(ctx.w, None, ctx.prec, ctx.cache, True)
             dxp = torch.empty(B, N, cin_p, device=dev, dtype=torch.float32)
-            call("craft_conv2d_nhwc", g, g.stride(-2), cout_p, wt, zb, cin_p, KH, KW, ACT_NONE, dxp, cin_p, B, H8, W8, ctx.prec)
+            call("craft_conv2d_nhwc", g, g.stride(-2), cout_p, wt, zb, cin_p, KH, KW, ACT_NONE, dxp, cin_p, B, H8, W8, ctx.prec | flag)
             dx = dxp[..., :Cin] if cin_p != Cin else dxp
         if ctx.needs_input_grad[1]:
             dwp = torch.zeros(cout_p, KH, KW, cin_p, device=dev, dtype=torch.float32)
@@ -432,7 +538,7 @@ class Conv(Function):
             dbp = torch.zeros(cout_p, device=dev, dtype=torch.float32)
             call("craft_colsum", g, g.stride(-2), B * N, cout_p, dbp)
             db = dbp[:Cout]
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -31,19 +31,33 @@ __device__ __forceinline__ bool clamp_active(const unsigned* clamp_ord) {
 // ---------------------------------------------------------------------------------------------
 // column sums: out[c] += sum_r x[r][c]   (bias gradients)
 // ---------------------------------------------------------------------------------------------
+// block = 64 columns x 4 row-slices (one wave each); grid (row chunks, column groups): every wave reads whole 256-byte row
+// segments and the four slices of a block are combined in LDS before ONE atomic per column.
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, long ld, long rows, int C, int rows_per_block,
                                                 float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + lane;
   const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = 0.f;
-    for (long r = r0; r < r1; ++r) s += x[r * ld + c];
-    unsafeAtomicAdd(out + c, s);
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    long r = r0 + wv;
+    for (; r + 4 < r1; r += 8) { s0 += x[r * ld + c]; s1 += x[(r + 4) * ld + c]; }
+    if (r < r1) s0 += x[r * ld + c];
   }
+  part[wv][lane] = s0 + s1;
+  __syncthreads();
+  if (wv == 0 && c < C) unsafeAtomicAdd(out + c, part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
 }
 int launch_colsum(const float* x, long ld, long rows, int C, float* out, hipStream_t s) {
   if (rows <= 0 || C <= 0) return 0;
-  const int rpb = 128;
-  hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, x, ld, rows, C, rpb, out);
+  const int cg = (C + 63) / 64;
+  // enough blocks to fill the chip: ~2048 in total, at least 32 rows each
+  long chunks = 2048 / cg;
+  if (chunks < 1) chunks = 1;
+  long rpb = (rows + chunks - 1) / chunks;
+  if (rpb < 32) rpb = 32;
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)((rows + rpb - 1) / rpb), cg), dim3(256), 0, s, x, ld, rows, C, (int)rpb, out);
   return (int)hipGetLastError();
 }
 

@@ -34,8 +34,8 @@ def _attention_probs(module, x_ln, hw, prec, p_attn: float, seed: int):
     return AG.dropout(P, p_attn, seed)
 
 
-def _conv(x, conv, hw, act, prec):
-    return AG.Conv.apply(x, conv.weight, conv.bias, hw, act, prec)
+def _conv(x, conv, hw, act, prec, cache):
+    return AG.Conv.apply(x, conv.weight, conv.bias, hw, act, prec, cache)
 
 
 def forward_train(model, image1, image2, iters=12, flow_init=None):
@@ -105,12 +105,16 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
     ca = att.config
     xc = AG.dropout(AG.TokensNorm.apply(inp, ACT_NONE, True), p_hidden(ca), base_seed + 5)
     Patt = _attention_probs(att, xc, hw, prec, p_attn(ca), base_seed + 6)
+    pbox = []
+    ptoken = AG.ProbsToken.apply(Patt, pbox, prec)        # the 12 uses of Patt share ONE gradient product
+    pholder = pbox[0]
 
     # ---- iterative refinement (network.py:230-260; update.py:137-162) -------------------------------------------------
     ub = model.update_block
     enc, gru, fh, agg = ub.encoder, ub.gru, ub.flow_head, ub.aggregator
     coords0, coords1, _ = ops.coords_init(flow_init, B, H8, W8, dev)
     preds = []
+    wcache = {}          # conv operands (padded / packed / transposed weights) built once for this pass and its backward
     wzr = [torch.cat([gru.convz1.weight, gru.convr1.weight], 0), torch.cat([gru.convz2.weight, gru.convr2.weight], 0)]
     bzr = [torch.cat([gru.convz1.bias, gru.convr1.bias], 0), torch.cat([gru.convz2.bias, gru.convr2.bias], 0)]
     convq = [gru.convq1, gru.convq2]
@@ -122,27 +126,27 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
         flow = coords1 - coords0
         # BasicMotionEncoder (update.py:79-87)
         cor = AG.Act.apply(AG.Linear.apply(corr, wc1, enc.convc1.bias, prec.conv), ACT_RELU, 1.0)
-        cor = _conv(cor, enc.convc2, hw, ACT_RELU, prec)
-        flo = _conv(flow, enc.convf1, hw, ACT_RELU, prec)
-        flo = _conv(flo, enc.convf2, hw, ACT_RELU, prec)
-        out = _conv(torch.cat([cor, flo], dim=-1), enc.conv, hw, ACT_RELU, prec)
+        cor = _conv(cor, enc.convc2, hw, ACT_RELU, prec, wcache)
+        flo = _conv(flow, enc.convf1, hw, ACT_RELU, prec, wcache)
+        flo = _conv(flo, enc.convf2, hw, ACT_RELU, prec, wcache)
+        out = _conv(torch.cat([cor, flo], dim=-1), enc.conv, hw, ACT_RELU, prec, wcache)
         mf = torch.cat([out, flow], dim=-1)                                     # [B, N, 128]
         # motion aggregator (update.py:143-149): ExpandedFeatTrans on the raw motion features
         va = AG.Linear.apply(mf, agg.first_linear.weight, None, prec)
-        Oa = AG.AttnApply.apply(Patt, va, prec)
+        Oa = AG.AttnApplyShared.apply(ptoken, va, pholder, prec)
         mfg = AG.ModePoolLN.apply(Oa, mf, agg.feat_softaggr.feat2score.weight, agg.input_skip_coeff)
         # SepConvGRU (update.py:49-64)
         x = torch.cat([inp, mf, mfg], dim=-1)                                   # [B, N, 384]
         h = net
         for ps, (kh, kw) in enumerate(((1, 5), (5, 1))):
-            zr_pre = AG.Conv.apply(torch.cat([h, x], dim=-1), wzr[ps], bzr[ps], hw, ACT_NONE, prec)
+            zr_pre = AG.Conv.apply(torch.cat([h, x], dim=-1), wzr[ps], bzr[ps], hw, ACT_NONE, prec, wcache)
             z, rh = AG.GruZR.apply(zr_pre, h)
-            q_pre = _conv(torch.cat([rh, x], dim=-1), convq[ps], hw, ACT_NONE, prec)
+            q_pre = _conv(torch.cat([rh, x], dim=-1), convq[ps], hw, ACT_NONE, prec, wcache)
             h = AG.GruOut.apply(q_pre, z, h)
         net = h
         # heads (update.py:15-16, :124-127, :161)
-        delta = _conv(_conv(net, fh.conv1, hw, ACT_RELU, prec), fh.conv2, hw, ACT_NONE, prec)
-        mh = _conv(net, ub.mask[0], hw, ACT_RELU, prec)
+        delta = _conv(_conv(net, fh.conv1, hw, ACT_RELU, prec, wcache), fh.conv2, hw, ACT_NONE, prec, wcache)
+        mh = _conv(net, ub.mask[0], hw, ACT_RELU, prec, wcache)
         mask = AG.Act.apply(AG.Linear.apply(mh, wm2, ub.mask[2].bias, prec.conv), ACT_NONE, 0.25)
         coords1 = coords1 + delta                                               # network.py:247
         preds.append(AG.ConvexUpsample.apply(mask, coords1 - coords0, hw))      # :258

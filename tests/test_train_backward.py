@@ -220,7 +220,7 @@ def test_conv_backward(device, prec, KH, KW, cin, cout, act):
     b = rnd(cout, seed=32) * 0.1
     xt = x.permute(0, 2, 3, 1).reshape(B, H8 * W8, cin).contiguous()
     ld, lr = [_leaf(t, device) for t in (xt, w, b)], [t.clone().requires_grad_(True) for t in (x, w, b)]
-    yd = AG.Conv.apply(ld[0], ld[1], ld[2], (H8, W8), act, prec)
+    yd = AG.Conv.apply(ld[0], ld[1], ld[2], (H8, W8), act, prec, {})
     yr = F.conv2d(lr[0], lr[1], lr[2], padding=(KH // 2, KW // 2))
     yr = torch.relu(yr) if act == ACT_RELU else yr
     yr_t = yr.permute(0, 2, 3, 1).reshape(B, H8 * W8, cout)
