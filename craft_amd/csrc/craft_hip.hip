@@ -479,4 +479,20 @@ int craft_gru_zr_bwd(const float* dz, const float* drh, long lddrh, const float*
   return launch_gru_zr_bwd(dz, drh, lddrh, z, r, h, ldh, dzr_pre, dh, rows, C, S(stream));
 }
 
+// ---- input pipeline ---------------------------------------------------------------------------------------------
+int craft_aug_spatial(const float* src, int H, int W, int C, int do_resize, float fx, float fy, int hflip, int vflip, int y0, int x0, int ch,
+                      int cw, int is_flow, float* out, void* stream) {
+  return launch_aug_spatial(src, H, W, C, do_resize, fx, fy, hflip, vflip, y0, x0, ch, cw, is_flow, out, S(stream));
+}
+int craft_aug_photo(float* img, long npix, int op, float factor, float mean, void* stream) {
+  return launch_aug_photo(img, npix, op, factor, mean, S(stream));
+}
+int craft_aug_erase(float* img, int H, int W, const int* rects, int nrect, float mr, float mg, float mb, void* stream) {
+  return launch_aug_erase(img, H, W, rects, nrect, mr, mg, mb, S(stream));
+}
+int craft_aug_shift(const float* img1, const float* img2, const float* flow, int H, int W, int dx, int dy, float* out1, float* out2,
+                    float* out_flow, float* valid, void* stream) {
+  return launch_aug_shift(img1, img2, flow, H, W, dx, dy, out1, out2, out_flow, valid, S(stream));
+}
+
 }  // extern "C"

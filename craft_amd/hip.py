@@ -84,6 +84,11 @@ _SIGS = {
     "craft_gru_out_bwd": [P, L, P, P, P, L, P, P, P, L, I, P],
     "craft_gru_zr_bwd": [P, P, L, P, P, P, L, P, P, L, I, P],
     "craft_coords_init": [P, I, I, I, P, P, P, P],
+    # ---- input pipeline
+    "craft_aug_spatial": [P, I, I, I, I, F, F, I, I, I, I, I, I, I, P, P],
+    "craft_aug_photo": [P, L, I, F, F, P],
+    "craft_aug_erase": [P, I, I, P, I, F, F, F, P],
+    "craft_aug_shift": [P, P, P, I, I, I, I, P, P, P, P, P],
 }
 
 

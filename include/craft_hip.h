@@ -369,6 +369,26 @@ int craft_gru_out_bwd(const float* dh_new, long lddhn, const float* z, const flo
 int craft_gru_zr_bwd(const float* dz, const float* drh, long lddrh, const float* z, const float* r, const float* h, long ldh, float* dzr_pre,
                      float* dh, long rows, int C, void* stream);
 
+/* ==== input pipeline on the GPU (core/utils/augmentor.py) ========================================
+ * All images are float HWC in 0..255 ([H][W][3]), flow [H][W][2] (x, y); the host draws the random parameters.
+ * craft_aug_spatial: FlowAugmentor.spatial_transform (augmentor.py:141-193) as one gather: out [ch][cw][C] = crop at (y0, x0) of
+ *   v-flip(h-flip(resize(src))) where resize is cv2.INTER_LINEAR's mapping src = (dst + 0.5) / f - 0.5 with replicated borders on
+ *   a (round(H*fy), round(W*fx)) grid (do_resize = 0: no resize).  is_flow: C = 2, values scaled by (fx, fy) and negated by the
+ *   flips; else resized values are rounded to integer levels in 0..255.
+ * craft_aug_photo: one ColorJitter step on img [npix][3] in place (torchvision / PIL semantics on 8-bit images): op 0 brightness
+ *   (x * factor), 1 contrast (blend with `mean` = the mean grey level, which the caller reduces), 2 saturation (blend with the
+ *   pixel's grey), 3 hue (HSV hue shifted by `factor` turns); results rounded to integer levels.
+ * craft_aug_erase: FlowAugmentor.eraser_transform (augmentor.py:125-139): rects [nrect][4] = (x0, y0, dx, dy) (device ints) filled
+ *   with (mr, mg, mb).
+ * craft_aug_shift: random_shift (augmentor.py:16-78) for even (dx, dy): the two frames cropped against each other by the shift,
+ *   flow - (dx, dy), zero-padded back to [H][W], valid [H][W] = 1 inside the remaining area. */
+int craft_aug_spatial(const float* src, int H, int W, int C, int do_resize, float fx, float fy, int hflip, int vflip, int y0, int x0, int ch,
+                      int cw, int is_flow, float* out, void* stream);
+int craft_aug_photo(float* img, long npix, int op, float factor, float mean, void* stream);
+int craft_aug_erase(float* img, int H, int W, const int* rects, int nrect, float mr, float mg, float mb, void* stream);
+int craft_aug_shift(const float* img1, const float* img2, const float* flow, int H, int W, int dx, int dy, float* out1, float* out2,
+                    float* out_flow, float* valid, void* stream);
+
 /* CRAFT.upsample_flow (network.py:151-162): mask tokens [B*N][576], flow tokens [B*N][2] -> up NCHW
  * [B][2][8*H8][8*W8]. */
 int craft_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, void* stream);

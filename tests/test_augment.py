@@ -1,0 +1,140 @@
+"""Input pipeline on the GPU (reference core/utils/augmentor.py).
+
+* random_shift: bit-for-bit against outputs of the reference's own function (tests/golden/harness.npz 'shift.*'), with (dx, dy)
+  re-drawn by our sampler from the same seeds -- so the draw order is pinned too (CPU part) and the kernel (GPU part).
+* spatial gather (resize -> flips -> crop), ColorJitter steps, eraser: against numpy restatements written here (cv2 / PIL /
+  torchvision are not in this image: their 8-bit rounding is not pinned).
+* FlowAugmentor end to end: shapes, ranges, flow consistency under a pure flip / crop."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+Z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "harness.npz"))
+
+
+def test_shift_draw_order_matches_reference_outputs():
+    """Our (dx, dy) sampler, seeded like the fixture, must reproduce the crop geometry the reference produced."""
+    from craft_amd.augment import draw_shift
+    H, W = Z["shift.img1"].shape[:2]
+    for sd in Z["shift.seeds"].tolist():
+        random.seed(sd); np.random.seed(sd)
+        dx, dy = draw_shift((16, 10))
+        valid = Z[f"shift.{sd}.valid"]
+        assert dx % 2 == 0 and dy % 2 == 0
+        assert int(valid.sum()) == (H - abs(dy)) * (W - abs(dx)), (sd, dx, dy)
+        assert valid.shape == (H, W)
+
+
+@pytest.mark.gpu
+def test_random_shift_kernel_bit_exact(device):
+    from craft_amd.augment import draw_shift, random_shift
+    a1, a2, fl = (torch.from_numpy(Z[k]).to(device) for k in ("shift.img1", "shift.img2", "shift.flow"))
+    seen = set()
+    for sd in Z["shift.seeds"].tolist():
+        random.seed(sd); np.random.seed(sd)
+        dx, dy = draw_shift((16, 10))
+        seen.add((np.sign(dx), np.sign(dy)))
+        o1, o2, of, vm = random_shift(a1, a2, fl, dx, dy)
+        assert np.array_equal(o1.cpu().numpy(), Z[f"shift.{sd}.img1"]), (sd, dx, dy)
+        assert np.array_equal(o2.cpu().numpy(), Z[f"shift.{sd}.img2"])
+        assert np.array_equal(of.cpu().numpy(), Z[f"shift.{sd}.flow"])
+        assert np.array_equal(vm.cpu().numpy(), Z[f"shift.{sd}.valid"])
+    assert len(seen) >= 3, "the fixture should cover several sign combinations of the shift"
+
+
+def _resize_ref(a, fx, fy):
+    """cv2.resize(a, None, fx, fy, INTER_LINEAR) in float: dst size round(n*f), src = (dst + .5)/f - .5, replicate border."""
+    H, W, C = a.shape
+    Hs, Ws = int(round(H * fy)), int(round(W * fx))
+    ys = (np.arange(Hs) + 0.5) / np.float32(fy) - 0.5
+    xs = (np.arange(Ws) + 0.5) / np.float32(fx) - 0.5
+    y0 = np.floor(ys).astype(int); x0 = np.floor(xs).astype(int)
+    wy = (ys - y0)[:, None, None].astype(np.float32); wx = (xs - x0)[None, :, None].astype(np.float32)
+    cy = lambda v: np.clip(v, 0, H - 1); cx = lambda v: np.clip(v, 0, W - 1)
+    A = a[cy(y0)][:, cx(x0)]; B = a[cy(y0)][:, cx(x0 + 1)]; D = a[cy(y0 + 1)][:, cx(x0)]; E = a[cy(y0 + 1)][:, cx(x0 + 1)]
+    return (A * (1 - wx) + B * wx) * (1 - wy) + (D * (1 - wx) + E * wx) * wy
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("do_resize,hflip,vflip", [(True, False, False), (True, True, True), (False, True, False), (False, False, True)])
+def test_spatial_gather(device, do_resize, hflip, vflip):
+    from craft_amd.augment import spatial
+    r = np.random.RandomState(3)
+    H, W, crop = 60, 90, (40, 56)
+    img = r.randint(0, 256, size=(H, W, 3)).astype(np.float32)
+    flow = (r.standard_normal((H, W, 2)) * 4).astype(np.float32)
+    fx, fy = 1.37, 0.93
+    for a, is_flow in ((img, False), (flow, True)):
+        ref = _resize_ref(a, fx, fy) if do_resize else a.copy()
+        if is_flow and do_resize:
+            ref = ref * np.array([fx, fy], dtype=np.float32)
+        if hflip:
+            ref = ref[:, ::-1] * (np.array([-1.0, 1.0], dtype=np.float32) if is_flow else 1.0)
+        if vflip:
+            ref = ref[::-1] * (np.array([1.0, -1.0], dtype=np.float32) if is_flow else 1.0)
+        y0, x0 = 7, 11
+        ref = ref[y0:y0 + crop[0], x0:x0 + crop[1]]
+        if not is_flow and do_resize:
+            ref = np.clip(np.rint(ref), 0, 255)
+        got = spatial(torch.from_numpy(a).to(device), crop, y0, x0, fx, fy, do_resize, hflip, vflip, is_flow).cpu().numpy()
+        if is_flow or not do_resize:
+            assert np.allclose(got, ref, rtol=1e-5, atol=2e-4)
+        else:       # rounding to integer levels: values within float noise of a .5 boundary may land on either side
+            assert np.abs(got - ref).max() <= 1.0 and (got != ref).mean() < 2e-3
+
+
+@pytest.mark.gpu
+def test_photo_steps_and_eraser(device):
+    from craft_amd.augment import erase, photo_step
+    r = np.random.RandomState(4)
+    img = r.randint(0, 256, size=(32, 40, 3)).astype(np.float32)
+    q = lambda v: np.clip(np.rint(v), 0, 255)
+    gray = q(0.299 * img[..., 0] + 0.587 * img[..., 1] + 0.114 * img[..., 2])
+    t = lambda: torch.from_numpy(img.copy()).to(device)
+    assert np.array_equal(photo_step(t(), 0, 1.3).cpu().numpy(), q(img * np.float32(1.3)))
+    m = float(int(gray.mean() + 0.5))
+    assert np.abs(photo_step(t(), 1, 0.7).cpu().numpy() - q((img - m) * np.float32(0.7) + m)).max() <= 1.0
+    assert np.abs(photo_step(t(), 2, 1.25).cpu().numpy() - q((img - gray[..., None]) * np.float32(1.25) + gray[..., None])).max() <= 1.0
+    # hue: a zero shift is the identity up to the 8-bit HSV round trip; a full turn (256/255) as well
+    h0 = photo_step(t(), 3, 0.0).cpu().numpy()
+    assert np.abs(h0 - img).max() <= 3.0
+    hh = photo_step(t(), 3, 0.1).cpu().numpy()
+    assert np.abs(hh.max(-1) - img.max(-1)).max() <= 1.0, "a hue shift keeps the HSV value (max channel)"
+    assert np.abs(hh - img).mean() > 5.0
+    e = erase(t(), [(5, 3, 10, 7), (30, 25, 50, 50)], (1.0, 2.0, 3.0)).cpu().numpy()
+    ref = img.copy()
+    ref[3:10, 5:15] = (1.0, 2.0, 3.0)
+    ref[25:75, 30:80] = (1.0, 2.0, 3.0)
+    assert np.array_equal(e, ref)
+
+
+@pytest.mark.gpu
+def test_flow_augmentor_end_to_end(device):
+    from craft_amd.augment import FlowAugmentor
+    r = np.random.RandomState(6)
+    H, W, crop = 120, 160, (64, 96)
+    img1 = torch.from_numpy(r.randint(0, 256, size=(H, W, 3)).astype(np.float32)).to(device)
+    img2 = torch.from_numpy(r.randint(0, 256, size=(H, W, 3)).astype(np.float32)).to(device)
+    flow = torch.from_numpy((r.standard_normal((H, W, 2)) * 3).astype(np.float32)).to(device)
+    aug = FlowAugmentor("chairs", crop, min_scale=-0.1, max_scale=1.0, do_flip=True, shift_prob=0.5, shift_sigmas=(16, 10))
+    shifted = 0
+    for sd in range(12):
+        random.seed(sd); np.random.seed(sd)
+        a, b, f, v = aug(img1, img2, flow)
+        assert a.shape == (crop[0], crop[1], 3) and b.shape == a.shape and f.shape == (crop[0], crop[1], 2)
+        assert float(a.min()) >= 0 and float(a.max()) <= 255 and torch.equal(a, a.round())
+        assert torch.isfinite(f).all()
+        if v is not None:
+            shifted += 1
+            assert v.shape == crop and set(np.unique(v.cpu().numpy())) <= {0.0, 1.0}
+            assert float((f.abs().sum(-1) * (1 - v)).max()) == 0.0            # padded area: zero flow
+    assert 0 < shifted < 12
+    # same seed, same result (all randomness comes from the seeded module-level generators)
+    random.seed(3); np.random.seed(3)
+    x = aug(img1, img2, flow)
+    random.seed(3); np.random.seed(3)
+    y = aug(img1, img2, flow)
+    assert all(torch.equal(p, q) for p, q in zip(x[:3], y[:3]))

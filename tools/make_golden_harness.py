@@ -182,6 +182,25 @@ def main():
     out["loss.grads"] = torch.stack([p.grad for p in preds]).numpy()
     out["loss.max_flow"] = np.float64(tns["MAX_FLOW"])
 
+    # random_shift (core/utils/augmentor.py:16-78): the reference's own function (pure numpy + the `random` module; the file
+    # itself needs cv2 / torchvision, so only this FunctionDef is compiled), seeded, on integer-valued images
+    import random
+    ans = {"np": np, "random": random}
+    ref_functions(os.path.join(REF, "core", "utils", "augmentor.py"), ["random_shift"], ans)
+    r = np.random.RandomState(5)
+    Hh, Ww = 48, 64
+    a1 = r.randint(0, 256, size=(Hh, Ww, 3)).astype(np.float32)
+    a2 = r.randint(0, 256, size=(Hh, Ww, 3)).astype(np.float32)
+    fl = (r.standard_normal((Hh, Ww, 2)) * 5).astype(np.float32)
+    out["shift.img1"], out["shift.img2"], out["shift.flow"] = a1, a2, fl
+    seeds = [1, 2, 3, 4, 5, 6, 7, 8]
+    out["shift.seeds"] = np.array(seeds)
+    for sd in seeds:
+        random.seed(sd); np.random.seed(sd)
+        o1, o2, of, vm = ans["random_shift"](a1, a2, fl, shift_sigmas=(16, 10))
+        out[f"shift.{sd}.img1"], out[f"shift.{sd}.img2"] = o1.astype(np.float32), o2.astype(np.float32)
+        out[f"shift.{sd}.flow"], out[f"shift.{sd}.valid"] = of.astype(np.float32), vm.astype(np.float32)
+
     path = os.path.join(ROOT, "tests", "golden", "harness.npz")
     np.savez_compressed(path, **out)
     print(path, f"{os.path.getsize(path) / 1024:.0f} KiB", {k: float(v) for k, v in out.items() if np.ndim(v) == 0})
