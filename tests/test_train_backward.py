@@ -354,3 +354,47 @@ def test_train_mode_rejects_other_configs_and_sizes(device):
     gma = CRAFT(default_args(use_setrans=False)).to(device).train()
     with pytest.raises(NotImplementedError):
         gma(torch.zeros(1, 3, 128, 128, device=device), torch.zeros(1, 3, 128, 128, device=device), iters=1)
+
+
+def test_training_step_at_configs3_size_against_oracle(device):
+    """BASELINE configs[3] shape (368x496 -> 46x62 tokens, odd pooling sizes 23 / 11 / 5), batch 2 with BatchNorm batch statistics,
+    2 iterations, fp32 policy: loss and every parameter gradient of the HIP step against torch autograd over the CPU oracle
+    (which tests/test_oracle_train_golden.py pins to the reference)."""
+    from craft_amd.synth import synth_pair
+    B, H, W, iters = 2, 368, 496, 2
+    model = CRAFT(default_args(hip_precision="fp32", dropout_prob=0.0))
+    sd0 = synth_state_dict(model.state_dict(), seed=77)
+    model.load_state_dict(sd0, strict=True)
+    model = model.to(device).train()
+    im1, im2, flow = synth_pair(B, H, W, seed=31)
+    valid = (torch.rand(B, H, W, generator=torch.Generator().manual_seed(1)) > 0.15).float()
+    preds = model(im1.to(device), im2.to(device), iters=iters)
+    loss, _ = AG.sequence_loss(preds, flow, valid, 0.8)
+    loss.backward()
+    names = [k for k, _ in model.named_parameters()]
+    sd = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in sd0.items()}
+    sd["corr_fn.setrans.key.weight"], sd["corr_fn.setrans.key.bias"] = sd["corr_fn.setrans.query.weight"], sd["corr_fn.setrans.query.bias"]
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    preds_r, _ = O.craft_train_forward(sd, O.OracleConfig(), im1, im2, iters=iters)
+    loss_r, _ = O.sequence_loss(preds_r, flow, valid, 0.8)
+    loss_r.backward()
+    assert float(loss) == pytest.approx(float(loss_r), rel=3e-5)
+    for a, b in zip(preds, preds_r):
+        assert (a.detach().cpu() - b.detach()).abs().max().item() < 2e-3
+    rms_all = sorted(float(sd[k].grad.pow(2).mean().sqrt()) for k in names if sd[k].grad is not None)
+    scale = rms_all[len(rms_all) // 2]
+    worst, checked = 0.0, 0
+    seen = set()
+    for k, p in model.named_parameters():
+        if id(p) in seen or sd[k].grad is None or k.startswith("corr_fn.setrans.key."):
+            continue
+        seen.add(id(p))
+        ref = sd[k].grad
+        if float(ref.pow(2).mean().sqrt()) < 1e-4 * scale:      # mathematically zero (bias in front of a normalisation layer)
+            assert float(p.grad.pow(2).mean().sqrt()) < 1e-3 * scale, k
+            continue
+        l2 = ((p.grad.cpu() - ref).norm() / ref.norm()).item()
+        assert l2 < 1e-2, f"{k}: relative L2 error {l2:.2e}"
+        worst, checked = max(worst, l2), checked + 1
+    assert checked > 100
+    print(f"[train parity] 368x496 B=2: loss {float(loss):.6f} vs oracle {float(loss_r):.6f}; worst relative L2 gradient error {worst:.2e} over {checked} parameters")
