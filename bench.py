@@ -121,15 +121,25 @@ def roofline_pv(model, im1, im2, iters, prec, forwards=3):
     esz = torch.empty(0, dtype=PROB_DTYPE[pv]).element_size()
     bytes_alg = B * M * N * ldp * esz + B * M * Dv * ldp * esz + B * M * N * Dv * 4
     ach = bytes_alg / (ms * 1e-3) / 1e9
-    # HBM bytes per launch from the committed PMC passes of this kernel at this shape (rocprofv3 --pmc FETCH_SIZE and
-    # --pmc WRITE_SIZE in separate runs, gfx950 x2 correction on FETCH_SIZE: profiles/r1/pmc_traffic_pv16.json);
-    # only quoted when the live shape is the profiled one
+    # HBM bytes per launch from the committed PMC passes of this kernel (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
+    # separate runs, gfx950 x2 correction on FETCH_SIZE: profiles/r2/pmc_traffic_pv16.json).  Quoted only when the live launch is
+    # the profiled one: same shape, same element type AND the same kernel instantiation (rows per block chosen by the launcher's
+    # cost function, replicated here) -- otherwise null rather than a stale constant.
     traffic = None
     try:
         import json as _json
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1", "pmc_traffic_pv16.json")) as fh:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2", "pmc_traffic_pv16.json")) as fh:
             pmc = _json.load(fh)
-        if (B, H8, W8) == (4, 56, 128) and pv == PREC_F16:
+        best, best_cost = 4, None
+        for mt in (4, 5, 6, 7):           # launch_pv16 (kernels_gemm.hip): minimise resident rounds x rows per block
+            blocks = ((N + 32 * mt - 1) // (32 * mt)) * (Dv // 128) * B * M
+            slots = 256 * (3 if mt == 4 else 2)
+            cost = ((blocks + slots - 1) // slots) * mt
+            if best_cost is None or cost < best_cost:
+                best, best_cost = mt, cost
+        live = f"k_pv16<{pv}, {best}>"
+        sh = pmc.get("shape", {})
+        if (sh.get("B"), sh.get("H8"), sh.get("W8")) == (B, H8, W8) and pv == PREC_F16 and pmc.get("kernel", "").replace(" ", "") == live.replace(" ", ""):
             traffic = int(pmc["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         pass
@@ -138,7 +148,7 @@ def roofline_pv(model, im1, im2, iters, prec, forwards=3):
             "bytes_per_launch": bytes_alg, "ms_per_launch": round(ms, 4), "launches_timed": len(evs),
             "note": "timed live around every launch of real forward passes (HIP events on the launch stream); algorithmic bytes "
                     "= P (fp16, read once) + V^T + O; traffic = HBM bytes per launch from the PMC passes committed under "
-                    "profiles/r1 (FETCH_SIZE x2 on gfx950 + WRITE_SIZE); measured read-only ceiling of this access pattern "
+                    "profiles/r2 (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; null when the live kernel instantiation is not the profiled one); measured read-only ceiling of this access pattern "
                     "on the same chip: 6.1 TB/s (tools/ubench/hbm_rows.hip)"}
 
 
