@@ -492,6 +492,14 @@ def _conv_weights(w, b, cp, cache, transposed: bool):
     return out
 
 
+def _conv_wgrad(xp, g, B, H8, W8, cin_p, cout_p, KH, KW, prec) -> torch.Tensor:
+    """dW[co][ky][kx][ci] += sum_pix dY[pix][co] X[pix + tap][ci] (craft_conv2d_wgrad; split-K partial sums added with fp32 atomics:
+    measured equal to the scratch + reduction form, one kernel less)."""
+    dw = torch.zeros(cout_p, KH, KW, cin_p, device=xp.device, dtype=torch.float32)
+    call("craft_conv2d_wgrad", xp, xp.stride(-2), cin_p, g, g.stride(-2), cout_p, KH, KW, B, H8, W8, dw, None, 0, prec)
+    return dw
+
+
 class Conv(Function):
     """nn.Conv2d (stride 1, padding K//2) + bias (+ReLU) on tokens; w in PyTorch layout [Cout, Cin, KH, KW].
     Backward: input gradient = the same forward kernel with flipped / transposed weights, weight gradient =
@@ -531,8 +539,7 @@ class Conv(Function):
             call("craft_conv2d_nhwc", g, g.stride(-2), cout_p, wt, zb, cin_p, KH, KW, ACT_NONE, dxp, cin_p, B, H8, W8, ctx.prec | flag)
             dx = dxp[..., :Cin] if cin_p != Cin else dxp
         if ctx.needs_input_grad[1]:
-            dwp = torch.zeros(cout_p, KH, KW, cin_p, device=dev, dtype=torch.float32)
-            call("craft_conv2d_wgrad", xp, xp.stride(-2), cin_p, g, g.stride(-2), cout_p, KH, KW, B, H8, W8, dwp, ctx.prec)
+            dwp = _conv_wgrad(xp, g, B, H8, W8, cin_p, cout_p, KH, KW, ctx.prec)
             dw = dwp[:Cout, :, :, :Cin].permute(0, 3, 1, 2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbp = torch.zeros(cout_p, device=dev, dtype=torch.float32)

@@ -408,8 +408,8 @@ int craft_gemm(const float* A, long a_sm, long a_sk, long a_bs0, long a_bs1, con
                          accumulate, ksplit, prec, S(stream));
 }
 int craft_conv2d_wgrad(const float* x, long ldx, int cin, const float* dy, long ldy, int cout, int KH, int KW, int B, int H, int W,
-                       float* dW, int prec, void* stream) {
-  return launch_conv_wgrad(x, ldx, cin, dy, ldy, cout, KH, KW, B, H, W, dW, prec, S(stream));
+                       float* dW, float* ws, long ws_floats, int prec, void* stream) {
+  return launch_conv_wgrad(x, ldx, cin, dy, ldy, cout, KH, KW, B, H, W, dW, ws, ws_floats, prec, S(stream));
 }
 int craft_colsum(const float* x, long ld, long rows, int C, float* out, void* stream) { return launch_colsum(x, ld, rows, C, out, S(stream)); }
 int craft_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, void* stream) {

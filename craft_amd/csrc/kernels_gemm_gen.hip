@@ -8,77 +8,79 @@
 //     dP = dO . V^T        A = dO rows,        B = V  rows
 //     dV = P^T . dO        A = P  k-major,     B = dO k-major
 //     dQ = dS . K, dK = dS^T . Q               likewise
-// A k-major tile is fetched as float4s ALONG THE ROWS (coalesced: 8 lanes x 16 B per k) and scattered into the [row][k]
-// LDS layout the fragment reads expect.
+// A k-major tile is fetched with lane = row (a wave reads 256 contiguous bytes of one k-row per load), four consecutive k per
+// thread and group, so that every group is one vector write into the [row][k] LDS layout the fragment reads expect.
 #include "launch.hpp"
 
 namespace craft {
 
 // ---------------------------------------------------------------------------------------------
-// k-major staging registers: thread -> k = tid >> 3 (0..31), row chunks (tid & 7) + 8*i, 4 rows each
+// k-major operands.  Thread -> ONE row of the tile (lane = row: the 64 lanes of a wave read 256 contiguous bytes of a k-row)
+// and NG groups of 4 consecutive k; a group is 4 scalar loads (each coalesced across the wave) that land in one float4 =
+// (row, k..k+3), i.e. exactly what the [row][k] LDS layout stores as ONE 8-byte (16-bit modes) / 16-byte (fp32) write.
+// (The first version fetched float4s along the rows and scattered them with four 2-byte LDS writes per plane: 64 ds_write_b16
+// per thread and k-tile made the weight-gradient kernel LDS-write-bound at 25 % of the MFMA rate.)
+// zmask: 4 bits per group, bit 4*i + j = "k component j of group i is out of range / padding -> store zero".
 // ---------------------------------------------------------------------------------------------
-template <int ROWS> struct RegsF32T { float4 v[ROWS / 32]; unsigned zmask; };
+template <int ROWS> struct RegsF32K { float4 v[ROWS / 32]; unsigned zmask; };     // NG = 32 k / 4 / (256 / ROWS) = ROWS / 32
 
 template <int PREC, int ROWS>
-__device__ __forceinline__ void stage_store_piece(typename PrecT<PREC>::lds_t* S, const RegsF32T<ROWS>& r, int tid, int i) {
-  constexpr int LD = PrecT<PREC>::LD;
-  typedef typename PrecT<PREC>::lds_t lds_t;
-  const int k = tid >> 3, row = ((tid & 7) + 8 * i) * 4;
-  const bool z = (r.zmask >> i) & 1u;
+__device__ __forceinline__ void stage_store_piece(typename PrecT<PREC>::lds_t* S, const RegsF32K<ROWS>& r, int tid, int i) {
+  constexpr int LD = PrecT<PREC>::LD, NG = ROWS / 32;
+  const int row = tid % ROWS, kg = (tid / ROWS) * NG + i;
+  const unsigned z = r.zmask >> (4 * i);
   float4 v;
-  v.x = z ? 0.f : r.v[i].x; v.y = z ? 0.f : r.v[i].y; v.z = z ? 0.f : r.v[i].z; v.w = z ? 0.f : r.v[i].w;
-  if constexpr (PREC == CRAFT_PREC_F16X3) {
+  v.x = (z & 1u) ? 0.f : r.v[i].x; v.y = (z & 2u) ? 0.f : r.v[i].y; v.z = (z & 4u) ? 0.f : r.v[i].z; v.w = (z & 8u) ? 0.f : r.v[i].w;
+  if constexpr (PREC == CRAFT_PREC_F32) {
+    *reinterpret_cast<float4*>(&S[row * LD + kg * 4]) = v;
+  } else if constexpr (PREC == CRAFT_PREC_BF16) {
+    bf16x4 h;
+    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+    *reinterpret_cast<bf16x4*>(&S[row * LD + kg * 4]) = h;
+  } else if constexpr (PREC == CRAFT_PREC_F16) {
+    f16x4 h;
+    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+    *reinterpret_cast<f16x4*>(&S[row * LD + kg * 4]) = h;
+  } else {
     f16x4 h, l;
     split_f16x3(v, h, l);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      S[(row + j) * LD + k] = h[j];
-      S[(ROWS + row + j) * LD + k] = l[j];
-    }
-  } else {
-    S[(row + 0) * LD + k] = (lds_t)v.x;
-    S[(row + 1) * LD + k] = (lds_t)v.y;
-    S[(row + 2) * LD + k] = (lds_t)v.z;
-    S[(row + 3) * LD + k] = (lds_t)v.w;
+    *reinterpret_cast<f16x4*>(&S[row * LD + kg * 4]) = h;
+    *reinterpret_cast<f16x4*>(&S[(ROWS + row) * LD + kg * 4]) = l;
   }
 }
-template <int ROWS> __device__ __forceinline__ constexpr int stage_pieces(const RegsF32T<ROWS>&) { return ROWS / 32; }
+template <int ROWS> __device__ __forceinline__ constexpr int stage_pieces(const RegsF32K<ROWS>&) { return ROWS / 32; }
 template <int PREC, int ROWS>
-__device__ __forceinline__ void stage_store(typename PrecT<PREC>::lds_t* S, const RegsF32T<ROWS>& r, int tid) {
+__device__ __forceinline__ void stage_store(typename PrecT<PREC>::lds_t* S, const RegsF32K<ROWS>& r, int tid) {
 #pragma unroll
   for (int i = 0; i < ROWS / 32; ++i) stage_store_piece<PREC, ROWS>(S, r, tid, i);
 }
 
-// K-major fp32 operand: element (row, k) at base[k*ld + row], k in [k0, k1) (split-K range), rows >= nrows and k >= k1 read
-// as zero.  ld % 4 == 0, base 16-B aligned.  A chunk of 4 rows that straddles nrows is loaded element-wise from clamped
-// addresses (its out-of-range rows only reach output rows / columns the epilogue drops).
+// K-major fp32 operand: element (row, k) at base[k*ld + row], k in [k0, k1) (split-K range); rows >= nrows re-read the last valid
+// row (their products only reach output rows / columns the epilogue drops), k >= k1 is stored as zero.
 template <int ROWS> struct LoaderColsF32 {
-  typedef RegsF32T<ROWS> Regs;
-  const float* base;
+  typedef RegsF32K<ROWS> Regs;
+  static constexpr int NG = ROWS / 32;
+  const float* base;       // + row
   long ld;
-  int row[ROWS / 32];
-  int nrows, k0, k1, kk;
-  __device__ __forceinline__ void init(const float* base_, long ld_, int row0, int nrows_, int k0_, int k1_, int tid) {
-    base = base_; ld = ld_; nrows = nrows_; k0 = k0_; k1 = k1_;
-    kk = tid >> 3;
-#pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) row[i] = row0 + ((tid & 7) + 8 * i) * 4;
+  int k0, k1, kg0;
+  __device__ __forceinline__ void init(const float* base_, long ld_, int row0, int nrows, int k0_, int k1_, int tid) {
+    ld = ld_; k0 = k0_; k1 = k1_;
+    base = base_ + min(row0 + tid % ROWS, nrows - 1);
+    kg0 = (tid / ROWS) * NG;
   }
   __device__ __forceinline__ void fetch(int kt, Regs& r) const {
-    const int k = k0 + kt * BK + kk;
-    const bool kok = k < k1;
-    const float* p = base + (long)(kok ? k : k1 - 1) * ld;
-    unsigned zm = kok ? 0u : 0xffffffffu;
+    unsigned zm = 0u;
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-      const int r0 = row[i];
-      if (r0 + 4 <= nrows) {
-        r.v[i] = *reinterpret_cast<const float4*>(p + r0);
-      } else {
-        float4 t;
-        t.x = p[min(r0, nrows - 1)]; t.y = p[min(r0 + 1, nrows - 1)]; t.z = p[min(r0 + 2, nrows - 1)]; t.w = p[min(r0 + 3, nrows - 1)];
-        r.v[i] = t;
+    for (int i = 0; i < NG; ++i) {
+      const int k = k0 + kt * BK + (kg0 + i) * 4;
+      float t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = k + j < k1;
+        zm |= ok ? 0u : (1u << (4 * i + j));
+        t[j] = base[(long)(ok ? k + j : k1 - 1) * ld];                 // unconditional load from a valid address
       }
+      r.v[i] = make_float4(t[0], t[1], t[2], t[3]);
     }
     r.zmask = zm;
   }
@@ -166,11 +168,11 @@ int launch_gemm_gen(const float* A, long a_sm, long a_sk, long a_bs0, long a_bs1
   const bool at = a_sm == 1 && a_sk != 1, bt = b_sn == 1 && b_sk != 1;
   if (!at && a_sk != 1) return CRAFT_ERR_ARG;
   if (!bt && b_sk != 1) return CRAFT_ERR_ARG;
-  // 16-byte vector loads: leading dimensions and batch strides in multiples of 4 floats, bases 16-B aligned
-  const long lda = at ? a_sk : a_sm, ldb = bt ? b_sk : b_sn;
-  if ((lda & 3) || (ldb & 3) || (a_bs0 & 3) || (a_bs1 & 3) || (b_bs0 & 3) || (b_bs1 & 3)) return CRAFT_ERR_ALIGN;
-  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return CRAFT_ERR_ALIGN;
-  if ((!at || !bt) && (K & 3)) return CRAFT_ERR_ALIGN;       // a k-contiguous operand is read 4 k at a time
+  // a k-contiguous ("rows") operand is read with 16-byte vector loads: its leading dimension and batch strides are multiples of 4
+  // floats, its base is 16-byte aligned and K is a multiple of 4; a k-major operand is read with scalar loads (lane = row) and has
+  // no alignment requirement (the convolution weight gradient uses batch strides of ONE element: the tap shift)
+  if (!at && ((a_sm & 3) || (a_bs0 & 3) || (a_bs1 & 3) || (reinterpret_cast<uintptr_t>(A) & 15) || (K & 3))) return CRAFT_ERR_ALIGN;
+  if (!bt && ((b_sn & 3) || (b_bs0 & 3) || (b_bs1 & 3) || (reinterpret_cast<uintptr_t>(B) & 15) || (K & 3))) return CRAFT_ERR_ALIGN;
   GenGemmParams p = {};
   p.A = A; p.B = B; p.C = C;
   p.a_sm = a_sm; p.a_sk = a_sk; p.a_bs0 = a_bs0; p.a_bs1 = a_bs1;
@@ -203,57 +205,71 @@ int launch_gemm_gen(const float* A, long a_sm, long a_sk, long a_bs0, long a_bs1
 // grid (ceil(cout / 128), taps * ceil(cin / BN), ksplit); split-K partial sums are added with atomics.
 // ---------------------------------------------------------------------------------------------
 template <int ROWS> struct LoaderShiftColsF32 {
-  typedef RegsF32T<ROWS> Regs;
-  const float* base;
+  typedef RegsF32K<ROWS> Regs;
+  static constexpr int NG = ROWS / 32;
+  const float* base;       // + row (input channel)
   long ld;
-  int row[ROWS / 32];
-  int nrows, k0, k1, kk, H, W, dy, dx;
-  __device__ __forceinline__ void init(const float* base_, long ld_, int row0, int nrows_, int k0_, int k1_, int H_, int W_, int dy_,
-                                       int dx_, int tid) {
-    base = base_; ld = ld_; nrows = nrows_; k0 = k0_; k1 = k1_; H = H_; W = W_; dy = dy_; dx = dx_;
-    kk = tid >> 3;
-#pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) row[i] = row0 + ((tid & 7) + 8 * i) * 4;
+  int k0, k1, kg0, H, W, dy, dx;
+  unsigned magic_hw, magic_w;          // ceil(2^32 / (H*W)), ceil(2^32 / W): k / d = umulhi(k, magic) for k * d < 2^32 (launcher checks)
+  __device__ __forceinline__ void init(const float* base_, long ld_, int row0, int nrows, int k0_, int k1_, int H_, int W_, int dy_,
+                                       int dx_, unsigned magic_hw_, unsigned magic_w_, int tid) {
+    ld = ld_; k0 = k0_; k1 = k1_; H = H_; W = W_; dy = dy_; dx = dx_; magic_hw = magic_hw_; magic_w = magic_w_;
+    base = base_ + min(row0 + tid % ROWS, nrows - 1);
+    kg0 = (tid / ROWS) * NG;
   }
   __device__ __forceinline__ void fetch(int kt, Regs& r) const {
-    const int k = k0 + kt * BK + kk;
-    const int kc = k < k1 ? k : k1 - 1;
+    unsigned zm = 0u;
     const int hw = H * W;
-    const int b = kc / hw, rem = kc - b * hw;
-    const int y = rem / W, x = rem - y * W;
-    const int yy = y + dy, xx = x + dx;
-    const bool ok = k < k1 && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    const float* p = base + (ok ? ((long)b * hw + (long)yy * W + xx) : 0L) * ld;       // unconditional load, valid address
+    const long shift = (long)dy * W + dx;             // a valid tap of pixel p is pixel p + shift of the same image
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-      const int r0 = row[i];
-      if (r0 + 4 <= nrows) {
-        r.v[i] = *reinterpret_cast<const float4*>(p + r0);
-      } else {
-        float4 t;
-        t.x = p[min(r0, nrows - 1)]; t.y = p[min(r0 + 1, nrows - 1)]; t.z = p[min(r0 + 2, nrows - 1)]; t.w = p[min(r0 + 3, nrows - 1)];
-        r.v[i] = t;
+    for (int i = 0; i < NG; ++i) {
+      const int k = k0 + kt * BK + (kg0 + i) * 4;
+      // the 4 pixels of a group are consecutive: one pair of divisions, then x carries into y (and y into the next image)
+      const int kc = min(k, k1 - 1);
+      const int rem = kc - (int)__umulhi((unsigned)kc, magic_hw) * hw;
+      const int y = (int)__umulhi((unsigned)rem, magic_w), x = rem - y * W;
+      float t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int xj = x + j, yj = y;
+        if (xj >= W) { xj -= W; yj += 1; }
+        if (yj >= H) yj -= H;
+        const bool ok = k + j < k1 && (unsigned)(yj + dy) < (unsigned)H && (unsigned)(xj + dx) < (unsigned)W;
+        zm |= ok ? 0u : (1u << (4 * i + j));
+        t[j] = base[(ok ? (long)(k + j) + shift : 0L) * ld];
       }
+      r.v[i] = make_float4(t[0], t[1], t[2], t[3]);
     }
-    r.zmask = ok ? 0u : 0xffffffffu;
+    r.zmask = zm;
   }
 };
 
 struct WgradParams {
   const float* X; const float* dY; float* dW;
+  float* ws;                           // non-null: split z writes its partial tile to ws + z * (cout*taps*cin) with plain stores
   long ldx, ldy;
   int cin, cout, KH, KW, B, H, W;
-  int ksplit, kchunk, ntile_n;
+  int ksplit, kchunk, ntile_n, ntile_m;
+  unsigned magic_hw, magic_w;
 };
 
 template <int PREC, int BN>
 __global__ __launch_bounds__(NTHREADS) void k_conv_wgrad(WgradParams p) {
   constexpr int BM = 128, WM = 2, WN = 2, MT = BM / WM / 32, NT = BN / WN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tap = blockIdx.y / p.ntile_n, nt_i = blockIdx.y - tap * p.ntile_n;
-  const int m0 = blockIdx.x * BM, n0 = nt_i * BN;
+  // XCD-aware block -> (output tile, pixel range) map.  Every output tile of one pixel range re-reads the same rows of dY and X:
+  // if they are spread over the 8 XCDs (block b runs on XCD b % 8) each private L2 fetches the range from the Infinity Cache on
+  // its own and the kernel is bound by that fabric.  So: XCD x owns the pixel ranges x, x + 8, ... and walks all output tiles
+  // of one range back to back (their working set, kchunk x (cout + cin) x 4 B, stays in that XCD's 4 MB L2).
+  const int ntile = p.ntile_m * p.ntile_n * p.KH * p.KW;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int split = xcd + 8 * (j / ntile), tile = j - (j / ntile) * ntile;
+  const int mt_i = tile % p.ntile_m, yy = tile / p.ntile_m;
+  const int tap = yy / p.ntile_n, nt_i = yy - tap * p.ntile_n;
+  const int m0 = mt_i * BM, n0 = nt_i * BN;
   const int npix = p.B * p.H * p.W;
-  const int k0 = blockIdx.z * p.kchunk, k1 = min(npix, k0 + p.kchunk);
+  if (split >= p.ksplit) return;
+  const int k0 = split * p.kchunk, k1 = min(npix, k0 + p.kchunk);
   if (k0 >= k1) return;
   const int ky = tap / p.KW, kx = tap - ky * p.KW;
   f32x16 acc[MT][NT];
@@ -261,33 +277,56 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_wgrad(WgradParams p) {
   LoaderColsF32<BM> la;
   la.init(p.dY, p.ldy, m0, p.cout, k0, k1, tid);
   LoaderShiftColsF32<BN> lb;
-  lb.init(p.X, p.ldx, n0, p.cin, k0, k1, p.H, p.W, ky - p.KH / 2, kx - p.KW / 2, tid);
+  lb.init(p.X, p.ldx, n0, p.cin, k0, k1, p.H, p.W, ky - p.KH / 2, kx - p.KW / 2, p.magic_hw, p.magic_w, tid);
   gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, (k1 - k0 + BK - 1) / BK, acc, NoFold());
   const int rb = m0 + (wave / WN) * (BM / WM), cb = n0 + (wave % WN) * (BN / WN);
   const long taps = (long)p.KH * p.KW;
-  acc_foreach(acc, lane, [&](int r, int c, float v, int, int, int) {
-    const int co = rb + r, ci = cb + c;
-    if (co < p.cout && ci < p.cin) unsafeAtomicAdd(p.dW + ((long)co * taps + tap) * p.cin + ci, v);
-  });
+  if (p.ws) {
+    float* dst = p.ws + (long)split * p.cout * taps * p.cin;
+    acc_foreach(acc, lane, [&](int r, int c, float v, int, int, int) {
+      const int co = rb + r, ci = cb + c;
+      if (co < p.cout && ci < p.cin) dst[((long)co * taps + tap) * p.cin + ci] = v;
+    });
+  } else {
+    acc_foreach(acc, lane, [&](int r, int c, float v, int, int, int) {
+      const int co = rb + r, ci = cb + c;
+      if (co < p.cout && ci < p.cin) unsafeAtomicAdd(p.dW + ((long)co * taps + tap) * p.cin + ci, v);
+    });
+  }
 }
 
+int launch_reduce_replicas(const float* rep, int nrep, int n, float* out, hipStream_t s);
+
 int launch_conv_wgrad(const float* x, long ldx, int cin, const float* dy, long ldy, int cout, int KH, int KW, int B, int H, int W,
-                      float* dW, int prec, hipStream_t s) {
+                      float* dW, float* ws, long ws_floats, int prec, hipStream_t s) {
   if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return 0;
   if ((ldx & 3) || (ldy & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(dy) & 15)) return CRAFT_ERR_ALIGN;
   WgradParams p = {};
   p.X = x; p.dY = dy; p.dW = dW; p.ldx = ldx; p.ldy = ldy; p.cin = cin; p.cout = cout; p.KH = KH; p.KW = KW; p.B = B; p.H = H; p.W = W;
   const int bn = cin > 96 ? 128 : 64;
   p.ntile_n = (cin + bn - 1) / bn;
+  p.ntile_m = (cout + 127) / 128;
+  if ((double)B * H * W * ((double)H * W) >= 4294967296.0 || H * W < 2 || W < 2) return CRAFT_ERR_UNSUPPORTED;   // magic-number division range
+  p.magic_hw = (unsigned)((4294967296ULL + (unsigned long long)(H * W) - 1) / (unsigned long long)(H * W));
+  p.magic_w = (unsigned)((4294967296ULL + (unsigned long long)W - 1) / (unsigned long long)W);
   const long npix = (long)B * H * W;
   const long tiles = (long)((cout + 127) / 128) * p.ntile_n * KH * KW;
   long want = (768 + tiles - 1) / tiles;
   const long maxs = (npix + 511) / 512;
   p.ksplit = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
+  // split-K partial sums: plain stores into the caller's scratch + one reduction pass when it is large enough (millions of
+  // same-line fp32 atomics in L2 cost more than the products); atomics straight into dW otherwise
+  const long nw = (long)cout * KH * KW * cin;
+  p.ws = (ws != nullptr && p.ksplit > 1 && ws_floats >= nw * p.ksplit) ? ws : nullptr;
   p.kchunk = (int)((((npix + p.ksplit - 1) / p.ksplit) + BK - 1) / BK * BK);
-  dim3 grid((cout + 127) / 128, p.ntile_n * KH * KW, p.ksplit);
+  const int nz = (int)((npix + p.kchunk - 1) / p.kchunk);          // splits that actually own pixels (the others would leave holes)
+  p.ksplit = nz;
+  const int ntile = p.ntile_m * p.ntile_n * KH * KW;
+  dim3 grid((unsigned)(8 * ntile * ((p.ksplit + 7) / 8)), 1, 1);
 #define GO(PR) do { if (bn == 128) hipLaunchKernelGGL((k_conv_wgrad<PR, 128>), grid, dim3(NTHREADS), 0, s, p); \
-                    else hipLaunchKernelGGL((k_conv_wgrad<PR, 64>), grid, dim3(NTHREADS), 0, s, p); return (int)hipGetLastError(); } while (0)
+                    else hipLaunchKernelGGL((k_conv_wgrad<PR, 64>), grid, dim3(NTHREADS), 0, s, p); \
+                    if (hipGetLastError() != hipSuccess) return (int)hipGetLastError(); \
+                    return p.ws ? launch_reduce_replicas(p.ws, p.ksplit, (int)nw, dW, s) : 0; } while (0)
   if (prec == CRAFT_PREC_F32) GO(CRAFT_PREC_F32);
   if (prec == CRAFT_PREC_BF16) GO(CRAFT_PREC_BF16);
   if (prec == CRAFT_PREC_F16) GO(CRAFT_PREC_F16);

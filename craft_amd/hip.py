@@ -64,7 +64,7 @@ _SIGS = {
     "craft_convex_upsample": [P, P, I, I, I, P, P],
     # ---- training
     "craft_gemm": [P, L, L, L, L, P, L, L, L, L, P, L, L, L, I, I, I, I, I, F, I, I, I, P],
-    "craft_conv2d_wgrad": [P, L, I, P, L, I, I, I, I, I, I, P, I, P],
+    "craft_conv2d_wgrad": [P, L, I, P, L, I, I, I, I, I, I, P, P, L, I, P],
     "craft_colsum": [P, L, L, I, P, P],
     "craft_act_fwd": [P, L, P, L, L, I, I, F, P],
     "craft_act_bwd": [P, L, P, L, P, L, L, I, I, F, P],

@@ -289,12 +289,15 @@ int craft_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
  *
  * craft_gemm:  C[z][m][n] = alpha * sum_k A(z,m,k) * B(z,n,k)  (+ C[z][m][n] when accumulate), z = z0*zdiv + z1 < batch,
  *   A(z,m,k) at A + z0*a_bs0 + z1*a_bs1 + m*a_sm + k*a_sk with a_sk == 1 (k contiguous: rows operand) or a_sm == 1 (k-major:
- *   a transposed operand read in place); likewise B with (b_sn, b_sk).  C row-major with row stride ldc.  Leading dimensions
- *   and batch strides are multiples of 4 floats, bases 16-byte aligned; M, N, K arbitrary.  ksplit: K is cut into that many
+ *   a transposed operand read in place); likewise B with (b_sn, b_sk).  C row-major with row stride ldc.  A rows operand has
+ *   its leading dimension and batch strides in multiples of 4 floats, a 16-byte aligned base and K % 4 == 0; a k-major operand has
+ *   no alignment requirement (batch strides of one element are legal: shifted views of one buffer); M, N arbitrary.  ksplit: K is cut into that many
  *   ranges whose partial products are added with atomics (needs accumulate = 1 and a zero-filled or running C); 0 = choose
  *   so that the grid fills the chip (weight gradients: M x N is tiny, K = all rows).  prec as craft_linear.
  * craft_conv2d_wgrad: dW[co][ky][kx][ci] += sum_pix dY[pix][co] * X[pix + (ky-KH/2, kx-KW/2)][ci]  (stride 1, zero padding;
  *   x [B*H*W][cin] row stride ldx, dy [B*H*W][cout] row stride ldy; dW in the packed [cout][KH][KW][cin] layout, ACCUMULATED).
+ *   ws (or NULL) / ws_floats: scratch for the split-K partial sums; with >= 32 * cout*KH*KW*cin floats every split stores its
+ *   partial tile with plain writes and one pass folds them into dW, else the partial sums are added with fp32 atomics.
  * craft_colsum: out[c] += sum_r x[r][c]   (bias gradients).
  * craft_act_fwd / craft_act_bwd: y = scale * act(x);  dx = scale * dy * act'(.) evaluated from the UNSCALED output y / scale the
  *   caller kept (relu: y > 0, tanh: 1 - y^2, sigmoid (CRAFT_ACT_SIGMOID = 3): y (1 - y)); C % 4 == 0.
@@ -305,7 +308,7 @@ int craft_gemm(const float* A, long a_sm, long a_sk, long a_bs0, long a_bs1, con
                long b_bs1, float* C, long ldc, long c_bs0, long c_bs1, int zdiv, int batch, int M, int N, int K, float alpha,
                int accumulate, int ksplit, int prec, void* stream);
 int craft_conv2d_wgrad(const float* x, long ldx, int cin, const float* dy, long ldy, int cout, int KH, int KW, int B, int H, int W,
-                       float* dW, int prec, void* stream);
+                       float* dW, float* ws, long ws_floats, int prec, void* stream);
 int craft_colsum(const float* x, long ld, long rows, int C, float* out, void* stream);
 int craft_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, void* stream);
 int craft_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,
