@@ -8,7 +8,7 @@ does (uniform factors, random order of the four operations) from ``np.random`` a
 those draws cannot be replayed).  Pixel semantics: ``random_shift`` is pinned bit-for-bit by a fixture produced by the
 reference's own function (tests/golden/harness.npz); resize / colour steps restate cv2.INTER_LINEAR / PIL in float and are
 checked against numpy restatements in the tests -- cv2, PIL's enhancers and torchvision are absent from this image, so their
-8-bit fixed-point rounding is NOT pinned (documented gap).  ``SparseFlowAugmentor`` (KITTI) is not built.
+8-bit fixed-point rounding is NOT pinned (documented gap).  ``SparseFlowAugmentor`` (KITTI): the sparse flow map is moved, not interpolated (``craft_aug_sparse``; exact integer logic, checked against a numpy restatement of resize_sparse_flow_map).
 """
 from __future__ import annotations
 
@@ -160,3 +160,58 @@ class FlowAugmentor:
             dx, dy = draw_shift(self.shift_sigmas)
             img1, img2, flow, valid = random_shift(img1, img2, flow, dx, dy)
         return img1, img2, flow, valid
+
+
+def sparse_resize_crop(flow: torch.Tensor, valid: torch.Tensor, crop, y0: int, x0: int, fx: float = 1.0, fy: float = 1.0, hflip: bool = False):
+    """resize_sparse_flow_map (augmentor.py:249-281) + h-flip + crop on the GPU -> (flow [ch, cw, 2], valid [ch, cw])."""
+    flow, valid = _f(flow), _f(valid)
+    H, W, _ = flow.shape
+    Hs, Ws = int(round(H * fy)), int(round(W * fx))
+    owner = torch.empty(Hs * Ws, device=flow.device, dtype=torch.int32)
+    of = torch.empty(crop[0], crop[1], 2, device=flow.device, dtype=torch.float32)
+    ov = torch.empty(crop[0], crop[1], device=flow.device, dtype=torch.float32)
+    call("craft_aug_sparse", flow, valid, H, W, float(fx), float(fy), int(hflip), int(y0), int(x0), crop[0], crop[1], owner, of, ov)
+    return of, ov
+
+
+class SparseFlowAugmentor(FlowAugmentor):
+    """Sparse-flow augmentation (KITTI / HD1K; augmentor.py:207-328): symmetric photometric jitter only, eraser, one isotropic
+    scale (no stretch), h-flip (if enabled), crop with margins; the flow map is moved pixel by pixel instead of interpolated.
+    ``__call__(img1, img2, flow, valid)`` -> (img1, img2, flow, valid)."""
+
+    def __init__(self, ds_name, crop_size, min_scale=-0.2, max_scale=0.5, spatial_aug_prob=0.8, do_flip=False, shift_prob=0, shift_sigmas=(16, 10)):
+        super().__init__(ds_name, crop_size, min_scale, max_scale, spatial_aug_prob, do_flip=do_flip, shift_prob=shift_prob, shift_sigmas=shift_sigmas)
+        self.jitter = dict(brightness=0.3, contrast=0.3, saturation=0.3, hue=0.3 / 3.14)
+
+    def color_transform(self, img1, img2):
+        stack = torch.cat([img1, img2], dim=0)
+        order, fac = self._jitter_params()
+        for op in order:
+            photo_step(stack, int(op), fac[op])
+        H = img1.shape[0]
+        return stack[:H].contiguous(), stack[H:].contiguous()
+
+    def eraser_transform(self, img1, img2):
+        return super().eraser_transform(img1, img2, bounds=(50, 100))
+
+    def __call__(self, img1, img2, flow, valid):
+        img1, img2, flow, valid = _f(img1).clone(), _f(img2).clone(), _f(flow), _f(valid)
+        img1, img2 = self.color_transform(img1, img2)
+        img1, img2 = self.eraser_transform(img1, img2)
+        ht, wd = img1.shape[:2]
+        min_scale = np.maximum((self.crop_size[0] + 1) / float(ht), (self.crop_size[1] + 1) / float(wd))
+        scale = 2 ** np.random.uniform(self.min_scale, self.max_scale)
+        s = float(np.clip(scale, min_scale, None))
+        do_resize = np.random.rand() < self.spatial_aug_prob
+        fx = fy = s if do_resize else 1.0
+        hs, ws = (int(round(ht * fy)), int(round(wd * fx)))
+        hflip = bool(self.do_flip and np.random.rand() < 0.5)
+        margin_y, margin_x = 20, 50
+        y0 = np.random.randint(0, hs - self.crop_size[0] + margin_y)
+        x0 = np.random.randint(-margin_x, ws - self.crop_size[1] + margin_x)
+        y0 = int(np.clip(y0, 0, hs - self.crop_size[0]))
+        x0 = int(np.clip(x0, 0, ws - self.crop_size[1]))
+        a = spatial(img1, self.crop_size, y0, x0, fx, fy, do_resize, hflip, False)
+        b = spatial(img2, self.crop_size, y0, x0, fx, fy, do_resize, hflip, False)
+        f, v = sparse_resize_crop(flow, valid, self.crop_size, y0, x0, fx, fy, hflip)
+        return a, b, f, v

@@ -484,6 +484,10 @@ int craft_aug_spatial(const float* src, int H, int W, int C, int do_resize, floa
                       int cw, int is_flow, float* out, void* stream) {
   return launch_aug_spatial(src, H, W, C, do_resize, fx, fy, hflip, vflip, y0, x0, ch, cw, is_flow, out, S(stream));
 }
+int craft_aug_sparse(const float* flow, const float* valid, int H, int W, float fx, float fy, int hflip, int y0, int x0, int ch, int cw,
+                     int* owner, float* out_flow, float* out_valid, void* stream) {
+  return launch_aug_sparse(flow, valid, H, W, fx, fy, hflip, y0, x0, ch, cw, owner, out_flow, out_valid, S(stream));
+}
 int craft_aug_photo(float* img, long npix, int op, float factor, float mean, void* stream) {
   return launch_aug_photo(img, npix, op, factor, mean, S(stream));
 }

@@ -130,7 +130,41 @@ __global__ void k_aug_shift(const float* __restrict__ img1, const float* __restr
   valid[i] = in ? 1.f : 0.f;
 }
 
+// SparseFlowAugmentor.resize_sparse_flow_map (augmentor.py:249-281): every valid source pixel (x, y) lands on (round(x fx),
+// round(y fy)) if that is strictly inside (0, wd1) x (0, ht1); numpy's fancy assignment lets the LAST source pixel (row-major
+// order) win a contested target.  Pass 1 records the largest source index per target (atomicMax), pass 2 gathers: deterministic
+// and identical to the reference's order.  Then flips / crop like the dense path (no interpolation: values are moved, not mixed).
+__global__ void k_aug_sparse_claim(const float* __restrict__ valid, int H, int W, float fx, float fy, int Hs, int Ws, int* __restrict__ owner) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)H * W) return;
+  if (valid[i] < 1.f) return;
+  const int x = (int)(i % W), y = (int)(i / W);
+  const int xx = (int)rintf((float)x * fx), yy = (int)rintf((float)y * fy);
+  if (xx > 0 && xx < Ws && yy > 0 && yy < Hs) atomicMax(&owner[(long)yy * Ws + xx], (int)i);
+}
+__global__ void k_aug_sparse_gather(const float* __restrict__ flow, const int* __restrict__ owner, int Hs, int Ws, float fx, float fy,
+                                    int hflip, int y0, int x0, int ch, int cw, float* __restrict__ oflow, float* __restrict__ ovalid) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)ch * cw) return;
+  const int x = (int)(i % cw), y = (int)(i / cw);
+  const int ys = y0 + y, xs = hflip ? Ws - 1 - (x0 + x) : x0 + x;
+  const int src = owner[(long)ys * Ws + xs];
+  float u = 0.f, v = 0.f, ok = 0.f;
+  if (src >= 0) { u = flow[2 * (long)src] * fx; v = flow[2 * (long)src + 1] * fy; ok = 1.f; if (hflip) u = -u; }
+  oflow[2 * i] = u; oflow[2 * i + 1] = v; ovalid[i] = ok;
+}
+
 #define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, s
+int launch_aug_sparse(const float* flow, const float* valid, int H, int W, float fx, float fy, int hflip, int y0, int x0, int ch, int cw,
+                      int* owner, float* oflow, float* ovalid, hipStream_t s) {
+  const int Hs = (int)rint((double)H * fy), Ws = (int)rint((double)W * fx);
+  if (y0 < 0 || x0 < 0 || y0 + ch > Hs || x0 + cw > Ws) return CRAFT_ERR_ARG;
+  hipError_t e = hipMemsetAsync(owner, 0xff, sizeof(int) * (size_t)Hs * Ws, s);       // -1
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(k_aug_sparse_claim, GRID1((long)H * W), valid, H, W, fx, fy, Hs, Ws, owner);
+  hipLaunchKernelGGL(k_aug_sparse_gather, GRID1((long)ch * cw), flow, owner, Hs, Ws, fx, fy, hflip, y0, x0, ch, cw, oflow, ovalid);
+  return (int)hipGetLastError();
+}
 int launch_aug_spatial(const float* src, int H, int W, int C, int do_resize, float fx, float fy, int hflip, int vflip, int y0, int x0, int ch,
                        int cw, int is_flow, float* out, hipStream_t s) {
   if (H <= 0 || W <= 0 || ch <= 0 || cw <= 0 || C <= 0) return CRAFT_ERR_ARG;

@@ -179,6 +179,8 @@ int launch_gru_zr_bwd(const float* dz, const float* drh, long lddrh, const float
 // ---- input pipeline (kernels_augment.hip) ----
 int launch_aug_spatial(const float* src, int H, int W, int C, int do_resize, float fx, float fy, int hflip, int vflip, int y0, int x0, int ch,
                        int cw, int is_flow, float* out, hipStream_t s);
+int launch_aug_sparse(const float* flow, const float* valid, int H, int W, float fx, float fy, int hflip, int y0, int x0, int ch, int cw,
+                      int* owner, float* oflow, float* ovalid, hipStream_t s);
 int launch_aug_photo(float* img, long npix, int op, float factor, float mean, hipStream_t s);
 int launch_aug_erase(float* img, int H, int W, const int* rects, int nrect, float mr, float mg, float mb, hipStream_t s);
 int launch_aug_shift(const float* img1, const float* img2, const float* flow, int H, int W, int dx, int dy, float* o1, float* o2, float* oflow,

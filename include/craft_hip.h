@@ -388,6 +388,12 @@ int craft_gru_zr_bwd(const float* dz, const float* drh, long lddrh, const float*
 int craft_aug_spatial(const float* src, int H, int W, int C, int do_resize, float fx, float fy, int hflip, int vflip, int y0, int x0, int ch,
                       int cw, int is_flow, float* out, void* stream);
 int craft_aug_photo(float* img, long npix, int op, float factor, float mean, void* stream);
+/* SparseFlowAugmentor (KITTI; augmentor.py:249-316): resize_sparse_flow_map -- every valid source pixel moves to (round(x fx), round(y
+ * fy)) when strictly inside the resized frame, the last source pixel in row-major order winning a contested target -- followed by
+ * the h-flip and the crop at (y0, x0): out_flow [ch][cw][2] (scaled by (fx, fy), u negated by the flip), out_valid [ch][cw].
+ * owner: scratch of round(H fy) * round(W fx) ints.  fx = fy = 1 is the no-resize case. */
+int craft_aug_sparse(const float* flow, const float* valid, int H, int W, float fx, float fy, int hflip, int y0, int x0, int ch, int cw,
+                     int* owner, float* out_flow, float* out_valid, void* stream);
 int craft_aug_erase(float* img, int H, int W, const int* rects, int nrect, float mr, float mg, float mb, void* stream);
 int craft_aug_shift(const float* img1, const float* img2, const float* flow, int H, int W, int dx, int dy, float* out1, float* out2,
                     float* out_flow, float* valid, void* stream);

@@ -138,3 +138,51 @@ def test_flow_augmentor_end_to_end(device):
     random.seed(3); np.random.seed(3)
     y = aug(img1, img2, flow)
     assert all(torch.equal(p, q) for p, q in zip(x[:3], y[:3]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fx,hflip", [(1.0, False), (1.31, False), (0.77, True)])
+def test_sparse_flow_resize(device, fx, hflip):
+    """craft_aug_sparse vs a numpy restatement of SparseFlowAugmentor.resize_sparse_flow_map + flip + crop (augmentor.py:249-316),
+    including numpy's last-writer-wins order on contested targets (fx < 1 makes many collisions)."""
+    from craft_amd.augment import sparse_resize_crop
+    r = np.random.RandomState(8)
+    H, W = 50, 70
+    flow = (r.standard_normal((H, W, 2)) * 6).astype(np.float32)
+    valid = (r.random_sample((H, W)) > 0.5).astype(np.float32)
+    fy = fx
+    coords = np.stack(np.meshgrid(np.arange(W), np.arange(H)), axis=-1).reshape(-1, 2).astype(np.float32)
+    fl, va = flow.reshape(-1, 2), valid.reshape(-1)
+    c0, f0 = coords[va >= 1], fl[va >= 1]
+    ht1, wd1 = int(round(H * fy)), int(round(W * fx))
+    c1, f1 = c0 * [fx, fy], f0 * [fx, fy]
+    xx, yy = np.round(c1[:, 0]).astype(np.int32), np.round(c1[:, 1]).astype(np.int32)
+    v = (xx > 0) & (xx < wd1) & (yy > 0) & (yy < ht1)
+    fimg, vimg = np.zeros([ht1, wd1, 2], np.float32), np.zeros([ht1, wd1], np.int32)
+    fimg[yy[v], xx[v]] = f1[v]
+    vimg[yy[v], xx[v]] = 1
+    if hflip:
+        fimg, vimg = fimg[:, ::-1] * [-1.0, 1.0], vimg[:, ::-1]
+    crop = (min(30, ht1 - 3), min(40, wd1 - 4))
+    y0, x0 = 2, 3
+    ref_f, ref_v = fimg[y0:y0 + crop[0], x0:x0 + crop[1]], vimg[y0:y0 + crop[0], x0:x0 + crop[1]]
+    gf, gv = sparse_resize_crop(torch.from_numpy(flow).to(device), torch.from_numpy(valid).to(device), crop, y0, x0, fx, fy, hflip)
+    assert np.array_equal(gv.cpu().numpy(), ref_v.astype(np.float32))
+    assert np.allclose(gf.cpu().numpy(), ref_f, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_sparse_augmentor_end_to_end(device):
+    from craft_amd.augment import SparseFlowAugmentor
+    r = np.random.RandomState(9)
+    H, W, crop = 150, 400, (96, 256)
+    img1 = torch.from_numpy(r.randint(0, 256, size=(H, W, 3)).astype(np.float32)).to(device)
+    img2 = torch.from_numpy(r.randint(0, 256, size=(H, W, 3)).astype(np.float32)).to(device)
+    flow = torch.from_numpy((r.standard_normal((H, W, 2)) * 3).astype(np.float32)).to(device)
+    valid = torch.from_numpy((r.random_sample((H, W)) > 0.6).astype(np.float32)).to(device)
+    aug = SparseFlowAugmentor("kitti", crop, min_scale=-0.2, max_scale=0.4, do_flip=False)
+    for sd in range(6):
+        random.seed(sd); np.random.seed(sd)
+        a, b, f, v = aug(img1, img2, flow, valid)
+        assert a.shape == (crop[0], crop[1], 3) and f.shape == (crop[0], crop[1], 2) and v.shape == crop
+        assert 0.05 < float(v.mean()) < 0.6 and float((f.abs().sum(-1) * (1 - v)).max()) == 0.0
