@@ -122,7 +122,7 @@ def mm_scores(xq: Tensor, xk: Tensor, Wq: Tensor, bq: Optional[Tensor], Wk: Tens
 def clamp_rule(S: Tensor) -> Tensor:
     """setrans.py:520-529: if the global max (over batch, modes, i, j) exceeds attn_clip, clamp the
     whole tensor to [-100, 100]; only the positive max is tested."""
-    if float(S.max()) > ATTN_CLIP:
+    if float(S.detach().max()) > ATTN_CLIP:
         return S.clamp(-ATTN_CLIP, ATTN_CLIP)
     return S
 
