@@ -499,4 +499,32 @@ int craft_aug_shift(const float* img1, const float* img2, const float* flow, int
   return launch_aug_shift(img1, img2, flow, H, W, dx, dy, out1, out2, out_flow, valid, S(stream));
 }
 
+// ---- host-side helper of the evaluation harness (no device work) ----------------------------------------------------
+// PNG scan-line unfiltering (filter types 0-4, PNG spec 9.2): rows [h][1 + stride] (filter byte + filtered bytes) -> out [h][stride].
+// Average and Paeth are sequential along the line, so the Python reader (craft_amd/flow_io.py) needed one interpreter iteration per
+// byte: seconds per KITTI frame.  Returns 0, or -1 on an unknown filter type.
+int craft_png_unfilter(const unsigned char* rows, int h, int stride, int bpp, unsigned char* out) {
+  for (int y = 0; y < h; ++y) {
+    const unsigned char* in = rows + (long)y * (stride + 1);
+    unsigned char* cur = out + (long)y * stride;
+    const unsigned char* prev = y ? cur - stride : nullptr;
+    const int ft = in[0];
+    ++in;
+    if (ft < 0 || ft > 4) return -1;
+    for (int x = 0; x < stride; ++x) {
+      const int a = x >= bpp ? cur[x - bpp] : 0, b = prev ? prev[x] : 0, c = (prev && x >= bpp) ? prev[x - bpp] : 0;
+      int pr = 0;
+      if (ft == 1) pr = a;
+      else if (ft == 2) pr = b;
+      else if (ft == 3) pr = (a + b) >> 1;
+      else if (ft == 4) {
+        const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+        pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+      }
+      cur[x] = (unsigned char)(in[x] + pr);
+    }
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -137,33 +137,14 @@ def _png_read(path: str) -> np.ndarray:
     if len(data) != h * (stride + 1):
         raise ValueError(f"{path}: PNG payload size mismatch")
     rows = np.frombuffer(data, dtype=np.uint8).reshape(h, stride + 1)
-    out = np.zeros((h, stride), dtype=np.uint8)
-    prev = np.zeros(stride, dtype=np.int32)
-    for y in range(h):
-        ft, line = int(rows[y, 0]), rows[y, 1:].astype(np.int32)
-        if ft == 0:
-            cur = line
-        elif ft == 2:                          # Up
-            cur = (line + prev) & 255
-        elif ft == 1:                          # Sub: a running sum per byte lane
-            cur = line.reshape(-1, bpp).cumsum(axis=0).reshape(-1) & 255
-        elif ft in (3, 4):                     # Average / Paeth: sequential in x
-            cur = np.zeros(stride, dtype=np.int32)
-            for x in range(stride):
-                a = int(cur[x - bpp]) if x >= bpp else 0
-                b = int(prev[x])
-                if ft == 3:
-                    pr = (a + b) >> 1
-                else:
-                    c = int(prev[x - bpp]) if x >= bpp else 0
-                    p = a + b - c
-                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
-                    pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
-                cur[x] = (int(line[x]) + pr) & 255
-        else:
-            raise ValueError(f"{path}: bad PNG filter type {ft}")
-        out[y] = cur
-        prev = cur
+    out = np.empty((h, stride), dtype=np.uint8)
+    # unfiltering is sequential along a scan line (Average / Paeth): done by the extension's host helper, not per byte in Python
+    import ctypes
+    from .hip import load
+    fn = load().craft_png_unfilter
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    if fn(rows.ctypes.data, h, stride, bpp, out.ctypes.data) != 0:
+        raise ValueError(f"{path}: bad PNG filter type")
     if depth == 16:
         arr = out.reshape(h, w, ch, 2)
         arr = (arr[..., 0].astype(np.uint16) << 8) | arr[..., 1].astype(np.uint16)     # big-endian samples
@@ -235,13 +216,21 @@ def read_image(path: str) -> np.ndarray:
     """png / jpg / ppm -> uint8 [H, W, 3] (grey images are tiled, alpha dropped: datasets.py:112-119)."""
     ext = os.path.splitext(path)[-1].lower()
     if ext == ".png":
-        img = _png_read(path)
-        if img.dtype == np.uint16:
-            img = (img >> 8).astype(np.uint8)
+        try:
+            img = _png_read(path)
+            if img.dtype == np.uint16:
+                img = (img >> 8).astype(np.uint8)
+        except ValueError as e:
+            if "unsupported PNG" not in str(e):
+                raise
+            from PIL import Image                      # palette / 1-2-4 bit / interlaced files: Pillow expands them
+            img = np.array(Image.open(path).convert("RGB"))
     else:
         from PIL import Image
         img = np.array(Image.open(path))
     img = img.astype(np.uint8)
+    if img.ndim == 3 and img.shape[2] == 2:            # grey + alpha
+        img = img[..., 0]
     if img.ndim == 2:
         img = np.tile(img[..., None], (1, 1, 3))
     return img[..., :3]

@@ -93,6 +93,9 @@ _SIGS = {
 }
 
 
+# host-side helpers of the library (no stream argument, host pointers): bound where they are used
+HOST_FUNCTIONS = {"craft_png_unfilter"}
+
 # Named policies.  "mixed" is the default for mixed_precision=True: split-fp16 (F16X3: fp32 operands as hi + lo fp16 planes,
 # 3 fp16 MFMAs per product, fp32 accumulate -- fp32-class results) for the projections, Q K^T and every convolution, and
 # plain fp16 storage + fp16 MFMA for the attention probabilities (P V); measured mean end-point deviation from the fp32

@@ -398,6 +398,10 @@ int craft_aug_erase(float* img, int H, int W, const int* rects, int nrect, float
 int craft_aug_shift(const float* img1, const float* img2, const float* flow, int H, int W, int dx, int dy, float* out1, float* out2,
                     float* out_flow, float* valid, void* stream);
 
+/* Host helper of the evaluation harness (frame_utils.py:70-120 reads KITTI's 16-bit PNGs through cv2): PNG scan-line unfiltering,
+ * filter types 0-4; rows [h][1 + stride] -> out [h][stride], bpp = bytes per pixel.  HOST pointers, no stream, no device work. */
+int craft_png_unfilter(const unsigned char* rows, int h, int stride, int bpp, unsigned char* out);
+
 /* CRAFT.upsample_flow (network.py:151-162): mask tokens [B*N][576], flow tokens [B*N][2] -> up NCHW
  * [B][2][8*H8][8*W8]. */
 int craft_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, void* stream);

@@ -182,3 +182,20 @@ def test_dataset_walkers(tmp_path):
     (tmp_path / "FlyingChairs_release" / "FlyingChairs_train_val.txt").write_text("1\n2\n2\n")
     assert len(FlyingChairs(split="validation", root=str(croot))) == 2
     assert len(FlyingChairs(split="training", root=str(croot))) == 1
+
+
+def test_read_image_palette_and_grey_alpha(tmp_path):
+    """Palette PNGs and grey+alpha PNGs: read_image must hand back uint8 [H, W, 3] like the reference's reader."""
+    from PIL import Image
+    from craft_amd import flow_io
+    r = np.random.RandomState(2)
+    rgb = r.randint(0, 256, size=(9, 13, 3)).astype(np.uint8)
+    Image.fromarray(rgb).convert("P", palette=Image.ADAPTIVE, colors=16).save(str(tmp_path / "pal.png"))
+    ref = np.array(Image.open(str(tmp_path / "pal.png")).convert("RGB"))
+    got = flow_io.read_image(str(tmp_path / "pal.png"))
+    assert got.shape == (9, 13, 3) and got.dtype == np.uint8 and np.array_equal(got, ref)
+    la = np.stack([r.randint(0, 256, size=(9, 13)), r.randint(0, 256, size=(9, 13))], -1).astype(np.uint8)
+    flow_io._png_write(str(tmp_path / "la.png"), la[..., 0])
+    Image.fromarray(la, mode="LA").save(str(tmp_path / "la.png"))
+    got = flow_io.read_image(str(tmp_path / "la.png"))
+    assert got.shape == (9, 13, 3) and np.array_equal(got[..., 0], la[..., 0]) and np.array_equal(got[..., 2], la[..., 0])
