@@ -105,6 +105,13 @@ int craft_corr_build(const float* q, long ldq, const float* k, long ldk, int B, 
                            pyr0, sums, ws, prec, S(stream));
 }
 
+int craft_corr_build_pyramid(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d, float scale,
+                             const float* pos_tab, int R, float pos_w, float w_aggr, const unsigned* clamp_ord, float* pyr0,
+                             float* pyr1, float* pyr2, float* pyr3, double* sums, void* ws, int prec, void* stream) {
+  return launch_corr_build_pyramid(make_score(q, ldq, k, ldk, B, H8, W8, M, d, scale, pos_tab, R, pos_w, -1, clamp_ord), w_aggr,
+                                   pyr0, pyr1, pyr2, pyr3, sums, ws, prec, S(stream));
+}
+
 int craft_corr_finish(const float* pyr0, float* pyr1, float* pyr2, float* pyr3, const double* sums, float* mu_rstd, int B,
                       int H8, int W8, int do_norm, void* stream) {
   const long N = (long)H8 * W8;

@@ -389,6 +389,219 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build4s(ScoreParams p, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same build with the whole pyramid written from the tile (corr.py:186-189 fused in; level 0 is never read back --
+// k_corr_pyramid re-read 604 MB at 768x1024).  Operand roles are SWAPPED with respect to k_corr_build4s: the KEYS are the MFMA
+// rows and the queries the columns, and the 64 keys of a wave are an 8 x 8 CELL of the key image enumerated so that MFMA row
+// r = (e & 3) + 8 (e >> 2) + 4 g of tile mt is key (dy = 4 mt + (e >> 2), dx = 4 g + (e & 3)).  A lane (one query, g = lane >> 5)
+// then holds a 4 x 4 block of keys per tile in its 16 accumulator registers: the 2x2 / 4x4 averages of levels 1 and 2 are
+// register adds, level 3 adds the two tiles and the partner lane (one shuffle), and level 0 leaves as 16-byte stores.
+// (A first fused version kept keys across lanes and pooled with DPP / ds_bpermute: 0.95 ms against 0.75 ms unfused.)
+// Block = 4 waves: (wave >> 1) = one of two horizontally adjacent cells, (wave & 1) = one of two groups of 32 queries.
+// ---------------------------------------------------------------------------------------------
+template <bool CLAMP, bool BIAS, bool VEC>
+__device__ __forceinline__ void corr4t_epilogue(const ScoreParams& p, const f32x16 (&acc)[4][2], float wl, long q, bool qvalid, int qh,
+                                                int qw, int cy, int cx, int g, const float* s_tab, int R, int TW, float* __restrict__ pyr0,
+                                                float* __restrict__ pyr1, float* __restrict__ pyr2, float* __restrict__ pyr3, float& s1,
+                                                float& s2) {
+  const int N = p.N, H8 = p.H8, W8 = p.W8;
+  const int h1 = H8 >> 1, w1 = W8 >> 1, h2 = h1 >> 1, w2 = w1 >> 1, h3 = h2 >> 1, w3 = w2 >> 1;
+  const unsigned umax = 2 * R + 2;
+  const int kw0 = 8 * cx + 4 * g;
+  float cell = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    float cv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float sv[4], tv[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        sv[m] = CLAMP ? __builtin_amdgcn_fmed3f(acc[m][mt][e], -CRAFT_ATTN_CLIP, CRAFT_ATTN_CLIP) : acc[m][mt][e];
+        tv[m] = wl * sv[m];
+      }
+      const float mx = fmaxf(fmaxf(tv[0], tv[1]), fmaxf(tv[2], tv[3]));
+      float den = 0.f, num = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float ex = __builtin_amdgcn_exp2f(tv[m] - mx);
+        den += ex;
+        num += sv[m] * ex;
+      }
+      float c = num * __builtin_amdgcn_rcpf(den);
+      if (BIAS) {
+        const int kh = 8 * cy + 4 * mt + (e >> 2), kw = kw0 + (e & 3);
+        const unsigned u = min((unsigned)(R + 1 + kh - qh), umax), v = min((unsigned)(R + 1 + kw - qw), umax);
+        c += s_tab[u * TW + v];
+      }
+      cv[e] = c;
+    }
+    // level 0: four rows of four keys
+#pragma unroll
+    for (int dyl = 0; dyl < 4; ++dyl) {
+      const int kh = 8 * cy + 4 * mt + dyl;
+      if (qvalid && kh < H8) {
+        float* d = pyr0 + q * N + (long)kh * W8 + kw0;
+        if (VEC || kw0 + 3 < W8) {
+          if (VEC) *reinterpret_cast<float4*>(d) = make_float4(cv[4 * dyl], cv[4 * dyl + 1], cv[4 * dyl + 2], cv[4 * dyl + 3]);
+          else { d[0] = cv[4 * dyl]; d[1] = cv[4 * dyl + 1]; d[2] = cv[4 * dyl + 2]; d[3] = cv[4 * dyl + 3]; }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { s1 += cv[4 * dyl + j]; s2 += cv[4 * dyl + j] * cv[4 * dyl + j]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (kw0 + j < W8) { d[j] = cv[4 * dyl + j]; s1 += cv[4 * dyl + j]; s2 += cv[4 * dyl + j] * cv[4 * dyl + j]; }
+        }
+      }
+    }
+    // level 1: 2 x 2 averages (same association as k_corr_pyramid: ((a + b) + c) + d, top row first)
+    float sum16 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int y1 = 4 * cy + 2 * mt + a;
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) {
+        const int x1 = 4 * cx + 2 * g + b2;
+        const float v = (((cv[8 * a + 2 * b2] + cv[8 * a + 2 * b2 + 1]) + cv[8 * a + 4 + 2 * b2]) + cv[8 * a + 5 + 2 * b2]) * 0.25f;
+        sum16 += v;
+        if (qvalid && y1 < h1 && x1 < w1) pyr1[(q * h1 + y1) * w1 + x1] = v;
+      }
+    }
+    // level 2: the lane's 4 x 4 block = mean of its four level-1 cells
+    const int y2 = 2 * cy + mt, x2 = 2 * cx + g;
+    const float v2 = sum16 * 0.25f;
+    if (qvalid && y2 < h2 && x2 < w2) pyr2[(q * h2 + y2) * w2 + x2] = v2;
+    cell += v2;
+  }
+  // level 3: 8 x 8 cell = the two tiles of this lane + the partner lane (g ^ 1)
+  cell += __shfl_xor(cell, 32);
+  if (g == 0 && qvalid && cy < h3 && cx < w3) pyr3[(q * h3 + cy) * w3 + cx] = cell * 0.25f;
+}
+
+__global__ __launch_bounds__(NTHREADS) void k_corr_build4t(ScoreParams p, const _Float16* __restrict__ Qs, const _Float16* __restrict__ Ks,
+                                                          float w_aggr, float* __restrict__ pyr0, float* __restrict__ pyr1,
+                                                          float* __restrict__ pyr2, float* __restrict__ pyr3, double* __restrict__ sums) {
+  constexpr int BK_ = 128, BQ = 64, D = 64, LD = D + 8, MT = 2;       // keys x queries per block
+  __shared__ __attribute__((aligned(16))) _Float16 As[2 * BK_ * LD];      // keys, planes hi | lo
+  __shared__ __attribute__((aligned(16))) _Float16 Bs[2 * BQ * LD];       // queries
+  __shared__ float s_tab[33 * 33];
+  __shared__ float s_red[8];
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncx2 = (((p.W8 + 7) >> 3) + 1) >> 1;                    // cell pairs per cell row
+  const int cy = blockIdx.y / ncx2, cxp = blockIdx.y - cy * ncx2;
+  const int q0 = blockIdx.x * BQ, b = blockIdx.z;
+  const int N = p.N, C = 4 * D;
+  const long rows_tot = (long)p.B * N;
+  const int wk = wave >> 1, wq = wave & 1;
+  const bool clamp = p.clamp_ord != nullptr && ord2f(*p.clamp_ord) > CRAFT_ATTN_CLIP;
+  const int R = p.pos_tab ? p.R : 0, TW = 2 * R + 3;
+  for (int i = tid; i < TW * TW; i += NTHREADS) {
+    const int dh = i / TW - R - 1, dw = i - (i / TW) * TW - R - 1;
+    s_tab[i] = (p.pos_tab && abs(dh) <= R && abs(dw) <= R) ? p.pos_w * p.pos_tab[(dh + R) * (2 * R + 1) + dw + R] : 0.f;
+  }
+  // staging: thread -> (row r8 + 32 i, 16-byte chunk c8 of the 128-byte mode row).  Key row a of the tile = cell (a >> 6) of the
+  // pair, key (dy, dx) = ((a >> 3) & 7, a & 7) -- MFMA row r of tile mt is a = cell*64 + mt*32 + r, i.e. dy = 4 mt + (r >> 3), dx = r & 7
+  const int c8 = tid & 7, r8 = tid >> 3;
+  const _Float16* kp[4];
+  const _Float16* qp[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int a = r8 + 32 * i;
+    const int ky = min(8 * cy + ((a >> 3) & 7), p.H8 - 1), kx = min(8 * (2 * cxp + (a >> 6)) + (a & 7), p.W8 - 1);
+    kp[i] = Ks + ((long)b * N + (long)ky * p.W8 + kx) * C + c8 * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) qp[i] = Qs + ((long)b * N + min(q0 + r8 + 32 * i, N - 1)) * C + c8 * 8;
+  u32x4 ra[2][4], rb[2][2];
+  auto fetch = [&](int m) __attribute__((always_inline)) {
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra[pl][i] = *reinterpret_cast<const u32x4*>(kp[i] + pl * rows_tot * C + m * D);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) rb[pl][i] = *reinterpret_cast<const u32x4*>(qp[i] + pl * rows_tot * C + m * D);
+    }
+  };
+  auto store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&As[(pl * BK_ + r8 + 32 * i) * LD + c8 * 8]) = ra[pl][i];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(&Bs[(pl * BQ + r8 + 32 * i) * LD + c8 * 8]) = rb[pl][i];
+    }
+  };
+  f32x16 acc[4][MT];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][mt][e] = 0.f;
+  const int r = lane & 31, g = lane >> 5, g8 = g * 8;
+  // MFMA A row r of tile mt must be key (dy = 4 mt + (r' >> 2 ...)): the C layout puts row (e & 3) + 8 (e >> 2) + 4 g in register e,
+  // so LDS row a = wk*64 + mt*32 + rho where rho is the tile row whose (dy, dx) we want at MFMA row r: MFMA row index R_ = r maps to
+  // key (dyl = R_ >> 3, dx = R_ & 7) when the tile rows are stored in that same order -- which is the staging order above.
+  fetch(0);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    __syncthreads();
+    store();
+    __syncthreads();
+    if (m + 1 < 4) fetch(m + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f16x8 ah[MT], al[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        ah[mt] = *reinterpret_cast<const f16x8*>(&As[(wk * 64 + mt * 32 + r) * LD + kk * 16 + g8]);
+        al[mt] = *reinterpret_cast<const f16x8*>(&As[(BK_ + wk * 64 + mt * 32 + r) * LD + kk * 16 + g8]);
+      }
+      const f16x8 bh = *reinterpret_cast<const f16x8*>(&Bs[(wq * 32 + r) * LD + kk * 16 + g8]);
+      const f16x8 bl = *reinterpret_cast<const f16x8*>(&Bs[(BQ + wq * 32 + r) * LD + kk * 16 + g8]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[m][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[m][mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[m][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[m][mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[m][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[m][mt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const float wl = w_aggr * 1.4426950408889634f;
+  // this lane's query and cell
+  const int ql = q0 + wq * 32 + r;
+  const bool qvalid = ql < N;
+  const int qi = min(ql, N - 1);
+  const int qh = qi / p.W8, qw = qi - qh * p.W8;
+  const int cx = 2 * cxp + wk;
+  const long q = (long)b * N + qi;
+  // positional window: rows of the key cell vs rows of the query tile (block-uniform)
+  const int q_hmin = q0 / p.W8, q_hmax = min(q0 + BQ - 1, N - 1) / p.W8;
+  const int k_hmin = 8 * cy, k_hmax = min(8 * cy + 7, p.H8 - 1);
+  const bool has_bias = p.pos_tab != nullptr && k_hmax >= q_hmin - R && k_hmin <= q_hmax + R;
+  const bool vec = (p.W8 & 3) == 0 && 8 * cx + 7 < p.W8;        // every 4-key run of this wave is a full, 16-byte aligned float4
+  float s1 = 0.f, s2 = 0.f;
+  if (8 * cx < p.W8) {                                           // (the second cell of the last pair may lie outside the image)
+#define EPI(CL, BI, VE) corr4t_epilogue<CL, BI, VE>(p, acc, wl, q, qvalid, qh, qw, cy, cx, g, s_tab, R, TW, pyr0, pyr1, pyr2, pyr3, s1, s2)
+    if (clamp) { if (has_bias) { if (vec) EPI(true, true, true); else EPI(true, true, false); } else { if (vec) EPI(true, false, true); else EPI(true, false, false); } }
+    else { if (has_bias) { if (vec) EPI(false, true, true); else EPI(false, true, false); } else { if (vec) EPI(false, false, true); else EPI(false, false, false); } }
+#undef EPI
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) { s_red[wave] = s1; s_red[4 + wave] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    const double a = (double)s_red[0] + (double)s_red[1] + (double)s_red[2] + (double)s_red[3];
+    const double qq = (double)s_red[4] + (double)s_red[5] + (double)s_red[6] + (double)s_red[7];
+    atomicAdd(&sums[2 * b], a);
+    atomicAdd(&sums[2 * b + 1], qq);
+  }
+}
+
 static int check_score(const ScoreParams& p) {
   if (p.d % BK || p.M < 1 || (p.ldq & 3) || (p.ldk & 3) || (p.q_bs & 3) || (p.k_bs & 3)) return CRAFT_ERR_ALIGN;
   if (p.pos_tab && p.R > 15) return CRAFT_ERR_UNSUPPORTED;
@@ -467,6 +680,27 @@ int launch_corr_build(const ScoreParams& p, float w_aggr, float* pyr0, double* s
   else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_F16, false>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums, nullptr);
   else if (prec == CRAFT_PREC_F16X3) hipLaunchKernelGGL((k_corr_build<CRAFT_PREC_F16X3, false>), grid, dim3(NTHREADS), 0, s, p, w_aggr, pyr0, sums, nullptr);
   else return CRAFT_ERR_ARG;
+  return (int)hipGetLastError();
+}
+
+// fused build + pyramid (f16x3, 4 modes of 64, pre-split operands in ws): everything else returns CRAFT_ERR_UNSUPPORTED and the
+// caller uses craft_corr_build + craft_corr_finish
+int launch_corr_build_pyramid(const ScoreParams& p, float w_aggr, float* pyr0, float* pyr1, float* pyr2, float* pyr3, double* sums,
+                              void* ws, int prec, hipStream_t s) {
+  if (int e = check_score(p)) return e;
+  if (!(ws != nullptr && prec == CRAFT_PREC_F16X3 && p.M == 4 && p.d == 64 && p.ldq % 4 == 0 && p.ldk % 4 == 0)) return CRAFT_ERR_UNSUPPORTED;
+  if (p.H8 < 8 || p.W8 < 8 || !pyr1 || !pyr2 || !pyr3) return CRAFT_ERR_UNSUPPORTED;
+  hipError_t me = hipMemsetAsync(sums, 0, sizeof(double) * 2 * p.B, s);
+  if (me != hipSuccess) return (int)me;
+  const long rows = (long)p.B * p.N, n4 = rows * 256 / 4;
+  _Float16* Qs = reinterpret_cast<_Float16*>(ws);
+  _Float16* Ks = Qs + 2 * rows * 256;
+  dim3 g1((unsigned)((n4 + 255) / 256));
+  hipLaunchKernelGGL(k_split_planes, g1, dim3(256), 0, s, p.Q, p.ldq, rows, 256, p.scale, Qs);
+  hipLaunchKernelGGL(k_split_planes, g1, dim3(256), 0, s, p.Kf, p.ldk, rows, 256, 1.f, Ks);
+  const int ncx2 = (((p.W8 + 7) / 8) + 1) / 2;
+  dim3 grid((p.N + 63) / 64, ((p.H8 + 7) / 8) * ncx2, p.B);
+  hipLaunchKernelGGL(k_corr_build4t, grid, dim3(NTHREADS), 0, s, p, Qs, Ks, w_aggr, pyr0, pyr1, pyr2, pyr3, sums);
   return (int)hipGetLastError();
 }
 

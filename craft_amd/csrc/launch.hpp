@@ -100,6 +100,8 @@ int launch_flash_attn(const ScoreParams& sp, const void* vT, long ldt, int Dv, f
 
 int launch_score_max(const ScoreParams& p, unsigned* max_ord, int prec, hipStream_t s);
 int launch_corr_build(const ScoreParams& p, float w_aggr, float* pyr0, double* sums, void* ws, int prec, hipStream_t s);
+int launch_corr_build_pyramid(const ScoreParams& p, float w_aggr, float* pyr0, float* pyr1, float* pyr2, float* pyr3, double* sums,
+                              void* ws, int prec, hipStream_t s);
 int launch_attn_probs(const ScoreParams& p, void* P, long ldp, int p_prec, int prec, hipStream_t s);
 template <int D> int launch_attn_probs_d(const ScoreParams& p, void* P, long ldp, int p_prec, int prec, hipStream_t s);
 

@@ -36,6 +36,7 @@ _SIGS = {
     "craft_linear_t": [P, L, P, P, L, I, I, I, I, I, I, I, P],
     "craft_score_max": [P, L, P, L, I, I, I, I, I, F, P, I, P],
     "craft_corr_build": [P, L, P, L, I, I, I, I, I, F, P, I, F, F, P, P, P, P, I, P],
+    "craft_corr_build_pyramid": [P, L, P, L, I, I, I, I, I, F, P, I, F, F, P, P, P, P, P, P, P, I, P],
     "craft_corr_finish": [P, P, P, P, P, P, I, I, I, I, P],
     "craft_corr_lookup": [P, P, P, P, I, P, P, I, I, I, I, P, L, I, I, P],
     "craft_attn_probs": [P, L, P, L, I, I, I, I, I, F, P, I, F, I, P, P, P, F, P, L, P, I, I, P],

@@ -7,6 +7,7 @@ is forwarded as ``ld``).  No compute happens in Python.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -173,9 +174,15 @@ def corr_build(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale
     sp = pick(prec, "score")
     # f16x3, 4 modes of 64: scratch for the pre-split (hi / lo fp16) copies of Q and K
     ws = torch.empty(4 * B * N * C, device=q.device, dtype=torch.float16) if (sp == hip.PREC_F16X3 and M == 4 and C == 256) else None
-    call("craft_corr_build", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale,
-         None if pos_tab is None else pos_tab.contiguous(), R, pos_w, w_aggr, clamp_ord, pyr.lv[0], pyr.sums, ws, sp)
+    tab = None if pos_tab is None else pos_tab.contiguous()
     lv = pyr.lv + [None] * (4 - len(pyr.lv))
+    if ws is not None and len(pyr.lv) == 4 and min(H8, W8) >= 8 and not os.environ.get("CRAFT_NO_FUSED_PYRAMID"):
+        # pyramid written from the tile that produced level 0 (no re-read of the 604 MB level 0 at 768x1024)
+        call("craft_corr_build_pyramid", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale, tab, R, pos_w, w_aggr, clamp_ord,
+             lv[0], lv[1], lv[2], lv[3], pyr.sums, ws, sp)
+        call("craft_corr_finish", lv[0], None, None, None, pyr.sums, pyr.mu_rstd, B, H8, W8, int(do_norm))
+        return pyr
+    call("craft_corr_build", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale, tab, R, pos_w, w_aggr, clamp_ord, pyr.lv[0], pyr.sums, ws, sp)
     call("craft_corr_finish", lv[0], lv[1], lv[2], lv[3], pyr.sums, pyr.mu_rstd, B, H8, W8, int(do_norm))
     return pyr
 

@@ -90,6 +90,15 @@ int craft_corr_build(const float* q, long ldq, const float* k, long ldk, int B, 
                      float scale, const float* pos_tab, int R, float pos_w, float w_aggr,
                      const unsigned* clamp_ord, float* pyr0, double* sums, void* ws, int prec, void* stream);
 
+/* craft_corr_build with the pyramid fused in (corr.py:186-189): the keys of a wave tile are an 8x8 cell of the key image held in
+ * registers per query, so levels 1..3 (2x2 / 4x4 / 8x8 averages, floor sizes) are register sums of the tile that produced
+ * level 0, which is never read back.  Implemented for prec = F16X3, M = 4, d = 64 with the ws of craft_corr_build, H8, W8 >= 8
+ * and all four levels; anything else returns CRAFT_ERR_UNSUPPORTED (10003) and the caller uses craft_corr_build +
+ * craft_corr_finish.  Follow it with craft_corr_finish(pyr0, NULL, NULL, NULL, ...) for the (mean, rstd) of the lazy LayerNorm. */
+int craft_corr_build_pyramid(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d, float scale,
+                             const float* pos_tab, int R, float pos_w, float w_aggr, const unsigned* clamp_ord, float* pyr0,
+                             float* pyr1, float* pyr2, float* pyr3, double* sums, void* ws, int prec, void* stream);
+
 /* corr.py:186-189 + :200-204: levels 1..3 by 2x2 average pooling (floor sizes; pass NULL to stop early) and
  * mu_rstd[b] = (mean, 1/sqrt(var+1e-12)) over all N*N entries (do_norm=0: (0,1)). */
 int craft_corr_finish(const float* pyr0, float* pyr1, float* pyr2, float* pyr3, const double* sums,
