@@ -256,7 +256,12 @@ def train_bench(a, rank, world, dev, dist):
         print(json.dumps({
             "metric": f"training image-pairs/sec at {H}x{W}, {a.iters} iters (forward + backward + gradient all-reduce + AdamW)",
             "value": round(value, 3), "unit": "image-pairs/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+            # BASELINE.md section 1 derives training throughput from the reference's own logs (ETA column; 2 unnamed GPUs,
+            # nn.DataParallel, AMP): 20.6 pairs/s at 368x496 batch 8 (logs/11 ...:651), 10.5 pairs/s at 368x768 batch 6 (logs/13 ...:709)
+            "vs_baseline": round(value / (20.6 if a.train == 3 else 10.5), 3) if (H, W) == ((368, 496) if a.train == 3 else (368, 768)) else None,
+            "baseline_note": "reference logs, derived from ETA: whole job on 2 unnamed GPUs (DataParallel + AMP)"
+                             + ("" if a.train == 3 else ", batch 6 there vs 4 per GPU here"),
             "dtype": policy + " (fp32 activations / probabilities in HBM; MFMA operand mode per role, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": name + f", {a.iters} iters, model.train(): dropout 0.1 / 0.2, "
                                           + ("BatchNorm batch statistics" if a.train == 3 else "frozen BatchNorm")
