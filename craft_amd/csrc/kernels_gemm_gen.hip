@@ -28,9 +28,9 @@ template <int PREC, int ROWS>
 __device__ __forceinline__ void stage_store_piece(typename PrecT<PREC>::lds_t* S, const RegsF32K<ROWS>& r, int tid, int i) {
   constexpr int LD = PrecT<PREC>::LD, NG = ROWS / 32;
   const int row = tid % ROWS, kg = (tid / ROWS) * NG + i;
-  const unsigned z = r.zmask >> (4 * i);
-  float4 v;
-  v.x = (z & 1u) ? 0.f : r.v[i].x; v.y = (z & 2u) ? 0.f : r.v[i].y; v.z = (z & 4u) ? 0.f : r.v[i].z; v.w = (z & 8u) ? 0.f : r.v[i].w;
+  const unsigned z = (r.zmask >> (4 * i)) & 15u;                // wave-uniform (see the loaders): a scalar test, not per-lane selects
+  float4 v = r.v[i];
+  if (z) { v.x = (z & 1u) ? 0.f : v.x; v.y = (z & 2u) ? 0.f : v.y; v.z = (z & 4u) ? 0.f : v.z; v.w = (z & 8u) ? 0.f : v.w; }
   if constexpr (PREC == CRAFT_PREC_F32) {
     *reinterpret_cast<float4*>(&S[row * LD + kg * 4]) = v;
   } else if constexpr (PREC == CRAFT_PREC_BF16) {
@@ -57,31 +57,54 @@ __device__ __forceinline__ void stage_store(typename PrecT<PREC>::lds_t* S, cons
 
 // K-major fp32 operand: element (row, k) at base[k*ld + row], k in [k0, k1) (split-K range); rows >= nrows re-read the last valid
 // row (their products only reach output rows / columns the epilogue drops), k >= k1 is stored as zero.
+// Everything about k is WAVE-UNIFORM here (a wave holds 64 rows of the same k groups: tid / ROWS is constant over a wave), so
+// the k-row addresses, the range tests and the zero mask live on the scalar unit (readfirstlane makes that visible to the
+// compiler) and the loads are BUFFER loads: descriptor base = the tile's first k-row (scalar), soffset = k-row byte offset
+// (scalar, one s_add per element), voffset = this lane's row (a loop-invariant VGPR) -- no vector address arithmetic at all.
+// The first version computed a 64-bit address per lane and element: 16 VALU instructions per MFMA, a quarter of them quarter-
+// rate integer multiplies, and the weight-gradient products ran at a quarter of the MFMA rate because of it.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t krow_rsrc(const float* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)0xffffffffu, 0x00020000);      // raw dword buffer, no range limit
+}
+__device__ __forceinline__ float krow_load(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+
 template <int ROWS> struct LoaderColsF32 {
   typedef RegsF32K<ROWS> Regs;
-  static constexpr int NG = ROWS / 32;
-  const float* base;       // + row
+  static constexpr int NG = ROWS / 32, NE = 4 * NG;
+  const float* base;       // uniform
+  unsigned rowoff;         // per lane: byte offset of this lane's row
   long ld;
   int k0, k1, kg0;
   __device__ __forceinline__ void init(const float* base_, long ld_, int row0, int nrows, int k0_, int k1_, int tid) {
     ld = ld_; k0 = k0_; k1 = k1_;
-    base = base_ + min(row0 + tid % ROWS, nrows - 1);
-    kg0 = (tid / ROWS) * NG;
+    base = base_;
+    rowoff = 4u * (unsigned)min(row0 + tid % ROWS, nrows - 1);
+    kg0 = __builtin_amdgcn_readfirstlane((tid / ROWS) * NG);
   }
   __device__ __forceinline__ void fetch(int kt, Regs& r) const {
+    const int kb = k0 + kt * BK + kg0 * 4;
+    const unsigned ld4 = (unsigned)ld * 4u;                      // launcher: ld < 2^26
+    float t[NE];
     unsigned zm = 0u;
+    if (kb + NE <= k1) {
+      const __amdgpu_buffer_rsrc_t rs = krow_rsrc(base + (long)kb * ld);
+      unsigned so = 0u;
 #pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      const int k = k0 + kt * BK + (kg0 + i) * 4;
-      float t[4];
+      for (int e = 0; e < NE; ++e) { t[e] = krow_load(rs, rowoff, so); so += ld4; }
+    } else {                                                     // the tail of the K range: clamp (a valid address) and zero
+      const int kc = min(kb, k1 - 1);
+      const __amdgpu_buffer_rsrc_t rs = krow_rsrc(base + (long)kc * ld);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool ok = k + j < k1;
-        zm |= ok ? 0u : (1u << (4 * i + j));
-        t[j] = base[(long)(ok ? k + j : k1 - 1) * ld];                 // unconditional load from a valid address
+      for (int e = 0; e < NE; ++e) {
+        const bool ok = kb + e < k1;
+        zm |= ok ? 0u : (1u << e);
+        t[e] = krow_load(rs, rowoff, (unsigned)(min(kb + e, k1 - 1) - kc) * ld4);
       }
-      r.v[i] = make_float4(t[0], t[1], t[2], t[3]);
     }
+#pragma unroll
+    for (int i = 0; i < NG; ++i) r.v[i] = make_float4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
     r.zmask = zm;
   }
 };
@@ -167,6 +190,7 @@ int launch_gemm_gen(const float* A, long a_sm, long a_sk, long a_bs0, long a_bs1
   if (zdiv <= 0 || ksplit < 0) return CRAFT_ERR_ARG;
   const bool at = a_sm == 1 && a_sk != 1, bt = b_sn == 1 && b_sk != 1;
   if (!at && a_sk != 1) return CRAFT_ERR_ARG;
+  if ((at && (a_sk < 0 || a_sk >= (1L << 26))) || (bt && (b_sk < 0 || b_sk >= (1L << 26)))) return CRAFT_ERR_UNSUPPORTED;   // 32-bit k-row offsets
   if (!bt && b_sk != 1) return CRAFT_ERR_ARG;
   // a k-contiguous ("rows") operand is read with 16-byte vector loads: its leading dimension and batch strides are multiples of 4
   // floats, its base is 16-byte aligned and K is a multiple of 4; a k-major operand is read with scalar loads (lane = row) and has
@@ -204,42 +228,65 @@ int launch_gemm_gen(const float* A, long a_sm, long a_sk, long a_bs0, long a_bs1
 // = for every tap a (cout x cin) product over K = all pixels: A = dY k-major, B = X k-major read at the tap's offset.
 // grid (ceil(cout / 128), taps * ceil(cin / BN), ksplit); split-K partial sums are added with atomics.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned bits_range(int lo, int hi) {       // bits lo .. hi-1 (hi <= 16)
+  lo = max(lo, 0);
+  return hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+}
+
 template <int ROWS> struct LoaderShiftColsF32 {
   typedef RegsF32K<ROWS> Regs;
-  static constexpr int NG = ROWS / 32;
-  const float* base;       // + row (input channel)
+  static constexpr int NG = ROWS / 32, NE = 4 * NG;
+  const float* base;       // uniform
+  unsigned rowoff;         // per lane: byte offset of this lane's row (input channel)
   long ld;
-  int k0, k1, kg0, H, W, dy, dx;
+  int k0, k1, kg0, H, W, dy, dx, npix;
   unsigned magic_hw, magic_w;          // ceil(2^32 / (H*W)), ceil(2^32 / W): k / d = umulhi(k, magic) for k * d < 2^32 (launcher checks)
-  __device__ __forceinline__ void init(const float* base_, long ld_, int row0, int nrows, int k0_, int k1_, int H_, int W_, int dy_,
-                                       int dx_, unsigned magic_hw_, unsigned magic_w_, int tid) {
-    ld = ld_; k0 = k0_; k1 = k1_; H = H_; W = W_; dy = dy_; dx = dx_; magic_hw = magic_hw_; magic_w = magic_w_;
-    base = base_ + min(row0 + tid % ROWS, nrows - 1);
-    kg0 = (tid / ROWS) * NG;
+  __device__ __forceinline__ void init(const float* base_, long ld_, int row0, int nrows, int k0_, int k1_, int npix_, int H_, int W_,
+                                       int dy_, int dx_, unsigned magic_hw_, unsigned magic_w_, int tid) {
+    ld = ld_; k0 = k0_; k1 = k1_; npix = npix_; H = H_; W = W_; dy = dy_; dx = dx_; magic_hw = magic_hw_; magic_w = magic_w_;
+    base = base_;
+    rowoff = 4u * (unsigned)min(row0 + tid % ROWS, nrows - 1);
+    kg0 = __builtin_amdgcn_readfirstlane((tid / ROWS) * NG);
   }
+  // A wave's NE pixels of one K-tile are consecutive (k = kb .. kb + NE - 1) and wave-uniform (see LoaderColsF32): ONE pair of
+  // divisions per fetch gives (y, x) of the first, the validity of the tap is a bit mask built from at most two row segments,
+  // and the NE k-rows are read unconditionally at consecutive addresses kb + shift + e (inside the tensor away from its two ends).
   __device__ __forceinline__ void fetch(int kt, Regs& r) const {
-    unsigned zm = 0u;
     const int hw = H * W;
-    const long shift = (long)dy * W + dx;             // a valid tap of pixel p is pixel p + shift of the same image
-#pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      const int k = k0 + kt * BK + (kg0 + i) * 4;
-      // the 4 pixels of a group are consecutive: one pair of divisions, then x carries into y (and y into the next image)
-      const int kc = min(k, k1 - 1);
-      const int rem = kc - (int)__umulhi((unsigned)kc, magic_hw) * hw;
+    const int shift = dy * W + dx;                    // a valid tap of pixel p is pixel p + shift of the same image
+    const int kb = k0 + kt * BK + kg0 * 4;
+    const unsigned ld4 = (unsigned)ld * 4u;
+    float t[NE];
+    unsigned zm = 0u;
+    if (kb + NE <= k1 && kb + shift >= 0 && kb + NE - 1 + shift < npix && W >= NE) {
+      const int rem = kb - (int)__umulhi((unsigned)kb, magic_hw) * hw;
       const int y = (int)__umulhi((unsigned)rem, magic_w), x = rem - y * W;
-      float t[4];
+      const int n1 = min(NE, W - x);                  // pixels left in row y; the rest start row y + 1 (or row 0 of the next image)
+      const int x0 = x + dx;
+      unsigned m = (unsigned)(y + dy) < (unsigned)H ? bits_range(-x0, min(n1, W - x0)) : 0u;
+      const int y2 = (y + 1 == H ? 0 : y + 1) + dy;
+      if ((unsigned)y2 < (unsigned)H) m |= bits_range(n1 + max(0, -dx), min((int)NE, n1 + W - dx));
+      zm = ~m & ((1u << NE) - 1u);
+      const __amdgpu_buffer_rsrc_t rs = krow_rsrc(base + (long)(kb + shift) * ld);
+      unsigned so = 0u;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int xj = x + j, yj = y;
-        if (xj >= W) { xj -= W; yj += 1; }
-        if (yj >= H) yj -= H;
-        const bool ok = k + j < k1 && (unsigned)(yj + dy) < (unsigned)H && (unsigned)(xj + dx) < (unsigned)W;
-        zm |= ok ? 0u : (1u << (4 * i + j));
-        t[j] = base[(ok ? (long)(k + j) + shift : 0L) * ld];
+      for (int e = 0; e < NE; ++e) { t[e] = krow_load(rs, rowoff, so); so += ld4; }
+    } else {                                          // the ends of the tensor / of the K range, images narrower than NE
+      const __amdgpu_buffer_rsrc_t rs = krow_rsrc(base);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int k = kb + e, kc = min(k, k1 - 1);
+        const int rem = kc - (int)__umulhi((unsigned)kc, magic_hw) * hw;
+        const int y = (int)__umulhi((unsigned)rem, magic_w), x = rem - y * W;
+        const bool ok = k < k1 && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
+        zm |= ok ? 0u : (1u << e);
+        const float* pk = base + (long)(ok ? kc + shift : 0) * ld;
+        t[e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pk) + rowoff);
       }
-      r.v[i] = make_float4(t[0], t[1], t[2], t[3]);
+      (void)rs;
     }
+#pragma unroll
+    for (int i = 0; i < NG; ++i) r.v[i] = make_float4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
     r.zmask = zm;
   }
 };
@@ -277,7 +324,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_wgrad(WgradParams p) {
   LoaderColsF32<BM> la;
   la.init(p.dY, p.ldy, m0, p.cout, k0, k1, tid);
   LoaderShiftColsF32<BN> lb;
-  lb.init(p.X, p.ldx, n0, p.cin, k0, k1, p.H, p.W, ky - p.KH / 2, kx - p.KW / 2, p.magic_hw, p.magic_w, tid);
+  lb.init(p.X, p.ldx, n0, p.cin, k0, k1, npix, p.H, p.W, ky - p.KH / 2, kx - p.KW / 2, p.magic_hw, p.magic_w, tid);
   gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, (k1 - k0 + BK - 1) / BK, acc, NoFold());
   const int rb = m0 + (wave / WN) * (BM / WM), cb = n0 + (wave % WN) * (BN / WN);
   const long taps = (long)p.KH * p.KW;
@@ -300,6 +347,7 @@ int launch_reduce_replicas(const float* rep, int nrep, int n, float* out, hipStr
 int launch_conv_wgrad(const float* x, long ldx, int cin, const float* dy, long ldy, int cout, int KH, int KW, int B, int H, int W,
                       float* dW, float* ws, long ws_floats, int prec, hipStream_t s) {
   if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return 0;
+  if (ldx >= (1L << 26) || ldy >= (1L << 26)) return CRAFT_ERR_UNSUPPORTED;
   if ((ldx & 3) || (ldy & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(dy) & 15)) return CRAFT_ERR_ALIGN;
   WgradParams p = {};
   p.X = x; p.dY = dy; p.dW = dW; p.ldx = ldx; p.ldy = ldy; p.cin = cin; p.cout = cout; p.KH = KH; p.KW = KW; p.B = B; p.H = H; p.W = W;

@@ -53,6 +53,21 @@ def main():
         enc = m._henc_f if which == "fnet" else m._henc_c
         for _ in range(2):
             enc.forward_tokens(raw, prec)
+    elif which in ("wgrad", "gemm_tt"):
+        from craft_amd import hip as H
+        Bq, h8, w8, cin, cout = 8, 46, 62, 512, 256
+        npix = Bq * h8 * w8
+        x = torch.randn(npix, cin, device=dev)
+        dy = torch.randn(npix, cout, device=dev)
+        cp = pick(prec, "conv")
+        if which == "wgrad":
+            dw = torch.zeros(cout, 1, 5, cin, device=dev)
+            for _ in range(3):
+                H.call("craft_conv2d_wgrad", x, cin, cin, dy, cout, cout, 1, 5, Bq, h8, w8, dw, None, 0, cp)
+        else:       # the same contraction without taps: dW = dY^T X (k-major x k-major, split-K)
+            dw = torch.zeros(cout, cin, device=dev)
+            for _ in range(3):
+                H.call("craft_gemm", dy, 1, cout, 0, 0, x, 1, cin, 0, 0, dw, cin, 0, 0, 1, 1, cout, cin, npix, 1.0, 1, 0, cp)
     elif which == "corr":
         import math
         C, Mm = 256, 4
