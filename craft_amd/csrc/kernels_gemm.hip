@@ -116,7 +116,16 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
   constexpr int TILE = BM * LD;
   __shared__ __attribute__((aligned(16))) lds_t S[2 * TILE];      // A0 | A1
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * 128, z = blockIdx.z;
+  // XCD-aware block map.  Blocks are dealt to the 8 XCDs round-robin (block b -> XCD b % 8), and every block of one batch entry z
+  // re-reads that entry's V^T (N x Dv x 2 B: 1.8 MB at 448x1024) from ITS XCD's L2.  With z outermost in the grid all 8 L2s
+  // fetched all batch x modes copies (8 x 29 MB of a 1.97 GB launch, 13 % over the algorithmic bytes: PMC FETCH_SIZE); here XCD x
+  // owns a contiguous eighth of the (z, row block) list, i.e. two whole entries at batch 4 x 4 modes, whose V^T stay L2-resident.
+  const int gx = (p.M + BM - 1) / BM, gy = p.N / 128;
+  int lin = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) lin = (lin & 7) * (nblk >> 3) + (lin >> 3);
+  const int bx = lin % gx, byz = lin / gx;
+  const int m0 = bx * BM, n0 = (byz % gy) * 128, z = byz / gy;
   const int z0 = z / p.zdiv, z1 = z - z0 * p.zdiv;
   const uint16_t* A = reinterpret_cast<const uint16_t*>(p.A) + z0 * p.a_bs0 + z1 * p.a_bs1;
   const int NB = p.N / 32, ng = p.K / 16;
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
 }
 
 template <int PREC, int MT> static void launch_pv_t(const RowsGemmParams& p, hipStream_t s) {
-  dim3 grid((p.M + 32 * MT - 1) / (32 * MT), p.N / 128, p.batch);
+  dim3 grid((unsigned)((long)((p.M + 32 * MT - 1) / (32 * MT)) * (p.N / 128) * p.batch), 1, 1);
   hipLaunchKernelGGL((k_pv16<PREC, MT>), grid, dim3(NTHREADS), 0, s, p);
 }
 
