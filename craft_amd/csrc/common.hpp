@@ -24,6 +24,15 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define CRAFT_LN_EPS 1e-12f      // setrans.py:715, :362; corr.py:203
 #define CRAFT_STATS_REPLICAS 64  // == include/craft_hip.h
 
+// XCD-aware work mapping.  The hardware deals consecutive block ids round-robin over the 8 XCDs (block b runs on XCD b % 8, each
+// with a private L2).  xcd_chunk(b, total) renumbers the blocks so that XCD x owns a CONTIGUOUS eighth of the work list:
+// blocks that re-read the same operand (adjacent in the list) then share one L2 instead of pulling 8 copies through the fabric.
+// Bijective for any block count.
+__device__ __forceinline__ int xcd_chunk(int bid, int total) {
+  const int xcd = bid & 7, qn = total >> 3, rn = total & 7;
+  return (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

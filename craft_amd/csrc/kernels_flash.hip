@@ -54,8 +54,7 @@ __global__ __launch_bounds__(512) void k_flash_attn(FlashParams p) {
   // Every block of one z streams the same K / V^T (5.5 MB at 448x1024), so the blocks of a z are given to ONE XCD:
   // virtual id v = (blocks of lower XCDs) + (id / 8), z = v / nqx, query block = v % nqx  (bijective for any count).
   const int nqx = (p.N + 255) / 256, total = nqx * p.B * p.M;
-  const int xcd = blockIdx.x & 7, qn = total >> 3, rn = total & 7;
-  const int v = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (blockIdx.x >> 3);
+  const int v = xcd_chunk(blockIdx.x, total);
   const int z = v / nqx, bx = v - z * nqx, b = z / p.M, m = z - b * p.M;
   const int N = p.N, W8 = p.W8, R = p.R;
   const int q0 = bx * 256;
