@@ -121,7 +121,11 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
   // fetched all batch x modes copies (8 x 29 MB of a 1.97 GB launch, 13 % over the algorithmic bytes: PMC FETCH_SIZE); here XCD x
   // owns a contiguous eighth of the (z, row block) list, i.e. two whole entries at batch 4 x 4 modes, whose V^T stay L2-resident.
   const int gx = (p.M + BM - 1) / BM, gy = p.N / 128;
+#ifdef CRAFT_PV_NO_XCD_MAP                       // developer A/B (tools/build_variant.py): z outermost, round-robin over the XCDs
+  const int lin = blockIdx.x;
+#else
   const int lin = xcd_chunk(blockIdx.x, gridDim.x);
+#endif
   const int bx = lin % gx, byz = lin / gx;
   const int m0 = bx * BM, n0 = (byz % gy) * 128, z = byz / gy;
   const int z0 = z / p.zdiv, z1 = z - z0 * p.zdiv;

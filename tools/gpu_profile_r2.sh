@@ -5,15 +5,16 @@
 #  2. the bench line itself (un-profiled)                                        -> bench.json
 #  3. PMC passes (separate runs, FETCH_SIZE / WRITE_SIZE) of the dominant kernel -> pmc_traffic_pv16.json
 #  4. kernel stats of the steady-state training step (configs[3])                 -> train_cfg3_kernel_stats.txt
+#  5. per-kernel L2<->fabric traffic of the whole forward (FETCH_SIZE / WRITE_SIZE) -> traffic_table.txt
 set -u
 REPO=$(pwd); OUT=$REPO/gpurun_out/prof_r2; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 python $REPO/bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
 python $REPO/tools/kstats.py $(find $OUT/trace -name "*kernel_stats.csv" | head -1) 40 > $OUT/bench_kernel_stats_short.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_pv_$c -o k -- python $REPO/tools/run_kernel.py pv mixed > /dev/null 2> $OUT/pmc_pv_$c.err
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_pv_$c -o k -- python $REPO/tools/run_kernel.py pv mixed > /dev/null 2> $OUT/pmc_pv_$c.err
   f=$(find $OUT/pmc_pv_$c -name "*counter_collection.csv" | head -1)
   grep -E "k_pv16|Kernel_Name" "$f" > $OUT/pmc_pv_$c.csv
 done
@@ -33,10 +34,15 @@ json.dump({"kernel": name, "shape": {"B": 4, "H8": 56, "W8": 128, "M": 4, "Dv": 
 PY
 # steady-state training step: drop the first (MIOpen find) iteration by tracing only kernels of the last steps is not possible
 # with --stats, so the table lists averages over all calls; MIOpen's one-off search kernels (naive_conv_*) are marked by name
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -o train -- python $REPO/bench.py --train 3 --steps 3 --warmup 1 > $OUT/train3_under_rocprof.json 2> $OUT/rocprof_train.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -o train -- python $REPO/bench.py --train 3 --steps 3 --warmup 1 > $OUT/train3_under_rocprof.json 2> $OUT/rocprof_train.err
 python $REPO/tools/kstats.py $(find $OUT/trace_train -name "*kernel_stats.csv" | head -1) 60 > $OUT/train_cfg3_kernel_stats.txt
 python $REPO/bench.py --train 3 --steps 5 --warmup 2 > $OUT/bench_train_cfg3.json 2>/dev/null
 python $REPO/bench.py --train 4 --steps 5 --warmup 2 > $OUT/bench_train_cfg4.json 2>/dev/null
 python $REPO/tools/bench_corr.py > $OUT/bench_corr_768x1024.json 2>/dev/null
+CMD="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tt0 -o k -- $CMD > /dev/null 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do timeout 400 rocprofv3 --pmc $c --output-format csv -d $OUT/tt_$c -o k -- $CMD > /dev/null 2>&1; done
+python $REPO/tools/traffic_table.py $(find $OUT/tt0 -name "*kernel_stats.csv" | head -1) $(find $OUT/tt_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $OUT/tt_WRITE_SIZE -name "*counter_collection.csv" | head -1) 32 > $OUT/traffic_table.txt
+rm -rf $OUT/tt0 $OUT/tt_FETCH_SIZE $OUT/tt_WRITE_SIZE
 rm -rf $OUT/trace $OUT/trace_train $OUT/pmc_pv_FETCH_SIZE $OUT/pmc_pv_WRITE_SIZE
 du -sh $OUT
