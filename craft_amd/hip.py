@@ -107,7 +107,11 @@ NAMED_POLICIES = {"mixed": "proj=f16x3,score=f16x3,pv=fp16,conv=f16x3", "mixed_f
                   # forward AND backward contractions): everything fp32-class / bf16 MFMA for the cross- and self-attention
                   # contractions (BASELINE.json configs[4]: "bf16 MFMA cross-attention")
                   "train_f16x3": "proj=f16x3,score=f16x3,pv=f16x3,conv=f16x3",
-                  "train_bf16attn": "proj=f16x3,score=bf16,pv=bf16,conv=f16x3"}
+                  "train_bf16attn": "proj=f16x3,score=bf16,pv=bf16,conv=f16x3",
+                  # + the two CNN encoders (PyTorch-ROCm modules in training) under torch.autocast(bfloat16): what the reference's
+                  # own training does with --mixed_precision (network.py:179-183 autocast around fnet / cnet), bf16 instead of fp16
+                  # so that no loss scaling is needed
+                  "train_bf16": "proj=f16x3,score=bf16,pv=bf16,conv=f16x3,enc=bf16"}
 
 
 class CraftHipError(RuntimeError):

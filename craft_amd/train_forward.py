@@ -18,7 +18,7 @@ import torch
 
 from . import autograd as AG
 from . import ops
-from .hip import ACT_NONE, ACT_RELU, ACT_TANH
+from .hip import ACT_NONE, ACT_RELU, ACT_TANH, PREC_BF16, PREC_F16
 
 
 def _attention_probs(module, x_ln, hw, prec, p_attn: float, seed: int):
@@ -65,8 +65,13 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
     # ---- CNN encoders: PyTorch-ROCm modules under autograd (network.py:169-183, :203) ---------------------------------
     im1 = (2 * (image1.float() / 255.0) - 1.0).contiguous()
     im2 = (2 * (image2.float() / 255.0) - 1.0).contiguous()
-    fmap1, fmap2 = model.fnet([im1, im2])
-    cnet_feat = model.cnet(im1)
+    # prec.enc = bf16: the encoders run under autocast like the reference's mixed-precision training (network.py:179,199);
+    # fp16 would need the reference's GradScaler and is refused
+    if prec.enc == PREC_F16:
+        raise NotImplementedError("training: enc=fp16 needs loss scaling; use enc=bf16 (autocast) or an fp32-class mode")
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=prec.enc == PREC_BF16):
+        fmap1, fmap2 = model.fnet([im1, im2])
+        cnet_feat = model.cnet(im1)
     f1_tok = AG.NchwToTokens.apply(fmap1.float())
     f2_tok = AG.NchwToTokens.apply(fmap2.float())
     cn_tok = AG.NchwToTokens.apply(cnet_feat.float())

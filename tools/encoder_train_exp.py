@@ -9,7 +9,7 @@ model = model.to(dev).train()
 B, H, W = 8, 368, 496
 im1, im2, _ = synth_pair(B, H, W, seed=100)
 a = (2 * (im1 / 255.0) - 1).to(dev); b = (2 * (im2 / 255.0) - 1).to(dev)
-def run(cl):
+def run(cl, amp=None):
     if cl:
         model.fnet.to(memory_format=torch.channels_last); model.cnet.to(memory_format=torch.channels_last)
         x, y = a.contiguous(memory_format=torch.channels_last), b.contiguous(memory_format=torch.channels_last)
@@ -19,10 +19,18 @@ def run(cl):
         for p in model.parameters(): p.grad = None
         t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True); t2 = torch.cuda.Event(enable_timing=True)
         t0.record()
-        f1, f2 = model.fnet([x, y]); cn = model.cnet(x)
+        with torch.autocast('cuda', dtype=amp, enabled=amp is not None):
+            f1, f2 = model.fnet([x, y]); cn = model.cnet(x)
+        f1, f2, cn = f1.float(), f2.float(), cn.float()
         t1.record()
         torch.autograd.backward([f1, f2, cn], [torch.ones_like(f1), torch.ones_like(f2), torch.ones_like(cn)])
         t2.record(); torch.cuda.synchronize()
-        print(f"channels_last={cl} iter {it}: fwd {t0.elapsed_time(t1):.2f} ms bwd {t1.elapsed_time(t2):.2f} ms", flush=True)
+        print(f"channels_last={cl} amp={amp} iter {it}: fwd {t0.elapsed_time(t1):.2f} ms bwd {t1.elapsed_time(t2):.2f} ms", flush=True)
+mode = sys.argv[1] if len(sys.argv) > 1 else 'all'
 run(False)
-run(True)
+if mode == 'all':
+    run(True)
+run(False, torch.bfloat16)
+run(False, torch.float16)
+if mode == 'all':
+    run(True, torch.bfloat16)
