@@ -418,6 +418,40 @@ int craft_conv2d_wgrad(const float* x, long ldx, int cin, const float* dy, long 
                        float* dW, float* ws, long ws_floats, int prec, void* stream) {
   return launch_conv_wgrad(x, ldx, cin, dy, ldy, cout, KH, KW, B, H, W, dW, ws, ws_floats, prec, S(stream));
 }
+// ---- CNN encoders in training (kernels_enc_train.hip)
+int craft_norm_act_fwd(const float* x, long ldx, const float* mean_rstd, int mr_per_image, const float* gamma, const float* beta, int act,
+                       const float* res, long ldr, float* out, long ldo, int B, int N, int C, void* stream) {
+  NormActParams p = {};
+  p.x = x; p.ldx = ldx; p.mr = mean_rstd; p.mr_bs = mr_per_image ? C : 0; p.gamma = gamma; p.beta = beta; p.act = act;
+  p.res = res; p.ldr = ldr; p.out = out; p.ldo = ldo; p.B = B; p.N = N; p.C = C;
+  if (act != CRAFT_ACT_NONE && act != CRAFT_ACT_RELU) return CRAFT_ERR_UNSUPPORTED;
+  return launch_norm_act_fwd(p, S(stream));
+}
+int craft_norm_act_bwd_reduce(const float* dy, long ldg, const float* out, long ldo, const float* x, long ldx, const float* mean_rstd,
+                              int mr_per_image, const float* gamma, const float* beta, int act, int has_res, double* sums, int B, int N,
+                              int C, void* stream) {
+  NormActParams p = {};
+  p.dy = dy; p.ldg = ldg; p.out = const_cast<float*>(out); p.ldo = ldo; p.x = x; p.ldx = ldx; p.mr = mean_rstd;
+  p.mr_bs = mr_per_image ? C : 0; p.gamma = gamma; p.beta = beta; p.act = act; p.has_res = has_res; p.sums = sums; p.B = B; p.N = N; p.C = C;
+  if (act != CRAFT_ACT_NONE && act != CRAFT_ACT_RELU) return CRAFT_ERR_UNSUPPORTED;
+  return launch_norm_act_bwd_reduce(p, S(stream));
+}
+int craft_norm_act_bwd_apply(const float* dy, long ldg, const float* out, long ldo, const float* x, long ldx, const float* mean_rstd,
+                             int mr_per_image, const float* gamma, const float* beta, int act, int has_res, const float* red,
+                             int red_per_image, float* dx, long lddx, float* dres, long lddr, int B, int N, int C, void* stream) {
+  NormActParams p = {};
+  p.dy = dy; p.ldg = ldg; p.out = const_cast<float*>(out); p.ldo = ldo; p.x = x; p.ldx = ldx; p.mr = mean_rstd;
+  p.mr_bs = mr_per_image ? C : 0; p.gamma = gamma; p.beta = beta; p.act = act; p.has_res = has_res; p.red = red;
+  p.red_bs = red_per_image ? C : 0; p.dx = dx; p.lddx = lddx; p.dres = dres; p.lddr = lddr; p.B = B; p.N = N; p.C = C;
+  if (act != CRAFT_ACT_NONE && act != CRAFT_ACT_RELU) return CRAFT_ERR_UNSUPPORTED;
+  return launch_norm_act_bwd_apply(p, S(stream));
+}
+int craft_stem_im2col(const float* image, int B, int H, int W, float* cols, void* stream) {
+  return launch_stem_im2col(image, B, H, W, cols, S(stream));
+}
+int craft_zero_stuff2(const float* g, long ldg, int B, int Hin, int Win, int C, float* gf, long ldf, void* stream) {
+  return launch_zero_stuff2(g, ldg, B, Hin, Win, C, gf, ldf, S(stream));
+}
 int craft_colsum(const float* x, long ld, long rows, int C, float* out, void* stream) { return launch_colsum(x, ld, rows, C, out, S(stream)); }
 int craft_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, void* stream) {
   return launch_act_fwd(x, ldx, y, ldy, rows, C, act, scale, S(stream));

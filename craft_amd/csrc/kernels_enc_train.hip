@@ -1,0 +1,204 @@
+// Training-mode pieces of the CNN encoders (BasicEncoder / ResidualBlock, extractor.py:6-64, 124-196) that the inference
+// path folds away: the normalisation layers as real operators with a backward, and the stem's weight gradient.
+//
+//   out = tail(act((x - mean) * rstd * gamma + beta))            tail(t) = relu(res + t) when a residual input is given
+//
+// covers nn.InstanceNorm2d (mean / rstd per image and channel, no affine), nn.BatchNorm2d in training (per channel over the
+// batch) and in eval / freeze_bn mode (running statistics), followed by the block's ReLU and, for the last norm of a residual
+// block, by relu(x + y) (extractor.py:56-64).  Tensors are channels-last tokens [B][N][C] (C % 4 == 0), one float4 of channels
+// per thread; the statistics come from the producing convolution's epilogue (craft_conv2d_nhwc_ex `stats`).
+//
+// Backward of y = norm(x) over a population P (an image's pixels, or the batch's):  with dz = dL/dz and x^ = (x - mean) * rstd
+//   dx = gamma * rstd * (dz - mean_P(dz) - x^ * mean_P(dz * x^)),   dgamma = sum dz * x^,   dbeta = sum dz
+// (eval-mode BatchNorm: the two means are dropped).  Two passes: a column reduction of (dz, dz * x^) per image and channel,
+// then the elementwise pass; both recompute dz from (dy, out, x) instead of storing it.
+#include "launch.hpp"
+
+namespace craft {
+
+struct Quad { float4 xh, sc, z; };        // x^, rstd * gamma, normalised + affine value
+
+__device__ __forceinline__ Quad norm_quad(const NormActParams& p, int b, long row, int c) {
+  const float4 x = *reinterpret_cast<const float4*>(p.x + row * p.ldx + c);
+  const float* m = p.mr + ((long)b * p.mr_bs + c) * 2;
+  const float4 m01 = *reinterpret_cast<const float4*>(m), m23 = *reinterpret_cast<const float4*>(m + 4);
+  float4 g = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+  if (p.gamma) g = *reinterpret_cast<const float4*>(p.gamma + c);
+  if (p.beta) be = *reinterpret_cast<const float4*>(p.beta + c);
+  Quad q;
+  q.xh = make_float4((x.x - m01.x) * m01.y, (x.y - m01.z) * m01.w, (x.z - m23.x) * m23.y, (x.w - m23.z) * m23.w);
+  q.sc = make_float4(m01.y * g.x, m01.w * g.y, m23.y * g.z, m23.w * g.w);
+  q.z = make_float4(q.xh.x * g.x + be.x, q.xh.y * g.y + be.y, q.xh.z * g.z + be.z, q.xh.w * g.w + be.w);
+  return q;
+}
+
+// dz (gradient at the normalised value) and, when there is a residual tail, the gradient that flows to the residual input
+__device__ __forceinline__ float4 norm_dz(const NormActParams& p, const Quad& q, long row, int c, float4* dres) {
+  float4 g = *reinterpret_cast<const float4*>(p.dy + row * p.ldg + c);
+  if (p.has_res) {
+    const float4 o = *reinterpret_cast<const float4*>(p.out + row * p.ldo + c);
+    g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+    if (dres) *dres = g;
+  }
+  if (p.act == CRAFT_ACT_RELU) {
+    g.x = q.z.x > 0.f ? g.x : 0.f; g.y = q.z.y > 0.f ? g.y : 0.f; g.z = q.z.z > 0.f ? g.z : 0.f; g.w = q.z.w > 0.f ? g.w : 0.f;
+  }
+  return g;
+}
+
+__global__ void k_norm_act_fwd(NormActParams p) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = p.C >> 2;
+  if (i >= (long)p.B * p.N * c4) return;
+  const long row = i / c4;
+  const int c = (int)(i - row * c4) * 4, b = (int)(row / p.N);
+  const Quad q = norm_quad(p, b, row, c);
+  float4 t = q.z;
+  if (p.act == CRAFT_ACT_RELU) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+  if (p.res) {
+    const float4 r = *reinterpret_cast<const float4*>(p.res + row * p.ldr + c);
+    t.x = fmaxf(t.x + r.x, 0.f); t.y = fmaxf(t.y + r.y, 0.f); t.z = fmaxf(t.z + r.z, 0.f); t.w = fmaxf(t.w + r.w, 0.f);
+  }
+  *reinterpret_cast<float4*>(p.out + row * p.ldo + c) = t;
+}
+
+// grid (row chunks, B); a block owns NORM_ROWS rows of one image; thread -> channel quad (tid % c4) and row lane (tid / c4)
+constexpr int NORM_ROWS = 512;
+__global__ __launch_bounds__(256) void k_norm_act_bwd_reduce(NormActParams p) {
+  __shared__ float sh[256 * 8];
+  const int tid = threadIdx.x, c4 = p.C >> 2, b = blockIdx.y;
+  const int rl = tid / c4, nrl = 256 / c4, cq = tid - rl * c4;
+  float4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  if (rl < nrl) {
+    const int r0 = blockIdx.x * NORM_ROWS, r1 = min(p.N, r0 + NORM_ROWS);
+    for (int r = r0 + rl; r < r1; r += nrl) {
+      const long row = (long)b * p.N + r;
+      const Quad q = norm_quad(p, b, row, cq * 4);
+      const float4 dz = norm_dz(p, q, row, cq * 4, nullptr);
+      s1.x += dz.x; s1.y += dz.y; s1.z += dz.z; s1.w += dz.w;
+      s2.x += dz.x * q.xh.x; s2.y += dz.y * q.xh.y; s2.z += dz.z * q.xh.z; s2.w += dz.w * q.xh.w;
+    }
+  }
+  float* my = sh + tid * 8;
+  my[0] = s1.x; my[1] = s1.y; my[2] = s1.z; my[3] = s1.w; my[4] = s2.x; my[5] = s2.y; my[6] = s2.z; my[7] = s2.w;
+  __syncthreads();
+  // t < C * 2: channel t / 2, which = t & 1 -> sum over the row lanes
+  for (int t = tid; t < p.C * 2; t += 256) {
+    const int ch = t >> 1, which = t & 1;
+    const int q = ch >> 2, j = ch & 3;
+    double acc = 0.0;
+    for (int l = 0; l < nrl; ++l) acc += (double)sh[(l * c4 + q) * 8 + which * 4 + j];
+    unsafeAtomicAdd(p.sums + ((long)b * p.C + ch) * 2 + which, acc);
+  }
+}
+
+__global__ void k_norm_act_bwd_apply(NormActParams p) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = p.C >> 2;
+  if (i >= (long)p.B * p.N * c4) return;
+  const long row = i / c4;
+  const int c = (int)(i - row * c4) * 4, b = (int)(row / p.N);
+  const Quad q = norm_quad(p, b, row, c);
+  float4 dr;
+  const float4 dz = norm_dz(p, q, row, c, &dr);
+  if (p.has_res && p.dres) *reinterpret_cast<float4*>(p.dres + row * p.lddr + c) = dr;
+  float4 m1 = {0.f, 0.f, 0.f, 0.f}, m2 = {0.f, 0.f, 0.f, 0.f};
+  if (p.red) {
+    const float* m = p.red + ((long)b * p.red_bs + c) * 2;
+    const float4 a = *reinterpret_cast<const float4*>(m), bb = *reinterpret_cast<const float4*>(m + 4);
+    m1 = make_float4(a.x, a.z, bb.x, bb.z);
+    m2 = make_float4(a.y, a.w, bb.y, bb.w);
+  }
+  float4 dx;
+  dx.x = q.sc.x * (dz.x - m1.x - q.xh.x * m2.x);
+  dx.y = q.sc.y * (dz.y - m1.y - q.xh.y * m2.y);
+  dx.z = q.sc.z * (dz.z - m1.z - q.xh.z * m2.z);
+  dx.w = q.sc.w * (dz.w - m1.w - q.xh.w * m2.w);
+  *reinterpret_cast<float4*>(p.dx + row * p.lddx + c) = dx;
+}
+
+static int check_norm(const NormActParams& p) {
+  if (p.B <= 0 || p.N <= 0 || p.C <= 0) return 1;       // empty
+  if ((p.C & 3) || p.C > 512 || (p.ldx & 3) || (p.mr_bs != 0 && p.mr_bs != p.C)) return CRAFT_ERR_ALIGN;
+  return 0;
+}
+
+int launch_norm_act_fwd(const NormActParams& p, hipStream_t s) {
+  const int rc = check_norm(p);
+  if (rc) return rc == 1 ? 0 : rc;
+  if ((p.ldo & 3) || (p.res && (p.ldr & 3))) return CRAFT_ERR_ALIGN;
+  const long n = (long)p.B * p.N * (p.C >> 2);
+  hipLaunchKernelGGL(k_norm_act_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+  return (int)hipGetLastError();
+}
+int launch_norm_act_bwd_reduce(const NormActParams& p, hipStream_t s) {
+  const int rc = check_norm(p);
+  if (rc) return rc == 1 ? 0 : rc;
+  if ((p.ldg & 3) || (p.has_res && (p.ldo & 3))) return CRAFT_ERR_ALIGN;
+  hipLaunchKernelGGL(k_norm_act_bwd_reduce, dim3((unsigned)((p.N + NORM_ROWS - 1) / NORM_ROWS), (unsigned)p.B), dim3(256), 0, s, p);
+  return (int)hipGetLastError();
+}
+int launch_norm_act_bwd_apply(const NormActParams& p, hipStream_t s) {
+  const int rc = check_norm(p);
+  if (rc) return rc == 1 ? 0 : rc;
+  if ((p.ldg & 3) || (p.lddx & 3) || (p.has_res && ((p.ldo & 3) || (p.dres && (p.lddr & 3)))) || (p.red && p.red_bs != 0 && p.red_bs != p.C))
+    return CRAFT_ERR_ALIGN;
+  const long n = (long)p.B * p.N * (p.C >> 2);
+  hipLaunchKernelGGL(k_norm_act_bwd_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stem weight gradient: the 7x7 / stride-2 / 3-channel convolution's input patches as a matrix,
+//   cols[p][(ky*7 + kx)*3 + c] = 2 * image[b][c][2*oy + ky - 3][2*ox + kx - 3] / 255 - 1   (0 outside the image, and for k >= 147)
+// with p = (b, oy, ox) and ld = 160, so that dW = dY^T . cols is one k-major x k-major craft_gemm (K = all output pixels).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_stem_im2col(const float* __restrict__ img, int B, int H, int W, float* __restrict__ cols) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Ho = H / 2, Wo = W / 2;
+  if (i >= (long)B * Ho * Wo * 160) return;
+  const long pix = i / 160;
+  const int k = (int)(i - pix * 160);
+  float v = 0.f;
+  if (k < 147) {
+    const int tap = k / 3, c = k - tap * 3, ky = tap / 7, kx = tap - ky * 7;
+    const int b = (int)(pix / ((long)Ho * Wo));
+    const int rem = (int)(pix - (long)b * Ho * Wo), oy = rem / Wo, ox = rem - oy * Wo;
+    const int y = 2 * oy + ky - 3, x = 2 * ox + kx - 3;
+    if (y >= 0 && y < H && x >= 0 && x < W) v = 2.f * (img[(((long)b * 3 + c) * H + y) * W + x] / 255.f) - 1.f;
+  }
+  cols[i] = v;
+}
+int launch_stem_im2col(const float* img, int B, int H, int W, float* cols, hipStream_t s) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  if ((H & 1) || (W & 1)) return CRAFT_ERR_ALIGN;
+  const long n = (long)B * (H / 2) * (W / 2) * 160;
+  hipLaunchKernelGGL(k_stem_im2col, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img, B, H, W, cols);
+  return (int)hipGetLastError();
+}
+
+// zero-stuffing of a stride-2 layer's output gradient: g [B][Ho*Wo][C] -> gf [B][Hin*Win][C], gf(2oy, 2ox) = g(oy, ox), 0 elsewhere.
+// The backward of a stride-2 convolution is then the backward of the stride-1 convolution it subsamples.
+__global__ void k_zero_stuff2(const float* __restrict__ g, long ldg, int B, int Hin, int Win, int C, float* __restrict__ gf, long ldf) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C >> 2;
+  if (i >= (long)B * Hin * Win * c4) return;
+  const long row = i / c4;
+  const int c = (int)(i - row * c4) * 4;
+  const int b = (int)(row / ((long)Hin * Win));
+  const int rem = (int)(row - (long)b * Hin * Win), y = rem / Win, x = rem - y * Win;
+  float4 v = {0.f, 0.f, 0.f, 0.f};
+  const int Ho = Hin / 2, Wo = Win / 2;
+  if (!(y & 1) && !(x & 1) && (y >> 1) < Ho && (x >> 1) < Wo)
+    v = *reinterpret_cast<const float4*>(g + (((long)b * Ho + (y >> 1)) * Wo + (x >> 1)) * ldg + c);
+  *reinterpret_cast<float4*>(gf + row * ldf + c) = v;
+}
+int launch_zero_stuff2(const float* g, long ldg, int B, int Hin, int Win, int C, float* gf, long ldf, hipStream_t s) {
+  if (B <= 0 || Hin <= 0 || Win <= 0 || C <= 0) return 0;
+  if ((C & 3) || (ldg & 3) || (ldf & 3) || (Hin & 1) || (Win & 1)) return CRAFT_ERR_ALIGN;
+  const long n = (long)B * Hin * Win * (C >> 2);
+  hipLaunchKernelGGL(k_zero_stuff2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, ldg, B, Hin, Win, C, gf, ldf);
+  return (int)hipGetLastError();
+}
+
+}  // namespace craft

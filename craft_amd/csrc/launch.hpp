@@ -145,6 +145,27 @@ int launch_gemm_gen(const float* A, long a_sm, long a_sk, long a_bs0, long a_bs1
                     int accumulate, int ksplit, int prec, hipStream_t s);
 int launch_conv_wgrad(const float* x, long ldx, int cin, const float* dy, long ldy, int cout, int KH, int KW, int B, int H, int W,
                       float* dW, float* ws, long ws_floats, int prec, hipStream_t s);
+// kernels_enc_train.hip
+struct NormActParams {
+  const float* x; long ldx;
+  const float* mr; int mr_bs;             // (mean, rstd) at mr[(b * mr_bs + c) * 2]; mr_bs = C (per image) or 0 (per channel)
+  const float* gamma; const float* beta;  // may be null (1, 0)
+  int act;                                // CRAFT_ACT_NONE / CRAFT_ACT_RELU on the normalised value
+  const float* res; long ldr;             // forward: residual input (null: none)
+  float* out; long ldo;                   // forward output; backward: the forward's output (read only when has_res)
+  const float* dy; long ldg;
+  int has_res;
+  const float* red; int red_bs;           // backward apply: (mean dz, mean dz * x^) at red[(b * red_bs + c) * 2]; null = (0, 0)
+  float* dx; long lddx;
+  float* dres; long lddr;
+  double* sums;                           // backward reduce: [B][C][2] += (sum dz, sum dz * x^)
+  int B, N, C;
+};
+int launch_norm_act_fwd(const NormActParams& p, hipStream_t s);
+int launch_norm_act_bwd_reduce(const NormActParams& p, hipStream_t s);
+int launch_norm_act_bwd_apply(const NormActParams& p, hipStream_t s);
+int launch_stem_im2col(const float* img, int B, int H, int W, float* cols, hipStream_t s);
+int launch_zero_stuff2(const float* g, long ldg, int B, int Hin, int Win, int C, float* gf, long ldf, hipStream_t s);
 int launch_colsum(const float* x, long ld, long rows, int C, float* out, hipStream_t s);
 int launch_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, hipStream_t s);
 int launch_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,

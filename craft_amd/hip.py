@@ -66,6 +66,11 @@ _SIGS = {
     # ---- training
     "craft_gemm": [P, L, L, L, L, P, L, L, L, L, P, L, L, L, I, I, I, I, I, F, I, I, I, P],
     "craft_conv2d_wgrad": [P, L, I, P, L, I, I, I, I, I, I, P, P, L, I, P],
+    "craft_norm_act_fwd": [P, L, P, I, P, P, I, P, L, P, L, I, I, I, P],
+    "craft_norm_act_bwd_reduce": [P, L, P, L, P, L, P, I, P, P, I, I, P, I, I, I, P],
+    "craft_norm_act_bwd_apply": [P, L, P, L, P, L, P, I, P, P, I, I, P, I, P, L, P, L, I, I, I, P],
+    "craft_stem_im2col": [P, I, I, I, P, P],
+    "craft_zero_stuff2": [P, L, I, I, I, I, P, L, P],
     "craft_colsum": [P, L, L, I, P, P],
     "craft_act_fwd": [P, L, P, L, L, I, I, F, P],
     "craft_act_bwd": [P, L, P, L, P, L, L, I, I, F, P],

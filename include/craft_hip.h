@@ -381,6 +381,33 @@ int craft_gru_out_bwd(const float* dh_new, long lddhn, const float* z, const flo
 int craft_gru_zr_bwd(const float* dz, const float* drh, long lddrh, const float* z, const float* r, const float* h, long ldh, float* dzr_pre,
                      float* dh, long rows, int C, void* stream);
 
+/* ---- CNN encoders in training (BasicEncoder / ResidualBlock with autograd on: extractor.py:6-64, 124-196) ----
+ * The inference path folds the encoders' normalisation layers away; training needs them as operators with a backward.
+ * craft_norm_act_fwd: out = tail(act((x - mean) * rstd * gamma + beta)) on tokens [B][N][C] (C % 4 == 0);
+ *   mean_rstd [B][C][2] (mr_per_image = 1: nn.InstanceNorm2d, statistics from craft_conv2d_nhwc_ex + craft_stats_finalize) or
+ *   [C][2] (mr_per_image = 0: nn.BatchNorm2d, batch statistics in training / running statistics under freeze_bn);
+ *   gamma / beta may be NULL (InstanceNorm2d is not affine); act = 0 / CRAFT ReLU (2); res != NULL: tail(t) = relu(res + t), the
+ *   end of ResidualBlock.forward (extractor.py:56-64).
+ * craft_norm_act_bwd_reduce: sums [B][C][2] (doubles, zeroed by the caller) += (sum dz, sum dz * x^) per image and channel, where dz
+ *   is dy masked by the tail's ReLU (has_res: out > 0) and the inner ReLU, x^ = (x - mean) * rstd.  dbeta / dgamma are these sums
+ *   (summed over the batch), and mean_P(dz), mean_P(dz * x^) over the normalisation population P feed the next call.
+ * craft_norm_act_bwd_apply: dx = gamma * rstd * (dz - red[..][0] - x^ * red[..][1]) with red [B][C][2] / [C][2] (red_per_image) or
+ *   NULL (running statistics: no mean terms); has_res: dres = dy masked by out > 0 (the gradient of the residual input).
+ * craft_stem_im2col: the 7x7 / stride-2 stem's input patches as rows of 160 floats (147 = (ky*7+kx)*3 + c, then zeros) with the
+ *   input normalisation 2*(x/255)-1 applied, one row per output pixel: the stem's weight gradient is craft_gemm(dY^T . cols).
+ * craft_zero_stuff2: gf [B][Hin*Win][C] = g [B][(Hin/2)*(Win/2)][C] at the even positions, 0 elsewhere: the backward of a
+ *   stride-2 convolution is the backward of the stride-1 convolution it subsamples, applied to gf. */
+int craft_norm_act_fwd(const float* x, long ldx, const float* mean_rstd, int mr_per_image, const float* gamma, const float* beta, int act,
+                       const float* res, long ldr, float* out, long ldo, int B, int N, int C, void* stream);
+int craft_norm_act_bwd_reduce(const float* dy, long ldg, const float* out, long ldo, const float* x, long ldx, const float* mean_rstd,
+                              int mr_per_image, const float* gamma, const float* beta, int act, int has_res, double* sums, int B, int N,
+                              int C, void* stream);
+int craft_norm_act_bwd_apply(const float* dy, long ldg, const float* out, long ldo, const float* x, long ldx, const float* mean_rstd,
+                             int mr_per_image, const float* gamma, const float* beta, int act, int has_res, const float* red,
+                             int red_per_image, float* dx, long lddx, float* dres, long lddr, int B, int N, int C, void* stream);
+int craft_stem_im2col(const float* image, int B, int H, int W, float* cols, void* stream);
+int craft_zero_stuff2(const float* g, long ldg, int B, int Hin, int Win, int C, float* gf, long ldf, void* stream);
+
 /* ==== input pipeline on the GPU (core/utils/augmentor.py) ========================================
  * All images are float HWC in 0..255 ([H][W][3]), flow [H][W][2] (x, y); the host draws the random parameters.
  * craft_aug_spatial: FlowAugmentor.spatial_transform (augmentor.py:141-193) as one gather: out [ch][cw][C] = crop at (y0, x0) of
