@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0: min(32, logical CPUs))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ops", action="store_true", help="also print a per-operator timing table to stderr")
+    ap.add_argument("--torch-encoders", action="store_true",
+                    help="--train only: keep the two CNN encoders on PyTorch-ROCm / MIOpen under torch autograd (developer A/B)")
     ap.add_argument("--train", type=int, default=0, choices=[0, 3, 4],
                     help="3 / 4: time the TRAINING step of BASELINE.json configs[3] (FlyingChairs 368x496, batch 8/GPU) / configs[4] "
                          "(Sintel 368x768 crops, batch 4/GPU, bf16 MFMA attention) instead of the inference headline: forward + "
@@ -236,7 +238,7 @@ def train_bench(a, rank, world, dev, dist):
         W = a.width
     if "--precision" in argv:
         policy = a.precision
-    model = CRAFT(default_args(hip_precision=policy))
+    model = CRAFT(default_args(hip_precision=policy, hip_encoders=not a.torch_encoders))
     model.load_state_dict(synth_state_dict(model.state_dict(), seed=1234), strict=True)
     model = model.to(dev)
     tr = Trainer(model, lr=4e-4 if a.train == 3 else 1.25e-4, wdecay=1e-4 if a.train == 3 else 1e-5, num_steps=100000, iters=a.iters,

@@ -240,9 +240,10 @@ template <int ROWS> struct LoaderShiftColsF32 {
   unsigned rowoff;         // per lane: byte offset of this lane's row (input channel)
   long ld;
   int k0, k1, kg0, H, W, dy, dx, npix;
-  unsigned magic_hw, magic_w;          // ceil(2^32 / (H*W)), ceil(2^32 / W): k / d = umulhi(k, magic) for k * d < 2^32 (launcher checks)
+  unsigned long long magic_hw;         // ceil(2^64 / (H*W)): k / (H*W) = umul64hi(k, magic_hw), exact for every 32-bit k
+  unsigned magic_w;                    // ceil(2^32 / W): r / W = umulhi(r, magic_w) for r * W < 2^32 (r < H*W; launcher checks)
   __device__ __forceinline__ void init(const float* base_, long ld_, int row0, int nrows, int k0_, int k1_, int npix_, int H_, int W_,
-                                       int dy_, int dx_, unsigned magic_hw_, unsigned magic_w_, int tid) {
+                                       int dy_, int dx_, unsigned long long magic_hw_, unsigned magic_w_, int tid) {
     ld = ld_; k0 = k0_; k1 = k1_; npix = npix_; H = H_; W = W_; dy = dy_; dx = dx_; magic_hw = magic_hw_; magic_w = magic_w_;
     base = base_;
     rowoff = 4u * (unsigned)min(row0 + tid % ROWS, nrows - 1);
@@ -259,7 +260,7 @@ template <int ROWS> struct LoaderShiftColsF32 {
     float t[NE];
     unsigned zm = 0u;
     if (kb + NE <= k1 && kb + shift >= 0 && kb + NE - 1 + shift < npix && W >= NE) {
-      const int rem = kb - (int)__umulhi((unsigned)kb, magic_hw) * hw;
+      const int rem = kb - (int)__umul64hi((unsigned long long)kb, magic_hw) * hw;
       const int y = (int)__umulhi((unsigned)rem, magic_w), x = rem - y * W;
       const int n1 = min(NE, W - x);                  // pixels left in row y; the rest start row y + 1 (or row 0 of the next image)
       const int x0 = x + dx;
@@ -276,7 +277,7 @@ template <int ROWS> struct LoaderShiftColsF32 {
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         const int k = kb + e, kc = min(k, k1 - 1);
-        const int rem = kc - (int)__umulhi((unsigned)kc, magic_hw) * hw;
+        const int rem = kc - (int)__umul64hi((unsigned long long)kc, magic_hw) * hw;
         const int y = (int)__umulhi((unsigned)rem, magic_w), x = rem - y * W;
         const bool ok = k < k1 && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
         zm |= ok ? 0u : (1u << e);
@@ -297,7 +298,8 @@ struct WgradParams {
   long ldx, ldy;
   int cin, cout, KH, KW, B, H, W;
   int ksplit, kchunk, ntile_n, ntile_m;
-  unsigned magic_hw, magic_w;
+  unsigned long long magic_hw;
+  unsigned magic_w;
 };
 
 template <int PREC, int BN>
@@ -354,8 +356,8 @@ int launch_conv_wgrad(const float* x, long ldx, int cin, const float* dy, long l
   const int bn = cin > 96 ? 128 : 64;
   p.ntile_n = (cin + bn - 1) / bn;
   p.ntile_m = (cout + 127) / 128;
-  if ((double)B * H * W * ((double)H * W) >= 4294967296.0 || H * W < 2 || W < 2) return CRAFT_ERR_UNSUPPORTED;   // magic-number division range
-  p.magic_hw = (unsigned)((4294967296ULL + (unsigned long long)(H * W) - 1) / (unsigned long long)(H * W));
+  if ((double)B * H * W >= 2147483648.0 || (double)H * W * W >= 4294967296.0 || H * W < 2 || W < 2) return CRAFT_ERR_UNSUPPORTED;   // division ranges
+  p.magic_hw = ~0ULL / (unsigned long long)(H * W) + 1ULL;
   p.magic_w = (unsigned)((4294967296ULL + (unsigned long long)W - 1) / (unsigned long long)W);
   const long npix = (long)B * H * W;
   const long tiles = (long)((cout + 127) / 128) * p.ntile_n * KH * KW;

@@ -6,9 +6,9 @@ Training-mode semantics of the reference that are reproduced: BatchNorm batch st
 (extractor.py norm_fn='batch'; network.py:136-140), dropout 0.1 on the LayerNorm-ed tokens of every vispos encoder
 (setrans.py:791-795) and 0.2 on the attention probabilities of the F2 transformer and the intra-frame attention
 (setrans.py:553-557; not on the inter-frame scores, :544-550), ``coords1.detach()`` at the top of every iteration
-(network.py:232), all T upsampled predictions returned (test_mode=0).  The two CNN encoders run as PyTorch-ROCm modules
-under torch autograd (BASELINE.json north_star: "Host code stays Python on PyTorch-ROCm for the CNN feature/context
-extractors").  Only the released configuration trains here (``--craft --f2 full --setrans``, no ``--f1``).
+(network.py:232), all T upsampled predictions returned (test_mode=0).  The two CNN encoders run on the HIP kernels too
+(craft_amd/train_encoder.py); ``args.hip_encoders=False`` keeps them as PyTorch-ROCm modules under torch autograd (BASELINE.json
+north_star: "Host code stays Python on PyTorch-ROCm for the CNN feature/context extractors").  Only the released configuration trains here (``--craft --f2 full --setrans``, no ``--f1``).
 """
 from __future__ import annotations
 
@@ -18,6 +18,7 @@ import torch
 
 from . import autograd as AG
 from . import ops
+from . import train_encoder as TE
 from .hip import ACT_NONE, ACT_RELU, ACT_TANH, PREC_BF16, PREC_F16
 
 
@@ -62,19 +63,29 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
     def p_attn(cfg):
         return float(getattr(args, "dropout_prob", -1)) if getattr(args, "dropout_prob", -1) >= 0 else float(cfg.attention_probs_dropout_prob)
 
-    # ---- CNN encoders: PyTorch-ROCm modules under autograd (network.py:169-183, :203) ---------------------------------
-    im1 = (2 * (image1.float() / 255.0) - 1.0).contiguous()
-    im2 = (2 * (image2.float() / 255.0) - 1.0).contiguous()
-    # prec.enc = bf16: the encoders run under autocast like the reference's mixed-precision training (network.py:179,199);
-    # fp16 would need the reference's GradScaler and is refused
+    # ---- CNN encoders (network.py:169-183, :203) -----------------------------------------------------------------------
+    # default: on the HIP kernels (craft_amd/train_encoder.py; args.hip_encoders=False or prec.enc = bf16 keeps the PyTorch-ROCm
+    # modules under torch autograd, the latter under autocast like the reference's mixed-precision training, network.py:179,199;
+    # enc = fp16 would need the reference's GradScaler and is refused)
     if prec.enc == PREC_F16:
         raise NotImplementedError("training: enc=fp16 needs loss scaling; use enc=bf16 (autocast) or an fp32-class mode")
-    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=prec.enc == PREC_BF16):
-        fmap1, fmap2 = model.fnet([im1, im2])
-        cnet_feat = model.cnet(im1)
-    f1_tok = AG.NchwToTokens.apply(fmap1.float())
-    f2_tok = AG.NchwToTokens.apply(fmap2.float())
-    cn_tok = AG.NchwToTokens.apply(cnet_feat.float())
+    H, W = image1.shape[-2:]
+    use_henc = (getattr(args, "hip_encoders", True) and prec.enc != PREC_BF16 and TE.supported(model.fnet, H, W)
+                and TE.supported(model.cnet, H, W))
+    if use_henc:
+        B = image1.shape[0]
+        f12 = TE.encoder_forward_train(model.fnet, torch.cat([image1, image2], dim=0).float(), prec)
+        f1_tok, f2_tok = f12[:B], f12[B:]
+        cn_tok = TE.encoder_forward_train(model.cnet, image1.float(), prec)
+    else:
+        im1 = (2 * (image1.float() / 255.0) - 1.0).contiguous()
+        im2 = (2 * (image2.float() / 255.0) - 1.0).contiguous()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=prec.enc == PREC_BF16):
+            fmap1, fmap2 = model.fnet([im1, im2])
+            cnet_feat = model.cnet(im1)
+        f1_tok = AG.NchwToTokens.apply(fmap1.float())
+        f2_tok = AG.NchwToTokens.apply(fmap2.float())
+        cn_tok = AG.NchwToTokens.apply(cnet_feat.float())
     net = AG.TokensNorm.apply(cn_tok[..., 0:128], ACT_TANH, False)              # network.py:209-211
     inp = AG.TokensNorm.apply(cn_tok[..., 128:256], ACT_RELU, False)
 
