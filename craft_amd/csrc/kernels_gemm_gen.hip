@@ -244,9 +244,15 @@ template <int ROWS> struct LoaderShiftColsF32 {
   unsigned magic_w;                    // ceil(2^32 / W): r / W = umulhi(r, magic_w) for r * W < 2^32 (r < H*W; launcher checks)
   __device__ __forceinline__ void init(const float* base_, long ld_, int row0, int nrows, int k0_, int k1_, int npix_, int H_, int W_,
                                        int dy_, int dx_, unsigned long long magic_hw_, unsigned magic_w_, int tid) {
-    ld = ld_; k0 = k0_; k1 = k1_; npix = npix_; H = H_; W = W_; dy = dy_; dx = dx_; magic_hw = magic_hw_; magic_w = magic_w_;
+    init_row(base_, ld_, min(row0 + tid % ROWS, nrows - 1), k0_, k1_, npix_, H_, W_, dy_, dx_, magic_hw_, magic_w_, tid);
+  }
+  // `row` = this lane's channel, (dy_, dx_) = the tap: both may differ between WAVES (a wave = 64 consecutive tile rows), not lanes
+  __device__ __forceinline__ void init_row(const float* base_, long ld_, int row, int k0_, int k1_, int npix_, int H_, int W_, int dy_,
+                                           int dx_, unsigned long long magic_hw_, unsigned magic_w_, int tid) {
+    ld = ld_; k0 = k0_; k1 = k1_; npix = npix_; H = H_; W = W_; magic_hw = magic_hw_; magic_w = magic_w_;
+    dy = __builtin_amdgcn_readfirstlane(dy_); dx = __builtin_amdgcn_readfirstlane(dx_);
     base = base_;
-    rowoff = 4u * (unsigned)min(row0 + tid % ROWS, nrows - 1);
+    rowoff = 4u * (unsigned)row;
     kg0 = __builtin_amdgcn_readfirstlane((tid / ROWS) * NG);
   }
   // A wave's NE pixels of one K-tile are consecutive (k = kb .. kb + NE - 1) and wave-uniform (see LoaderColsF32): ONE pair of
@@ -344,6 +350,43 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_wgrad(WgradParams p) {
   }
 }
 
+// cout <= 64 and cin == 64 (the encoders' 64-channel layers): a 128-row M tile would be half padding.  Here the block tile is
+// 64 (cout) x 128 = TWO taps x 64 input channels, 4 waves side by side along N (each 64 x 32): the B tile's rows 0..63 are X at tap
+// 2t, rows 64..127 X at tap 2t + 1 -- a wave's 64 rows share one tap, which is all the shifted loader needs.
+template <int PREC>
+__global__ __launch_bounds__(NTHREADS) void k_conv_wgrad64(WgradParams p) {
+  constexpr int BM = 64, BN = 128, WM = 1, WN = 4, MT = 2, NT = 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int taps = p.KH * p.KW, ntile = (taps + 1) / 2;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int split = xcd + 8 * (j / ntile), tile = j - (j / ntile) * ntile;
+  const int npix = p.B * p.H * p.W;
+  if (split >= p.ksplit) return;
+  const int k0 = split * p.kchunk, k1 = min(npix, k0 + p.kchunk);
+  if (k0 >= k1) return;
+  f32x16 acc[MT][NT];
+  acc_zero(acc);
+  LoaderColsF32<BM> la;
+  la.init(p.dY, p.ldy, 0, p.cout, k0, k1, tid);
+  const int brow = tid % BN;                                   // tile row of the B operand this lane stages
+  const int tap_l = 2 * tile + brow / 64;
+  const bool tap_ok = tap_l < taps;
+  const int ky = tap_l / p.KW, kx = tap_l - ky * p.KW;
+  LoaderShiftColsF32<BN> lb;
+  // a tap that does not exist (odd tap count) reads as "always outside the image": dy = H
+  lb.init_row(p.X, p.ldx, brow % 64, k0, k1, npix, p.H, p.W, tap_ok ? ky - p.KH / 2 : p.H, tap_ok ? kx - p.KW / 2 : 0, p.magic_hw,
+              p.magic_w, tid);
+  gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, (k1 - k0 + BK - 1) / BK, acc, NoFold());
+  const int cb = wave * 32;
+  acc_foreach(acc, lane, [&](int r, int c, float v, int, int, int) {
+    const int co = r, n = cb + c, tap = 2 * tile + (n >> 6), ci = n & 63;
+    if (co < p.cout && tap < taps) {
+      float* d = (p.ws ? p.ws + (long)split * p.cout * taps * 64 : p.dW) + ((long)co * taps + tap) * 64 + ci;
+      if (p.ws) *d = v; else unsafeAtomicAdd(d, v);
+    }
+  });
+}
+
 int launch_reduce_replicas(const float* rep, int nrep, int n, float* out, hipStream_t s);
 
 int launch_conv_wgrad(const float* x, long ldx, int cin, const float* dy, long ldy, int cout, int KH, int KW, int B, int H, int W,
@@ -360,7 +403,7 @@ int launch_conv_wgrad(const float* x, long ldx, int cin, const float* dy, long l
   p.magic_hw = ~0ULL / (unsigned long long)(H * W) + 1ULL;
   p.magic_w = (unsigned)((4294967296ULL + (unsigned long long)W - 1) / (unsigned long long)W);
   const long npix = (long)B * H * W;
-  const long tiles = (long)((cout + 127) / 128) * p.ntile_n * KH * KW;
+  const long tiles = (cout <= 64 && cin == 64 && !tuning().no_wgrad64) ? (KH * KW + 1) / 2 : (long)((cout + 127) / 128) * p.ntile_n * KH * KW;
   long want = (768 + tiles - 1) / tiles;
   const long maxs = (npix + 511) / 512;
   p.ksplit = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
@@ -371,9 +414,11 @@ int launch_conv_wgrad(const float* x, long ldx, int cin, const float* dy, long l
   p.kchunk = (int)((((npix + p.ksplit - 1) / p.ksplit) + BK - 1) / BK * BK);
   const int nz = (int)((npix + p.kchunk - 1) / p.kchunk);          // splits that actually own pixels (the others would leave holes)
   p.ksplit = nz;
-  const int ntile = p.ntile_m * p.ntile_n * KH * KW;
+  const bool pair64 = cout <= 64 && cin == 64 && !tuning().no_wgrad64;
+  const int ntile = pair64 ? (KH * KW + 1) / 2 : p.ntile_m * p.ntile_n * KH * KW;
   dim3 grid((unsigned)(8 * ntile * ((p.ksplit + 7) / 8)), 1, 1);
-#define GO(PR) do { if (bn == 128) hipLaunchKernelGGL((k_conv_wgrad<PR, 128>), grid, dim3(NTHREADS), 0, s, p); \
+#define GO(PR) do { if (pair64) hipLaunchKernelGGL((k_conv_wgrad64<PR>), grid, dim3(NTHREADS), 0, s, p); \
+                    else if (bn == 128) hipLaunchKernelGGL((k_conv_wgrad<PR, 128>), grid, dim3(NTHREADS), 0, s, p); \
                     else hipLaunchKernelGGL((k_conv_wgrad<PR, 64>), grid, dim3(NTHREADS), 0, s, p); \
                     if (hipGetLastError() != hipSuccess) return (int)hipGetLastError(); \
                     return p.ws ? launch_reduce_replicas(p.ws, p.ksplit, (int)nw, dW, s) : 0; } while (0)

@@ -27,10 +27,32 @@ def run(cl, amp=None):
         t2.record(); torch.cuda.synchronize()
         print(f"channels_last={cl} amp={amp} iter {it}: fwd {t0.elapsed_time(t1):.2f} ms bwd {t1.elapsed_time(t2):.2f} ms", flush=True)
 mode = sys.argv[1] if len(sys.argv) > 1 else 'all'
-run(False)
+if mode != 'hip':
+    run(False)
 if mode == 'all':
     run(True)
-run(False, torch.bfloat16)
-run(False, torch.float16)
+if mode != 'hip':
+    run(False, torch.bfloat16)
+    run(False, torch.float16)
 if mode == 'all':
     run(True, torch.bfloat16)
+
+
+def run_hip(prec_name="train_f16x3"):
+    from craft_amd.train_encoder import encoder_forward_train
+    from craft_amd.hip import Precision
+    prec = Precision.parse(prec_name)
+    raw1, raw2 = im1.to(dev), im2.to(dev)
+    for it in range(4):
+        for p in model.parameters(): p.grad = None
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True); t2 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        f12 = encoder_forward_train(model.fnet, torch.cat([raw1, raw2], 0), prec); cn = encoder_forward_train(model.cnet, raw1, prec)
+        t1.record()
+        torch.autograd.backward([f12, cn], [torch.ones_like(f12), torch.ones_like(cn)])
+        t2.record(); torch.cuda.synchronize()
+        print(f"hip {prec_name} iter {it}: fwd {t0.elapsed_time(t1):.2f} ms bwd {t1.elapsed_time(t2):.2f} ms", flush=True)
+
+
+if mode in ("all", "hip"):
+    run_hip()
