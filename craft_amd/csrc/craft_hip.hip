@@ -447,6 +447,14 @@ int craft_norm_act_bwd_apply(const float* dy, long ldg, const float* out, long l
   if (act != CRAFT_ACT_NONE && act != CRAFT_ACT_RELU) return CRAFT_ERR_UNSUPPORTED;
   return launch_norm_act_bwd_apply(p, S(stream));
 }
+int craft_bn_finalize(const double* stats, int B, int C, double count, float eps, float momentum, float* mean_rstd, float* running_mean,
+                      float* running_var, void* stream) {
+  return launch_bn_finalize(stats, B, C, count, eps, momentum, mean_rstd, running_mean, running_var, S(stream));
+}
+int craft_norm_bwd_finalize(const double* sums, int B, int C, double population, int per_image, float* red, float* dgamma, float* dbeta,
+                            void* stream) {
+  return launch_norm_bwd_finalize(sums, B, C, population, per_image, red, dgamma, dbeta, S(stream));
+}
 int craft_stem_im2col(const float* image, int B, int H, int W, float* cols, void* stream) {
   return launch_stem_im2col(image, B, H, W, cols, S(stream));
 }

@@ -201,4 +201,59 @@ int launch_zero_stuff2(const float* g, long ldg, int B, int Hin, int Win, int C,
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small per-channel finalisers (one thread per channel; they replace a dozen tiny tensor ops per layer).
+// craft_bn_finalize: BatchNorm2d statistics for craft_norm_act_fwd.  stats != NULL (training): the conv epilogue's
+//   [CRAFT_STATS_REPLICAS][B][C][2] (sum, sum^2) -> batch mean / biased variance over n = B * count samples -> mean_rstd [C][2], and
+//   running_mean / running_var (momentum update with the UNBIASED variance, nn.BatchNorm2d semantics).  stats == NULL (eval /
+//   freeze_bn): mean_rstd from the running statistics.
+// craft_norm_bwd_finalize: sums [B][C][2] of craft_norm_act_bwd_reduce -> red = population means for craft_norm_act_bwd_apply
+//   ([B][C][2] per image, [C][2] over the batch; skipped when population == 0) and dgamma / dbeta (batch sums; may be NULL).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_bn_finalize(const double* __restrict__ stats, int B, int C, double count, float eps, float momentum,
+                              float* __restrict__ mr, float* __restrict__ rmean, float* __restrict__ rvar) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (!stats) {
+    mr[2 * c] = rmean[c];
+    mr[2 * c + 1] = (float)(1.0 / sqrt((double)rvar[c] + (double)eps));
+    return;
+  }
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = 0; i < CRAFT_STATS_REPLICAS * B; ++i) { s0 += stats[((long)i * C + c) * 2]; s1 += stats[((long)i * C + c) * 2 + 1]; }
+  const double n = (double)B * count, mean = s0 / n, var = fmax(s1 / n - mean * mean, 0.0);
+  mr[2 * c] = (float)mean;
+  mr[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+  if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * (n / fmax(n - 1.0, 1.0)));
+}
+int launch_bn_finalize(const double* stats, int B, int C, double count, float eps, float momentum, float* mr, float* rmean, float* rvar,
+                       hipStream_t s) {
+  if (C <= 0) return 0;
+  if (!stats && (!rmean || !rvar)) return CRAFT_ERR_ARG;
+  hipLaunchKernelGGL(k_bn_finalize, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, stats, B, C, count, eps, momentum, mr, rmean, rvar);
+  return (int)hipGetLastError();
+}
+
+__global__ void k_norm_bwd_finalize(const double* __restrict__ sums, int B, int C, double population, int per_image,
+                                    float* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double t0 = 0.0, t1 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const double a0 = sums[((long)b * C + c) * 2], a1 = sums[((long)b * C + c) * 2 + 1];
+    t0 += a0; t1 += a1;
+    if (red && per_image && population > 0.0) { red[((long)b * C + c) * 2] = (float)(a0 / population); red[((long)b * C + c) * 2 + 1] = (float)(a1 / population); }
+  }
+  if (red && !per_image && population > 0.0) { red[2 * c] = (float)(t0 / population); red[2 * c + 1] = (float)(t1 / population); }
+  if (dbeta) dbeta[c] = (float)t0;
+  if (dgamma) dgamma[c] = (float)t1;
+}
+int launch_norm_bwd_finalize(const double* sums, int B, int C, double population, int per_image, float* red, float* dgamma, float* dbeta,
+                             hipStream_t s) {
+  if (C <= 0 || B <= 0) return 0;
+  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, s, sums, B, C, population, per_image, red, dgamma, dbeta);
+  return (int)hipGetLastError();
+}
+
 }  // namespace craft

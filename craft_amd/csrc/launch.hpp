@@ -166,6 +166,10 @@ int launch_norm_act_bwd_reduce(const NormActParams& p, hipStream_t s);
 int launch_norm_act_bwd_apply(const NormActParams& p, hipStream_t s);
 int launch_stem_im2col(const float* img, int B, int H, int W, float* cols, hipStream_t s);
 int launch_zero_stuff2(const float* g, long ldg, int B, int Hin, int Win, int C, float* gf, long ldf, hipStream_t s);
+int launch_bn_finalize(const double* stats, int B, int C, double count, float eps, float momentum, float* mr, float* rmean, float* rvar,
+                       hipStream_t s);
+int launch_norm_bwd_finalize(const double* sums, int B, int C, double population, int per_image, float* red, float* dgamma, float* dbeta,
+                             hipStream_t s);
 int launch_colsum(const float* x, long ld, long rows, int C, float* out, hipStream_t s);
 int launch_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, hipStream_t s);
 int launch_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,

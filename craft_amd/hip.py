@@ -69,6 +69,8 @@ _SIGS = {
     "craft_norm_act_fwd": [P, L, P, I, P, P, I, P, L, P, L, I, I, I, P],
     "craft_norm_act_bwd_reduce": [P, L, P, L, P, L, P, I, P, P, I, I, P, I, I, I, P],
     "craft_norm_act_bwd_apply": [P, L, P, L, P, L, P, I, P, P, I, I, P, I, P, L, P, L, I, I, I, P],
+    "craft_bn_finalize": [P, I, I, ctypes.c_double, F, F, P, P, P, P],
+    "craft_norm_bwd_finalize": [P, I, I, ctypes.c_double, I, P, P, P, P],
     "craft_stem_im2col": [P, I, I, I, P, P],
     "craft_zero_stuff2": [P, L, I, I, I, I, P, L, P],
     "craft_colsum": [P, L, L, I, P, P],

@@ -32,7 +32,7 @@ EPS = 1e-5        # nn.InstanceNorm2d / nn.BatchNorm2d default (extractor.py use
 
 class Stem(Function):
     @staticmethod
-    def forward(ctx, raw, w, b, prec):
+    def forward(ctx, raw, w, b, prec, bias_dead=False):
         B, _, H, W = raw.shape
         raw = raw.contiguous().float()
         out = torch.empty(B, (H // 2) * (W // 2), 64, device=raw.device, dtype=torch.float32)
@@ -52,7 +52,7 @@ class Stem(Function):
             call("craft_pack_weights", wm, 64, 192, prec, packed)
             call("craft_stem_conv7x7_mfma", raw, packed, bias, ACT_NONE, B, H, W, out, stats, prec)
         ctx.save_for_backward(raw)
-        ctx.prec = prec
+        ctx.prec, ctx.bias_dead = prec, bias_dead
         ctx.mark_non_differentiable(stats)
         return out, stats
 
@@ -71,15 +71,16 @@ class Stem(Function):
             dw = dwc[:, :147].reshape(64, 7, 7, 3).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[2]:
             db = torch.zeros(64, device=raw.device, dtype=torch.float32)
-            call("craft_colsum", dy, dy.stride(-2), P, 64, db)
-        return None, dw, db, None
+            if not ctx.bias_dead:
+                call("craft_colsum", dy, dy.stride(-2), P, 64, db)
+        return None, dw, db, None, None
 
 
 class EncConv(Function):
     """nn.Conv2d(k = 3 pad 1 | k = 1, stride 1 | 2) + bias on tokens, plus the per-(image, channel) (sum, sum^2) of the output."""
 
     @staticmethod
-    def forward(ctx, x, w, b, hw_in, stride, prec, cache):
+    def forward(ctx, x, w, b, hw_in, stride, prec, cache, bias_dead=False):
         x = AG._rows(x)
         B, _, Cin = x.shape
         Cout, _, KH, KW = w.shape
@@ -95,7 +96,7 @@ class EncConv(Function):
         call("craft_conv2d_nhwc_ex", x, x.stride(1), Cin, Hin, Win, None, wp, b.detach().float().contiguous(), Cout, KH, KW, stride, ACT_NONE,
              y, Cout, B, Ho, Wo, stats, prec | (W_PACKED if halo else 0))
         ctx.save_for_backward(x)
-        ctx.w, ctx.cache, ctx.prec, ctx.stride, ctx.hw_in = w, cache, prec, stride, hw_in
+        ctx.w, ctx.cache, ctx.prec, ctx.stride, ctx.hw_in, ctx.bias_dead = w, cache, prec, stride, hw_in, bias_dead
         ctx.mark_non_differentiable(stats)
         return y, stats
 
@@ -122,8 +123,9 @@ class EncConv(Function):
             dw = dwp.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[2]:
             db = torch.zeros(Cout, device=dev, dtype=torch.float32)
-            call("craft_colsum", dy, dy.stride(-2), dy.shape[0] * dy.shape[1], Cout, db)
-        return dx, dw, db, None, None, None, None
+            if not ctx.bias_dead:          # a bias in front of a statistics-normalised layer cannot move the loss: its gradient is 0
+                call("craft_colsum", dy, dy.stride(-2), dy.shape[0] * dy.shape[1], Cout, db)
+        return dx, dw, db, None, None, None, None, None
 
 
 class NormAct(Function):
@@ -153,21 +155,17 @@ class NormAct(Function):
         ldo = out.stride(-2) if out is not None else 0
         call("craft_norm_act_bwd_reduce", dy, dy.stride(-2), out, ldo, x, x.stride(-2), mr, int(ctx.per_image), gamma, beta, ctx.act, int(ctx.has_res),
              sums, B, N, C)
-        red, red_pi = None, 0
+        red, red_pi = None, int(ctx.per_image)
         if ctx.population:
-            if ctx.per_image:
-                red, red_pi = (sums / float(ctx.population)).float().contiguous(), 1
-            else:
-                red = (sums.sum(0) / float(ctx.population)).float().contiguous()
+            red = torch.empty((B, C, 2) if ctx.per_image else (C, 2), device=dev, dtype=torch.float32)
+        dgamma = torch.empty(C, device=dev, dtype=torch.float32) if gamma is not None and ctx.needs_input_grad[2] else None
+        dbeta = torch.empty(C, device=dev, dtype=torch.float32) if beta is not None and ctx.needs_input_grad[3] else None
+        if red is not None or dgamma is not None or dbeta is not None:
+            call("craft_norm_bwd_finalize", sums, B, C, float(ctx.population), red_pi, red, dgamma, dbeta)
         dx = torch.empty(B, N, C, device=dev, dtype=torch.float32)
         dres = torch.empty(B, N, C, device=dev, dtype=torch.float32) if ctx.has_res and ctx.needs_input_grad[5] else None
         call("craft_norm_act_bwd_apply", dy, dy.stride(-2), out, ldo, x, x.stride(-2), mr, int(ctx.per_image), gamma, beta, ctx.act, int(ctx.has_res),
              red, red_pi, dx, C, dres, C, B, N, C)
-        dgamma = dbeta = None
-        if gamma is not None and ctx.needs_input_grad[2]:
-            dgamma = sums[..., 1].sum(0).float()
-        if beta is not None and ctx.needs_input_grad[3]:
-            dbeta = sums[..., 0].sum(0).float()
         return dx, None, dgamma, dbeta, None, dres, None
 
 
@@ -179,19 +177,14 @@ def _norm(y, stats, count, mod, act, res=None):
         call("craft_stats_finalize", stats, B * C, float(count), EPS, mr)
         return NormAct.apply(y, mr, None, None, act, res, count)
     if isinstance(mod, nn.BatchNorm2d):
-        if mod.training:
-            s = stats.sum((0, 1))                                  # [C, 2] doubles over replicas and images
-            n = float(B * count)
-            mean = s[:, 0] / n
-            var = (s[:, 1] / n - mean * mean).clamp_min(0.0)
-            mr = torch.stack([mean, torch.rsqrt(var + mod.eps)], dim=1).float().contiguous()
-            with torch.no_grad():                                  # running statistics (momentum 0.1, unbiased variance)
-                m = mod.momentum if mod.momentum is not None else 0.1
-                mod.running_mean.mul_(1 - m).add_(mean.float(), alpha=m)
-                mod.running_var.mul_(1 - m).add_((var * (n / max(n - 1.0, 1.0))).float(), alpha=m)
+        mr = torch.empty(C, 2, device=y.device, dtype=torch.float32)
+        if mod.training:                                           # batch statistics + running-statistics update in one tiny kernel
+            m = mod.momentum if mod.momentum is not None else 0.1
+            with torch.no_grad():
+                call("craft_bn_finalize", stats, B, C, float(count), float(mod.eps), float(m), mr, mod.running_mean, mod.running_var)
                 mod.num_batches_tracked.add_(1)
-            return NormAct.apply(y, mr, mod.weight, mod.bias, act, res, int(n))
-        mr = torch.stack([mod.running_mean.double(), torch.rsqrt(mod.running_var.double() + mod.eps)], dim=1).float().contiguous()
+            return NormAct.apply(y, mr, mod.weight, mod.bias, act, res, B * count)
+        call("craft_bn_finalize", None, B, C, float(count), float(mod.eps), 0.0, mr, mod.running_mean, mod.running_var)
         return NormAct.apply(y, mr, mod.weight, mod.bias, act, res, 0)
     raise NotImplementedError(f"training encoder: norm layer {type(mod).__name__} (extractor.py norm_fn 'group' / 'none') is not built")
 
@@ -206,17 +199,20 @@ def encoder_forward_train(enc: BasicEncoder, raw: torch.Tensor, prec) -> torch.T
     cp = pick(prec, "enc")
     cache = {}
     hw = (H // 2, W // 2)
-    y, st = Stem.apply(raw, enc.conv1.weight, enc.conv1.bias, cp)
+    def dead(norm):      # does this norm layer recompute its statistics from its input (then the conv bias in front of it is inert)?
+        return isinstance(norm, nn.InstanceNorm2d) or (isinstance(norm, nn.BatchNorm2d) and norm.training)
+
+    y, st = Stem.apply(raw, enc.conv1.weight, enc.conv1.bias, cp, dead(enc.norm1))
     x = _norm(y, st, hw[0] * hw[1], enc.norm1, ACT_RELU)
     for blk in (enc.layer1[0], enc.layer1[1], enc.layer2[0], enc.layer2[1], enc.layer3[0], enc.layer3[1]):
         s = blk.conv1.stride[0]
         hw2 = (hw[0] // s, hw[1] // s)
         n2 = hw2[0] * hw2[1]
-        y, st = EncConv.apply(x, blk.conv1.weight, blk.conv1.bias, hw, s, cp, cache)
+        y, st = EncConv.apply(x, blk.conv1.weight, blk.conv1.bias, hw, s, cp, cache, dead(blk.norm1))
         y = _norm(y, st, n2, blk.norm1, ACT_RELU)
-        y2, st2 = EncConv.apply(y, blk.conv2.weight, blk.conv2.bias, hw2, 1, cp, cache)
+        y2, st2 = EncConv.apply(y, blk.conv2.weight, blk.conv2.bias, hw2, 1, cp, cache, dead(blk.norm2))
         if blk.downsample is not None:
-            d, std = EncConv.apply(x, blk.downsample[0].weight, blk.downsample[0].bias, hw, s, cp, cache)
+            d, std = EncConv.apply(x, blk.downsample[0].weight, blk.downsample[0].bias, hw, s, cp, cache, dead(blk.norm3))
             xr = _norm(d, std, n2, blk.norm3, ACT_NONE)
         else:
             xr = x

@@ -405,6 +405,16 @@ int craft_norm_act_bwd_reduce(const float* dy, long ldg, const float* out, long 
 int craft_norm_act_bwd_apply(const float* dy, long ldg, const float* out, long ldo, const float* x, long ldx, const float* mean_rstd,
                              int mr_per_image, const float* gamma, const float* beta, int act, int has_res, const float* red,
                              int red_per_image, float* dx, long lddx, float* dres, long lddr, int B, int N, int C, void* stream);
+/* craft_bn_finalize: nn.BatchNorm2d statistics for craft_norm_act_fwd.  stats != NULL (training): the producing conv's
+ *   [CRAFT_STATS_REPLICAS][B][C][2] sums over `count` pixels per image -> batch mean / biased variance -> mean_rstd [C][2]; running_mean
+ *   / running_var (may be NULL) get the momentum update with the unbiased variance.  stats == NULL: mean_rstd from the running
+ *   statistics (eval mode, CRAFT.freeze_bn()).
+ * craft_norm_bwd_finalize: sums [B][C][2] of craft_norm_act_bwd_reduce -> red (population means for craft_norm_act_bwd_apply: [B][C][2]
+ *   when per_image, else [C][2]; untouched when population == 0) and dgamma / dbeta [C] (sums over the batch; may be NULL). */
+int craft_bn_finalize(const double* stats, int B, int C, double count, float eps, float momentum, float* mean_rstd, float* running_mean,
+                      float* running_var, void* stream);
+int craft_norm_bwd_finalize(const double* sums, int B, int C, double population, int per_image, float* red, float* dgamma, float* dbeta,
+                            void* stream);
 int craft_stem_im2col(const float* image, int B, int H, int W, float* cols, void* stream);
 int craft_zero_stuff2(const float* g, long ldg, int B, int Hin, int Win, int C, float* gf, long ldf, void* stream);
 
