@@ -132,13 +132,48 @@ class Act(Function):
 # ------------------------------------------------------------------------------------------------------------------
 # nn.Linear on tokens
 # ------------------------------------------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------------------------------------
+# Weight gradients of layers that run many times per pass (the update block: 12 iterations).  Autograd would get one freshly
+# zero-filled gradient tensor per call and add them up with one elementwise kernel each (~500 tiny kernels per step); instead the
+# calls of one pass share ONE accumulation buffer per weight (the weight-gradient kernels add into their output anyway), the
+# uses are counted in the forward, and only the last backward call hands the buffer to autograd (the others return None).
+# ``cache`` is the per-pass dict the conv operands already live in.
+# ------------------------------------------------------------------------------------------------------------------
+def _count_use(cache, t):
+    if cache is not None and t is not None:
+        k = (id(t), "uses")
+        cache[k] = cache.get(k, 0) + 1
+
+
+def _acc_buffer(cache, t, kind, shape, device):
+    """(buffer, is_last_use): the pass-wide accumulation buffer for the gradient of tensor t."""
+    if cache is None:
+        return torch.zeros(shape, device=device, dtype=torch.float32), True
+    k = (id(t), kind)
+    buf = cache.get(k)
+    if buf is None:
+        buf = cache[k] = torch.zeros(shape, device=device, dtype=torch.float32)
+    return buf, None
+
+
+def _release_use(cache, t) -> bool:
+    """Count one backward call of t; True when it was the last one of this pass (the accumulated gradient is complete)."""
+    if cache is None:
+        return True
+    k = (id(t), "uses")
+    cache[k] -= 1
+    return cache[k] == 0
+
+
 class Linear(Function):
     @staticmethod
-    def forward(ctx, x, w, b, prec):
+    def forward(ctx, x, w, b, prec, cache=None):
         x = _rows(x)
         w = _c(w)
         ctx.save_for_backward(x, w)
         ctx.has_bias, ctx.prec = b is not None, prec
+        ctx.cache, ctx.wobj = cache, w          # (the Python object: saved_tensors may hand back a different wrapper, and ids key the cache)
+        _count_use(cache, w)
         return ops.linear(x, w, b, prec)
 
     @staticmethod
@@ -149,19 +184,23 @@ class Linear(Function):
         Cout = w.shape[0]
         rows = B * N
         pp = pick(ctx.prec, "proj")
+        cache, wobj = ctx.cache, ctx.wobj
+        last = _release_use(cache, wobj)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(B, N, Cin, device=x.device, dtype=torch.float32)
             # dX = dY . W : A = dY rows (k = cout contiguous), B(n = ci, k = co) = W[co][ci] k-major
             gemm(dy, dy.stride(-2), 1, 0, 0, w, 1, Cin, 0, 0, dx, Cin, 0, 0, 1, 1, rows, Cin, Cout, prec=pp)
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros(Cout, Cin, device=x.device, dtype=torch.float32)
+            acc, _ = _acc_buffer(cache, wobj, "dw", (Cout, Cin), x.device)
             # dW = dY^T . X : both operands k-major over the rows, split-K
-            gemm(dy, 1, dy.stride(-2), 0, 0, x, 1, x.stride(-2), 0, 0, dw, Cin, 0, 0, 1, 1, Cout, Cin, rows, accumulate=True, ksplit=0, prec=pp)
+            gemm(dy, 1, dy.stride(-2), 0, 0, x, 1, x.stride(-2), 0, 0, acc, Cin, 0, 0, 1, 1, Cout, Cin, rows, accumulate=True, ksplit=0, prec=pp)
+            dw = acc if last else None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.zeros(Cout, device=x.device, dtype=torch.float32)
-            call("craft_colsum", dy, dy.stride(-2), rows, Cout, db)
-        return dx, dw, db, None
+            acc, _ = _acc_buffer(cache, wobj, "db", (Cout,), x.device)
+            call("craft_colsum", dy, dy.stride(-2), rows, Cout, acc)
+            db = acc if last else None
+        return dx, dw, db, None, None
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -503,7 +542,7 @@ def _conv_wgrad(xp, g, B, H8, W8, cin_p, cout_p, KH, KW, prec) -> torch.Tensor:
 class Conv(Function):
     """nn.Conv2d (stride 1, padding K//2) + bias (+ReLU) on tokens; w in PyTorch layout [Cout, Cin, KH, KW].
     Backward: input gradient = the same forward kernel with flipped / transposed weights, weight gradient =
-    craft_conv2d_wgrad, bias gradient = column sums."""
+    craft_conv2d_wgrad, bias gradient = column sums (both accumulated over the calls of one pass, see _acc_buffer)."""
 
     @staticmethod
     def forward(ctx, x, w, b, hw, act, prec, cache=None):
@@ -519,6 +558,7 @@ class Conv(Function):
         ctx.w, ctx.cache = w, cache
         ctx.dims = (B, N, Cin, Cout, KH, KW, cin_p, cout_p)
         ctx.hw, ctx.act, ctx.prec, ctx.has_bias = hw, act, cp, b is not None
+        _count_use(cache, w)
         return y[..., :Cout] if cout_p != Cout else y
 
     @staticmethod
@@ -527,6 +567,8 @@ class Conv(Function):
         B, N, Cin, Cout, KH, KW, cin_p, cout_p = ctx.dims
         H8, W8 = ctx.hw
         dev = xp.device
+        cache = ctx.cache
+        last = _release_use(cache, ctx.w)
         g = _pad_cols(dy, cout_p)
         if ctx.act != ACT_NONE:
             ga = torch.empty(B, N, cout_p, device=dev, dtype=torch.float32)
@@ -534,17 +576,20 @@ class Conv(Function):
             g = ga
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt, zb, flag, _ = _conv_weights(ctx.w, None, ctx.prec, ctx.cache, True)
+            wt, zb, flag, _ = _conv_weights(ctx.w, None, ctx.prec, cache, True)
             dxp = torch.empty(B, N, cin_p, device=dev, dtype=torch.float32)
             call("craft_conv2d_nhwc", g, g.stride(-2), cout_p, wt, zb, cin_p, KH, KW, ACT_NONE, dxp, cin_p, B, H8, W8, ctx.prec | flag)
             dx = dxp[..., :Cin] if cin_p != Cin else dxp
         if ctx.needs_input_grad[1]:
-            dwp = _conv_wgrad(xp, g, B, H8, W8, cin_p, cout_p, KH, KW, ctx.prec)
-            dw = dwp[:Cout, :, :, :Cin].permute(0, 3, 1, 2)
+            acc, _ = _acc_buffer(cache, ctx.w, "dw", (cout_p, KH, KW, cin_p), dev)
+            call("craft_conv2d_wgrad", xp, xp.stride(-2), cin_p, g, g.stride(-2), cout_p, KH, KW, B, H8, W8, acc, None, 0, ctx.prec)
+            if last:
+                dw = acc[:Cout, :, :, :Cin].permute(0, 3, 1, 2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            dbp = torch.zeros(cout_p, device=dev, dtype=torch.float32)
-            call("craft_colsum", g, g.stride(-2), B * N, cout_p, dbp)
-            db = dbp[:Cout]
+            acc, _ = _acc_buffer(cache, ctx.w, "db", (cout_p,), dev)
+            call("craft_colsum", g, g.stride(-2), B * N, cout_p, acc)
+            if last:
+                db = acc[:Cout]
         return dx, dw, db, None, None, None, None
 
 

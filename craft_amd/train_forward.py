@@ -141,14 +141,14 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
         corr = AG.CorrLookup.apply(token, coords1, holder, cf.radius)           # :235
         flow = coords1 - coords0
         # BasicMotionEncoder (update.py:79-87)
-        cor = AG.Act.apply(AG.Linear.apply(corr, wc1, enc.convc1.bias, prec.conv), ACT_RELU, 1.0)
+        cor = AG.Act.apply(AG.Linear.apply(corr, wc1, enc.convc1.bias, prec.conv, wcache), ACT_RELU, 1.0)
         cor = _conv(cor, enc.convc2, hw, ACT_RELU, prec, wcache)
         flo = _conv(flow, enc.convf1, hw, ACT_RELU, prec, wcache)
         flo = _conv(flo, enc.convf2, hw, ACT_RELU, prec, wcache)
         out = _conv(torch.cat([cor, flo], dim=-1), enc.conv, hw, ACT_RELU, prec, wcache)
         mf = torch.cat([out, flow], dim=-1)                                     # [B, N, 128]
         # motion aggregator (update.py:143-149): ExpandedFeatTrans on the raw motion features
-        va = AG.Linear.apply(mf, agg.first_linear.weight, None, prec)
+        va = AG.Linear.apply(mf, agg.first_linear.weight, None, prec, wcache)
         Oa = AG.AttnApplyShared.apply(ptoken, va, pholder, prec)
         mfg = AG.ModePoolLN.apply(Oa, mf, agg.feat_softaggr.feat2score.weight, agg.input_skip_coeff)
         # SepConvGRU (update.py:49-64)
@@ -163,7 +163,7 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
         # heads (update.py:15-16, :124-127, :161)
         delta = _conv(_conv(net, fh.conv1, hw, ACT_RELU, prec, wcache), fh.conv2, hw, ACT_NONE, prec, wcache)
         mh = _conv(net, ub.mask[0], hw, ACT_RELU, prec, wcache)
-        mask = AG.Act.apply(AG.Linear.apply(mh, wm2, ub.mask[2].bias, prec.conv), ACT_NONE, 0.25)
+        mask = AG.Act.apply(AG.Linear.apply(mh, wm2, ub.mask[2].bias, prec.conv, wcache), ACT_NONE, 0.25)
         coords1 = coords1 + delta                                               # network.py:247
         preds.append(AG.ConvexUpsample.apply(mask, coords1 - coords0, hw))      # :258
     return preds
