@@ -16,6 +16,7 @@ const Tuning& tuning() {
     if (const char* e = getenv("CRAFT_HALO_BN")) v.halo_bn = atoi(e);
     v.no_c64 = getenv("CRAFT_NO_C64") != nullptr;
     v.wf_dynamic_taps = getenv("CRAFT_WF_DYNAMIC_TAPS") != nullptr;
+    v.wgrad_sb = getenv("CRAFT_NO_WGRAD_SB") == nullptr;     // weight gradient with one LDS tile buffer (3 resident blocks per CU instead of 2; off: developer A/B)
     v.no_wgrad64 = getenv("CRAFT_NO_WGRAD64") != nullptr;   // weight gradient of 64-channel layers on the generic 128-row tile (developer A/B)
     return v;
   }();

@@ -394,4 +394,38 @@ __device__ __forceinline__ void gemm_mainloop(const LA& la, const LB& lb, int nk
   }
 }
 
+// The same K loop with ONE LDS tile buffer (half the LDS: twice the resident blocks where LDS is the occupancy limit).  The next
+// tile still travels global -> registers during the MFMAs; it is converted and stored after a barrier (nobody reads the buffer any
+// more) and published by a second one.  The store phase is not hidden behind this block's own MFMAs -- the extra resident waves
+// are what covers it.
+template <int PREC, int BM, int BN, int WM, int WN, class LA, class LB>
+__device__ __forceinline__ void gemm_mainloop_sb(const LA& la, const LB& lb, int nk, f32x16 (&acc)[BM / WM / 32][BN / WN / 32]) {
+  typedef typename PrecT<PREC>::lds_t lds_t;
+  typedef TileLds<PREC, BM, BN> L;
+  constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
+  __shared__ __attribute__((aligned(16))) lds_t S[L::A_ELEMS + L::B_ELEMS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+  typename LA::Regs ra;
+  typename LB::Regs rb;
+  la.fetch(0, ra);
+  lb.fetch(0, rb);
+  stage_store<PREC>(&S[0], ra, tid);
+  stage_store<PREC>(&S[L::A_ELEMS], rb, tid);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ktn = min(kt + 1, nk - 1);
+    la.fetch(ktn, ra);
+    lb.fetch(ktn, rb);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tile<PREC, MT, NT, BM, BN>(&S[0], &S[L::A_ELEMS], wm0, wn0, lane, acc);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      stage_store<PREC>(&S[0], ra, tid);
+      stage_store<PREC>(&S[L::A_ELEMS], rb, tid);
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace craft

@@ -308,7 +308,7 @@ struct WgradParams {
   unsigned magic_w;
 };
 
-template <int PREC, int BN>
+template <int PREC, int BN, bool SB>
 __global__ __launch_bounds__(NTHREADS) void k_conv_wgrad(WgradParams p) {
   constexpr int BM = 128, WM = 2, WN = 2, MT = BM / WM / 32, NT = BN / WN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -333,7 +333,8 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_wgrad(WgradParams p) {
   la.init(p.dY, p.ldy, m0, p.cout, k0, k1, tid);
   LoaderShiftColsF32<BN> lb;
   lb.init(p.X, p.ldx, n0, p.cin, k0, k1, npix, p.H, p.W, ky - p.KH / 2, kx - p.KW / 2, p.magic_hw, p.magic_w, tid);
-  gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, (k1 - k0 + BK - 1) / BK, acc, NoFold());
+  if constexpr (SB) gemm_mainloop_sb<PREC, BM, BN, WM, WN>(la, lb, (k1 - k0 + BK - 1) / BK, acc);
+  else gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, (k1 - k0 + BK - 1) / BK, acc, NoFold());
   const int rb = m0 + (wave / WN) * (BM / WM), cb = n0 + (wave % WN) * (BN / WN);
   const long taps = (long)p.KH * p.KW;
   if (p.ws) {
@@ -415,11 +416,13 @@ int launch_conv_wgrad(const float* x, long ldx, int cin, const float* dy, long l
   const int nz = (int)((npix + p.kchunk - 1) / p.kchunk);          // splits that actually own pixels (the others would leave holes)
   p.ksplit = nz;
   const bool pair64 = cout <= 64 && cin == 64 && !tuning().no_wgrad64;
+  const bool sb = tuning().wgrad_sb;
   const int ntile = pair64 ? (KH * KW + 1) / 2 : p.ntile_m * p.ntile_n * KH * KW;
   dim3 grid((unsigned)(8 * ntile * ((p.ksplit + 7) / 8)), 1, 1);
 #define GO(PR) do { if (pair64) hipLaunchKernelGGL((k_conv_wgrad64<PR>), grid, dim3(NTHREADS), 0, s, p); \
-                    else if (bn == 128) hipLaunchKernelGGL((k_conv_wgrad<PR, 128>), grid, dim3(NTHREADS), 0, s, p); \
-                    else hipLaunchKernelGGL((k_conv_wgrad<PR, 64>), grid, dim3(NTHREADS), 0, s, p); \
+                    else if (bn == 128 && sb) hipLaunchKernelGGL((k_conv_wgrad<PR, 128, true>), grid, dim3(NTHREADS), 0, s, p); \
+                    else if (bn == 128) hipLaunchKernelGGL((k_conv_wgrad<PR, 128, false>), grid, dim3(NTHREADS), 0, s, p); \
+                    else hipLaunchKernelGGL((k_conv_wgrad<PR, 64, false>), grid, dim3(NTHREADS), 0, s, p); \
                     if (hipGetLastError() != hipSuccess) return (int)hipGetLastError(); \
                     return p.ws ? launch_reduce_replicas(p.ws, p.ksplit, (int)nw, dW, s) : 0; } while (0)
   if (prec == CRAFT_PREC_F32) GO(CRAFT_PREC_F32);
