@@ -247,13 +247,13 @@ class AttnSoftmax(Function):
     @staticmethod
     def forward(ctx, S, pos_tab, pos_w, mask_radius, clamp_ord, hw):
         B, M, N, ld = S.shape
-        R = (pos_tab.shape[0] - 1) // 2
+        R = (pos_tab.shape[0] - 1) // 2 if pos_tab is not None else 0          # None: plain softmax (gma.Attention, gma.py:96-98)
         bits = torch.empty(B * M * N * (ld // 32), device=S.device, dtype=torch.int32)
-        tab = _c(pos_tab.detach())
+        tab = _c(pos_tab.detach()) if pos_tab is not None else None
         call("craft_attn_softmax_fwd", S, ld, B, M, hw[0], hw[1], tab, R, float(pos_w), int(mask_radius), clamp_ord, bits)
         ctx.mark_dirty(S)
         ctx.save_for_backward(S, bits, clamp_ord)
-        ctx.hw, ctx.R, ctx.pos_w = hw, R, pos_w
+        ctx.hw, ctx.R, ctx.pos_w, ctx.has_tab = hw, R, pos_w, pos_tab is not None
         return S
 
     @staticmethod
@@ -262,10 +262,12 @@ class AttnSoftmax(Function):
         B, M, N, ld = P.shape
         dS = dP.contiguous().clone()
         T = 2 * ctx.R + 1
-        rep = torch.zeros(STATS_REPLICAS, T * T, device=P.device, dtype=torch.float32)
+        rep = torch.zeros(STATS_REPLICAS, T * T, device=P.device, dtype=torch.float32) if ctx.has_tab else None
         call("craft_attn_softmax_bwd", P, dS, ld, B, M, ctx.hw[0], ctx.hw[1], ctx.R, float(ctx.pos_w), clamp_ord, bits, rep)
-        dtab = torch.zeros(T, T, device=P.device, dtype=torch.float32)
-        call("craft_reduce_replicas", rep, STATS_REPLICAS, T * T, dtab)
+        dtab = None
+        if ctx.has_tab:
+            dtab = torch.zeros(T, T, device=P.device, dtype=torch.float32)
+            call("craft_reduce_replicas", rep, STATS_REPLICAS, T * T, dtab)
         return dS, dtab, None, None, None, None
 
 
@@ -376,6 +378,31 @@ class AttnApplyShared(Function):
         return torch.zeros(1, device=P.device, dtype=torch.float32), dv, None, None
 
 
+class GmaResidual(Function):
+    """gma.Aggregate.forward's tail (gma.py:138): out = mf + gamma * O."""
+
+    @staticmethod
+    def forward(ctx, mf, O, gamma):
+        mf, O = _rows(mf), _c(O)
+        ctx.save_for_backward(O, gamma)
+        return ops.gma_residual(mf, O, gamma)
+
+    @staticmethod
+    def backward(ctx, dy):
+        O, gamma = ctx.saved_tensors
+        dy = _c(dy)
+        B, N, C = dy.shape
+        dO = dg = None
+        if ctx.needs_input_grad[1]:                      # gamma * dy = dy + (gamma - 1) * dy: the forward kernel, no host read of gamma
+            dO = ops.gma_residual(dy, dy, (gamma.detach() - 1.0).contiguous())
+        if ctx.needs_input_grad[2]:                      # <dy, O>: a 1 x 1 product over K = all elements, split-K
+            K = B * N * C
+            acc = torch.zeros(1, 1, device=dy.device, dtype=torch.float32)
+            gemm(dy, K, 1, 0, 0, O, K, 1, 0, 0, acc, 1, 0, 0, 1, 1, 1, 1, K, accumulate=True, ksplit=0, prec=hip.PREC_F16X3)
+            dg = acc.view(gamma.shape)
+        return dy, dO, dg
+
+
 class ModePoolLN(Function):
     """y = LayerNorm(skip * x + sum_m softmax_m(<O_m, w>) O_m)  (setrans.py:395-407)."""
 
@@ -425,15 +452,15 @@ class CorrVolume(Function):
     def forward(ctx, S, pos_tab, w_aggr, pos_w, clamp_ord, hw, holder_box, do_norm):
         B, M, N, ld = S.shape
         H8, W8 = hw
-        R = (pos_tab.shape[0] - 1) // 2
+        R = (pos_tab.shape[0] - 1) // 2 if pos_tab is not None else 0          # None: no positional bias (CorrBlock.corr, corr.py:73-81)
         pyr = ops.CorrPyramid(B, H8, W8, 4, S.device)
-        tab = _c(pos_tab.detach())
+        tab = _c(pos_tab.detach()) if pos_tab is not None else None
         wv = _c(w_aggr.detach()).view(-1)
         call("craft_corr_pool_fwd", S, ld, B, M, H8, W8, tab, R, float(pos_w), wv, clamp_ord, pyr.lv[0], pyr.sums)
         call("craft_corr_finish", pyr.lv[0], pyr.lv[1], pyr.lv[2], pyr.lv[3], pyr.sums, pyr.mu_rstd, B, H8, W8, int(do_norm))
         holder = TrainPyramid(pyr)
         holder_box.append(holder)
-        ctx.holder, ctx.hw, ctx.R, ctx.pos_w, ctx.do_norm = holder, hw, R, pos_w, do_norm
+        ctx.holder, ctx.hw, ctx.R, ctx.pos_w, ctx.do_norm, ctx.has_tab = holder, hw, R, pos_w, do_norm, pos_tab is not None
         ctx.save_for_backward(S, tab, wv, clamp_ord)
         ctx.w_shape = w_aggr.shape
         return pyr.mu_rstd
@@ -448,15 +475,17 @@ class CorrVolume(Function):
         gstats = torch.zeros(B, 2, device=S.device, dtype=torch.float64)
         call("craft_corr_pyramid_bwd", G[0], G[1], G[2], G[3], pyr.lv[0], pyr.mu_rstd, B, H8, W8, gstats)
         T = 2 * ctx.R + 1
-        rep = torch.zeros(STATS_REPLICAS, T * T, device=S.device, dtype=torch.float32)
+        rep = torch.zeros(STATS_REPLICAS, T * T, device=S.device, dtype=torch.float32) if ctx.has_tab else None
         dw = torch.zeros(1, device=S.device, dtype=torch.float64)
         dS = S                                                    # the scores are dead after this: overwritten with dS
         call("craft_corr_pool_bwd", dS, ld, B, M, H8, W8, tab, ctx.R, float(ctx.pos_w), wv, clamp_ord, pyr.lv[0], G[0], pyr.mu_rstd, gstats,
              int(ctx.do_norm), rep, dw)
-        dtab = torch.zeros(T, T, device=S.device, dtype=torch.float32)
-        call("craft_reduce_replicas", rep, STATS_REPLICAS, T * T, dtab)
+        dtab = None
+        if ctx.has_tab:
+            dtab = torch.zeros(T, T, device=S.device, dtype=torch.float32)
+            call("craft_reduce_replicas", rep, STATS_REPLICAS, T * T, dtab)
         ctx.holder.G = None
-        return dS, dtab, dw.float().reshape(ctx.w_shape), None, None, None, None, None
+        return dS, dtab, (dw.float().reshape(ctx.w_shape) if ctx.needs_input_grad[2] else None), None, None, None, None, None
 
 
 class CorrLookup(Function):

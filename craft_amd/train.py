@@ -224,6 +224,12 @@ def unused_parameters(model: torch.nn.Module) -> List[torch.nn.Parameter]:
     st = getattr(att, "setrans", None)
     if st is not None and getattr(st, "out_attn_probs_only", False) and hasattr(st, "attn_softaggr"):
         out += list(st.attn_softaggr.parameters())
+    # gma.Attention: the relative-position embeddings only enter the scores with --position_only / --position_and_content
+    # (gma.py:84-98); content-only attention (the default) leaves them without a gradient
+    args = getattr(model, "args", None)
+    pos = getattr(att, "pos_emb", None)
+    if pos is not None and not (getattr(args, "position_only", False) or getattr(args, "position_and_content", False)):
+        out += list(pos.parameters())
     return out
 
 

@@ -8,7 +8,8 @@ Training-mode semantics of the reference that are reproduced: BatchNorm batch st
 (setrans.py:553-557; not on the inter-frame scores, :544-550), ``coords1.detach()`` at the top of every iteration
 (network.py:232), all T upsampled predictions returned (test_mode=0).  The two CNN encoders run on the HIP kernels too
 (craft_amd/train_encoder.py); ``args.hip_encoders=False`` keeps them as PyTorch-ROCm modules under torch autograd (BASELINE.json
-north_star: "Host code stays Python on PyTorch-ROCm for the CNN feature/context extractors").  Only the released configuration trains here (``--craft --f2 full --setrans``, no ``--f1``).
+north_star: "Host code stays Python on PyTorch-ROCm for the CNN feature/context extractors").  Trains what the reference's shipped scripts train: ``--craft --f2 full`` with either attention (``--setrans`` or GMA's)
+and the plain-correlation GMA model; ``--f1`` and GMA's relative-position scores run in inference only.
 """
 from __future__ import annotations
 
@@ -41,8 +42,14 @@ def _conv(x, conv, hw, act, prec, cache):
 
 def forward_train(model, image1, image2, iters=12, flow_init=None):
     args = model.args
-    if not (args.craft and args.use_setrans and args.f2trans != "none" and model.f1_trans is None):
-        raise NotImplementedError("training is implemented for the released configuration (--craft --f2 full --setrans, no --f1)")
+    # the reference's four shipped training scripts: --craft --f2 full --setrans (train-craft-f2full.sh), --craft --f2 full with GMA's
+    # attention / aggregator (train-craft-f2full-gma.sh), plain correlation + GMA (train-gma.sh), and any mix of those three switches
+    if getattr(model, "f1_trans", None) is not None:
+        raise NotImplementedError("training with --f1 (two-way correlation) is not built; it runs in inference")
+    if args.f2trans == "none":
+        raise NotImplementedError("--f2 none: the reference's own constructor fails without the F2 transformer (network.py:93-106)")
+    if not args.use_setrans and (getattr(args, "position_only", False) or getattr(args, "position_and_content", False)):
+        raise NotImplementedError("training GMA's relative-position scores (RelPosEmb) is not built; they run in inference")
     prec = model.hip_prec()
     B, _, H, W = image1.shape
     if H % 8 or W % 8:
@@ -100,27 +107,41 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
     fmap2_t = AG.ModePoolLN.apply(O2, x2, ot.feat_softaggr.feat2score.weight, ot.input_skip_coeff)
 
     # ---- inter-frame correlation volume + pyramid (network.py:225-228; corr.py:148-207) -------------------------------
-    cf = model.corr_fn
-    cc = cf.config
-    x1 = AG.dropout(AG.TokensNorm.apply(f1_tok, ACT_NONE, True), p_hidden(cc), base_seed + 3)
-    x2t = AG.dropout(AG.TokensNorm.apply(fmap2_t, ACT_NONE, True), p_hidden(cc), base_seed + 4)
-    st = cf.setrans
-    q = AG.Linear.apply(x1, st.query.weight, st.query.bias, prec)
-    k = AG.Linear.apply(x2t, st.key.weight, st.key.bias, prec)
-    scale = 1.0 / math.sqrt(st.attention_mode_dim)
-    mx = ops.score_max(q.detach(), k.detach(), H8, W8, st.num_modes, scale, prec)
-    Sc = AG.Scores.apply(q, k, st.num_modes, scale, prec)
     box = []
-    w_aggr = st.attn_softaggr.feat2score.weight if st.num_modes > 1 else torch.ones(1, 1, device=dev)
-    token = AG.CorrVolume.apply(Sc, cf.vispos_encoder.pos_coder.biases, w_aggr, float(st.pos_code_weight), mx, hw, box,
-                                bool(cf.do_corr_global_norm))
+    if args.craft:
+        cf = model.corr_fn
+        cc = cf.config
+        x1 = AG.dropout(AG.TokensNorm.apply(f1_tok, ACT_NONE, True), p_hidden(cc), base_seed + 3)
+        x2t = AG.dropout(AG.TokensNorm.apply(fmap2_t, ACT_NONE, True), p_hidden(cc), base_seed + 4)
+        st = cf.setrans
+        q = AG.Linear.apply(x1, st.query.weight, st.query.bias, prec)
+        k = AG.Linear.apply(x2t, st.key.weight, st.key.bias, prec)
+        scale = 1.0 / math.sqrt(st.attention_mode_dim)
+        mx = ops.score_max(q.detach(), k.detach(), H8, W8, st.num_modes, scale, prec)
+        Sc = AG.Scores.apply(q, k, st.num_modes, scale, prec)
+        w_aggr = st.attn_softaggr.feat2score.weight if st.num_modes > 1 else torch.ones(1, 1, device=dev)
+        token = AG.CorrVolume.apply(Sc, cf.vispos_encoder.pos_coder.biases, w_aggr, float(st.pos_code_weight), mx, hw, box,
+                                    bool(cf.do_corr_global_norm))
+        radius = cf.radius
+    else:
+        # CorrBlock (corr.py:17-45, :73-81): <fmap1, fmap2> / sqrt(256), no positional bias, no global LayerNorm, avg-pool pyramid
+        Sc = AG.Scores.apply(f1_tok, fmap2_t, 1, 1.0 / math.sqrt(256.0), prec)
+        token = AG.CorrVolume.apply(Sc, None, torch.ones(1, 1, device=dev), 0.0, None, hw, box, False)
+        radius = int(args.corr_radius)
     holder = box[0]
 
     # ---- intra-frame attention (network.py:214): computed once, used by every iteration ------------------------------
     att = model.att
-    ca = att.config
-    xc = AG.dropout(AG.TokensNorm.apply(inp, ACT_NONE, True), p_hidden(ca), base_seed + 5)
-    Patt = _attention_probs(att, xc, hw, prec, p_attn(ca), base_seed + 6)
+    if args.use_setrans:
+        ca = att.config
+        xc = AG.dropout(AG.TokensNorm.apply(inp, ACT_NONE, True), p_hidden(ca), base_seed + 5)
+        Patt = _attention_probs(att, xc, hw, prec, p_attn(ca), base_seed + 6)
+    else:
+        # gma.Attention (gma.py:53-102): softmax(scale * q k^T) of the 1x1-conv projections of the context features, no dropout
+        inner = att.heads * att.dim_head
+        qk = AG.Linear.apply(inp, att.to_qk.weight.view(2 * inner, -1), None, prec)
+        Sg = AG.Scores.apply(qk[..., :inner], qk[..., inner:], att.heads, float(att.scale), prec)
+        Patt = AG.AttnSoftmax.apply(Sg, None, 0.0, -1, None, hw)
     pbox = []
     ptoken = AG.ProbsToken.apply(Patt, pbox, prec)        # the 12 uses of Patt share ONE gradient product
     pholder = pbox[0]
@@ -138,7 +159,7 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
     wm2 = ub.mask[2].weight.view(576, -1)
     for _ in range(iters):
         coords1 = coords1.detach()                                              # network.py:232
-        corr = AG.CorrLookup.apply(token, coords1, holder, cf.radius)           # :235
+        corr = AG.CorrLookup.apply(token, coords1, holder, radius)              # :235
         flow = coords1 - coords0
         # BasicMotionEncoder (update.py:79-87)
         cor = AG.Act.apply(AG.Linear.apply(corr, wc1, enc.convc1.bias, prec.conv, wcache), ACT_RELU, 1.0)
@@ -148,9 +169,14 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
         out = _conv(torch.cat([cor, flo], dim=-1), enc.conv, hw, ACT_RELU, prec, wcache)
         mf = torch.cat([out, flow], dim=-1)                                     # [B, N, 128]
         # motion aggregator (update.py:143-149): ExpandedFeatTrans on the raw motion features
-        va = AG.Linear.apply(mf, agg.first_linear.weight, None, prec, wcache)
-        Oa = AG.AttnApplyShared.apply(ptoken, va, pholder, prec)
-        mfg = AG.ModePoolLN.apply(Oa, mf, agg.feat_softaggr.feat2score.weight, agg.input_skip_coeff)
+        if args.use_setrans:
+            va = AG.Linear.apply(mf, agg.first_linear.weight, None, prec, wcache)
+            Oa = AG.AttnApplyShared.apply(ptoken, va, pholder, prec)
+            mfg = AG.ModePoolLN.apply(Oa, mf, agg.feat_softaggr.feat2score.weight, agg.input_skip_coeff)
+        else:                                                                   # gma.Aggregate (gma.py:128-140), one head
+            va = AG.Linear.apply(mf, agg.to_v.weight.view(agg.heads * agg.dim_head, -1), None, prec, wcache)
+            Oa = AG.AttnApplyShared.apply(ptoken, va, pholder, prec)            # [B, 1, N, 128]
+            mfg = AG.GmaResidual.apply(mf, Oa.reshape(B, N, -1), agg.gamma)
         # SepConvGRU (update.py:49-64)
         x = torch.cat([inp, mf, mfg], dim=-1)                                   # [B, N, 384]
         h = net

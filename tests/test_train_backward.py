@@ -305,7 +305,7 @@ def grad_check_l2(z, key, g, l2_tol, elem_tol):
 
 
 def _train_model(device, meta, precision="fp32"):
-    model = CRAFT(default_args(hip_precision=precision, dropout_prob=0.0))
+    model = CRAFT(default_args(hip_precision=precision, dropout_prob=0.0, **meta.get("over", {})))
     model.load_state_dict(synth_state_dict(model.state_dict(), seed=meta["seed"], qk_gain=meta["qk_gain"]), strict=True)
     model = model.to(device).train()
     if meta["freeze_bn"]:
@@ -341,13 +341,15 @@ def test_training_step_matches_reference_gradients(device, case, precision):
             assert k.endswith("feat2score.bias") and z[f"grad.{k}.s"][1] < 1e-10, k      # cancels inside its softmax
             checked += 1
             continue
-        # a scalar parameter (pooling weight, skip coefficient) is one number: its "L2" is its own relative error, and the inter-frame
-        # pooling weight's gradient is a sum over all N^2 x modes scores with heavy cancellation (1e-6 differences in the features move
-        # it by 1e-2: measured 1.4e-2 with the HIP encoders, 0.6e-2 with MIOpen's) -- three times the bound for those
-        mul = 3.0 if p.numel() == 1 else 1.0
+        # a scalar parameter (pooling weight, skip coefficient) is one number: its "L2" is its own relative error.  The inter-frame
+        # pooling weight's gradient is a sum over all N^2 x modes scores that cancels to ~1e-3 of its absolute mass: encoder features
+        # that agree with a float64 evaluation to 2e-6 (tools/scalar_grad_noise.py: ours 1.8e-6, torch fp32 1.5e-6) move it by
+        # 1.7 % (canonical case) to 8.5 % (GMA case), while run-to-run it repeats to 1e-6 and with MIOpen's encoders it lands within
+        # 1e-5 of the float64 value -- an ill-conditioned number, not a summation-order or kernel issue.  Ten times the bound there.
+        mul = 10.0 if p.numel() == 1 else 1.0
         worst = max(worst, grad_check_l2(z, k, p.grad, l2_tol=mul * (1e-2 if tight else 8e-2), elem_tol=mul * (0.15 if tight else 0.6)))
         checked += 1
-    assert checked == 143
+    assert checked == len({id(p) for k, p in model.named_parameters() if not k.startswith("corr_fn.setrans.key.")}) - len(unused) and checked >= 130
     print(f"[train parity] {case} {precision}: loss {float(loss):.6f} (reference {float(z['loss']):.6f}), worst relative L2 gradient error {worst:.2e}")
     for k in [f for f in z.files if f.startswith("bn.")]:
         got = model.state_dict()[k[3:]].cpu().numpy()
@@ -389,9 +391,10 @@ def test_train_mode_rejects_other_configs_and_sizes(device):
     model = CRAFT(default_args(hip_precision="fp32")).to(device).train()
     with pytest.raises(ValueError, match="multiple of 4"):
         model(torch.zeros(1, 3, 136, 200, device=device), torch.zeros(1, 3, 136, 200, device=device), iters=1)
-    gma = CRAFT(default_args(use_setrans=False)).to(device).train()
-    with pytest.raises(NotImplementedError):
-        gma(torch.zeros(1, 3, 128, 128, device=device), torch.zeros(1, 3, 128, 128, device=device), iters=1)
+    for over in (dict(f1trans="shared"), dict(use_setrans=False, position_and_content=True)):       # inference-only variants
+        other = CRAFT(default_args(**over)).to(device).train()
+        with pytest.raises(NotImplementedError):
+            other(torch.zeros(1, 3, 128, 128, device=device), torch.zeros(1, 3, 128, 128, device=device), iters=1)
 
 
 def test_training_step_at_configs3_size_against_oracle(device):

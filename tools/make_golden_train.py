@@ -29,6 +29,12 @@ from make_golden import ref_args, sample  # noqa: E402
 CASES = [
     dict(name="train_b2_128x192_T3", B=2, H=128, W=192, iters=3, seed=1234, qk_gain=2.5, freeze_bn=False, gamma=0.8),
     dict(name="train_freezebn_b2_128x160_T2", B=2, H=128, W=160, iters=2, seed=41, qk_gain=2.5, freeze_bn=True, gamma=0.85),
+    # the reference's other shipped training configurations: train-craft-f2full-gma.sh (--craft --f2 full, GMA attention),
+    # the plain-correlation variant of row A, and train-gma.sh (plain correlation + GMA attention; --f2 defaults to full there too)
+    dict(name="train_gma_b2_128x160_T2", over=dict(use_setrans=False), B=2, H=128, W=160, iters=2, seed=43, qk_gain=2.5, freeze_bn=False, gamma=0.8),
+    dict(name="train_nocraft_b2_128x160_T2", over=dict(craft=False), B=2, H=128, W=160, iters=2, seed=47, qk_gain=2.5, freeze_bn=True, gamma=0.8),
+    dict(name="train_plaingma_b2_128x160_T2", over=dict(craft=False, use_setrans=False), B=2, H=128, W=160, iters=2, seed=53,
+         qk_gain=2.5, freeze_bn=False, gamma=0.8),
 ]
 
 
@@ -47,7 +53,7 @@ def ref_sequence_loss():
 def run(c, seq_loss):
     from network import CRAFT  # the reference
     torch.manual_seed(0)
-    m = CRAFT(ref_args())
+    m = CRAFT(ref_args(**c.get("over", {})))
     sd = synth_state_dict(m.state_dict(), seed=c["seed"], qk_gain=c["qk_gain"])
     m.load_state_dict(sd, strict=True)
     m.train()
@@ -68,7 +74,8 @@ def run(c, seq_loss):
     loss, metrics = seq_loss(preds, gt, valid, c["gamma"])
     loss.backward()
     out = {"meta": json.dumps(dict(name=c["name"], B=B, H=H, W=W, iters=c["iters"], seed=c["seed"], qk_gain=c["qk_gain"],
-                                   freeze_bn=c["freeze_bn"], gamma=c["gamma"], dropouts_zeroed=n_drop, torch=torch.__version__)),
+                                   freeze_bn=c["freeze_bn"], gamma=c["gamma"], dropouts_zeroed=n_drop, over=c.get("over", {}),
+                                   torch=torch.__version__)),
            "image1": im1.numpy().astype(np.uint8), "image2": im2.numpy().astype(np.uint8), "flow_gt": gt.numpy(),
            "valid": valid.numpy(), "loss": np.float64(loss.item()),
            "metrics": np.array([metrics["epe"], metrics["1px"], metrics["3px"], metrics["5px"]])}
@@ -95,7 +102,8 @@ def run(c, seq_loss):
 
 def main():
     seq_loss = ref_sequence_loss()
-    for c in CASES:
+    only = sys.argv[1:]
+    for c in [c for c in CASES if not only or c["name"] in only]:
         out, unused = run(c, seq_loss)
         path = os.path.join(ROOT, "tests", "golden", c["name"] + ".npz")
         np.savez_compressed(path, **out)
