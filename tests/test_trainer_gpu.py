@@ -151,3 +151,22 @@ def test_two_rank_data_parallel_equals_one_process_on_both_pairs(device, tmp_pat
     # (AdamW's first steps move every weight by ~lr regardless of the gradient's size, so rounding-level gradient differences
     # between the two reduction orders can flip tiny updates: bound = a fraction of lr)
     assert worst < 2e-4, f"data-parallel and single-process parameters differ by {worst:.2e}"
+
+
+def test_trainer_gma_variant_skips_unused_position_embeddings(device):
+    """train-gma.sh's model (plain correlation + GMA attention): two steps run, the loss is finite, and the relative-position
+    embeddings that content-only attention never reads (no gradient in the reference: tests/golden/train_plaingma_*.npz 'unused')
+    are left untouched by the optimizer -- no weight decay on them either, like torch.optim.AdamW with grad None."""
+    from craft_amd import CRAFT, default_args
+    from craft_amd.synth import synth_state_dict
+    model = CRAFT(default_args(hip_precision="fp32", craft=False, use_setrans=False))
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=5), strict=True)
+    model = model.to(device)
+    tr = Trainer(model, lr=2e-4, wdecay=1e-2, num_steps=50, iters=2, clip=1.0)
+    before = {k: v.clone() for k, v in model.state_dict().items() if k.startswith("att.pos_emb.")}
+    assert len(before) >= 2                      # the two embedding tables (+ the rel_ind index buffer)
+    im1, im2, flow, valid = _batch(2, 128, 160, 7)
+    losses = [tr.step(im1, im2, flow, valid)["loss"] for _ in range(2)]
+    assert all(l == l and l < 1e4 for l in losses), losses
+    for k, v in before.items():
+        assert torch.equal(model.state_dict()[k], v), k
