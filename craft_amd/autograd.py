@@ -560,11 +560,11 @@ def _conv_weights(w, b, cp, cache, transposed: bool):
     return out
 
 
-def _conv_wgrad(xp, g, B, H8, W8, cin_p, cout_p, KH, KW, prec) -> torch.Tensor:
+def _conv_wgrad(xp, g, B, H8, W8, cin_p, cout_p, KH, KW, prec, db=None) -> torch.Tensor:
     """dW[co][ky][kx][ci] += sum_pix dY[pix][co] X[pix + tap][ci] (craft_conv2d_wgrad; split-K partial sums added with fp32 atomics:
     measured equal to the scratch + reduction form, one kernel less)."""
     dw = torch.zeros(cout_p, KH, KW, cin_p, device=xp.device, dtype=torch.float32)
-    call("craft_conv2d_wgrad", xp, xp.stride(-2), cin_p, g, g.stride(-2), cout_p, KH, KW, B, H8, W8, dw, None, 0, prec)
+    call("craft_conv2d_wgrad", xp, xp.stride(-2), cin_p, g, g.stride(-2), cout_p, KH, KW, B, H8, W8, dw, db, None, 0, prec)
     return dw
 
 
@@ -609,16 +609,18 @@ class Conv(Function):
             dxp = torch.empty(B, N, cin_p, device=dev, dtype=torch.float32)
             call("craft_conv2d_nhwc", g, g.stride(-2), cout_p, wt, zb, cin_p, KH, KW, ACT_NONE, dxp, cin_p, B, H8, W8, ctx.prec | flag)
             dx = dxp[..., :Cin] if cin_p != Cin else dxp
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        accb = _acc_buffer(cache, ctx.w, "db", (cout_p,), dev)[0] if want_db else None
         if ctx.needs_input_grad[1]:
             acc, _ = _acc_buffer(cache, ctx.w, "dw", (cout_p, KH, KW, cin_p), dev)
-            call("craft_conv2d_wgrad", xp, xp.stride(-2), cin_p, g, g.stride(-2), cout_p, KH, KW, B, H8, W8, acc, None, 0, ctx.prec)
+            # (the bias gradient rides on the same launch: the blocks of tap 0 add the column sums of dY)
+            call("craft_conv2d_wgrad", xp, xp.stride(-2), cin_p, g, g.stride(-2), cout_p, KH, KW, B, H8, W8, acc, accb, None, 0, ctx.prec)
             if last:
                 dw = acc[:Cout, :, :, :Cin].permute(0, 3, 1, 2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            acc, _ = _acc_buffer(cache, ctx.w, "db", (cout_p,), dev)
-            call("craft_colsum", g, g.stride(-2), B * N, cout_p, acc)
-            if last:
-                db = acc[:Cout]
+        elif want_db:
+            call("craft_colsum", g, g.stride(-2), B * N, cout_p, accb)
+        if want_db and last:
+            db = accb[:Cout]
         return dx, dw, db, None, None, None, None
 
 

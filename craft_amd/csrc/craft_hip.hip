@@ -417,8 +417,8 @@ int craft_gemm(const float* A, long a_sm, long a_sk, long a_bs0, long a_bs1, con
                          accumulate, ksplit, prec, S(stream));
 }
 int craft_conv2d_wgrad(const float* x, long ldx, int cin, const float* dy, long ldy, int cout, int KH, int KW, int B, int H, int W,
-                       float* dW, float* ws, long ws_floats, int prec, void* stream) {
-  return launch_conv_wgrad(x, ldx, cin, dy, ldy, cout, KH, KW, B, H, W, dW, ws, ws_floats, prec, S(stream));
+                       float* dW, float* db, float* ws, long ws_floats, int prec, void* stream) {
+  return launch_conv_wgrad(x, ldx, cin, dy, ldy, cout, KH, KW, B, H, W, dW, db, ws, ws_floats, prec, S(stream));
 }
 // ---- CNN encoders in training (kernels_enc_train.hip)
 int craft_norm_act_fwd(const float* x, long ldx, const float* mean_rstd, int mr_per_image, const float* gamma, const float* beta, int act,

@@ -300,6 +300,7 @@ template <int ROWS> struct LoaderShiftColsF32 {
 
 struct WgradParams {
   const float* X; const float* dY; float* dW;
+  float* db;                           // non-null: db[co] += sum_pix dY[pix][co] (bias gradient), added by the blocks of tap 0 / input tile 0
   float* ws;                           // non-null: split z writes its partial tile to ws + z * (cout*taps*cin) with plain stores
   long ldx, ldy;
   int cin, cout, KH, KW, B, H, W;
@@ -307,6 +308,22 @@ struct WgradParams {
   unsigned long long magic_hw;
   unsigned magic_w;
 };
+
+// Bias gradient folded into the weight-gradient launch: the blocks that own (tap 0, first input-channel tile) of a pixel range
+// also add that range's column sums of dY (their A operand, L2-resident after the K loop) into db.  One launch less per conv and
+// iteration (132 craft_colsum launches per training step at 12 iterations).
+__device__ __forceinline__ void wgrad_bias_tail(const WgradParams& p, int m0, int rows, int k0, int k1, int tid) {
+  const int co = m0 + tid % rows, lane_k = tid / rows, nk = NTHREADS / rows;
+  if (lane_k >= nk || co >= p.cout) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int k = k0 + lane_k;
+  for (; k + 3 * nk < k1; k += 4 * nk) {
+    a0 += p.dY[(long)k * p.ldy + co]; a1 += p.dY[(long)(k + nk) * p.ldy + co];
+    a2 += p.dY[(long)(k + 2 * nk) * p.ldy + co]; a3 += p.dY[(long)(k + 3 * nk) * p.ldy + co];
+  }
+  for (; k < k1; k += nk) a0 += p.dY[(long)k * p.ldy + co];
+  unsafeAtomicAdd(p.db + co, (a0 + a1) + (a2 + a3));
+}
 
 template <int PREC, int BN, bool SB>
 __global__ __launch_bounds__(NTHREADS) void k_conv_wgrad(WgradParams p) {
@@ -349,6 +366,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_wgrad(WgradParams p) {
       if (co < p.cout && ci < p.cin) unsafeAtomicAdd(p.dW + ((long)co * taps + tap) * p.cin + ci, v);
     });
   }
+  if (p.db && tap == 0 && nt_i == 0) wgrad_bias_tail(p, m0, BM, k0, k1, tid);
 }
 
 // cout <= 64 and cin == 64 (the encoders' 64-channel layers): a 128-row M tile would be half padding.  Here the block tile is
@@ -386,17 +404,18 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_wgrad64(WgradParams p) {
       if (p.ws) *d = v; else unsafeAtomicAdd(d, v);
     }
   });
+  if (p.db && tile == 0) wgrad_bias_tail(p, 0, BM, k0, k1, tid);
 }
 
 int launch_reduce_replicas(const float* rep, int nrep, int n, float* out, hipStream_t s);
 
 int launch_conv_wgrad(const float* x, long ldx, int cin, const float* dy, long ldy, int cout, int KH, int KW, int B, int H, int W,
-                      float* dW, float* ws, long ws_floats, int prec, hipStream_t s) {
+                      float* dW, float* db, float* ws, long ws_floats, int prec, hipStream_t s) {
   if (B <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return 0;
   if (ldx >= (1L << 26) || ldy >= (1L << 26)) return CRAFT_ERR_UNSUPPORTED;
   if ((ldx & 3) || (ldy & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(dy) & 15)) return CRAFT_ERR_ALIGN;
   WgradParams p = {};
-  p.X = x; p.dY = dy; p.dW = dW; p.ldx = ldx; p.ldy = ldy; p.cin = cin; p.cout = cout; p.KH = KH; p.KW = KW; p.B = B; p.H = H; p.W = W;
+  p.X = x; p.dY = dy; p.dW = dW; p.db = db; p.ldx = ldx; p.ldy = ldy; p.cin = cin; p.cout = cout; p.KH = KH; p.KW = KW; p.B = B; p.H = H; p.W = W;
   const int bn = cin > 96 ? 128 : 64;
   p.ntile_n = (cin + bn - 1) / bn;
   p.ntile_m = (cout + 127) / 128;

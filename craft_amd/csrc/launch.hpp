@@ -144,7 +144,7 @@ int launch_gemm_gen(const float* A, long a_sm, long a_sk, long a_bs0, long a_bs1
                     long b_bs1, float* C, long ldc, long c_bs0, long c_bs1, int zdiv, int batch, int M, int N, int K, float alpha,
                     int accumulate, int ksplit, int prec, hipStream_t s);
 int launch_conv_wgrad(const float* x, long ldx, int cin, const float* dy, long ldy, int cout, int KH, int KW, int B, int H, int W,
-                      float* dW, float* ws, long ws_floats, int prec, hipStream_t s);
+                      float* dW, float* db, float* ws, long ws_floats, int prec, hipStream_t s);
 // kernels_enc_train.hip
 struct NormActParams {
   const float* x; long ldx;

@@ -65,7 +65,7 @@ _SIGS = {
     "craft_convex_upsample": [P, P, I, I, I, P, P],
     # ---- training
     "craft_gemm": [P, L, L, L, L, P, L, L, L, L, P, L, L, L, I, I, I, I, I, F, I, I, I, P],
-    "craft_conv2d_wgrad": [P, L, I, P, L, I, I, I, I, I, I, P, P, L, I, P],
+    "craft_conv2d_wgrad": [P, L, I, P, L, I, I, I, I, I, I, P, P, P, L, I, P],
     "craft_norm_act_fwd": [P, L, P, I, P, P, I, P, L, P, L, I, I, I, P],
     "craft_norm_act_bwd_reduce": [P, L, P, L, P, L, P, I, P, P, I, I, P, I, I, I, P],
     "craft_norm_act_bwd_apply": [P, L, P, L, P, L, P, I, P, P, I, I, P, I, P, L, P, L, I, I, I, P],

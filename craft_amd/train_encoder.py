@@ -118,13 +118,16 @@ class EncConv(Function):
             wt, zb, flag, _ = AG._conv_weights(w, None, prec, ctx.cache, True)
             dx = torch.empty(B, Hin * Win, Cin, device=dev, dtype=torch.float32)
             call("craft_conv2d_nhwc", g, g.stride(-2), Cout, wt, zb, Cin, KH, KW, ACT_NONE, dx, Cin, B, Hin, Win, prec | flag)
-        if ctx.needs_input_grad[1]:
-            dwp = AG._conv_wgrad(x, g, B, Hin, Win, Cin, Cout, KH, KW, prec)
-            dw = dwp.permute(0, 3, 1, 2)
         if ctx.needs_input_grad[2]:
             db = torch.zeros(Cout, device=dev, dtype=torch.float32)
-            if not ctx.bias_dead:          # a bias in front of a statistics-normalised layer cannot move the loss: its gradient is 0
-                call("craft_colsum", dy, dy.stride(-2), dy.shape[0] * dy.shape[1], Cout, db)
+        # a bias in front of a statistics-normalised layer cannot move the loss: its gradient is exactly 0; otherwise the column sums
+        # of dY ride on the weight-gradient launch (the zero-stuffed rows of a stride-2 layer add nothing)
+        live_db = db if (db is not None and not ctx.bias_dead) else None
+        if ctx.needs_input_grad[1]:
+            dwp = AG._conv_wgrad(x, g, B, Hin, Win, Cin, Cout, KH, KW, prec, live_db)
+            dw = dwp.permute(0, 3, 1, 2)
+        elif live_db is not None:
+            call("craft_colsum", dy, dy.stride(-2), dy.shape[0] * dy.shape[1], Cout, live_db)
         return dx, dw, db, None, None, None, None, None
 
 

@@ -305,6 +305,7 @@ int craft_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
  *   so that the grid fills the chip (weight gradients: M x N is tiny, K = all rows).  prec as craft_linear.
  * craft_conv2d_wgrad: dW[co][ky][kx][ci] += sum_pix dY[pix][co] * X[pix + (ky-KH/2, kx-KW/2)][ci]  (stride 1, zero padding;
  *   x [B*H*W][cin] row stride ldx, dy [B*H*W][cout] row stride ldy; dW in the packed [cout][KH][KW][cin] layout, ACCUMULATED).
+ *   db (or NULL): db[co] += sum_pix dY[pix][co], the bias gradient, added by the same launch.
  *   ws (or NULL) / ws_floats: scratch for the split-K partial sums; with >= 32 * cout*KH*KW*cin floats every split stores its
  *   partial tile with plain writes and one pass folds them into dW, else the partial sums are added with fp32 atomics.
  * craft_colsum: out[c] += sum_r x[r][c]   (bias gradients).
@@ -317,7 +318,7 @@ int craft_gemm(const float* A, long a_sm, long a_sk, long a_bs0, long a_bs1, con
                long b_bs1, float* C, long ldc, long c_bs0, long c_bs1, int zdiv, int batch, int M, int N, int K, float alpha,
                int accumulate, int ksplit, int prec, void* stream);
 int craft_conv2d_wgrad(const float* x, long ldx, int cin, const float* dy, long ldy, int cout, int KH, int KW, int B, int H, int W,
-                       float* dW, float* ws, long ws_floats, int prec, void* stream);
+                       float* dW, float* db, float* ws, long ws_floats, int prec, void* stream);
 int craft_colsum(const float* x, long ld, long rows, int C, float* out, void* stream);
 int craft_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, void* stream);
 int craft_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,

@@ -89,11 +89,13 @@ def test_conv_wgrad(device, prec, KH, KW, cin, cout, H, W):
     xt = x.permute(0, 2, 3, 1).reshape(B, H * W, cin).contiguous().to(device)
     dyt = dy.permute(0, 2, 3, 1).reshape(B, H * W, cout).contiguous().to(device)
     dw = torch.zeros(cout, KH, KW, cin, device=device)
-    hip.call("craft_conv2d_wgrad", xt, cin, cin, dyt, cout, cout, KH, KW, B, H, W, dw, None, 0, prec)        # atomics
+    db = torch.zeros(cout, device=device)
+    hip.call("craft_conv2d_wgrad", xt, cin, cin, dyt, cout, cout, KH, KW, B, H, W, dw, db, None, 0, prec)    # atomics (+ bias gradient)
     assert rel_err(dw.permute(0, 3, 1, 2), w.grad) < 3e-5
+    assert rel_err(db, dy.sum((0, 2, 3))) < 1e-5                                                               # bias gradient, same launch
     dw2 = torch.full_like(dw, 1.0)                                                                             # scratch + reduction, +=
     ws = torch.empty(32 * dw.numel(), device=device)
-    hip.call("craft_conv2d_wgrad", xt, cin, cin, dyt, cout, cout, KH, KW, B, H, W, dw2, ws, ws.numel(), prec)
+    hip.call("craft_conv2d_wgrad", xt, cin, cin, dyt, cout, cout, KH, KW, B, H, W, dw2, None, ws, ws.numel(), prec)
     assert rel_err(dw2.permute(0, 3, 1, 2) - 1.0, w.grad) < 3e-5
 
 

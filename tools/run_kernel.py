@@ -63,7 +63,7 @@ def main():
         if which == "wgrad":
             dw = torch.zeros(cout, 1, 5, cin, device=dev)
             for _ in range(3):
-                H.call("craft_conv2d_wgrad", x, cin, cin, dy, cout, cout, 1, 5, Bq, h8, w8, dw, None, 0, cp)
+                H.call("craft_conv2d_wgrad", x, cin, cin, dy, cout, cout, 1, 5, Bq, h8, w8, dw, None, None, 0, cp)
         else:       # the same contraction without taps: dW = dY^T X (k-major x k-major, split-K)
             dw = torch.zeros(cout, cin, device=dev)
             for _ in range(3):
