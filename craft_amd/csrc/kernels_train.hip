@@ -484,8 +484,11 @@ int launch_corr_pyramid_bwd(float* G0, const float* G1, const float* G2, const f
 }
 
 // ---------------------------------------------------------------------------------------------
-// lookup backward (CorrBlock.__call__, corr.py:47-71): scatter w * g of every bilinear tap into the gradient of the
-// NORMALISED pyramid level it sampled (zero padding: out-of-image taps have no gradient).  One wave per query.
+// lookup backward (CorrBlock.__call__, corr.py:47-71): w * g of every bilinear tap goes into the gradient of the NORMALISED
+// pyramid level it sampled (zero padding: out-of-image taps have no gradient).  One wave per query.  The (2r+1)^2 taps of a level
+// cover a (2r+2)^2 footprint of that query's own correlation image, each cell fed by up to 4 taps: a lane GATHERS the
+// contributions of its cell and adds them with one plain read-modify-write (nothing else touches query q's images during a
+// launch) -- 100 coalesced updates per level instead of 324 fp32 atomics (the scatter form took 246 us per call at configs[3]).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_corr_lookup_bwd(const float* __restrict__ dout, long ldo, const float* __restrict__ coords,
                                                          float* __restrict__ G0, float* __restrict__ G1, float* __restrict__ G2,
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(256) void k_corr_lookup_bwd(const float* __restrict
   const long q = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= nq) return;
   const float cx = coords[2 * q], cy = coords[2 * q + 1];
-  const int win = 2 * radius + 1;
+  const int win = 2 * radius + 1, fp = win + 1;
   float* Gl[4] = {G0, G1, G2, G3};
   int h = H8, w = W8;
   float sc = 1.f;
@@ -506,15 +509,19 @@ __global__ __launch_bounds__(256) void k_corr_lookup_bwd(const float* __restrict
     const int x0 = (int)fminf(fmaxf(x0f, -100000.f), 100000.f) - radius;
     const int y0 = (int)fminf(fmaxf(y0f, -100000.f), 100000.f) - radius;
     float* img = Gl[l] + q * (long)h * w;
-    const float wt[4] = {(1.f - fx) * (1.f - fy), fx * (1.f - fy), (1.f - fx) * fy, fx * fy};
-    for (int k = lane; k < win * win; k += 64) {
-      const int a = k / win, bb = k - a * win;          // x offset a, y offset bb (the x offset runs along the first window axis)
-      const float g = dout[q * ldo + l * lvl_stride + col_off + k];
+    const float* g = dout + q * ldo + l * lvl_stride + col_off;      // g[a * win + bb]: x offset a, y offset bb
+    const float wx[2] = {1.f - fx, fx}, wy[2] = {1.f - fy, fy};
+    for (int c = lane; c < fp * fp; c += 64) {
+      const int v = c / fp, u = c - v * fp;             // footprint cell: x = x0 + u, y = y0 + v (u fastest: coalesced rows)
+      const int x = x0 + u, y = y0 + v;
+      if (x < 0 || x >= w || y < 0 || y >= h) continue;
+      float acc = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int x = x0 + a + (t & 1), y = y0 + bb + (t >> 1);
-        if (x >= 0 && x < w && y >= 0 && y < h) unsafeAtomicAdd(img + y * w + x, wt[t] * g);
+        const int a = u - (t & 1), bb = v - (t >> 1);
+        if (a >= 0 && a < win && bb >= 0 && bb < win) acc += wx[t & 1] * wy[t >> 1] * g[a * win + bb];
       }
+      img[y * w + x] += acc;
     }
     h >>= 1; w >>= 1; sc *= 0.5f;
   }
