@@ -22,3 +22,12 @@ def test_random_shapes_and_model_variants_against_oracle(device):
     import fuzz_parity
     bad, worst = fuzz_parity.sweep(14, seed0=2000, verbose=False, variants=True)
     assert bad == 0, f"{bad} of 14 random draws exceed the tolerance (worst error / tolerance {worst:.2f})"
+
+
+def test_random_shapes_training_step_against_oracle(device):
+    """Training: loss and every parameter gradient of the HIP forward + backward vs torch autograd over the CPU oracle on random
+    sizes / batch / iterations / BatchNorm mode / variant (--setrans or GMA attention, cross-attention or plain correlation) --
+    tools/fuzz_train_parity.py.  Relative L2 per parameter <= 3e-2 (fp32 policy), loss to 1e-4."""
+    import fuzz_train_parity
+    bad, worst = fuzz_train_parity.sweep(8, seed0=5000, verbose=False)
+    assert bad == 0, f"{bad} of 8 random draws exceed the tolerance (worst gradient relative L2 {worst:.2e})"
