@@ -156,6 +156,12 @@ def _acc_buffer(cache, t, kind, shape, device):
     return buf, None
 
 
+def pending_uses(cache) -> int:
+    """Forward uses whose backward has not run (0 after a complete backward pass).  A non-zero count after ``loss.backward()`` means
+    autograd pruned a call of an accumulated layer -- its weight gradient would be missing -- so callers treat it as an error."""
+    return sum(v for k, v in (cache or {}).items() if isinstance(k, tuple) and len(k) == 2 and k[1] == "uses")
+
+
 def _release_use(cache, t) -> bool:
     """Count one backward call of t; True when it was the last one of this pass (the accumulated gradient is complete)."""
     if cache is None:

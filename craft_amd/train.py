@@ -284,6 +284,9 @@ class Trainer:
         preds = model(image1, image2, iters=self.iters)
         loss, metrics = seq_loss(preds, flow, valid, self.gamma)
         loss.backward()
+        from .autograd import pending_uses
+        if pending_uses(model.__dict__.get("_train_pass_cache")):
+            raise RuntimeError("backward left accumulated weight gradients incomplete (a layer call was pruned from the graph)")
         mul = opt.allreduce_grads(self.group)                          # ONE collective over the flat gradient buffer
         if self.reference_loss_scaling:
             mul = mul / self._world()

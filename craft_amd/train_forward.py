@@ -152,6 +152,7 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
     coords0, coords1, _ = ops.coords_init(flow_init, B, H8, W8, dev)
     preds = []
     wcache = {}          # conv operands (padded / packed / transposed weights) built once for this pass and its backward
+    model.__dict__["_train_pass_cache"] = wcache            # (autograd.pending_uses: Trainer.step checks it after backward)
     wzr = [torch.cat([gru.convz1.weight, gru.convr1.weight], 0), torch.cat([gru.convz2.weight, gru.convr2.weight], 0)]
     bzr = [torch.cat([gru.convz1.bias, gru.convr1.bias], 0), torch.cat([gru.convz2.bias, gru.convr2.bias], 0)]
     convq = [gru.convq1, gru.convq2]
