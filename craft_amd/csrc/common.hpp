@@ -20,6 +20,12 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define CRAFT_ACT_RELU 2
 #define CRAFT_ACT_SIGMOID 3
 
+// developer experiment (tools/build_variant.py -DCRAFT_X3_TERMS=5|6): which terms of the split-fp16 product the CONVOLUTION kernels
+// execute -- bit 0: lo(activation) x hi(weight), bit 1: hi(activation) x lo(weight), bit 2: hi x hi.  7 = the shipped f16x3.
+#ifndef CRAFT_X3_TERMS
+#define CRAFT_X3_TERMS 7
+#endif
+
 #define CRAFT_ATTN_CLIP 100.0f   // setrans.py:98
 #define CRAFT_LN_EPS 1e-12f      // setrans.py:715, :362; corr.py:203
 #define CRAFT_STATS_REPLICAS 64  // == include/craft_hip.h

@@ -189,14 +189,18 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo(ConvGemmParams p) {
         }
         // term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent chain)
         if constexpr (PREC == CRAFT_PREC_F16X3) {
+          if constexpr (CRAFT_X3_TERMS & 1) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+              for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          }
+          if constexpr (CRAFT_X3_TERMS & 2) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+              for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+          }
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)

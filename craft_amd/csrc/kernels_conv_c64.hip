@@ -165,10 +165,14 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_c64(ConvGemmParams p) {
       frag_t (&l)[MT] = al[s & 1];
       frag_t (&bw)[PL] = bfr[s % BDEPTH];
       if constexpr (PL == 2) {
+        if constexpr (CRAFT_X3_TERMS & 1) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(l[mt], bw[0], acc[mt][0]);
+          for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(l[mt], bw[0], acc[mt][0]);
+        }
+        if constexpr (CRAFT_X3_TERMS & 2) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(h[mt], bw[1], acc[mt][0]);
+          for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(h[mt], bw[1], acc[mt][0]);
+        }
       }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(h[mt], bw[0], acc[mt][0]);

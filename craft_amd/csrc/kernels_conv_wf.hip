@@ -173,10 +173,14 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   // MFMAs of one k-half; term-major order so that consecutive MFMAs hit different accumulators
   auto mma_half = [&](const frag_t (&h)[MT], const frag_t (&l)[MT], int slot) __attribute__((always_inline)) {
     if constexpr (PL == 2) {
+      if constexpr (CRAFT_X3_TERMS & 1) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(l[mt], bq[0][slot], acc[mt][0]);
+        for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(l[mt], bq[0][slot], acc[mt][0]);
+      }
+      if constexpr (CRAFT_X3_TERMS & 2) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(h[mt], bq[1][slot], acc[mt][0]);
+        for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(h[mt], bq[1][slot], acc[mt][0]);
+      }
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(h[mt], bq[0][slot], acc[mt][0]);
