@@ -185,6 +185,24 @@ def pick(prec, role: str) -> int:
     return prec if isinstance(prec, int) else getattr(prec, role)
 
 
+_GROUP_OVERRIDE = None
+
+
+def conv_group_prec(prec, group: str) -> int:
+    """MFMA operand mode of one group of update-block convolutions ("gru", "menc", "fh", "mask"): the policy's ``conv`` role unless
+    the developer override CRAFT_CONV_GROUPS="gru=fp16,mask=fp16,..." names the group (sensitivity study, tools/conv_group_sweep.sh)."""
+    global _GROUP_OVERRIDE
+    if _GROUP_OVERRIDE is None:
+        _GROUP_OVERRIDE = {}
+        for item in filter(None, os.environ.get("CRAFT_CONV_GROUPS", "").split(",")):
+            k, v = item.split("=")
+            _GROUP_OVERRIDE[k.strip()] = PREC_NAMES[v.strip()]
+    cp = pick(prec, "conv")
+    if cp == PREC_F32:
+        return cp
+    return _GROUP_OVERRIDE.get(group, cp)
+
+
 def lib_path() -> str:
     return _LIB_PATH
 

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import ops
 from .gma import Aggregate
-from .hip import PREC_F32, W_PACKED, call, pick, weights_epoch
+from .hip import conv_group_prec, PREC_F32, W_PACKED, call, pick, weights_epoch
 from .setrans import ExpandedFeatTrans
 
 
@@ -100,7 +100,7 @@ class SepConvGRU(nn.Module):
         """Once per forward: the contribution of the (iteration-invariant) context features to all six gate
         convolutions, biases included -> fields [B, N, 768]."""
         B, N, cc = inp.shape
-        cp = pick(prec, "conv")
+        cp = conv_group_prec(prec, "gru")
         _, const = self.packed_split(cp, self.hidden_dim, self.hidden_dim + cc)
         fields = torch.empty(B, N, 768, device=inp.device, dtype=torch.float32)
         call("craft_sepconv_gru_context", inp, inp.stride(1), cc, *const, B, hw[0], hw[1], fields, cp | W_PACKED)
@@ -109,7 +109,7 @@ class SepConvGRU(nn.Module):
     def step_tokens(self, hx: torch.Tensor, hw, ws: torch.Tensor, prec, fields: torch.Tensor, c_lo: int, c_hi: int):
         """One GRU update in place on hx = [h | inp | v]: only h and v enter the K loops, `fields` carries the rest."""
         B, N, ctot = hx.shape
-        cp = pick(prec, "conv")
+        cp = conv_group_prec(prec, "gru")
         var, _ = self.packed_split(cp, c_lo, c_hi)
         call("craft_sepconv_gru_step", hx, hx.stride(1), c_hi, ctot - c_hi, *var, fields, B, hw[0], hw[1], ws, cp | W_PACKED)
 
@@ -117,7 +117,7 @@ class SepConvGRU(nn.Module):
         """In place on hx = [h (128) | x (input_dim)] tokens [B, N, 128+input_dim]."""
         B, N, _ = hx.shape
         H8, W8 = hw
-        cp = pick(prec, "conv")
+        cp = conv_group_prec(prec, "gru")
         wzr1, bzr1, wq1, bq1, wzr2, bzr2, wq2, bq2 = self.packed(cp)
         call("craft_sepconv_gru", hx, hx.stride(1), self.input_dim, wzr1, bzr1, wq1, bq1, wzr2, bzr2, wq2, bq2, B, H8, W8,
              ws, cp | W_PACKED)
@@ -165,7 +165,7 @@ class BasicMotionEncoder(nn.Module):
         (convf1 -> convf2) runs on a side stream next to the correlation branch."""
         B, N, _ = flow.shape
         H8, W8 = hw
-        cp = pick(prec, "conv")
+        cp = conv_group_prec(prec, "menc")
         wc1, bc1, wc2, bc2, wf1, bf1, wf2, bf2, wcv, bcv = self.packed(cp)
         st = ev = None
         if fork and not os.environ.get("CRAFT_NO_FORK"):
@@ -217,7 +217,7 @@ class GMAUpdateBlock(nn.Module):
 
     def flow_head_tokens(self, hx, hw, coords1, coords0, flow, delta, ws, prec):
         B, N, _ = hx.shape
-        cp = pick(prec, "conv")
+        cp = conv_group_prec(prec, "fh")
         w1, b1, w2, b2 = self.flow_head.packed(cp)
         call("craft_flow_head", hx, hx.stride(1), w1, b1, w2, b2, B, hw[0], hw[1], coords1, coords0, flow, delta, ws,
              cp | W_PACKED)
@@ -226,7 +226,7 @@ class GMAUpdateBlock(nn.Module):
         B, N, _ = hx.shape
         if out is None:
             out = torch.empty(B, N, 576, device=hx.device, dtype=torch.float32)
-        cp = pick(prec, "conv")
+        cp = conv_group_prec(prec, "mask")
         w0, b0, w2, b2 = self.packed_mask(cp)
         call("craft_mask_head", hx, hx.stride(1), w0, b0, w2, b2, B, hw[0], hw[1], out, ws, cp | W_PACKED)
         return out
