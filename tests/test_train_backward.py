@@ -399,16 +399,18 @@ def test_train_mode_rejects_other_configs_and_sizes(device):
             other(torch.zeros(1, 3, 128, 128, device=device), torch.zeros(1, 3, 128, 128, device=device), iters=1)
 
 
-def test_training_step_at_configs3_size_against_oracle(device):
-    """BASELINE configs[3] shape (368x496 -> 46x62 tokens, odd pooling sizes 23 / 11 / 5), batch 2 with BatchNorm batch statistics,
-    2 iterations, fp32 policy: loss and every parameter gradient of the HIP step against torch autograd over the CPU oracle
-    (which tests/test_oracle_train_golden.py pins to the reference)."""
+@pytest.mark.parametrize("B,H,W,iters,freeze_bn", [(2, 368, 496, 2, False), (1, 368, 768, 1, True)])
+def test_training_step_at_configs3_size_against_oracle(device, B, H, W, iters, freeze_bn):
+    """BASELINE configs[3] shape (368x496 -> 46x62 tokens, odd pooling sizes 23 / 11 / 5; batch 2 with BatchNorm batch statistics,
+    2 iterations) and configs[4] shape (368x768 -> 46x96 tokens, frozen BatchNorm), fp32 policy: loss and every parameter gradient
+    of the HIP step against torch autograd over the CPU oracle (which tests/test_oracle_train_golden.py pins to the reference)."""
     from craft_amd.synth import synth_pair
-    B, H, W, iters = 2, 368, 496, 2
     model = CRAFT(default_args(hip_precision="fp32", dropout_prob=0.0))
     sd0 = synth_state_dict(model.state_dict(), seed=77)
     model.load_state_dict(sd0, strict=True)
     model = model.to(device).train()
+    if freeze_bn:
+        model.freeze_bn()
     im1, im2, flow = synth_pair(B, H, W, seed=31)
     valid = (torch.rand(B, H, W, generator=torch.Generator().manual_seed(1)) > 0.15).float()
     preds = model(im1.to(device), im2.to(device), iters=iters)
@@ -418,7 +420,7 @@ def test_training_step_at_configs3_size_against_oracle(device):
     sd = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in sd0.items()}
     sd["corr_fn.setrans.key.weight"], sd["corr_fn.setrans.key.bias"] = sd["corr_fn.setrans.query.weight"], sd["corr_fn.setrans.query.bias"]
     torch.set_num_threads(min(32, torch.get_num_threads()))
-    preds_r, _ = O.craft_train_forward(sd, O.OracleConfig(), im1, im2, iters=iters)
+    preds_r, _ = O.craft_train_forward(sd, O.OracleConfig(), im1, im2, iters=iters, freeze_bn=freeze_bn)
     loss_r, _ = O.sequence_loss(preds_r, flow, valid, 0.8)
     loss_r.backward()
     assert float(loss) == pytest.approx(float(loss_r), rel=3e-5)
@@ -440,4 +442,4 @@ def test_training_step_at_configs3_size_against_oracle(device):
         assert l2 < 1e-2, f"{k}: relative L2 error {l2:.2e}"
         worst, checked = max(worst, l2), checked + 1
     assert checked > 100
-    print(f"[train parity] 368x496 B=2: loss {float(loss):.6f} vs oracle {float(loss_r):.6f}; worst relative L2 gradient error {worst:.2e} over {checked} parameters")
+    print(f"[train parity] {H}x{W} B={B}: loss {float(loss):.6f} vs oracle {float(loss_r):.6f}; worst relative L2 gradient error {worst:.2e} over {checked} parameters")
