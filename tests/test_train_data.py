@@ -1,0 +1,72 @@
+"""Training input feed (craft_amd/train_data.py = datasets.py FlowDataset.__getitem__ + fetch_dataloader): miniature Sintel and KITTI
+trees on disk -> GPU augmentation -> batches -> one Trainer.step."""
+import numpy as np
+import pytest
+import torch
+
+from craft_amd import CRAFT, default_args, flow_io
+from craft_amd.flow_datasets import KITTI, MpiSintel
+from craft_amd.synth import synth_pair, synth_state_dict
+from craft_amd.train import Trainer
+from craft_amd.train_data import STAGE_AUG, TrainSource, make_augmentor, seed_workers, train_batches
+
+pytestmark = pytest.mark.gpu
+
+
+def _trees(tmp_path, n=4, H=160, W=240):
+    im1, im2, flow = synth_pair(n + 1, H, W, seed=21, max_flow=5)
+    gt = flow.permute(0, 2, 3, 1).numpy()
+    u8 = lambda t: t.permute(1, 2, 0).numpy().astype(np.uint8)
+    root = tmp_path / "Sintel"
+    for i in range(n):
+        for sub in ("clean", "final", "flow"):
+            (root / "training" / sub / f"s{i}").mkdir(parents=True)
+        for dst in ("clean", "final"):
+            flow_io.write_image(str(root / "training" / dst / f"s{i}" / "frame_0001.png"), u8(im1[i]))
+            flow_io.write_image(str(root / "training" / dst / f"s{i}" / "frame_0002.png"), u8(im2[i]))
+        flow_io.write_flo(str(root / "training" / "flow" / f"s{i}" / "frame_0001.flo"), gt[i])
+    kroot = tmp_path / "KITTI"
+    (kroot / "training" / "image_2").mkdir(parents=True)
+    (kroot / "training" / "flow_occ").mkdir(parents=True)
+    flow_io.write_image(str(kroot / "training" / "image_2" / "000000_10.png"), u8(im1[n]))
+    flow_io.write_image(str(kroot / "training" / "image_2" / "000000_11.png"), u8(im2[n]))
+    flow_io.write_flow_kitti(str(kroot / "training" / "flow_occ" / "000000_10.png"), gt[n])
+    return str(root), str(kroot)
+
+
+def test_stage_parameters_match_fetch_dataloader():
+    assert STAGE_AUG["chairs"] == dict(min_scale=-0.1, max_scale=1.0, do_flip=True)                      # datasets.py:513-515
+    assert STAGE_AUG["sintel"] == dict(min_scale=-0.2, max_scale=0.6, do_flip=True)                      # :537
+    assert STAGE_AUG["kitti"] == dict(min_scale=-0.2, max_scale=0.4, do_flip=False)                      # :554
+    assert STAGE_AUG["viper"]["spatial_aug_prob"] == 1 and STAGE_AUG["autoflow"]["spatial_aug_prob"] == 1
+
+
+def test_batches_from_files_and_one_training_step(device, tmp_path):
+    root, kroot = _trees(tmp_path)
+    crop = (96, 128)
+    clean, final, kitti = MpiSintel("training", root, "clean"), MpiSintel("training", root, "final"), KITTI("training", kroot)
+    # the sintel stage's mix (datasets.py:548: replication factors in front of each dataset), miniature factors here
+    sources = [TrainSource(clean, make_augmentor(clean, "sintel", crop), repeat=2),
+               TrainSource(final, make_augmentor(final, "sintel", crop, shift_prob=0.5), repeat=2),
+               TrainSource(kitti, make_augmentor(kitti, "sintel/kitti", crop), repeat=3)]
+    assert sum(len(s) for s in sources) == 2 * 4 + 2 * 4 + 3
+    seed_workers(3)
+    it = train_batches(sources, batch_size=2, device=device, seed=1, epochs=1)
+    batches = list(it)
+    assert len(batches) == 19 // 2                                   # drop_last
+    for im1, im2, flow, valid in batches:
+        assert im1.shape == (2, 3, *crop) and im2.shape == im1.shape and flow.shape == (2, 2, *crop) and valid.shape == (2, *crop)
+        assert im1.is_cuda and torch.isfinite(im1).all() and torch.isfinite(flow).all()
+        assert float(im1.min()) >= 0 and float(im1.max()) <= 255
+        assert set(torch.unique(valid).tolist()) <= {0.0, 1.0} and float(valid.mean()) > 0.2
+    # two ranks see disjoint halves of the epoch's permutation
+    seed_workers(3)
+    r0 = list(train_batches(sources, 2, device, seed=1, rank=0, world=2, epochs=1))
+    r1 = list(train_batches(sources, 2, device, seed=1, rank=1, world=2, epochs=1))
+    assert len(r0) == len(r1) == (19 + 1) // 2 // 2 or len(r0) + len(r1) <= 9
+    # and the batches train
+    model = CRAFT(default_args(hip_precision="fp32"))
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=2), strict=True)
+    tr = Trainer(model.to(device), lr=1e-4, num_steps=20, iters=2, freeze_bn=True)
+    m = tr.step(*batches[0])
+    assert m["loss"] == m["loss"] and m["loss"] < 1e4
