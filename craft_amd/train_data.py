@@ -79,6 +79,9 @@ def train_batches(sources: List[TrainSource], batch_size: int, device, seed: int
     epoch = 0
     while epochs is None or epoch < epochs:
         order = np.random.RandomState(seed + epoch).permutation(len(table))
+        if world > 1:                                             # DistributedSampler: pad to a multiple of `world` so that every rank
+            pad = (-len(order)) % world                           # runs the same number of steps (an all-reduce per step needs them all)
+            order = np.concatenate([order, order[:pad]])
         mine = order[rank::world]
         for b0 in range(0, len(mine) - batch_size + 1, batch_size):
             items = [sources[table[j][0]].sample(table[j][1], device) for j in mine[b0:b0 + batch_size]]
