@@ -115,10 +115,13 @@ NAMED_POLICIES = {"mixed": "proj=f16x3,score=f16x3,pv=fp16,conv=f16x3", "mixed_f
                   # contractions (BASELINE.json configs[4]: "bf16 MFMA cross-attention")
                   "train_f16x3": "proj=f16x3,score=f16x3,pv=f16x3,conv=f16x3",
                   "train_bf16attn": "proj=f16x3,score=bf16,pv=bf16,conv=f16x3",
-                  # + the two CNN encoders (PyTorch-ROCm modules in training) under torch.autocast(bfloat16): what the reference's
-                  # own training does with --mixed_precision (network.py:179-183 autocast around fnet / cnet), bf16 instead of fp16
-                  # so that no loss scaling is needed
-                  "train_bf16": "proj=f16x3,score=bf16,pv=bf16,conv=f16x3,enc=bf16"}
+                  # + the two CNN encoders with bf16 MFMA operands (the reference's --mixed_precision runs fnet / cnet under fp16
+                  # autocast, network.py:179-183; bf16 so that no loss scaling is needed).  With args.hip_encoders=False the
+                  # PyTorch-ROCm modules run under torch.autocast(bfloat16) instead
+                  "train_bf16": "proj=f16x3,score=bf16,pv=bf16,conv=f16x3,enc=bf16",
+                  # bf16 MFMA operands everywhere, fp32 accumulation / activations / master weights: the precision class of the
+                  # reference's own training runs (every shipped train-*.sh passes --mixed_precision: fp16 autocast + GradScaler)
+                  "train_amp_bf16": "proj=bf16,score=bf16,pv=bf16,conv=bf16,enc=bf16"}
 
 
 class CraftHipError(RuntimeError):

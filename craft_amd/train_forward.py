@@ -71,14 +71,13 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
         return float(getattr(args, "dropout_prob", -1)) if getattr(args, "dropout_prob", -1) >= 0 else float(cfg.attention_probs_dropout_prob)
 
     # ---- CNN encoders (network.py:169-183, :203) -----------------------------------------------------------------------
-    # default: on the HIP kernels (craft_amd/train_encoder.py; args.hip_encoders=False or prec.enc = bf16 keeps the PyTorch-ROCm
-    # modules under torch autograd, the latter under autocast like the reference's mixed-precision training, network.py:179,199;
-    # enc = fp16 would need the reference's GradScaler and is refused)
+    # default: on the HIP kernels in the policy's `enc` operand mode (craft_amd/train_encoder.py).  args.hip_encoders=False keeps the
+    # PyTorch-ROCm modules under torch autograd -- with enc = bf16 under autocast, like the reference's mixed-precision training
+    # (network.py:179,199); enc = fp16 would need the reference's GradScaler and is refused
     if prec.enc == PREC_F16:
         raise NotImplementedError("training: enc=fp16 needs loss scaling; use enc=bf16 (autocast) or an fp32-class mode")
     H, W = image1.shape[-2:]
-    use_henc = (getattr(args, "hip_encoders", True) and prec.enc != PREC_BF16 and TE.supported(model.fnet, H, W)
-                and TE.supported(model.cnet, H, W))
+    use_henc = getattr(args, "hip_encoders", True) and TE.supported(model.fnet, H, W) and TE.supported(model.cnet, H, W)
     if use_henc:
         B = image1.shape[0]
         f12 = TE.encoder_forward_train(model.fnet, torch.cat([image1, image2], dim=0).float(), prec)

@@ -358,12 +358,12 @@ def test_training_step_matches_reference_gradients(device, case, precision):
         assert np.allclose(got, z[k], rtol=1e-3, atol=1e-5), k
 
 
-@pytest.mark.parametrize("precision,loss_rel,l2_tol", [("train_bf16attn", 1e-4, 0.3), ("train_bf16", 1e-2, 0.6)])
+@pytest.mark.parametrize("precision,loss_rel,l2_tol", [("train_bf16attn", 1e-4, 0.3), ("train_bf16", 1e-2, 0.6), ("train_amp_bf16", 1e-2, 0.6)])
 @pytest.mark.parametrize("case", TRAIN_CASES)
 def test_training_step_bf16_policies(device, case, precision, loss_rel, l2_tol):
     """The bf16 training policies against the reference's FP32 capture.  bf16 MFMA operands for Q.K^T / P.V and their gradients
-    ("train_bf16attn", BASELINE configs[4]) and, in "train_bf16", the CNN encoders under torch.autocast(bfloat16) as in the
-    reference's --mixed_precision training.  These bounds are regression guards with ~2x margin over the measured errors
+    ("train_bf16attn", BASELINE configs[4]); in "train_bf16" also the CNN encoders' convolutions, in "train_amp_bf16" every
+    contraction (the precision class of the reference's --mixed_precision training, bf16 instead of fp16).  These bounds are regression guards with ~2x margin over the measured errors
     (tools/train_policy_err.py: bf16attn loss 2e-6, gradients <= 0.16 relative L2; train_bf16 loss 2.4e-3, gradients <= 0.31 --
     the encoders' 8-bit mantissa perturbs the features every later gradient is computed from), not fp32-parity claims: the
     parity-grade training policies are "fp32" and "train_f16x3" above."""
