@@ -507,11 +507,17 @@ int launch_coords_init(const float* flow_init_nchw, int B, int H8, int W8, float
 
 // (sum, sum^2) -> (mean, 1/sqrt(var + eps)) for n independent populations of `count` samples each
 // (lazy InstanceNorm of the HIP encoders: one population per (image, channel)).
-__global__ void k_stats_finalize(const double* __restrict__ sums, long n, double count, float eps, float* __restrict__ mr) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per population: its 64 lanes fetch the CRAFT_STATS_REPLICAS = 64 partial sums in one go (a thread per population walked
+// them serially: 11 us per call, nine calls on the feature encoder's critical path).
+__global__ __launch_bounds__(256) void k_stats_finalize(const double* __restrict__ sums, long n, double count, float eps, float* __restrict__ mr) {
+  static_assert(CRAFT_STATS_REPLICAS == 64, "one replica per lane");
+  const int lane = threadIdx.x & 63;
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
-  double a = 0.0, q = 0.0;
-  for (int r = 0; r < CRAFT_STATS_REPLICAS; ++r) { a += sums[(r * n + i) * 2]; q += sums[(r * n + i) * 2 + 1]; }
+  double a = sums[(lane * n + i) * 2], q = sums[(lane * n + i) * 2 + 1];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+  if (lane) return;
   const double mu = a / count;
   double var = q / count - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -519,7 +525,8 @@ __global__ void k_stats_finalize(const double* __restrict__ sums, long n, double
   mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 int launch_stats_finalize(const double* sums, long n, double count, float eps, float* mean_rstd, hipStream_t s) {
-  hipLaunchKernelGGL(k_stats_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sums, n, count, eps, mean_rstd);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_stats_finalize, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, sums, n, count, eps, mean_rstd);
   return (int)hipGetLastError();
 }
 
