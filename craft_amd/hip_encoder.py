@@ -140,21 +140,31 @@ class HipEncoder:
             else:
                 call("craft_stem_conv7x7", raw.contiguous(), sw, sb, act, B, H, W, t, stats)
         if inorm:
-            s0 = torch.zeros(STATS_REPLICAS, B, 64, 2, device=dev, dtype=torch.float64)
+            # the (sum, sum^2) tables of ALL convolutions of this forward come out of one zero fill (15 fills of ~1 MB otherwise)
+            couts = [64] + [c for pk in packs for c in ([pk["c1"].cout, pk["c2"].cout] + ([pk["ds"].cout] if "ds" in pk else []))]
+            pool = torch.zeros(STATS_REPLICAS * B * 2 * sum(couts), device=dev, dtype=torch.float64)
+            pool_off = [0]
+
+            def new_stats(cout):
+                n = STATS_REPLICAS * B * cout * 2
+                v = pool[pool_off[0]:pool_off[0] + n].view(STATS_REPLICAS, B, cout, 2)
+                pool_off[0] += n
+                return v
+            s0 = new_stats(64)
             stem(ACT_NONE, s0)
             t_norm = self._finalize(s0, hw[0] * hw[1])          # norm1 + ReLU are applied lazily by layer1.0
         else:
             stem(ACT_RELU, None)
         for pk in packs:
             if inorm:
-                s1 = torch.zeros(STATS_REPLICAS, B, pk["c1"].cout, 2, device=dev, dtype=torch.float64)
+                s1 = new_stats(pk["c1"].cout)
                 c1, hw1 = self._conv(t, B, hw, pk["c1"], ACT_NONE, cp, in_norm=t_norm, stats=s1)
                 n1 = self._finalize(s1, hw1[0] * hw1[1])
-                s2 = torch.zeros(STATS_REPLICAS, B, pk["c2"].cout, 2, device=dev, dtype=torch.float64)
+                s2 = new_stats(pk["c2"].cout)
                 c2, _ = self._conv(c1, B, hw1, pk["c2"], ACT_NONE, cp, in_norm=n1, stats=s2)
                 n2 = self._finalize(s2, hw1[0] * hw1[1])
                 if "ds" in pk:
-                    s3 = torch.zeros(STATS_REPLICAS, B, pk["ds"].cout, 2, device=dev, dtype=torch.float64)
+                    s3 = new_stats(pk["ds"].cout)
                     xs, _ = self._conv(t, B, hw, pk["ds"], ACT_NONE, cp, stats=s3)
                     n3 = self._finalize(s3, hw1[0] * hw1[1])
                     flags = 1
