@@ -109,7 +109,10 @@ def linear_t(x: torch.Tensor, w: torch.Tensor, ldt: int, prec: int, out: Optiona
     Cout = w.shape[0]
     pv = pick(prec, "pv")
     if out is None:
-        out = torch.zeros(B, Cout, ldt, device=x.device, dtype=PROB_DTYPE[pv])
+        # the tail columns N .. ldt-1 must read as zero; without a tail (N a multiple of 32: every BASELINE size) the kernel writes
+        # every element and the 29 MB zero fill per aggregator call (12 per forward at 448x1024) is skipped
+        alloc = torch.empty if ldt == N else torch.zeros
+        out = alloc(B, Cout, ldt, device=x.device, dtype=PROB_DTYPE[pv])
     frag = Dv if (Dv and pv != PREC_F32) else 0
     if acc_order:
         if not frag:
