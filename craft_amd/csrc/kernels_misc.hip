@@ -784,7 +784,8 @@ int launch_flow_l1(const float* pred, const float* gt, const float* valid, int B
   const long hw = (long)H * W, tot = hw * B;
   if (tot <= 0) return 0;
   const long nb = (tot + 255) / 256;
-  hipLaunchKernelGGL(k_flow_l1, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, s, pred, gt, valid, hw, tot, weight, max_flow,
+  // (512 blocks: every block ends with one double atomic on the same address; 4 096 of them cost more than the 35 MB pass itself)
+  hipLaunchKernelGGL(k_flow_l1, dim3((unsigned)(nb < 512 ? nb : 512)), dim3(256), 0, s, pred, gt, valid, hw, tot, weight, max_flow,
                      loss, grad);
   return (int)hipGetLastError();
 }
