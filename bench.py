@@ -20,6 +20,10 @@ Extra objects on the line:
                 step): algorithmic flops / time against the dense MFMA peak.
   cpu_baseline  the CPU oracle (oracle/craft_oracle.py, fp32 torch-CPU restatement of the reference's
                 forward) timed on this box's host cores on ONE 448x1024 pair, 12 iterations.
+  train_cfg3    a short leg of BASELINE.json configs[3] (training step at 368x496, batch 8/GPU: 3 warm-up + 5 timed steps, same
+                barrier / max-over-ranks protocol): ms_per_step, pairs_per_s and the roofline of the backward's dominant kernel
+                (k_conv_wgrad, timed live).  `python bench.py --train 3|4` is the full training benchmark (its own JSON line with
+                roofline and the CPU oracle's training step as cpu_baseline).
 """
 import argparse
 import json
@@ -46,6 +50,8 @@ def parse():
                     help="fp32 | bf16 | fp16 or a per-role policy such as score=bf16,pv=fp16,conv=fp32 (craft_amd.hip.Precision)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0: min(32, logical CPUs))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true",
+                    help="skip the short configs[3] training leg (3 warm-up + 5 timed steps) that the default line carries as `train_cfg3`")
     ap.add_argument("--ops", action="store_true", help="also print a per-operator timing table to stderr")
     ap.add_argument("--torch-encoders", action="store_true",
                     help="--train only: keep the two CNN encoders on PyTorch-ROCm / MIOpen under torch autograd (developer A/B)")
@@ -219,30 +225,101 @@ def self_launch(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def train_bench(a, rank, world, dev, dist):
-    """BASELINE.json configs[3] / configs[4]: whole training steps (train.py:215-236 / train_ddp.py:230-262) on synthetic
-    pairs resident in HBM.  One rank per GPU, full replica, its own pairs; the one data-path collective is the all-reduce of
-    the flat gradient buffer (RCCL over xGMI)."""
+TRAIN_CFG = {3: (368, 496, 8, "train_f16x3", "configs[3]: FlyingChairs-size 368x496, batch 8/GPU"),
+             4: (368, 768, 4, "train_bf16attn", "configs[4]: Sintel-crop 368x768, batch 4/GPU, bf16 MFMA attention")}
+
+
+def roofline_wgrad(step, policy, steps=2):
+    """The dominant kernel of the backward pass, k_conv_wgrad (convolution weight gradients: per tap a cout x cin product over
+    K = all pixels), timed LIVE: HIP events around every craft_conv2d_wgrad call of `steps` real training steps (events on the
+    launch stream).  Algorithmic flops per launch = 2 * pixels * cout * cin * KH * KW from the launch's own arguments.  Reported:
+    the launch shape with the largest total time (`kernel`, per-launch numbers) and the aggregate over all launches."""
+    import craft_amd.autograd as ag_mod
+    import craft_amd.train_encoder as te_mod
+    orig = ag_mod.call
+    evs = []
+
+    def timed(name, *args):
+        if name != "craft_conv2d_wgrad":
+            return orig(name, *args)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        orig(name, *args)
+        e.record()
+        # (x, ldx, cin, dy, ldy, cout, KH, KW, B, H, W, dW, db, ws, ws_floats, prec)
+        evs.append(((args[2], args[5], args[6], args[7], args[8], args[9], args[10]), s, e))
+    ag_mod.call = timed
+    te_orig = getattr(te_mod, "call", None)
+    if te_orig is not None:
+        te_mod.call = timed
+    try:
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        ag_mod.call = orig
+        if te_orig is not None:
+            te_mod.call = te_orig
+    if not evs:
+        return None
+    by = {}
+    for key, s, e in evs:
+        by.setdefault(key, []).append(s.elapsed_time(e))
+    flop = lambda k: 2.0 * k[4] * k[5] * k[6] * k[1] * k[0] * k[2] * k[3]      # noqa: E731
+    tot_ms = sum(sum(v) for v in by.values())
+    tot_fl = sum(flop(k) * len(v) for k, v in by.items())
+    key = max(by, key=lambda k: sum(by[k]))
+    ms = sum(by[key]) / len(by[key])
+    ach = flop(key) / (ms * 1e-3) / 1e12
+    mult = 3 if "f16x3" in policy else 1
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r3", "pmc_traffic_wgrad.json")) as fh:
+            pmc = json.load(fh)
+        if list(pmc.get("shape", [])) == list(key) and pmc.get("policy") == policy:
+            traffic = int(pmc["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
+    cin, cout, KH, KW, B, H, W = key
+    return {"bound": "mfma", "kernel": f"k_conv_wgrad (weight gradient of the {KH}x{KW} convolution {cin}->{cout} at {B}x{H}x{W}: "
+                                       f"{len(by[key]) // steps} launches per step, the launch shape with the largest total time)",
+            "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic,
+            "flops_per_launch": flop(key), "ms_per_launch": round(ms, 4), "launches_timed": len(by[key]),
+            "executed_frac": round(mult * ach / 2500.0, 4),
+            "all_wgrad_launches": {"launches_per_step": len(evs) // steps, "ms_per_step": round(tot_ms / steps, 3),
+                                   "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 1), "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / 2500.0, 4)},
+            "note": "algorithmic (fp32-equivalent) flops against the dense fp16 MFMA peak; executed_frac counts the MFMAs issued "
+                    f"({mult} per product in this policy); timed live with HIP events around every launch of real training steps"}
+
+
+def cpu_baseline_train(H, W, iters, threads, freeze_bn):
+    """The CPU oracle's training step (craft_train_forward + sequence loss + torch autograd) on ONE pair, in a subprocess."""
+    import subprocess
+    threads = threads or min(32, os.cpu_count() or 1)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--train", "--threads", str(threads), "--height", str(H),
+           "--width", str(W), "--iters", str(iters)] + (["--freeze-bn"] if freeze_bn else [])
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] cpu training baseline failed: {e!r}", file=sys.stderr)
+        return None
+
+
+def train_leg(cfg, rank, world, dev, steps, warmup, iters, B=None, H=None, W=None, policy=None, torch_encoders=False, roofline=True):
+    """Time whole training steps of BASELINE.json configs[cfg] on this rank (every rank calls it: the step contains the
+    gradient all-reduce).  -> dict (rank-0 view: aggregate pairs/s over all ranks, max-over-ranks time)."""
     from craft_amd import CRAFT, default_args
     from craft_amd.dist import aggregate_throughput, timed_steps
     from craft_amd.synth import synth_pair, synth_state_dict
     from craft_amd.train import Trainer
-    H, W, B, policy, name = {3: (368, 496, 8, "train_f16x3", "configs[3]: FlyingChairs-size 368x496, batch 8/GPU"),
-                             4: (368, 768, 4, "train_bf16attn", "configs[4]: Sintel-crop 368x768, batch 4/GPU, bf16 MFMA attention")}[a.train]
-    argv = " ".join(sys.argv[1:])
-    if "--batch" in argv:
-        B = a.batch
-    if "--height" in argv:
-        H = a.height
-    if "--width" in argv:
-        W = a.width
-    if "--precision" in argv:
-        policy = a.precision
-    model = CRAFT(default_args(hip_precision=policy, hip_encoders=not a.torch_encoders))
+    H0, W0, B0, pol0, name = TRAIN_CFG[cfg]
+    H, W, B, policy = H or H0, W or W0, B or B0, policy or pol0
+    model = CRAFT(default_args(hip_precision=policy, hip_encoders=not torch_encoders))
     model.load_state_dict(synth_state_dict(model.state_dict(), seed=1234), strict=True)
     model = model.to(dev)
-    tr = Trainer(model, lr=4e-4 if a.train == 3 else 1.25e-4, wdecay=1e-4 if a.train == 3 else 1e-5, num_steps=100000, iters=a.iters,
-                 clip=1.0, freeze_bn=a.train != 3)
+    tr = Trainer(model, lr=4e-4 if cfg == 3 else 1.25e-4, wdecay=1e-4 if cfg == 3 else 1e-5, num_steps=100000, iters=iters,
+                 clip=1.0, freeze_bn=cfg != 3)
     im1, im2, flow = synth_pair(B, H, W, seed=100 + rank)
     im1, im2, flow = im1.to(dev), im2.to(dev), flow.to(dev)
     valid = torch.ones(B, H, W, device=dev)
@@ -251,25 +328,49 @@ def train_bench(a, rank, world, dev, dist):
     def step():
         last["m"] = tr.step(im1, im2, flow, valid)
 
-    dt_rank = timed_steps(step, steps=a.steps, warmup=a.warmup, sync=torch.cuda.synchronize)
-    value, dt = aggregate_throughput(pairs_per_rank_step=B, steps=a.steps, dt=dt_rank)
+    dt_rank = timed_steps(step, steps=steps, warmup=warmup, sync=torch.cuda.synchronize)
+    value, dt = aggregate_throughput(pairs_per_rank_step=B, steps=steps, dt=dt_rank)
     assert last["m"]["loss"] == last["m"]["loss"]
+    out = {"H": H, "W": W, "B": B, "policy": policy, "name": name, "value": value, "dt": dt, "steps": steps, "warmup": warmup,
+           "loss": last["m"]["loss"], "numel": tr.optimizer.numel, "freeze_bn": cfg != 3,
+           "allreduce_ms": tr.allreduce_ms(), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)}
+    if roofline:
+        out["roofline"] = roofline_wgrad(step, policy)      # every rank runs the extra steps (they contain the collective)
+    del tr, model
+    return out
+
+
+def train_bench(a, rank, world, dev, dist):
+    """BASELINE.json configs[3] / configs[4]: whole training steps (train.py:215-236 / train_ddp.py:230-262) on synthetic
+    pairs resident in HBM.  One rank per GPU, full replica, its own pairs; the one data-path collective is the all-reduce of
+    the flat gradient buffer (RCCL over xGMI)."""
+    argv = " ".join(sys.argv[1:])
+    r = train_leg(a.train, rank, world, dev, a.steps, a.warmup, a.iters, B=a.batch if "--batch" in argv else None,
+                  H=a.height if "--height" in argv else None, W=a.width if "--width" in argv else None,
+                  policy=a.precision if "--precision" in argv else None, torch_encoders=a.torch_encoders)
+    H, W, B, policy, name = r["H"], r["W"], r["B"], r["policy"], r["name"]
+    value, dt = r["value"], r["dt"]
     if rank == 0:
-        print(json.dumps({
+        line = {
             "metric": f"training image-pairs/sec at {H}x{W}, {a.iters} iters (forward + backward + gradient all-reduce + AdamW)",
             "value": round(value, 3), "unit": "image-pairs/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak",
-            # BASELINE.md section 1 derives training throughput from the reference's own logs (ETA column; 2 unnamed GPUs,
-            # nn.DataParallel, AMP): 20.6 pairs/s at 368x496 batch 8 (logs/11 ...:651), 10.5 pairs/s at 368x768 batch 6 (logs/13 ...:709)
-            "vs_baseline": round(value / (20.6 if a.train == 3 else 10.5), 3) if (H, W) == ((368, 496) if a.train == 3 else (368, 768)) else None,
-            "baseline_note": "reference logs, derived from ETA: whole job on 2 unnamed GPUs (DataParallel + AMP)"
-                             + ("" if a.train == 3 else ", batch 6 there vs 4 per GPU here"),
+            # BASELINE.md holds no published number for this metric (its section 1 only derives 20.6 / 10.5 pairs/s from the ETA
+            # column of the reference's logs: whole job on 2 unnamed GPUs, DataParallel + AMP) -> null, the derived figure as a note
+            "vs_baseline": None,
+            "baseline_note": f"not a published number: BASELINE.md section 1 derives {20.6 if a.train == 3 else 10.5} pairs/s from the ETA "
+                             "column of the reference's own logs (whole job, 2 unnamed GPUs, DataParallel + AMP"
+                             + (")" if a.train == 3 else ", batch 6 there vs 4 per GPU here)"),
             "dtype": policy + " (fp32 activations / probabilities in HBM; MFMA operand mode per role, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": name + f", {a.iters} iters, model.train(): dropout 0.1 / 0.2, "
                                           + ("BatchNorm batch statistics" if a.train == 3 else "frozen BatchNorm")
                                           + ", synthetic weights and pairs", "global_batch": B * world,
-                       "parallelism": f"dp{world} (one all-reduce of the {tr.optimizer.numel * 4 / 1e6:.1f} MB flat gradient per step)"},
-            "loss": round(last["m"]["loss"], 4), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)}), flush=True)
+                       "parallelism": f"dp{world} (one all-reduce of the {r['numel'] * 4 / 1e6:.1f} MB flat gradient per step)"},
+            "loss": round(r["loss"], 4), "peak_mem_GB": r["peak_mem_GB"], "allreduce_ms_per_step": r["allreduce_ms"],
+            "roofline": r.get("roofline")}
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_train(H, W, a.iters, a.cpu_threads, r["freeze_bn"])
+        print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -331,6 +432,13 @@ def main():
     value, dt = aggregate_throughput(pairs_per_rank_step=a.batch, steps=a.steps, dt=dt_rank)
     assert torch.isfinite(last["out"][1]).all()
 
+    # the short training leg of the default line (every rank runs it: a training step contains the gradient all-reduce)
+    tl = None
+    if not a.no_train_leg:
+        del last["out"]
+        torch.cuda.empty_cache()
+        tl = train_leg(3, rank, world, dev, steps=5, warmup=3, iters=12)
+
     if rank == 0:
         line = {
             "metric": "image-pairs/sec at 448x1024, 12 iters",
@@ -349,6 +457,13 @@ def main():
         line["roofline_conv"] = roofline_conv(a.batch, a.height // 8, a.width // 8, prec)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.height, a.width, a.iters, a.cpu_threads)
+        if tl is not None:
+            line["train_cfg3"] = {
+                "workload": tl["name"] + ", 12 iters, whole training steps (forward + backward + gradient all-reduce + clip + AdamW), "
+                            "model.train(): dropout on, BatchNorm batch statistics; policy " + tl["policy"],
+                "ms_per_step": round(1e3 * tl["dt"] / tl["steps"], 3), "pairs_per_s": round(tl["value"], 3), "steps": tl["steps"],
+                "warmup": tl["warmup"], "n_gpus": world, "loss": round(tl["loss"], 4), "allreduce_ms_per_step": tl["allreduce_ms"],
+                "roofline": tl.get("roofline")}
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()

@@ -213,5 +213,13 @@ class SparseFlowAugmentor(FlowAugmentor):
         x0 = int(np.clip(x0, 0, ws - self.crop_size[1]))
         a = spatial(img1, self.crop_size, y0, x0, fx, fy, do_resize, hflip, False)
         b = spatial(img2, self.crop_size, y0, x0, fx, fy, do_resize, hflip, False)
-        f, v = sparse_resize_crop(flow, valid, self.crop_size, y0, x0, fx, fy, hflip)
+        if do_resize:
+            f, v = sparse_resize_crop(flow, valid, self.crop_size, y0, x0, fx, fy, hflip)
+        else:
+            # augmentor.py:301-305: without a resize the flow map is NOT rebuilt pixel by pixel (no strict x > 0 / y > 0 test, flow at
+            # invalid pixels kept as it is): h-flip (augmentor.py:307-312) and crop (:324-325) of the maps as they are
+            ch, cw = self.crop_size
+            if hflip:
+                flow, valid = flow.flip(1) * torch.tensor([-1.0, 1.0], device=flow.device), valid.flip(1)
+            f, v = flow[y0:y0 + ch, x0:x0 + cw].contiguous(), valid[y0:y0 + ch, x0:x0 + cw].contiguous()
         return a, b, f, v

@@ -2,8 +2,9 @@
 
 Inference needs no data-path collective: every rank holds a full replica (25 MB of weights) and
 processes its own pairs; only the timing protocol is collective (barrier + max over ranks).  The
-training exchange (one RCCL all-reduce of the flat 25.2 MB gradient buffer per step,
-train_ddp.py:187-200) is not built yet because backward kernels do not exist.
+training exchange lives in craft_amd/train.py: ``Trainer`` broadcasts rank 0's parameters, optimizer state and
+buffers at construction (what DDP does, train_ddp.py:196-200) and ``FlatAdamW.allreduce_grads`` is ONE RCCL
+all-reduce of the flat 25.2 MB gradient buffer per step (train_ddp.py:187-200).
 """
 from __future__ import annotations
 

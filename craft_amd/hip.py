@@ -12,6 +12,7 @@ from ctypes import c_double, c_float, c_int, c_long, c_void_p, c_char_p
 
 import torch
 
+ABI_VERSION = 2          # == CRAFT_HIP_ABI_VERSION (include/craft_hip.h): bumped whenever an existing entry point changes its signature
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 W_PACKED = 0x100
@@ -227,7 +228,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = c_int
         fn.argtypes = sig
-    if lib.craft_hip_abi_version() != 1:
+    if lib.craft_hip_abi_version() != ABI_VERSION:
         raise CraftHipError("libcraft_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -196,13 +196,19 @@ class CRAFT(nn.Module):
         if torch.is_grad_enabled() and self.training:
             # model.train() with autograd on: the differentiable composition of the same operators (craft_amd/train_forward.py,
             # backward kernels in craft_amd/autograd.py); returns what the reference returns for the requested test_mode
-            from .train_forward import forward_train
-            preds = forward_train(self, image1, image2, iters=iters, flow_init=flow_init)
-            self.call_counter += 1
             if test_mode != 0:
                 raise NotImplementedError("model.train() with gradients enabled returns the list of predictions (test_mode=0), the "
                                           "way train.py:228 calls it; use model.eval() / torch.no_grad() for test_mode 1 / 2")
+            from .train_forward import forward_train
+            preds = forward_train(self, image1, image2, iters=iters, flow_init=flow_init)
+            self.call_counter += 1
             return preds
+        if self.training:
+            # model.train() under torch.no_grad(): the reference would run dropout and BatchNorm batch statistics without a graph.
+            # The inference kernels implement neither (BatchNorm folded into the weights, no dropout), so refuse instead of
+            # silently computing something else; validation calls model.eval() first (train.py:253-262 / evaluate.py)
+            raise NotImplementedError("model.train() under torch.no_grad(): call model.eval() for inference (the inference path has no "
+                                      "dropout / batch-statistics mode), or enable gradients for a training pass")
         args = self.args
         prec = self.hip_prec()
         raw1, raw2 = image1.float().contiguous(), image2.float().contiguous()
@@ -217,7 +223,7 @@ class CRAFT(nn.Module):
         dev = image1.device
 
         with torch.no_grad():
-            use_henc = getattr(args, "hip_encoders", True) and not self.training
+            use_henc = getattr(args, "hip_encoders", True)
             # The context chain (cnet -> net / inp -> intra-frame attention -> GRU context fields) and the feature
             # chain (fnet -> F2 transformer -> correlation volume) are independent until the refinement loop: the
             # context chain is enqueued on a side stream (fork / join by events; every side-stream tensor is consumed

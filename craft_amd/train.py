@@ -161,6 +161,20 @@ class FlatAdamW:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
         return 1.0 / dist.get_world_size(group)
 
+    def broadcast_state(self, src: int = 0, group=None):
+        """Make every rank's weights and optimizer state rank ``src``'s (what torch DDP does for parameters at construction,
+        train_ddp.py:196-200; the optimizer state matters after a resume that only one rank loaded): four collectives over the
+        flat buffers."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        sc = torch.tensor([float(self.step_count)], dtype=torch.float64)
+        for t in (self.flat, self.exp_avg, self.exp_avg_sq, sc):
+            _broadcast(t, src, group)
+        self.step_count = int(sc.item())
+        from .hip import bump_weights_epoch
+        bump_weights_epoch()
+
     def step(self, lr: Optional[float] = None, max_norm: float = 0.0, grad_mul: float = 1.0):
         """One update; ``max_norm`` > 0 applies clip_grad_norm_(params, max_norm) (train.py:234) without a host sync."""
         self._check_views()
@@ -215,6 +229,23 @@ class FlatAdamW:
         self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
 
 
+def _broadcast(t: torch.Tensor, src: int, group=None):
+    """dist.broadcast in place; under gloo a device tensor is staged through the host (test configuration: several ranks share
+    one GPU), RCCL ("nccl") broadcasts device memory directly; a host tensor under nccl travels through the device."""
+    import torch.distributed as dist
+    backend = dist.get_backend(group)
+    if backend == "gloo" and t.is_cuda:
+        host = t.cpu()
+        dist.broadcast(host, src, group=group)
+        t.copy_(host)
+    elif backend == "nccl" and not t.is_cuda:
+        d = t.cuda()
+        dist.broadcast(d, src, group=group)
+        t.copy_(d.cpu())
+    else:
+        dist.broadcast(t, src, group=group)
+
+
 def unused_parameters(model: torch.nn.Module) -> List[torch.nn.Parameter]:
     """Parameters that exist for state-dict parity but never enter the forward pass: the attn_softaggr of an attention that
     returns probabilities (the intra-frame attention ``att``: setrans.py:455-458 creates it whenever num_modes > 1, the
@@ -259,9 +290,35 @@ class Trainer:
         self.clip, self.gamma, self.iters, self.add_noise, self.freeze_bn, self.group = clip, gamma, iters, add_noise, freeze_bn, group
         self.reference_loss_scaling = reference_loss_scaling
         self.total_steps = 0
+        self._ar_events = []                # (start, end) HIP events around the gradient all-reduce of recent steps
         model.train()
         if freeze_bn:
             model.freeze_bn()
+        self.sync_replicas()
+
+    def sync_replicas(self, src: int = 0):
+        """Rank ``src``'s parameters, optimizer state and module buffers on every rank.  torch DDP broadcasts parameters and buffers
+        at construction and (broadcast_buffers=True, the default train_ddp.py:198-200 runs with) the buffers again before every
+        forward -- cnet's BatchNorm running statistics are rank 0's everywhere.  Called here at construction; call it again after
+        a checkpoint was loaded on one rank; ``sync_buffers`` alone before a validation pass (train_ddp.py's val_freq)."""
+        if self._world() > 1:
+            self.optimizer.broadcast_state(src, self.group)
+            self.sync_buffers(src)
+
+    def sync_buffers(self, src: int = 0):
+        """BatchNorm running statistics (and every other module buffer) of rank ``src`` on all ranks: DDP's broadcast_buffers.
+        The training forward in batch-statistics mode does not read them, so once per validation interval is enough."""
+        if self._world() > 1:
+            for b in self.model.buffers():
+                if b.is_floating_point() or b.dtype in (torch.int64, torch.int32):
+                    _broadcast(b, src, self.group)
+
+    def allreduce_ms(self) -> Optional[float]:
+        """Mean device time of the gradient all-reduce over the recorded steps (None: single process / nothing recorded)."""
+        ev = [(s, e) for s, e in self._ar_events if e.query()]
+        if not ev:
+            return None
+        return round(sum(s.elapsed_time(e) for s, e in ev) / len(ev), 4)
 
     def _world(self) -> int:
         import torch.distributed as dist
@@ -287,7 +344,14 @@ class Trainer:
         from .autograd import pending_uses
         if pending_uses(model.__dict__.get("_train_pass_cache")):
             raise RuntimeError("backward left accumulated weight gradients incomplete (a layer call was pruned from the graph)")
+        timed = self._world() > 1 and opt.flat_grad.is_cuda
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         mul = opt.allreduce_grads(self.group)                          # ONE collective over the flat gradient buffer
+        if timed:
+            ev1.record()
+            self._ar_events = (self._ar_events + [(ev0, ev1)])[-64:]
         if self.reference_loss_scaling:
             mul = mul / self._world()
         opt.step(lr=self.scheduler.get_last_lr()[0], max_norm=self.clip, grad_mul=mul)
@@ -321,7 +385,8 @@ def load_checkpoint(path: str, model: torch.nn.Module, optimizer: Optional[FlatA
                     lr_scheduler: Optional[OneCycleLR] = None, load_optimizer_state: bool = False, load_scheduler_state: bool = False,
                     trusted: bool = False):
     """New dict layout or legacy bare state dict, strict=False; optimizer / scheduler only on request (train.py:147-175,
-    --loadopt / --loadsched)."""
+    --loadopt / --loadsched).  Data-parallel: either every rank loads the same file, or one rank does and then calls
+    ``Trainer.sync_replicas(src)``."""
     from .utils import load_checkpoint as load_model, read_checkpoint
     ck = read_checkpoint(path, trusted=trusted)
     msg = load_model(model, ck)

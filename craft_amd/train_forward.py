@@ -23,6 +23,31 @@ from . import train_encoder as TE
 from .hip import ACT_NONE, ACT_RELU, ACT_TANH, PREC_BF16, PREC_F16
 
 
+_warned_promote = []
+
+
+def training_precision(prec):
+    """The operand modes a training pass runs in.  Plain fp16 MFMA operands are refused by promotion: the reference's fp16
+    autocast training relies on GradScaler (train.py:215,231-238), which is not built here -- unscaled gradients (~3e-7 per
+    pixel at 368x496, batch 8) sit in fp16's subnormal / flush range and would degrade silently in dP = dO V^T, dV = P^T dO and the
+    convolution gradients.  Every role that asks for fp16 (e.g. ``pv`` of the inference default "mixed", which
+    args.mixed_precision=True selects) runs in f16x3 instead: fp32-class results, same fp16 MFMA pipe.  bf16 roles keep bf16
+    (fp32's exponent range: no scaling needed)."""
+    from .hip import PREC_F16X3, Precision
+    roles = [r for r in Precision.__slots__ if getattr(prec, r) == PREC_F16]
+    if not roles:
+        return prec
+    if not _warned_promote:
+        _warned_promote.append(1)
+        import warnings
+        warnings.warn(f"craft_amd training: fp16 operand mode of role(s) {roles} promoted to f16x3 (no loss scaling is built; "
+                      "use a bf16 policy such as train_amp_bf16 for 16-bit MFMA operands)")
+    out = Precision(prec.proj, prec.score, prec.pv, prec.conv, prec.enc)
+    for r in roles:
+        setattr(out, r, PREC_F16X3)
+    return out
+
+
 def _attention_probs(module, x_ln, hw, prec, p_attn: float, seed: int):
     """CrossAttFeatTrans up to (and including) the dropout of the probabilities (setrans.py:507-557) -> P [B, M, N, ld]."""
     st = module.setrans
@@ -50,7 +75,9 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
         raise NotImplementedError("--f2 none: the reference's own constructor fails without the F2 transformer (network.py:93-106)")
     if not args.use_setrans and (getattr(args, "position_only", False) or getattr(args, "position_and_content", False)):
         raise NotImplementedError("training GMA's relative-position scores (RelPosEmb) is not built; they run in inference")
-    prec = model.hip_prec()
+    if not args.use_setrans and (model.att.heads != 1 or getattr(model.update_block.aggregator, "project", None) is not None):
+        raise NotImplementedError("training gma.Aggregate with num_heads > 1 (head merge + project, gma.py:133-137) is not built")
+    prec = training_precision(model.hip_prec())
     B, _, H, W = image1.shape
     if H % 8 or W % 8:
         raise ValueError("image height and width must be multiples of 8")
@@ -73,9 +100,7 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
     # ---- CNN encoders (network.py:169-183, :203) -----------------------------------------------------------------------
     # default: on the HIP kernels in the policy's `enc` operand mode (craft_amd/train_encoder.py).  args.hip_encoders=False keeps the
     # PyTorch-ROCm modules under torch autograd -- with enc = bf16 under autocast, like the reference's mixed-precision training
-    # (network.py:179,199); enc = fp16 would need the reference's GradScaler and is refused
-    if prec.enc == PREC_F16:
-        raise NotImplementedError("training: enc=fp16 needs loss scaling; use enc=bf16 (autocast) or an fp32-class mode")
+    # (network.py:179,199); fp16 roles were promoted to f16x3 above (training_precision): no loss scaling is built
     H, W = image1.shape[-2:]
     use_henc = getattr(args, "hip_encoders", True) and TE.supported(model.fnet, H, W) and TE.supported(model.cnet, H, W)
     if use_henc:

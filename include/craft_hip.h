@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CRAFT_HIP_ABI_VERSION 1
+#define CRAFT_HIP_ABI_VERSION 2
 
 #define CRAFT_PREC_F32 0
 #define CRAFT_PREC_BF16 1

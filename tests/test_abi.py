@@ -27,7 +27,9 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name, _ in fns:
         assert hasattr(lib, name), f"{name} declared in craft_hip.h but not exported by libcraft_hip.so"
     lib.craft_hip_abi_version.restype = ctypes.c_int
-    assert lib.craft_hip_abi_version() == 1
+    from craft_amd import hip
+    header_version = int(re.search(r"#define\s+CRAFT_HIP_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert lib.craft_hip_abi_version() == hip.ABI_VERSION == header_version >= 2
     lib.craft_hip_error_string.restype = ctypes.c_char_p
     assert b"alignment" in lib.craft_hip_error_string(10002)
 

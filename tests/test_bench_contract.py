@@ -32,6 +32,58 @@ def test_single_gpu_line(device):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "workload" in d["config"]
+    # the short configs[3] training leg rides on the default line (always at its own shape: 368x496, batch 8)
+    t3 = d["train_cfg3"]
+    assert t3["ms_per_step"] > 0 and t3["pairs_per_s"] > 0 and t3["steps"] == 5 and "368x496" in t3["workload"]
+    rw = t3["roofline"]
+    assert rw["bound"] == "mfma" and rw["unit"] == "TFLOP/s" and abs(rw["frac"] - rw["achieved"] / rw["peak"]) < 1e-3
+    assert abs(rw["achieved"] - rw["flops_per_launch"] / (rw["ms_per_launch"] * 1e-3) / 1e12) / rw["achieved"] < 0.02
+
+
+def test_training_line(device):
+    """`bench.py --train 3` (reduced shape): the same contract keys, roofline of the weight-gradient kernel, the CPU oracle's
+    training step as cpu_baseline, vs_baseline null (BASELINE.md publishes no number for this metric)."""
+    r = subprocess.run([sys.executable, "bench.py", "--train", "3", "--steps", "2", "--warmup", "1", "--batch", "2", "--height", "128",
+                        "--width", "160", "--iters", "2"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["value"] > 0 and d["vs_baseline"] is None and d["loss"] == d["loss"]
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["launches_timed"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and "backward" in cb["sample"]
+
+
+def _backends():
+    import torch
+    return ["gloo"] + (["nccl"] if torch.cuda.device_count() >= 2 else [])
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_rank_training_launch_path(device, backend):
+    """`bench.py --train 3 --gpus 2`: two ranks, one gradient all-reduce per step.  gloo: ranks share the GPU (host-staged
+    all-reduce); nccl: RCCL with one rank per GPU (skipped on a 1-GPU box) -- the first execution of the device all-reduce."""
+    if backend not in _backends():
+        pytest.skip("needs >= 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["CRAFT_BENCH_BACKEND"] = backend
+    r = subprocess.run([sys.executable, "bench.py", "--train", "3", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1",
+                        "--height", "128", "--width", "160", "--iters", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and d["value"] > 0 and "cpu_baseline" not in d
+    assert d["allreduce_ms_per_step"] is not None and d["allreduce_ms_per_step"] > 0
+
+
+def test_two_rank_inference_nccl(device):
+    """The inference launch path under RCCL with one rank per GPU (skipped on a 1-GPU box)."""
+    if "nccl" not in _backends():
+        pytest.skip("needs >= 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CRAFT_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1", "--height", "128",
+                        "--width", "256", "--iters", "2", "--no-train-leg"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and d["value"] > 0
 
 
 def test_two_rank_launch_path(device):
@@ -42,7 +94,7 @@ def test_two_rank_launch_path(device):
     env = dict(os.environ, CRAFT_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1", "--height", "128",
-           "--width", "256", "--iters", "2"]
+           "--width", "256", "--iters", "2", "--no-train-leg"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
@@ -56,7 +108,7 @@ def test_self_launch_gpus_flag(device):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["CRAFT_BENCH_BACKEND"] = "gloo"
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1", "--height", "128",
-                        "--width", "256", "--iters", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                        "--width", "256", "--iters", "2", "--no-train-leg"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and d["value"] > 0

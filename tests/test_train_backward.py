@@ -8,7 +8,7 @@
    captured from the imported reference (tests/golden/train_*.npz, tools/make_golden_train.py; dropout forced to 0 there and
    here): fp32 policy: relative L2 error of every gradient <= 1e-2 (measured: update block 2e-4 .. 1e-3, attention / correlation
    parameters <= 3e-3, the encoders -- whose backward is MIOpen's, fed by our d fmap -- <= 5.6e-3) and the loss to 3e-5
-   (SURVEY H': "loss value & selected grads"); mixed policy (fp16 P.V): <= 8e-2.
+   (SURVEY H': "loss value & selected grads"); "mixed" (fp16 roles promoted to f16x3 in training): <= 2e-2.
 4. Dropout: keep rate, scaling, determinism per seed, identical mask in forward and backward.
 """
 import json
@@ -328,7 +328,7 @@ def test_training_step_matches_reference_gradients(device, case, precision):
     loss, metrics = AG.sequence_loss(preds, torch.from_numpy(z["flow_gt"]), torch.from_numpy(z["valid"]), meta["gamma"])
     loss.backward()
     tight = precision == "fp32"
-    assert float(loss) == pytest.approx(float(z["loss"]), rel=3e-5 if tight else 3e-4)
+    assert float(loss) == pytest.approx(float(z["loss"]), rel=3e-5 if tight else 1e-4)
     assert [metrics["epe"], metrics["1px"], metrics["3px"], metrics["5px"]] == pytest.approx(z["metrics"].tolist(), rel=1e-3, abs=1e-4)
     unused = set(json.loads(str(z["unused"])))
     seen, checked, worst = set(), 0, 0.0
@@ -349,7 +349,9 @@ def test_training_step_matches_reference_gradients(device, case, precision):
         # 1.7 % (canonical case) to 8.5 % (GMA case), while run-to-run it repeats to 1e-6 and with MIOpen's encoders it lands within
         # 1e-5 of the float64 value -- an ill-conditioned number, not a summation-order or kernel issue.  Ten times the bound there.
         mul = 10.0 if p.numel() == 1 else 1.0
-        worst = max(worst, grad_check_l2(z, k, p.grad, l2_tol=mul * (1e-2 if tight else 8e-2), elem_tol=mul * (0.15 if tight else 0.6)))
+        # "mixed" (what args.mixed_precision=True selects) trains with its fp16 roles promoted to f16x3 (train_forward.training_precision:
+        # no loss scaling is built): fp32-class, measured <= 5e-3 relative L2 -> 2e-2
+        worst = max(worst, grad_check_l2(z, k, p.grad, l2_tol=mul * (1e-2 if tight else 2e-2), elem_tol=mul * (0.15 if tight else 0.3)))
         checked += 1
     assert checked == len({id(p) for k, p in model.named_parameters() if not k.startswith("corr_fn.setrans.key.")}) - len(unused) and checked >= 130
     print(f"[train parity] {case} {precision}: loss {float(loss):.6f} (reference {float(z['loss']):.6f}), worst relative L2 gradient error {worst:.2e}")
@@ -393,19 +395,27 @@ def test_train_mode_rejects_other_configs_and_sizes(device):
     model = CRAFT(default_args(hip_precision="fp32")).to(device).train()
     with pytest.raises(ValueError, match="multiple of 4"):
         model(torch.zeros(1, 3, 136, 200, device=device), torch.zeros(1, 3, 136, 200, device=device), iters=1)
+    with torch.no_grad(), pytest.raises(NotImplementedError, match="model.eval"):     # train mode without a graph: refused, not eval-ed
+        model(torch.zeros(1, 3, 128, 128, device=device), torch.zeros(1, 3, 128, 128, device=device), iters=1)
+    with pytest.raises(NotImplementedError, match="test_mode"):
+        model(torch.zeros(1, 3, 128, 128, device=device), torch.zeros(1, 3, 128, 128, device=device), iters=1, test_mode=1)
     for over in (dict(f1trans="shared"), dict(use_setrans=False, position_and_content=True)):       # inference-only variants
         other = CRAFT(default_args(**over)).to(device).train()
         with pytest.raises(NotImplementedError):
             other(torch.zeros(1, 3, 128, 128, device=device), torch.zeros(1, 3, 128, 128, device=device), iters=1)
 
 
-@pytest.mark.parametrize("B,H,W,iters,freeze_bn", [(2, 368, 496, 2, False), (1, 368, 768, 1, True)])
-def test_training_step_at_configs3_size_against_oracle(device, B, H, W, iters, freeze_bn):
+@pytest.mark.parametrize("B,H,W,iters,freeze_bn,policy", [(2, 368, 496, 2, False, "fp32"), (1, 368, 768, 1, True, "fp32"),
+                                                          # the full refinement depth of the benchmarked step (12 iterations: the
+                                                          # per-pass gradient accumulators see all 12 uses, the deferred dP product
+                                                          # has K = 12 * 128) in the policy bench.py --train 3 times
+                                                          (2, 368, 496, 12, False, "train_f16x3")])
+def test_training_step_at_configs3_size_against_oracle(device, B, H, W, iters, freeze_bn, policy):
     """BASELINE configs[3] shape (368x496 -> 46x62 tokens, odd pooling sizes 23 / 11 / 5; batch 2 with BatchNorm batch statistics,
     2 iterations) and configs[4] shape (368x768 -> 46x96 tokens, frozen BatchNorm), fp32 policy: loss and every parameter gradient
     of the HIP step against torch autograd over the CPU oracle (which tests/test_oracle_train_golden.py pins to the reference)."""
     from craft_amd.synth import synth_pair
-    model = CRAFT(default_args(hip_precision="fp32", dropout_prob=0.0))
+    model = CRAFT(default_args(hip_precision=policy, dropout_prob=0.0))
     sd0 = synth_state_dict(model.state_dict(), seed=77)
     model.load_state_dict(sd0, strict=True)
     model = model.to(device).train()
@@ -442,4 +452,46 @@ def test_training_step_at_configs3_size_against_oracle(device, B, H, W, iters, f
         assert l2 < 1e-2, f"{k}: relative L2 error {l2:.2e}"
         worst, checked = max(worst, l2), checked + 1
     assert checked > 100
-    print(f"[train parity] {H}x{W} B={B}: loss {float(loss):.6f} vs oracle {float(loss_r):.6f}; worst relative L2 gradient error {worst:.2e} over {checked} parameters")
+    print(f"[train parity] {H}x{W} B={B} T={iters} {policy}: loss {float(loss):.6f} vs oracle {float(loss_r):.6f}; worst relative L2 gradient error {worst:.2e} over {checked} parameters")
+
+
+def test_bf16attn_step_at_configs4_shape_against_fp32_step(device):
+    """BASELINE configs[4] at its own shape and batch (368x768, batch 4, 12 iterations, frozen BatchNorm) in the policy
+    `bench.py --train 4` times -- bf16 MFMA operands for Q.K^T / P.V and their gradients -- against the fp32-class HIP step
+    (train_f16x3, which the test above holds to the oracle at this image size) on the same weights and pairs, dropout 0.
+    Bounds: loss 1e-4 relative; per-parameter gradient relative L2 <= 2x the figures measured on the MI355X (printed)."""
+    from craft_amd.synth import synth_pair
+    B, H, W, iters = 4, 368, 768, 12
+    im1, im2, flow = synth_pair(B, H, W, seed=47)
+    valid = torch.ones(B, H, W)
+    out = {}
+    for policy in ("train_f16x3", "train_bf16attn"):
+        model = CRAFT(default_args(hip_precision=policy, dropout_prob=0.0))
+        model.load_state_dict(synth_state_dict(model.state_dict(), seed=78), strict=True)
+        model = model.to(device).train()
+        model.freeze_bn()
+        preds = model(im1.to(device), im2.to(device), iters=iters)
+        loss, _ = AG.sequence_loss(preds, flow, valid, 0.8)
+        loss.backward()
+        out[policy] = (float(loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+        del model, preds, loss
+        torch.cuda.empty_cache()
+    (l_ref, g_ref), (l_bf, g_bf) = out["train_f16x3"], out["train_bf16attn"]
+    assert l_bf == pytest.approx(l_ref, rel=1e-4)
+    rms = sorted(float(g.pow(2).mean().sqrt()) for g in g_ref.values())
+    scale = rms[len(rms) // 2]
+    worst, worst_k, n = 0.0, None, 0
+    for k, g in g_ref.items():
+        if g.numel() == 1 or float(g.pow(2).mean().sqrt()) < 1e-4 * scale:
+            continue
+        assert torch.isfinite(g_bf[k]).all(), k
+        l2 = float((g_bf[k] - g).norm() / g.norm())
+        if l2 > worst:
+            worst, worst_k = l2, k
+        n += 1
+    print(f"[train parity] configs[4] shape, train_bf16attn vs train_f16x3: loss {l_bf:.6f} vs {l_ref:.6f}; worst relative L2 gradient "
+          f"error {worst:.3e} ({worst_k}) over {n} parameters")
+    assert n > 100 and worst <= BF16ATTN_L2_BOUND
+
+
+BF16ATTN_L2_BOUND = 0.3      # 2x the measured worst case goes here once measured on the box (see the test's print)

@@ -106,13 +106,21 @@ WORKER = textwrap.dedent("""
     from craft_amd.train import Trainer
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
+    backend = os.environ.get("CRAFT_TEST_BACKEND", "gloo")
     if world > 1:
-        dist.init_process_group("gloo", init_method="env://")
-    dev = torch.device("cuda:0")
+        dist.init_process_group(backend, init_method="env://")
+    # gloo: both ranks share GPU 0 (1-GPU box); nccl (= RCCL): one rank per GPU, the gradient all-reduce runs on the devices
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
     model = CRAFT(default_args(hip_precision="fp32", dropout_prob=0.0))
-    model.load_state_dict(synth_state_dict(model.state_dict(), seed=1234), strict=True)
+    # rank 1 starts from DIFFERENT weights and BatchNorm statistics: Trainer must bring rank 0's over (DDP's construction broadcast)
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=1234 + 77 * rank), strict=True)
     model = model.to(dev)
     tr = Trainer(model, lr=2e-4, num_steps=50, iters=2, clip=1.0, freeze_bn=True)
+    if world > 1:
+        ref = synth_state_dict(model.state_dict(), seed=1234)
+        for k, v in model.state_dict().items():
+            assert torch.equal(v.cpu(), ref[k].to(v.dtype)), "rank %%d: %%s is not rank 0's after Trainer()" %% (rank, k)
     im1, im2, flow = synth_pair(2, 128, 160, seed=9)
     valid = torch.ones(2, 128, 160)
     sl = slice(rank, rank + 1) if world > 1 else slice(0, 2)
@@ -127,14 +135,20 @@ WORKER = textwrap.dedent("""
 """)
 
 
-def test_two_rank_data_parallel_equals_one_process_on_both_pairs(device, tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_rank_data_parallel_equals_one_process_on_both_pairs(device, tmp_path, backend):
+    """Two data-parallel ranks (one pair each) against one process that trains on both pairs.  "gloo": the ranks share the box's
+    GPU and the flat gradient is staged through the host.  "nccl": RCCL, one rank per GPU, the all-reduce of train_ddp.py:187-200 on
+    the devices -- needs two GPUs, skipped on a 1-GPU box."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL data-parallel test needs >= 2 GPUs")
     script = tmp_path / "worker.py"
     script.write_text(WORKER % ROOT)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = str(sk.getsockname()[1])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2", CRAFT_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", port, str(script), str(tmp_path / "dp.pt")], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
