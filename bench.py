@@ -230,25 +230,38 @@ TRAIN_CFG = {3: (368, 496, 8, "train_f16x3", "configs[3]: FlyingChairs-size 368x
 
 
 def roofline_wgrad(step, policy, steps=2):
-    """The dominant kernel of the backward pass, k_conv_wgrad (convolution weight gradients: per tap a cout x cin product over
-    K = all pixels), timed LIVE: HIP events around every craft_conv2d_wgrad call of `steps` real training steps (events on the
-    launch stream).  Algorithmic flops per launch = 2 * pixels * cout * cin * KH * KW from the launch's own arguments.  Reported:
-    the launch shape with the largest total time (`kernel`, per-launch numbers) and the aggregate over all launches."""
+    """The dominant kernel family of the backward pass, the convolution weight gradients (per tap a cout x cin product over K = all
+    pixels: k_gemm_pk on packed operands, craft_wgrad_pk; k_conv_wgrad in the fp32 policy), timed LIVE: HIP events around every launch
+    of `steps` real training steps (events on the launch stream).  Algorithmic flops per launch = 2 * pixels * calls * cout * cin *
+    KH * KW from the launch's own arguments.  Reported: the launch shape with the largest total time (`kernel`, per-launch numbers)
+    and the aggregate over all weight-gradient launches."""
     import craft_amd.autograd as ag_mod
     import craft_amd.train_encoder as te_mod
-    orig = ag_mod.call
+    orig_call, orig_pk = ag_mod.call, ag_mod.wgrad_pk
     evs = []
 
-    def timed(name, *args):
+    def ev_pair():
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(name, *args):                    # round-2 kernel (fp32 policy, odd channel counts): one launch per call
         if name != "craft_conv2d_wgrad":
-            return orig(name, *args)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            return orig_call(name, *args)
+        s, e = ev_pair()
         s.record()
-        orig(name, *args)
+        orig_call(name, *args)
         e.record()
         # (x, ldx, cin, dy, ldy, cout, KH, KW, B, H, W, dW, db, ws, ws_floats, prec)
-        evs.append(((args[2], args[5], args[6], args[7], args[8], args[9], args[10]), s, e))
-    ag_mod.call = timed
+        evs.append((("k_conv_wgrad", args[2], args[5], args[6], args[7], args[8] * args[9] * args[10], 1), s, e))
+
+    def timed_pk(pairs, KH, KW, acc):          # packed-operand kernel: ONE launch over the calls of a layer in the pass
+        pairs = [pairs] if isinstance(pairs, tuple) else pairs
+        s, e = ev_pair()
+        s.record()
+        orig_pk(pairs, KH, KW, acc)
+        e.record()
+        gp, xp = pairs[0]
+        evs.append((("k_gemm_pk", xp.C, gp.C, KH, KW, gp.rows, len(pairs)), s, e))
+    ag_mod.call, ag_mod.wgrad_pk = timed, timed_pk
     te_orig = getattr(te_mod, "call", None)
     if te_orig is not None:
         te_mod.call = timed
@@ -257,7 +270,7 @@ def roofline_wgrad(step, policy, steps=2):
             step()
         torch.cuda.synchronize()
     finally:
-        ag_mod.call = orig
+        ag_mod.call, ag_mod.wgrad_pk = orig_call, orig_pk
         if te_orig is not None:
             te_mod.call = te_orig
     if not evs:
@@ -265,24 +278,26 @@ def roofline_wgrad(step, policy, steps=2):
     by = {}
     for key, s, e in evs:
         by.setdefault(key, []).append(s.elapsed_time(e))
-    flop = lambda k: 2.0 * k[4] * k[5] * k[6] * k[1] * k[0] * k[2] * k[3]      # noqa: E731
+    flop = lambda k: 2.0 * k[5] * k[6] * k[1] * k[2] * k[3] * k[4]      # noqa: E731   (2 * pixels * calls * cin * cout * taps)
     tot_ms = sum(sum(v) for v in by.values())
     tot_fl = sum(flop(k) * len(v) for k, v in by.items())
     key = max(by, key=lambda k: sum(by[k]))
     ms = sum(by[key]) / len(by[key])
     ach = flop(key) / (ms * 1e-3) / 1e12
-    mult = 3 if "f16x3" in policy else 1
+    from craft_amd.hip import PREC_F16X3, Precision
+    mult = 3 if Precision.parse(policy).conv == PREC_F16X3 else 1
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r3", "pmc_traffic_wgrad.json")) as fh:
             pmc = json.load(fh)
-        if list(pmc.get("shape", [])) == list(key) and pmc.get("policy") == policy:
+        if list(pmc.get("shape", [])) == list(key[1:]) and pmc.get("kernel") == kern and pmc.get("policy") == policy:
             traffic = int(pmc["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         pass
-    cin, cout, KH, KW, B, H, W = key
-    return {"bound": "mfma", "kernel": f"k_conv_wgrad (weight gradient of the {KH}x{KW} convolution {cin}->{cout} at {B}x{H}x{W}: "
-                                       f"{len(by[key]) // steps} launches per step, the launch shape with the largest total time)",
+    kern, cin, cout, KH, KW, rows, calls = key
+    return {"bound": "mfma", "kernel": f"{kern} (weight gradient of the {KH}x{KW} convolution {cin}->{cout} over {rows} pixels x {calls} "
+                                       f"call(s) of the layer per launch: {len(by[key]) // steps} launch(es) per step, the launch shape with "
+                                       "the largest total time; operand packing not included)",
             "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic,
             "flops_per_launch": flop(key), "ms_per_launch": round(ms, 4), "launches_timed": len(by[key]),
             "executed_frac": round(mult * ach / 2500.0, 4),

@@ -197,15 +197,23 @@ class Linear(Function):
             dx = torch.empty(B, N, Cin, device=x.device, dtype=torch.float32)
             # dX = dY . W : A = dY rows (k = cout contiguous), B(n = ci, k = co) = W[co][ci] k-major
             gemm(dy, dy.stride(-2), 1, 0, 0, w, 1, Cin, 0, 0, dx, Cin, 0, 0, 1, 1, rows, Cin, Cout, prec=pp)
-        if ctx.needs_input_grad[1]:
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        accb = _acc_buffer(cache, wobj, "db", (Cout,), x.device)[0] if want_db else None
+        pk = _use_pk(pp) and ctx.needs_input_grad[1] and Cin % 4 == 0 and Cout % 4 == 0
+        if pk:
+            co_p, ci_p = round_up(Cout, 32), round_up(Cin, 32)
+            acc, _ = _acc_buffer(cache, wobj, "dw", (co_p, ci_p), x.device)
+            _wgrad_deferred(cache, wobj, last, (Packed(dy, pp, colsum=accb), Packed(x, pp)), 1, 1, acc)
+            dw = acc[:Cout, :Cin] if last else None
+        elif ctx.needs_input_grad[1]:
             acc, _ = _acc_buffer(cache, wobj, "dw", (Cout, Cin), x.device)
             # dW = dY^T . X : both operands k-major over the rows, split-K
             gemm(dy, 1, dy.stride(-2), 0, 0, x, 1, x.stride(-2), 0, 0, acc, Cin, 0, 0, 1, 1, Cout, Cin, rows, accumulate=True, ksplit=0, prec=pp)
             dw = acc if last else None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            acc, _ = _acc_buffer(cache, wobj, "db", (Cout,), x.device)
-            call("craft_colsum", dy, dy.stride(-2), rows, Cout, acc)
-            db = acc if last else None
+        if want_db:
+            if not pk:
+                call("craft_colsum", dy, dy.stride(-2), rows, Cout, accb)
+            db = accb if last else None
         return dx, dw, db, None, None
 
 
@@ -566,11 +574,77 @@ def _conv_weights(w, b, cp, cache, transposed: bool):
     return out
 
 
+class Packed:
+    """A tokens tensor as a packed MFMA operand (craft_pack_operand): 16-bit planes [plane][C/32][rows_p][32] over a zero-padded
+    pixel grid, so that a convolution tap is one row shift and the weight-gradient K loop is a pure copy (kernels_gemm_pk.hip)."""
+    __slots__ = ("buf", "rows_p", "guard", "K", "C_p", "prec", "Wp", "rows", "C")
+
+    def __init__(self, x: torch.Tensor, prec: int, spatial=None, colsum=None):
+        """x [.., C] tokens (unit channel stride, uniform row stride); spatial = (B, H, W, padH, padW) or None (plain rows)."""
+        C = x.shape[-1]
+        rows = x.numel() // C
+        self.rows, self.C = rows, C
+        if spatial is not None:
+            B, H, W, ph, pw = spatial
+            grid = B * (H + 2 * ph) * (W + 2 * pw)
+            self.Wp = W + 2 * pw
+            self.guard = ph * self.Wp + pw
+        else:
+            B = H = W = ph = pw = 0
+            grid, self.Wp, self.guard = rows, 1, 0
+        self.K = round_up(grid, 32)
+        self.rows_p = round_up(2 * self.guard + self.K, 64)
+        self.C_p, self.prec = round_up(C, 32), prec
+        planes = 2 if prec == hip.PREC_F16X3 else 1
+        self.buf = torch.empty(planes * (self.C_p // 32) * self.rows_p * 32, device=x.device, dtype=torch.int16)
+        call("craft_pack_operand", x, x.stride(-2), C, rows, B, H, W, ph, pw, self.guard, self.rows_p, prec, self.buf, colsum)
+
+
+def wgrad_pk(pairs, KH: int, KW: int, acc: torch.Tensor):
+    """acc[cout_p][KH][KW][cin_p] += sum over the (dY pack, X pack) pairs of dY^T X (craft_wgrad_pk: ONE launch over the concatenated K)."""
+    import ctypes
+    if isinstance(pairs, tuple):
+        pairs = [pairs]
+    gp, xp = pairs[0]
+    for g2, x2 in pairs:
+        assert (g2.K, g2.guard, g2.prec, g2.rows_p, g2.C_p, g2.Wp) == (gp.K, gp.guard, gp.prec, gp.rows_p, gp.C_p, gp.Wp)
+        assert (x2.K, x2.guard, x2.prec, x2.rows_p, x2.C_p) == (gp.K, gp.guard, gp.prec, xp.rows_p, xp.C_p)
+    n = len(pairs)
+    ga = (ctypes.c_void_p * n)(*[g2.buf.data_ptr() for g2, _ in pairs])
+    xa = (ctypes.c_void_p * n)(*[x2.buf.data_ptr() for _, x2 in pairs])
+    call("craft_wgrad_pk", ga, xa, n, gp.rows_p, gp.C_p, xp.rows_p, xp.C_p, gp.guard, gp.K, KH, KW, gp.Wp, acc, gp.prec)
+
+
+def _wgrad_deferred(cache, wobj, last: bool, pair, KH: int, KW: int, acc: torch.Tensor):
+    """Weight gradient of a layer that runs several times per pass (the update block: once per refinement iteration): the packed
+    (dY, X) pairs of its calls are queued and the LAST backward call launches one product over all of them -- K = calls x pixels,
+    one split-K atomic epilogue and one launch per pass instead of one per call (the epilogue was a third of a per-call launch)."""
+    if cache is None:
+        wgrad_pk([pair], KH, KW, acc)
+        return
+    k = (id(wobj), "pk_pending")
+    cache.setdefault(k, []).append(pair)
+    if last:
+        wgrad_pk(cache.pop(k), KH, KW, acc)
+
+
+def _use_pk(prec: int) -> bool:
+    return prec != hip.PREC_F32 and not _NO_PK
+
+
+import os as _os
+_NO_PK = bool(_os.environ.get("CRAFT_NO_PK"))      # developer A/B: the round-2 weight-gradient kernels
+
+
 def _conv_wgrad(xp, g, B, H8, W8, cin_p, cout_p, KH, KW, prec, db=None) -> torch.Tensor:
     """dW[co][ky][kx][ci] += sum_pix dY[pix][co] X[pix + tap][ci] (craft_conv2d_wgrad; split-K partial sums added with fp32 atomics:
     measured equal to the scratch + reduction form, one kernel less)."""
     dw = torch.zeros(cout_p, KH, KW, cin_p, device=xp.device, dtype=torch.float32)
-    call("craft_conv2d_wgrad", xp, xp.stride(-2), cin_p, g, g.stride(-2), cout_p, KH, KW, B, H8, W8, dw, db, None, 0, prec)
+    if _use_pk(prec) and cin_p % 32 == 0 and cout_p % 32 == 0:
+        geom = (B, H8, W8, KH // 2, KW // 2)
+        wgrad_pk([(Packed(g, prec, geom, colsum=db), Packed(xp, prec, geom))], KH, KW, dw)
+    else:
+        call("craft_conv2d_wgrad", xp, xp.stride(-2), cin_p, g, g.stride(-2), cout_p, KH, KW, B, H8, W8, dw, db, None, 0, prec)
     return dw
 
 
@@ -619,8 +693,13 @@ class Conv(Function):
         accb = _acc_buffer(cache, ctx.w, "db", (cout_p,), dev)[0] if want_db else None
         if ctx.needs_input_grad[1]:
             acc, _ = _acc_buffer(cache, ctx.w, "dw", (cout_p, KH, KW, cin_p), dev)
-            # (the bias gradient rides on the same launch: the blocks of tap 0 add the column sums of dY)
-            call("craft_conv2d_wgrad", xp, xp.stride(-2), cin_p, g, g.stride(-2), cout_p, KH, KW, B, H8, W8, acc, accb, None, 0, ctx.prec)
+            if _use_pk(ctx.prec):
+                # packed operands (the bias gradient rides on the pack of dY)
+                geom = (B, H8, W8, KH // 2, KW // 2)
+                _wgrad_deferred(cache, ctx.w, last, (Packed(g, ctx.prec, geom, colsum=accb), Packed(xp, ctx.prec, geom)), KH, KW, acc)
+            else:
+                # (the bias gradient rides on the same launch: the blocks of tap 0 add the column sums of dY)
+                call("craft_conv2d_wgrad", xp, xp.stride(-2), cin_p, g, g.stride(-2), cout_p, KH, KW, B, H8, W8, acc, accb, None, 0, ctx.prec)
             if last:
                 dw = acc[:Cout, :, :, :Cin].permute(0, 3, 1, 2)
         elif want_db:

@@ -18,6 +18,7 @@ const Tuning& tuning() {
     v.wf_dynamic_taps = getenv("CRAFT_WF_DYNAMIC_TAPS") != nullptr;
     v.wgrad_sb = getenv("CRAFT_NO_WGRAD_SB") == nullptr;     // weight gradient with one LDS tile buffer (3 resident blocks per CU instead of 2; off: developer A/B)
     v.no_wgrad64 = getenv("CRAFT_NO_WGRAD64") != nullptr;   // weight gradient of 64-channel layers on the generic 128-row tile (developer A/B)
+    if (const char* e = getenv("CRAFT_PK_MODE")) v.pk_mode = atoi(e);      // ablations of k_gemm_pk (developer): 1 no DMA after tile 0, 2 no epilogue, 4 no MFMA phase
     return v;
   }();
   return t;
@@ -419,6 +420,14 @@ int craft_gemm(const float* A, long a_sm, long a_sk, long a_bs0, long a_bs1, con
 int craft_conv2d_wgrad(const float* x, long ldx, int cin, const float* dy, long ldy, int cout, int KH, int KW, int B, int H, int W,
                        float* dW, float* db, float* ws, long ws_floats, int prec, void* stream) {
   return launch_conv_wgrad(x, ldx, cin, dy, ldy, cout, KH, KW, B, H, W, dW, db, ws, ws_floats, prec, S(stream));
+}
+int craft_pack_operand(const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
+                       int prec, void* out, float* colsum, void* stream) {
+  return launch_pack_operand(x, ldx, C, rows, B, H, W, padH, padW, guard, rows_p, prec, out, colsum, S(stream));
+}
+int craft_wgrad_pk(const void* const* dYp, const void* const* Xp, int nseg, long dy_rows_p, int cout, long x_rows_p, int cin, long guard, long K,
+                   int KH, int KW, int Wp, float* dW, int prec, void* stream) {
+  return launch_wgrad_pk(dYp, Xp, nseg, dy_rows_p, cout, x_rows_p, cin, guard, K, KH, KW, Wp, dW, prec, S(stream));
 }
 // ---- CNN encoders in training (kernels_enc_train.hip)
 int craft_norm_act_fwd(const float* x, long ldx, const float* mean_rstd, int mr_per_image, const float* gamma, const float* beta, int act,

@@ -816,6 +816,7 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
   float gm = grad_mul;
   if (sumsq != nullptr && max_norm > 0.f) {        // clip_grad_norm_: the norm is that of the (already averaged) gradient
     const float norm = (float)sqrt(*sumsq) * grad_mul;
+    if (!(norm < 3.0e38f)) return;                  // non-finite gradient (an overflow under a loss scale): skip the update, as GradScaler.step
     gm *= fminf(1.f, max_norm / (norm + 1e-6f));
   }
   const float gi = g[i] * gm;

@@ -14,7 +14,7 @@ namespace craft {
 // Developer A/B overrides from the environment, read ONCE when the library is loaded (never in a launch path):
 // CRAFT_HALO_BN (64 | 128), CRAFT_NO_C64, CRAFT_WF_DYNAMIC_TAPS.  Everything a caller may legitimately vary per call is an
 // argument of the C ABI instead (e.g. CRAFT_PV_ROWS in craft_attn_apply's prec).
-struct Tuning { int halo_bn; bool no_c64, wf_dynamic_taps, no_wgrad64, wgrad_sb; };
+struct Tuning { int halo_bn; bool no_c64, wf_dynamic_taps, no_wgrad64, wgrad_sb; int pk_mode; };
 const Tuning& tuning();
 
 struct RowsGemmParams {
@@ -52,6 +52,10 @@ struct ConvGemmParams {
                                         // iteration-invariant part of a conv: SepConvGRU context term)
 };
 
+int launch_pack_operand(const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
+                        int prec, void* out, float* colsum, hipStream_t s);
+int launch_wgrad_pk(const void* const* dYp, const void* const* Xp, int nseg, long dy_rows_p, int cout, long x_rows_p, int cin, long guard, long K,
+                    int KH, int KW, int Wp, float* dW, int prec, hipStream_t s);
 int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s);
 int launch_pv16(const RowsGemmParams& p, int prec, int rows32, hipStream_t s);   // A and B both 16-bit (type = prec), C fp32;
                                                                                   // rows32: 32-row groups per block (4..7), 0 = auto

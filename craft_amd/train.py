@@ -271,6 +271,22 @@ def fetch_optimizer(model: torch.nn.Module, lr: float, wdecay: float, epsilon: f
     return opt, OneCycleLR(lr, num_steps + 100, pct_start=0.05)
 
 
+def auto_loss_scale(n_loss_elements: int) -> float:
+    """Power-of-two loss scale that centres the backward pass on fp16's exponent range.  ``sequence_loss`` is a MEAN over B*2*H*W
+    elements (train.py:58): its gradient per element is 1 / (B*2*H*W) -- 3.4e-7 at 368x496 with batch 8, BELOW fp16's smallest normal
+    number (6.1e-5) and within a few of its subnormal steps (6e-8).  The 16-bit MFMA operand modes of the backward contractions
+    (fp16, and f16x3, whose hi / lo planes are fp16 too) would round such operands to ~10 % (measured: 33 % relative L2 error of the
+    correlation path's weight gradients at 368x496, 12 iterations; the same step with this scale: fp32-class).  The reference trains
+    with fp16 autocast under torch.cuda.amp.GradScaler for the same reason (train.py:215, :231-238).
+    Scale = 2^(ceil(log2(N)) - 6): the initial gradient g0 becomes 2^-7 .. 2^-6.  Measured over the backward operators of configs[3] /
+    configs[4] steps (tools/grad_range.py, profiles/r3/grad_range_*.txt): the gradient tensors' RMS spans 0.008 g0 .. 1 100 g0, their
+    largest element 1.1e5 g0 -- scaled, RMS >= 1.2e-4 (above fp16's smallest normal 6.1e-5) and max <= 1 800 (36 x below fp16's largest
+    65 504; with g0 scaled to ~1 the context encoder's first layers overflowed).  A power of two scales exactly; the un-scaling is folded
+    into the optimizer's gradient multiplier, and a gradient that overflows anyway (non-finite norm) skips the update instead of
+    poisoning the weights."""
+    return float(2 ** max(0, math.ceil(math.log2(max(1, int(n_loss_elements)))) - 6))
+
+
 class Trainer:
     """One process of train.py / train_ddp.py around a ``craft_amd.CRAFT`` on one GPU.
 
@@ -280,12 +296,16 @@ class Trainer:
     buffer per step -- RCCL over xGMI with the "nccl" backend -- folded into the update as a 1/world factor (DDP's gradient
     averaging), plus a 2-double all-reduce for the logged loss / EPE.  ``reference_loss_scaling``: train_ddp.py:60,84-88
     back-propagates the all-reduced loss divided by the world size, so its gradients carry a second 1/world on top of DDP's
-    average; True reproduces that, False (default) is the plain data-parallel mean."""
+    average; True reproduces that, False (default) is the plain data-parallel mean.  ``loss_scale``: "auto"
+    (default: ``auto_loss_scale`` of the loss' element count), a number, or None / 1.0 (off) -- the counterpart of train.py's GradScaler:
+    the loss gradient is multiplied by it before the backward pass and the gradients are un-scaled inside the fused AdamW (clipping
+    sees the un-scaled norm; a non-finite scaled norm skips the update like GradScaler.step)."""
 
     def __init__(self, model: torch.nn.Module, lr: float = 4e-4, wdecay: float = 1e-4, epsilon: float = 1e-8, num_steps: int = 100000,
                  clip: float = 1.0, gamma: float = 0.8, iters: int = 12, add_noise: bool = False, freeze_bn: bool = False, group=None,
-                 reference_loss_scaling: bool = False):
+                 reference_loss_scaling: bool = False, loss_scale="auto"):
         self.model = model
+        self.loss_scale = loss_scale
         self.optimizer, self.scheduler = fetch_optimizer(model, lr, wdecay, epsilon, num_steps)
         self.clip, self.gamma, self.iters, self.add_noise, self.freeze_bn, self.group = clip, gamma, iters, add_noise, freeze_bn, group
         self.reference_loss_scaling = reference_loss_scaling
@@ -340,7 +360,10 @@ class Trainer:
         opt.zero_grad()
         preds = model(image1, image2, iters=self.iters)
         loss, metrics = seq_loss(preds, flow, valid, self.gamma)
-        loss.backward()
+        ls = self.loss_scale
+        ls = auto_loss_scale(flow.numel()) if ls == "auto" else float(ls or 1.0)
+        self.last_loss_scale = ls
+        loss.backward(torch.full((), ls, device=loss.device, dtype=loss.dtype)) if ls != 1.0 else loss.backward()
         from .autograd import pending_uses
         if pending_uses(model.__dict__.get("_train_pass_cache")):
             raise RuntimeError("backward left accumulated weight gradients incomplete (a layer call was pruned from the graph)")
@@ -354,6 +377,7 @@ class Trainer:
             self._ar_events = (self._ar_events + [(ev0, ev1)])[-64:]
         if self.reference_loss_scaling:
             mul = mul / self._world()
+        mul = mul / ls                                                 # the flat gradient buffer holds loss_scale x the gradient
         opt.step(lr=self.scheduler.get_last_lr()[0], max_norm=self.clip, grad_mul=mul)
         self.scheduler.step()
         self.total_steps += 1

@@ -320,6 +320,26 @@ int craft_gemm(const float* A, long a_sm, long a_sk, long a_bs0, long a_bs1, con
 int craft_conv2d_wgrad(const float* x, long ldx, int cin, const float* dy, long ldy, int cout, int KH, int KW, int B, int H, int W,
                        float* dW, float* db, float* ws, long ws_floats, int prec, void* stream);
 int craft_colsum(const float* x, long ld, long rows, int C, float* out, void* stream);
+/* Packed-operand weight gradients (round 3; craft_amd/csrc/kernels_gemm_pk.hip): the same contraction as craft_conv2d_wgrad /
+ * craft_gemm's dW = dY^T X for the 16-bit MFMA modes, with the fp32 -> fp16-plane split taken OUT of the K loop.
+ * craft_pack_operand: tokens x [rows][C] (fp32, row stride ldx, C % 4 == 0) -> out[plane][ceil(C/32)][rows_p][32] 16-bit
+ *   (prec = CRAFT_PREC_F16X3: two fp16 planes hi, lo; CRAFT_PREC_F16 / CRAFT_PREC_BF16: one plane; channels >= C are zero).
+ *   Plain form (B = 0): pack row r holds source row r - guard (zero outside [0, rows)).  Spatial form (B > 0, rows = B*H*W pixels):
+ *   pack row r holds pixel (b, y, x) of the ZERO-PADDED grid [B][H + 2 padH][W + 2 padW] at index r - guard, so that a convolution
+ *   tap is one constant row shift dy * (W + 2 padW) + dx.  rows_p >= the rows the consumer reads, caller-allocated
+ *   (planes * ceil(C/32) * rows_p * 64 bytes).  colsum (or NULL): colsum[c] += sum_r x[r][c] (a convolution's bias gradient rides
+ *   on the pack of its dY).
+ * craft_wgrad_pk: dW[co][tap][ci] += sum_{s < nseg} sum_{k < K} dYp[s][guard + k][co] * Xp[s][guard + k + shift(tap)][ci], shift(tap) =
+ *   (tap / KW - KH/2) * Wp + (tap % KW - KW/2); cout, cin multiples of 32 (the packs' channel groups), K % 32 == 0, guard >=
+ *   the largest |shift|, both packs built with the same geometry and prec.  dW in the [cout][KH][KW][cin] layout, ACCUMULATED
+ *   (split-K partial sums are added with fp32 atomics).  KH = KW = 1: nn.Linear's weight gradient.  dYp / Xp: HOST arrays of nseg device
+ *   pointers -- the packs of the nseg calls of one layer in a pass (the update block runs every layer once per refinement iteration:
+ *   their weight gradient is ONE launch over the concatenated K, one atomic epilogue per pass instead of one per iteration). */
+int craft_pack_operand(const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
+                       int prec, void* out, float* colsum, void* stream);
+int craft_wgrad_pk(const void* const* dYp, const void* const* Xp, int nseg, long dy_rows_p, int cout, long x_rows_p, int cin, long guard, long K,
+                   int KH, int KW, int Wp, float* dW, int prec, void* stream);
+
 int craft_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, void* stream);
 int craft_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,
                   void* stream);

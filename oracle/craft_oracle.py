@@ -167,7 +167,7 @@ def global_stats(c: Tensor) -> Tuple[Tensor, Tensor]:
     flat = c.reshape(B, -1).double()
     mu = flat.mean(dim=1)
     var = ((flat - mu[:, None]) ** 2).mean(dim=1)
-    return mu.float(), (1.0 / torch.sqrt(var + LN_EPS)).float()
+    return mu.to(c.dtype), (1.0 / torch.sqrt(var + LN_EPS)).to(c.dtype)     # (c.dtype: float32 everywhere except float64 conditioning studies)
 
 
 def build_pyramid(c: Tensor, H8: int, W8: int, levels: int = 4) -> List[Tensor]:
@@ -439,9 +439,9 @@ def basic_encoder(x: Tensor, sd, p: str, kind: str, bn_stats=None) -> Tensor:
     return F.conv2d(x, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"])
 
 
-def coords_grid(B: int, H8: int, W8: int) -> Tensor:
+def coords_grid(B: int, H8: int, W8: int, dtype=torch.float32) -> Tensor:
     """utils.py:82-85: channel 0 = x (column index), channel 1 = y (row index)."""
-    ys, xs = torch.meshgrid(torch.arange(H8, dtype=torch.float32), torch.arange(W8, dtype=torch.float32), indexing="ij")
+    ys, xs = torch.meshgrid(torch.arange(H8, dtype=dtype), torch.arange(W8, dtype=dtype), indexing="ij")
     return torch.stack([xs, ys], dim=0)[None].expand(B, -1, -1, -1).clone()
 
 
@@ -475,7 +475,7 @@ def hot_path(fmap1: Tensor, fmap2: Tensor, net: Tensor, inp: Tensor, sd, cfg: Or
         c = plain_corr_raw(fmap1, fmap2t)
         mu, rstd = None, None
         pyr = build_pyramid(c, H8, W8, cfg.corr_levels)
-    coords0 = coords_grid(B, H8, W8)
+    coords0 = coords_grid(B, H8, W8, fmap1.dtype)
     coords1 = coords0.clone()
     if flow_init is not None:
         coords1 = coords1 + flow_init

@@ -425,7 +425,14 @@ def test_training_step_at_configs3_size_against_oracle(device, B, H, W, iters, f
     valid = (torch.rand(B, H, W, generator=torch.Generator().manual_seed(1)) > 0.15).float()
     preds = model(im1.to(device), im2.to(device), iters=iters)
     loss, _ = AG.sequence_loss(preds, flow, valid, 0.8)
-    loss.backward()
+    # the backward pass as Trainer.step runs it: under the power-of-two loss scale (the per-element loss gradient 1 / (B*2*H*W) is
+    # below fp16's normal range; the 16-bit operand modes need it, fp32 MFMA is indifferent), gradients un-scaled for the comparison
+    from craft_amd.train import auto_loss_scale
+    ls = auto_loss_scale(flow.numel())
+    loss.backward(torch.full((), ls, device=loss.device))
+    for p_ in model.parameters():
+        if p_.grad is not None:
+            p_.grad.mul_(1.0 / ls)
     names = [k for k, _ in model.named_parameters()]
     sd = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in sd0.items()}
     sd["corr_fn.setrans.key.weight"], sd["corr_fn.setrans.key.bias"] = sd["corr_fn.setrans.query.weight"], sd["corr_fn.setrans.query.bias"]
@@ -472,8 +479,10 @@ def test_bf16attn_step_at_configs4_shape_against_fp32_step(device):
         model.freeze_bn()
         preds = model(im1.to(device), im2.to(device), iters=iters)
         loss, _ = AG.sequence_loss(preds, flow, valid, 0.8)
-        loss.backward()
-        out[policy] = (float(loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+        from craft_amd.train import auto_loss_scale
+        ls = auto_loss_scale(flow.numel())
+        loss.backward(torch.full((), ls, device=loss.device))             # (as Trainer.step: loss scale, un-scaled below)
+        out[policy] = (float(loss.detach()), {k: p.grad.detach().clone() / ls for k, p in model.named_parameters() if p.grad is not None})
         del model, preds, loss
         torch.cuda.empty_cache()
     (l_ref, g_ref), (l_bf, g_bf) = out["train_f16x3"], out["train_bf16attn"]

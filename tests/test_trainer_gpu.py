@@ -125,7 +125,7 @@ WORKER = textwrap.dedent("""
     valid = torch.ones(2, 128, 160)
     sl = slice(rank, rank + 1) if world > 1 else slice(0, 2)
     m = tr.step(im1[sl], im2[sl], flow[sl], valid[sl])
-    grad = (tr.optimizer.flat_grad / world).cpu()            # the all-reduced (summed) gradient, averaged
+    grad = (tr.optimizer.flat_grad / world / tr.last_loss_scale).cpu()   # the all-reduced (summed) gradient, averaged and un-scaled
     m = tr.step(im1[sl], im2[sl], flow[sl], valid[sl])
     if rank == 0:
         torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "loss": m["loss"], "grad": grad}, sys.argv[1])
