@@ -579,10 +579,13 @@ class Packed:
     pixel grid, so that a convolution tap is one row shift and the weight-gradient K loop is a pure copy (kernels_gemm_pk.hip)."""
     __slots__ = ("buf", "rows_p", "guard", "K", "C_p", "prec", "Wp", "rows", "C")
 
-    def __init__(self, x: torch.Tensor, prec: int, spatial=None, colsum=None):
-        """x [.., C] tokens (unit channel stride, uniform row stride); spatial = (B, H, W, padH, padW) or None (plain rows)."""
-        C = x.shape[-1]
-        rows = x.numel() // C
+    def __init__(self, x, prec: int, spatial=None, colsum=None):
+        """x: tokens [.., C] (unit channel stride, uniform row stride) or a LIST of such tensors over the same rows -- their channel
+        concatenation (every source but the last with C % 32 == 0), packed without a torch.cat; spatial = (B, H, W, padH, padW) or
+        None (plain rows); colsum: [C] buffer that receives += the column sums (single source only)."""
+        srcs = list(x) if isinstance(x, (list, tuple)) else [x]
+        C = sum(t.shape[-1] for t in srcs)
+        rows = srcs[0].numel() // srcs[0].shape[-1]
         self.rows, self.C = rows, C
         if spatial is not None:
             B, H, W, ph, pw = spatial
@@ -594,25 +597,37 @@ class Packed:
             grid, self.Wp, self.guard = rows, 1, 0
         self.K = round_up(grid, 32)
         self.rows_p = round_up(2 * self.guard + self.K, 64)
-        self.C_p, self.prec = round_up(C, 32), prec
+        self.C_p, self.prec = sum(round_up(t.shape[-1], 32) for t in srcs), prec
         planes = 2 if prec == hip.PREC_F16X3 else 1
-        self.buf = torch.empty(planes * (self.C_p // 32) * self.rows_p * 32, device=x.device, dtype=torch.int16)
-        call("craft_pack_operand", x, x.stride(-2), C, rows, B, H, W, ph, pw, self.guard, self.rows_p, prec, self.buf, colsum)
+        ncg = self.C_p // 32
+        self.buf = torch.empty(planes * ncg * self.rows_p * 32, device=srcs[0].device, dtype=torch.int16)
+        off = 0
+        for t in srcs:
+            c = t.shape[-1]
+            if t is not srcs[-1] and c % 32:
+                raise ValueError("Packed: only the last source of a concatenation may have a channel count that is not a multiple of 32")
+            call("craft_pack_operand", t, t.stride(-2), c, rows, B, H, W, ph, pw, self.guard, self.rows_p, prec, self.buf, off, ncg,
+                 colsum if len(srcs) == 1 else None)
+            off += round_up(c, 32) // 32
 
 
 def wgrad_pk(pairs, KH: int, KW: int, acc: torch.Tensor):
-    """acc[cout_p][KH][KW][cin_p] += sum over the (dY pack, X pack) pairs of dY^T X (craft_wgrad_pk: ONE launch over the concatenated K)."""
+    """acc[cout_p][KH][KW][cin_p] += sum over the (dY pack, X pack) pairs of dY^T X (craft_wgrad_pk: ONE launch over the concatenated K).
+    An X operand may be a pair of packs (attributes .a / .b: train_update._CatPack) read as their channel concatenation."""
     import ctypes
     if isinstance(pairs, tuple):
         pairs = [pairs]
     gp, xp = pairs[0]
+    two = hasattr(xp, "a")
     for g2, x2 in pairs:
         assert (g2.K, g2.guard, g2.prec, g2.rows_p, g2.C_p, g2.Wp) == (gp.K, gp.guard, gp.prec, gp.rows_p, gp.C_p, gp.Wp)
-        assert (x2.K, x2.guard, x2.prec, x2.rows_p, x2.C_p) == (gp.K, gp.guard, gp.prec, xp.rows_p, xp.C_p)
+        assert (x2.K, x2.guard, x2.prec, x2.rows_p, x2.C_p, hasattr(x2, "a")) == (gp.K, gp.guard, gp.prec, xp.rows_p, xp.C_p, two)
+        assert not two or x2.a.C_p == xp.a.C_p
     n = len(pairs)
     ga = (ctypes.c_void_p * n)(*[g2.buf.data_ptr() for g2, _ in pairs])
-    xa = (ctypes.c_void_p * n)(*[x2.buf.data_ptr() for _, x2 in pairs])
-    call("craft_wgrad_pk", ga, xa, n, gp.rows_p, gp.C_p, xp.rows_p, xp.C_p, gp.guard, gp.K, KH, KW, gp.Wp, acc, gp.prec)
+    xa = (ctypes.c_void_p * n)(*[(x2.a if two else x2).buf.data_ptr() for _, x2 in pairs])
+    xb = (ctypes.c_void_p * n)(*[x2.b.buf.data_ptr() for _, x2 in pairs]) if two else None
+    call("craft_wgrad_pk", ga, xa, xb, xp.a.C_p if two else xp.C_p, n, gp.rows_p, gp.C_p, xp.rows_p, xp.C_p, gp.guard, gp.K, KH, KW, gp.Wp, acc, gp.prec)
 
 
 def _wgrad_deferred(cache, wobj, last: bool, pair, KH: int, KW: int, acc: torch.Tensor):

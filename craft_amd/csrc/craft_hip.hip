@@ -347,6 +347,15 @@ int craft_conv2d_nhwc(const float* x, long ldx, int cin, const float* w, const f
   return launch_gemm_conv(q, PREC_OF(prec), S(stream));
 }
 
+int craft_conv2d_nhwc2(const float* x0, long ld0, int c0, const float* x1, long ld1, int c1, const float* w, const float* bias, int cout,
+                       int KH, int KW, int act, float* y, long ldy, int B, int H, int W, int prec, void* stream) {
+  if (c0 % 32 || c1 % 32 || c0 <= 0 || c1 < 0 || (c1 > 0 && x1 == nullptr)) return CRAFT_ERR_ALIGN;
+  ConvGemmParams q = conv_params(x0, (int)ld0, c0, c1 ? x1 : nullptr, (int)ld1, c1, B, H, W, KH, KW, w, bias, cout, CONV_EPI_BIAS_ACT, act, 1.f, y,
+                                 (int)ldy);
+  q.w_packed = PACKED_OF(prec);
+  return launch_gemm_conv(q, PREC_OF(prec), S(stream));
+}
+
 int craft_conv2d_nhwc_ex(const float* x, long ldx, int cin, int Hin, int Win, const float* in_norm, const float* w,
                          const float* bias, int cout, int KH, int KW, int stride, int act, float* y, long ldy, int B, int Hout,
                          int Wout, double* stats, int prec, void* stream) {
@@ -422,12 +431,12 @@ int craft_conv2d_wgrad(const float* x, long ldx, int cin, const float* dy, long 
   return launch_conv_wgrad(x, ldx, cin, dy, ldy, cout, KH, KW, B, H, W, dW, db, ws, ws_floats, prec, S(stream));
 }
 int craft_pack_operand(const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
-                       int prec, void* out, float* colsum, void* stream) {
-  return launch_pack_operand(x, ldx, C, rows, B, H, W, padH, padW, guard, rows_p, prec, out, colsum, S(stream));
+                       int prec, void* out, int cg_off, int ncg_total, float* colsum, void* stream) {
+  return launch_pack_operand(x, ldx, C, rows, B, H, W, padH, padW, guard, rows_p, prec, out, cg_off, ncg_total, colsum, S(stream));
 }
-int craft_wgrad_pk(const void* const* dYp, const void* const* Xp, int nseg, long dy_rows_p, int cout, long x_rows_p, int cin, long guard, long K,
-                   int KH, int KW, int Wp, float* dW, int prec, void* stream) {
-  return launch_wgrad_pk(dYp, Xp, nseg, dy_rows_p, cout, x_rows_p, cin, guard, K, KH, KW, Wp, dW, prec, S(stream));
+int craft_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* const* Xp1, int cin0, int nseg, long dy_rows_p, int cout, long x_rows_p,
+                   int cin, long guard, long K, int KH, int KW, int Wp, float* dW, int prec, void* stream) {
+  return launch_wgrad_pk(dYp, Xp, Xp1, cin0, nseg, dy_rows_p, cout, x_rows_p, cin, guard, K, KH, KW, Wp, dW, prec, S(stream));
 }
 // ---- CNN encoders in training (kernels_enc_train.hip)
 int craft_norm_act_fwd(const float* x, long ldx, const float* mean_rstd, int mr_per_image, const float* gamma, const float* beta, int act,

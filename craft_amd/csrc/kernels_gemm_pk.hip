@@ -34,7 +34,8 @@ struct PackParams {
   long guard, rows_p;
   unsigned short* out; int prec;
   float* colsum;                 // optional [C]: += sum over rows (bias gradient of a convolution: its dY is packed anyway)
-  int ncg;
+  int ncg;                       // channel groups of THIS source
+  int cg_off, ncg_total;         // where they go: groups [cg_off, cg_off + ncg) of a pack of ncg_total groups (a virtual torch.cat)
 };
 
 // block = 256 threads; it packs PACK_ROWS rows x one 32-channel group: thread -> (row = tid >> 2 (+ 64 per pass), 8 channels at
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void k_pack_operand(PackParams p) {
   constexpr int NP = PACK_ROWS / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cg = blockIdx.y, cq = (tid & 3) * 8, c = cg * 32 + cq;
-  const long plane = (long)p.ncg * p.rows_p * 32;
+  const long plane = (long)p.ncg_total * p.rows_p * 32;
   const int Hp = p.H + 2 * p.padH, Wp = p.W + 2 * p.padW;
   float4 v0[NP], v1[NP];
 #pragma unroll
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void k_pack_operand(PackParams p) {
   for (int i = 0; i < NP; ++i) {
     const long r = (long)blockIdx.x * PACK_ROWS + i * 64 + (tid >> 2);
     if (r >= p.rows_p) continue;
-    unsigned short* o = p.out + ((long)cg * p.rows_p + r) * 32 + cq;
+    unsigned short* o = p.out + ((long)(p.cg_off + cg) * p.rows_p + r) * 32 + cq;
     if constexpr (PREC == CRAFT_PREC_F16X3) {
       f16x4 h0, l0, h1, l1;
       split_f16x3(v0[i], h0, l0);
@@ -119,14 +120,16 @@ __global__ __launch_bounds__(256) void k_pack_operand(PackParams p) {
 }
 
 int launch_pack_operand(const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
-                        int prec, void* out, float* colsum, hipStream_t s) {
+                        int prec, void* out, int cg_off, int ncg_total, float* colsum, hipStream_t s) {
   if (rows_p <= 0 || C <= 0) return 0;
+  if (cg_off < 0 || cg_off + (C + 31) / 32 > ncg_total) return CRAFT_ERR_ARG;
   if ((C & 3) || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return CRAFT_ERR_ALIGN;
   if (prec != CRAFT_PREC_F16X3 && prec != CRAFT_PREC_F16 && prec != CRAFT_PREC_BF16) return CRAFT_ERR_UNSUPPORTED;
   if (B > 0 && (double)B * (H + 2 * padH) * (W + 2 * padW) >= 2147483648.0) return CRAFT_ERR_UNSUPPORTED;
   PackParams p = {};
   p.x = x; p.ldx = ldx; p.C = C; p.rows = rows; p.B = B; p.H = H; p.W = W; p.padH = padH; p.padW = padW; p.guard = guard; p.rows_p = rows_p;
   p.out = static_cast<unsigned short*>(out); p.prec = prec; p.colsum = colsum; p.ncg = (C + 31) / 32;
+  p.cg_off = cg_off; p.ncg_total = ncg_total;
   dim3 grid((unsigned)((rows_p + PACK_ROWS - 1) / PACK_ROWS), (unsigned)p.ncg);
 #define GO(PR) do { if (colsum) hipLaunchKernelGGL((k_pack_operand<PR, true>), grid, dim3(256), 0, s, p); \
                     else hipLaunchKernelGGL((k_pack_operand<PR, false>), grid, dim3(256), 0, s, p); } while (0)
@@ -145,6 +148,8 @@ struct PkParams {
   // K is the concatenation of nseg segments (the calls of one layer in the 12 refinement iterations: ONE launch, one atomic epilogue
   // per pass instead of twelve): segment s = packs (A[s], B[s]) of identical geometry, seg_splits K ranges each
   const unsigned char* A[PK_MAX_SEG]; const unsigned char* B[PK_MAX_SEG]; float* C;
+  const unsigned char* B1[PK_MAX_SEG];       // optional second pack of the B operand: channel groups >= ncg_b0 come from it (a virtual cat)
+  int ncg_b0; unsigned b1_plane;
   int nseg, seg_splits;
   unsigned a_plane, a_cg, b_plane, b_cg;     // byte strides of the packs (cg stride = rows_p * 64)
   int ncg_a, ncg_b;                          // channel groups of A (M / 32) and of B per tap (cin / 32)
@@ -175,6 +180,7 @@ __global__ __launch_bounds__(512) void k_gemm_pk(PkParams p) {
   const long k0 = (long)(split - seg * p.seg_splits) * p.kchunk;
   const unsigned char* const Aseg = p.A[seg];
   const unsigned char* const Bseg = p.B[seg];
+  const unsigned char* const B1seg = p.B1[seg];
   const int nk = (int)((min(p.K, k0 + p.kchunk) - k0) / 32);
   if (nk <= 0) return;
 
@@ -198,7 +204,8 @@ __global__ __launch_bounds__(512) void k_gemm_pk(PkParams p) {
       const int pl = c2 / (BN / 32), g = min(tn * (BN / 32) + c2 % (BN / 32), p.ngroups - 1);
       const int tap = g / p.ncg_b, cg = g - tap * p.ncg_b;
       const int shift = (tap / p.KW - p.KH / 2) * p.Wp + (tap % p.KW - p.KW / 2);
-      base = Bseg + (p.b_row0 + k0 + shift) * 64 + (long)pl * p.b_plane + (long)cg * p.b_cg + half * 1024;
+      base = cg < p.ncg_b0 ? Bseg + (long)pl * p.b_plane + (long)cg * p.b_cg : B1seg + (long)pl * p.b1_plane + (long)(cg - p.ncg_b0) * p.b_cg;
+      base += (p.b_row0 + k0 + shift) * 64 + half * 1024;
     }
     const unsigned long long a = reinterpret_cast<unsigned long long>(base);
     blo[i] = __builtin_amdgcn_readfirstlane((unsigned)a);
@@ -319,15 +326,17 @@ __global__ __launch_bounds__(512) void k_gemm_pk(PkParams p) {
 
 static int pick_tile(int m) { return m > 128 ? 256 : (m > 64 ? 128 : 64); }
 
-int launch_wgrad_pk(const void* const* dYp, const void* const* Xp, int nseg, long dy_rows_p, int cout, long x_rows_p, int cin, long guard, long K,
-                    int KH, int KW, int Wp, float* dW, int prec, hipStream_t s) {
+int launch_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* const* Xp1, int cin0, int nseg, long dy_rows_p, int cout, long x_rows_p,
+                    int cin, long guard, long K, int KH, int KW, int Wp, float* dW, int prec, hipStream_t s) {
   if (cout <= 0 || cin <= 0 || K <= 0 || nseg <= 0) return 0;
   if ((cout & 31) || (cin & 31) || (K & 31) || KH < 1 || KW < 1) return CRAFT_ERR_ARG;
+  if (Xp1 == nullptr) cin0 = cin;
+  if ((cin0 & 31) || cin0 <= 0 || cin0 > cin || (Xp1 != nullptr && cin0 == cin)) return CRAFT_ERR_ARG;
   if (prec != CRAFT_PREC_F16X3 && prec != CRAFT_PREC_F16 && prec != CRAFT_PREC_BF16) return CRAFT_ERR_UNSUPPORTED;
   if (nseg > PK_MAX_SEG) {                              // more segments than one launch carries: in groups
     for (int i = 0; i < nseg; i += PK_MAX_SEG) {
       const int n = nseg - i < PK_MAX_SEG ? nseg - i : PK_MAX_SEG;
-      const int rc = launch_wgrad_pk(dYp + i, Xp + i, n, dy_rows_p, cout, x_rows_p, cin, guard, K, KH, KW, Wp, dW, prec, s);
+      const int rc = launch_wgrad_pk(dYp + i, Xp + i, Xp1 ? Xp1 + i : nullptr, cin0, n, dy_rows_p, cout, x_rows_p, cin, guard, K, KH, KW, Wp, dW, prec, s);
       if (rc) return rc;
     }
     return 0;
@@ -341,12 +350,14 @@ int launch_wgrad_pk(const void* const* dYp, const void* const* Xp, int nseg, lon
   for (int i = 0; i < nseg; ++i) {
     p.A[i] = static_cast<const unsigned char*>(dYp[i]);
     p.B[i] = static_cast<const unsigned char*>(Xp[i]);
-    if (!p.A[i] || !p.B[i]) return CRAFT_ERR_ARG;
+    p.B1[i] = Xp1 ? static_cast<const unsigned char*>(Xp1[i]) : p.B[i];
+    if (!p.A[i] || !p.B[i] || !p.B1[i]) return CRAFT_ERR_ARG;
   }
   p.C = dW; p.nseg = nseg;
   p.ncg_a = cout / 32; p.ncg_b = cin / 32;
   p.a_cg = (unsigned)(dy_rows_p * 64); p.a_plane = (unsigned)(p.ncg_a * dy_rows_p * 64);
-  p.b_cg = (unsigned)(x_rows_p * 64); p.b_plane = (unsigned)(p.ncg_b * x_rows_p * 64);
+  p.ncg_b0 = cin0 / 32;
+  p.b_cg = (unsigned)(x_rows_p * 64); p.b_plane = (unsigned)(p.ncg_b0 * x_rows_p * 64); p.b1_plane = (unsigned)((p.ncg_b - p.ncg_b0) * x_rows_p * 64);
   p.a_row0 = guard; p.b_row0 = guard; p.KH = KH; p.KW = KW; p.Wp = Wp;
   p.ldc = (long)KH * KW * cin; p.K = K;
   p.ngroups = KH * KW * p.ncg_b;

@@ -14,13 +14,14 @@ and the plain-correlation GMA model; ``--f1`` and GMA's relative-position scores
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
 from . import autograd as AG
 from . import ops
 from . import train_encoder as TE
-from .hip import ACT_NONE, ACT_RELU, ACT_TANH, PREC_BF16, PREC_F16
+from .hip import ACT_NONE, ACT_RELU, ACT_TANH, PREC_BF16, PREC_F16, PREC_F32
 
 
 _warned_promote = []
@@ -171,6 +172,20 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
     pholder = pbox[0]
 
     # ---- iterative refinement (network.py:230-260; update.py:137-162) -------------------------------------------------
+    radius_ = radius
+    if getattr(args, "hip_fused_update", True) and prec.conv != PREC_F32 and not os.environ.get("CRAFT_TRAIN_UNFUSED"):
+        # one autograd node per iteration with a hand-written backward (craft_amd/train_update.py)
+        from . import train_update as TU
+        coords0, coords1, _ = ops.coords_init(flow_init, B, H8, W8, dev)
+        ups = TU.UpdatePass(model, prec, hw, B, iters, net, inp, holder, pholder, radius_)
+        model.__dict__["_train_pass_cache"] = ups.cache
+        params = TU.update_params(model)
+        preds = []
+        for t in range(iters):
+            corr = AG.CorrLookup.apply(token, coords1, holder, radius_)              # network.py:235 (coords1 carries no gradient, :232)
+            net, up, coords1 = TU.UpdateIter.apply(net, corr, ptoken, inp, ups, t, coords1, coords0, *params)
+            preds.append(up)
+        return preds
     ub = model.update_block
     enc, gru, fh, agg = ub.encoder, ub.gru, ub.flow_head, ub.aggregator
     coords0, coords1, _ = ops.coords_init(flow_init, B, H8, W8, dev)

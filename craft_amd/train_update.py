@@ -1,0 +1,392 @@
+"""One refinement iteration of ``CRAFT.forward`` in training mode as ONE autograd node with a hand-written backward
+(network.py:230-260, update.py:137-162: motion encoder -> motion aggregator -> SepConvGRU -> flow head / mask head -> convex
+upsampling).
+
+The first training path (round 2, craft_amd/train_forward.py with ``args.hip_fused_update = False``) composed the iteration from ~40
+small autograd.Functions: correct, but every ``torch.cat`` / zero fill / gradient add between them was a PyTorch kernel (~1 000 per
+step, 8 % of the kernel time) and the forward could not use the fused inference kernels.  Here the iteration works on ONE 640-wide
+token buffer per iteration
+
+    HX_t = [ h1 (128) | h0 (128) | inp (128) | mf (128) | mfg (128) ]          h0 = net_t, h1 = hidden state after the horizontal GRU pass,
+                                                                              the vertical pass writes net_{t+1} into HX_{t+1}'s h0 slot
+
+(every ``torch.cat`` of update.py is a column range, the q gate's cat([r*h, x]) a two-segment convolution input), the forward runs
+the inference entry points where they keep what the backward needs (``craft_motion_encoder``, ``craft_flow_head``, ``craft_mask_head``:
+their workspaces ARE the saved activations), the convolution inputs are packed for the weight gradients while they are at hand
+(``autograd.Packed``: the fp32 copies need not survive), and the backward is one straight sequence of kernel calls: input gradients =
+the forward convolution with flipped weights, weight gradients queued per layer and launched once per pass over all 12 iterations
+(``craft_wgrad_pk``), gate / activation / pooling gradients by their kernels.  Results equal the unfused path's up to summation order
+(tests/test_train_update.py).
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import autograd as AG
+from . import hip, ops
+from .hip import ACT_NONE, ACT_RELU, STATS_REPLICAS, W_PACKED, call, pick, round_up
+
+_C = 640          # columns of HX
+H1, H0, INP, MF, MFG = 0, 128, 256, 384, 512
+
+
+class UpdatePass:
+    """Everything the 12 iterations of one forward pass share: buffers, packed weights, gradient accumulators."""
+
+    def __init__(self, model, prec, hw, B, iters, net, inp, holder, pholder, radius):
+        self.model, self.prec, self.hw, self.B, self.iters = model, prec, hw, B, iters
+        self.N = hw[0] * hw[1]
+        self.holder, self.pholder, self.radius = holder, pholder, radius
+        dev = net.device
+        self.dev = dev
+        self.cp = pick(prec, "conv")
+        if self.cp == hip.PREC_F32:
+            raise NotImplementedError("the fused update iteration runs the 16-bit / f16x3 operand modes; fp32 takes the unfused path")
+        ub = model.update_block
+        self.setrans = bool(model.args.use_setrans)
+        # one buffer for all iterations (+ 1: the last iteration's net_{T} slot); inp is written once for all of them
+        self.HX = torch.empty(iters + 1, B, self.N, _C, device=dev, dtype=torch.float32)
+        self.HX[:iters, :, :, INP:INP + 128] = inp.detach()
+        self.HX[0, :, :, H0:H0 + 128] = net.detach()
+        self.cache = {}            # conv operand cache of the pass (transposed weights), gradient accumulators, queued packs
+        gru = ub.gru
+        # forward weights: the inference modules' packed copies (re-made when the optimizer bumps the weights epoch)
+        self.w_enc = ub.encoder.packed(self.cp)
+        self.w_gru = gru.packed(self.cp)           # (wzr1, bzr1, wq1, bq1, wzr2, bzr2, wq2, bq2), input channel order [h | inp | mf | mfg]
+        self.w_fh = ub.flow_head.packed(self.cp)
+        self.w_mask = ub.packed_mask(self.cp)
+        # the z|r gates as one 256-row weight (their gradient is split again at the end of the pass)
+        self.wzr = [torch.cat([gru.convz1.weight, gru.convr1.weight], 0).detach(), torch.cat([gru.convz2.weight, gru.convr2.weight], 0).detach()]
+        self.wq = [gru.convq1.weight, gru.convq2.weight]
+        self.d_inp = torch.zeros(B, self.N, 128, device=dev, dtype=torch.float32)
+        self.rep_agg = None        # replicated (dw_agg, dskip) table of the aggregator's pooling, reduced at the end of the pass
+        self.dgamma = None
+        self.saved = [None] * iters
+        self.zero1 = torch.zeros(1, device=dev, dtype=torch.float32)
+
+    # ---- gradient accumulators ------------------------------------------------------------------------------------
+    def acc(self, key, shape):
+        k = ("acc", key)
+        b = self.cache.get(k)
+        if b is None:
+            b = self.cache[k] = torch.zeros(shape, device=self.dev, dtype=torch.float32)
+        return b
+
+    def wgrad(self, key, pair, KH, KW, acc, last):
+        """Queue the packed (dY, X) pair of this iteration; the last backward call (iteration 0) launches ONE product over all of them."""
+        k = ("pk_pending", key)
+        self.cache.setdefault(k, []).append(pair)
+        if last:
+            AG.wgrad_pk(self.cache.pop(k), KH, KW, acc)
+
+
+def _flow32(flow, B, N):
+    f = torch.zeros(B, N, 32, device=flow.device, dtype=torch.float32)
+    f[..., :2] = flow
+    return f
+
+
+def _conv_dx(ps: UpdatePass, w, g, cout_p, KH, KW, out=None):
+    """Input gradient of a stride-1 'same' convolution: the forward kernel with flipped / transposed weights.  g [B, N, cout_p]
+    (row stride may exceed cout_p) -> [B, N, cin_p]."""
+    wt, zb, flag, _ = AG._conv_weights(w, None, ps.cp, ps.cache, True)
+    cin_p = round_up(w.shape[1], 32)
+    if out is None:
+        out = torch.empty(ps.B, ps.N, cin_p, device=ps.dev, dtype=torch.float32)
+    call("craft_conv2d_nhwc", g, g.stride(-2), cout_p, wt, zb, cin_p, KH, KW, ACT_NONE, out, out.stride(-2), ps.B, ps.hw[0], ps.hw[1], ps.cp | flag)
+    return out
+
+
+def _act_bwd(dy, y, C, out=None, act=ACT_RELU, scale=1.0):
+    rows = dy.shape[0] * dy.shape[1]
+    if out is None:
+        out = torch.empty(dy.shape[0], dy.shape[1], C, device=dy.device, dtype=torch.float32)
+    call("craft_act_bwd", dy, dy.stride(-2), y, y.stride(-2), out, out.stride(-2), rows, C, act, float(scale))
+    return out
+
+
+class UpdateIter(Function):
+    """(net_t, corr_t, P token, inp, *parameters) -> (net_{t+1}, flow prediction t)."""
+
+    @staticmethod
+    def forward(ctx, net, corr, ptoken, inp, ps: UpdatePass, t: int, coords1, coords0, *params):
+        m = ps.model
+        ub = m.update_block
+        B, N, (H8, W8) = ps.B, ps.N, ps.hw
+        rows, cp, prec, dev = B * N, ps.cp, ps.prec, ps.dev
+        hx, hxn = ps.HX[t], ps.HX[t + 1]
+        corr = AG._rows(corr)
+        S = {}
+        flow = coords1 - coords0                                                     # [B, N, 2]
+        # ---- BasicMotionEncoder (update.py:79-87): one fused call; its workspace keeps cor1 | [cor2 | flo2] | flo1
+        me = torch.empty(rows * 640, device=dev, dtype=torch.float32)
+        call("craft_motion_encoder", corr, corr.stride(-2), ub.encoder.cor_planes, flow, *ps.w_enc, B, H8, W8, hx[..., MF:MF + 128], _C, me,
+             cp | W_PACKED, None, None)
+        S["cor1"] = me[: rows * 256].view(B, N, 256)
+        S["cf"] = me[rows * 256: rows * 512].view(B, N, 256)
+        S["flo1"] = me[rows * 512:].view(B, N, 128)
+        mf = hx[..., MF:MF + 128]
+        # packs of the motion encoder's conv inputs (for the weight gradients)
+        g3, g7 = (B, H8, W8, 1, 1), (B, H8, W8, 3, 3)
+        S["pk_corr"] = AG.Packed(corr, cp)
+        S["pk_cor1"] = AG.Packed(S["cor1"], cp, g3)
+        S["pk_flow"] = AG.Packed(_flow32(flow, B, N), cp, g7)
+        S["pk_flo1"] = AG.Packed(S["flo1"], cp, g3)
+        S["pk_cf"] = AG.Packed(S["cf"], cp, g3)
+        # ---- motion aggregator (update.py:143-149)
+        P = ps.pholder.P
+        Bp, M, _, ld = P.shape
+        agg = ub.aggregator
+        pv = pick(prec, "pv")
+        if ps.setrans:
+            va = ops.linear(mf, agg.first_linear.weight.detach(), None, prec)             # [B, N, M*128]
+        else:
+            va = ops.linear(mf, agg.to_v.weight.detach().view(agg.heads * agg.dim_head, -1), None, prec)
+        Cv = va.shape[-1] // M
+        Oa = torch.empty(B, M, N, Cv, device=dev, dtype=torch.float32)
+        AG.gemm(P, ld, 1, M * N * ld, N * ld, va, 1, va.stride(-2), N * va.stride(-2), Cv, Oa, Cv, M * N * Cv, N * Cv, M, B * M, N, Cv, N, prec=pv)
+        if ps.setrans:
+            ops.mode_pool_ln(Oa, mf, agg.feat_softaggr.feat2score.weight.detach(), agg.input_skip_coeff.detach(), out=hx[..., MFG:MFG + 128])
+        else:
+            ops.gma_residual(mf, Oa.view(B, N, Cv), agg.gamma.detach(), out=hx[..., MFG:MFG + 128])
+        S["va"], S["Oa"] = va, Oa
+        S["pk_mf"] = AG.Packed(mf, pick(prec, "proj"))
+        # ---- SepConvGRU (update.py:49-64): horizontal pass h0 -> h1 (in HX_t), vertical pass h1 -> net_{t+1} (into HX_{t+1})
+        wzr1, bzr1, wq1, bq1, wzr2, bzr2, wq2, bq2 = ps.w_gru
+        x = hx[..., INP:INP + 384]
+        for p_, (KH, KW, wzr, bzr, wq, bq) in enumerate(((1, 5, wzr1, bzr1, wq1, bq1), (5, 1, wzr2, bzr2, wq2, bq2))):
+            h = hx[..., H0:H0 + 128] if p_ == 0 else hx[..., H1:H1 + 128]
+            hn = hx[..., H1:H1 + 128] if p_ == 0 else hxn[..., H0:H0 + 128]
+            geom = (B, H8, W8, KH // 2, KW // 2)
+            zr_pre = torch.empty(B, N, 256, device=dev, dtype=torch.float32)
+            call("craft_conv2d_nhwc2", h, _C, 128, x, _C, 384, wzr, bzr, 256, KH, KW, ACT_NONE, zr_pre, 256, B, H8, W8, cp | W_PACKED)
+            z, r, rh = (torch.empty(B, N, 128, device=dev, dtype=torch.float32) for _ in range(3))
+            call("craft_gru_zr_fwd", zr_pre, 256, h, _C, z, r, rh, rows, 128)
+            q_pre = zr_pre[..., :128]                                                # (zr_pre is dead: reuse its first half)
+            call("craft_conv2d_nhwc2", rh, 128, 128, x, _C, 384, wq, bq, 128, KH, KW, ACT_NONE, q_pre, 256, B, H8, W8, cp | W_PACKED)
+            q = torch.empty(B, N, 128, device=dev, dtype=torch.float32)
+            call("craft_gru_out_fwd", q_pre, 256, z, h, _C, q, hn, _C, rows, 128)
+            pk_x = AG.Packed(x, cp, geom)                                            # shared by the z|r and the q convolution of this pass
+            S[f"pk_h{p_}"] = AG.Packed(h, cp, geom)
+            S[f"pk_rh{p_}"] = AG.Packed(rh, cp, geom)
+            S[f"pk_x{p_}"] = pk_x
+            S[f"z{p_}"], S[f"r{p_}"], S[f"q{p_}"] = z, r, q
+        h2 = hxn[..., H0:H0 + 128]
+        S["pk_h2"] = AG.Packed(h2, cp, g3)
+        # ---- heads (update.py:15-16, :124-127, :161) + coords1 += delta (network.py:247) + convex upsampling (:258)
+        fh1 = torch.empty(B, N, 256, device=dev, dtype=torch.float32)
+        c1n = coords1.clone()
+        flow_new = torch.empty(B, N, 2, device=dev, dtype=torch.float32)
+        call("craft_flow_head", h2, _C, *ps.w_fh, B, H8, W8, c1n, coords0, flow_new, None, fh1, cp | W_PACKED)
+        mh = torch.empty(B, N, 256, device=dev, dtype=torch.float32)
+        mask = torch.empty(B, N, 576, device=dev, dtype=torch.float32)
+        call("craft_mask_head", h2, _C, *ps.w_mask, B, H8, W8, mask, mh, cp | W_PACKED)
+        up = ops.convex_upsample(mask, flow_new, H8, W8)
+        S["fh1"], S["mh"], S["mask"], S["flow_new"] = fh1, mh, mask, flow_new
+        S["pk_fh1"] = AG.Packed(fh1, cp, g3)
+        S["pk_mh"] = AG.Packed(mh, cp)
+        ps.saved[t] = S
+        ctx.ps, ctx.t = ps, t
+        ctx.nparams = len(params)
+        ctx.mark_non_differentiable(c1n)
+        return hxn[..., H0:H0 + 128], up, c1n
+
+    @staticmethod
+    def backward(ctx, d_hn, d_up, _dc):
+        ps, t = ctx.ps, ctx.t
+        S = ps.saved[t]
+        ps.saved[t] = None
+        m = ps.model
+        ub = m.update_block
+        enc, gru, fh, agg = ub.encoder, ub.gru, ub.flow_head, ub.aggregator
+        B, N, (H8, W8) = ps.B, ps.N, ps.hw
+        rows, cp, prec, dev = B * N, ps.cp, ps.prec, ps.dev
+        hx, hxn = ps.HX[t], ps.HX[t + 1]
+        last = t == 0                                # backward runs the iterations in reverse: t = 0 completes every accumulator
+        g3, g7 = (B, H8, W8, 1, 1), (B, H8, W8, 3, 3)
+        E = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)      # noqa: E731
+        h2 = hxn[..., H0:H0 + 128]
+
+        # ---- convex upsampling, mask head
+        dh2 = None
+        if d_up is not None:
+            dmask = E(B, N, 576)
+            dflow = torch.zeros(B, N, 32, device=dev, dtype=torch.float32)           # (2 live columns; the flow head's padded output)
+            d2 = torch.zeros(B, N, 2, device=dev, dtype=torch.float32)
+            call("craft_convex_upsample_bwd", S["mask"], 576, S["flow_new"], AG._c(d_up), B, H8, W8, dmask, 576, d2)
+            dflow[..., :2] = d2
+            # mask = 0.25 * (W2 mh + b2): the gradient w.r.t. the pre-scale output
+            dm = _act_bwd(dmask, dmask, 576, out=dmask, act=ACT_NONE, scale=0.25)
+            w2 = ub.mask[2].weight
+            w2m = w2.detach().view(576, 256)
+            d_mh = E(B, N, 256)
+            AG.gemm(dm, 576, 1, 0, 0, w2m, 1, 256, 0, 0, d_mh, 256, 0, 0, 1, 1, rows, 256, 576, prec=cp)
+            ps.wgrad(("mask2",), (AG.Packed(dm, cp, colsum=ps.acc(("mask2", "db"), (576,))), S["pk_mh"]), 1, 1, ps.acc(("mask2", "dw"), (576, 256)), last)
+            g_mh = _act_bwd(d_mh, S["mh"], 256, out=d_mh)
+            dh2 = _conv_dx(ps, ub.mask[0].weight, g_mh, 256, 3, 3)
+            ps.wgrad(("mask0",), (AG.Packed(g_mh, cp, g3, colsum=ps.acc(("mask0", "db"), (256,))), S["pk_h2"]), 3, 3, ps.acc(("mask0", "dw"), (256, 3, 3, 128)), last)
+            # ---- flow head: delta = conv2(relu(conv1(h2)))
+            d_fh1 = _conv_dx(ps, fh.conv2.weight, dflow, 32, 3, 3)
+            ps.wgrad(("fh2",), (AG.Packed(dflow, cp, g3, colsum=ps.acc(("fh2", "db"), (32,))), S["pk_fh1"]), 3, 3, ps.acc(("fh2", "dw"), (32, 3, 3, 256)), last)
+            g_fh1 = _act_bwd(d_fh1, S["fh1"], 256, out=d_fh1)
+            dh2b = _conv_dx(ps, fh.conv1.weight, g_fh1, 256, 3, 3)
+            ps.wgrad(("fh1",), (AG.Packed(g_fh1, cp, g3, colsum=ps.acc(("fh1", "db"), (256,))), S["pk_h2"]), 3, 3, ps.acc(("fh1", "dw"), (256, 3, 3, 128)), last)
+            dh2.add_(dh2b)
+            if d_hn is not None:
+                dh2.add_(d_hn)
+        elif d_hn is not None:
+            dh2 = AG._c(d_hn).clone()
+        S.pop("pk_h2"); S.pop("pk_fh1"); S.pop("pk_mh")
+        if dh2 is None:
+            raise RuntimeError("UpdateIter.backward without any output gradient")
+
+        # ---- SepConvGRU, vertical pass then horizontal pass
+        x = hx[..., INP:INP + 384]
+        dx = None
+        dh = dh2
+        for p_, (KH, KW) in ((1, (5, 1)), (0, (1, 5))):
+            h = hx[..., H0:H0 + 128] if p_ == 0 else hx[..., H1:H1 + 128]
+            z, r, q = S[f"z{p_}"], S[f"r{p_}"], S[f"q{p_}"]
+            geom = (B, H8, W8, KH // 2, KW // 2)
+            dqp, dz, dhp = E(B, N, 128), E(B, N, 128), E(B, N, 128)
+            call("craft_gru_out_bwd", dh, dh.stride(-2), z, q, h, _C, dqp, dz, dhp, rows, 128)
+            tq = _conv_dx(ps, ps.wq[p_], dqp, 128, KH, KW)                                    # d[rh | x]
+            bq = (gru.convq1 if p_ == 0 else gru.convq2)
+            ps.wgrad(("q", p_), (AG.Packed(dqp, cp, geom, colsum=ps.acc(("q", p_, "db"), (128,))), _cat_pack(S[f"pk_rh{p_}"], S[f"pk_x{p_}"])), KH, KW,
+                     ps.acc(("q", p_, "dw"), (128, KH, KW, 512)), last)
+            dzr = E(B, N, 256)
+            call("craft_gru_zr_bwd", dz, tq, 512, z, r, h, _C, dzr, dhp, rows, 128)            # dhp += d(rh) r
+            tz = _conv_dx(ps, ps.wzr[p_], dzr, 256, KH, KW)                                   # d[h | x]
+            ps.wgrad(("zr", p_), (AG.Packed(dzr, cp, geom, colsum=ps.acc(("zr", p_, "db"), (256,))), _cat_pack(S[f"pk_h{p_}"], S[f"pk_x{p_}"])), KH, KW,
+                     ps.acc(("zr", p_, "dw"), (256, KH, KW, 512)), last)
+            dhp.add_(tz[..., :128])
+            if dx is None:
+                dx = torch.add(tq[..., 128:], tz[..., 128:])
+            else:
+                dx.add_(tq[..., 128:]).add_(tz[..., 128:])
+            dh = dhp
+            for k in (f"pk_h{p_}", f"pk_rh{p_}", f"pk_x{p_}", f"z{p_}", f"r{p_}", f"q{p_}"):
+                S.pop(k)
+        d_net = dh                                                                            # gradient of net_t
+        ps.d_inp.add_(dx[..., 0:128])
+        d_mfg = dx[..., 256:384]
+        mf = hx[..., MF:MF + 128]
+        # ---- motion aggregator
+        P = ps.pholder.P
+        _, M, _, ld = P.shape
+        va, Oa = S["va"], S["Oa"]
+        Cv = Oa.shape[-1]
+        pv = pick(prec, "pv")
+        pp = pick(prec, "proj")
+        d_mf = E(B, N, 128)
+        if ps.setrans:
+            if ps.rep_agg is None:
+                ps.rep_agg = torch.zeros(STATS_REPLICAS, Cv + 1, device=dev, dtype=torch.float32)
+            dOa = torch.empty_like(Oa)
+            w_agg, skip = agg.feat_softaggr.feat2score.weight, agg.input_skip_coeff
+            call("craft_mode_pool_ln_bwd", Oa, mf, _C, AG._c(w_agg.detach()).view(-1), skip.detach(), d_mfg, d_mfg.stride(-2), B, N, M, Cv, dOa, d_mf, 128,
+                 ps.rep_agg)
+            w_v = agg.first_linear.weight
+        else:
+            gamma = agg.gamma
+            dmc = d_mfg.contiguous()
+            dOa = ops.gma_residual(dmc, dmc, (gamma.detach() - 1.0).contiguous()).view(B, 1, N, Cv)          # gamma * d_mfg
+            if ps.dgamma is None:
+                ps.dgamma = torch.zeros(1, 1, device=dev, dtype=torch.float32)
+            K = B * N * Cv
+            AG.gemm(dmc, K, 1, 0, 0, Oa, K, 1, 0, 0, ps.dgamma, 1, 0, 0, 1, 1, 1, 1, K, accumulate=True, ksplit=0, prec=hip.PREC_F16X3)
+            d_mf.copy_(d_mfg)
+            w_v = agg.to_v.weight
+        dva = E(B, N, M * Cv)
+        AG.gemm(P, 1, ld, M * N * ld, N * ld, dOa, 1, Cv, M * N * Cv, N * Cv, dva, M * Cv, N * M * Cv, Cv, M, B * M, N, Cv, N, prec=pv)
+        ps.pholder.pending.append((dOa, va))
+        wv2 = w_v.detach().view(M * Cv, 128)
+        d_mf3 = E(B, N, 128)
+        AG.gemm(dva, M * Cv, 1, 0, 0, wv2, 1, 128, 0, 0, d_mf3, 128, 0, 0, 1, 1, rows, 128, M * Cv, prec=pp)
+        ps.wgrad(("agg_v",), (AG.Packed(dva, pp), S["pk_mf"]), 1, 1, ps.acc(("agg_v", "dw"), (M * Cv, 128)), last)
+        d_mf.add_(d_mf3).add_(dx[..., 128:256])
+        # ---- BasicMotionEncoder
+        d_mf[..., 126:128] = 0.0                                                              # the two pass-through flow channels carry no gradient
+        g_out = _act_bwd(d_mf, mf, 128, out=d_mf)
+        g_out[..., 126:128] = 0.0
+        d_cf = _conv_dx(ps, enc.conv.weight, g_out, 128, 3, 3)
+        ps.wgrad(("menc",), (AG.Packed(g_out, cp, g3, colsum=ps.acc(("menc", "db"), (128,))), S["pk_cf"]), 3, 3, ps.acc(("menc", "dw"), (128, 3, 3, 256)), last)
+        g_cf = _act_bwd(d_cf, S["cf"], 256, out=d_cf)
+        g_c2, g_f2 = g_cf[..., :192], g_cf[..., 192:256]
+        d_cor1 = _conv_dx(ps, enc.convc2.weight, g_c2, 192, 3, 3)
+        ps.wgrad(("c2",), (AG.Packed(g_c2, cp, g3, colsum=ps.acc(("c2", "db"), (192,))), S["pk_cor1"]), 3, 3, ps.acc(("c2", "dw"), (192, 3, 3, 256)), last)
+        g_cor1 = _act_bwd(d_cor1, S["cor1"], 256, out=d_cor1)
+        wc1 = enc.convc1.weight.detach().view(256, -1)
+        cpl = wc1.shape[1]
+        d_corr = E(B, N, cpl)
+        AG.gemm(g_cor1, 256, 1, 0, 0, wc1, 1, cpl, 0, 0, d_corr, cpl, 0, 0, 1, 1, rows, cpl, 256, prec=cp)
+        ps.wgrad(("c1",), (AG.Packed(g_cor1, cp, colsum=ps.acc(("c1", "db"), (256,))), S["pk_corr"]), 1, 1, ps.acc(("c1", "dw"), (256, round_up(cpl, 32))), last)
+        d_flo1 = _conv_dx(ps, enc.convf2.weight, g_f2, 64, 3, 3)
+        ps.wgrad(("f2",), (AG.Packed(g_f2, cp, g3, colsum=ps.acc(("f2", "db"), (64,))), S["pk_flo1"]), 3, 3, ps.acc(("f2", "dw"), (64, 3, 3, 128)), last)
+        g_flo1 = _act_bwd(d_flo1, S["flo1"], 128, out=d_flo1)
+        ps.wgrad(("f1",), (AG.Packed(g_flo1, cp, g7, colsum=ps.acc(("f1", "db"), (128,))), S["pk_flow"]), 7, 7, ps.acc(("f1", "dw"), (128, 7, 7, 32)), last)
+        S.clear()
+        grads = _param_grads(ps) if last else (None,) * ctx.nparams
+        d_inp = ps.d_inp if last else None
+        return (d_net, d_corr, ps.zero1, d_inp, None, None, None, None) + tuple(grads)
+
+
+class _CatPack:
+    """Two packs over the same rows read as one operand: the channel concatenation [a | b] (craft_wgrad_pk takes the B operand as up
+    to two packs).  Used for cat([h, x]) / cat([r*h, x]): x is packed once per GRU pass and shared by both gates."""
+    __slots__ = ("a", "b", "rows", "C", "K", "guard", "prec", "rows_p", "C_p", "Wp")
+
+    def __init__(self, a, b):
+        assert (a.K, a.guard, a.prec, a.rows_p, a.Wp) == (b.K, b.guard, b.prec, b.rows_p, b.Wp) and a.C_p % 32 == 0
+        self.a, self.b = a, b
+        self.rows, self.C, self.K, self.guard, self.prec, self.rows_p, self.Wp = a.rows, a.C + b.C, a.K, a.guard, a.prec, a.rows_p, a.Wp
+        self.C_p = a.C_p + b.C_p
+
+
+def _cat_pack(a, b):
+    return _CatPack(a, b)
+
+
+def update_params(model):
+    """The parameters of the update block in the order UpdateIter takes (and returns gradients for) them."""
+    ub = model.update_block
+    enc, gru, fh, agg = ub.encoder, ub.gru, ub.flow_head, ub.aggregator
+    ps = [enc.convc1.weight, enc.convc1.bias, enc.convc2.weight, enc.convc2.bias, enc.convf1.weight, enc.convf1.bias, enc.convf2.weight,
+          enc.convf2.bias, enc.conv.weight, enc.conv.bias]
+    for c in (gru.convz1, gru.convr1, gru.convq1, gru.convz2, gru.convr2, gru.convq2):
+        ps += [c.weight, c.bias]
+    ps += [fh.conv1.weight, fh.conv1.bias, fh.conv2.weight, fh.conv2.bias, ub.mask[0].weight, ub.mask[0].bias, ub.mask[2].weight, ub.mask[2].bias]
+    if model.args.use_setrans:
+        ps += [agg.first_linear.weight, agg.feat_softaggr.feat2score.weight, agg.input_skip_coeff]
+    else:
+        ps += [agg.to_v.weight, agg.gamma]
+    return ps
+
+
+def _param_grads(ps: UpdatePass):
+    """The accumulated gradients in the layout of update_params (PyTorch's [Cout, Cin, KH, KW])."""
+    m = ps.model
+    ub = m.update_block
+    enc, gru, fh, agg = ub.encoder, ub.gru, ub.flow_head, ub.aggregator
+    A = lambda *k: ps.cache[("acc", k)]             # noqa: E731
+
+    def conv(key, w, has_b=True):
+        co, ci = w.shape[0], w.shape[1]
+        return [A(*key, "dw")[:co, :, :, :ci].permute(0, 3, 1, 2), A(*key, "db")[:co] if has_b else None]
+    out = [A("c1", "dw")[:, : enc.convc1.weight.shape[1]].reshape(enc.convc1.weight.shape), A("c1", "db")]
+    out += conv(("c2",), enc.convc2.weight) + conv(("f1",), enc.convf1.weight) + conv(("f2",), enc.convf2.weight) + conv(("menc",), enc.conv.weight)
+    for p_ in (0, 1):
+        zr, zrb = A("zr", p_, "dw").permute(0, 3, 1, 2), A("zr", p_, "db")
+        qw, qb = A("q", p_, "dw").permute(0, 3, 1, 2), A("q", p_, "db")
+        out += [zr[:128], zrb[:128], zr[128:], zrb[128:], qw, qb]
+    out += conv(("fh1",), fh.conv1.weight) + conv(("fh2",), fh.conv2.weight) + conv(("mask0",), ub.mask[0].weight)
+    out += [A("mask2", "dw").reshape(ub.mask[2].weight.shape), A("mask2", "db")]
+    if ps.setrans:
+        Cv = agg.first_linear.weight.shape[0] // ps.pholder.P.shape[1]
+        red = torch.zeros(Cv + 1, device=ps.dev, dtype=torch.float32)
+        call("craft_reduce_replicas", ps.rep_agg, STATS_REPLICAS, Cv + 1, red)
+        out += [A("agg_v", "dw"), red[:Cv].reshape(agg.feat_softaggr.feat2score.weight.shape), red[Cv:].reshape(agg.input_skip_coeff.shape)]
+    else:
+        out += [A("agg_v", "dw").reshape(agg.to_v.weight.shape), ps.dgamma.view(agg.gamma.shape)]
+    return out

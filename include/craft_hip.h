@@ -199,6 +199,10 @@ int craft_conv2d_nhwc(const float* x, long ldx, int cin, const float* w, const f
  * craft_stem_conv7x7: BasicEncoder.conv1 (7x7, stride 2, pad 3, 3 -> 64; extractor.py:139,181) fused with the input
  * normalisation 2*(x/255)-1 (network.py:169-173): image NCHW [B][3][H][W] raw 0..255, w packed [147 = (ky*7+kx)*3
  * + c][64] (weight.permute(2,3,1,0)), out tokens [B][(H/2)*(W/2)][64] = act(conv + bias); stats as above. */
+/* craft_conv2d_nhwc over the virtual channel concatenation [x0 (c0 channels, row stride ld0) | x1 (c1, ld1)] (c1 = 0: x0 alone):
+ * the conv input of SepConvGRU's q gate, cat([r*h, x]) (update.py:54, :61), without materialising the cat.  c0, c1 multiples of 32. */
+int craft_conv2d_nhwc2(const float* x0, long ld0, int c0, const float* x1, long ld1, int c1, const float* w, const float* bias, int cout,
+                       int KH, int KW, int act, float* y, long ldy, int B, int H, int W, int prec, void* stream);
 int craft_conv2d_nhwc_ex(const float* x, long ldx, int cin, int Hin, int Win, const float* in_norm, const float* w,
                          const float* bias, int cout, int KH, int KW, int stride, int act, float* y, long ldy, int B,
                          int Hout, int Wout, double* stats, int prec, void* stream);
@@ -327,18 +331,21 @@ int craft_colsum(const float* x, long ld, long rows, int C, float* out, void* st
  *   Plain form (B = 0): pack row r holds source row r - guard (zero outside [0, rows)).  Spatial form (B > 0, rows = B*H*W pixels):
  *   pack row r holds pixel (b, y, x) of the ZERO-PADDED grid [B][H + 2 padH][W + 2 padW] at index r - guard, so that a convolution
  *   tap is one constant row shift dy * (W + 2 padW) + dx.  rows_p >= the rows the consumer reads, caller-allocated
- *   (planes * ceil(C/32) * rows_p * 64 bytes).  colsum (or NULL): colsum[c] += sum_r x[r][c] (a convolution's bias gradient rides
+ *   (planes * ncg_total * rows_p * 64 bytes).  cg_off / ncg_total: this source fills the 32-channel groups [cg_off, cg_off + ceil(C/32))
+ *   of a pack of ncg_total groups -- several calls build the pack of a channel concatenation without a torch.cat.  colsum (or NULL): colsum[c] += sum_r x[r][c] (a convolution's bias gradient rides
  *   on the pack of its dY).
  * craft_wgrad_pk: dW[co][tap][ci] += sum_{s < nseg} sum_{k < K} dYp[s][guard + k][co] * Xp[s][guard + k + shift(tap)][ci], shift(tap) =
  *   (tap / KW - KH/2) * Wp + (tap % KW - KW/2); cout, cin multiples of 32 (the packs' channel groups), K % 32 == 0, guard >=
  *   the largest |shift|, both packs built with the same geometry and prec.  dW in the [cout][KH][KW][cin] layout, ACCUMULATED
  *   (split-K partial sums are added with fp32 atomics).  KH = KW = 1: nn.Linear's weight gradient.  dYp / Xp: HOST arrays of nseg device
  *   pointers -- the packs of the nseg calls of one layer in a pass (the update block runs every layer once per refinement iteration:
- *   their weight gradient is ONE launch over the concatenated K, one atomic epilogue per pass instead of one per iteration). */
+ *   their weight gradient is ONE launch over the concatenated K, one atomic epilogue per pass instead of one per iteration).
+ *   Xp1 (or NULL) / cin0: the X operand as the channel concatenation of TWO packs over the same rows -- input channels [0, cin0) from
+ *   Xp[s], [cin0, cin) from Xp1[s] (cat([h, x]) / cat([r*h, x]) of SepConvGRU: x is packed once per pass and shared by both gates). */
 int craft_pack_operand(const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
-                       int prec, void* out, float* colsum, void* stream);
-int craft_wgrad_pk(const void* const* dYp, const void* const* Xp, int nseg, long dy_rows_p, int cout, long x_rows_p, int cin, long guard, long K,
-                   int KH, int KW, int Wp, float* dW, int prec, void* stream);
+                       int prec, void* out, int cg_off, int ncg_total, float* colsum, void* stream);
+int craft_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* const* Xp1, int cin0, int nseg, long dy_rows_p, int cout, long x_rows_p,
+                   int cin, long guard, long K, int KH, int KW, int Wp, float* dW, int prec, void* stream);
 
 int craft_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, void* stream);
 int craft_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,

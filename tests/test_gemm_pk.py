@@ -149,3 +149,29 @@ def test_segments_concatenate_k(device, nseg):
     acc = torch.zeros(cout, KH, KW, cin, device=device)
     AG.wgrad_pk(pairs, KH, KW, acc)
     assert ((acc.cpu().double() - ref).norm() / ref.norm()).item() < 2e-5
+
+
+@pytest.mark.parametrize("KH,KW", [(1, 5), (5, 1), (3, 3)])
+def test_two_pack_x_operand(device, KH, KW):
+    """The X operand as the channel concatenation of two packs (cat([h, x]) of SepConvGRU: x packed once per pass, h / r*h separately;
+    the first from a column slice of a wider buffer) equals the product over the materialised cat."""
+    from craft_amd.train_update import _CatPack
+    B, H, W, c0, c1, cout = 2, 10, 12, 128, 384, 256
+    g = torch.Generator().manual_seed(KH * 7 + KW)
+    wide = torch.randn(B, H * W, 640, generator=g).to(device)
+    h, x = wide[..., 128:256], wide[..., 256:640]
+    dy = torch.randn(B, H * W, cout, generator=g).to(device)
+    geom = (B, H, W, KH // 2, KW // 2)
+    gp = AG.Packed(dy, PREC_F16X3, geom)
+    acc = torch.zeros(cout, KH, KW, c0 + c1, device=device)
+    AG.wgrad_pk([(gp, _CatPack(AG.Packed(h, PREC_F16X3, geom), AG.Packed(x, PREC_F16X3, geom)))] * 3, KH, KW, acc)
+    ref = torch.zeros_like(acc)
+    AG.wgrad_pk([(gp, AG.Packed(torch.cat([h, x], -1).contiguous(), PREC_F16X3, geom))] * 3, KH, KW, ref)
+    for lo, hi in ((0, 128), (128, 512)):
+        e = ((acc[..., lo:hi] - ref[..., lo:hi]).norm() / ref[..., lo:hi].norm()).item()
+        assert e < 1e-6, (lo, hi, e)
+    # and a list of sources packed into ONE pack
+    one = AG.Packed([h, x], PREC_F16X3, geom)
+    acc2 = torch.zeros_like(acc)
+    AG.wgrad_pk([(gp, one)] * 3, KH, KW, acc2)
+    assert ((acc2 - ref).norm() / ref.norm()).item() < 1e-6
