@@ -20,8 +20,8 @@ Extra objects on the line:
                 step): algorithmic flops / time against the dense MFMA peak.
   cpu_baseline  the CPU oracle (oracle/craft_oracle.py, fp32 torch-CPU restatement of the reference's
                 forward) timed on this box's host cores on ONE 448x1024 pair, 12 iterations.
-  train_cfg3    a short leg of BASELINE.json configs[3] (training step at 368x496, batch 8/GPU: 3 warm-up + 5 timed steps, same
-                barrier / max-over-ranks protocol): ms_per_step, pairs_per_s and the roofline of the backward's dominant kernel
+  train_cfg3    a short leg of BASELINE.json configs[3] (training step at 368x496, batch 8/GPU: 6 warm-up + 5 timed steps, same
+                barrier / max-over-ranks protocol; 6 warm-up steps): ms_per_step, pairs_per_s and the roofline of the backward's dominant kernel
                 (k_conv_wgrad, timed live).  `python bench.py --train 3|4` is the full training benchmark (its own JSON line with
                 roofline and the CPU oracle's training step as cpu_baseline).
 """
@@ -452,7 +452,7 @@ def main():
     if not a.no_train_leg:
         del last["out"]
         torch.cuda.empty_cache()
-        tl = train_leg(3, rank, world, dev, steps=5, warmup=3, iters=12)
+        tl = train_leg(3, rank, world, dev, steps=5, warmup=6, iters=12)      # (6 warm-up steps: the caching allocator's pool settles after ~5)
 
     if rank == 0:
         line = {

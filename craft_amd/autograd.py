@@ -328,6 +328,7 @@ class SharedProbs:
     def __init__(self, P: torch.Tensor):
         self.P = P.detach()
         self.pending: List = []            # (dO_t [B, M, N, C], v_t [B, N, M*C]) of every use, in backward order
+        self.cat = None                    # or: the concatenations ([B, M, N, T*C] dO, V) already built by train_update._phase2
 
 
 class ProbsToken(Function):
@@ -348,7 +349,12 @@ class ProbsToken(Function):
         P = holder.P
         B, M, N, ld = P.shape
         dP = torch.zeros(B, M, N, ld, device=P.device, dtype=torch.float32) if ld != N else torch.empty_like(P)
-        if holder.pending:
+        if holder.cat is not None:
+            dO, V = holder.cat
+            K = dO.shape[-1]
+            gemm(dO, K, 1, M * N * K, N * K, V, K, 1, M * N * K, N * K, dP, ld, M * N * ld, N * ld, M, B * M, N, N, K, prec=ctx.prec)
+            holder.cat = None
+        elif holder.pending:
             T = len(holder.pending)
             C = holder.pending[0][0].shape[-1]
             dO = torch.cat([d for d, _ in holder.pending], dim=-1)                                   # [B, M, N, T*C]
@@ -547,6 +553,17 @@ def _conv_weights(w, b, cp, cache, transposed: bool):
         return hit
     Cout, Cin, KH, KW = w.shape
     cin_p, cout_p = round_up(Cin, 32), round_up(Cout, 32)
+    if cp != hip.PREC_F32 and KH * KW > 1 and KH <= 5 and KW <= 5:
+        # fragment-order operand in one launch, straight from the nn.Conv2d layout (padding, flip and transposition included)
+        wt = ops.pack_conv_weights(w, cp, transposed=transposed)
+        rows = cin_p if transposed else cout_p
+        bias = torch.zeros(rows, device=w.device, dtype=torch.float32)
+        if b is not None and not transposed:
+            bias[:Cout] = b.detach()
+        out = (wt, bias, hip.W_PACKED, None)
+        if cache is not None:
+            cache[key] = out
+        return out
     raw = cache.get((id(w), "raw")) if cache is not None else None
     if raw is None:
         raw = torch.zeros(cout_p, KH, KW, cin_p, device=w.device, dtype=torch.float32)

@@ -347,11 +347,19 @@ int craft_conv2d_nhwc(const float* x, long ldx, int cin, const float* w, const f
   return launch_gemm_conv(q, PREC_OF(prec), S(stream));
 }
 
-int craft_conv2d_nhwc2(const float* x0, long ld0, int c0, const float* x1, long ld1, int c1, const float* w, const float* bias, int cout,
-                       int KH, int KW, int act, float* y, long ldy, int B, int H, int W, int prec, void* stream) {
+int craft_pack_conv_weights(const float* w0, int cout0, const float* w1, int cout1, int Cin, int KH, int KW, int a0, int a1, int b0, int b1,
+                             int transposed, int prec, void* out, void* stream) {
+  return launch_pack_conv_weights(w0, cout0, w1, cout1, Cin, KH, KW, a0, a1, b0, b1, transposed, prec, out, S(stream));
+}
+
+int craft_conv2d_nhwc2(const float* x0, long ld0, int c0, const float* x1, long ld1, int c1, const float* w, const float* bias,
+                       const float* bias_field, long ld_bf, int cout, int KH, int KW, int act, float* y, long ldy, int B, int H, int W, int prec,
+                       void* stream) {
   if (c0 % 32 || c1 % 32 || c0 <= 0 || c1 < 0 || (c1 > 0 && x1 == nullptr)) return CRAFT_ERR_ALIGN;
+  if ((bias == nullptr) == (bias_field == nullptr)) return CRAFT_ERR_ARG;          // exactly one of the two
   ConvGemmParams q = conv_params(x0, (int)ld0, c0, c1 ? x1 : nullptr, (int)ld1, c1, B, H, W, KH, KW, w, bias, cout, CONV_EPI_BIAS_ACT, act, 1.f, y,
                                  (int)ldy);
+  q.bias_field = bias_field; q.ld_bf = (int)ld_bf;
   q.w_packed = PACKED_OF(prec);
   return launch_gemm_conv(q, PREC_OF(prec), S(stream));
 }

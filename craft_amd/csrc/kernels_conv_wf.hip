@@ -366,6 +366,75 @@ __global__ void k_pack_weights_wf(const float* __restrict__ w, int rows, int K, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// craft_pack_conv_weights: the same fragment order straight from PyTorch's conv weight layout [Cout][Cin][KH][KW] -- one launch
+// instead of permute / contiguous / cat / flip / zero-pad tensor ops in front of craft_pack_weights (a training step re-packs every
+// weight after every optimizer update: ~300 host-latency-bound tiny kernels per step).
+//   source: up to two weights concatenated along Cout (w0: cout0 rows, w1: cout1 rows; the z | r gates of SepConvGRU), and a
+//   selection of input channels [a0, a1) u [b0, b1) (all of them, or the hoisted / varying split of the GRU input).
+//   forward form   : row = co,  k = (ky * KW + kx) * Cp + c,  c-th selected input channel          (Cp = selected channels, % 32 == 0)
+//   transposed form: row = c-th selected input channel, k = (ky * KW + kx) * Cp + co, value W[co][ci][KH-1-ky][KW-1-kx]   (Cp = round_up(Cout, 32))
+// the operand of the INPUT-gradient convolution.  Rows / channels beyond the source are zero.
+// ---------------------------------------------------------------------------------------------
+struct PackConvParams {
+  const float* w0; const float* w1; int cout0, cout1, Cin, KH, KW, a0, a1, b0, b1, transposed, rows, Cp;
+};
+template <int PREC>
+__global__ void k_pack_conv_weights(PackConvParams p, void* __restrict__ out) {
+  typedef typename PrecT<PREC>::lds_t h_t;
+  constexpr int PL = Planes<PREC>::N;
+  const int NB = (p.rows + 31) / 32, taps = p.KH * p.KW;
+  const long K = (long)taps * p.Cp;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (kt, nb, kk, lane)
+  const long total = (K / 32) * NB * 128;
+  if (i >= total) return;
+  const int lane = (int)(i & 63), kk = (int)((i >> 6) & 1);
+  const long t = i >> 7;
+  const int nbi = (int)(t % NB);
+  const long kt = t / NB;
+  const int row = nbi * 32 + (lane & 31);
+  const long k = kt * 32 + kk * 16 + (lane >> 5) * 8;
+  const int tap = (int)(k / p.Cp), c0 = (int)(k - (long)tap * p.Cp);
+  const int ky = tap / p.KW, kx = tap - ky * p.KW;
+  const int nsel = (p.a1 - p.a0) + (p.b1 - p.b0), cout = p.cout0 + p.cout1;
+  h_t* o = reinterpret_cast<h_t*>(out) + (((kt * NB + nbi) * PL) * 2 + kk) * 512 + lane * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c0 + j;
+    int co, s, sy, sx;                       // source (co, s-th selected channel, tap)
+    if (p.transposed) { co = c; s = row; sy = p.KH - 1 - ky; sx = p.KW - 1 - kx; }
+    else { co = row; s = c; sy = ky; sx = kx; }
+    float v = 0.f;
+    if (co < cout && s < nsel) {
+      const int ci = s < p.a1 - p.a0 ? p.a0 + s : p.b0 + (s - (p.a1 - p.a0));
+      const float* w = co < p.cout0 ? p.w0 + (long)co * p.Cin * taps : p.w1 + (long)(co - p.cout0) * p.Cin * taps;
+      v = w[((long)ci * p.KH + sy) * p.KW + sx];
+    }
+    const h_t h = (h_t)v;
+    o[j] = h;
+    if constexpr (PL == 2) o[1024 + j] = (h_t)(v - (float)h);
+  }
+}
+
+int launch_pack_conv_weights(const float* w0, int cout0, const float* w1, int cout1, int Cin, int KH, int KW, int a0, int a1, int b0, int b1,
+                             int transposed, int prec, void* out, hipStream_t s) {
+  if (cout0 <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || cout1 < 0 || (cout1 > 0 && !w1)) return CRAFT_ERR_ARG;
+  if (a0 < 0 || a1 < a0 || a1 > Cin || b0 < 0 || b1 < b0 || b1 > Cin) return CRAFT_ERR_ARG;
+  PackConvParams p = {};
+  p.w0 = w0; p.w1 = w1; p.cout0 = cout0; p.cout1 = cout1; p.Cin = Cin; p.KH = KH; p.KW = KW; p.a0 = a0; p.a1 = a1; p.b0 = b0; p.b1 = b1;
+  p.transposed = transposed;
+  const int nsel = (a1 - a0) + (b1 - b0), cout = cout0 + cout1;
+  p.rows = transposed ? nsel : cout;
+  p.Cp = ((transposed ? cout : nsel) + 31) / 32 * 32;
+  const long total = ((long)KH * KW * p.Cp / 32) * ((p.rows + 31) / 32) * 128;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_pack_conv_weights<CRAFT_PREC_BF16>), grid, dim3(256), 0, s, p, out);
+  else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_pack_conv_weights<CRAFT_PREC_F16>), grid, dim3(256), 0, s, p, out);
+  else if (prec == CRAFT_PREC_F16X3) hipLaunchKernelGGL((k_pack_conv_weights<CRAFT_PREC_F16X3>), grid, dim3(256), 0, s, p, out);
+  else return CRAFT_ERR_UNSUPPORTED;
+  return (int)hipGetLastError();
+}
+
 int launch_pack_weights(const float* w, int rows, int K, int prec, void* out, hipStream_t s) {
   if (rows <= 0 || K <= 0) return 0;
   if (prec == CRAFT_PREC_F32) return (int)hipMemcpyAsync(out, w, (size_t)rows * K * sizeof(float), hipMemcpyDeviceToDevice, s);

@@ -162,16 +162,36 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_gen(GenGemmParams p) {
   gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, acc, NoFold());
   float* C = p.C + z0 * p.c_bs0 + z1 * p.c_bs1;
   const int rb = m0 + (wave / WN) * (BM / WM), cb = n0 + (wave % WN) * (BN / WN);
-  const bool atomic = p.ksplit > 1;
-  acc_foreach(acc, lane, [&](int r, int c, float v, int, int, int) {
-    const int row = rb + r, col = cb + c;
-    if (row < p.M && col < p.N) {
-      float* d = C + (long)row * p.ldc + col;
-      const float t = v * p.alpha;
-      if (atomic) unsafeAtomicAdd(d, t);
-      else *d = p.accumulate ? *d + t : t;
-    }
-  });
+  // The store mode is decided ONCE, outside the element loops (a per-element `accumulate ? *d + t : t` made hipcc branch around a
+  // load and wait for it 64 times per lane: the N x N score products, two K-tiles deep, spent most of their time there), and a
+  // tile that lies inside the matrix skips the bounds tests.
+  const int mode = p.ksplit > 1 ? 2 : (p.accumulate ? 1 : 0);
+  const float alpha = p.alpha;
+  const long ldc = p.ldc;
+  const int M = p.M, N = p.N;
+  const bool inside = rb + MT * 32 <= M && cb + NT * 32 <= N;
+  const int c = lane & 31, rh = 4 * (lane >> 5);
+  auto store_all = [&](auto&& put, auto inb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = cb + nt * 32 + c;
+        float* d0 = C + (long)(rb + mt * 32 + rh) * ldc + col;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = (e & 3) + 8 * (e >> 2);
+          if (decltype(inb)::value || (rb + mt * 32 + rh + r < M && col < N)) put(d0 + (long)r * ldc, acc[mt][nt][e] * alpha);
+        }
+      }
+  };
+  auto go = [&](auto inb) __attribute__((always_inline)) {
+    if (mode == 0) store_all([](float* d, float t) __attribute__((always_inline)) { *d = t; }, inb);
+    else if (mode == 1) store_all([](float* d, float t) __attribute__((always_inline)) { *d += t; }, inb);
+    else store_all([](float* d, float t) __attribute__((always_inline)) { unsafeAtomicAdd(d, t); }, inb);
+  };
+  if (inside) go(std::true_type());
+  else go(std::false_type());
 }
 
 template <int PREC, bool AT, bool BT> static int launch_gen_t(const GenGemmParams& p, hipStream_t s) {

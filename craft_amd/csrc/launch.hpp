@@ -56,6 +56,8 @@ int launch_pack_operand(const float* x, long ldx, int C, long rows, int B, int H
                         int prec, void* out, int cg_off, int ncg_total, float* colsum, hipStream_t s);
 int launch_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* const* Xp1, int cin0, int nseg, long dy_rows_p, int cout, long x_rows_p,
                     int cin, long guard, long K, int KH, int KW, int Wp, float* dW, int prec, hipStream_t s);
+int launch_pack_conv_weights(const float* w0, int cout0, const float* w1, int cout1, int Cin, int KH, int KW, int a0, int a1, int b0, int b1,
+                             int transposed, int prec, void* out, hipStream_t s);
 int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s);
 int launch_pv16(const RowsGemmParams& p, int prec, int rows32, hipStream_t s);   // A and B both 16-bit (type = prec), C fp32;
                                                                                   // rows32: 32-row groups per block (4..7), 0 = auto

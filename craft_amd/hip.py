@@ -68,7 +68,8 @@ _SIGS = {
     "craft_gemm": [P, L, L, L, L, P, L, L, L, L, P, L, L, L, I, I, I, I, I, F, I, I, I, P],
     "craft_conv2d_wgrad": [P, L, I, P, L, I, I, I, I, I, I, P, P, P, L, I, P],
     "craft_pack_operand": [P, L, I, L, I, I, I, I, I, L, L, I, P, I, I, P, P],
-    "craft_conv2d_nhwc2": [P, L, I, P, L, I, P, P, I, I, I, I, P, L, I, I, I, I, P],
+    "craft_pack_conv_weights": [P, I, P, I, I, I, I, I, I, I, I, I, I, P, P],
+    "craft_conv2d_nhwc2": [P, L, I, P, L, I, P, P, P, L, I, I, I, I, P, L, I, I, I, I, P],
     "craft_wgrad_pk": [P, P, P, I, I, L, I, L, I, L, L, I, I, I, P, I, P],
     "craft_norm_act_fwd": [P, L, P, I, P, P, I, P, L, P, L, I, I, I, P],
     "craft_norm_act_bwd_reduce": [P, L, P, L, P, L, P, I, P, P, I, I, P, I, I, I, P],

@@ -346,9 +346,33 @@ def pack_conv(w: torch.Tensor) -> torch.Tensor:
     return w.detach().permute(0, 2, 3, 1).contiguous().float()
 
 
+def pack_conv_weights(w0: torch.Tensor, prec: int, w1: Optional[torch.Tensor] = None, sel=None, transposed: bool = False) -> torch.Tensor:
+    """nn.Conv2d weights [Cout, Cin, KH, KW] (w0 and optionally w1 concatenated along Cout) -> the MFMA fragment-order operand of the
+    conv kernels in ONE launch (craft_pack_conv_weights): input channels ``sel`` = ((a0, a1), (b0, b1)) or None (all); ``transposed``:
+    the operand of the input-gradient convolution (rows = selected input channels, taps flipped).  16-bit / f16x3 precisions."""
+    w0 = w0.detach()
+    w0 = w0 if w0.is_contiguous() else w0.contiguous()
+    cout0, Cin, KH, KW = w0.shape
+    cout1 = 0
+    if w1 is not None:
+        w1 = w1.detach()
+        w1 = w1 if w1.is_contiguous() else w1.contiguous()
+        cout1 = w1.shape[0]
+        assert tuple(w1.shape[1:]) == (Cin, KH, KW)
+    (a0, a1), (b0, b1) = sel if sel is not None else ((0, Cin), (0, 0))
+    nsel, cout = (a1 - a0) + (b1 - b0), cout0 + cout1
+    rows, Cp = (nsel, round_up(cout, 32)) if transposed else (cout, round_up(nsel, 32))
+    planes = 2 if prec == hip.PREC_F16X3 else 1
+    out = torch.empty(planes * round_up(rows, 32) * KH * KW * Cp, device=w0.device, dtype=torch.bfloat16 if prec == hip.PREC_BF16 else torch.float16)
+    call("craft_pack_conv_weights", w0.float() if w0.dtype != torch.float32 else w0, cout0, w1, cout1, Cin, KH, KW, a0, a1, b0, b1, int(transposed), prec, out)
+    return out
+
+
 def pack_conv_prec(w: torch.Tensor, prec: int) -> torch.Tensor:
     """[Cout, Cin, KH, KW] -> the weight operand the KxK conv kernels take with W_PACKED (craft_pack_weights): fp32 stays
     [Cout, KH, KW, Cin]; bf16 / fp16 / f16x3 become MFMA fragment order [K/32][ceil(Cout/32)][planes][2][64][8] (flat)."""
+    if prec != PREC_F32 and w.dtype == torch.float32:
+        return pack_conv_weights(w, prec)
     wp = pack_conv(w)
     if prec == PREC_F32:
         return wp

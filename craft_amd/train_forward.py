@@ -181,9 +181,8 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
         model.__dict__["_train_pass_cache"] = ups.cache
         params = TU.update_params(model)
         preds = []
-        for t in range(iters):
-            corr = AG.CorrLookup.apply(token, coords1, holder, radius_)              # network.py:235 (coords1 carries no gradient, :232)
-            net, up, coords1 = TU.UpdateIter.apply(net, corr, ptoken, inp, ups, t, coords1, coords0, *params)
+        for t in range(iters):       # (the correlation lookup of network.py:235 is part of the node: coords1 carries no gradient, :232)
+            net, up, coords1 = TU.UpdateIter.apply(net, token, ptoken, inp, ups, t, coords1, coords0, *params)
             preds.append(up)
         return preds
     ub = model.update_block

@@ -7,8 +7,13 @@ small autograd.Functions: correct, but every ``torch.cat`` / zero fill / gradien
 step, 8 % of the kernel time) and the forward could not use the fused inference kernels.  Here the iteration works on ONE 640-wide
 token buffer per iteration
 
-    HX_t = [ h1 (128) | h0 (128) | inp (128) | mf (128) | mfg (128) ]          h0 = net_t, h1 = hidden state after the horizontal GRU pass,
-                                                                              the vertical pass writes net_{t+1} into HX_{t+1}'s h0 slot
+    HX_t = [ h1 (128) | h0 (128) | mf (128) | mfg (128) ]          h0 = net_t, h1 = hidden state after the horizontal GRU pass,
+                                                                  the vertical pass writes net_{t+1} into HX_{t+1}'s h0 slot
+
+The context features ``inp`` are the same in every iteration, so their share of the six gate convolutions is hoisted out of the loop in
+BOTH directions (as the inference path hoists the forward): forward = per-pixel bias fields computed once (``craft_sepconv_gru_context``),
+the per-iteration convolutions run over [h | mf | mfg] only (K 2560 -> 1920); backward = the gate gradients dY are summed over the
+iterations and ONE input-gradient convolution and ONE weight-gradient product per gate convolution handle the inp channels at the end.
 
 (every ``torch.cat`` of update.py is a column range, the q gate's cat([r*h, x]) a two-segment convolution input), the forward runs
 the inference entry points where they keep what the backward needs (``craft_motion_encoder``, ``craft_flow_head``, ``craft_mask_head``:
@@ -27,8 +32,8 @@ from . import autograd as AG
 from . import hip, ops
 from .hip import ACT_NONE, ACT_RELU, STATS_REPLICAS, W_PACKED, call, pick, round_up
 
-_C = 640          # columns of HX
-H1, H0, INP, MF, MFG = 0, 128, 256, 384, 512
+_C = 512          # columns of HX
+H1, H0, MF, MFG = 0, 128, 256, 384
 
 
 class UpdatePass:
@@ -47,23 +52,38 @@ class UpdatePass:
         self.setrans = bool(model.args.use_setrans)
         # one buffer for all iterations (+ 1: the last iteration's net_{T} slot); inp is written once for all of them
         self.HX = torch.empty(iters + 1, B, self.N, _C, device=dev, dtype=torch.float32)
-        self.HX[:iters, :, :, INP:INP + 128] = inp.detach()
         self.HX[0, :, :, H0:H0 + 128] = net.detach()
+        self.inp = AG._rows(inp.detach())
         self.cache = {}            # conv operand cache of the pass (transposed weights), gradient accumulators, queued packs
         gru = ub.gru
-        # forward weights: the inference modules' packed copies (re-made when the optimizer bumps the weights epoch)
+        # forward weights: the inference modules' packed copies (re-made when the optimizer bumps the weights epoch); one stream here,
+        # so no device synchronisation behind the re-packing
+        from . import update as _U
+        _sync, _U.PACK_SYNC[0] = _U.PACK_SYNC[0], False
         self.w_enc = ub.encoder.packed(self.cp)
-        self.w_gru = gru.packed(self.cp)           # (wzr1, bzr1, wq1, bq1, wzr2, bzr2, wq2, bq2), input channel order [h | inp | mf | mfg]
+        # gate convolutions over [h | mf | mfg] (the inp channels 128..255 of the 512-channel input are hoisted): (zr1, q1, zr2, q2)
+        self.w_gru, _ = gru.packed_split(self.cp, 128, 256)
+        self.fields = gru.context_tokens(self.inp, hw, prec)        # [B, N, 768]: inp's share + bias of zr1 | q1 | zr2 | q2
         self.w_fh = ub.flow_head.packed(self.cp)
         self.w_mask = ub.packed_mask(self.cp)
-        # the z|r gates as one 256-row weight (their gradient is split again at the end of the pass)
-        self.wzr = [torch.cat([gru.convz1.weight, gru.convr1.weight], 0).detach(), torch.cat([gru.convz2.weight, gru.convr2.weight], 0).detach()]
-        self.wq = [gru.convq1.weight, gru.convq2.weight]
-        self.d_inp = torch.zeros(B, self.N, 128, device=dev, dtype=torch.float32)
+        _U.PACK_SYNC[0] = _sync
+        # input-gradient operands of the gate convolutions (flipped / transposed, one launch each): the varying channels [h | mf | mfg]
+        # per iteration, the hoisted inp channels once per pass
+        VAR, INP_ = ((0, 128), (256, 512)), ((128, 256), (0, 0))
+        zr = [(gru.convz1.weight, gru.convr1.weight), (gru.convz2.weight, gru.convr2.weight)]
+        q = [gru.convq1.weight, gru.convq2.weight]
+        self.wzrT = [ops.pack_conv_weights(a, self.cp, b, sel=VAR, transposed=True) for a, b in zr]
+        self.wqT = [ops.pack_conv_weights(a, self.cp, None, sel=VAR, transposed=True) for a in q]
+        self.wzrT_inp = [ops.pack_conv_weights(a, self.cp, b, sel=INP_, transposed=True) for a, b in zr]
+        self.wqT_inp = [ops.pack_conv_weights(a, self.cp, None, sel=INP_, transposed=True) for a in q]
+        self.zero_bias = torch.zeros(1024, device=dev, dtype=torch.float32)
+        self.dysum = {}            # (gate, pass) -> sum over the iterations of that convolution's output gradient (for the inp channels)
         self.rep_agg = None        # replicated (dw_agg, dskip) table of the aggregator's pooling, reduced at the end of the pass
         self.dgamma = None
         self.saved = [None] * iters
+        self.dv = [None] * iters
         self.zero1 = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.zero_tok = None
 
     # ---- gradient accumulators ------------------------------------------------------------------------------------
     def acc(self, key, shape):
@@ -87,11 +107,15 @@ def _flow32(flow, B, N):
     return f
 
 
-def _conv_dx(ps: UpdatePass, w, g, cout_p, KH, KW, out=None):
+def _conv_dx(ps: UpdatePass, w, g, cout_p, KH, KW, out=None, cin_p=None):
     """Input gradient of a stride-1 'same' convolution: the forward kernel with flipped / transposed weights.  g [B, N, cout_p]
-    (row stride may exceed cout_p) -> [B, N, cin_p]."""
-    wt, zb, flag, _ = AG._conv_weights(w, None, ps.cp, ps.cache, True)
-    cin_p = round_up(w.shape[1], 32)
+    (row stride may exceed cout_p) -> [B, N, cin_p].  w: the nn.Conv2d weight, or (with cin_p) an operand already packed by
+    ops.pack_conv_weights(transposed=True)."""
+    if cin_p is None:
+        wt, zb, flag, _ = AG._conv_weights(w, None, ps.cp, ps.cache, True)
+        cin_p = round_up(w.shape[1], 32)
+    else:
+        wt, zb, flag = w, ps.zero_bias, W_PACKED
     if out is None:
         out = torch.empty(ps.B, ps.N, cin_p, device=ps.dev, dtype=torch.float32)
     call("craft_conv2d_nhwc", g, g.stride(-2), cout_p, wt, zb, cin_p, KH, KW, ACT_NONE, out, out.stride(-2), ps.B, ps.hw[0], ps.hw[1], ps.cp | flag)
@@ -107,17 +131,28 @@ def _act_bwd(dy, y, C, out=None, act=ACT_RELU, scale=1.0):
 
 
 class UpdateIter(Function):
-    """(net_t, corr_t, P token, inp, *parameters) -> (net_{t+1}, flow prediction t)."""
+    """(net_t, correlation token, P token, inp, *parameters) -> (net_{t+1}, flow prediction t, coords1_{t+1}).
+
+    Backward in two phases.  The motion features of iteration t depend on the (detached, network.py:232) coordinates only -- not on
+    net_t -- so their gradient never re-enters the recurrence: phase 1 (this node's backward, iterations in reverse) runs the heads
+    and the SepConvGRU and keeps the gradient of [mf | mfg]; phase 2 (once, inside the backward of iteration 0) runs aggregator,
+    motion encoder and correlation-lookup gradients of ALL iterations, with the 12 products dV_t = P^T dO_t as ONE product over the
+    concatenated dO (the 1 GB of attention probabilities is streamed once instead of twelve times; the same concatenation serves the
+    deferred dP = [dO_1 .. dO_T] [V_1 .. V_T]^T of autograd.ProbsToken).  The correlation pyramid's and P's gradients leave through the
+    two token inputs (autograd.CorrVolume / ProbsToken run after every node that took the token)."""
 
     @staticmethod
-    def forward(ctx, net, corr, ptoken, inp, ps: UpdatePass, t: int, coords1, coords0, *params):
+    def forward(ctx, net, token, ptoken, inp, ps: UpdatePass, t: int, coords1, coords0, *params):
         m = ps.model
         ub = m.update_block
         B, N, (H8, W8) = ps.B, ps.N, ps.hw
         rows, cp, prec, dev = B * N, ps.cp, ps.prec, ps.dev
         hx, hxn = ps.HX[t], ps.HX[t + 1]
-        corr = AG._rows(corr)
-        S = {}
+        coords1 = AG._c(coords1.detach())
+        corr = ops.corr_lookup(ps.holder.pyr, coords1, ps.radius)                    # network.py:235 / corr.py:47-71
+        S = {"coords": coords1}
+        if ps.zero_tok is None:
+            ps.zero_tok = torch.zeros_like(token)
         flow = coords1 - coords0                                                     # [B, N, 2]
         # ---- BasicMotionEncoder (update.py:79-87): one fused call; its workspace keeps cor1 | [cor2 | flo2] | flo1
         me = torch.empty(rows * 640, device=dev, dtype=torch.float32)
@@ -152,25 +187,26 @@ class UpdateIter(Function):
             ops.gma_residual(mf, Oa.view(B, N, Cv), agg.gamma.detach(), out=hx[..., MFG:MFG + 128])
         S["va"], S["Oa"] = va, Oa
         S["pk_mf"] = AG.Packed(mf, pick(prec, "proj"))
-        # ---- SepConvGRU (update.py:49-64): horizontal pass h0 -> h1 (in HX_t), vertical pass h1 -> net_{t+1} (into HX_{t+1})
-        wzr1, bzr1, wq1, bq1, wzr2, bzr2, wq2, bq2 = ps.w_gru
-        x = hx[..., INP:INP + 384]
-        for p_, (KH, KW, wzr, bzr, wq, bq) in enumerate(((1, 5, wzr1, bzr1, wq1, bq1), (5, 1, wzr2, bzr2, wq2, bq2))):
+        # ---- SepConvGRU (update.py:49-64): horizontal pass h0 -> h1 (in HX_t), vertical pass h1 -> net_{t+1} (into HX_{t+1});
+        # convolutions over [h | v], v = [mf | mfg]; inp's share and the biases arrive as per-pixel fields
+        wzr1, wq1, wzr2, wq2 = ps.w_gru
+        v = hx[..., MF:MF + 256]
+        F_ = ps.fields
+        for p_, (KH, KW, wzr, wq, fz, fq) in enumerate(((1, 5, wzr1, wq1, 0, 256), (5, 1, wzr2, wq2, 384, 640))):
             h = hx[..., H0:H0 + 128] if p_ == 0 else hx[..., H1:H1 + 128]
             hn = hx[..., H1:H1 + 128] if p_ == 0 else hxn[..., H0:H0 + 128]
             geom = (B, H8, W8, KH // 2, KW // 2)
             zr_pre = torch.empty(B, N, 256, device=dev, dtype=torch.float32)
-            call("craft_conv2d_nhwc2", h, _C, 128, x, _C, 384, wzr, bzr, 256, KH, KW, ACT_NONE, zr_pre, 256, B, H8, W8, cp | W_PACKED)
+            call("craft_conv2d_nhwc2", h, _C, 128, v, _C, 256, wzr, None, F_[..., fz:], 768, 256, KH, KW, ACT_NONE, zr_pre, 256, B, H8, W8, cp | W_PACKED)
             z, r, rh = (torch.empty(B, N, 128, device=dev, dtype=torch.float32) for _ in range(3))
             call("craft_gru_zr_fwd", zr_pre, 256, h, _C, z, r, rh, rows, 128)
             q_pre = zr_pre[..., :128]                                                # (zr_pre is dead: reuse its first half)
-            call("craft_conv2d_nhwc2", rh, 128, 128, x, _C, 384, wq, bq, 128, KH, KW, ACT_NONE, q_pre, 256, B, H8, W8, cp | W_PACKED)
+            call("craft_conv2d_nhwc2", rh, 128, 128, v, _C, 256, wq, None, F_[..., fq:], 768, 128, KH, KW, ACT_NONE, q_pre, 256, B, H8, W8, cp | W_PACKED)
             q = torch.empty(B, N, 128, device=dev, dtype=torch.float32)
             call("craft_gru_out_fwd", q_pre, 256, z, h, _C, q, hn, _C, rows, 128)
-            pk_x = AG.Packed(x, cp, geom)                                            # shared by the z|r and the q convolution of this pass
             S[f"pk_h{p_}"] = AG.Packed(h, cp, geom)
             S[f"pk_rh{p_}"] = AG.Packed(rh, cp, geom)
-            S[f"pk_x{p_}"] = pk_x
+            S[f"pk_v{p_}"] = AG.Packed(v, cp, geom)                                  # shared by the z|r and the q convolution of this pass
             S[f"z{p_}"], S[f"r{p_}"], S[f"q{p_}"] = z, r, q
         h2 = hxn[..., H0:H0 + 128]
         S["pk_h2"] = AG.Packed(h2, cp, g3)
@@ -196,7 +232,6 @@ class UpdateIter(Function):
     def backward(ctx, d_hn, d_up, _dc):
         ps, t = ctx.ps, ctx.t
         S = ps.saved[t]
-        ps.saved[t] = None
         m = ps.model
         ub = m.update_block
         enc, gru, fh, agg = ub.encoder, ub.gru, ub.flow_head, ub.aggregator
@@ -237,13 +272,13 @@ class UpdateIter(Function):
                 dh2.add_(d_hn)
         elif d_hn is not None:
             dh2 = AG._c(d_hn).clone()
-        S.pop("pk_h2"); S.pop("pk_fh1"); S.pop("pk_mh")
+        for k in ("pk_h2", "pk_fh1", "pk_mh", "fh1", "mh", "mask", "flow_new"):
+            S.pop(k)
         if dh2 is None:
             raise RuntimeError("UpdateIter.backward without any output gradient")
 
         # ---- SepConvGRU, vertical pass then horizontal pass
-        x = hx[..., INP:INP + 384]
-        dx = None
+        dv = None
         dh = dh2
         for p_, (KH, KW) in ((1, (5, 1)), (0, (1, 5))):
             h = hx[..., H0:H0 + 128] if p_ == 0 else hx[..., H1:H1 + 128]
@@ -251,43 +286,76 @@ class UpdateIter(Function):
             geom = (B, H8, W8, KH // 2, KW // 2)
             dqp, dz, dhp = E(B, N, 128), E(B, N, 128), E(B, N, 128)
             call("craft_gru_out_bwd", dh, dh.stride(-2), z, q, h, _C, dqp, dz, dhp, rows, 128)
-            tq = _conv_dx(ps, ps.wq[p_], dqp, 128, KH, KW)                                    # d[rh | x]
-            bq = (gru.convq1 if p_ == 0 else gru.convq2)
-            ps.wgrad(("q", p_), (AG.Packed(dqp, cp, geom, colsum=ps.acc(("q", p_, "db"), (128,))), _cat_pack(S[f"pk_rh{p_}"], S[f"pk_x{p_}"])), KH, KW,
-                     ps.acc(("q", p_, "dw"), (128, KH, KW, 512)), last)
+            tq = _conv_dx(ps, ps.wqT[p_], dqp, 128, KH, KW, cin_p=384)                        # d[rh | mf | mfg]
+            ps.wgrad(("q", p_), (AG.Packed(dqp, cp, geom, colsum=ps.acc(("q", p_, "db"), (128,))), _cat_pack(S[f"pk_rh{p_}"], S[f"pk_v{p_}"])), KH, KW,
+                     ps.acc(("q", p_, "dw"), (128, KH, KW, 384)), last)
             dzr = E(B, N, 256)
-            call("craft_gru_zr_bwd", dz, tq, 512, z, r, h, _C, dzr, dhp, rows, 128)            # dhp += d(rh) r
-            tz = _conv_dx(ps, ps.wzr[p_], dzr, 256, KH, KW)                                   # d[h | x]
-            ps.wgrad(("zr", p_), (AG.Packed(dzr, cp, geom, colsum=ps.acc(("zr", p_, "db"), (256,))), _cat_pack(S[f"pk_h{p_}"], S[f"pk_x{p_}"])), KH, KW,
-                     ps.acc(("zr", p_, "dw"), (256, KH, KW, 512)), last)
+            call("craft_gru_zr_bwd", dz, tq, 384, z, r, h, _C, dzr, dhp, rows, 128)            # dhp += d(rh) r
+            tz = _conv_dx(ps, ps.wzrT[p_], dzr, 256, KH, KW, cin_p=384)                       # d[h | mf | mfg]
+            ps.wgrad(("zr", p_), (AG.Packed(dzr, cp, geom, colsum=ps.acc(("zr", p_, "db"), (256,))), _cat_pack(S[f"pk_h{p_}"], S[f"pk_v{p_}"])), KH, KW,
+                     ps.acc(("zr", p_, "dw"), (256, KH, KW, 384)), last)
             dhp.add_(tz[..., :128])
-            if dx is None:
-                dx = torch.add(tq[..., 128:], tz[..., 128:])
+            if dv is None:
+                dv = torch.add(tq[..., 128:], tz[..., 128:])
             else:
-                dx.add_(tq[..., 128:]).add_(tz[..., 128:])
+                dv.add_(tq[..., 128:]).add_(tz[..., 128:])
+            # the inp channels see the SUM of the gate gradients over the iterations (one input-gradient convolution and one
+            # weight-gradient product per gate convolution at the end of the pass)
+            for kind, g in (("q", dqp), ("zr", dzr)):
+                if (kind, p_) in ps.dysum:
+                    ps.dysum[(kind, p_)].add_(g)
+                else:
+                    ps.dysum[(kind, p_)] = g                   # (this iteration's own buffer: nobody else holds it)
             dh = dhp
-            for k in (f"pk_h{p_}", f"pk_rh{p_}", f"pk_x{p_}", f"z{p_}", f"r{p_}", f"q{p_}"):
+            for k in (f"pk_h{p_}", f"pk_rh{p_}", f"pk_v{p_}", f"z{p_}", f"r{p_}", f"q{p_}"):
                 S.pop(k)
         d_net = dh                                                                            # gradient of net_t
-        ps.d_inp.add_(dx[..., 0:128])
-        d_mfg = dx[..., 256:384]
-        mf = hx[..., MF:MF + 128]
-        # ---- motion aggregator
-        P = ps.pholder.P
-        _, M, _, ld = P.shape
-        va, Oa = S["va"], S["Oa"]
-        Cv = Oa.shape[-1]
-        pv = pick(prec, "pv")
-        pp = pick(prec, "proj")
+        ps.dv[t] = dv                                                                         # gradient of [mf | mfg]: phase 2
+        ps.saved[t] = S
+        d_inp = None
+        if last:
+            # ---- the hoisted inp channels: d_inp = sum over the four gate convolutions of conv^T(W_inp, sum_t dY_t), dW_inp = (sum_t dY_t)^T inp
+            for p_, (KH, KW) in ((0, (1, 5)), (1, (5, 1))):
+                geom = (B, H8, W8, KH // 2, KW // 2)
+                pk_inp = AG.Packed(ps.inp, cp, geom)
+                for kind, w_inp, co in (("zr", ps.wzrT_inp[p_], 256), ("q", ps.wqT_inp[p_], 128)):
+                    g = ps.dysum.pop((kind, p_))
+                    di = _conv_dx(ps, w_inp, g, co, KH, KW, cin_p=128)
+                    d_inp = di if d_inp is None else d_inp.add_(di)
+                    AG.wgrad_pk([(AG.Packed(g, cp, geom), pk_inp)], KH, KW, ps.acc((kind, p_, "dw_inp"), (co, KH, KW, 128)))
+        if last:
+            _phase2(ps)
+        grads = _param_grads(ps) if last else (None,) * ctx.nparams
+        return (d_net, ps.zero_tok, ps.zero1, d_inp, None, None, None, None) + tuple(grads)
+
+
+def _phase2(ps: UpdatePass):
+    """Aggregator, motion-encoder and correlation-lookup gradients of all iterations (see UpdateIter)."""
+    m = ps.model
+    ub = m.update_block
+    enc, agg = ub.encoder, ub.aggregator
+    B, N, (H8, W8), T = ps.B, ps.N, ps.hw, ps.iters
+    rows, cp, prec, dev = B * N, ps.cp, ps.prec, ps.dev
+    g3, g7 = (B, H8, W8, 1, 1), (B, H8, W8, 3, 3)
+    E = lambda *s_: torch.empty(*s_, device=dev, dtype=torch.float32)      # noqa: E731
+    P = ps.pholder.P
+    _, M, _, ld = P.shape
+    pv, pp = pick(prec, "pv"), pick(prec, "proj")
+    Cv = ps.saved[0]["Oa"].shape[-1]
+    # ---- A: gradient of the aggregator's pooling per iteration -> dO_t, the direct part of d mf_t
+    dOs, d_mfs = [], []
+    for t in range(T):
+        S, dv = ps.saved[t], ps.dv[t]
+        mf = ps.HX[t][..., MF:MF + 128]
+        d_mfg = dv[..., 128:256]
         d_mf = E(B, N, 128)
         if ps.setrans:
             if ps.rep_agg is None:
                 ps.rep_agg = torch.zeros(STATS_REPLICAS, Cv + 1, device=dev, dtype=torch.float32)
-            dOa = torch.empty_like(Oa)
+            dOa = torch.empty_like(S["Oa"])
             w_agg, skip = agg.feat_softaggr.feat2score.weight, agg.input_skip_coeff
-            call("craft_mode_pool_ln_bwd", Oa, mf, _C, AG._c(w_agg.detach()).view(-1), skip.detach(), d_mfg, d_mfg.stride(-2), B, N, M, Cv, dOa, d_mf, 128,
-                 ps.rep_agg)
-            w_v = agg.first_linear.weight
+            call("craft_mode_pool_ln_bwd", S["Oa"], mf, _C, AG._c(w_agg.detach()).view(-1), skip.detach(), d_mfg, d_mfg.stride(-2), B, N, M, Cv, dOa, d_mf,
+                 128, ps.rep_agg)
         else:
             gamma = agg.gamma
             dmc = d_mfg.contiguous()
@@ -295,21 +363,36 @@ class UpdateIter(Function):
             if ps.dgamma is None:
                 ps.dgamma = torch.zeros(1, 1, device=dev, dtype=torch.float32)
             K = B * N * Cv
-            AG.gemm(dmc, K, 1, 0, 0, Oa, K, 1, 0, 0, ps.dgamma, 1, 0, 0, 1, 1, 1, 1, K, accumulate=True, ksplit=0, prec=hip.PREC_F16X3)
+            AG.gemm(dmc, K, 1, 0, 0, S["Oa"], K, 1, 0, 0, ps.dgamma, 1, 0, 0, 1, 1, 1, 1, K, accumulate=True, ksplit=0, prec=hip.PREC_F16X3)
             d_mf.copy_(d_mfg)
-            w_v = agg.to_v.weight
-        dva = E(B, N, M * Cv)
-        AG.gemm(P, 1, ld, M * N * ld, N * ld, dOa, 1, Cv, M * N * Cv, N * Cv, dva, M * Cv, N * M * Cv, Cv, M, B * M, N, Cv, N, prec=pv)
-        ps.pholder.pending.append((dOa, va))
-        wv2 = w_v.detach().view(M * Cv, 128)
+        dOs.append(dOa)
+        d_mfs.append(d_mf)
+        S.pop("Oa")
+    # ---- B: dV of all iterations in one product over the concatenated dO (P is read once), and the operands of the deferred dP
+    TC = T * Cv
+    dO_cat = torch.cat(dOs, dim=-1) if T > 1 else dOs[0]                                     # [B, M, N, T*Cv]
+    del dOs
+    dva_cat = E(B, N, M, TC)
+    AG.gemm(P, 1, ld, M * N * ld, N * ld, dO_cat, 1, TC, M * N * TC, N * TC, dva_cat, M * TC, N * M * TC, TC, M, B * M, N, TC, N, prec=pv)
+    V_cat = torch.cat([ps.saved[t]["va"].view(B, N, M, Cv).permute(0, 2, 1, 3) for t in range(T)], dim=-1)    # [B, M, N, T*Cv]
+    ps.pholder.cat = (dO_cat, V_cat)
+    w_v = agg.first_linear.weight if ps.setrans else agg.to_v.weight
+    wv2 = w_v.detach().view(M * Cv, 128)
+    dva5 = dva_cat.view(B, N, M, T, Cv)
+    for t in range(T):
+        S = ps.saved[t]
+        last = t == T - 1                                    # (the order of phase 2 is free: the accumulators complete with its last iteration)
+        mf = ps.HX[t][..., MF:MF + 128]
+        d_mf = d_mfs[t]
+        dva = dva5[:, :, :, t, :].reshape(B, N, M * Cv)              # M > 1: a contiguous copy; one mode: a strided view (row stride T*Cv)
         d_mf3 = E(B, N, 128)
-        AG.gemm(dva, M * Cv, 1, 0, 0, wv2, 1, 128, 0, 0, d_mf3, 128, 0, 0, 1, 1, rows, 128, M * Cv, prec=pp)
+        AG.gemm(dva, dva.stride(-2), 1, 0, 0, wv2, 1, 128, 0, 0, d_mf3, 128, 0, 0, 1, 1, rows, 128, M * Cv, prec=pp)
         ps.wgrad(("agg_v",), (AG.Packed(dva, pp), S["pk_mf"]), 1, 1, ps.acc(("agg_v", "dw"), (M * Cv, 128)), last)
-        d_mf.add_(d_mf3).add_(dx[..., 128:256])
+        d_mf.add_(d_mf3).add_(ps.dv[t][..., 0:128])
+        ps.dv[t] = None
         # ---- BasicMotionEncoder
-        d_mf[..., 126:128] = 0.0                                                              # the two pass-through flow channels carry no gradient
         g_out = _act_bwd(d_mf, mf, 128, out=d_mf)
-        g_out[..., 126:128] = 0.0
+        g_out[..., 126:128] = 0.0                                                             # the two pass-through flow channels carry no gradient
         d_cf = _conv_dx(ps, enc.conv.weight, g_out, 128, 3, 3)
         ps.wgrad(("menc",), (AG.Packed(g_out, cp, g3, colsum=ps.acc(("menc", "db"), (128,))), S["pk_cf"]), 3, 3, ps.acc(("menc", "dw"), (128, 3, 3, 256)), last)
         g_cf = _act_bwd(d_cf, S["cf"], 256, out=d_cf)
@@ -326,10 +409,12 @@ class UpdateIter(Function):
         ps.wgrad(("f2",), (AG.Packed(g_f2, cp, g3, colsum=ps.acc(("f2", "db"), (64,))), S["pk_flo1"]), 3, 3, ps.acc(("f2", "dw"), (64, 3, 3, 128)), last)
         g_flo1 = _act_bwd(d_flo1, S["flo1"], 128, out=d_flo1)
         ps.wgrad(("f1",), (AG.Packed(g_flo1, cp, g7, colsum=ps.acc(("f1", "db"), (128,))), S["pk_flow"]), 7, 7, ps.acc(("f1", "dw"), (128, 7, 7, 32)), last)
+        # ---- correlation lookup (corr.py:47-71): the gradient goes into the shared buffers of the normalised pyramid; autograd.CorrVolume
+        # (every iteration took its token) folds them into the volume's gradient after this node
+        pyr, G = ps.holder.pyr, ps.holder.grads()
+        call("craft_corr_lookup_bwd", d_corr, d_corr.stride(-2), S["coords"], G[0], G[1], G[2], G[3], pyr.levels, pyr.B, pyr.H8, pyr.W8, ps.radius, 0, 0)
         S.clear()
-        grads = _param_grads(ps) if last else (None,) * ctx.nparams
-        d_inp = ps.d_inp if last else None
-        return (d_net, d_corr, ps.zero1, d_inp, None, None, None, None) + tuple(grads)
+        ps.saved[t] = None
 
 
 class _CatPack:
@@ -377,8 +462,11 @@ def _param_grads(ps: UpdatePass):
     out = [A("c1", "dw")[:, : enc.convc1.weight.shape[1]].reshape(enc.convc1.weight.shape), A("c1", "db")]
     out += conv(("c2",), enc.convc2.weight) + conv(("f1",), enc.convf1.weight) + conv(("f2",), enc.convf2.weight) + conv(("menc",), enc.conv.weight)
     for p_ in (0, 1):
-        zr, zrb = A("zr", p_, "dw").permute(0, 3, 1, 2), A("zr", p_, "db")
-        qw, qb = A("q", p_, "dw").permute(0, 3, 1, 2), A("q", p_, "db")
+        def full(kind):       # input channels [h | inp | mf | mfg]: h, mf, mfg from the per-iteration products, inp from the hoisted one
+            var, hoisted = A(kind, p_, "dw"), A(kind, p_, "dw_inp")
+            return torch.cat([var[..., :128], hoisted, var[..., 128:]], dim=-1).permute(0, 3, 1, 2)
+        zr, zrb = full("zr"), A("zr", p_, "db")
+        qw, qb = full("q"), A("q", p_, "db")
         out += [zr[:128], zrb[:128], zr[128:], zrb[128:], qw, qb]
     out += conv(("fh1",), fh.conv1.weight) + conv(("fh2",), fh.conv2.weight) + conv(("mask0",), ub.mask[0].weight)
     out += [A("mask2", "dw").reshape(ub.mask[2].weight.shape), A("mask2", "db")]

@@ -20,6 +20,10 @@ from .hip import conv_group_prec, PREC_F32, W_PACKED, call, pick, weights_epoch
 from .setrans import ExpandedFeatTrans
 
 
+PACK_SYNC = [True]      # False inside a training pass (single stream: the packed copies are consumed in stream order; a device
+                        # synchronisation after every re-pack -- every step -- would drain the pipeline six times per step)
+
+
 class _PackCache:
     """Caches re-laid-out weights; invalidated when any source parameter is updated in place or replaced."""
 
@@ -35,7 +39,7 @@ class _PackCache:
             self._key = key
             # the packed copy may be consumed on other HIP streams (batch-sliced refinement loop): packing happens
             # once per weight update, so simply finish it before anybody can see it
-            if torch.cuda.is_available():
+            if torch.cuda.is_available() and PACK_SYNC[0]:
                 torch.cuda.current_stream().synchronize()
         return self._val
 
@@ -88,11 +92,16 @@ class SepConvGRU(nn.Module):
 
         def make():
             var, const = [], []
+            cin = self.hidden_dim + self.input_dim
             for z, r, q in ((self.convz1, self.convr1, self.convq1), (self.convz2, self.convr2, self.convq2)):
-                for w, b in ((torch.cat([z.weight, r.weight], 0), torch.cat([z.bias, r.bias], 0)), (q.weight, q.bias)):
-                    w = w.detach()
-                    var.append(ops.pack_conv_prec(torch.cat([w[:, :c_lo], w[:, c_hi:]], 1).contiguous(), prec))
-                    const += [ops.pack_conv_prec(w[:, c_lo:c_hi].contiguous(), prec), b.detach().float().contiguous()]
+                for w0, w1, b in ((z.weight, r.weight, torch.cat([z.bias, r.bias], 0)), (q.weight, None, q.bias)):
+                    if prec != PREC_F32:        # one launch per operand, straight from the nn.Conv2d layout
+                        var.append(ops.pack_conv_weights(w0, prec, w1, sel=((0, c_lo), (c_hi, cin))))
+                        const += [ops.pack_conv_weights(w0, prec, w1, sel=((c_lo, c_hi), (0, 0))), b.detach().float().contiguous()]
+                    else:
+                        w = (torch.cat([w0, w1], 0) if w1 is not None else w0).detach()
+                        var.append(ops.pack_conv_prec(torch.cat([w[:, :c_lo], w[:, c_hi:]], 1).contiguous(), prec))
+                        const += [ops.pack_conv_prec(w[:, c_lo:c_hi].contiguous(), prec), b.detach().float().contiguous()]
             return tuple(var), tuple(const)
         return self._pk_split.get(params, make, tag=(prec, c_lo, c_hi))
 

@@ -199,10 +199,20 @@ int craft_conv2d_nhwc(const float* x, long ldx, int cin, const float* w, const f
  * craft_stem_conv7x7: BasicEncoder.conv1 (7x7, stride 2, pad 3, 3 -> 64; extractor.py:139,181) fused with the input
  * normalisation 2*(x/255)-1 (network.py:169-173): image NCHW [B][3][H][W] raw 0..255, w packed [147 = (ky*7+kx)*3
  * + c][64] (weight.permute(2,3,1,0)), out tokens [B][(H/2)*(W/2)][64] = act(conv + bias); stats as above. */
+/* craft_pack_weights straight from nn.Conv2d's weight layout [Cout][Cin][KH][KW] (16-bit / f16x3 precisions): w0 (cout0 rows) and
+ * optionally w1 (cout1 rows) concatenated along Cout; input channels [a0, a1) u [b0, b1) selected (b0 == b1: one range).
+ * transposed = 0: the forward operand (rows = output channels, K = KH*KW*selected channels; selected count % 32 == 0).
+ * transposed = 1: the operand of the INPUT-gradient convolution (rows = selected input channels, K = KH*KW*round_up(Cout, 32),
+ * taps flipped): W'[ci][KH-1-ky][KW-1-kx][co] = W[co][ci][ky][kx].  out: planes * round_up(rows, 32) * K 16-bit elements. */
+int craft_pack_conv_weights(const float* w0, int cout0, const float* w1, int cout1, int Cin, int KH, int KW, int a0, int a1, int b0, int b1,
+                            int transposed, int prec, void* out, void* stream);
 /* craft_conv2d_nhwc over the virtual channel concatenation [x0 (c0 channels, row stride ld0) | x1 (c1, ld1)] (c1 = 0: x0 alone):
- * the conv input of SepConvGRU's q gate, cat([r*h, x]) (update.py:54, :61), without materialising the cat.  c0, c1 multiples of 32. */
-int craft_conv2d_nhwc2(const float* x0, long ld0, int c0, const float* x1, long ld1, int c1, const float* w, const float* bias, int cout,
-                       int KH, int KW, int act, float* y, long ldy, int B, int H, int W, int prec, void* stream);
+ * the conv input of SepConvGRU's q gate, cat([r*h, x]) (update.py:54, :61), without materialising the cat.  c0, c1 multiples of 32.
+ * Exactly one of bias [cout] / bias_field [B*H*W][ld_bf] (a per-pixel bias: the hoisted, iteration-invariant share of a convolution,
+ * as craft_sepconv_gru_context produces it) is non-NULL. */
+int craft_conv2d_nhwc2(const float* x0, long ld0, int c0, const float* x1, long ld1, int c1, const float* w, const float* bias,
+                       const float* bias_field, long ld_bf, int cout, int KH, int KW, int act, float* y, long ldy, int B, int H, int W, int prec,
+                       void* stream);
 int craft_conv2d_nhwc_ex(const float* x, long ldx, int cin, int Hin, int Win, const float* in_norm, const float* w,
                          const float* bias, int cout, int KH, int KW, int stride, int act, float* y, long ldy, int B,
                          int Hout, int Wout, double* stats, int prec, void* stream);

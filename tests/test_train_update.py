@@ -55,4 +55,4 @@ def test_fused_iteration_equals_operator_path(device, over, policy, B, H, W, ite
         if l2 > worst:
             worst, wk = l2, k
     print(f"[fused update] {over} {policy} {B}x{H}x{W} T={iters}: loss {la:.6f} / {lb:.6f}, worst relative L2 {worst:.2e} ({wk})")
-    assert worst < (0.25 if bf else 3e-3), (wk, worst)
+    assert worst < (0.25 if bf else 1e-2), (wk, worst)
