@@ -285,6 +285,29 @@ class AttnSoftmax(Function):
         return dS, dtab, None, None, None, None
 
 
+class RelPosAdd(Function):
+    """S += w (Hs (+) Ws): the relative-position scores of gma.Attention (RelPosEmb, gma.py:21-50, :84-98) added to the materialised
+    scores in place.  Hs [B, heads, N, nh >= 2 H8 - 1] / Ws [.., nw >= 2 W8 - 1]: q . E_h / q . E_w of the offsets that can occur."""
+
+    @staticmethod
+    def forward(ctx, S, Hs, Ws, w, hw):
+        B, Mh, N, ld = S.shape
+        Hs, Ws = _c(Hs), _c(Ws)
+        call("craft_relpos_add", S, ld, B * Mh, hw[0], hw[1], Hs, Hs.shape[-1], Ws, Ws.shape[-1], float(w))
+        ctx.mark_dirty(S)
+        ctx.w, ctx.hw, ctx.nh, ctx.nw = float(w), hw, Hs.shape[-1], Ws.shape[-1]
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        dS = _c(dS)
+        B, Mh, N, ld = dS.shape
+        dHs = torch.empty(B, Mh, N, ctx.nh, device=dS.device, dtype=torch.float32)
+        dWs = torch.empty(B, Mh, N, ctx.nw, device=dS.device, dtype=torch.float32)
+        call("craft_relpos_bwd", dS, ld, B * Mh, ctx.hw[0], ctx.hw[1], dHs, ctx.nh, ctx.nh, dWs, ctx.nw, ctx.nw, ctx.w)
+        return dS, dHs, dWs, None, None
+
+
 class AttnApply(Function):
     """O[b][m] = P[b][m] V_m with V = first_linear(x) [B, N, M*C] in its natural layout (setrans.py:373-384)."""
 
@@ -509,24 +532,34 @@ class CorrVolume(Function):
 
 
 class CorrLookup(Function):
-    """corr tokens [B, N, 4*81] = bilinear samples of the normalised pyramid around coords (corr.py:47-71).  coords carry no
-    gradient (network.py:232 detaches them); the volume's gradient is scattered into the holder's buffers."""
+    """corr tokens [B, N, V*4*81] = bilinear samples of the normalised pyramid(s) around coords (corr.py:47-71).  coords carry no
+    gradient (network.py:232 detaches them); the volume's gradient is scattered into the holder's buffers.  ``holder``: one
+    TrainPyramid, or the list of the V = 2 volumes of the two-way correlation of --f1 (corr.py:164-171: every level holds
+    [volume 0 window | volume 1 window]); ``token`` is then the sum of their tokens, so that every volume's backward runs after this."""
 
     @staticmethod
     def forward(ctx, token, coords, holder, radius):
-        ctx.holder, ctx.radius = holder, radius
+        holders = list(holder) if isinstance(holder, (list, tuple)) else [holder]
+        ctx.holders, ctx.radius = holders, radius
         coords = _c(coords.detach())
         ctx.save_for_backward(coords)
-        return ops.corr_lookup(holder.pyr, coords, radius)
+        return ops.corr_lookup([h.pyr for h in holders], coords, radius)
 
     @staticmethod
     def backward(ctx, dout):
         (coords,) = ctx.saved_tensors
-        pyr = ctx.holder.pyr
-        G = ctx.holder.grads()
         dout = _rows(dout)
-        call("craft_corr_lookup_bwd", dout, dout.stride(-2), coords, G[0], G[1], G[2], G[3], pyr.levels, pyr.B, pyr.H8, pyr.W8, ctx.radius, 0, 0)
-        return torch.zeros(pyr.B, 2, device=dout.device, dtype=torch.float32), None, None, None
+        lookup_bwd(ctx.holders, dout, coords, ctx.radius)
+        return torch.zeros(ctx.holders[0].pyr.B, 2, device=dout.device, dtype=torch.float32), None, None, None
+
+
+def lookup_bwd(holders, dout, coords, radius):
+    """Gradient of the lookup output into the shared gradient buffers of the (normalised) pyramids of every volume."""
+    V, win2 = len(holders), (2 * radius + 1) ** 2
+    for v, h in enumerate(holders):
+        pyr, G = h.pyr, h.grads()
+        call("craft_corr_lookup_bwd", dout, dout.stride(-2), coords, G[0], G[1], G[2], G[3], pyr.levels, pyr.B, pyr.H8, pyr.W8, radius,
+             win2 * V if V > 1 else 0, win2 * v)
 
 
 # ------------------------------------------------------------------------------------------------------------------

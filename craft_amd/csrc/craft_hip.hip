@@ -446,6 +446,13 @@ int craft_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* co
                    int cin, long guard, long K, int KH, int KW, int Wp, float* dW, int prec, void* stream) {
   return launch_wgrad_pk(dYp, Xp, Xp1, cin0, nseg, dy_rows_p, cout, x_rows_p, cin, guard, K, KH, KW, Wp, dW, prec, S(stream));
 }
+int craft_relpos_add(float* S, long ld, int BZ, int H8, int W8, const float* Hs, long ldh, const float* Ws, long ldw, float w, void* stream) {
+  return launch_relpos_add(S, ld, BZ, H8, W8, Hs, ldh, Ws, ldw, w, S(stream));
+}
+int craft_relpos_bwd(const float* dS, long ld, int BZ, int H8, int W8, float* dHs, long ldh, int nh, float* dWs, long ldw, int nw, float w,
+                     void* stream) {
+  return launch_relpos_bwd(dS, ld, BZ, H8, W8, dHs, ldh, nh, dWs, ldw, nw, w, S(stream));
+}
 // ---- CNN encoders in training (kernels_enc_train.hip)
 int craft_norm_act_fwd(const float* x, long ldx, const float* mean_rstd, int mr_per_image, const float* gamma, const float* beta, int act,
                        const float* res, long ldr, float* out, long ldo, int B, int N, int C, void* stream) {

@@ -789,4 +789,59 @@ int launch_gru_zr_bwd(const float* dz, const float* drh, long lddrh, const float
   return (int)hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// RelPosEmb scores of gma.Attention (gma.py:21-50, :84-98) on MATERIALISED scores: query i = (x, y) (x = row), key j = (u, v):
+//   S[z][i][j] += w * (Hs[z][i][u - x + H8 - 1] + Ws[z][i][v - y + W8 - 1])
+// Hs / Ws = (scaled) q . E_h / E_w rows (two small GEMMs of the caller), row strides ldh / ldw.  One block per query row.
+// backward: dHs[z][i][d] = w * sum_v dS[i][(u, v)], d = u - x + H8 - 1 (unreachable offsets: 0); dWs likewise over u.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_relpos_add(float* __restrict__ S, long ld, int N, int H8, int W8, const float* __restrict__ Hs, long ldh,
+                                                    const float* __restrict__ Ws, long ldw, float w) {
+  const long row = blockIdx.x;                       // z * N + i
+  const int i = (int)(row % N), x = i / W8, y = i - x * W8;
+  float* s = S + row * ld;
+  const float* hs = Hs + row * ldh + (H8 - 1 - x);
+  const float* ws = Ws + row * ldw + (W8 - 1 - y);
+  for (int j = threadIdx.x; j < N; j += 256) {
+    const int u = j / W8, v = j - u * W8;
+    s[j] += w * (hs[u] + ws[v]);
+  }
+}
+__global__ __launch_bounds__(256) void k_relpos_bwd(const float* __restrict__ dS, long ld, int N, int H8, int W8, float* __restrict__ dHs, long ldh,
+                                                    int nh, float* __restrict__ dWs, long ldw, int nw, float w) {
+  extern __shared__ float sm[];                      // [H8] row sums | [W8] column sums
+  const long row = blockIdx.x;
+  const int i = (int)(row % N), x = i / W8, y = i - x * W8;
+  const float* g = dS + row * ld;
+  for (int t = threadIdx.x; t < H8 + W8; t += 256) sm[t] = 0.f;
+  __syncthreads();
+  for (int j = threadIdx.x; j < N; j += 256) {
+    const int u = j / W8, v = j - u * W8;
+    const float d = g[j];
+    atomicAdd(&sm[u], d);
+    atomicAdd(&sm[H8 + v], d);
+  }
+  __syncthreads();
+  float* dh = dHs + row * ldh;
+  float* dw = dWs + row * ldw;
+  for (int t = threadIdx.x; t < nh; t += 256) { const int u = t - (H8 - 1 - x); dh[t] = (u >= 0 && u < H8) ? w * sm[u] : 0.f; }
+  for (int t = threadIdx.x; t < nw; t += 256) { const int v = t - (W8 - 1 - y); dw[t] = (v >= 0 && v < W8) ? w * sm[H8 + v] : 0.f; }
+}
+int launch_relpos_add(float* S, long ld, int BZ, int H8, int W8, const float* Hs, long ldh, const float* Ws, long ldw, float w, hipStream_t s) {
+  const int N = H8 * W8;
+  if (BZ <= 0 || N <= 0) return 0;
+  hipLaunchKernelGGL(k_relpos_add, dim3((unsigned)((long)BZ * N)), dim3(256), 0, s, S, ld, N, H8, W8, Hs, ldh, Ws, ldw, w);
+  return (int)hipGetLastError();
+}
+int launch_relpos_bwd(const float* dS, long ld, int BZ, int H8, int W8, float* dHs, long ldh, int nh, float* dWs, long ldw, int nw, float w,
+                      hipStream_t s) {
+  const int N = H8 * W8;
+  if (BZ <= 0 || N <= 0) return 0;
+  if (nh < 2 * H8 - 1 || nw < 2 * W8 - 1) return CRAFT_ERR_ARG;
+  hipLaunchKernelGGL(k_relpos_bwd, dim3((unsigned)((long)BZ * N)), dim3(256), (H8 + W8) * sizeof(float), s, dS, ld, N, H8, W8, dHs, ldh, nh, dWs, ldw,
+                     nw, w);
+  return (int)hipGetLastError();
+}
+
 }  // namespace craft

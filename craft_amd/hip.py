@@ -85,6 +85,8 @@ _SIGS = {
     "craft_tokens_bwd": [P, L, P, L, P, L, L, I, I, I, P],
     "craft_attn_softmax_fwd": [P, L, I, I, I, I, P, I, F, I, P, P, P],
     "craft_attn_softmax_bwd": [P, P, L, I, I, I, I, I, F, P, P, P, P],
+    "craft_relpos_add": [P, L, I, I, I, P, L, P, L, F, P],
+    "craft_relpos_bwd": [P, L, I, I, I, P, L, I, P, L, I, F, P],
     "craft_reduce_replicas": [P, I, I, P, P],
     "craft_corr_pool_fwd": [P, L, I, I, I, I, P, I, F, P, P, P, P, P],
     "craft_corr_lookup_bwd": [P, L, P, P, P, P, P, I, I, I, I, I, I, I, P],
@@ -126,7 +128,10 @@ NAMED_POLICIES = {"mixed": "proj=f16x3,score=f16x3,pv=fp16,conv=f16x3", "mixed_f
                   "train_bf16": "proj=f16x3,score=bf16,pv=bf16,conv=f16x3,enc=bf16",
                   # bf16 MFMA operands everywhere, fp32 accumulation / activations / master weights: the precision class of the
                   # reference's own training runs (every shipped train-*.sh passes --mixed_precision: fp16 autocast + GradScaler)
-                  "train_amp_bf16": "proj=bf16,score=bf16,pv=bf16,conv=bf16,enc=bf16"}
+                  "train_amp_bf16": "proj=bf16,score=bf16,pv=bf16,conv=bf16,enc=bf16",
+                  # the reference's own recipe: fp16 MFMA operands everywhere (fp16 autocast, train.py:215) -- legal only under a loss
+                  # scale (train.Trainer's counterpart of GradScaler, train.py:231-238); without one forward_train promotes fp16 to f16x3
+                  "train_amp_fp16": "proj=fp16,score=fp16,pv=fp16,conv=fp16,enc=fp16"}
 
 
 class CraftHipError(RuntimeError):

@@ -306,6 +306,8 @@ class Trainer:
                  reference_loss_scaling: bool = False, loss_scale="auto"):
         self.model = model
         self.loss_scale = loss_scale
+        if getattr(model, "args", None) is not None:      # fp16 operand roles are legal under the loss scale (train_forward.training_precision)
+            model.args.hip_loss_scaled = loss_scale == "auto" or bool(loss_scale and float(loss_scale) > 1.0)
         self.optimizer, self.scheduler = fetch_optimizer(model, lr, wdecay, epsilon, num_steps)
         self.clip, self.gamma, self.iters, self.add_noise, self.freeze_bn, self.group = clip, gamma, iters, add_noise, freeze_bn, group
         self.reference_loss_scaling = reference_loss_scaling

@@ -27,22 +27,24 @@ from .hip import ACT_NONE, ACT_RELU, ACT_TANH, PREC_BF16, PREC_F16, PREC_F32
 _warned_promote = []
 
 
-def training_precision(prec):
-    """The operand modes a training pass runs in.  Plain fp16 MFMA operands are refused by promotion: the reference's fp16
-    autocast training relies on GradScaler (train.py:215,231-238), which is not built here -- unscaled gradients (~3e-7 per
-    pixel at 368x496, batch 8) sit in fp16's subnormal / flush range and would degrade silently in dP = dO V^T, dV = P^T dO and the
-    convolution gradients.  Every role that asks for fp16 (e.g. ``pv`` of the inference default "mixed", which
-    args.mixed_precision=True selects) runs in f16x3 instead: fp32-class results, same fp16 MFMA pipe.  bf16 roles keep bf16
-    (fp32's exponent range: no scaling needed)."""
+def training_precision(prec, loss_scaled: bool = False):
+    """The operand modes a training pass runs in.  Plain fp16 MFMA operands need a loss scale: the reference's fp16 autocast training
+    relies on GradScaler (train.py:215,231-238) -- unscaled gradients (~3e-7 per pixel at 368x496, batch 8) sit in fp16's subnormal /
+    flush range and degrade silently in dP = dO V^T, dV = P^T dO and the convolution gradients.  ``loss_scaled`` (set by train.Trainer,
+    whose step multiplies the loss gradient by a power of two and un-scales inside the optimizer: ``args.hip_loss_scaled``): fp16 roles
+    run as asked.  Otherwise (a bare ``loss.backward()``) every role that asks for fp16 (e.g. ``pv`` of the inference default "mixed",
+    which args.mixed_precision=True selects) runs in f16x3 instead: fp32-class results, same fp16 MFMA pipe (f16x3's planes are fp16 too:
+    it needs the loss scale just as much at full image sizes, tests/test_train_backward.py).  bf16 roles keep bf16 (fp32's exponent
+    range)."""
     from .hip import PREC_F16X3, Precision
     roles = [r for r in Precision.__slots__ if getattr(prec, r) == PREC_F16]
-    if not roles:
+    if not roles or loss_scaled:
         return prec
     if not _warned_promote:
         _warned_promote.append(1)
         import warnings
-        warnings.warn(f"craft_amd training: fp16 operand mode of role(s) {roles} promoted to f16x3 (no loss scaling is built; "
-                      "use a bf16 policy such as train_amp_bf16 for 16-bit MFMA operands)")
+        warnings.warn(f"craft_amd training: fp16 operand mode of role(s) {roles} promoted to f16x3 (no loss scale announced: train.Trainer "
+                      "sets args.hip_loss_scaled; a bare loss.backward() should use a bf16 policy such as train_amp_bf16 for 16-bit operands)")
     out = Precision(prec.proj, prec.score, prec.pv, prec.conv, prec.enc)
     for r in roles:
         setattr(out, r, PREC_F16X3)
@@ -70,15 +72,11 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
     args = model.args
     # the reference's four shipped training scripts: --craft --f2 full --setrans (train-craft-f2full.sh), --craft --f2 full with GMA's
     # attention / aggregator (train-craft-f2full-gma.sh), plain correlation + GMA (train-gma.sh), and any mix of those three switches
-    if getattr(model, "f1_trans", None) is not None:
-        raise NotImplementedError("training with --f1 (two-way correlation) is not built; it runs in inference")
     if args.f2trans == "none":
         raise NotImplementedError("--f2 none: the reference's own constructor fails without the F2 transformer (network.py:93-106)")
-    if not args.use_setrans and (getattr(args, "position_only", False) or getattr(args, "position_and_content", False)):
-        raise NotImplementedError("training GMA's relative-position scores (RelPosEmb) is not built; they run in inference")
     if not args.use_setrans and (model.att.heads != 1 or getattr(model.update_block.aggregator, "project", None) is not None):
         raise NotImplementedError("training gma.Aggregate with num_heads > 1 (head merge + project, gma.py:133-137) is not built")
-    prec = training_precision(model.hip_prec())
+    prec = training_precision(model.hip_prec(), bool(getattr(args, "hip_loss_scaled", False)))
     B, _, H, W = image1.shape
     if H % 8 or W % 8:
         raise ValueError("image height and width must be multiples of 8")
@@ -121,39 +119,52 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
     net = AG.TokensNorm.apply(cn_tok[..., 0:128], ACT_TANH, False)              # network.py:209-211
     inp = AG.TokensNorm.apply(cn_tok[..., 128:256], ACT_RELU, False)
 
-    # ---- F2 transformer (network.py:185-187; setrans.py:578-619, 364-410) ---------------------------------------------
-    f2 = model.f2_trans
-    c2 = f2.config
-    x2 = AG.dropout(AG.TokensNorm.apply(f2_tok, ACT_NONE, True), p_hidden(c2), base_seed + 1)
-    P2 = _attention_probs(f2, x2, hw, prec, p_attn(c2), base_seed + 2)
-    ot = f2.setrans.out_trans
-    v2 = AG.Linear.apply(x2, ot.first_linear.weight, None, prec)
-    O2 = AG.AttnApply.apply(P2, v2, prec)
-    fmap2_t = AG.ModePoolLN.apply(O2, x2, ot.feat_softaggr.feat2score.weight, ot.input_skip_coeff)
+    # ---- F2 transformer (network.py:185-187; setrans.py:578-619, 364-410); with --f1 shared | private the same block (the same
+    # module or a private one, network.py:94-103) transforms frame 1 too (:180-183)
+    def feature_transformer(mod, tok, seed):
+        c = mod.config
+        x = AG.dropout(AG.TokensNorm.apply(tok, ACT_NONE, True), p_hidden(c), seed)
+        Pm = _attention_probs(mod, x, hw, prec, p_attn(c), seed + 1)
+        ot = mod.setrans.out_trans
+        v = AG.Linear.apply(x, ot.first_linear.weight, None, prec)
+        return AG.ModePoolLN.apply(AG.AttnApply.apply(Pm, v, prec), x, ot.feat_softaggr.feat2score.weight, ot.input_skip_coeff)
+
+    fmap2_t = feature_transformer(model.f2_trans, f2_tok, base_seed + 1)
+    f1t = getattr(model, "f1_trans", None)
+    fmap1_t = feature_transformer(f1t, f1_tok, base_seed + 9) if (f1t is not None and args.craft) else None
 
     # ---- inter-frame correlation volume + pyramid (network.py:225-228; corr.py:148-207) -------------------------------
     box = []
     if args.craft:
         cf = model.corr_fn
         cc = cf.config
-        x1 = AG.dropout(AG.TokensNorm.apply(f1_tok, ACT_NONE, True), p_hidden(cc), base_seed + 3)
-        x2t = AG.dropout(AG.TokensNorm.apply(fmap2_t, ACT_NONE, True), p_hidden(cc), base_seed + 4)
         st = cf.setrans
-        q = AG.Linear.apply(x1, st.query.weight, st.query.bias, prec)
-        k = AG.Linear.apply(x2t, st.key.weight, st.key.bias, prec)
         scale = 1.0 / math.sqrt(st.attention_mode_dim)
-        mx = ops.score_max(q.detach(), k.detach(), H8, W8, st.num_modes, scale, prec)
-        Sc = AG.Scores.apply(q, k, st.num_modes, scale, prec)
         w_aggr = st.attn_softaggr.feat2score.weight if st.num_modes > 1 else torch.ones(1, 1, device=dev)
-        token = AG.CorrVolume.apply(Sc, cf.vispos_encoder.pos_coder.biases, w_aggr, float(st.pos_code_weight), mx, hw, box,
-                                    bool(cf.do_corr_global_norm))
+
+        def vispos(tok, seed):                    # the correlation block's own input encoder: LayerNorm + dropout (setrans.py:791-795)
+            return AG.dropout(AG.TokensNorm.apply(tok, ACT_NONE, True), p_hidden(cc), seed)
+
+        def volume(xq, xk):
+            q = AG.Linear.apply(xq, st.query.weight, st.query.bias, prec)
+            k = AG.Linear.apply(xk, st.key.weight, st.key.bias, prec)
+            mx = ops.score_max(q.detach(), k.detach(), H8, W8, st.num_modes, scale, prec)
+            Sc = AG.Scores.apply(q, k, st.num_modes, scale, prec)
+            return AG.CorrVolume.apply(Sc, cf.vispos_encoder.pos_coder.biases, w_aggr, float(st.pos_code_weight), mx, hw, box,
+                                       bool(cf.do_corr_global_norm))
+
+        if fmap1_t is not None:
+            # two-way correlation (corr.py:164-171): (transformed 1, conv 2) and (conv 1, transformed 2), concatenated per level
+            token = volume(vispos(fmap1_t, base_seed + 3), vispos(f2_tok, base_seed + 11)) + volume(vispos(f1_tok, base_seed + 12), vispos(fmap2_t, base_seed + 4))
+        else:
+            token = volume(vispos(f1_tok, base_seed + 3), vispos(fmap2_t, base_seed + 4))
         radius = cf.radius
     else:
         # CorrBlock (corr.py:17-45, :73-81): <fmap1, fmap2> / sqrt(256), no positional bias, no global LayerNorm, avg-pool pyramid
         Sc = AG.Scores.apply(f1_tok, fmap2_t, 1, 1.0 / math.sqrt(256.0), prec)
         token = AG.CorrVolume.apply(Sc, None, torch.ones(1, 1, device=dev), 0.0, None, hw, box, False)
         radius = int(args.corr_radius)
-    holder = box[0]
+    holder = box if len(box) > 1 else box[0]          # (two volumes with --f1)
 
     # ---- intra-frame attention (network.py:214): computed once, used by every iteration ------------------------------
     att = model.att
@@ -165,7 +176,22 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
         # gma.Attention (gma.py:53-102): softmax(scale * q k^T) of the 1x1-conv projections of the context features, no dropout
         inner = att.heads * att.dim_head
         qk = AG.Linear.apply(inp, att.to_qk.weight.view(2 * inner, -1), None, prec)
-        Sg = AG.Scores.apply(qk[..., :inner], qk[..., inner:], att.heads, float(att.scale), prec)
+        pos_only = bool(getattr(args, "position_only", False))
+        q_ = qk[..., :inner]
+        Sg = AG.Scores.apply(q_, qk[..., inner:], att.heads, 0.0 if pos_only else float(att.scale), prec)
+        if pos_only or getattr(args, "position_and_content", False):
+            # RelPosEmb (gma.py:21-50): (scale q)(x, y) . E_h[u - x] + (scale q)(x, y) . E_w[v - y] -- per query a row of 2 H8 - 1 and one
+            # of 2 W8 - 1 scores (two small products against the embedding rows of the offsets that can occur), added to the scores
+            if max(H8, W8) > att.max_pos_size:
+                raise ValueError(f"feature map {H8}x{W8} exceeds RelPosEmb max_pos_size {att.max_pos_size}")
+            P0 = att.max_pos_size - 1
+            pad4 = lambda e: torch.nn.functional.pad(e, (0, 0, 0, (-e.shape[0]) % 4))          # noqa: E731  (row counts % 4: vector loads)
+            Eh = pad4(att.pos_emb.rel_height.weight[P0 - (H8 - 1): P0 + H8])
+            Ew = pad4(att.pos_emb.rel_width.weight[P0 - (W8 - 1): P0 + W8])
+            qh = q_.reshape(B, N, att.heads, att.dim_head).permute(0, 2, 1, 3).reshape(B * att.heads, N, att.dim_head)
+            Hs = AG.Linear.apply(qh, Eh, None, prec).view(B, att.heads, N, -1)
+            Ws = AG.Linear.apply(qh, Ew, None, prec).view(B, att.heads, N, -1)
+            Sg = AG.RelPosAdd.apply(Sg, Hs, Ws, float(att.scale) * (1.0 if pos_only else float(att.pos_embed_weight)), hw)
         Patt = AG.AttnSoftmax.apply(Sg, None, 0.0, -1, None, hw)
     pbox = []
     ptoken = AG.ProbsToken.apply(Patt, pbox, prec)        # the 12 uses of Patt share ONE gradient product

@@ -42,7 +42,8 @@ class UpdatePass:
     def __init__(self, model, prec, hw, B, iters, net, inp, holder, pholder, radius):
         self.model, self.prec, self.hw, self.B, self.iters = model, prec, hw, B, iters
         self.N = hw[0] * hw[1]
-        self.holder, self.pholder, self.radius = holder, pholder, radius
+        self.holders = list(holder) if isinstance(holder, (list, tuple)) else [holder]     # one volume, or the two of --f1
+        self.pholder, self.radius = pholder, radius
         dev = net.device
         self.dev = dev
         self.cp = pick(prec, "conv")
@@ -149,7 +150,7 @@ class UpdateIter(Function):
         rows, cp, prec, dev = B * N, ps.cp, ps.prec, ps.dev
         hx, hxn = ps.HX[t], ps.HX[t + 1]
         coords1 = AG._c(coords1.detach())
-        corr = ops.corr_lookup(ps.holder.pyr, coords1, ps.radius)                    # network.py:235 / corr.py:47-71
+        corr = ops.corr_lookup([h.pyr for h in ps.holders], coords1, ps.radius)       # network.py:235 / corr.py:47-71
         S = {"coords": coords1}
         if ps.zero_tok is None:
             ps.zero_tok = torch.zeros_like(token)
@@ -411,8 +412,7 @@ def _phase2(ps: UpdatePass):
         ps.wgrad(("f1",), (AG.Packed(g_flo1, cp, g7, colsum=ps.acc(("f1", "db"), (128,))), S["pk_flow"]), 7, 7, ps.acc(("f1", "dw"), (128, 7, 7, 32)), last)
         # ---- correlation lookup (corr.py:47-71): the gradient goes into the shared buffers of the normalised pyramid; autograd.CorrVolume
         # (every iteration took its token) folds them into the volume's gradient after this node
-        pyr, G = ps.holder.pyr, ps.holder.grads()
-        call("craft_corr_lookup_bwd", d_corr, d_corr.stride(-2), S["coords"], G[0], G[1], G[2], G[3], pyr.levels, pyr.B, pyr.H8, pyr.W8, ps.radius, 0, 0)
+        AG.lookup_bwd(ps.holders, d_corr, S["coords"], ps.radius)
         S.clear()
         ps.saved[t] = None
 

@@ -378,6 +378,14 @@ int craft_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, int
                            const unsigned* clamp_ord, const unsigned* clampbits, float* dtab_rep, void* stream);
 int craft_reduce_replicas(const float* rep, int nrep, int n, float* out, void* stream);
 
+/* gma.Attention's relative-position scores (RelPosEmb, gma.py:21-50, :84-98) added to materialised scores S [BZ][N][ld], BZ = B*heads:
+ *   S[z][(x,y)][(u,v)] += w * (Hs[z][(x,y)][u - x + H8 - 1] + Ws[z][(x,y)][v - y + W8 - 1]), x / u rows, y / v columns;
+ *   Hs [BZ][N][>= 2 H8 - 1] (row stride ldh) = q . E_h rows of the offsets -(H8-1) .. H8-1, Ws likewise (products of the caller).
+ * craft_relpos_bwd: dHs[z][i][d] = w * sum_v dS[z][i][(u, v)] for d = u - x + H8 - 1, 0 for the nh - H8 unreachable offsets; dWs likewise. */
+int craft_relpos_add(float* S, long ld, int BZ, int H8, int W8, const float* Hs, long ldh, const float* Ws, long ldw, float w, void* stream);
+int craft_relpos_bwd(const float* dS, long ld, int BZ, int H8, int W8, float* dHs, long ldh, int nh, float* dWs, long ldw, int nw, float w,
+                     void* stream);
+
 /* Correlation volume from MATERIALISED scores (training form of craft_corr_build; corr.py:191-199, setrans.py:520-550):
  *   S [B][M][N][ld] -> c0 [B*N][N] = sum_m s_m softmax_m(w s_m), s_m = clamp?(S_m) + pos_w*pb; sums[b] += (sum c, sum c^2).
  *   w: DEVICE pointer to attn_softaggr.feat2score.weight (no host read-back).  craft_corr_finish then builds the pyramid and

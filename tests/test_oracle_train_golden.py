@@ -16,7 +16,10 @@ from oracle import craft_oracle as O
 
 TRAIN_CASES = ["train_b2_128x192_T3", "train_freezebn_b2_128x160_T2",
                # the reference's other shipped training configurations (train-craft-f2full-gma.sh, plain correlation, train-gma.sh)
-               "train_gma_b2_128x160_T2", "train_nocraft_b2_128x160_T2", "train_plaingma_b2_128x160_T2"]
+               "train_gma_b2_128x160_T2", "train_nocraft_b2_128x160_T2", "train_plaingma_b2_128x160_T2",
+               # what CRAFT.forward accepts under model.train() beyond the shipped scripts: the two-way correlation of --f1 shared | private
+               # (corr.py:164-171) and GMA's relative-position scores (gma.py:34-50, :84-98)
+               "train_f1shared_b2_128x160_T2", "train_f1private_b2_128x160_T2", "train_gmapos_b2_128x160_T2", "train_gmaposonly_b2_128x160_T2"]
 
 
 def grad_scale(z):
@@ -56,6 +59,9 @@ def test_oracle_training_step_matches_reference(case):
     sd = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
     if "corr_fn.setrans.key.weight" in sd:
         sd["corr_fn.setrans.key.weight"], sd["corr_fn.setrans.key.bias"] = sd["corr_fn.setrans.query.weight"], sd["corr_fn.setrans.query.bias"]
+    if over.get("f1trans") == "shared":               # --f1 shared: f1_trans IS f2_trans (network.py:94-97), one set of Parameters under two names
+        for k in [k for k in sd if k.startswith("f1_trans.")]:
+            sd[k] = sd["f2_trans." + k[len("f1_trans."):]]
     im1, im2 = torch.from_numpy(z["image1"].astype(np.float32)), torch.from_numpy(z["image2"].astype(np.float32))
     preds, bn = O.craft_train_forward(sd, O.OracleConfig(**over), im1, im2, iters=meta["iters"], freeze_bn=meta["freeze_bn"])
     loss, metrics = O.sequence_loss(preds, torch.from_numpy(z["flow_gt"]), torch.from_numpy(z["valid"]), meta["gamma"])

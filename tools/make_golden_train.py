@@ -35,6 +35,14 @@ CASES = [
     dict(name="train_nocraft_b2_128x160_T2", over=dict(craft=False), B=2, H=128, W=160, iters=2, seed=47, qk_gain=2.5, freeze_bn=True, gamma=0.8),
     dict(name="train_plaingma_b2_128x160_T2", over=dict(craft=False, use_setrans=False), B=2, H=128, W=160, iters=2, seed=53,
          qk_gain=2.5, freeze_bn=False, gamma=0.8),
+    # round 3: the configurations CRAFT.forward accepts under model.train() beyond the shipped scripts -- the two-way correlation of
+    # --f1 shared | private (corr.py:164-171, network.py:94-103) and GMA's relative-position scores (gma.py:34-50, :84-98)
+    dict(name="train_f1shared_b2_128x160_T2", over=dict(f1trans="shared"), B=2, H=128, W=160, iters=2, seed=59, qk_gain=2.5, freeze_bn=False, gamma=0.8),
+    dict(name="train_f1private_b2_128x160_T2", over=dict(f1trans="private"), B=2, H=128, W=160, iters=2, seed=61, qk_gain=2.5, freeze_bn=True, gamma=0.8),
+    dict(name="train_gmapos_b2_128x160_T2", over=dict(use_setrans=False, position_and_content=True), B=2, H=128, W=160, iters=2, seed=67,
+         qk_gain=2.5, freeze_bn=False, gamma=0.8),
+    dict(name="train_gmaposonly_b2_128x160_T2", over=dict(use_setrans=False, position_only=True), B=2, H=128, W=160, iters=2, seed=71,
+         qk_gain=2.5, freeze_bn=True, gamma=0.8),
 ]
 
 
