@@ -8,7 +8,7 @@ from craft_amd import CRAFT, default_args, flow_io
 from craft_amd.flow_datasets import KITTI, MpiSintel
 from craft_amd.synth import synth_pair, synth_state_dict
 from craft_amd.train import Trainer
-from craft_amd.train_data import STAGE_AUG, TrainSource, make_augmentor, seed_workers, train_batches
+from craft_amd.train_data import STAGE_AUG, TrainSource, make_augmentor, seed_workers, train_batches, train_batches_async
 
 pytestmark = pytest.mark.gpu
 
@@ -70,3 +70,30 @@ def test_batches_from_files_and_one_training_step(device, tmp_path):
     tr = Trainer(model.to(device), lr=1e-4, num_steps=20, iters=2, freeze_bn=True)
     m = tr.step(*batches[0])
     assert m["loss"] == m["loss"] and m["loss"] < 1e4
+
+
+def test_async_feed_yields_the_same_batches(device, tmp_path):
+    """train_batches_async (decode workers + pinned staging + augmentation on a side stream, datasets.py:569-580 / train.py:337's
+    DataLoader(num_workers=4)) reproduces train_batches batch for batch under the same seeds, over two epochs, and stops cleanly when
+    the consumer walks away early."""
+    root, kroot = _trees(tmp_path)
+    crop = (96, 128)
+    clean, kitti = MpiSintel("training", root, "clean"), KITTI("training", kroot)
+
+    def sources():
+        return [TrainSource(clean, make_augmentor(clean, "sintel", crop, shift_prob=0.5), repeat=2),
+                TrainSource(kitti, make_augmentor(kitti, "sintel/kitti", crop), repeat=3)]
+    seed_workers(5)
+    ref = [tuple(t.clone() for t in b) for b in train_batches(sources(), 2, device, seed=4, epochs=2)]
+    seed_workers(5)
+    got = []
+    for b in train_batches_async(sources(), 2, device, seed=4, epochs=2, workers=3, prefetch=2):
+        got.append(tuple(t.clone() for t in b))
+    assert len(got) == len(ref) == 2 * (11 // 2)
+    for a, b in zip(got, ref):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    it = train_batches_async(sources(), 2, device, seed=4, epochs=None, workers=2, prefetch=2)      # endless: take 3 batches, then close
+    for _ in range(3):
+        next(it)
+    it.close()
