@@ -440,7 +440,7 @@ __device__ __forceinline__ void corr4t_epilogue(const ScoreParams& p, const f32x
 #pragma unroll
     for (int dyl = 0; dyl < 4; ++dyl) {
       const int kh = 8 * cy + 4 * mt + dyl;
-      if (qvalid && kh < H8) {
+      if (qvalid && kh < H8 && !(p.dbg & 1)) {
         float* d = pyr0 + q * N + (long)kh * W8 + kw0;
         if (VEC || kw0 + 3 < W8) {
           if (VEC) *reinterpret_cast<float4*>(d) = make_float4(cv[4 * dyl], cv[4 * dyl + 1], cv[4 * dyl + 2], cv[4 * dyl + 3]);
@@ -464,18 +464,18 @@ __device__ __forceinline__ void corr4t_epilogue(const ScoreParams& p, const f32x
         const int x1 = 4 * cx + 2 * g + b2;
         const float v = (((cv[8 * a + 2 * b2] + cv[8 * a + 2 * b2 + 1]) + cv[8 * a + 4 + 2 * b2]) + cv[8 * a + 5 + 2 * b2]) * 0.25f;
         sum16 += v;
-        if (qvalid && y1 < h1 && x1 < w1) pyr1[(q * h1 + y1) * w1 + x1] = v;
+        if (qvalid && y1 < h1 && x1 < w1 && !(p.dbg & 2)) pyr1[(q * h1 + y1) * w1 + x1] = v;
       }
     }
     // level 2: the lane's 4 x 4 block = mean of its four level-1 cells
     const int y2 = 2 * cy + mt, x2 = 2 * cx + g;
     const float v2 = sum16 * 0.25f;
-    if (qvalid && y2 < h2 && x2 < w2) pyr2[(q * h2 + y2) * w2 + x2] = v2;
+    if (qvalid && y2 < h2 && x2 < w2 && !(p.dbg & 2)) pyr2[(q * h2 + y2) * w2 + x2] = v2;
     cell += v2;
   }
   // level 3: 8 x 8 cell = the two tiles of this lane + the partner lane (g ^ 1)
   cell += __shfl_xor(cell, 32);
-  if (g == 0 && qvalid && cy < h3 && cx < w3) pyr3[(q * h3 + cy) * w3 + cx] = cell * 0.25f;
+  if (g == 0 && qvalid && cy < h3 && cx < w3 && !(p.dbg & 2)) pyr3[(q * h3 + cy) * w3 + cx] = cell * 0.25f;
 }
 
 __global__ __launch_bounds__(NTHREADS) void k_corr_build4t(ScoreParams p, const _Float16* __restrict__ Qs, const _Float16* __restrict__ Ks,
@@ -700,7 +700,9 @@ int launch_corr_build_pyramid(const ScoreParams& p, float w_aggr, float* pyr0, f
   hipLaunchKernelGGL(k_split_planes, g1, dim3(256), 0, s, p.Kf, p.ldk, rows, 256, 1.f, Ks);
   const int ncx2 = (((p.W8 + 7) / 8) + 1) / 2;
   dim3 grid((p.N + 63) / 64, ((p.H8 + 7) / 8) * ncx2, p.B);
-  hipLaunchKernelGGL(k_corr_build4t, grid, dim3(NTHREADS), 0, s, p, Qs, Ks, w_aggr, pyr0, pyr1, pyr2, pyr3, sums);
+  ScoreParams pd = p;
+  pd.dbg = tuning().corr_dbg;
+  hipLaunchKernelGGL(k_corr_build4t, grid, dim3(NTHREADS), 0, s, pd, Qs, Ks, w_aggr, pyr0, pyr1, pyr2, pyr3, sums);
   return (int)hipGetLastError();
 }
 

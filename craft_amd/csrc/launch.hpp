@@ -14,7 +14,7 @@ namespace craft {
 // Developer A/B overrides from the environment, read ONCE when the library is loaded (never in a launch path):
 // CRAFT_HALO_BN (64 | 128), CRAFT_NO_C64, CRAFT_WF_DYNAMIC_TAPS.  Everything a caller may legitimately vary per call is an
 // argument of the C ABI instead (e.g. CRAFT_PV_ROWS in craft_attn_apply's prec).
-struct Tuning { int halo_bn; bool no_c64, wf_dynamic_taps, no_wgrad64, wgrad_sb; int pk_mode; };
+struct Tuning { int halo_bn; bool no_c64, wf_dynamic_taps, no_wgrad64, wgrad_sb; int pk_mode, corr_dbg; };
 const Tuning& tuning();
 
 struct RowsGemmParams {
@@ -91,6 +91,7 @@ struct ScoreParams {
   const float* rb_h; const float* rb_wd; long ld_rbh, ld_rbw; float rb_w;
   float* rowsum;                      // k_attn_probs: non-null = deferred normalisation, row sums [B][M][N] out ...
   unsigned* rowmax;                   // ... followed by [B][M][N] ordered-uint row maxima (scratch): rowsum + B*M*N
+  int dbg;                            // developer ablation of k_corr_build4t's stores (CRAFT_CORR_DBG: 1 no level 0, 2 no levels 1-3), 0 in production
 };
 
 // ---- flash-fused attention (kernels_flash.hip) ----
