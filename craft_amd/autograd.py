@@ -629,10 +629,11 @@ class Packed:
     pixel grid, so that a convolution tap is one row shift and the weight-gradient K loop is a pure copy (kernels_gemm_pk.hip)."""
     __slots__ = ("buf", "rows_p", "guard", "K", "C_p", "prec", "Wp", "rows", "C")
 
-    def __init__(self, x, prec: int, spatial=None, colsum=None):
+    def __init__(self, x, prec: int, spatial=None, colsum=None, batch=None):
         """x: tokens [.., C] (unit channel stride, uniform row stride) or a LIST of such tensors over the same rows -- their channel
         concatenation (every source but the last with C % 32 == 0), packed without a torch.cat; spatial = (B, H, W, padH, padW) or
-        None (plain rows); colsum: [C] buffer that receives += the column sums (single source only)."""
+        None (plain rows); colsum: [C] buffer that receives += the column sums (single source only).  ``batch`` (a PackBatch): the
+        pack is queued instead of launched -- ``batch.flush()`` packs everything queued in ONE launch (craft_pack_operands)."""
         srcs = list(x) if isinstance(x, (list, tuple)) else [x]
         C = sum(t.shape[-1] for t in srcs)
         rows = srcs[0].numel() // srcs[0].shape[-1]
@@ -656,9 +657,33 @@ class Packed:
             c = t.shape[-1]
             if t is not srcs[-1] and c % 32:
                 raise ValueError("Packed: only the last source of a concatenation may have a channel count that is not a multiple of 32")
-            call("craft_pack_operand", t, t.stride(-2), c, rows, B, H, W, ph, pw, self.guard, self.rows_p, prec, self.buf, off, ncg,
-                 colsum if len(srcs) == 1 else None)
+            cs = colsum if len(srcs) == 1 else None
+            if batch is not None:
+                if not t.is_cuda:
+                    raise hip.CraftHipError("craft_amd HIP ops need device tensors (no CPU fallback)")
+                batch.add([t.data_ptr(), t.stride(-2), c, rows, B, H, W, ph, pw, self.guard, self.rows_p, prec, self.buf.data_ptr(), off, ncg,
+                           cs.data_ptr() if cs is not None else 0], (t, self.buf, cs))
+            else:
+                call("craft_pack_operand", t, t.stride(-2), c, rows, B, H, W, ph, pw, self.guard, self.rows_p, prec, self.buf, off, ncg, cs)
             off += round_up(c, 32) // 32
+
+
+class PackBatch:
+    """Queued craft_pack_operand calls, launched together by ``flush`` (craft_pack_operands)."""
+
+    def __init__(self):
+        self.descs, self.keep = [], []
+
+    def add(self, desc, keep):
+        self.descs.append(desc)
+        self.keep.append(keep)                   # the sources stay alive until the launch is enqueued
+
+    def flush(self):
+        import ctypes
+        if self.descs:
+            flat = [int(v) for d in self.descs for v in d]
+            call("craft_pack_operands", (ctypes.c_long * len(flat))(*flat), len(self.descs))
+        self.descs, self.keep = [], []
 
 
 def wgrad_pk(pairs, KH: int, KW: int, acc: torch.Tensor):

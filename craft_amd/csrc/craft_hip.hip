@@ -443,6 +443,7 @@ int craft_pack_operand(const float* x, long ldx, int C, long rows, int B, int H,
                        int prec, void* out, int cg_off, int ncg_total, float* colsum, void* stream) {
   return launch_pack_operand(x, ldx, C, rows, B, H, W, padH, padW, guard, rows_p, prec, out, cg_off, ncg_total, colsum, S(stream));
 }
+int craft_pack_operands(const long* descs, int n, void* stream) { return launch_pack_operands(descs, n, S(stream)); }
 int craft_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* const* Xp1, int cin0, int nseg, long dy_rows_p, int cout, long x_rows_p,
                    int cin, long guard, long K, int KH, int KW, int Wp, float* dW, int prec, void* stream) {
   return launch_wgrad_pk(dYp, Xp, Xp1, cin0, nseg, dy_rows_p, cout, x_rows_p, cin, guard, K, KH, KW, Wp, dW, prec, S(stream));

@@ -39,21 +39,26 @@ struct PackParams {
 };
 
 // block = 256 threads; it packs PACK_ROWS rows x one 32-channel group: thread -> (row = tid >> 2 (+ 64 per pass), 8 channels at
-// (tid & 3) * 8), PACK_ROWS / 64 passes with every load issued before the first store; grid (row blocks, channel groups).
+// (tid & 3) * 8), PACK_ROWS / 64 passes with every load issued before the first store.
 // Column sums: per-thread partial sums over the passes, reduced over the 16 row lanes by shuffles and over the 4 waves through LDS:
 // 32 atomics per block (the first version had every wave add its 16-row sums: 3 000 same-address atomics per channel cost 20 x the copy).
+// One launch packs up to PACK_MAX_DESC tensors (a training iteration packs ~14 conv inputs of 2 - 12 MB each: as separate launches they
+// were overhead, not bandwidth -- 13 us for 5 us of traffic): block -> (descriptor, row block, channel group) through a prefix table.
 constexpr int PACK_ROWS = 256;
-template <int PREC, bool SUM>
-__global__ __launch_bounds__(256) void k_pack_operand(PackParams p) {
+constexpr int PACK_MAX_DESC = 16;
+struct PackBatch { PackParams d[PACK_MAX_DESC]; int first_block[PACK_MAX_DESC + 1]; int n; };
+
+template <int PREC>
+__device__ __forceinline__ void pack_block(const PackParams& p, int rb, int cg, bool sum, float (*red)[32]) {
   constexpr int NP = PACK_ROWS / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cg = blockIdx.y, cq = (tid & 3) * 8, c = cg * 32 + cq;
+  const int cq = (tid & 3) * 8, c = cg * 32 + cq;
   const long plane = (long)p.ncg_total * p.rows_p * 32;
   const int Hp = p.H + 2 * p.padH, Wp = p.W + 2 * p.padW;
   float4 v0[NP], v1[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    const long r = (long)blockIdx.x * PACK_ROWS + i * 64 + (tid >> 2);
+    const long r = (long)rb * PACK_ROWS + i * 64 + (tid >> 2);
     long src = -1;
     const long q = r - p.guard;
     if (p.B > 0) {
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256) void k_pack_operand(PackParams p) {
   }
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    const long r = (long)blockIdx.x * PACK_ROWS + i * 64 + (tid >> 2);
+    const long r = (long)rb * PACK_ROWS + i * 64 + (tid >> 2);
     if (r >= p.rows_p) continue;
     unsigned short* o = p.out + ((long)(p.cg_off + cg) * p.rows_p + r) * 32 + cq;
     if constexpr (PREC == CRAFT_PREC_F16X3) {
@@ -97,8 +102,7 @@ __global__ __launch_bounds__(256) void k_pack_operand(PackParams p) {
       *reinterpret_cast<bf16x8*>(o) = h;
     }
   }
-  if constexpr (SUM) {
-    __shared__ float red[4][32];
+  if (sum) {                                         // (block-uniform)
     float sm[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -119,25 +123,62 @@ __global__ __launch_bounds__(256) void k_pack_operand(PackParams p) {
   }
 }
 
-int launch_pack_operand(const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
-                        int prec, void* out, int cg_off, int ncg_total, float* colsum, hipStream_t s) {
-  if (rows_p <= 0 || C <= 0) return 0;
+__global__ __launch_bounds__(256) void k_pack_operands(PackBatch pb) {
+  __shared__ float red[4][32];
+  int i = 0;
+#pragma unroll 1
+  while (i + 1 < pb.n && (int)blockIdx.x >= pb.first_block[i + 1]) ++i;
+  const PackParams& p = pb.d[i];
+  const int local = blockIdx.x - pb.first_block[i];
+  const int rb = local / p.ncg, cg = local - rb * p.ncg;
+  const bool sum = p.colsum != nullptr;
+  if (p.prec == CRAFT_PREC_F16X3) pack_block<CRAFT_PREC_F16X3>(p, rb, cg, sum, red);
+  else if (p.prec == CRAFT_PREC_F16) pack_block<CRAFT_PREC_F16>(p, rb, cg, sum, red);
+  else pack_block<CRAFT_PREC_BF16>(p, rb, cg, sum, red);
+}
+
+static int fill_pack_params(PackParams& p, const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
+                            int prec, void* out, int cg_off, int ncg_total, float* colsum) {
+  if (rows_p <= 0 || C <= 0) return CRAFT_ERR_ARG;
   if (cg_off < 0 || cg_off + (C + 31) / 32 > ncg_total) return CRAFT_ERR_ARG;
   if ((C & 3) || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return CRAFT_ERR_ALIGN;
   if (prec != CRAFT_PREC_F16X3 && prec != CRAFT_PREC_F16 && prec != CRAFT_PREC_BF16) return CRAFT_ERR_UNSUPPORTED;
   if (B > 0 && (double)B * (H + 2 * padH) * (W + 2 * padW) >= 2147483648.0) return CRAFT_ERR_UNSUPPORTED;
-  PackParams p = {};
+  p = PackParams{};
   p.x = x; p.ldx = ldx; p.C = C; p.rows = rows; p.B = B; p.H = H; p.W = W; p.padH = padH; p.padW = padW; p.guard = guard; p.rows_p = rows_p;
   p.out = static_cast<unsigned short*>(out); p.prec = prec; p.colsum = colsum; p.ncg = (C + 31) / 32;
   p.cg_off = cg_off; p.ncg_total = ncg_total;
-  dim3 grid((unsigned)((rows_p + PACK_ROWS - 1) / PACK_ROWS), (unsigned)p.ncg);
-#define GO(PR) do { if (colsum) hipLaunchKernelGGL((k_pack_operand<PR, true>), grid, dim3(256), 0, s, p); \
-                    else hipLaunchKernelGGL((k_pack_operand<PR, false>), grid, dim3(256), 0, s, p); } while (0)
-  if (prec == CRAFT_PREC_F16X3) GO(CRAFT_PREC_F16X3);
-  else if (prec == CRAFT_PREC_F16) GO(CRAFT_PREC_F16);
-  else GO(CRAFT_PREC_BF16);
-#undef GO
-  return (int)hipGetLastError();
+  return 0;
+}
+
+// descs: n x 16 longs (x, ldx, C, rows, B, H, W, padH, padW, guard, rows_p, prec, out, cg_off, ncg_total, colsum), see craft_pack_operands
+int launch_pack_operands(const long* descs, int n, hipStream_t s) {
+  for (int i0 = 0; i0 < n; i0 += PACK_MAX_DESC) {
+    PackBatch pb = {};
+    pb.n = n - i0 < PACK_MAX_DESC ? n - i0 : PACK_MAX_DESC;
+    int blocks = 0;
+    for (int i = 0; i < pb.n; ++i) {
+      const long* d = descs + (long)(i0 + i) * 16;
+      const int rc = fill_pack_params(pb.d[i], reinterpret_cast<const float*>(d[0]), d[1], (int)d[2], d[3], (int)d[4], (int)d[5], (int)d[6], (int)d[7],
+                                      (int)d[8], d[9], d[10], (int)d[11], reinterpret_cast<void*>(d[12]), (int)d[13], (int)d[14],
+                                      reinterpret_cast<float*>(d[15]));
+      if (rc) return rc;
+      pb.first_block[i] = blocks;
+      blocks += (int)((d[10] + PACK_ROWS - 1) / PACK_ROWS) * pb.d[i].ncg;
+    }
+    pb.first_block[pb.n] = blocks;
+    hipLaunchKernelGGL(k_pack_operands, dim3((unsigned)blocks), dim3(256), 0, s, pb);
+    if (hipGetLastError() != hipSuccess) return (int)hipGetLastError();
+  }
+  return 0;
+}
+
+int launch_pack_operand(const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
+                        int prec, void* out, int cg_off, int ncg_total, float* colsum, hipStream_t s) {
+  if (rows_p <= 0 || C <= 0) return 0;
+  const long d[16] = {(long)reinterpret_cast<uintptr_t>(x), ldx, C, rows, B, H, W, padH, padW, guard, rows_p, prec, (long)reinterpret_cast<uintptr_t>(out),
+                      cg_off, ncg_total, (long)reinterpret_cast<uintptr_t>(colsum)};
+  return launch_pack_operands(d, 1, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -54,6 +54,7 @@ struct ConvGemmParams {
 
 int launch_pack_operand(const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
                         int prec, void* out, int cg_off, int ncg_total, float* colsum, hipStream_t s);
+int launch_pack_operands(const long* descs, int n, hipStream_t s);
 int launch_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* const* Xp1, int cin0, int nseg, long dy_rows_p, int cout, long x_rows_p,
                     int cin, long guard, long K, int KH, int KW, int Wp, float* dW, int prec, hipStream_t s);
 int launch_pack_conv_weights(const float* w0, int cout0, const float* w1, int cout1, int Cin, int KH, int KW, int a0, int a1, int b0, int b1,

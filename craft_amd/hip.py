@@ -70,6 +70,7 @@ _SIGS = {
     "craft_pack_operand": [P, L, I, L, I, I, I, I, I, L, L, I, P, I, I, P, P],
     "craft_pack_conv_weights": [P, I, P, I, I, I, I, I, I, I, I, I, I, P, P],
     "craft_conv2d_nhwc2": [P, L, I, P, L, I, P, P, P, L, I, I, I, I, P, L, I, I, I, I, P],
+    "craft_pack_operands": [P, I, P],
     "craft_wgrad_pk": [P, P, P, I, I, L, I, L, I, L, L, I, I, I, P, I, P],
     "craft_norm_act_fwd": [P, L, P, I, P, P, I, P, L, P, L, I, I, I, P],
     "craft_norm_act_bwd_reduce": [P, L, P, L, P, L, P, I, P, P, I, I, P, I, I, I, P],

@@ -82,6 +82,7 @@ class UpdatePass:
         self.rep_agg = None        # replicated (dw_agg, dskip) table of the aggregator's pooling, reduced at the end of the pass
         self.dgamma = None
         self.saved = [None] * iters
+        self.ready = []
         self.dv = [None] * iters
         self.zero1 = torch.zeros(1, device=dev, dtype=torch.float32)
         self.zero_tok = None
@@ -95,11 +96,17 @@ class UpdatePass:
         return b
 
     def wgrad(self, key, pair, KH, KW, acc, last):
-        """Queue the packed (dY, X) pair of this iteration; the last backward call (iteration 0) launches ONE product over all of them."""
+        """Queue the packed (dY, X) pair of this iteration; after the last one (iteration 0 in phase 1) ``launch_ready`` runs ONE product
+        over all of them -- once the pack batch that holds this iteration's dY packs has been flushed."""
         k = ("pk_pending", key)
         self.cache.setdefault(k, []).append(pair)
         if last:
+            self.ready.append((k, KH, KW, acc))
+
+    def launch_ready(self):
+        for k, KH, KW, acc in self.ready:
             AG.wgrad_pk(self.cache.pop(k), KH, KW, acc)
+        self.ready = []
 
 
 def _flow32(flow, B, N):
@@ -152,6 +159,7 @@ class UpdateIter(Function):
         coords1 = AG._c(coords1.detach())
         corr = ops.corr_lookup([h.pyr for h in ps.holders], coords1, ps.radius)       # network.py:235 / corr.py:47-71
         S = {"coords": coords1}
+        pb = AG.PackBatch()                                                          # the iteration's conv inputs: ONE pack launch at its end
         if ps.zero_tok is None:
             ps.zero_tok = torch.zeros_like(token)
         flow = coords1 - coords0                                                     # [B, N, 2]
@@ -165,11 +173,11 @@ class UpdateIter(Function):
         mf = hx[..., MF:MF + 128]
         # packs of the motion encoder's conv inputs (for the weight gradients)
         g3, g7 = (B, H8, W8, 1, 1), (B, H8, W8, 3, 3)
-        S["pk_corr"] = AG.Packed(corr, cp)
-        S["pk_cor1"] = AG.Packed(S["cor1"], cp, g3)
-        S["pk_flow"] = AG.Packed(_flow32(flow, B, N), cp, g7)
-        S["pk_flo1"] = AG.Packed(S["flo1"], cp, g3)
-        S["pk_cf"] = AG.Packed(S["cf"], cp, g3)
+        S["pk_corr"] = AG.Packed(corr, cp, batch=pb)
+        S["pk_cor1"] = AG.Packed(S["cor1"], cp, g3, batch=pb)
+        S["pk_flow"] = AG.Packed(_flow32(flow, B, N), cp, g7, batch=pb)
+        S["pk_flo1"] = AG.Packed(S["flo1"], cp, g3, batch=pb)
+        S["pk_cf"] = AG.Packed(S["cf"], cp, g3, batch=pb)
         # ---- motion aggregator (update.py:143-149)
         P = ps.pholder.P
         Bp, M, _, ld = P.shape
@@ -187,7 +195,7 @@ class UpdateIter(Function):
         else:
             ops.gma_residual(mf, Oa.view(B, N, Cv), agg.gamma.detach(), out=hx[..., MFG:MFG + 128])
         S["va"], S["Oa"] = va, Oa
-        S["pk_mf"] = AG.Packed(mf, pick(prec, "proj"))
+        S["pk_mf"] = AG.Packed(mf, pick(prec, "proj"), batch=pb)
         # ---- SepConvGRU (update.py:49-64): horizontal pass h0 -> h1 (in HX_t), vertical pass h1 -> net_{t+1} (into HX_{t+1});
         # convolutions over [h | v], v = [mf | mfg]; inp's share and the biases arrive as per-pixel fields
         wzr1, wq1, wzr2, wq2 = ps.w_gru
@@ -205,12 +213,12 @@ class UpdateIter(Function):
             call("craft_conv2d_nhwc2", rh, 128, 128, v, _C, 256, wq, None, F_[..., fq:], 768, 128, KH, KW, ACT_NONE, q_pre, 256, B, H8, W8, cp | W_PACKED)
             q = torch.empty(B, N, 128, device=dev, dtype=torch.float32)
             call("craft_gru_out_fwd", q_pre, 256, z, h, _C, q, hn, _C, rows, 128)
-            S[f"pk_h{p_}"] = AG.Packed(h, cp, geom)
-            S[f"pk_rh{p_}"] = AG.Packed(rh, cp, geom)
-            S[f"pk_v{p_}"] = AG.Packed(v, cp, geom)                                  # shared by the z|r and the q convolution of this pass
+            S[f"pk_h{p_}"] = AG.Packed(h, cp, geom, batch=pb)
+            S[f"pk_rh{p_}"] = AG.Packed(rh, cp, geom, batch=pb)
+            S[f"pk_v{p_}"] = AG.Packed(v, cp, geom, batch=pb)                                  # shared by the z|r and the q convolution of this pass
             S[f"z{p_}"], S[f"r{p_}"], S[f"q{p_}"] = z, r, q
         h2 = hxn[..., H0:H0 + 128]
-        S["pk_h2"] = AG.Packed(h2, cp, g3)
+        S["pk_h2"] = AG.Packed(h2, cp, g3, batch=pb)
         # ---- heads (update.py:15-16, :124-127, :161) + coords1 += delta (network.py:247) + convex upsampling (:258)
         fh1 = torch.empty(B, N, 256, device=dev, dtype=torch.float32)
         c1n = coords1.clone()
@@ -221,8 +229,9 @@ class UpdateIter(Function):
         call("craft_mask_head", h2, _C, *ps.w_mask, B, H8, W8, mask, mh, cp | W_PACKED)
         up = ops.convex_upsample(mask, flow_new, H8, W8)
         S["fh1"], S["mh"], S["mask"], S["flow_new"] = fh1, mh, mask, flow_new
-        S["pk_fh1"] = AG.Packed(fh1, cp, g3)
-        S["pk_mh"] = AG.Packed(mh, cp)
+        S["pk_fh1"] = AG.Packed(fh1, cp, g3, batch=pb)
+        S["pk_mh"] = AG.Packed(mh, cp, batch=pb)
+        pb.flush()
         ps.saved[t] = S
         ctx.ps, ctx.t = ps, t
         ctx.nparams = len(params)
@@ -242,6 +251,7 @@ class UpdateIter(Function):
         last = t == 0                                # backward runs the iterations in reverse: t = 0 completes every accumulator
         g3, g7 = (B, H8, W8, 1, 1), (B, H8, W8, 3, 3)
         E = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)      # noqa: E731
+        pb = AG.PackBatch()                                                  # this call's dY packs: one launch at its end
         h2 = hxn[..., H0:H0 + 128]
 
         # ---- convex upsampling, mask head
@@ -258,16 +268,16 @@ class UpdateIter(Function):
             w2m = w2.detach().view(576, 256)
             d_mh = E(B, N, 256)
             AG.gemm(dm, 576, 1, 0, 0, w2m, 1, 256, 0, 0, d_mh, 256, 0, 0, 1, 1, rows, 256, 576, prec=cp)
-            ps.wgrad(("mask2",), (AG.Packed(dm, cp, colsum=ps.acc(("mask2", "db"), (576,))), S["pk_mh"]), 1, 1, ps.acc(("mask2", "dw"), (576, 256)), last)
+            ps.wgrad(("mask2",), (AG.Packed(dm, cp, colsum=ps.acc(("mask2", "db"), (576,)), batch=pb), S["pk_mh"]), 1, 1, ps.acc(("mask2", "dw"), (576, 256)), last)
             g_mh = _act_bwd(d_mh, S["mh"], 256, out=d_mh)
             dh2 = _conv_dx(ps, ub.mask[0].weight, g_mh, 256, 3, 3)
-            ps.wgrad(("mask0",), (AG.Packed(g_mh, cp, g3, colsum=ps.acc(("mask0", "db"), (256,))), S["pk_h2"]), 3, 3, ps.acc(("mask0", "dw"), (256, 3, 3, 128)), last)
+            ps.wgrad(("mask0",), (AG.Packed(g_mh, cp, g3, colsum=ps.acc(("mask0", "db"), (256,)), batch=pb), S["pk_h2"]), 3, 3, ps.acc(("mask0", "dw"), (256, 3, 3, 128)), last)
             # ---- flow head: delta = conv2(relu(conv1(h2)))
             d_fh1 = _conv_dx(ps, fh.conv2.weight, dflow, 32, 3, 3)
-            ps.wgrad(("fh2",), (AG.Packed(dflow, cp, g3, colsum=ps.acc(("fh2", "db"), (32,))), S["pk_fh1"]), 3, 3, ps.acc(("fh2", "dw"), (32, 3, 3, 256)), last)
+            ps.wgrad(("fh2",), (AG.Packed(dflow, cp, g3, colsum=ps.acc(("fh2", "db"), (32,)), batch=pb), S["pk_fh1"]), 3, 3, ps.acc(("fh2", "dw"), (32, 3, 3, 256)), last)
             g_fh1 = _act_bwd(d_fh1, S["fh1"], 256, out=d_fh1)
             dh2b = _conv_dx(ps, fh.conv1.weight, g_fh1, 256, 3, 3)
-            ps.wgrad(("fh1",), (AG.Packed(g_fh1, cp, g3, colsum=ps.acc(("fh1", "db"), (256,))), S["pk_h2"]), 3, 3, ps.acc(("fh1", "dw"), (256, 3, 3, 128)), last)
+            ps.wgrad(("fh1",), (AG.Packed(g_fh1, cp, g3, colsum=ps.acc(("fh1", "db"), (256,)), batch=pb), S["pk_h2"]), 3, 3, ps.acc(("fh1", "dw"), (256, 3, 3, 128)), last)
             dh2.add_(dh2b)
             if d_hn is not None:
                 dh2.add_(d_hn)
@@ -288,12 +298,12 @@ class UpdateIter(Function):
             dqp, dz, dhp = E(B, N, 128), E(B, N, 128), E(B, N, 128)
             call("craft_gru_out_bwd", dh, dh.stride(-2), z, q, h, _C, dqp, dz, dhp, rows, 128)
             tq = _conv_dx(ps, ps.wqT[p_], dqp, 128, KH, KW, cin_p=384)                        # d[rh | mf | mfg]
-            ps.wgrad(("q", p_), (AG.Packed(dqp, cp, geom, colsum=ps.acc(("q", p_, "db"), (128,))), _cat_pack(S[f"pk_rh{p_}"], S[f"pk_v{p_}"])), KH, KW,
+            ps.wgrad(("q", p_), (AG.Packed(dqp, cp, geom, colsum=ps.acc(("q", p_, "db"), (128,)), batch=pb), _cat_pack(S[f"pk_rh{p_}"], S[f"pk_v{p_}"])), KH, KW,
                      ps.acc(("q", p_, "dw"), (128, KH, KW, 384)), last)
             dzr = E(B, N, 256)
             call("craft_gru_zr_bwd", dz, tq, 384, z, r, h, _C, dzr, dhp, rows, 128)            # dhp += d(rh) r
             tz = _conv_dx(ps, ps.wzrT[p_], dzr, 256, KH, KW, cin_p=384)                       # d[h | mf | mfg]
-            ps.wgrad(("zr", p_), (AG.Packed(dzr, cp, geom, colsum=ps.acc(("zr", p_, "db"), (256,))), _cat_pack(S[f"pk_h{p_}"], S[f"pk_v{p_}"])), KH, KW,
+            ps.wgrad(("zr", p_), (AG.Packed(dzr, cp, geom, colsum=ps.acc(("zr", p_, "db"), (256,)), batch=pb), _cat_pack(S[f"pk_h{p_}"], S[f"pk_v{p_}"])), KH, KW,
                      ps.acc(("zr", p_, "dw"), (256, KH, KW, 384)), last)
             dhp.add_(tz[..., :128])
             if dv is None:
@@ -313,6 +323,8 @@ class UpdateIter(Function):
         d_net = dh                                                                            # gradient of net_t
         ps.dv[t] = dv                                                                         # gradient of [mf | mfg]: phase 2
         ps.saved[t] = S
+        pb.flush()
+        ps.launch_ready()
         d_inp = None
         if last:
             # ---- the hoisted inp channels: d_inp = sum over the four gate convolutions of conv^T(W_inp, sum_t dY_t), dW_inp = (sum_t dY_t)^T inp
@@ -382,37 +394,40 @@ def _phase2(ps: UpdatePass):
     dva5 = dva_cat.view(B, N, M, T, Cv)
     for t in range(T):
         S = ps.saved[t]
+        pb = AG.PackBatch()
         last = t == T - 1                                    # (the order of phase 2 is free: the accumulators complete with its last iteration)
         mf = ps.HX[t][..., MF:MF + 128]
         d_mf = d_mfs[t]
         dva = dva5[:, :, :, t, :].reshape(B, N, M * Cv)              # M > 1: a contiguous copy; one mode: a strided view (row stride T*Cv)
         d_mf3 = E(B, N, 128)
         AG.gemm(dva, dva.stride(-2), 1, 0, 0, wv2, 1, 128, 0, 0, d_mf3, 128, 0, 0, 1, 1, rows, 128, M * Cv, prec=pp)
-        ps.wgrad(("agg_v",), (AG.Packed(dva, pp), S["pk_mf"]), 1, 1, ps.acc(("agg_v", "dw"), (M * Cv, 128)), last)
+        ps.wgrad(("agg_v",), (AG.Packed(dva, pp, batch=pb), S["pk_mf"]), 1, 1, ps.acc(("agg_v", "dw"), (M * Cv, 128)), last)
         d_mf.add_(d_mf3).add_(ps.dv[t][..., 0:128])
         ps.dv[t] = None
         # ---- BasicMotionEncoder
         g_out = _act_bwd(d_mf, mf, 128, out=d_mf)
         g_out[..., 126:128] = 0.0                                                             # the two pass-through flow channels carry no gradient
         d_cf = _conv_dx(ps, enc.conv.weight, g_out, 128, 3, 3)
-        ps.wgrad(("menc",), (AG.Packed(g_out, cp, g3, colsum=ps.acc(("menc", "db"), (128,))), S["pk_cf"]), 3, 3, ps.acc(("menc", "dw"), (128, 3, 3, 256)), last)
+        ps.wgrad(("menc",), (AG.Packed(g_out, cp, g3, colsum=ps.acc(("menc", "db"), (128,)), batch=pb), S["pk_cf"]), 3, 3, ps.acc(("menc", "dw"), (128, 3, 3, 256)), last)
         g_cf = _act_bwd(d_cf, S["cf"], 256, out=d_cf)
         g_c2, g_f2 = g_cf[..., :192], g_cf[..., 192:256]
         d_cor1 = _conv_dx(ps, enc.convc2.weight, g_c2, 192, 3, 3)
-        ps.wgrad(("c2",), (AG.Packed(g_c2, cp, g3, colsum=ps.acc(("c2", "db"), (192,))), S["pk_cor1"]), 3, 3, ps.acc(("c2", "dw"), (192, 3, 3, 256)), last)
+        ps.wgrad(("c2",), (AG.Packed(g_c2, cp, g3, colsum=ps.acc(("c2", "db"), (192,)), batch=pb), S["pk_cor1"]), 3, 3, ps.acc(("c2", "dw"), (192, 3, 3, 256)), last)
         g_cor1 = _act_bwd(d_cor1, S["cor1"], 256, out=d_cor1)
         wc1 = enc.convc1.weight.detach().view(256, -1)
         cpl = wc1.shape[1]
         d_corr = E(B, N, cpl)
         AG.gemm(g_cor1, 256, 1, 0, 0, wc1, 1, cpl, 0, 0, d_corr, cpl, 0, 0, 1, 1, rows, cpl, 256, prec=cp)
-        ps.wgrad(("c1",), (AG.Packed(g_cor1, cp, colsum=ps.acc(("c1", "db"), (256,))), S["pk_corr"]), 1, 1, ps.acc(("c1", "dw"), (256, round_up(cpl, 32))), last)
+        ps.wgrad(("c1",), (AG.Packed(g_cor1, cp, colsum=ps.acc(("c1", "db"), (256,)), batch=pb), S["pk_corr"]), 1, 1, ps.acc(("c1", "dw"), (256, round_up(cpl, 32))), last)
         d_flo1 = _conv_dx(ps, enc.convf2.weight, g_f2, 64, 3, 3)
-        ps.wgrad(("f2",), (AG.Packed(g_f2, cp, g3, colsum=ps.acc(("f2", "db"), (64,))), S["pk_flo1"]), 3, 3, ps.acc(("f2", "dw"), (64, 3, 3, 128)), last)
+        ps.wgrad(("f2",), (AG.Packed(g_f2, cp, g3, colsum=ps.acc(("f2", "db"), (64,)), batch=pb), S["pk_flo1"]), 3, 3, ps.acc(("f2", "dw"), (64, 3, 3, 128)), last)
         g_flo1 = _act_bwd(d_flo1, S["flo1"], 128, out=d_flo1)
-        ps.wgrad(("f1",), (AG.Packed(g_flo1, cp, g7, colsum=ps.acc(("f1", "db"), (128,))), S["pk_flow"]), 7, 7, ps.acc(("f1", "dw"), (128, 7, 7, 32)), last)
+        ps.wgrad(("f1",), (AG.Packed(g_flo1, cp, g7, colsum=ps.acc(("f1", "db"), (128,)), batch=pb), S["pk_flow"]), 7, 7, ps.acc(("f1", "dw"), (128, 7, 7, 32)), last)
         # ---- correlation lookup (corr.py:47-71): the gradient goes into the shared buffers of the normalised pyramid; autograd.CorrVolume
         # (every iteration took its token) folds them into the volume's gradient after this node
         AG.lookup_bwd(ps.holders, d_corr, S["coords"], ps.radius)
+        pb.flush()
+        ps.launch_ready()
         S.clear()
         ps.saved[t] = None
 

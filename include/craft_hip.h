@@ -354,6 +354,10 @@ int craft_colsum(const float* x, long ld, long rows, int C, float* out, void* st
  *   Xp[s], [cin0, cin) from Xp1[s] (cat([h, x]) / cat([r*h, x]) of SepConvGRU: x is packed once per pass and shared by both gates). */
 int craft_pack_operand(const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
                        int prec, void* out, int cg_off, int ncg_total, float* colsum, void* stream);
+/* n craft_pack_operand calls as ONE launch (a training iteration packs ~14 convolution inputs of a few MB each: separate launches are
+ * overhead-bound).  descs: HOST array of n x 16 longs per tensor, the arguments of craft_pack_operand in order with pointers as integers:
+ * (x, ldx, C, rows, B, H, W, padH, padW, guard, rows_p, prec, out, cg_off, ncg_total, colsum). */
+int craft_pack_operands(const long* descs, int n, void* stream);
 int craft_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* const* Xp1, int cin0, int nseg, long dy_rows_p, int cout, long x_rows_p,
                    int cin, long guard, long K, int KH, int KW, int Wp, float* dW, int prec, void* stream);
 
