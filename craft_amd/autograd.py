@@ -256,33 +256,41 @@ class Scores(Function):
 
 
 class AttnSoftmax(Function):
-    """P = softmax_j(clamp?(S) + pos_w pb + mask) in place on S (setrans.py:520-551)."""
+    """P = softmax_j(clamp?(S) + pos_w pb + mask) in place on S (setrans.py:520-551); with drop_p > 0 the dropout of the probabilities
+    (setrans.py:553-557) in the same two kernels: the forward returns the dropped copy (P itself stays in S for the backward), the
+    backward applies the mask to the incoming gradient as it reads it -- no separate pass over the [B, M, N, N] tensor either way."""
 
     @staticmethod
-    def forward(ctx, S, pos_tab, pos_w, mask_radius, clamp_ord, hw):
+    def forward(ctx, S, pos_tab, pos_w, mask_radius, clamp_ord, hw, drop_p=0.0, seed=0):
         B, M, N, ld = S.shape
         R = (pos_tab.shape[0] - 1) // 2 if pos_tab is not None else 0          # None: plain softmax (gma.Attention, gma.py:96-98)
         bits = torch.empty(B * M * N * (ld // 32), device=S.device, dtype=torch.int32)
         tab = _c(pos_tab.detach()) if pos_tab is not None else None
-        call("craft_attn_softmax_fwd", S, ld, B, M, hw[0], hw[1], tab, R, float(pos_w), int(mask_radius), clamp_ord, bits)
-        ctx.mark_dirty(S)
+        out = torch.empty_like(S) if drop_p > 0.0 else None
+        call("craft_attn_softmax_fwd", S, ld, B, M, hw[0], hw[1], tab, R, float(pos_w), int(mask_radius), clamp_ord, bits,
+             out, float(drop_p), int(seed))
+        ctx.hw, ctx.R, ctx.pos_w, ctx.has_tab, ctx.drop = hw, R, pos_w, pos_tab is not None, (float(drop_p), int(seed))
         ctx.save_for_backward(S, bits, clamp_ord)
-        ctx.hw, ctx.R, ctx.pos_w, ctx.has_tab = hw, R, pos_w, pos_tab is not None
-        return S
+        if out is None:
+            ctx.mark_dirty(S)
+            return S
+        return out                                     # S (this function's scratch by contract) keeps P for the backward
 
     @staticmethod
     def backward(ctx, dP):
         P, bits, clamp_ord = ctx.saved_tensors
         B, M, N, ld = P.shape
-        dS = dP.contiguous().clone()
+        # dS over the incoming gradient: it is the fresh output of the one consumer of P (AttnApply / ProbsToken), nothing else holds it
+        dS = dP if dP.is_contiguous() else dP.contiguous()
         T = 2 * ctx.R + 1
         rep = torch.zeros(STATS_REPLICAS, T * T, device=P.device, dtype=torch.float32) if ctx.has_tab else None
-        call("craft_attn_softmax_bwd", P, dS, ld, B, M, ctx.hw[0], ctx.hw[1], ctx.R, float(ctx.pos_w), clamp_ord, bits, rep)
+        call("craft_attn_softmax_bwd", P, dS, ld, B, M, ctx.hw[0], ctx.hw[1], ctx.R, float(ctx.pos_w), clamp_ord, bits, rep,
+             ctx.drop[0], ctx.drop[1])
         dtab = None
         if ctx.has_tab:
             dtab = torch.zeros(T, T, device=P.device, dtype=torch.float32)
             call("craft_reduce_replicas", rep, STATS_REPLICAS, T * T, dtab)
-        return dS, dtab, None, None, None, None
+        return dS, dtab, None, None, None, None, None, None
 
 
 class RelPosAdd(Function):

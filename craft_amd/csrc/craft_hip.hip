@@ -513,12 +513,13 @@ int craft_tokens_bwd(const float* x, long ldx, const float* dy, long lddy, float
   return launch_tokens_bwd(x, ldx, dy, lddy, dx, lddx, rows, C, act, do_ln, S(stream));
 }
 int craft_attn_softmax_fwd(float* Sc, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, int mask_radius,
-                           const unsigned* clamp_ord, unsigned* clampbits, void* stream) {
-  return launch_attn_softmax_fwd(Sc, ld, B, M, H8, W8, pos_tab, R, pos_w, mask_radius, clamp_ord, clampbits, S(stream));
+                           const unsigned* clamp_ord, unsigned* clampbits, float* Pdrop, float drop_p, unsigned long long seed, void* stream) {
+  return launch_attn_softmax_fwd(Sc, ld, B, M, H8, W8, pos_tab, R, pos_w, mask_radius, clamp_ord, clampbits, Pdrop, drop_p, seed, S(stream));
 }
 int craft_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, int H8, int W8, int R, float pos_w,
-                           const unsigned* clamp_ord, const unsigned* clampbits, float* dtab_rep, void* stream) {
-  return launch_attn_softmax_bwd(P, dP, ld, B, M, H8, W8, R, pos_w, clamp_ord, clampbits, dtab_rep, S(stream));
+                           const unsigned* clamp_ord, const unsigned* clampbits, float* dtab_rep, float drop_p, unsigned long long seed,
+                           void* stream) {
+  return launch_attn_softmax_bwd(P, dP, ld, B, M, H8, W8, R, pos_w, clamp_ord, clampbits, dtab_rep, drop_p, seed, S(stream));
 }
 int craft_reduce_replicas(const float* rep, int nrep, int n, float* out, void* stream) {
   return launch_reduce_replicas(rep, nrep, n, out, S(stream));

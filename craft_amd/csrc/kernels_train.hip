@@ -189,7 +189,8 @@ int launch_tokens_bwd(const float* x, long ldx, const float* dy, long lddy, floa
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_attn_softmax_fwd(float* __restrict__ S, long ld, int N, int H8, int W8,
                                                           const float* __restrict__ pos_tab, int R, float pos_w, int mask_radius,
-                                                          const unsigned* __restrict__ clamp_ord, unsigned* __restrict__ clampbits) {
+                                                          const unsigned* __restrict__ clamp_ord, unsigned* __restrict__ clampbits,
+                                                          float* __restrict__ Pdrop, float drop_p, unsigned long long seed) {
   extern __shared__ __attribute__((aligned(16))) float row[];
   __shared__ float red[4];
   const long rr = blockIdx.x;                   // (z, i)
@@ -226,15 +227,29 @@ __global__ __launch_bounds__(256) void k_attn_softmax_fwd(float* __restrict__ S,
   for (int j = threadIdx.x; j < N; j += 256) { const float e = expf(row[j] - mx); row[j] = e; sum += e; }
   sum = block_sum_256(sum, red);
   const float inv = 1.f / sum;
-  for (int j = threadIdx.x; j < ld; j += 256) Sr[j] = j < N ? row[j] * inv : 0.f;
+  if (Pdrop == nullptr) {
+    for (int j = threadIdx.x; j < ld; j += 256) Sr[j] = j < N ? row[j] * inv : 0.f;
+  } else {
+    // the dropout of the probabilities (setrans.py:553-557) in the same pass: P stays in S (the softmax backward needs it), the dropped
+    // copy goes to Pdrop -- the mask of k_dropout over the same flat element index
+    const unsigned thr = (unsigned)fminf(drop_p * 4294967296.f, 4294967040.f);
+    const float dinv = 1.f / (1.f - drop_p);
+    float* Dr = Pdrop + rr * ld;
+    for (int j = threadIdx.x; j < ld; j += 256) {
+      const float pj = j < N ? row[j] * inv : 0.f;
+      Sr[j] = pj;
+      Dr[j] = mix32(seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)(rr * ld + j)) >= thr ? pj * dinv : 0.f;
+    }
+  }
 }
 int launch_attn_softmax_fwd(float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, int mask_radius,
-                            const unsigned* clamp_ord, unsigned* clampbits, hipStream_t s) {
+                            const unsigned* clamp_ord, unsigned* clampbits, float* Pdrop, float drop_p, unsigned long long seed, hipStream_t s) {
   const int N = H8 * W8;
   if (N <= 0 || B <= 0) return 0;
   if (N > 16000 || (ld & 31) || ld < N) return CRAFT_ERR_UNSUPPORTED;
+  if (Pdrop != nullptr && (drop_p < 0.f || drop_p >= 1.f)) return CRAFT_ERR_ARG;
   hipLaunchKernelGGL(k_attn_softmax_fwd, dim3((unsigned)((long)B * M * N)), dim3(256), (size_t)N * sizeof(float), s, S, ld, N, H8, W8,
-                     pos_tab, R, pos_w, mask_radius, clamp_ord, clampbits);
+                     pos_tab, R, pos_w, mask_radius, clamp_ord, clampbits, Pdrop, drop_p, seed);
   return (int)hipGetLastError();
 }
 
@@ -243,9 +258,14 @@ int launch_attn_softmax_fwd(float* S, long ld, int B, int M, int H8, int W8, con
 constexpr int SM_ROWS_PER_BLOCK = 8;
 __global__ __launch_bounds__(256) void k_attn_softmax_bwd(const float* __restrict__ P, float* __restrict__ dP, long ld, int N, int H8,
                                                           int W8, int R, float pos_w, const unsigned* __restrict__ clamp_ord,
-                                                          const unsigned* __restrict__ clampbits, float* __restrict__ dtab, long nrows) {
+                                                          const unsigned* __restrict__ clampbits, float* __restrict__ dtab, long nrows,
+                                                          float drop_p, unsigned long long seed) {
   __shared__ float red[4];
   __shared__ float tab[32 * 32];
+  // drop_p > 0: dP is the gradient w.r.t. the DROPPED probabilities (k_attn_softmax_fwd's Pdrop): the dropout backward (the same mask)
+  // is applied while the row is read
+  const unsigned thr = (unsigned)fminf(drop_p * 4294967296.f, 4294967040.f);
+  const float dinv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const int T = 2 * R + 1;
   const bool want_tab = dtab != nullptr && R >= 0;
   if (want_tab) for (int t = threadIdx.x; t < T * T; t += 256) tab[t] = 0.f;
@@ -256,13 +276,18 @@ __global__ __launch_bounds__(256) void k_attn_softmax_bwd(const float* __restric
     const int hi = i / W8, wi = i - hi * W8;
     const float* Pr = P + rr * ld;
     float* Gr = dP + rr * ld;
+    auto grad = [&](int j) __attribute__((always_inline)) {
+      const float g = Gr[j];
+      if (drop_p <= 0.f) return g;
+      return mix32(seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)(rr * ld + j)) >= thr ? g * dinv : 0.f;
+    };
     float dot = 0.f;
-    for (int j = threadIdx.x; j < N; j += 256) dot += Pr[j] * Gr[j];
+    for (int j = threadIdx.x; j < N; j += 256) dot += Pr[j] * grad(j);
     dot = block_sum_256(dot, red);
     for (int j = threadIdx.x; j < ld; j += 256) {
       float ds = 0.f;
       if (j < N) {
-        ds = Pr[j] * (Gr[j] - dot);
+        ds = Pr[j] * (grad(j) - dot);
         if (want_tab) {
           const int hj = j / W8, wj = j - hj * W8;
           const int dh = hj - hi, dw = wj - wi;
@@ -280,13 +305,13 @@ __global__ __launch_bounds__(256) void k_attn_softmax_bwd(const float* __restric
   }
 }
 int launch_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, int H8, int W8, int R, float pos_w,
-                            const unsigned* clamp_ord, const unsigned* clampbits, float* dtab, hipStream_t s) {
+                            const unsigned* clamp_ord, const unsigned* clampbits, float* dtab, float drop_p, unsigned long long seed, hipStream_t s) {
   const int N = H8 * W8;
   if (N <= 0 || B <= 0) return 0;
   if (R > 15 || (ld & 31)) return CRAFT_ERR_UNSUPPORTED;
   const long nrows = (long)B * M * N;
   hipLaunchKernelGGL(k_attn_softmax_bwd, dim3((unsigned)((nrows + SM_ROWS_PER_BLOCK - 1) / SM_ROWS_PER_BLOCK)), dim3(256), 0, s, P, dP, ld,
-                     N, H8, W8, R, pos_w, clamp_ord, clampbits, dtab, nrows);
+                     N, H8, W8, R, pos_w, clamp_ord, clampbits, dtab, nrows, drop_p, seed);
   return (int)hipGetLastError();
 }
 

@@ -189,9 +189,10 @@ int launch_dropout(const float* x, float* y, long n, float p, unsigned long long
 int launch_tokens_bwd(const float* x, long ldx, const float* dy, long lddy, float* dx, long lddx, long rows, int C, int act, int do_ln,
                       hipStream_t s);
 int launch_attn_softmax_fwd(float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, int mask_radius,
-                            const unsigned* clamp_ord, unsigned* clampbits, hipStream_t s);
+                            const unsigned* clamp_ord, unsigned* clampbits, float* Pdrop, float drop_p, unsigned long long seed, hipStream_t s);
 int launch_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, int H8, int W8, int R, float pos_w,
-                            const unsigned* clamp_ord, const unsigned* clampbits, float* dtab, hipStream_t s);
+                            const unsigned* clamp_ord, const unsigned* clampbits, float* dtab, float drop_p, unsigned long long seed,
+                            hipStream_t s);
 int launch_reduce_replicas(const float* rep, int nrep, int n, float* out, hipStream_t s);
 int launch_corr_pool_fwd(const float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, const float* w,
                          const unsigned* clamp_ord, float* c0, double* sums, hipStream_t s);

@@ -84,8 +84,8 @@ _SIGS = {
     "craft_act_bwd": [P, L, P, L, P, L, L, I, I, F, P],
     "craft_dropout": [P, P, L, F, ctypes.c_ulonglong, P],
     "craft_tokens_bwd": [P, L, P, L, P, L, L, I, I, I, P],
-    "craft_attn_softmax_fwd": [P, L, I, I, I, I, P, I, F, I, P, P, P],
-    "craft_attn_softmax_bwd": [P, P, L, I, I, I, I, I, F, P, P, P, P],
+    "craft_attn_softmax_fwd": [P, L, I, I, I, I, P, I, F, I, P, P, P, F, ctypes.c_ulonglong, P],
+    "craft_attn_softmax_bwd": [P, P, L, I, I, I, I, I, F, P, P, P, F, ctypes.c_ulonglong, P],
     "craft_relpos_add": [P, L, I, I, I, P, L, P, L, F, P],
     "craft_relpos_bwd": [P, L, I, I, I, P, L, I, P, L, I, F, P],
     "craft_reduce_replicas": [P, I, I, P, P],

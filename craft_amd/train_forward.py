@@ -60,8 +60,8 @@ def _attention_probs(module, x_ln, hw, prec, p_attn: float, seed: int):
     scale = 1.0 / math.sqrt(st.attention_mode_dim)
     mx = ops.score_max(q.detach(), k.detach(), hw[0], hw[1], M, scale, prec)
     S = AG.Scores.apply(q, k, M, scale, prec)
-    P = AG.AttnSoftmax.apply(S, module.vispos_encoder.pos_coder.biases, float(st.pos_code_weight), int(module.attn_mask_radius), mx, hw)
-    return AG.dropout(P, p_attn, seed)
+    return AG.AttnSoftmax.apply(S, module.vispos_encoder.pos_coder.biases, float(st.pos_code_weight), int(module.attn_mask_radius), mx, hw,
+                                float(p_attn), int(seed))
 
 
 def _conv(x, conv, hw, act, prec, cache):

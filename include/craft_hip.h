@@ -375,11 +375,15 @@ int craft_tokens_bwd(const float* x, long ldx, const float* dy, long lddy, float
  *   clampbits (or NULL): [B*M*N][ld/32] words, bit j = "score (i, j) was clamped" -- written only when the clamp is active.
  * craft_attn_softmax_bwd: dP (gradient w.r.t. P, overwritten with dS) -> dS = P (dP - sum_j dP P), zero where clamped;
  *   dtab_rep [CRAFT_STATS_REPLICAS][(2R+1)^2] += pos_w * dS over the positional window (zero it first; craft_reduce_replicas
- *   folds the replicas into the table's gradient). */
+ *   folds the replicas into the table's gradient).
+ * Pdrop / drop_p / seed (Pdrop NULL: none): the dropout of the probabilities (setrans.py:553-557) fused into both passes -- the forward
+ *   also writes Pdrop = craft_dropout(P, drop_p, seed) (same mask: the flat element index), the backward (drop_p > 0) takes dP as the
+ *   gradient w.r.t. Pdrop and applies the mask while it reads the row (two 1 GB passes less per attention at 368x496, batch 8). */
 int craft_attn_softmax_fwd(float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, int mask_radius,
-                           const unsigned* clamp_ord, unsigned* clampbits, void* stream);
+                           const unsigned* clamp_ord, unsigned* clampbits, float* Pdrop, float drop_p, unsigned long long seed, void* stream);
 int craft_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, int H8, int W8, int R, float pos_w,
-                           const unsigned* clamp_ord, const unsigned* clampbits, float* dtab_rep, void* stream);
+                           const unsigned* clamp_ord, const unsigned* clampbits, float* dtab_rep, float drop_p, unsigned long long seed,
+                           void* stream);
 int craft_reduce_replicas(const float* rep, int nrep, int n, float* out, void* stream);
 
 /* gma.Attention's relative-position scores (RelPosEmb, gma.py:21-50, :84-98) added to materialised scores S [BZ][N][ld], BZ = B*heads:

@@ -256,6 +256,32 @@ def test_gru_gates_and_upsample_backward(device):
     _check_grads([hn, up], [hnr, upr], ld, lr, names=["zr_pre", "h", "q_pre", "mask", "flow"])
 
 
+def test_softmax_with_fused_probability_dropout(device):
+    """AttnSoftmax(drop_p, seed) (the dropout of the probabilities inside the softmax kernels, setrans.py:553-557) == AttnSoftmax followed by
+    Dropout with the same seed: outputs bit for bit, gradients of the scores and of the positional table to rounding."""
+    B, M, H8, W8 = 2, 4, 9, 11
+    N = H8 * W8
+    ld = hip.round_up(N, 32)
+    g = torch.Generator().manual_seed(3)
+    S0 = (torch.randn(B, M, N, ld, generator=g) * 3.0).to(device)
+    tab0 = (torch.randn(15, 15, generator=g) * 0.5).to(device)
+    gout = torch.randn(B, M, N, ld, generator=g).to(device)
+    res = []
+    for fused in (False, True):
+        S, tab = (S0.clone() * 1.0).requires_grad_(True), tab0.clone().requires_grad_(True)
+        Sw = S * 1.0                                             # a non-leaf the function may overwrite
+        if fused:
+            P = AG.AttnSoftmax.apply(Sw, tab, 0.5, 4, None, (H8, W8), 0.1, 77)
+        else:
+            P = AG.dropout(AG.AttnSoftmax.apply(Sw, tab, 0.5, 4, None, (H8, W8)), 0.1, 77)
+        P.backward(gout.clone())
+        res.append((P.detach(), S.grad, tab.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    keep = (res[1][0][..., :N] != 0).float().mean().item()
+    assert 0.3 < keep < 0.92                                           # the mask (radius 4) and the dropout both zero entries
+    assert rel_err(res[1][1], res[0][1]) < 1e-6 and rel_err(res[1][2], res[0][2]) < 1e-5
+
+
 def test_dropout(device):
     x = torch.ones(1 << 20, device=device).requires_grad_(True)
     for p in (0.1, 0.2, 0.5):
