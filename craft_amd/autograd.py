@@ -646,6 +646,7 @@ class Packed:
         C = sum(t.shape[-1] for t in srcs)
         rows = srcs[0].numel() // srcs[0].shape[-1]
         self.rows, self.C = rows, C
+        tail = 0
         if spatial is not None:
             B, H, W, ph, pw = spatial
             grid = B * (H + 2 * ph) * (W + 2 * pw)
@@ -670,10 +671,57 @@ class Packed:
                 if not t.is_cuda:
                     raise hip.CraftHipError("craft_amd HIP ops need device tensors (no CPU fallback)")
                 batch.add([t.data_ptr(), t.stride(-2), c, rows, B, H, W, ph, pw, self.guard, self.rows_p, prec, self.buf.data_ptr(), off, ncg,
-                           cs.data_ptr() if cs is not None else 0], (t, self.buf, cs))
+                           cs.data_ptr() if cs is not None else 0, tail], (t, self.buf, cs))
             else:
-                call("craft_pack_operand", t, t.stride(-2), c, rows, B, H, W, ph, pw, self.guard, self.rows_p, prec, self.buf, off, ncg, cs)
+                call("craft_pack_operand", t, t.stride(-2), c, rows, B, H, W, ph, pw, self.guard, self.rows_p, prec, self.buf, off, ncg, cs, tail)
             off += round_up(c, 32) // 32
+
+
+class PkMat:
+    """A batched packed operand of craft_gemm_pk: ``nb`` batches of ``rows`` rows, each padded to np_ = round_up(rows, 32) rows, over
+    ``ncg`` 32-channel groups -- [plane][ncg][nb * np_][32] 16-bit.  Filled by ``fill`` (craft_pack_operand(s)) or by a producer kernel
+    (craft_attn_softmax_fwd's Ppk)."""
+    __slots__ = ("buf", "nb", "rows", "np_", "ncg", "prec", "rows_total")
+
+    def __init__(self, nb: int, rows: int, C_p: int, prec: int, device):
+        self.nb, self.rows, self.np_, self.ncg, self.prec = nb, rows, round_up(rows, 32), C_p // 32, prec
+        self.rows_total = round_up(nb * self.np_, 64)
+        planes = 2 if prec == hip.PREC_F16X3 else 1
+        self.buf = torch.empty(planes * self.ncg * self.rows_total * 32, device=device, dtype=torch.int16)
+
+    def fill(self, x, cg_off: int = 0, batch=None, boff: int = 0):
+        """x [.., C] whose leading dims flatten to (batches, rows) with ONE row stride (a channel slice of a contiguous tensor is fine):
+        its batches go to batches boff, boff + 1, .. of the pack, channel groups [cg_off, cg_off + ceil(C / 32)); rows beyond ``rows`` and
+        channels beyond C of those groups are zeroed (every group of the pack must be filled by exactly one call)."""
+        C = x.shape[-1]
+        n = x.numel() // C
+        nbx = n // self.rows
+        if nbx * self.rows != n or nbx + boff > self.nb:
+            raise ValueError("PkMat.fill: the source is not a whole number of batches of the pack")
+        args = [x.data_ptr(), x.stride(-2), C, n, nbx, 1, self.rows, 0, 0, boff * self.np_, self.rows_total, self.prec, self.buf.data_ptr(), cg_off,
+                self.ncg, 0, self.np_ - self.rows]
+        if batch is not None:
+            if not x.is_cuda:
+                raise hip.CraftHipError("craft_amd HIP ops need device tensors (no CPU fallback)")
+            batch.add(args, (x, self.buf))
+        else:
+            call("craft_pack_operand", x, *args[1:12], self.buf, cg_off, self.ncg, None, args[16])
+        return self
+
+    def desc(self, kind: int, row_outer: int, row_inner: int, cg0: int = 0, cg_outer: int = 0, cg_inner: int = 0):
+        """The 9 longs of craft_gemm_pk for this pack (row strides in BATCHES of the pack)."""
+        return [kind, self.rows_total, self.ncg, 0, row_outer * self.np_, row_inner * self.np_, cg0, cg_outer, cg_inner]
+
+
+PK_ROWS, PK_CH = 0, 1
+
+
+def gemm_pk(A: PkMat, a_desc, B: PkMat, b_desc, C: torch.Tensor, ldc: int, c_outer: int, c_inner: int, inner: int, nbatch: int, M: int, N: int, K: int):
+    """C[z][m][n] = sum_k A_z[m, k] B_z[n, k] over packed operands (craft_gemm_pk; K padded to a multiple of 32 with zeros in both packs)."""
+    import ctypes
+    assert A.prec == B.prec
+    call("craft_gemm_pk", A.buf, (ctypes.c_long * 9)(*a_desc), B.buf, (ctypes.c_long * 9)(*b_desc), C, ldc, c_outer, c_inner, inner, nbatch, M, N,
+         round_up(K, 32), A.prec)
 
 
 class PackBatch:

@@ -440,8 +440,12 @@ int craft_conv2d_wgrad(const float* x, long ldx, int cin, const float* dy, long 
   return launch_conv_wgrad(x, ldx, cin, dy, ldy, cout, KH, KW, B, H, W, dW, db, ws, ws_floats, prec, S(stream));
 }
 int craft_pack_operand(const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
-                       int prec, void* out, int cg_off, int ncg_total, float* colsum, void* stream) {
-  return launch_pack_operand(x, ldx, C, rows, B, H, W, padH, padW, guard, rows_p, prec, out, cg_off, ncg_total, colsum, S(stream));
+                       int prec, void* out, int cg_off, int ncg_total, float* colsum, int tail, void* stream) {
+  return launch_pack_operand(x, ldx, C, rows, B, H, W, padH, padW, guard, rows_p, prec, out, cg_off, ncg_total, colsum, tail, S(stream));
+}
+int craft_gemm_pk(const void* A, const long* a_desc, const void* B, const long* b_desc, float* C, long ldc, long c_outer, long c_inner,
+                  int inner, int nbatch, int M, int N, int K, int prec, void* stream) {
+  return launch_gemm_pk(A, a_desc, B, b_desc, C, ldc, c_outer, c_inner, inner, nbatch, M, N, K, prec, S(stream));
 }
 int craft_pack_operands(const long* descs, int n, void* stream) { return launch_pack_operands(descs, n, S(stream)); }
 int craft_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* const* Xp1, int cin0, int nseg, long dy_rows_p, int cout, long x_rows_p,
@@ -513,8 +517,10 @@ int craft_tokens_bwd(const float* x, long ldx, const float* dy, long lddy, float
   return launch_tokens_bwd(x, ldx, dy, lddy, dx, lddx, rows, C, act, do_ln, S(stream));
 }
 int craft_attn_softmax_fwd(float* Sc, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, int mask_radius,
-                           const unsigned* clamp_ord, unsigned* clampbits, float* Pdrop, float drop_p, unsigned long long seed, void* stream) {
-  return launch_attn_softmax_fwd(Sc, ld, B, M, H8, W8, pos_tab, R, pos_w, mask_radius, clamp_ord, clampbits, Pdrop, drop_p, seed, S(stream));
+                           const unsigned* clamp_ord, unsigned* clampbits, float* Pdrop, float drop_p, unsigned long long seed,
+                           void* Ppk, long pk_rows, int pk_np, int pk_prec, void* stream) {
+  return launch_attn_softmax_fwd(Sc, ld, B, M, H8, W8, pos_tab, R, pos_w, mask_radius, clamp_ord, clampbits, Pdrop, drop_p, seed, Ppk, pk_rows,
+                                 pk_np, pk_prec, S(stream));
 }
 int craft_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, int H8, int W8, int R, float pos_w,
                            const unsigned* clamp_ord, const unsigned* clampbits, float* dtab_rep, float drop_p, unsigned long long seed,

@@ -31,6 +31,8 @@ typedef __bf16 bf16x4_raw __attribute__((__vector_size__(4 * sizeof(__bf16))));
 struct PackParams {
   const float* x; long ldx; int C; long rows;
   int B, H, W, padH, padW;       // B > 0: spatial form
+  int tail;                      // spatial form: extra (zero) columns behind every grid row: Wp = W + 2 padW + tail (H = 1, padW = 0: B batches of W
+                                 // rows, each padded to W + tail rows -- the per-batch operands of craft_gemm_pk)
   long guard, rows_p;
   unsigned short* out; int prec;
   float* colsum;                 // optional [C]: += sum over rows (bias gradient of a convolution: its dY is packed anyway)
@@ -54,7 +56,7 @@ __device__ __forceinline__ void pack_block(const PackParams& p, int rb, int cg, 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cq = (tid & 3) * 8, c = cg * 32 + cq;
   const long plane = (long)p.ncg_total * p.rows_p * 32;
-  const int Hp = p.H + 2 * p.padH, Wp = p.W + 2 * p.padW;
+  const int Hp = p.H + 2 * p.padH, Wp = p.W + 2 * p.padW + p.tail;
   float4 v0[NP], v1[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
@@ -138,30 +140,31 @@ __global__ __launch_bounds__(256) void k_pack_operands(PackBatch pb) {
 }
 
 static int fill_pack_params(PackParams& p, const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
-                            int prec, void* out, int cg_off, int ncg_total, float* colsum) {
+                            int prec, void* out, int cg_off, int ncg_total, float* colsum, int tail) {
   if (rows_p <= 0 || C <= 0) return CRAFT_ERR_ARG;
   if (cg_off < 0 || cg_off + (C + 31) / 32 > ncg_total) return CRAFT_ERR_ARG;
   if ((C & 3) || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return CRAFT_ERR_ALIGN;
   if (prec != CRAFT_PREC_F16X3 && prec != CRAFT_PREC_F16 && prec != CRAFT_PREC_BF16) return CRAFT_ERR_UNSUPPORTED;
-  if (B > 0 && (double)B * (H + 2 * padH) * (W + 2 * padW) >= 2147483648.0) return CRAFT_ERR_UNSUPPORTED;
+  if (tail < 0 || (B <= 0 && tail != 0)) return CRAFT_ERR_ARG;
+  if (B > 0 && (double)B * (H + 2 * padH) * (W + 2 * padW + tail) >= 2147483648.0) return CRAFT_ERR_UNSUPPORTED;
   p = PackParams{};
   p.x = x; p.ldx = ldx; p.C = C; p.rows = rows; p.B = B; p.H = H; p.W = W; p.padH = padH; p.padW = padW; p.guard = guard; p.rows_p = rows_p;
   p.out = static_cast<unsigned short*>(out); p.prec = prec; p.colsum = colsum; p.ncg = (C + 31) / 32;
-  p.cg_off = cg_off; p.ncg_total = ncg_total;
+  p.cg_off = cg_off; p.ncg_total = ncg_total; p.tail = tail;
   return 0;
 }
 
-// descs: n x 16 longs (x, ldx, C, rows, B, H, W, padH, padW, guard, rows_p, prec, out, cg_off, ncg_total, colsum), see craft_pack_operands
+// descs: n x 17 longs (x, ldx, C, rows, B, H, W, padH, padW, guard, rows_p, prec, out, cg_off, ncg_total, colsum, tail), see craft_pack_operands
 int launch_pack_operands(const long* descs, int n, hipStream_t s) {
   for (int i0 = 0; i0 < n; i0 += PACK_MAX_DESC) {
     PackBatch pb = {};
     pb.n = n - i0 < PACK_MAX_DESC ? n - i0 : PACK_MAX_DESC;
     int blocks = 0;
     for (int i = 0; i < pb.n; ++i) {
-      const long* d = descs + (long)(i0 + i) * 16;
+      const long* d = descs + (long)(i0 + i) * 17;
       const int rc = fill_pack_params(pb.d[i], reinterpret_cast<const float*>(d[0]), d[1], (int)d[2], d[3], (int)d[4], (int)d[5], (int)d[6], (int)d[7],
                                       (int)d[8], d[9], d[10], (int)d[11], reinterpret_cast<void*>(d[12]), (int)d[13], (int)d[14],
-                                      reinterpret_cast<float*>(d[15]));
+                                      reinterpret_cast<float*>(d[15]), (int)d[16]);
       if (rc) return rc;
       pb.first_block[i] = blocks;
       blocks += (int)((d[10] + PACK_ROWS - 1) / PACK_ROWS) * pb.d[i].ncg;
@@ -174,10 +177,10 @@ int launch_pack_operands(const long* descs, int n, hipStream_t s) {
 }
 
 int launch_pack_operand(const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
-                        int prec, void* out, int cg_off, int ncg_total, float* colsum, hipStream_t s) {
+                        int prec, void* out, int cg_off, int ncg_total, float* colsum, int tail, hipStream_t s) {
   if (rows_p <= 0 || C <= 0) return 0;
-  const long d[16] = {(long)reinterpret_cast<uintptr_t>(x), ldx, C, rows, B, H, W, padH, padW, guard, rows_p, prec, (long)reinterpret_cast<uintptr_t>(out),
-                      cg_off, ncg_total, (long)reinterpret_cast<uintptr_t>(colsum)};
+  const long d[17] = {(long)reinterpret_cast<uintptr_t>(x), ldx, C, rows, B, H, W, padH, padW, guard, rows_p, prec, (long)reinterpret_cast<uintptr_t>(out),
+                      cg_off, ncg_total, (long)reinterpret_cast<uintptr_t>(colsum), tail};
   return launch_pack_operands(d, 1, s);
 }
 

@@ -190,11 +190,27 @@ int launch_tokens_bwd(const float* x, long ldx, const float* dy, long lddy, floa
 __global__ __launch_bounds__(256) void k_attn_softmax_fwd(float* __restrict__ S, long ld, int N, int H8, int W8,
                                                           const float* __restrict__ pos_tab, int R, float pos_w, int mask_radius,
                                                           const unsigned* __restrict__ clamp_ord, unsigned* __restrict__ clampbits,
-                                                          float* __restrict__ Pdrop, float drop_p, unsigned long long seed) {
+                                                          float* __restrict__ Pdrop, float drop_p, unsigned long long seed,
+                                                          unsigned short* __restrict__ Ppk, long pk_rows, int pk_np, int pk_prec) {
   extern __shared__ __attribute__((aligned(16))) float row[];
   __shared__ float red[4];
-  const long rr = blockIdx.x;                   // (z, i)
-  const int i = (int)(rr % N);
+  // Ppk: the (dropped) probabilities also as a packed MFMA operand (craft_gemm_pk): [plane][j / 32][z * pk_np + i][32], pk_np >= N rows
+  // per batch -- the grid then covers the pk_np - N padding rows too (zeros: the contraction over i of dV = P^T dO runs over them)
+  const int rows_per = Ppk ? pk_np : N;
+  const long z = blockIdx.x / rows_per;
+  const int i = (int)(blockIdx.x - z * rows_per);
+  const long pk_plane = (ld >> 5) * pk_rows * 32;
+  unsigned short* const Pr = Ppk ? Ppk + (z * pk_np + i) * 32 : nullptr;
+  if (i >= N) {
+    const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j8 = threadIdx.x * 8; j8 < ld; j8 += 2048) {
+      unsigned short* o = Pr + (long)(j8 >> 5) * pk_rows * 32 + (j8 & 31);
+      *reinterpret_cast<f16x8*>(o) = zero;
+      if (pk_prec == CRAFT_PREC_F16X3) *reinterpret_cast<f16x8*>(o + pk_plane) = zero;
+    }
+    return;
+  }
+  const long rr = z * N + i;                    // (z, i)
   const int hi = i / W8, wi = i - hi * W8;
   float* Sr = S + rr * ld;
   const bool clamp = clamp_active(clamp_ord);
@@ -227,29 +243,66 @@ __global__ __launch_bounds__(256) void k_attn_softmax_fwd(float* __restrict__ S,
   for (int j = threadIdx.x; j < N; j += 256) { const float e = expf(row[j] - mx); row[j] = e; sum += e; }
   sum = block_sum_256(sum, red);
   const float inv = 1.f / sum;
-  if (Pdrop == nullptr) {
-    for (int j = threadIdx.x; j < ld; j += 256) Sr[j] = j < N ? row[j] * inv : 0.f;
-  } else {
-    // the dropout of the probabilities (setrans.py:553-557) in the same pass: P stays in S (the softmax backward needs it), the dropped
-    // copy goes to Pdrop -- the mask of k_dropout over the same flat element index
-    const unsigned thr = (unsigned)fminf(drop_p * 4294967296.f, 4294967040.f);
-    const float dinv = 1.f / (1.f - drop_p);
-    float* Dr = Pdrop + rr * ld;
-    for (int j = threadIdx.x; j < ld; j += 256) {
-      const float pj = j < N ? row[j] * inv : 0.f;
-      Sr[j] = pj;
-      Dr[j] = mix32(seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)(rr * ld + j)) >= thr ? pj * dinv : 0.f;
+  // the dropout of the probabilities (setrans.py:553-557) in the same pass: P stays in S (the softmax backward needs it), the dropped
+  // copy goes to Pdrop (fp32) and / or Ppk (packed) -- the mask of k_dropout over the same flat element index.  8 columns per thread.
+  const bool drop = drop_p > 0.f && (Pdrop != nullptr || Ppk != nullptr);
+  const unsigned thr = (unsigned)fminf(drop_p * 4294967296.f, 4294967040.f);
+  const float dinv = drop ? 1.f / (1.f - drop_p) : 1.f;
+  for (int j8 = threadIdx.x * 8; j8 < ld; j8 += 2048) {
+    float pv[8], dv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = j8 + e;
+      pv[e] = j < N ? row[j] * inv : 0.f;
+      dv[e] = pv[e];
+      if (drop) dv[e] = mix32(seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)(rr * ld + j)) >= thr ? pv[e] * dinv : 0.f;
+    }
+    *reinterpret_cast<float4*>(Sr + j8) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    *reinterpret_cast<float4*>(Sr + j8 + 4) = make_float4(pv[4], pv[5], pv[6], pv[7]);
+    if (Pdrop) {
+      float* Dr = Pdrop + rr * ld + j8;
+      *reinterpret_cast<float4*>(Dr) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+      *reinterpret_cast<float4*>(Dr + 4) = make_float4(dv[4], dv[5], dv[6], dv[7]);
+    }
+    if (Ppk) {
+      unsigned short* o = Pr + (long)(j8 >> 5) * pk_rows * 32 + (j8 & 31);
+      if (pk_prec == CRAFT_PREC_F16X3) {
+        f16x4 h0, l0, h1, l1;
+        split_f16x3(make_float4(dv[0], dv[1], dv[2], dv[3]), h0, l0);
+        split_f16x3(make_float4(dv[4], dv[5], dv[6], dv[7]), h1, l1);
+        f16x8 hh, ll;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hh[e] = h0[e]; hh[4 + e] = h1[e]; ll[e] = l0[e]; ll[4 + e] = l1[e]; }
+        *reinterpret_cast<f16x8*>(o) = hh;
+        *reinterpret_cast<f16x8*>(o + pk_plane) = ll;
+      } else if (pk_prec == CRAFT_PREC_F16) {
+        f16x8 hh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hh[e] = (_Float16)dv[e];
+        *reinterpret_cast<f16x8*>(o) = hh;
+      } else {
+        bf16x8 hh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hh[e] = (__bf16)dv[e];
+        *reinterpret_cast<bf16x8*>(o) = hh;
+      }
     }
   }
 }
 int launch_attn_softmax_fwd(float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, int mask_radius,
-                            const unsigned* clamp_ord, unsigned* clampbits, float* Pdrop, float drop_p, unsigned long long seed, hipStream_t s) {
+                            const unsigned* clamp_ord, unsigned* clampbits, float* Pdrop, float drop_p, unsigned long long seed,
+                            void* Ppk, long pk_rows, int pk_np, int pk_prec, hipStream_t s) {
   const int N = H8 * W8;
   if (N <= 0 || B <= 0) return 0;
   if (N > 16000 || (ld & 31) || ld < N) return CRAFT_ERR_UNSUPPORTED;
-  if (Pdrop != nullptr && (drop_p < 0.f || drop_p >= 1.f)) return CRAFT_ERR_ARG;
-  hipLaunchKernelGGL(k_attn_softmax_fwd, dim3((unsigned)((long)B * M * N)), dim3(256), (size_t)N * sizeof(float), s, S, ld, N, H8, W8,
-                     pos_tab, R, pos_w, mask_radius, clamp_ord, clampbits, Pdrop, drop_p, seed);
+  if ((Pdrop != nullptr || Ppk != nullptr) && (drop_p < 0.f || drop_p >= 1.f)) return CRAFT_ERR_ARG;
+  if (Ppk != nullptr) {
+    if (pk_np < N || (pk_np & 31) || pk_rows < (long)B * M * pk_np || (reinterpret_cast<uintptr_t>(Ppk) & 15)) return CRAFT_ERR_ARG;
+    if (pk_prec != CRAFT_PREC_F16X3 && pk_prec != CRAFT_PREC_F16 && pk_prec != CRAFT_PREC_BF16) return CRAFT_ERR_UNSUPPORTED;
+  }
+  if ((reinterpret_cast<uintptr_t>(S) & 15) || (Pdrop && (reinterpret_cast<uintptr_t>(Pdrop) & 15))) return CRAFT_ERR_ALIGN;
+  hipLaunchKernelGGL(k_attn_softmax_fwd, dim3((unsigned)((long)B * M * (Ppk ? pk_np : N))), dim3(256), (size_t)N * sizeof(float), s, S, ld, N, H8, W8,
+                     pos_tab, R, pos_w, mask_radius, clamp_ord, clampbits, Pdrop, drop_p, seed, static_cast<unsigned short*>(Ppk), pk_rows, pk_np, pk_prec);
   return (int)hipGetLastError();
 }
 

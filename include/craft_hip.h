@@ -343,7 +343,8 @@ int craft_colsum(const float* x, long ld, long rows, int C, float* out, void* st
  *   tap is one constant row shift dy * (W + 2 padW) + dx.  rows_p >= the rows the consumer reads, caller-allocated
  *   (planes * ncg_total * rows_p * 64 bytes).  cg_off / ncg_total: this source fills the 32-channel groups [cg_off, cg_off + ceil(C/32))
  *   of a pack of ncg_total groups -- several calls build the pack of a channel concatenation without a torch.cat.  colsum (or NULL): colsum[c] += sum_r x[r][c] (a convolution's bias gradient rides
- *   on the pack of its dY).
+ *   on the pack of its dY).  tail (spatial form, else 0): extra zero columns behind every grid row, Wp = W + 2 padW + tail -- with H = 1,
+ *   padW = 0 the pack holds B batches of W rows, each padded to W + tail rows (the per-batch operands of craft_gemm_pk).
  * craft_wgrad_pk: dW[co][tap][ci] += sum_{s < nseg} sum_{k < K} dYp[s][guard + k][co] * Xp[s][guard + k + shift(tap)][ci], shift(tap) =
  *   (tap / KW - KH/2) * Wp + (tap % KW - KW/2); cout, cin multiples of 32 (the packs' channel groups), K % 32 == 0, guard >=
  *   the largest |shift|, both packs built with the same geometry and prec.  dW in the [cout][KH][KW][cin] layout, ACCUMULATED
@@ -353,13 +354,26 @@ int craft_colsum(const float* x, long ld, long rows, int C, float* out, void* st
  *   Xp1 (or NULL) / cin0: the X operand as the channel concatenation of TWO packs over the same rows -- input channels [0, cin0) from
  *   Xp[s], [cin0, cin) from Xp1[s] (cat([h, x]) / cat([r*h, x]) of SepConvGRU: x is packed once per pass and shared by both gates). */
 int craft_pack_operand(const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
-                       int prec, void* out, int cg_off, int ncg_total, float* colsum, void* stream);
+                       int prec, void* out, int cg_off, int ncg_total, float* colsum, int tail, void* stream);
 /* n craft_pack_operand calls as ONE launch (a training iteration packs ~14 convolution inputs of a few MB each: separate launches are
- * overhead-bound).  descs: HOST array of n x 16 longs per tensor, the arguments of craft_pack_operand in order with pointers as integers:
- * (x, ldx, C, rows, B, H, W, padH, padW, guard, rows_p, prec, out, cg_off, ncg_total, colsum). */
+ * overhead-bound).  descs: HOST array of n x 17 longs per tensor, the arguments of craft_pack_operand in order with pointers as integers:
+ * (x, ldx, C, rows, B, H, W, padH, padW, guard, rows_p, prec, out, cg_off, ncg_total, colsum, tail). */
 int craft_pack_operands(const long* descs, int n, void* stream);
 int craft_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* const* Xp1, int cin0, int nseg, long dy_rows_p, int cout, long x_rows_p,
                    int cin, long guard, long K, int KH, int KW, int Wp, float* dW, int prec, void* stream);
+
+/* Batched GEMM over packed operands (round 3; craft_amd/csrc/gemm_pkb.inc.hpp) -- the attention products of the training pass
+ * (autograd of setrans.py:373-384, :520-557; update.py:143-149) with nothing but copies and MFMAs in the K loop:
+ *   C[z][m][n] = sum_{k < K} A_z[m, k] * B_z[n, k],   z = outer * inner + inner_index < nbatch,  C_z = C + outer * c_outer + inner_index * c_inner
+ * A / B: packs [plane][channel group][row][32] (craft_pack_operand(s), craft_attn_softmax_fwd's Ppk), described by 9 longs each:
+ *   {kind, rows_p, ncg, row0, row_outer, row_inner, cg0, cg_outer, cg_inner}: kind 0 = K runs down the ROWS of the pack and M (N) over
+ *   its channels, kind 1 = K runs over the CHANNELS and M (N) down the rows; rows_p / ncg: rows and channel groups of the pack (its
+ *   strides); batch z reads from row row0 + outer * row_outer + inner_index * row_inner and channel group cg0 + ...
+ *   With P packed as (rows i, channels j):  O = P V -> (P kind 1, V kind 0);  dV = P^T dO -> (0, 0);  dP = dO V^T -> (1, 1).
+ * K % 32 == 0 with ZEROS in the K padding of both packs; the M / N padding may hold anything finite or not (never stored).
+ * Kind pairs (0,0), (1,0), (1,1); prec CRAFT_PREC_F16X3 / F16 / BF16 = the mode the packs were written in. */
+int craft_gemm_pk(const void* A, const long* a_desc, const void* B, const long* b_desc, float* C, long ldc, long c_outer, long c_inner,
+                  int inner, int nbatch, int M, int N, int K, int prec, void* stream);
 
 int craft_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, void* stream);
 int craft_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,
@@ -378,9 +392,13 @@ int craft_tokens_bwd(const float* x, long ldx, const float* dy, long lddy, float
  *   folds the replicas into the table's gradient).
  * Pdrop / drop_p / seed (Pdrop NULL: none): the dropout of the probabilities (setrans.py:553-557) fused into both passes -- the forward
  *   also writes Pdrop = craft_dropout(P, drop_p, seed) (same mask: the flat element index), the backward (drop_p > 0) takes dP as the
- *   gradient w.r.t. Pdrop and applies the mask while it reads the row (two 1 GB passes less per attention at 368x496, batch 8). */
+ *   gradient w.r.t. Pdrop and applies the mask while it reads the row (two 1 GB passes less per attention at 368x496, batch 8).
+ * Ppk (or NULL) / pk_rows / pk_np / pk_prec: the (dropped, if drop_p > 0) probabilities also as a packed operand of craft_gemm_pk,
+ *   [plane][ld / 32][pk_rows][32] in mode pk_prec with batch z = b * M + m in rows [z * pk_np, (z + 1) * pk_np), pk_np >= N a multiple
+ *   of 32, rows >= N of a batch zero: rows = query i, channels = key j. */
 int craft_attn_softmax_fwd(float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, int mask_radius,
-                           const unsigned* clamp_ord, unsigned* clampbits, float* Pdrop, float drop_p, unsigned long long seed, void* stream);
+                           const unsigned* clamp_ord, unsigned* clampbits, float* Pdrop, float drop_p, unsigned long long seed,
+                           void* Ppk, long pk_rows, int pk_np, int pk_prec, void* stream);
 int craft_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, int H8, int W8, int R, float pos_w,
                            const unsigned* clamp_ord, const unsigned* clampbits, float* dtab_rep, float drop_p, unsigned long long seed,
                            void* stream);

@@ -1,0 +1,110 @@
+"""craft_gemm_pk (batched GEMM over packed operands, csrc/gemm_pkb.inc.hpp) against float64 matmul: the three operand-kind pairs in the
+roles they play in an attention layer (O = P V, dV = P^T dO, dP = dO V^T; autograd of setrans.py:373-384, :520-557), batch strides
+(outer / inner), ragged M / N / K that hit every tile instantiation and the clamped / masked tile borders, and the three operand modes."""
+import pytest
+import torch
+
+from craft_amd import autograd as AG
+from craft_amd.hip import PREC_BF16, PREC_F16, PREC_F16X3, round_up
+
+pytestmark = pytest.mark.gpu
+PRECS = [(PREC_F16X3, 2e-5), (PREC_F16, 4e-3), (PREC_BF16, 3e-2)]
+
+
+@pytest.fixture(scope="module")
+def device():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda")
+
+
+def _rel(got, ref):
+    return ((got.double().cpu() - ref).norm() / ref.norm()).item()
+
+
+# (B, Mh, N tokens, C per mode): P [B, Mh, N, N], V [B, N, Mh*C]
+ATTN_CASES = [(2, 3, 77, 32), (1, 4, 300, 128), (2, 1, 130, 64), (1, 2, 520, 256), (3, 2, 40, 160)]
+
+
+@pytest.mark.parametrize("prec,tol", PRECS)
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_products(device, case, prec, tol):
+    B, Mh, N, C = case
+    g = torch.Generator().manual_seed(sum(case))
+    ld = round_up(N, 32)
+    P = torch.zeros(B, Mh, N, ld)
+    P[..., :N] = torch.softmax(torch.randn(B, Mh, N, N, generator=g) * 2.0, dim=-1)
+    V = torch.randn(B, N, Mh * C, generator=g)
+    dO = torch.randn(B, Mh, N, C, generator=g)
+    Pd, Vd, dOd = P.to(device), V.to(device), dO.to(device)
+    Vm = V.view(B, N, Mh, C).permute(0, 2, 1, 3).double()                      # [B, Mh, N, C]
+    Ppk = AG.PkMat(B * Mh, N, ld, prec, device).fill(Pd)                       # rows i, channels j
+    Vpk = AG.PkMat(B, N, Mh * C, prec, device).fill(Vd)                        # rows j, channels (m, c)
+    dOpk = AG.PkMat(B * Mh, N, C, prec, device).fill(dOd)                      # rows i, channels c
+    cg = C // 32
+    # O = P V  (CH, ROWS)
+    O = torch.full((B, Mh, N, C), 7.0, device=device)
+    AG.gemm_pk(Ppk, Ppk.desc(AG.PK_CH, Mh, 1), Vpk, Vpk.desc(AG.PK_ROWS, 1, 0, 0, 0, cg), O, C, Mh * N * C, N * C, Mh, B * Mh, N, C, ld)
+    assert _rel(O, P[..., :N].double() @ Vm) < tol
+    # dV = P^T dO  (ROWS, ROWS) into the [B, N, Mh, C] layout of V
+    dV = torch.full((B, N, Mh, C), 7.0, device=device)
+    AG.gemm_pk(Ppk, Ppk.desc(AG.PK_ROWS, Mh, 1), dOpk, dOpk.desc(AG.PK_ROWS, Mh, 1), dV, Mh * C, N * Mh * C, C, Mh, B * Mh, N, C, N)
+    ref = (P[..., :N].double().transpose(-1, -2) @ dO.double()).permute(0, 2, 1, 3)
+    assert _rel(dV, ref) < tol
+    # dP = dO V^T  (CH, CH), padded columns untouched
+    dP = torch.full((B, Mh, N, ld), 7.0, device=device)
+    AG.gemm_pk(dOpk, dOpk.desc(AG.PK_CH, Mh, 1), Vpk, Vpk.desc(AG.PK_CH, 1, 0, 0, 0, cg), dP, ld, Mh * N * ld, N * ld, Mh, B * Mh, N, N, C)
+    assert _rel(dP[..., :N], dO.double() @ Vm.transpose(-1, -2)) < tol
+    if ld > N:
+        assert float((dP[..., N:] - 7.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K", [(257, 129, 96), (31, 65, 700), (512, 256, 64), (300, 20, 2852)])
+def test_ragged_single_batch(device, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    Kc = round_up(K, 4)
+    A, Bm = torch.randn(M, Kc, generator=g), torch.randn(N, Kc, generator=g)
+    A[:, K:], Bm[:, K:] = 0.0, 0.0
+    ref = A.double() @ Bm.double().t()
+    Ad, Bd = A.to(device), Bm.to(device)
+    # CH x CH: rows = m / n
+    a1, b1 = AG.PkMat(1, M, round_up(Kc, 32), PREC_F16X3, device).fill(Ad), AG.PkMat(1, N, round_up(Kc, 32), PREC_F16X3, device).fill(Bd)
+    C = torch.zeros(M, N, device=device)
+    AG.gemm_pk(a1, a1.desc(AG.PK_CH, 0, 0), b1, b1.desc(AG.PK_CH, 0, 0), C, N, 0, 0, 1, 1, M, N, Kc)
+    assert _rel(C, ref) < 2e-5
+    # ROWS x ROWS: the transposed sources (rows = k); M / N must be channel counts % 4
+    M4, N4 = M // 4 * 4, N // 4 * 4
+    if M4 and N4:
+        At, Bt = A[:M4].t().contiguous().to(device), Bm[:N4].t().contiguous().to(device)
+        a0, b0 = AG.PkMat(1, Kc, round_up(M4, 32), PREC_F16X3, device).fill(At), AG.PkMat(1, Kc, round_up(N4, 32), PREC_F16X3, device).fill(Bt)
+        C0 = torch.zeros(M4, N4, device=device)
+        AG.gemm_pk(a0, a0.desc(AG.PK_ROWS, 0, 0), b0, b0.desc(AG.PK_ROWS, 0, 0), C0, N4, 0, 0, 1, 1, M4, N4, Kc)
+        assert _rel(C0, ref[:M4, :N4]) < 2e-5
+        # CH x ROWS
+        C1 = torch.zeros(M, N4, device=device)
+        AG.gemm_pk(a1, a1.desc(AG.PK_CH, 0, 0), b0, b0.desc(AG.PK_ROWS, 0, 0), C1, N4, 0, 0, 1, 1, M, N4, Kc)
+        assert _rel(C1, ref[:, :N4]) < 2e-5
+
+
+def test_softmax_writes_the_packed_probabilities(device):
+    """craft_attn_softmax_fwd's Ppk output == craft_pack_operand of its (dropped) fp32 output, bit for bit, padding rows zero."""
+    B, M, H8, W8 = 2, 3, 7, 9
+    N = H8 * W8
+    ld = round_up(N, 32)
+    g = torch.Generator().manual_seed(1)
+    S0 = (torch.randn(B, M, N, ld, generator=g) * 3.0).to(device)
+    for prec in (PREC_F16X3, PREC_F16, PREC_BF16):
+        for p in (0.0, 0.2):
+            S = S0.clone()
+            pk = AG.PkMat(B * M, N, ld, prec, device)
+            pk.buf.fill_(0x7e00)                                        # NaN patterns: every element must be written
+            AG.call("craft_attn_softmax_fwd", S, ld, B, M, H8, W8, None, 0, 0.0, -1, None, None, None, float(p), 99, pk.buf, pk.rows_total, pk.np_, prec)
+            S2 = S0.clone()
+            Pd = torch.empty_like(S2) if p > 0 else None
+            AG.call("craft_attn_softmax_fwd", S2, ld, B, M, H8, W8, None, 0, 0.0, -1, None, None, Pd, float(p), 99, None, 0, 0, 0)
+            assert torch.equal(S, S2)
+            ref = AG.PkMat(B * M, N, ld, prec, device).fill(Pd if p > 0 else S2)
+            planes = 2 if prec == PREC_F16X3 else 1
+            a = pk.buf.view(planes, pk.ncg, pk.rows_total, 32)[:, :, :B * M * pk.np_]
+            b = ref.buf.view(planes, pk.ncg, pk.rows_total, 32)[:, :, :B * M * pk.np_]
+            assert torch.equal(a, b)
