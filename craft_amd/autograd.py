@@ -261,14 +261,18 @@ class AttnSoftmax(Function):
     backward applies the mask to the incoming gradient as it reads it -- no separate pass over the [B, M, N, N] tensor either way."""
 
     @staticmethod
-    def forward(ctx, S, pos_tab, pos_w, mask_radius, clamp_ord, hw, drop_p=0.0, seed=0):
+    def forward(ctx, S, pos_tab, pos_w, mask_radius, clamp_ord, hw, drop_p=0.0, seed=0, pk=None):
+        """pk (a PkMat of B*M batches x N rows x ld channels): the (dropped) probabilities are written as that packed operand INSTEAD of a
+        dropped fp32 tensor, and the return value is only the autograd handle of P (its data: the undropped P) -- the consumers
+        (AttnApply, ProbsToken / train_update) multiply with the pack."""
         B, M, N, ld = S.shape
         R = (pos_tab.shape[0] - 1) // 2 if pos_tab is not None else 0          # None: plain softmax (gma.Attention, gma.py:96-98)
         bits = torch.empty(B * M * N * (ld // 32), device=S.device, dtype=torch.int32)
         tab = _c(pos_tab.detach()) if pos_tab is not None else None
-        out = torch.empty_like(S) if drop_p > 0.0 else None
+        out = torch.empty_like(S) if (drop_p > 0.0 and pk is None) else None
         call("craft_attn_softmax_fwd", S, ld, B, M, hw[0], hw[1], tab, R, float(pos_w), int(mask_radius), clamp_ord, bits,
-             out, float(drop_p), int(seed))
+             out, float(drop_p), int(seed), pk.buf if pk is not None else None, pk.rows_total if pk is not None else 0,
+             pk.np_ if pk is not None else 0, pk.prec if pk is not None else 0)
         ctx.hw, ctx.R, ctx.pos_w, ctx.has_tab, ctx.drop = hw, R, pos_w, pos_tab is not None, (float(drop_p), int(seed))
         ctx.save_for_backward(S, bits, clamp_ord)
         if out is None:
@@ -290,7 +294,7 @@ class AttnSoftmax(Function):
         if ctx.has_tab:
             dtab = torch.zeros(T, T, device=P.device, dtype=torch.float32)
             call("craft_reduce_replicas", rep, STATS_REPLICAS, T * T, dtab)
-        return dS, dtab, None, None, None, None, None, None
+        return dS, dtab, None, None, None, None, None, None, None
 
 
 class RelPosAdd(Function):
@@ -320,12 +324,20 @@ class AttnApply(Function):
     """O[b][m] = P[b][m] V_m with V = first_linear(x) [B, N, M*C] in its natural layout (setrans.py:373-384)."""
 
     @staticmethod
-    def forward(ctx, P, v, prec):
+    def forward(ctx, P, v, prec, pk=None):
+        """pk: P as a packed operand (AttnSoftmax(pk=...)): the three products run on craft_gemm_pk and P's own data is not read."""
         v = _rows(v)
         B, M, N, ld = P.shape
         C = v.shape[-1] // M
         O = torch.empty(B, M, N, C, device=P.device, dtype=torch.float32)
         pv = pick(prec, "pv")
+        ctx.pk = pk
+        if pk is not None:
+            cg = C // 32
+            vpk = PkMat(B, N, M * C, pk.prec, P.device).fill(v)                    # rows j, channels (m, c)
+            gemm_pk(pk, pk.desc(PK_CH, M, 1), vpk, vpk.desc(PK_ROWS, 1, 0, 0, 0, cg), O, C, M * N * C, N * C, M, B * M, N, C, ld)
+            ctx.vpk, ctx.dims = vpk, (B, M, N, ld, C)
+            return O
         ldv = v.stride(-2)
         gemm(P, ld, 1, M * N * ld, N * ld, v, 1, ldv, N * ldv, C, O, C, M * N * C, N * C, M, B * M, N, C, N, prec=pv)
         ctx.save_for_backward(P, v)
@@ -334,8 +346,22 @@ class AttnApply(Function):
 
     @staticmethod
     def backward(ctx, dO):
-        P, v = ctx.saved_tensors
         dO = _c(dO)
+        if ctx.pk is not None:
+            pk, vpk = ctx.pk, ctx.vpk
+            B, M, N, ld, C = ctx.dims
+            cg = C // 32
+            dopk = PkMat(B * M, N, C, pk.prec, dO.device).fill(dO)                  # rows i, channels c
+            dP = dv = None
+            if ctx.needs_input_grad[0]:
+                dP = torch.empty(B, M, N, ld, device=dO.device, dtype=torch.float32)   # (columns >= N: never read by the softmax backward)
+                gemm_pk(dopk, dopk.desc(PK_CH, M, 1), vpk, vpk.desc(PK_CH, 1, 0, 0, 0, cg), dP, ld, M * N * ld, N * ld, M, B * M, N, N, C)
+            if ctx.needs_input_grad[1]:
+                dv = torch.empty(B, N, M * C, device=dO.device, dtype=torch.float32)
+                gemm_pk(pk, pk.desc(PK_ROWS, M, 1), dopk, dopk.desc(PK_ROWS, M, 1), dv, M * C, N * M * C, C, M, B * M, N, C, N)
+            ctx.pk = ctx.vpk = None
+            return dP, dv, None, None
+        P, v = ctx.saved_tensors
         B, M, N, ld = P.shape
         C = v.shape[-1] // M
         ldv = v.stride(-2)
@@ -348,7 +374,7 @@ class AttnApply(Function):
             dv = torch.empty(B, N, M * C, device=P.device, dtype=torch.float32)
             # dV_m = P_m^T . dO_m : A(m = j, k = i) = P[i][j] k-major, B(n = c, k = i) = dO[i][c] k-major
             gemm(P, 1, ld, M * N * ld, N * ld, dO, 1, C, M * N * C, N * C, dv, M * C, N * M * C, C, M, B * M, N, C, N, prec=ctx.prec)
-        return dP, dv, None
+        return dP, dv, None, None
 
 
 class SharedProbs:
@@ -356,10 +382,12 @@ class SharedProbs:
     every refinement iteration, network.py:214 / update.py:143-149) and what their backward passes leave behind for the ONE
     gradient product of P."""
 
-    def __init__(self, P: torch.Tensor):
+    def __init__(self, P: torch.Tensor, pk=None):
         self.P = P.detach()
+        self.pk = pk                       # P as a packed operand (then P's own data is the UNdropped P: only the pack may be multiplied)
         self.pending: List = []            # (dO_t [B, M, N, C], v_t [B, N, M*C]) of every use, in backward order
-        self.cat = None                    # or: the concatenations ([B, M, N, T*C] dO, V) already built by train_update._phase2
+        self.cat = None                    # or: the concatenations ([B, M, N, T*C] dO, V) already built by train_update._phase2 -- tensors, or
+                                           # (with pk) the packs (dO: rows (b, m, i) x channels (t, c); V: rows (b, j) x channels (m, t, c))
 
 
 class ProbsToken(Function):
@@ -368,8 +396,8 @@ class ProbsToken(Function):
     the 1 GB gradient of P is written once instead of being produced, zero-filled and accumulated T times."""
 
     @staticmethod
-    def forward(ctx, P, box, prec):
-        holder = SharedProbs(P)
+    def forward(ctx, P, box, prec, pk=None):
+        holder = SharedProbs(P, pk)
         box.append(holder)
         ctx.holder, ctx.prec = holder, pick(prec, "pv")
         return torch.zeros(1, device=P.device, dtype=torch.float32)
@@ -379,6 +407,15 @@ class ProbsToken(Function):
         holder = ctx.holder
         P = holder.P
         B, M, N, ld = P.shape
+        if holder.pk is not None:
+            if holder.cat is None:
+                raise RuntimeError("ProbsToken: packed probabilities are consumed by train_update only (it leaves the packed dO / V behind)")
+            dO, V = holder.cat
+            dP = torch.empty(B, M, N, ld, device=P.device, dtype=torch.float32)     # (columns >= N: never read by the softmax backward)
+            K = dO.ncg * 32
+            gemm_pk(dO, dO.desc(PK_CH, M, 1), V, V.desc(PK_CH, 1, 0, 0, 0, K // 32), dP, ld, M * N * ld, N * ld, M, B * M, N, N, K)
+            holder.cat = holder.pk = None
+            return dP, None, None, None
         dP = torch.zeros(B, M, N, ld, device=P.device, dtype=torch.float32) if ld != N else torch.empty_like(P)
         if holder.cat is not None:
             dO, V = holder.cat
@@ -395,7 +432,7 @@ class ProbsToken(Function):
             holder.pending = []
         elif ld == N:
             dP.zero_()
-        return dP, None, None
+        return dP, None, None, None
 
 
 class AttnApplyShared(Function):

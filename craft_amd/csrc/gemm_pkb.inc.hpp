@@ -98,9 +98,8 @@ __global__ __launch_bounds__(512) void k_gemm_pkb(PkbParams p) {
     voff[i] = kind == 0 ? v_lin : v_swz;
   }
   const unsigned lds0 = (unsigned)(size_t)(CRAFT_LDS unsigned char*)(S);
-  auto dma = [&](int stage, int kt) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < DPW; ++i) {
+  auto dma1 = [&](int stage, int kt, int i) __attribute__((always_inline)) {
+    {
       const int id = wave * DPW + i;
       const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(id < NDMA ? stage * STAGE + id * 1024 : NST * STAGE + (id - NDMA) * 1024));
       const unsigned soff = (unsigned)kt * kstep[i];
@@ -110,6 +109,10 @@ __global__ __launch_bounds__(512) void k_gemm_pkb(PkbParams p) {
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(voff[i]), "s"(dst), "s"(d), "s"(soff) : "memory");
     }
+  };
+  auto dma = [&](int stage, int kt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) dma1(stage, kt, i);
   };
 
   // ---- fragments.  k-slot assignment of a 16-k MFMA step (the same for both operands): lane half h = lane >> 5 holds k = 8 h .. 8 h + 7.
@@ -161,7 +164,10 @@ __global__ __launch_bounds__(512) void k_gemm_pkb(PkbParams p) {
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW * (D - 1)) : "memory");      // this wave's pieces of tile kt have landed ...
     __syncthreads();                                                          // ... and everybody's; stage (kt - 1) % NST is free
-    dma(st == 0 ? NST - 1 : st - 1, min(kt + D, nk - 1));
+    // the next tile's DPW pieces are issued BETWEEN the MFMA groups of this one: right after the barrier all 8 waves would sit in their
+    // DMA issue (~100 cycles a piece beside LDS reads) with the matrix pipes idle
+    const int nst = st == 0 ? NST - 1 : st - 1, nkt = min(kt + D, nk - 1);
+    constexpr int NPAIR = 2 * MT * NT;
     const unsigned sb = (unsigned)st * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -185,6 +191,9 @@ __global__ __launch_bounds__(512) void k_gemm_pkb(PkbParams p) {
             mma(ah[mt], bl[nt], acc[mt][nt]);
           }
           mma(ah[mt], bh[nt], acc[mt][nt]);
+          const int q = (ks * MT + mt) * NT + nt;                             // pieces [ceil(q DPW / NPAIR), ceil((q + 1) DPW / NPAIR)) go here
+#pragma unroll
+          for (int c = (q * DPW + NPAIR - 1) / NPAIR; c < ((q + 1) * DPW + NPAIR - 1) / NPAIR; ++c) dma1(nst, nkt, c);
         }
     }
     st = st + 1 == NST ? 0 : st + 1;
@@ -212,16 +221,19 @@ __global__ __launch_bounds__(512) void k_gemm_pkb(PkbParams p) {
 // one translation unit per operand-kind pair (kernels_gemm_pkb_*.hip): 3 tiles x 3 operand modes each
 template <int AK, int BK>
 int launch_gemm_pkb_kind(PkbParams& p, int prec, hipStream_t s) {
+  // wide outputs: 256 x 256 (MFMA-bound).  Narrow outputs (N <= 128: O = P V, dQ = dS K) stream the A operand once and are HBM-bound:
+  // 128-row tiles with 4 stages keep 96 KiB in flight per CU and quantise to ~3 rounds of blocks instead of 1.5
   const int bn = p.N > 128 ? 256 : (p.N > 64 ? 128 : 64);
-  p.ntile_m = (p.M + 255) / 256;
+  const int bm = bn == 256 ? 256 : 128;
+  p.ntile_m = (p.M + bm - 1) / bm;
   p.ntile_n = (p.N + bn - 1) / bn;
   const long tiles = (long)p.ntile_m * p.ntile_n;
   dim3 grid((unsigned)(8 * tiles * ((p.nbatch + 7) / 8)));
-#define GO2(PL, BN_, WM_, WN_, BF) hipLaunchKernelGGL((k_gemm_pkb<PL, 256, BN_, WM_, WN_, BF, AK, BK>), grid, dim3(512), 0, s, p)
+#define GO2(PL, BM_, BN_, WM_, WN_, BF) hipLaunchKernelGGL((k_gemm_pkb<PL, BM_, BN_, WM_, WN_, BF, AK, BK>), grid, dim3(512), 0, s, p)
 #define GO(PL, BF) do { \
-    if (bn == 256) GO2(PL, 256, 2, 4, BF); \
-    else if (bn == 128) GO2(PL, 128, 4, 2, BF); \
-    else GO2(PL, 64, 8, 1, BF); } while (0)
+    if (bn == 256) GO2(PL, 256, 256, 2, 4, BF); \
+    else if (bn == 128) GO2(PL, 128, 128, 2, 4, BF); \
+    else GO2(PL, 128, 64, 4, 2, BF); } while (0)
   if (prec == CRAFT_PREC_F16X3) GO(2, false);
   else if (prec == CRAFT_PREC_F16) GO(1, false);
   else GO(1, true);

@@ -51,8 +51,14 @@ def training_precision(prec, loss_scaled: bool = False):
     return out
 
 
-def _attention_probs(module, x_ln, hw, prec, p_attn: float, seed: int):
-    """CrossAttFeatTrans up to (and including) the dropout of the probabilities (setrans.py:507-557) -> P [B, M, N, ld]."""
+def use_pk_attention(prec) -> bool:
+    """The attention products on packed operands (craft_gemm_pk): every 16-bit / f16x3 `pv` mode; CRAFT_NO_PK=1 keeps the fp32-source engine."""
+    return AG.pick(prec, "pv") != PREC_F32 and not os.environ.get("CRAFT_NO_PK") and not os.environ.get("CRAFT_NO_PK_ATTN")
+
+
+def _attention_probs(module, x_ln, hw, prec, p_attn: float, seed: int, pk_box=None):
+    """CrossAttFeatTrans up to (and including) the dropout of the probabilities (setrans.py:507-557) -> P [B, M, N, ld].
+    pk_box (a list): the dropped probabilities are produced as a packed operand appended to it, the returned tensor is P's autograd handle."""
     st = module.setrans
     q = AG.Linear.apply(x_ln, st.query.weight, st.query.bias, prec)
     k = AG.Linear.apply(x_ln, st.key.weight, st.key.bias, prec)
@@ -60,8 +66,12 @@ def _attention_probs(module, x_ln, hw, prec, p_attn: float, seed: int):
     scale = 1.0 / math.sqrt(st.attention_mode_dim)
     mx = ops.score_max(q.detach(), k.detach(), hw[0], hw[1], M, scale, prec)
     S = AG.Scores.apply(q, k, M, scale, prec)
+    pk = None
+    if pk_box is not None:
+        pk = AG.PkMat(S.shape[0] * S.shape[1], S.shape[2], S.shape[3], AG.pick(prec, "pv"), S.device)
+        pk_box.append(pk)
     return AG.AttnSoftmax.apply(S, module.vispos_encoder.pos_coder.biases, float(st.pos_code_weight), int(module.attn_mask_radius), mx, hw,
-                                float(p_attn), int(seed))
+                                float(p_attn), int(seed), pk)
 
 
 def _conv(x, conv, hw, act, prec, cache):
@@ -124,10 +134,11 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
     def feature_transformer(mod, tok, seed):
         c = mod.config
         x = AG.dropout(AG.TokensNorm.apply(tok, ACT_NONE, True), p_hidden(c), seed)
-        Pm = _attention_probs(mod, x, hw, prec, p_attn(c), seed + 1)
         ot = mod.setrans.out_trans
+        pkb = [] if (use_pk_attention(prec) and (ot.first_linear.weight.shape[0] // mod.setrans.num_modes) % 32 == 0) else None
+        Pm = _attention_probs(mod, x, hw, prec, p_attn(c), seed + 1, pkb)
         v = AG.Linear.apply(x, ot.first_linear.weight, None, prec)
-        return AG.ModePoolLN.apply(AG.AttnApply.apply(Pm, v, prec), x, ot.feat_softaggr.feat2score.weight, ot.input_skip_coeff)
+        return AG.ModePoolLN.apply(AG.AttnApply.apply(Pm, v, prec, pkb[0] if pkb else None), x, ot.feat_softaggr.feat2score.weight, ot.input_skip_coeff)
 
     fmap2_t = feature_transformer(model.f2_trans, f2_tok, base_seed + 1)
     f1t = getattr(model, "f1_trans", None)
@@ -168,10 +179,14 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
 
     # ---- intra-frame attention (network.py:214): computed once, used by every iteration ------------------------------
     att = model.att
+    fused = getattr(args, "hip_fused_update", True) and prec.conv != PREC_F32 and not os.environ.get("CRAFT_TRAIN_UNFUSED")
+    agg_ = model.update_block.aggregator
+    cv_agg = (agg_.first_linear.weight.shape[0] // att.setrans.num_modes) if args.use_setrans else agg_.dim_head
+    apk = [] if (fused and use_pk_attention(prec) and cv_agg % 32 == 0) else None       # (the packed P is consumed by train_update only)
     if args.use_setrans:
         ca = att.config
         xc = AG.dropout(AG.TokensNorm.apply(inp, ACT_NONE, True), p_hidden(ca), base_seed + 5)
-        Patt = _attention_probs(att, xc, hw, prec, p_attn(ca), base_seed + 6)
+        Patt = _attention_probs(att, xc, hw, prec, p_attn(ca), base_seed + 6, apk)
     else:
         # gma.Attention (gma.py:53-102): softmax(scale * q k^T) of the 1x1-conv projections of the context features, no dropout
         inner = att.heads * att.dim_head
@@ -192,14 +207,16 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
             Hs = AG.Linear.apply(qh, Eh, None, prec).view(B, att.heads, N, -1)
             Ws = AG.Linear.apply(qh, Ew, None, prec).view(B, att.heads, N, -1)
             Sg = AG.RelPosAdd.apply(Sg, Hs, Ws, float(att.scale) * (1.0 if pos_only else float(att.pos_embed_weight)), hw)
-        Patt = AG.AttnSoftmax.apply(Sg, None, 0.0, -1, None, hw)
+        if apk is not None:
+            apk.append(AG.PkMat(Sg.shape[0] * Sg.shape[1], Sg.shape[2], Sg.shape[3], AG.pick(prec, "pv"), Sg.device))
+        Patt = AG.AttnSoftmax.apply(Sg, None, 0.0, -1, None, hw, 0.0, 0, apk[0] if apk else None)
     pbox = []
-    ptoken = AG.ProbsToken.apply(Patt, pbox, prec)        # the 12 uses of Patt share ONE gradient product
+    ptoken = AG.ProbsToken.apply(Patt, pbox, prec, apk[0] if apk else None)        # the 12 uses of Patt share ONE gradient product
     pholder = pbox[0]
 
     # ---- iterative refinement (network.py:230-260; update.py:137-162) -------------------------------------------------
     radius_ = radius
-    if getattr(args, "hip_fused_update", True) and prec.conv != PREC_F32 and not os.environ.get("CRAFT_TRAIN_UNFUSED"):
+    if fused:
         # one autograd node per iteration with a hand-written backward (craft_amd/train_update.py)
         from . import train_update as TU
         coords0, coords1, _ = ops.coords_init(flow_init, B, H8, W8, dev)

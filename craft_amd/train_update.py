@@ -44,6 +44,7 @@ class UpdatePass:
         self.N = hw[0] * hw[1]
         self.holders = list(holder) if isinstance(holder, (list, tuple)) else [holder]     # one volume, or the two of --f1
         self.pholder, self.radius = pholder, radius
+        self.vcat = None           # packed [V_1 .. V_T] of the aggregator (craft_gemm_pk; built iteration by iteration in the forward)
         dev = net.device
         self.dev = dev
         self.cp = pick(prec, "conv")
@@ -189,12 +190,26 @@ class UpdateIter(Function):
             va = ops.linear(mf, agg.to_v.weight.detach().view(agg.heads * agg.dim_head, -1), None, prec)
         Cv = va.shape[-1] // M
         Oa = torch.empty(B, M, N, Cv, device=dev, dtype=torch.float32)
-        AG.gemm(P, ld, 1, M * N * ld, N * ld, va, 1, va.stride(-2), N * va.stride(-2), Cv, Oa, Cv, M * N * Cv, N * Cv, M, B * M, N, Cv, N, prec=pv)
+        ppk = ps.pholder.pk
+        if ppk is not None:
+            # packed operands (craft_gemm_pk): V_t goes straight into the pack the deferred dP = [dO_1..dO_T] [V_1..V_T]^T reads in the
+            # backward -- rows (b, j), channels (m, t, c) -- and O_t = P V_t reads its (t) channel groups from there
+            T, cgv = ps.iters, Cv // 32
+            if ps.vcat is None:
+                ps.vcat = AG.PkMat(B, N, M * T * Cv, ppk.prec, dev)
+            vb = AG.PackBatch()
+            for m_ in range(M):
+                ps.vcat.fill(va[..., m_ * Cv:(m_ + 1) * Cv], cg_off=(m_ * T + t) * cgv, batch=vb)
+            vb.flush()
+            AG.gemm_pk(ppk, ppk.desc(AG.PK_CH, M, 1), ps.vcat, ps.vcat.desc(AG.PK_ROWS, 1, 0, t * cgv, 0, T * cgv), Oa, Cv, M * N * Cv, N * Cv, M, B * M,
+                       N, Cv, ld)
+        else:
+            AG.gemm(P, ld, 1, M * N * ld, N * ld, va, 1, va.stride(-2), N * va.stride(-2), Cv, Oa, Cv, M * N * Cv, N * Cv, M, B * M, N, Cv, N, prec=pv)
         if ps.setrans:
             ops.mode_pool_ln(Oa, mf, agg.feat_softaggr.feat2score.weight.detach(), agg.input_skip_coeff.detach(), out=hx[..., MFG:MFG + 128])
         else:
             ops.gma_residual(mf, Oa.view(B, N, Cv), agg.gamma.detach(), out=hx[..., MFG:MFG + 128])
-        S["va"], S["Oa"] = va, Oa
+        S["va"], S["Oa"] = (va if ppk is None else None), Oa
         S["pk_mf"] = AG.Packed(mf, pick(prec, "proj"), batch=pb)
         # ---- SepConvGRU (update.py:49-64): horizontal pass h0 -> h1 (in HX_t), vertical pass h1 -> net_{t+1} (into HX_{t+1});
         # convolutions over [h | v], v = [mf | mfg]; inp's share and the biases arrive as per-pixel fields
@@ -357,6 +372,9 @@ def _phase2(ps: UpdatePass):
     Cv = ps.saved[0]["Oa"].shape[-1]
     # ---- A: gradient of the aggregator's pooling per iteration -> dO_t, the direct part of d mf_t
     dOs, d_mfs = [], []
+    ppk = ps.pholder.pk
+    docat = AG.PkMat(B * M, N, T * Cv, ppk.prec, dev) if ppk is not None else None       # rows (b, m, i), channels (t, c)
+    dob = AG.PackBatch()
     for t in range(T):
         S, dv = ps.saved[t], ps.dv[t]
         mf = ps.HX[t][..., MF:MF + 128]
@@ -378,17 +396,27 @@ def _phase2(ps: UpdatePass):
             K = B * N * Cv
             AG.gemm(dmc, K, 1, 0, 0, S["Oa"], K, 1, 0, 0, ps.dgamma, 1, 0, 0, 1, 1, 1, 1, K, accumulate=True, ksplit=0, prec=hip.PREC_F16X3)
             d_mf.copy_(d_mfg)
-        dOs.append(dOa)
+        if docat is not None:
+            docat.fill(dOa, cg_off=t * (Cv // 32), batch=dob)
+            if len(dob.descs) == 4 or t == T - 1:
+                dob.flush()                                          # (4 x 47 MB of dO alive at a time)
+        else:
+            dOs.append(dOa)
         d_mfs.append(d_mf)
         S.pop("Oa")
     # ---- B: dV of all iterations in one product over the concatenated dO (P is read once), and the operands of the deferred dP
     TC = T * Cv
-    dO_cat = torch.cat(dOs, dim=-1) if T > 1 else dOs[0]                                     # [B, M, N, T*Cv]
-    del dOs
     dva_cat = E(B, N, M, TC)
-    AG.gemm(P, 1, ld, M * N * ld, N * ld, dO_cat, 1, TC, M * N * TC, N * TC, dva_cat, M * TC, N * M * TC, TC, M, B * M, N, TC, N, prec=pv)
-    V_cat = torch.cat([ps.saved[t]["va"].view(B, N, M, Cv).permute(0, 2, 1, 3) for t in range(T)], dim=-1)    # [B, M, N, T*Cv]
-    ps.pholder.cat = (dO_cat, V_cat)
+    if ppk is not None:
+        AG.gemm_pk(ppk, ppk.desc(AG.PK_ROWS, M, 1), docat, docat.desc(AG.PK_ROWS, M, 1), dva_cat, M * TC, N * M * TC, TC, M, B * M, N, TC, N)
+        ps.pholder.cat = (docat, ps.vcat)
+        ps.vcat = None
+    else:
+        dO_cat = torch.cat(dOs, dim=-1) if T > 1 else dOs[0]                                     # [B, M, N, T*Cv]
+        del dOs
+        AG.gemm(P, 1, ld, M * N * ld, N * ld, dO_cat, 1, TC, M * N * TC, N * TC, dva_cat, M * TC, N * M * TC, TC, M, B * M, N, TC, N, prec=pv)
+        V_cat = torch.cat([ps.saved[t]["va"].view(B, N, M, Cv).permute(0, 2, 1, 3) for t in range(T)], dim=-1)    # [B, M, N, T*Cv]
+        ps.pholder.cat = (dO_cat, V_cat)
     w_v = agg.first_linear.weight if ps.setrans else agg.to_v.weight
     wv2 = w_v.detach().view(M * Cv, 128)
     dva5 = dva_cat.view(B, N, M, T, Cv)
