@@ -187,104 +187,126 @@ int launch_tokens_bwd(const float* x, long ldx, const float* dy, long lddy, floa
 // One block per query row; the row lives in LDS between the passes.  clampbits (optional, [rows][ld/32] words): bit j of row
 // = "this score was clamped" (its gradient is zero), written only when the clamp is active.
 // ---------------------------------------------------------------------------------------------
+// One block per query row, the row in REGISTERS: thread t holds the float4s t, t + 256, .. (ITER of them, every load issued before the
+// first use), so the row crosses HBM -> registers -> HBM once with 16-byte accesses and the two block reductions are the only syncs
+// (the first version staged the row in LDS with 4-byte loads and divided by W8 per element: 2.8 TB/s of the 8).
+template <int ITER>
 __global__ __launch_bounds__(256) void k_attn_softmax_fwd(float* __restrict__ S, long ld, int N, int H8, int W8,
                                                           const float* __restrict__ pos_tab, int R, float pos_w, int mask_radius,
                                                           const unsigned* __restrict__ clamp_ord, unsigned* __restrict__ clampbits,
                                                           float* __restrict__ Pdrop, float drop_p, unsigned long long seed,
-                                                          unsigned short* __restrict__ Ppk, long pk_rows, int pk_np, int pk_prec) {
-  extern __shared__ __attribute__((aligned(16))) float row[];
+                                                          unsigned short* __restrict__ Ppk, long pk_rows, int pk_np, int pk_prec, long nrows_grid) {
   __shared__ float red[4];
+  __shared__ float stab[31 * 31];
   // Ppk: the (dropped) probabilities also as a packed MFMA operand (craft_gemm_pk): [plane][j / 32][z * pk_np + i][32], pk_np >= N rows
   // per batch -- the grid then covers the pk_np - N padding rows too (zeros: the contraction over i of dV = P^T dO runs over them)
+  // Consecutive blocks go to different XCDs (8 L2s), but the packed output of a row is 64-byte pieces whose neighbours in memory belong
+  // to rows i +- 1: runs of 8 consecutive rows are mapped to ONE XCD, back to back, so that its L2 merges their pieces into full lines
   const int rows_per = Ppk ? pk_np : N;
-  const long z = blockIdx.x / rows_per;
-  const int i = (int)(blockIdx.x - z * rows_per);
+  const long seq = blockIdx.x >> 3;
+  const long row = ((seq >> 3) * 8 + (blockIdx.x & 7)) * 8 + (seq & 7);
+  if (row >= nrows_grid) return;
+  const long z = row / rows_per;
+  const int i = (int)(row - z * rows_per);
   const long pk_plane = (ld >> 5) * pk_rows * 32;
   unsigned short* const Pr = Ppk ? Ppk + (z * pk_np + i) * 32 : nullptr;
+  const int tid = threadIdx.x;
   if (i >= N) {
-    const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int j8 = threadIdx.x * 8; j8 < ld; j8 += 2048) {
-      unsigned short* o = Pr + (long)(j8 >> 5) * pk_rows * 32 + (j8 & 31);
-      *reinterpret_cast<f16x8*>(o) = zero;
-      if (pk_prec == CRAFT_PREC_F16X3) *reinterpret_cast<f16x8*>(o + pk_plane) = zero;
+    const f16x4 zero = {0, 0, 0, 0};
+    for (int j = tid * 4; j < ld; j += 1024) {
+      unsigned short* o = Pr + (long)(j >> 5) * pk_rows * 32 + (j & 31);
+      *reinterpret_cast<f16x4*>(o) = zero;
+      if (pk_prec == CRAFT_PREC_F16X3) *reinterpret_cast<f16x4*>(o + pk_plane) = zero;
     }
     return;
   }
   const long rr = z * N + i;                    // (z, i)
   const int hi = i / W8, wi = i - hi * W8;
   float* Sr = S + rr * ld;
+  float4 v[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int j = (tid + 256 * it) * 4;
+    v[it] = j < ld ? *reinterpret_cast<const float4*>(Sr + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int T = 2 * R + 1;
+  if (pos_tab) {
+    for (int t = tid; t < T * T; t += 256) stab[t] = pos_tab[t] * pos_w;
+    __syncthreads();
+  }
   const bool clamp = clamp_active(clamp_ord);
   float mx = -3.0e38f;
-  for (int j0 = 0; j0 < N; j0 += 256) {
-    const int j = j0 + threadIdx.x;
-    float v = -3.0e38f;
-    bool hit = false;
-    if (j < N) {
-      v = Sr[j];
-      if (clamp) { hit = v > CRAFT_ATTN_CLIP || v < -CRAFT_ATTN_CLIP; v = fminf(fmaxf(v, -CRAFT_ATTN_CLIP), CRAFT_ATTN_CLIP); }
-      const int hj = j / W8, wj = j - hj * W8;
-      if (pos_tab) v += pos_w * pos_bias_at(pos_tab, R, hi, wi, hj, wj);
-      if (mask_radius > 0 && max(abs(hj - hi), abs(wj - wi)) > mask_radius) v += -1e9f;
-      row[j] = v;
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int j0 = (tid + 256 * it) * 4;
+    int hj = j0 / W8, wj = j0 - hj * W8;
+    float* e = reinterpret_cast<float*>(&v[it]);
+    unsigned hit = 0u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float x = e[c];
+      if (j0 + c < N) {
+        if (clamp) { if (x > CRAFT_ATTN_CLIP || x < -CRAFT_ATTN_CLIP) hit |= 1u << c; x = fminf(fmaxf(x, -CRAFT_ATTN_CLIP), CRAFT_ATTN_CLIP); }
+        const int dh = hj - hi, dw = wj - wi;
+        if (pos_tab && dh >= -R && dh <= R && dw >= -R && dw <= R) x += stab[(dh + R) * T + dw + R];
+        if (mask_radius > 0 && max(abs(dh), abs(dw)) > mask_radius) x += -1e9f;
+      } else {
+        x = -3.0e38f;
+      }
+      e[c] = x;
+      mx = fmaxf(mx, x);
+      if (++wj == W8) { wj = 0; ++hj; }
     }
     if (clampbits && clamp) {
-      const unsigned long long m = __ballot(hit);
-      const int w0 = (j0 + (threadIdx.x & ~63)) >> 5;
-      if ((threadIdx.x & 63) == 0) {
-        unsigned* cb = clampbits + rr * (ld >> 5);
-        if (w0 < (ld >> 5)) cb[w0] = (unsigned)m;
-        if (w0 + 1 < (ld >> 5)) cb[w0 + 1] = (unsigned)(m >> 32);
-      }
+      // bit j of the row's words = "score j was clamped": the 8 lanes of a 32-column word OR their nibbles together
+      unsigned w = hit << (4 * (tid & 7));
+      w |= __shfl_xor(w, 1); w |= __shfl_xor(w, 2); w |= __shfl_xor(w, 4);
+      if ((tid & 7) == 0 && j0 < ld) clampbits[rr * (ld >> 5) + (j0 >> 5)] = w;
     }
-    mx = fmaxf(mx, v);
   }
   mx = block_max_256(mx, red);
   float sum = 0.f;
-  for (int j = threadIdx.x; j < N; j += 256) { const float e = expf(row[j] - mx); row[j] = e; sum += e; }
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    float* e = reinterpret_cast<float*>(&v[it]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { e[c] = expf(e[c] - mx); sum += e[c]; }      // (columns >= N: exp(-3e38 - mx) = 0)
+  }
   sum = block_sum_256(sum, red);
   const float inv = 1.f / sum;
   // the dropout of the probabilities (setrans.py:553-557) in the same pass: P stays in S (the softmax backward needs it), the dropped
-  // copy goes to Pdrop (fp32) and / or Ppk (packed) -- the mask of k_dropout over the same flat element index.  8 columns per thread.
+  // copy goes to Pdrop (fp32) and / or Ppk (packed) -- the mask of k_dropout over the same flat element index
   const bool drop = drop_p > 0.f && (Pdrop != nullptr || Ppk != nullptr);
   const unsigned thr = (unsigned)fminf(drop_p * 4294967296.f, 4294967040.f);
   const float dinv = drop ? 1.f / (1.f - drop_p) : 1.f;
-  for (int j8 = threadIdx.x * 8; j8 < ld; j8 += 2048) {
-    float pv[8], dv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int j = j8 + e;
-      pv[e] = j < N ? row[j] * inv : 0.f;
-      dv[e] = pv[e];
-      if (drop) dv[e] = mix32(seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)(rr * ld + j)) >= thr ? pv[e] * dinv : 0.f;
+  for (int it = 0; it < ITER; ++it) {
+    const int j = (tid + 256 * it) * 4;
+    if (j >= ld) continue;
+    float4 pv = make_float4(v[it].x * inv, v[it].y * inv, v[it].z * inv, v[it].w * inv);
+    *reinterpret_cast<float4*>(Sr + j) = pv;
+    if (drop) {
+      float* e = reinterpret_cast<float*>(&pv);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        e[c] = mix32(seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)(rr * ld + j + c)) >= thr ? e[c] * dinv : 0.f;
     }
-    *reinterpret_cast<float4*>(Sr + j8) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-    *reinterpret_cast<float4*>(Sr + j8 + 4) = make_float4(pv[4], pv[5], pv[6], pv[7]);
-    if (Pdrop) {
-      float* Dr = Pdrop + rr * ld + j8;
-      *reinterpret_cast<float4*>(Dr) = make_float4(dv[0], dv[1], dv[2], dv[3]);
-      *reinterpret_cast<float4*>(Dr + 4) = make_float4(dv[4], dv[5], dv[6], dv[7]);
-    }
+    if (Pdrop) *reinterpret_cast<float4*>(Pdrop + rr * ld + j) = pv;
     if (Ppk) {
-      unsigned short* o = Pr + (long)(j8 >> 5) * pk_rows * 32 + (j8 & 31);
+      unsigned short* o = Pr + (long)(j >> 5) * pk_rows * 32 + (j & 31);
       if (pk_prec == CRAFT_PREC_F16X3) {
-        f16x4 h0, l0, h1, l1;
-        split_f16x3(make_float4(dv[0], dv[1], dv[2], dv[3]), h0, l0);
-        split_f16x3(make_float4(dv[4], dv[5], dv[6], dv[7]), h1, l1);
-        f16x8 hh, ll;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { hh[e] = h0[e]; hh[4 + e] = h1[e]; ll[e] = l0[e]; ll[4 + e] = l1[e]; }
-        *reinterpret_cast<f16x8*>(o) = hh;
-        *reinterpret_cast<f16x8*>(o + pk_plane) = ll;
+        f16x4 h, l;
+        split_f16x3(pv, h, l);
+        *reinterpret_cast<f16x4*>(o) = h;
+        *reinterpret_cast<f16x4*>(o + pk_plane) = l;
       } else if (pk_prec == CRAFT_PREC_F16) {
-        f16x8 hh;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) hh[e] = (_Float16)dv[e];
-        *reinterpret_cast<f16x8*>(o) = hh;
+        f16x4 h;
+        h[0] = (_Float16)pv.x; h[1] = (_Float16)pv.y; h[2] = (_Float16)pv.z; h[3] = (_Float16)pv.w;
+        *reinterpret_cast<f16x4*>(o) = h;
       } else {
-        bf16x8 hh;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) hh[e] = (__bf16)dv[e];
-        *reinterpret_cast<bf16x8*>(o) = hh;
+        bf16x4 h;
+        h[0] = (__bf16)pv.x; h[1] = (__bf16)pv.y; h[2] = (__bf16)pv.z; h[3] = (__bf16)pv.w;
+        *reinterpret_cast<bf16x4*>(o) = h;
       }
     }
   }
@@ -301,27 +323,36 @@ int launch_attn_softmax_fwd(float* S, long ld, int B, int M, int H8, int W8, con
     if (pk_prec != CRAFT_PREC_F16X3 && pk_prec != CRAFT_PREC_F16 && pk_prec != CRAFT_PREC_BF16) return CRAFT_ERR_UNSUPPORTED;
   }
   if ((reinterpret_cast<uintptr_t>(S) & 15) || (Pdrop && (reinterpret_cast<uintptr_t>(Pdrop) & 15))) return CRAFT_ERR_ALIGN;
-  hipLaunchKernelGGL(k_attn_softmax_fwd, dim3((unsigned)((long)B * M * (Ppk ? pk_np : N))), dim3(256), (size_t)N * sizeof(float), s, S, ld, N, H8, W8,
-                     pos_tab, R, pos_w, mask_radius, clamp_ord, clampbits, Pdrop, drop_p, seed, static_cast<unsigned short*>(Ppk), pk_rows, pk_np, pk_prec);
+  if (R > 15) return CRAFT_ERR_UNSUPPORTED;
+  const long nrows_grid = (long)B * M * (Ppk ? pk_np : N);
+  const dim3 grid((unsigned)((nrows_grid + 63) / 64 * 64));
+  const int iter = (int)((ld + 1023) / 1024);
+#define GO(I) hipLaunchKernelGGL(k_attn_softmax_fwd<I>, grid, dim3(256), 0, s, S, ld, N, H8, W8, pos_tab, R, pos_w, mask_radius, clamp_ord, clampbits, \
+                                 Pdrop, drop_p, seed, static_cast<unsigned short*>(Ppk), pk_rows, pk_np, pk_prec, nrows_grid)
+  if (iter <= 1) GO(1); else if (iter <= 2) GO(2); else if (iter <= 3) GO(3); else if (iter <= 4) GO(4); else if (iter <= 5) GO(5);
+  else if (iter <= 6) GO(6); else if (iter <= 8) GO(8); else GO(16);
+#undef GO
   return (int)hipGetLastError();
 }
 
 // backward: dS = P * (dP - sum_j dP*P), zero where the score was clamped; dtab[rep][(dh+R)*(2R+1)+(dw+R)] += pos_w * dS' over
 // the window (dS' = before the clamp mask: the bias is added after the clamp).  dP is overwritten with dS.
 constexpr int SM_ROWS_PER_BLOCK = 8;
+// rows in registers as in the forward (P and the incoming gradient: 2 ITER float4 per thread, all loads of a row issued together)
+template <int ITER>
 __global__ __launch_bounds__(256) void k_attn_softmax_bwd(const float* __restrict__ P, float* __restrict__ dP, long ld, int N, int H8,
                                                           int W8, int R, float pos_w, const unsigned* __restrict__ clamp_ord,
                                                           const unsigned* __restrict__ clampbits, float* __restrict__ dtab, long nrows,
                                                           float drop_p, unsigned long long seed) {
   __shared__ float red[4];
   __shared__ float tab[32 * 32];
-  // drop_p > 0: dP is the gradient w.r.t. the DROPPED probabilities (k_attn_softmax_fwd's Pdrop): the dropout backward (the same mask)
-  // is applied while the row is read
+  // drop_p > 0: dP is the gradient w.r.t. the DROPPED probabilities (k_attn_softmax_fwd's Pdrop / Ppk): the dropout backward (the same
+  // mask) is applied while the row is read
   const unsigned thr = (unsigned)fminf(drop_p * 4294967296.f, 4294967040.f);
   const float dinv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  const int T = 2 * R + 1;
+  const int T = 2 * R + 1, tid = threadIdx.x;
   const bool want_tab = dtab != nullptr && R >= 0;
-  if (want_tab) for (int t = threadIdx.x; t < T * T; t += 256) tab[t] = 0.f;
+  if (want_tab) for (int t = tid; t < T * T; t += 256) tab[t] = 0.f;
   const bool clamp = clamp_active(clamp_ord) && clampbits != nullptr;
   const long r0 = (long)blockIdx.x * SM_ROWS_PER_BLOCK;
   for (long rr = r0; rr < min(nrows, r0 + SM_ROWS_PER_BLOCK); ++rr) {
@@ -329,32 +360,57 @@ __global__ __launch_bounds__(256) void k_attn_softmax_bwd(const float* __restric
     const int hi = i / W8, wi = i - hi * W8;
     const float* Pr = P + rr * ld;
     float* Gr = dP + rr * ld;
-    auto grad = [&](int j) __attribute__((always_inline)) {
-      const float g = Gr[j];
-      if (drop_p <= 0.f) return g;
-      return mix32(seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)(rr * ld + j)) >= thr ? g * dinv : 0.f;
-    };
+    float4 pv[ITER], gv[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int j = (tid + 256 * it) * 4;
+      const bool in = j < ld;
+      pv[it] = in ? *reinterpret_cast<const float4*>(Pr + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      gv[it] = in ? *reinterpret_cast<const float4*>(Gr + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float dot = 0.f;
-    for (int j = threadIdx.x; j < N; j += 256) dot += Pr[j] * grad(j);
-    dot = block_sum_256(dot, red);
-    for (int j = threadIdx.x; j < ld; j += 256) {
-      float ds = 0.f;
-      if (j < N) {
-        ds = Pr[j] * (grad(j) - dot);
-        if (want_tab) {
-          const int hj = j / W8, wj = j - hj * W8;
-          const int dh = hj - hi, dw = wj - wi;
-          if (dh >= -R && dh <= R && dw >= -R && dw <= R) atomicAdd(&tab[(dh + R) * T + dw + R], ds);
-        }
-        if (clamp && ((clampbits[rr * (ld >> 5) + (j >> 5)] >> (j & 31)) & 1u)) ds = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int j = (tid + 256 * it) * 4;
+      float* g = reinterpret_cast<float*>(&gv[it]);
+      const float* pp = reinterpret_cast<const float*>(&pv[it]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float x = j + c < N ? g[c] : 0.f;                            // (the padding columns of dP may hold anything)
+        if (drop_p > 0.f) x = mix32(seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)(rr * ld + j + c)) >= thr ? x * dinv : 0.f;
+        g[c] = x;
+        dot += pp[c] * x;
       }
-      Gr[j] = ds;
+    }
+    dot = block_sum_256(dot, red);
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int j = (tid + 256 * it) * 4;
+      if (j >= ld) continue;
+      const float* g = reinterpret_cast<const float*>(&gv[it]);
+      const float* pp = reinterpret_cast<const float*>(&pv[it]);
+      float4 o;
+      float* ds = reinterpret_cast<float*>(&o);
+      int hj = j / W8, wj = j - hj * W8;
+      unsigned bits = 0u;
+      if (clamp) bits = clampbits[rr * (ld >> 5) + (j >> 5)] >> (j & 31);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        ds[c] = pp[c] * (g[c] - dot);                                // (columns >= N: P = 0)
+        if (want_tab && j + c < N) {
+          const int dh = hj - hi, dw = wj - wi;
+          if (dh >= -R && dh <= R && dw >= -R && dw <= R) atomicAdd(&tab[(dh + R) * T + dw + R], ds[c]);
+        }
+        if ((bits >> c) & 1u) ds[c] = 0.f;
+        if (++wj == W8) { wj = 0; ++hj; }
+      }
+      *reinterpret_cast<float4*>(Gr + j) = o;
     }
   }
   if (want_tab) {
     __syncthreads();
     float* rep = dtab + (long)(blockIdx.x % CRAFT_STATS_REPLICAS) * T * T;
-    for (int t = threadIdx.x; t < T * T; t += 256) if (tab[t] != 0.f) unsafeAtomicAdd(rep + t, tab[t] * pos_w);
+    for (int t = tid; t < T * T; t += 256) if (tab[t] != 0.f) unsafeAtomicAdd(rep + t, tab[t] * pos_w);
   }
 }
 int launch_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, int H8, int W8, int R, float pos_w,
@@ -362,9 +418,15 @@ int launch_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, in
   const int N = H8 * W8;
   if (N <= 0 || B <= 0) return 0;
   if (R > 15 || (ld & 31)) return CRAFT_ERR_UNSUPPORTED;
+  if (N > 16000 || ld < N) return CRAFT_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(P) & 15) || (reinterpret_cast<uintptr_t>(dP) & 15)) return CRAFT_ERR_ALIGN;
   const long nrows = (long)B * M * N;
-  hipLaunchKernelGGL(k_attn_softmax_bwd, dim3((unsigned)((nrows + SM_ROWS_PER_BLOCK - 1) / SM_ROWS_PER_BLOCK)), dim3(256), 0, s, P, dP, ld,
-                     N, H8, W8, R, pos_w, clamp_ord, clampbits, dtab, nrows, drop_p, seed);
+  const dim3 grid((unsigned)((nrows + SM_ROWS_PER_BLOCK - 1) / SM_ROWS_PER_BLOCK));
+  const int iter = (int)((ld + 1023) / 1024);
+#define GO(I) hipLaunchKernelGGL(k_attn_softmax_bwd<I>, grid, dim3(256), 0, s, P, dP, ld, N, H8, W8, R, pos_w, clamp_ord, clampbits, dtab, nrows, drop_p, seed)
+  if (iter <= 1) GO(1); else if (iter <= 2) GO(2); else if (iter <= 3) GO(3); else if (iter <= 4) GO(4); else if (iter <= 5) GO(5);
+  else if (iter <= 6) GO(6); else if (iter <= 8) GO(8); else GO(16);
+#undef GO
   return (int)hipGetLastError();
 }
 
