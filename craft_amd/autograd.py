@@ -148,11 +148,11 @@ def _count_use(cache, t):
 def _acc_buffer(cache, t, kind, shape, device):
     """(buffer, is_last_use): the pass-wide accumulation buffer for the gradient of tensor t."""
     if cache is None:
-        return torch.zeros(shape, device=device, dtype=torch.float32), True
+        return hip.zeros(shape, device), True
     k = (id(t), kind)
     buf = cache.get(k)
     if buf is None:
-        buf = cache[k] = torch.zeros(shape, device=device, dtype=torch.float32)
+        buf = cache[k] = hip.zeros(shape, device)
     return buf, None
 
 
@@ -287,12 +287,12 @@ class AttnSoftmax(Function):
         # dS over the incoming gradient: it is the fresh output of the one consumer of P (AttnApply / ProbsToken), nothing else holds it
         dS = dP if dP.is_contiguous() else dP.contiguous()
         T = 2 * ctx.R + 1
-        rep = torch.zeros(STATS_REPLICAS, T * T, device=P.device, dtype=torch.float32) if ctx.has_tab else None
+        rep = hip.zeros((STATS_REPLICAS, T * T,), P.device) if ctx.has_tab else None
         call("craft_attn_softmax_bwd", P, dS, ld, B, M, ctx.hw[0], ctx.hw[1], ctx.R, float(ctx.pos_w), clamp_ord, bits, rep,
              ctx.drop[0], ctx.drop[1])
         dtab = None
         if ctx.has_tab:
-            dtab = torch.zeros(T, T, device=P.device, dtype=torch.float32)
+            dtab = hip.zeros((T, T,), P.device)
             call("craft_reduce_replicas", rep, STATS_REPLICAS, T * T, dtab)
         return dS, dtab, None, None, None, None, None, None, None
 
@@ -400,7 +400,7 @@ class ProbsToken(Function):
         holder = SharedProbs(P, pk)
         box.append(holder)
         ctx.holder, ctx.prec = holder, pick(prec, "pv")
-        return torch.zeros(1, device=P.device, dtype=torch.float32)
+        return hip.zeros((1,), P.device)
 
     @staticmethod
     def backward(ctx, _dtoken):
@@ -463,7 +463,7 @@ class AttnApplyShared(Function):
         holder.pending.append((dO, v if v.is_contiguous() else v.contiguous()))
         dv = torch.empty(B, N, M * C, device=P.device, dtype=torch.float32)
         gemm(P, 1, ld, M * N * ld, N * ld, dO, 1, C, M * N * C, N * C, dv, M * C, N * M * C, C, M, B * M, N, C, N, prec=ctx.prec)
-        return torch.zeros(1, device=P.device, dtype=torch.float32), dv, None, None
+        return hip.zeros((1,), P.device), dv, None, None
 
 
 class GmaResidual(Function):
@@ -485,7 +485,7 @@ class GmaResidual(Function):
             dO = ops.gma_residual(dy, dy, (gamma.detach() - 1.0).contiguous())
         if ctx.needs_input_grad[2]:                      # <dy, O>: a 1 x 1 product over K = all elements, split-K
             K = B * N * C
-            acc = torch.zeros(1, 1, device=dy.device, dtype=torch.float32)
+            acc = hip.zeros((1, 1,), dy.device)
             gemm(dy, K, 1, 0, 0, O, K, 1, 0, 0, acc, 1, 0, 0, 1, 1, 1, 1, K, accumulate=True, ksplit=0, prec=hip.PREC_F16X3)
             dg = acc.view(gamma.shape)
         return dy, dO, dg
@@ -507,10 +507,10 @@ class ModePoolLN(Function):
         B, M, N, C = O.shape
         dO = torch.empty_like(O)
         dx = torch.empty(B, N, C, device=O.device, dtype=torch.float32)
-        rep = torch.zeros(STATS_REPLICAS, C + 1, device=O.device, dtype=torch.float32)
+        rep = hip.zeros((STATS_REPLICAS, C + 1,), O.device)
         call("craft_mode_pool_ln_bwd", O, x, x.stride(-2), _c(w_agg.detach()).view(-1), skip.detach(), dy, dy.stride(-2), B, N, M, C,
              dO, dx, C, rep)
-        red = torch.zeros(C + 1, device=O.device, dtype=torch.float32)
+        red = hip.zeros((C + 1,), O.device)
         call("craft_reduce_replicas", rep, STATS_REPLICAS, C + 1, red)
         return dO, dx, red[:C].reshape(w_agg.shape), red[C:].reshape(skip.shape)
 
@@ -560,17 +560,17 @@ class CorrVolume(Function):
         H8, W8 = ctx.hw
         pyr = ctx.holder.pyr
         G = ctx.holder.grads()
-        gstats = torch.zeros(B, 2, device=S.device, dtype=torch.float64)
+        gstats = hip.zeros((B, 2,), S.device, torch.float64)
         call("craft_corr_pyramid_bwd", G[0], G[1], G[2], G[3], pyr.lv[0], pyr.mu_rstd, B, H8, W8, gstats)
         T = 2 * ctx.R + 1
-        rep = torch.zeros(STATS_REPLICAS, T * T, device=S.device, dtype=torch.float32) if ctx.has_tab else None
-        dw = torch.zeros(1, device=S.device, dtype=torch.float64)
+        rep = hip.zeros((STATS_REPLICAS, T * T,), S.device) if ctx.has_tab else None
+        dw = hip.zeros((1,), S.device, torch.float64)
         dS = S                                                    # the scores are dead after this: overwritten with dS
         call("craft_corr_pool_bwd", dS, ld, B, M, H8, W8, tab, ctx.R, float(ctx.pos_w), wv, clamp_ord, pyr.lv[0], G[0], pyr.mu_rstd, gstats,
              int(ctx.do_norm), rep, dw)
         dtab = None
         if ctx.has_tab:
-            dtab = torch.zeros(T, T, device=S.device, dtype=torch.float32)
+            dtab = hip.zeros((T, T,), S.device)
             call("craft_reduce_replicas", rep, STATS_REPLICAS, T * T, dtab)
         ctx.holder.G = None
         return dS, dtab, (dw.float().reshape(ctx.w_shape) if ctx.needs_input_grad[2] else None), None, None, None, None, None
@@ -595,7 +595,7 @@ class CorrLookup(Function):
         (coords,) = ctx.saved_tensors
         dout = _rows(dout)
         lookup_bwd(ctx.holders, dout, coords, ctx.radius)
-        return torch.zeros(ctx.holders[0].pyr.B, 2, device=dout.device, dtype=torch.float32), None, None, None
+        return hip.zeros((ctx.holders[0].pyr.B, 2,), dout.device), None, None, None
 
 
 def lookup_bwd(holders, dout, coords, radius):
@@ -822,7 +822,7 @@ _NO_PK = bool(_os.environ.get("CRAFT_NO_PK"))      # developer A/B: the round-2 
 def _conv_wgrad(xp, g, B, H8, W8, cin_p, cout_p, KH, KW, prec, db=None) -> torch.Tensor:
     """dW[co][ky][kx][ci] += sum_pix dY[pix][co] X[pix + tap][ci] (craft_conv2d_wgrad; split-K partial sums added with fp32 atomics:
     measured equal to the scratch + reduction form, one kernel less)."""
-    dw = torch.zeros(cout_p, KH, KW, cin_p, device=xp.device, dtype=torch.float32)
+    dw = hip.zeros((cout_p, KH, KW, cin_p,), xp.device)
     if _use_pk(prec) and cin_p % 32 == 0 and cout_p % 32 == 0:
         geom = (B, H8, W8, KH // 2, KW // 2)
         wgrad_pk([(Packed(g, prec, geom, colsum=db), Packed(xp, prec, geom))], KH, KW, dw)
@@ -960,7 +960,7 @@ class ConvexUpsample(Function):
         B, N, _ = flow.shape
         dup = _c(dup)
         dmask = torch.empty(B, N, 576, device=flow.device, dtype=torch.float32)
-        dflow = torch.zeros(B, N, 2, device=flow.device, dtype=torch.float32)
+        dflow = hip.zeros((B, N, 2,), flow.device)
         call("craft_convex_upsample_bwd", mask, mask.stride(-2), flow, dup, B, ctx.hw[0], ctx.hw[1], dmask, 576, dflow)
         return dmask, dflow, None
 

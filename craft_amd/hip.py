@@ -271,5 +271,58 @@ def call(name: str, *args):
         raise CraftHipError(f"{name} failed with code {rc}: {msg}")
 
 
+class ZeroPool:
+    """The many small zero-initialised buffers of a training step (gradient accumulators, statistics replicas: ~300 torch.zeros, a 4 us
+    fill kernel each) from ONE zeroed allocation per step.  The first step records the (shape, dtype) sequence; later steps allocate the
+    whole sequence at ``begin`` (one memset) and hand the pieces out in order -- any deviation from the recorded sequence falls back to
+    torch.zeros for the rest of the step and re-records.  Every piece is handed out once and the flat buffer is fresh per step, so
+    nothing aliases across steps; a piece that outlives its step only keeps that step's flat buffer alive."""
+
+    def __init__(self):
+        self.plan, self.rec, self.flat, self.idx, self.ok = None, [], None, 0, False
+
+    def begin(self, device):
+        if self.rec and (self.plan is None or not self.ok):
+            self.plan = self.rec                        # (re-)learned from the step that just ran
+        self.rec, self.idx, self.ok, self.flat = [], 0, False, None
+        if self.plan:
+            total = sum(n for _, _, _, n in self.plan)
+            self.flat = torch.zeros(total, device=device, dtype=torch.uint8)
+            self.ok = True
+            self.off = 0
+
+    def zeros(self, shape, device, dtype=torch.float32):
+        shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
+        numel = 1
+        for s_ in shape:
+            numel *= s_
+        live = numel * _ELEM_SIZE[dtype]
+        nbytes = (live + 255) // 256 * 256
+        self.rec.append((shape, dtype, None, nbytes))
+        if self.ok:
+            if self.idx < len(self.plan) and self.plan[self.idx][:2] == (shape, dtype) and self.flat.device.type == torch.device(device).type:
+                out = self.flat[self.off:self.off + live].view(dtype).view(shape)
+                self.off += nbytes
+                self.idx += 1
+                return out
+            self.ok = False                             # the sequence changed (other shapes, another model): plain allocations from here on
+        return torch.zeros(shape, device=device, dtype=dtype)
+
+
+_ELEM_SIZE = {torch.float32: 4, torch.float64: 8, torch.int32: 4, torch.int64: 8, torch.int16: 2, torch.uint8: 1, torch.float16: 2, torch.bfloat16: 2}
+_POOL = [None]
+
+
+def set_zero_pool(pool):
+    """Make ``pool`` (or None) the source of ``zeros`` until the next call (train_forward.forward_train: one pool per model)."""
+    _POOL[0] = pool
+
+
+def zeros(shape, device, dtype=torch.float32):
+    """A zero-initialised per-step temporary (see ZeroPool); plain torch.zeros outside a training step."""
+    pool = _POOL[0]
+    return pool.zeros(shape, device, dtype) if pool is not None else torch.zeros(shape, device=device, dtype=dtype)
+
+
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m

@@ -23,7 +23,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from . import autograd as AG
-from . import ops
+from . import hip, ops
 from .extractor import BasicEncoder
 from .hip import ACT_NONE, ACT_RELU, PREC_BF16, PREC_F16X3, PREC_F32, STATS_REPLICAS, W_PACKED, call, pick
 
@@ -36,7 +36,7 @@ class Stem(Function):
         B, _, H, W = raw.shape
         raw = raw.contiguous().float()
         out = torch.empty(B, (H // 2) * (W // 2), 64, device=raw.device, dtype=torch.float32)
-        stats = torch.zeros(STATS_REPLICAS, B, 64, 2, device=raw.device, dtype=torch.float64)
+        stats = hip.zeros((STATS_REPLICAS, B, 64, 2,), raw.device, torch.float64)
         bias = b.detach().float().contiguous()
         if prec == PREC_F32:
             wk = w.detach().float().permute(2, 3, 1, 0).reshape(147, 64).contiguous()
@@ -66,14 +66,14 @@ class Stem(Function):
         if ctx.needs_input_grad[1]:
             cols = torch.empty(P, 160, device=raw.device, dtype=torch.float32)
             call("craft_stem_im2col", raw, B, H, W, cols)
-            dwc = torch.zeros(64, 160, device=raw.device, dtype=torch.float32)
+            dwc = hip.zeros((64, 160,), raw.device)
             if AG._use_pk(ctx.prec):
                 AG.wgrad_pk([(AG.Packed(dy, ctx.prec), AG.Packed(cols, ctx.prec))], 1, 1, dwc)
             else:
                 AG.gemm(dy, 1, dy.stride(-2), 0, 0, cols, 1, 160, 0, 0, dwc, 160, 0, 0, 1, 1, 64, 160, P, accumulate=True, ksplit=0, prec=ctx.prec)
             dw = dwc[:, :147].reshape(64, 7, 7, 3).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[2]:
-            db = torch.zeros(64, device=raw.device, dtype=torch.float32)
+            db = hip.zeros((64,), raw.device)
             if not ctx.bias_dead:
                 call("craft_colsum", dy, dy.stride(-2), P, 64, db)
         return None, dw, db, None, None
@@ -95,7 +95,7 @@ class EncConv(Function):
         if wp is None:
             wp = cache[key] = ops.pack_conv_prec(w, prec) if halo else ops.pack_conv(w)
         y = torch.empty(B, Ho * Wo, Cout, device=x.device, dtype=torch.float32)
-        stats = torch.zeros(STATS_REPLICAS, B, Cout, 2, device=x.device, dtype=torch.float64)
+        stats = hip.zeros((STATS_REPLICAS, B, Cout, 2,), x.device, torch.float64)
         call("craft_conv2d_nhwc_ex", x, x.stride(1), Cin, Hin, Win, None, wp, b.detach().float().contiguous(), Cout, KH, KW, stride, ACT_NONE,
              y, Cout, B, Ho, Wo, stats, prec | (W_PACKED if halo else 0))
         ctx.save_for_backward(x)
@@ -122,7 +122,7 @@ class EncConv(Function):
             dx = torch.empty(B, Hin * Win, Cin, device=dev, dtype=torch.float32)
             call("craft_conv2d_nhwc", g, g.stride(-2), Cout, wt, zb, Cin, KH, KW, ACT_NONE, dx, Cin, B, Hin, Win, prec | flag)
         if ctx.needs_input_grad[2]:
-            db = torch.zeros(Cout, device=dev, dtype=torch.float32)
+            db = hip.zeros((Cout,), dev)
         # a bias in front of a statistics-normalised layer cannot move the loss: its gradient is exactly 0; otherwise the column sums
         # of dY ride on the weight-gradient launch (the zero-stuffed rows of a stride-2 layer add nothing)
         live_db = db if (db is not None and not ctx.bias_dead) else None
@@ -157,7 +157,7 @@ class NormAct(Function):
         B, N, C = x.shape
         dy = AG._rows(dy)
         dev = x.device
-        sums = torch.zeros(B, C, 2, device=dev, dtype=torch.float64)
+        sums = hip.zeros((B, C, 2,), dev, torch.float64)
         ldo = out.stride(-2) if out is not None else 0
         call("craft_norm_act_bwd_reduce", dy, dy.stride(-2), out, ldo, x, x.stride(-2), mr, int(ctx.per_image), gamma, beta, ctx.act, int(ctx.has_res),
              sums, B, N, C)

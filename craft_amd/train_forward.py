@@ -19,6 +19,7 @@ import os
 import torch
 
 from . import autograd as AG
+from . import hip as hip_mod
 from . import ops
 from . import train_encoder as TE
 from .hip import ACT_NONE, ACT_RELU, ACT_TANH, PREC_BF16, PREC_F16, PREC_F32
@@ -110,6 +111,12 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
     # default: on the HIP kernels in the policy's `enc` operand mode (craft_amd/train_encoder.py).  args.hip_encoders=False keeps the
     # PyTorch-ROCm modules under torch autograd -- with enc = bf16 under autocast, like the reference's mixed-precision training
     # (network.py:179,199); fp16 roles were promoted to f16x3 above (training_precision): no loss scaling is built
+    # the step's small zero-initialised buffers come from one allocation (hip.ZeroPool; valid through this pass's backward)
+    pool = model.__dict__.get("_zero_pool")
+    if pool is None:
+        pool = model.__dict__["_zero_pool"] = hip_mod.ZeroPool()
+    pool.begin(dev)
+    hip_mod.set_zero_pool(None if os.environ.get("CRAFT_NO_ZERO_POOL") else pool)
     H, W = image1.shape[-2:]
     use_henc = getattr(args, "hip_encoders", True) and TE.supported(model.fnet, H, W) and TE.supported(model.cnet, H, W)
     if use_henc:

@@ -93,7 +93,7 @@ class UpdatePass:
         k = ("acc", key)
         b = self.cache.get(k)
         if b is None:
-            b = self.cache[k] = torch.zeros(shape, device=self.dev, dtype=torch.float32)
+            b = self.cache[k] = hip.zeros(shape, self.dev)
         return b
 
     def wgrad(self, key, pair, KH, KW, acc, last):
@@ -273,8 +273,8 @@ class UpdateIter(Function):
         dh2 = None
         if d_up is not None:
             dmask = E(B, N, 576)
-            dflow = torch.zeros(B, N, 32, device=dev, dtype=torch.float32)           # (2 live columns; the flow head's padded output)
-            d2 = torch.zeros(B, N, 2, device=dev, dtype=torch.float32)
+            dflow = hip.zeros((B, N, 32), dev)           # (2 live columns; the flow head's padded output)
+            d2 = hip.zeros((B, N, 2), dev)
             call("craft_convex_upsample_bwd", S["mask"], 576, S["flow_new"], AG._c(d_up), B, H8, W8, dmask, 576, d2)
             dflow[..., :2] = d2
             # mask = 0.25 * (W2 mh + b2): the gradient w.r.t. the pre-scale output
@@ -382,7 +382,7 @@ def _phase2(ps: UpdatePass):
         d_mf = E(B, N, 128)
         if ps.setrans:
             if ps.rep_agg is None:
-                ps.rep_agg = torch.zeros(STATS_REPLICAS, Cv + 1, device=dev, dtype=torch.float32)
+                ps.rep_agg = hip.zeros((STATS_REPLICAS, Cv + 1), dev)
             dOa = torch.empty_like(S["Oa"])
             w_agg, skip = agg.feat_softaggr.feat2score.weight, agg.input_skip_coeff
             call("craft_mode_pool_ln_bwd", S["Oa"], mf, _C, AG._c(w_agg.detach()).view(-1), skip.detach(), d_mfg, d_mfg.stride(-2), B, N, M, Cv, dOa, d_mf,
@@ -392,7 +392,7 @@ def _phase2(ps: UpdatePass):
             dmc = d_mfg.contiguous()
             dOa = ops.gma_residual(dmc, dmc, (gamma.detach() - 1.0).contiguous()).view(B, 1, N, Cv)          # gamma * d_mfg
             if ps.dgamma is None:
-                ps.dgamma = torch.zeros(1, 1, device=dev, dtype=torch.float32)
+                ps.dgamma = hip.zeros((1, 1), dev)
             K = B * N * Cv
             AG.gemm(dmc, K, 1, 0, 0, S["Oa"], K, 1, 0, 0, ps.dgamma, 1, 0, 0, 1, 1, 1, 1, K, accumulate=True, ksplit=0, prec=hip.PREC_F16X3)
             d_mf.copy_(d_mfg)
@@ -515,7 +515,7 @@ def _param_grads(ps: UpdatePass):
     out += [A("mask2", "dw").reshape(ub.mask[2].weight.shape), A("mask2", "db")]
     if ps.setrans:
         Cv = agg.first_linear.weight.shape[0] // ps.pholder.P.shape[1]
-        red = torch.zeros(Cv + 1, device=ps.dev, dtype=torch.float32)
+        red = hip.zeros((Cv + 1,), ps.dev)
         call("craft_reduce_replicas", ps.rep_agg, STATS_REPLICAS, Cv + 1, red)
         out += [A("agg_v", "dw"), red[:Cv].reshape(agg.feat_softaggr.feat2score.weight.shape), red[Cv:].reshape(agg.input_skip_coeff.shape)]
     else:
