@@ -915,7 +915,7 @@ class GruZR(Function):
         drh = _rows(drh) if drh is not None else torch.zeros_like(z)
         dzr = torch.empty(B, N, 2 * C, device=h.device, dtype=torch.float32)
         dh = torch.zeros(B, N, C, device=h.device, dtype=torch.float32)
-        call("craft_gru_zr_bwd", dz, drh, drh.stride(-2), z, r, h, h.stride(-2), dzr, dh, B * N, C)
+        call("craft_gru_zr_bwd", dz, drh, drh.stride(-2), z, r, h, h.stride(-2), dzr, dh, B * N, C, None, None, 0)
         return dzr, dh
 
 
@@ -938,7 +938,7 @@ class GruOut(Function):
         dhn = _rows(dhn)
         B, N, C = h.shape
         dqp, dz, dh = (torch.empty(B, N, C, device=h.device, dtype=torch.float32) for _ in range(3))
-        call("craft_gru_out_bwd", dhn, dhn.stride(-2), z, q, h, h.stride(-2), dqp, dz, dh, B * N, C)
+        call("craft_gru_out_bwd", dhn, dhn.stride(-2), z, q, h, h.stride(-2), dqp, dz, dh, B * N, C, None)
         return dqp, dz, dh
 
 

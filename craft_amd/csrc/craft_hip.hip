@@ -564,12 +564,12 @@ int craft_gru_out_fwd(const float* q_pre, long ldq, const float* z, const float*
   return launch_gru_out_fwd(q_pre, ldq, z, h, ldh, q, h_new, ldhn, rows, C, S(stream));
 }
 int craft_gru_out_bwd(const float* dh_new, long lddhn, const float* z, const float* q, const float* h, long ldh, float* dq_pre, float* dz,
-                      float* dh, long rows, int C, void* stream) {
-  return launch_gru_out_bwd(dh_new, lddhn, z, q, h, ldh, dq_pre, dz, dh, rows, C, S(stream));
+                      float* dh, long rows, int C, float* dq_pre_sum, void* stream) {
+  return launch_gru_out_bwd(dh_new, lddhn, z, q, h, ldh, dq_pre, dz, dh, rows, C, dq_pre_sum, S(stream));
 }
 int craft_gru_zr_bwd(const float* dz, const float* drh, long lddrh, const float* z, const float* r, const float* h, long ldh, float* dzr_pre,
-                     float* dh, long rows, int C, void* stream) {
-  return launch_gru_zr_bwd(dz, drh, lddrh, z, r, h, ldh, dzr_pre, dh, rows, C, S(stream));
+                     float* dh, long rows, int C, float* dzr_pre_sum, float* dh_out, long lddho, void* stream) {
+  return launch_gru_zr_bwd(dz, drh, lddrh, z, r, h, ldh, dzr_pre, dh, rows, C, dzr_pre_sum, dh_out, lddho, S(stream));
 }
 
 // ---- input pipeline ---------------------------------------------------------------------------------------------

@@ -870,7 +870,7 @@ __global__ void k_gru_out_fwd(const float* __restrict__ qp, long ldq, const floa
 // dh' -> dq_pre = dh' z (1 - q^2), dz = dh' (q - h), dh = dh' (1 - z)
 __global__ void k_gru_out_bwd(const float* __restrict__ dhn, long lddhn, const float* __restrict__ z, const float* __restrict__ q,
                               const float* __restrict__ h, long ldh, float* __restrict__ dqp, float* __restrict__ dz, float* __restrict__ dh,
-                              long rows, int C) {
+                              long rows, int C, float* __restrict__ dqp_sum) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c4 = C >> 2;
   if (i >= rows * c4) return;
@@ -882,11 +882,16 @@ __global__ void k_gru_out_bwd(const float* __restrict__ dhn, long lddhn, const f
   b2.x = g.x * (qv.x - hv.x); b2.y = g.y * (qv.y - hv.y); b2.z = g.z * (qv.z - hv.z); b2.w = g.w * (qv.w - hv.w);
   d.x = g.x * (1.f - zv.x); d.y = g.y * (1.f - zv.y); d.z = g.z * (1.f - zv.z); d.w = g.w * (1.f - zv.w);
   st4(dqp + row * C + c, a); st4(dz + row * C + c, b2); st4(dh + row * C + c, d);
+  if (dqp_sum) {                                     // running sum over the refinement iterations (the hoisted context's gradients)
+    float4 t = ld4(dqp_sum + row * C + c);
+    t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+    st4(dqp_sum + row * C + c, t);
+  }
 }
 // (dz, d(rh)) -> dzr_pre = [dz z (1-z) | d(rh) h r (1-r)], dh += d(rh) r
 __global__ void k_gru_zr_bwd(const float* __restrict__ dz, const float* __restrict__ drh, long lddrh, const float* __restrict__ z,
                              const float* __restrict__ r, const float* __restrict__ h, long ldh, float* __restrict__ dzr,
-                             float* __restrict__ dh, long rows, int C) {
+                             const float* __restrict__ dh, long rows, int C, float* __restrict__ dzr_sum, float* dh_out, long lddho) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c4 = C >> 2;
   if (i >= rows * c4) return;
@@ -898,7 +903,13 @@ __global__ void k_gru_zr_bwd(const float* __restrict__ dz, const float* __restri
   a.x = gz.x * zv.x * (1.f - zv.x); a.y = gz.y * zv.y * (1.f - zv.y); a.z = gz.z * zv.z * (1.f - zv.z); a.w = gz.w * zv.w * (1.f - zv.w);
   b2.x = gr.x * hv.x * rv.x * (1.f - rv.x); b2.y = gr.y * hv.y * rv.y * (1.f - rv.y); b2.z = gr.z * hv.z * rv.z * (1.f - rv.z); b2.w = gr.w * hv.w * rv.w * (1.f - rv.w);
   d.x += gr.x * rv.x; d.y += gr.y * rv.y; d.z += gr.z * rv.z; d.w += gr.w * rv.w;
-  st4(dzr + row * 2 * C + c, a); st4(dzr + row * 2 * C + C + c, b2); st4(dh + row * C + c, d);
+  st4(dzr + row * 2 * C + c, a); st4(dzr + row * 2 * C + C + c, b2);
+  st4(dh_out + row * lddho + c, d);                 // (dh_out may be drh itself: each element is read before it is written, by this thread)
+  if (dzr_sum) {
+    float4 t = ld4(dzr_sum + row * 2 * C + c), u = ld4(dzr_sum + row * 2 * C + C + c);
+    t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w; u.x += b2.x; u.y += b2.y; u.z += b2.z; u.w += b2.w;
+    st4(dzr_sum + row * 2 * C + c, t); st4(dzr_sum + row * 2 * C + C + c, u);
+  }
 }
 #define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, s
 int launch_gru_zr_fwd(const float* zr, long ldzr, const float* h, long ldh, float* z, float* r, float* rh, long rows, int C, hipStream_t s) {
@@ -915,17 +926,18 @@ int launch_gru_out_fwd(const float* qp, long ldq, const float* z, const float* h
   return (int)hipGetLastError();
 }
 int launch_gru_out_bwd(const float* dhn, long lddhn, const float* z, const float* q, const float* h, long ldh, float* dqp, float* dz, float* dh,
-                       long rows, int C, hipStream_t s) {
+                       long rows, int C, float* dqp_sum, hipStream_t s) {
   if (rows <= 0) return 0;
   if ((C & 3) || (lddhn & 3) || (ldh & 3)) return CRAFT_ERR_ALIGN;
-  hipLaunchKernelGGL(k_gru_out_bwd, GRID1(rows * (C >> 2)), dhn, lddhn, z, q, h, ldh, dqp, dz, dh, rows, C);
+  hipLaunchKernelGGL(k_gru_out_bwd, GRID1(rows * (C >> 2)), dhn, lddhn, z, q, h, ldh, dqp, dz, dh, rows, C, dqp_sum);
   return (int)hipGetLastError();
 }
 int launch_gru_zr_bwd(const float* dz, const float* drh, long lddrh, const float* z, const float* r, const float* h, long ldh, float* dzr,
-                      float* dh, long rows, int C, hipStream_t s) {
+                      float* dh, long rows, int C, float* dzr_sum, float* dh_out, long lddho, hipStream_t s) {
   if (rows <= 0) return 0;
-  if ((C & 3) || (lddrh & 3) || (ldh & 3)) return CRAFT_ERR_ALIGN;
-  hipLaunchKernelGGL(k_gru_zr_bwd, GRID1(rows * (C >> 2)), dz, drh, lddrh, z, r, h, ldh, dzr, dh, rows, C);
+  if (dh_out == nullptr) { dh_out = dh; lddho = C; }
+  if ((C & 3) || (lddrh & 3) || (ldh & 3) || (lddho & 3)) return CRAFT_ERR_ALIGN;
+  hipLaunchKernelGGL(k_gru_zr_bwd, GRID1(rows * (C >> 2)), dz, drh, lddrh, z, r, h, ldh, dzr, dh, rows, C, dzr_sum, dh_out, lddho);
   return (int)hipGetLastError();
 }
 

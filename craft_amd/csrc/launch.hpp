@@ -214,9 +214,9 @@ int launch_gru_zr_fwd(const float* zr, long ldzr, const float* h, long ldh, floa
 int launch_gru_out_fwd(const float* qp, long ldq, const float* z, const float* h, long ldh, float* q, float* hn, long ldhn, long rows, int C,
                        hipStream_t s);
 int launch_gru_out_bwd(const float* dhn, long lddhn, const float* z, const float* q, const float* h, long ldh, float* dqp, float* dz, float* dh,
-                       long rows, int C, hipStream_t s);
+                       long rows, int C, float* dqp_sum, hipStream_t s);
 int launch_gru_zr_bwd(const float* dz, const float* drh, long lddrh, const float* z, const float* r, const float* h, long ldh, float* dzr,
-                      float* dh, long rows, int C, hipStream_t s);
+                      float* dh, long rows, int C, float* dzr_sum, float* dh_out, long lddho, hipStream_t s);
 
 // ---- input pipeline (kernels_augment.hip) ----
 int launch_aug_spatial(const float* src, int H, int W, int C, int do_resize, float fx, float fy, int hflip, int vflip, int y0, int x0, int ch,

@@ -98,8 +98,8 @@ _SIGS = {
     "craft_convex_upsample_bwd": [P, L, P, P, I, I, I, P, L, P, P],
     "craft_gru_zr_fwd": [P, L, P, L, P, P, P, L, I, P],
     "craft_gru_out_fwd": [P, L, P, P, L, P, P, L, L, I, P],
-    "craft_gru_out_bwd": [P, L, P, P, P, L, P, P, P, L, I, P],
-    "craft_gru_zr_bwd": [P, P, L, P, P, P, L, P, P, L, I, P],
+    "craft_gru_out_bwd": [P, L, P, P, P, L, P, P, P, L, I, P, P],
+    "craft_gru_zr_bwd": [P, P, L, P, P, P, L, P, P, L, I, P, P, L, P],
     "craft_coords_init": [P, I, I, I, P, P, P, P],
     # ---- input pipeline
     "craft_aug_spatial": [P, I, I, I, I, F, F, I, I, I, I, I, I, I, P, P],

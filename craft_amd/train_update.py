@@ -116,10 +116,11 @@ def _flow32(flow, B, N):
     return f
 
 
-def _conv_dx(ps: UpdatePass, w, g, cout_p, KH, KW, out=None, cin_p=None):
+def _conv_dx(ps: UpdatePass, w, g, cout_p, KH, KW, out=None, cin_p=None, field=None):
     """Input gradient of a stride-1 'same' convolution: the forward kernel with flipped / transposed weights.  g [B, N, cout_p]
     (row stride may exceed cout_p) -> [B, N, cin_p].  w: the nn.Conv2d weight, or (with cin_p) an operand already packed by
-    ops.pack_conv_weights(transposed=True)."""
+    ops.pack_conv_weights(transposed=True).  field [B, N, >= cin_p]: out = conv + field (a gradient that is already there: the
+    convolution's per-pixel bias field, `out` may be `field` itself) instead of a separate add pass."""
     if cin_p is None:
         wt, zb, flag, _ = AG._conv_weights(w, None, ps.cp, ps.cache, True)
         cin_p = round_up(w.shape[1], 32)
@@ -127,7 +128,11 @@ def _conv_dx(ps: UpdatePass, w, g, cout_p, KH, KW, out=None, cin_p=None):
         wt, zb, flag = w, ps.zero_bias, W_PACKED
     if out is None:
         out = torch.empty(ps.B, ps.N, cin_p, device=ps.dev, dtype=torch.float32)
-    call("craft_conv2d_nhwc", g, g.stride(-2), cout_p, wt, zb, cin_p, KH, KW, ACT_NONE, out, out.stride(-2), ps.B, ps.hw[0], ps.hw[1], ps.cp | flag)
+    if field is not None:
+        call("craft_conv2d_nhwc2", g, g.stride(-2), cout_p, None, 0, 0, wt, None, field, field.stride(-2), cin_p, KH, KW, ACT_NONE, out, out.stride(-2),
+             ps.B, ps.hw[0], ps.hw[1], ps.cp | flag)
+    else:
+        call("craft_conv2d_nhwc", g, g.stride(-2), cout_p, wt, zb, cin_p, KH, KW, ACT_NONE, out, out.stride(-2), ps.B, ps.hw[0], ps.hw[1], ps.cp | flag)
     return out
 
 
@@ -285,17 +290,14 @@ class UpdateIter(Function):
             AG.gemm(dm, 576, 1, 0, 0, w2m, 1, 256, 0, 0, d_mh, 256, 0, 0, 1, 1, rows, 256, 576, prec=cp)
             ps.wgrad(("mask2",), (AG.Packed(dm, cp, colsum=ps.acc(("mask2", "db"), (576,)), batch=pb), S["pk_mh"]), 1, 1, ps.acc(("mask2", "dw"), (576, 256)), last)
             g_mh = _act_bwd(d_mh, S["mh"], 256, out=d_mh)
-            dh2 = _conv_dx(ps, ub.mask[0].weight, g_mh, 256, 3, 3)
+            dh2 = _conv_dx(ps, ub.mask[0].weight, g_mh, 256, 3, 3, field=AG._rows(d_hn) if d_hn is not None else None)   # (+ the recurrence's share)
             ps.wgrad(("mask0",), (AG.Packed(g_mh, cp, g3, colsum=ps.acc(("mask0", "db"), (256,)), batch=pb), S["pk_h2"]), 3, 3, ps.acc(("mask0", "dw"), (256, 3, 3, 128)), last)
             # ---- flow head: delta = conv2(relu(conv1(h2)))
             d_fh1 = _conv_dx(ps, fh.conv2.weight, dflow, 32, 3, 3)
             ps.wgrad(("fh2",), (AG.Packed(dflow, cp, g3, colsum=ps.acc(("fh2", "db"), (32,)), batch=pb), S["pk_fh1"]), 3, 3, ps.acc(("fh2", "dw"), (32, 3, 3, 256)), last)
             g_fh1 = _act_bwd(d_fh1, S["fh1"], 256, out=d_fh1)
-            dh2b = _conv_dx(ps, fh.conv1.weight, g_fh1, 256, 3, 3)
+            _conv_dx(ps, fh.conv1.weight, g_fh1, 256, 3, 3, out=dh2, field=dh2)
             ps.wgrad(("fh1",), (AG.Packed(g_fh1, cp, g3, colsum=ps.acc(("fh1", "db"), (256,)), batch=pb), S["pk_h2"]), 3, 3, ps.acc(("fh1", "dw"), (256, 3, 3, 128)), last)
-            dh2.add_(dh2b)
-            if d_hn is not None:
-                dh2.add_(d_hn)
         elif d_hn is not None:
             dh2 = AG._c(d_hn).clone()
         for k in ("pk_h2", "pk_fh1", "pk_mh", "fh1", "mh", "mask", "flow_new"):
@@ -311,28 +313,22 @@ class UpdateIter(Function):
             z, r, q = S[f"z{p_}"], S[f"r{p_}"], S[f"q{p_}"]
             geom = (B, H8, W8, KH // 2, KW // 2)
             dqp, dz, dhp = E(B, N, 128), E(B, N, 128), E(B, N, 128)
-            call("craft_gru_out_bwd", dh, dh.stride(-2), z, q, h, _C, dqp, dz, dhp, rows, 128)
+            # the inp channels see the SUM of the gate gradients over the iterations (one input-gradient convolution and one weight-gradient
+            # product per gate convolution at the end of the pass): the gate kernels keep the running sums
+            if ("q", p_) not in ps.dysum:
+                ps.dysum[("q", p_)], ps.dysum[("zr", p_)] = hip.zeros((B, N, 128), dev), hip.zeros((B, N, 256), dev)
+            call("craft_gru_out_bwd", dh, dh.stride(-2), z, q, h, _C, dqp, dz, dhp, rows, 128, ps.dysum[("q", p_)])
             tq = _conv_dx(ps, ps.wqT[p_], dqp, 128, KH, KW, cin_p=384)                        # d[rh | mf | mfg]
             ps.wgrad(("q", p_), (AG.Packed(dqp, cp, geom, colsum=ps.acc(("q", p_, "db"), (128,)), batch=pb), _cat_pack(S[f"pk_rh{p_}"], S[f"pk_v{p_}"])), KH, KW,
                      ps.acc(("q", p_, "dw"), (128, KH, KW, 384)), last)
             dzr = E(B, N, 256)
-            call("craft_gru_zr_bwd", dz, tq, 384, z, r, h, _C, dzr, dhp, rows, 128)            # dhp += d(rh) r
-            tz = _conv_dx(ps, ps.wzrT[p_], dzr, 256, KH, KW, cin_p=384)                       # d[h | mf | mfg]
+            # tq[:, :128] <- dhp + d(rh) r: tq is now [dh so far | d(mf, mfg) so far], the field the z|r convolution adds its own to
+            call("craft_gru_zr_bwd", dz, tq, 384, z, r, h, _C, dzr, dhp, rows, 128, ps.dysum[("zr", p_)], tq, 384)
+            _conv_dx(ps, ps.wzrT[p_], dzr, 256, KH, KW, cin_p=384, out=tq, field=tq)          # += d[h | mf | mfg]
             ps.wgrad(("zr", p_), (AG.Packed(dzr, cp, geom, colsum=ps.acc(("zr", p_, "db"), (256,)), batch=pb), _cat_pack(S[f"pk_h{p_}"], S[f"pk_v{p_}"])), KH, KW,
                      ps.acc(("zr", p_, "dw"), (256, KH, KW, 384)), last)
-            dhp.add_(tz[..., :128])
-            if dv is None:
-                dv = torch.add(tq[..., 128:], tz[..., 128:])
-            else:
-                dv.add_(tq[..., 128:]).add_(tz[..., 128:])
-            # the inp channels see the SUM of the gate gradients over the iterations (one input-gradient convolution and one
-            # weight-gradient product per gate convolution at the end of the pass)
-            for kind, g in (("q", dqp), ("zr", dzr)):
-                if (kind, p_) in ps.dysum:
-                    ps.dysum[(kind, p_)].add_(g)
-                else:
-                    ps.dysum[(kind, p_)] = g                   # (this iteration's own buffer: nobody else holds it)
-            dh = dhp
+            dv = tq[..., 128:] if dv is None else torch.add(dv, tq[..., 128:])
+            dh = tq[..., :128]
             for k in (f"pk_h{p_}", f"pk_rh{p_}", f"pk_v{p_}", f"z{p_}", f"r{p_}", f"q{p_}"):
                 S.pop(k)
         d_net = dh                                                                            # gradient of net_t

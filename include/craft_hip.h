@@ -448,10 +448,14 @@ int craft_convex_upsample_bwd(const float* mask, long ldm, const float* flow, co
 int craft_gru_zr_fwd(const float* zr_pre, long ldzr, const float* h, long ldh, float* z, float* r, float* rh, long rows, int C, void* stream);
 int craft_gru_out_fwd(const float* q_pre, long ldq, const float* z, const float* h, long ldh, float* q, float* h_new, long ldhn, long rows,
                       int C, void* stream);
+/* dq_pre_sum / dzr_pre_sum (or NULL): += the gate gradients just written -- their sum over the refinement iterations is what the hoisted
+ *   context share of the gate convolutions differentiates once per pass.  dh_out / lddho (NULL: dh in place): where zr_bwd writes
+ *   dh + drh r; it may be drh's own buffer (the first C columns of the q convolution's input gradient), which makes that buffer the
+ *   per-pixel field the z|r input-gradient convolution accumulates into (craft_conv2d_nhwc2's bias_field, in place). */
 int craft_gru_out_bwd(const float* dh_new, long lddhn, const float* z, const float* q, const float* h, long ldh, float* dq_pre, float* dz,
-                      float* dh, long rows, int C, void* stream);
+                      float* dh, long rows, int C, float* dq_pre_sum, void* stream);
 int craft_gru_zr_bwd(const float* dz, const float* drh, long lddrh, const float* z, const float* r, const float* h, long ldh, float* dzr_pre,
-                     float* dh, long rows, int C, void* stream);
+                     float* dh, long rows, int C, float* dzr_pre_sum, float* dh_out, long lddho, void* stream);
 
 /* ---- CNN encoders in training (BasicEncoder / ResidualBlock with autograd on: extractor.py:6-64, 124-196) ----
  * The inference path folds the encoders' normalisation layers away; training needs them as operators with a backward.
