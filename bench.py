@@ -22,8 +22,10 @@ Extra objects on the line:
                 forward) timed on this box's host cores on ONE 448x1024 pair, 12 iterations.
   train_cfg3    a short leg of BASELINE.json configs[3] (training step at 368x496, batch 8/GPU: 6 warm-up + 5 timed steps, same
                 barrier / max-over-ranks protocol; 6 warm-up steps): ms_per_step, pairs_per_s and the roofline of the backward's dominant kernel
-                (k_conv_wgrad, timed live).  `python bench.py --train 3|4` is the full training benchmark (its own JSON line with
-                roofline and the CPU oracle's training step as cpu_baseline).
+                (the packed weight-gradient kernel k_gemm_pk, timed live), and `amp_fp16`: the same step under the reference's own
+                --mixed_precision arithmetic (fp16 operands + loss scaling; reported beside the fp32-class headline, not instead of it).
+                `python bench.py --train 3|4` is the full training benchmark (its own JSON line with roofline, amp_fp16 and the CPU
+                oracle's training step as cpu_baseline).
 """
 import argparse
 import json
@@ -355,6 +357,18 @@ def train_leg(cfg, rank, world, dev, steps, warmup, iters, B=None, H=None, W=Non
     return out
 
 
+AMP_NOTE = ("the same step in the reference's own arithmetic: every shipped training script passes --mixed_precision (train.py:215,231-238: fp16 "
+            "autocast + GradScaler); here fp16 MFMA operands in every contraction, fp32 accumulation / activations / master weights, the "
+            "Trainer's loss scale with skip-on-overflow.  Reported beside the headline, which stays on the fp32-class policy")
+
+
+def amp_leg(cfg, rank, world, dev, iters, **kw):
+    """The training step of configs[cfg] under policy train_amp_fp16 (5 timed steps) -> a compact dict for the bench line."""
+    r = train_leg(cfg, rank, world, dev, steps=5, warmup=6, iters=iters, policy="train_amp_fp16", roofline=False, **kw)
+    return {"policy": "train_amp_fp16", "ms_per_step": round(1e3 * r["dt"] / r["steps"], 3), "pairs_per_s": round(r["value"], 3),
+            "steps": r["steps"], "warmup": r["warmup"], "loss": round(r["loss"], 4), "note": AMP_NOTE}
+
+
 def train_bench(a, rank, world, dev, dist):
     """BASELINE.json configs[3] / configs[4]: whole training steps (train.py:215-236 / train_ddp.py:230-262) on synthetic
     pairs resident in HBM.  One rank per GPU, full replica, its own pairs; the one data-path collective is the all-reduce of
@@ -365,6 +379,9 @@ def train_bench(a, rank, world, dev, dist):
                   policy=a.precision if "--precision" in argv else None, torch_encoders=a.torch_encoders)
     H, W, B, policy, name = r["H"], r["W"], r["B"], r["policy"], r["name"]
     value, dt = r["value"], r["dt"]
+    amp = None
+    if "--precision" not in argv:
+        amp = amp_leg(a.train, rank, world, dev, a.iters, B=B, H=H, W=W, torch_encoders=a.torch_encoders)
     if rank == 0:
         line = {
             "metric": f"training image-pairs/sec at {H}x{W}, {a.iters} iters (forward + backward + gradient all-reduce + AdamW)",
@@ -382,7 +399,7 @@ def train_bench(a, rank, world, dev, dist):
                                           + ", synthetic weights and pairs", "global_batch": B * world,
                        "parallelism": f"dp{world} (one all-reduce of the {r['numel'] * 4 / 1e6:.1f} MB flat gradient per step)"},
             "loss": round(r["loss"], 4), "peak_mem_GB": r["peak_mem_GB"], "allreduce_ms_per_step": r["allreduce_ms"],
-            "roofline": r.get("roofline")}
+            "roofline": r.get("roofline"), "amp_fp16": amp}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_train(H, W, a.iters, a.cpu_threads, r["freeze_bn"])
         print(json.dumps(line), flush=True)
@@ -453,6 +470,7 @@ def main():
         del last["out"]
         torch.cuda.empty_cache()
         tl = train_leg(3, rank, world, dev, steps=5, warmup=6, iters=12)      # (6 warm-up steps: the caching allocator's pool settles after ~5)
+        tl["amp"] = amp_leg(3, rank, world, dev, 12)
 
     if rank == 0:
         line = {
@@ -478,7 +496,7 @@ def main():
                             "model.train(): dropout on, BatchNorm batch statistics; policy " + tl["policy"],
                 "ms_per_step": round(1e3 * tl["dt"] / tl["steps"], 3), "pairs_per_s": round(tl["value"], 3), "steps": tl["steps"],
                 "warmup": tl["warmup"], "n_gpus": world, "loss": round(tl["loss"], 4), "allreduce_ms_per_step": tl["allreduce_ms"],
-                "roofline": tl.get("roofline")}
+                "roofline": tl.get("roofline"), "amp_fp16": tl.get("amp")}
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()

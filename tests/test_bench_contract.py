@@ -35,6 +35,7 @@ def test_single_gpu_line(device):
     # the short configs[3] training leg rides on the default line (always at its own shape: 368x496, batch 8)
     t3 = d["train_cfg3"]
     assert t3["ms_per_step"] > 0 and t3["pairs_per_s"] > 0 and t3["steps"] == 5 and "368x496" in t3["workload"]
+    assert t3["amp_fp16"]["policy"] == "train_amp_fp16" and t3["amp_fp16"]["ms_per_step"] > 0 and t3["amp_fp16"]["loss"] == t3["amp_fp16"]["loss"]
     rw = t3["roofline"]
     assert rw["bound"] == "mfma" and rw["unit"] == "TFLOP/s" and abs(rw["frac"] - rw["achieved"] / rw["peak"]) < 1e-3
     assert abs(rw["achieved"] - rw["flops_per_launch"] / (rw["ms_per_launch"] * 1e-3) / 1e12) / rw["achieved"] < 0.02
@@ -49,6 +50,7 @@ def test_training_line(device):
     d = _json_line(r.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["value"] > 0 and d["vs_baseline"] is None and d["loss"] == d["loss"]
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["launches_timed"] > 0
+    assert d["amp_fp16"]["policy"] == "train_amp_fp16" and d["amp_fp16"]["pairs_per_s"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and "backward" in cb["sample"]
 
