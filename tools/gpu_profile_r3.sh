@@ -44,3 +44,13 @@ json.dump({"kernel": "k_gemm_pk", "kernel_instantiation": name, "policy": "train
 PY
 cat $O/pmc_traffic_wgrad.json; cat $O/pmc_wgrad_sq.txt 2>/dev/null | head -14
 du -sh $O
+# attention products / softmax kernels at configs[3]'s shapes, per-call and aten views of the step
+python $REPO/tools/bench_gemm_pkb.py f16x3 > $O/bench_gemm_pkb_f16x3.txt 2>/dev/null
+python $REPO/tools/bench_gemm_pkb.py bf16 > $O/bench_gemm_pkb_bf16.txt 2>/dev/null
+python $REPO/tools/bench_softmax.py > $O/bench_softmax.txt 2>/dev/null
+python $REPO/tools/call_profile.py 3 60 > $O/call_profile_cfg3.txt 2>/dev/null
+python $REPO/tools/call_profile.py 4 60 > $O/call_profile_cfg4.txt 2>/dev/null
+python $REPO/tools/aten_profile.py 3 > $O/aten_profile_cfg3.txt 2>/dev/null
+cd $REPO && bash tools/gpu_pmc_pkb.sh f16x3 > /dev/null 2>&1
+cp $REPO/gpurun_out/pmc_pkb/kernel_stats.txt $O/pmc_pkb_kernel_stats.txt; cp $REPO/gpurun_out/pmc_pkb/pmc_sq.txt $O/pmc_pkb_sq.txt; cp $REPO/gpurun_out/pmc_pkb/pmc_b.txt $O/pmc_pkb_grbm_lds.txt
+du -sh $O
