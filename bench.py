@@ -289,14 +289,14 @@ def roofline_wgrad(step, policy, steps=2):
     from craft_amd.hip import PREC_F16X3, Precision
     mult = 3 if Precision.parse(policy).conv == PREC_F16X3 else 1
     traffic = None
-    try:
+    kern, cin, cout, KH, KW, rows, calls = key
+    try:        # HBM bytes per launch from the PMC passes committed under profiles/r3 -- quoted only for the launch shape and operand mode profiled
         with open(os.path.join(ROOT, "profiles", "r3", "pmc_traffic_wgrad.json")) as fh:
             pmc = json.load(fh)
-        if list(pmc.get("shape", [])) == list(key[1:]) and pmc.get("kernel") == kern and pmc.get("policy") == policy:
+        if list(pmc.get("shape", [])) == list(key[1:]) and pmc.get("kernel") == kern and mult == 3:
             traffic = int(pmc["hbm_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, TypeError):
         pass
-    kern, cin, cout, KH, KW, rows, calls = key
     return {"bound": "mfma", "kernel": f"{kern} (weight gradient of the {KH}x{KW} convolution {cin}->{cout} over {rows} pixels x {calls} "
                                        f"call(s) of the layer per launch: {len(by[key]) // steps} launch(es) per step, the launch shape with "
                                        "the largest total time; operand packing not included)",

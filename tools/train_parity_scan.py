@@ -55,7 +55,7 @@ if a.f64:
     l64, g64, p64 = oracle(torch.float64)
     report("oracle fp32 vs oracle fp64", g32, g64)
 for pol in a.policies.split(","):
-    m = CRAFT(default_args(hip_precision=pol, dropout_prob=0.0))
+    m = CRAFT(default_args(hip_precision=pol, dropout_prob=0.0, hip_loss_scaled=a.loss_scale != "1"))   # (fp16 roles run as fp16 under a loss scale)
     m.load_state_dict(sd0, strict=True)
     m = m.to(dev).train()
     if a.freeze_bn:
