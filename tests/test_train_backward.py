@@ -471,13 +471,16 @@ def test_train_mode_rejects_other_configs_and_sizes(device):
                                                           # the full refinement depth of the benchmarked step (12 iterations: the
                                                           # per-pass gradient accumulators see all 12 uses, the deferred dP product
                                                           # has K = 12 * 128) in the policy bench.py --train 3 times
-                                                          (2, 368, 496, 12, False, "train_f16x3")])
+                                                          (2, 368, 496, 12, False, "train_f16x3"),
+                                                          # ... and in the library's default policy, which bench.py's configs[3] lines time:
+                                                          # fp16 operands for the attention products (under the loss scale), f16x3 elsewhere
+                                                          (2, 368, 496, 12, False, "mixed")])
 def test_training_step_at_configs3_size_against_oracle(device, B, H, W, iters, freeze_bn, policy):
     """BASELINE configs[3] shape (368x496 -> 46x62 tokens, odd pooling sizes 23 / 11 / 5; batch 2 with BatchNorm batch statistics,
     2 iterations) and configs[4] shape (368x768 -> 46x96 tokens, frozen BatchNorm), fp32 policy: loss and every parameter gradient
     of the HIP step against torch autograd over the CPU oracle (which tests/test_oracle_train_golden.py pins to the reference)."""
     from craft_amd.synth import synth_pair
-    model = CRAFT(default_args(hip_precision=policy, dropout_prob=0.0))
+    model = CRAFT(default_args(hip_precision=policy, dropout_prob=0.0, hip_loss_scaled=True))       # (the backward below runs under the loss scale)
     sd0 = synth_state_dict(model.state_dict(), seed=77)
     model.load_state_dict(sd0, strict=True)
     model = model.to(device).train()
@@ -504,7 +507,7 @@ def test_training_step_at_configs3_size_against_oracle(device, B, H, W, iters, f
     loss_r.backward()
     assert float(loss) == pytest.approx(float(loss_r), rel=3e-5)
     for a, b in zip(preds, preds_r):
-        assert (a.detach().cpu() - b.detach()).abs().max().item() < 2e-3
+        assert (a.detach().cpu() - b.detach()).abs().max().item() < (5e-3 if policy == "mixed" else 2e-3)       # px (measured 2.4e-3 / 3.5e-4)
     rms_all = sorted(float(sd[k].grad.pow(2).mean().sqrt()) for k in names if sd[k].grad is not None)
     scale = rms_all[len(rms_all) // 2]
     worst, checked = 0.0, 0

@@ -11,7 +11,7 @@ from craft_amd.train import Trainer
 
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 45
-H, W, B, policy = {3: (368, 496, 8, "train_f16x3"), 4: (368, 768, 4, "train_bf16attn")}[cfg]
+H, W, B, policy = {3: (368, 496, 8, "mixed"), 4: (368, 768, 4, "train_bf16attn")}[cfg]
 dev = torch.device("cuda:0")
 model = CRAFT(default_args(hip_precision=policy))
 model.load_state_dict(synth_state_dict(model.state_dict(), seed=1234), strict=True)

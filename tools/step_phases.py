@@ -9,7 +9,7 @@ from craft_amd.synth import synth_pair, synth_state_dict
 from craft_amd.train import Trainer, auto_loss_scale
 
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-H, W, B, policy = {3: (368, 496, 8, "train_f16x3"), 4: (368, 768, 4, "train_bf16attn")}[cfg]
+H, W, B, policy = {3: (368, 496, 8, "mixed"), 4: (368, 768, 4, "train_bf16attn")}[cfg]
 dev = torch.device("cuda:0")
 model = CRAFT(default_args(hip_precision=policy))
 model.load_state_dict(synth_state_dict(model.state_dict(), seed=1234), strict=True)
