@@ -224,21 +224,44 @@ class Scores(Function):
     """S[b][m] = scale * Q_m K_m^T (setrans.py:507-515), materialised fp32 [B, M, N, ld] (ld = N rounded up to 32)."""
 
     @staticmethod
-    def forward(ctx, q, k, M, scale, prec):
+    def forward(ctx, q, k, M, scale, prec, link=None):
+        """link (a ScoreLink shared with the AttnSoftmax that consumes S directly): the three products run on packed operands
+        (craft_gemm_pk) and the softmax backward hands dS over as a pack instead of an fp32 tensor."""
         q, k = _rows(q), _rows(k)
         B, N, C = q.shape
         d = C // M
         ld = round_up(N, 32)
         S = torch.empty(B, M, N, ld, device=q.device, dtype=torch.float32)
         sp = pick(prec, "score")
+        ctx.M, ctx.scale, ctx.prec, ctx.link = M, scale, sp, None
+        if link is not None and sp != hip.PREC_F32 and d % 32 == 0:
+            qpk = PkMat(B, N, C, sp, q.device).fill(q)                           # rows (b, i), channels (m, d)
+            kpk = qpk if k is q else PkMat(B, N, C, sp, q.device).fill(k)
+            cg = d // 32
+            gemm_pk(qpk, qpk.desc(PK_CH, 1, 0, 0, 0, cg), kpk, kpk.desc(PK_CH, 1, 0, 0, 0, cg), S, ld, M * N * ld, N * ld, M, B * M, N, N, d, alpha=scale)
+            link.want, link.prec = True, sp
+            ctx.link, ctx.packs, ctx.dims = link, (qpk, kpk), (B, N, C)
+            return S
         gemm(q, q.stride(-2), 1, N * q.stride(-2), d, k, k.stride(-2), 1, N * k.stride(-2), d, S, ld, M * N * ld, N * ld, M, B * M,
              N, N, d, alpha=scale, prec=sp)
         ctx.save_for_backward(q, k)
-        ctx.M, ctx.scale, ctx.prec = M, scale, sp
         return S
 
     @staticmethod
     def backward(ctx, dS):
+        if ctx.link is not None:
+            link, (qpk, kpk), (B, N, C) = ctx.link, ctx.packs, ctx.dims
+            M, d = ctx.M, C // ctx.M
+            cg = d // 32
+            dspk = link.dS
+            if dspk is None:                                                     # the consumer did not hand a pack over: pack here
+                dspk = PkMat(B * M, N, dS.shape[-1], ctx.prec, dS.device).fill(_c(dS))
+            dq = torch.empty(B, N, C, device=dS.device, dtype=torch.float32)
+            dk = torch.empty(B, N, C, device=dS.device, dtype=torch.float32)
+            gemm_pk(dspk, dspk.desc(PK_CH, M, 1), kpk, kpk.desc(PK_ROWS, 1, 0, 0, 0, cg), dq, C, N * C, d, M, B * M, N, d, N, alpha=ctx.scale)
+            gemm_pk(dspk, dspk.desc(PK_ROWS, M, 1), qpk, qpk.desc(PK_ROWS, 1, 0, 0, 0, cg), dk, C, N * C, d, M, B * M, N, d, N, alpha=ctx.scale)
+            link.dS = ctx.packs = None
+            return dq, dk, None, None, None, None
         q, k = ctx.saved_tensors
         dS = _c(dS)
         B, N, C = q.shape
@@ -252,7 +275,16 @@ class Scores(Function):
         # dK_m = scale * dS_m^T . Q_m : A(m = j, k = i) = dS[i][j] k-major, B(n = c, k = i) = Q[b][i][m*d + c] k-major
         gemm(dS, 1, ld, M * N * ld, N * ld, q, 1, q.stride(-2), N * q.stride(-2), d, dk, C, N * C, d, M, B * M, N, d, N, alpha=ctx.scale,
              prec=ctx.prec)
-        return dq, dk, None, None, None
+        return dq, dk, None, None, None, None
+
+
+class ScoreLink:
+    """Side channel between a Scores node and the AttnSoftmax that consumes its output directly: when the scores were formed on packed
+    operands (``want``), the softmax backward writes dS as a pack of mode ``prec`` into ``dS`` and returns a zero-stride placeholder."""
+    __slots__ = ("want", "prec", "dS")
+
+    def __init__(self):
+        self.want, self.prec, self.dS = False, 0, None
 
 
 class AttnSoftmax(Function):
@@ -261,7 +293,7 @@ class AttnSoftmax(Function):
     backward applies the mask to the incoming gradient as it reads it -- no separate pass over the [B, M, N, N] tensor either way."""
 
     @staticmethod
-    def forward(ctx, S, pos_tab, pos_w, mask_radius, clamp_ord, hw, drop_p=0.0, seed=0, pk=None):
+    def forward(ctx, S, pos_tab, pos_w, mask_radius, clamp_ord, hw, drop_p=0.0, seed=0, pk=None, link=None):
         """pk (a PkMat of B*M batches x N rows x ld channels): the (dropped) probabilities are written as that packed operand INSTEAD of a
         dropped fp32 tensor, and the return value is only the autograd handle of P (its data: the undropped P) -- the consumers
         (AttnApply, ProbsToken / train_update) multiply with the pack."""
@@ -274,6 +306,7 @@ class AttnSoftmax(Function):
              out, float(drop_p), int(seed), pk.buf if pk is not None else None, pk.rows_total if pk is not None else 0,
              pk.np_ if pk is not None else 0, pk.prec if pk is not None else 0)
         ctx.hw, ctx.R, ctx.pos_w, ctx.has_tab, ctx.drop = hw, R, pos_w, pos_tab is not None, (float(drop_p), int(seed))
+        ctx.link = link if (link is not None and link.want) else None
         ctx.save_for_backward(S, bits, clamp_ord)
         if out is None:
             ctx.mark_dirty(S)
@@ -288,13 +321,18 @@ class AttnSoftmax(Function):
         dS = dP if dP.is_contiguous() else dP.contiguous()
         T = 2 * ctx.R + 1
         rep = hip.zeros((STATS_REPLICAS, T * T,), P.device) if ctx.has_tab else None
+        dspk = PkMat(B * M, N, ld, ctx.link.prec, P.device) if ctx.link is not None else None
         call("craft_attn_softmax_bwd", P, dS, ld, B, M, ctx.hw[0], ctx.hw[1], ctx.R, float(ctx.pos_w), clamp_ord, bits, rep,
-             ctx.drop[0], ctx.drop[1])
+             ctx.drop[0], ctx.drop[1], dspk.buf if dspk is not None else None, dspk.rows_total if dspk is not None else 0,
+             dspk.np_ if dspk is not None else 0, dspk.prec if dspk is not None else 0)
+        if dspk is not None:
+            ctx.link.dS = dspk
+            dS = dS.new_zeros(1).expand(B, M, N, ld)            # (a placeholder of the right shape: Scores.backward takes the pack)
         dtab = None
         if ctx.has_tab:
             dtab = hip.zeros((T, T,), P.device)
             call("craft_reduce_replicas", rep, STATS_REPLICAS, T * T, dtab)
-        return dS, dtab, None, None, None, None, None, None, None
+        return dS, dtab, None, None, None, None, None, None, None, None
 
 
 class RelPosAdd(Function):
@@ -753,12 +791,13 @@ class PkMat:
 PK_ROWS, PK_CH = 0, 1
 
 
-def gemm_pk(A: PkMat, a_desc, B: PkMat, b_desc, C: torch.Tensor, ldc: int, c_outer: int, c_inner: int, inner: int, nbatch: int, M: int, N: int, K: int):
-    """C[z][m][n] = sum_k A_z[m, k] B_z[n, k] over packed operands (craft_gemm_pk; K padded to a multiple of 32 with zeros in both packs)."""
+def gemm_pk(A: PkMat, a_desc, B: PkMat, b_desc, C: torch.Tensor, ldc: int, c_outer: int, c_inner: int, inner: int, nbatch: int, M: int, N: int, K: int,
+            alpha: float = 1.0):
+    """C[z][m][n] = alpha sum_k A_z[m, k] B_z[n, k] over packed operands (craft_gemm_pk; K padded to a multiple of 32 with zeros in both packs)."""
     import ctypes
     assert A.prec == B.prec
     call("craft_gemm_pk", A.buf, (ctypes.c_long * 9)(*a_desc), B.buf, (ctypes.c_long * 9)(*b_desc), C, ldc, c_outer, c_inner, inner, nbatch, M, N,
-         round_up(K, 32), A.prec)
+         round_up(K, 32), float(alpha), A.prec)
 
 
 class PackBatch:

@@ -444,8 +444,8 @@ int craft_pack_operand(const float* x, long ldx, int C, long rows, int B, int H,
   return launch_pack_operand(x, ldx, C, rows, B, H, W, padH, padW, guard, rows_p, prec, out, cg_off, ncg_total, colsum, tail, S(stream));
 }
 int craft_gemm_pk(const void* A, const long* a_desc, const void* B, const long* b_desc, float* C, long ldc, long c_outer, long c_inner,
-                  int inner, int nbatch, int M, int N, int K, int prec, void* stream) {
-  return launch_gemm_pk(A, a_desc, B, b_desc, C, ldc, c_outer, c_inner, inner, nbatch, M, N, K, prec, S(stream));
+                  int inner, int nbatch, int M, int N, int K, float alpha, int prec, void* stream) {
+  return launch_gemm_pk(A, a_desc, B, b_desc, C, ldc, c_outer, c_inner, inner, nbatch, M, N, K, alpha, prec, S(stream));
 }
 int craft_pack_operands(const long* descs, int n, void* stream) { return launch_pack_operands(descs, n, S(stream)); }
 int craft_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* const* Xp1, int cin0, int nseg, long dy_rows_p, int cout, long x_rows_p,
@@ -524,8 +524,9 @@ int craft_attn_softmax_fwd(float* Sc, long ld, int B, int M, int H8, int W8, con
 }
 int craft_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, int H8, int W8, int R, float pos_w,
                            const unsigned* clamp_ord, const unsigned* clampbits, float* dtab_rep, float drop_p, unsigned long long seed,
-                           void* stream) {
-  return launch_attn_softmax_bwd(P, dP, ld, B, M, H8, W8, R, pos_w, clamp_ord, clampbits, dtab_rep, drop_p, seed, S(stream));
+                           void* dSpk, long pk_rows, int pk_np, int pk_prec, void* stream) {
+  return launch_attn_softmax_bwd(P, dP, ld, B, M, H8, W8, R, pos_w, clamp_ord, clampbits, dtab_rep, drop_p, seed, dSpk, pk_rows, pk_np, pk_prec,
+                                 S(stream));
 }
 int craft_reduce_replicas(const float* rep, int nrep, int n, float* out, void* stream) {
   return launch_reduce_replicas(rep, nrep, n, out, S(stream));

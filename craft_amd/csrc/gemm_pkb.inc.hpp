@@ -39,6 +39,7 @@ struct PkbOperand {
 struct PkbParams {
   PkbOperand A, B;
   float* C; long ldc, c_outer, c_inner;
+  float alpha;
   int inner, nbatch;
   int M, N, K;                        // K: padded to a multiple of 32 (zeros in BOTH packs)
   int ntile_m, ntile_n;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(512) void k_gemm_pkb(PkbParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + (e & 3) + 8 * (e >> 2);
-        if (m < p.M) cb[(long)m * p.ldc + n] = acc[mt][nt][e];
+        if (m < p.M) cb[(long)m * p.ldc + n] = acc[mt][nt][e] * p.alpha;
       }
     }
   }

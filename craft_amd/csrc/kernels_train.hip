@@ -343,9 +343,14 @@ template <int ITER>
 __global__ __launch_bounds__(256) void k_attn_softmax_bwd(const float* __restrict__ P, float* __restrict__ dP, long ld, int N, int H8,
                                                           int W8, int R, float pos_w, const unsigned* __restrict__ clamp_ord,
                                                           const unsigned* __restrict__ clampbits, float* __restrict__ dtab, long nrows,
-                                                          float drop_p, unsigned long long seed) {
+                                                          float drop_p, unsigned long long seed,
+                                                          unsigned short* __restrict__ dSpk, long pk_rows, int pk_np, int pk_prec) {
   __shared__ float red[4];
   __shared__ float tab[32 * 32];
+  // dSpk: dS leaves as a packed operand of craft_gemm_pk ([plane][j / 32][z * pk_np + i][32], rows >= N of a batch zero) INSTEAD of fp32
+  // over dP -- its only consumers are dQ = dS K and dK = dS^T Q.  The row index then runs over the padded rows (nrows = Z * pk_np).
+  const int rows_per = dSpk ? pk_np : N;
+  const long pk_plane = (ld >> 5) * pk_rows * 32;
   // drop_p > 0: dP is the gradient w.r.t. the DROPPED probabilities (k_attn_softmax_fwd's Pdrop / Ppk): the dropout backward (the same
   // mask) is applied while the row is read
   const unsigned thr = (unsigned)fminf(drop_p * 4294967296.f, 4294967040.f);
@@ -355,8 +360,20 @@ __global__ __launch_bounds__(256) void k_attn_softmax_bwd(const float* __restric
   if (want_tab) for (int t = tid; t < T * T; t += 256) tab[t] = 0.f;
   const bool clamp = clamp_active(clamp_ord) && clampbits != nullptr;
   const long r0 = (long)blockIdx.x * SM_ROWS_PER_BLOCK;
-  for (long rr = r0; rr < min(nrows, r0 + SM_ROWS_PER_BLOCK); ++rr) {
-    const int i = (int)(rr % N);
+  for (long rp = r0; rp < min(nrows, r0 + SM_ROWS_PER_BLOCK); ++rp) {
+    const long z = rp / rows_per;
+    const int i = (int)(rp - z * rows_per);
+    unsigned short* const Dr = dSpk ? dSpk + (z * pk_np + i) * 32 : nullptr;
+    if (i >= N) {                                                    // a padding row of the pack
+      const f16x4 zero = {0, 0, 0, 0};
+      for (int j = tid * 4; j < ld; j += 1024) {
+        unsigned short* o = Dr + (long)(j >> 5) * pk_rows * 32 + (j & 31);
+        *reinterpret_cast<f16x4*>(o) = zero;
+        if (pk_prec == CRAFT_PREC_F16X3) *reinterpret_cast<f16x4*>(o + pk_plane) = zero;
+      }
+      continue;
+    }
+    const long rr = z * N + i;
     const int hi = i / W8, wi = i - hi * W8;
     const float* Pr = P + rr * ld;
     float* Gr = dP + rr * ld;
@@ -404,7 +421,25 @@ __global__ __launch_bounds__(256) void k_attn_softmax_bwd(const float* __restric
         if ((bits >> c) & 1u) ds[c] = 0.f;
         if (++wj == W8) { wj = 0; ++hj; }
       }
-      *reinterpret_cast<float4*>(Gr + j) = o;
+      if (Dr == nullptr) {
+        *reinterpret_cast<float4*>(Gr + j) = o;
+      } else {
+        unsigned short* q = Dr + (long)(j >> 5) * pk_rows * 32 + (j & 31);
+        if (pk_prec == CRAFT_PREC_F16X3) {
+          f16x4 h, l;
+          split_f16x3(o, h, l);
+          *reinterpret_cast<f16x4*>(q) = h;
+          *reinterpret_cast<f16x4*>(q + pk_plane) = l;
+        } else if (pk_prec == CRAFT_PREC_F16) {
+          f16x4 h;
+          h[0] = (_Float16)o.x; h[1] = (_Float16)o.y; h[2] = (_Float16)o.z; h[3] = (_Float16)o.w;
+          *reinterpret_cast<f16x4*>(q) = h;
+        } else {
+          bf16x4 h;
+          h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
+          *reinterpret_cast<bf16x4*>(q) = h;
+        }
+      }
     }
   }
   if (want_tab) {
@@ -414,16 +449,22 @@ __global__ __launch_bounds__(256) void k_attn_softmax_bwd(const float* __restric
   }
 }
 int launch_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, int H8, int W8, int R, float pos_w,
-                            const unsigned* clamp_ord, const unsigned* clampbits, float* dtab, float drop_p, unsigned long long seed, hipStream_t s) {
+                            const unsigned* clamp_ord, const unsigned* clampbits, float* dtab, float drop_p, unsigned long long seed,
+                            void* dSpk, long pk_rows, int pk_np, int pk_prec, hipStream_t s) {
   const int N = H8 * W8;
   if (N <= 0 || B <= 0) return 0;
   if (R > 15 || (ld & 31)) return CRAFT_ERR_UNSUPPORTED;
   if (N > 16000 || ld < N) return CRAFT_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(P) & 15) || (reinterpret_cast<uintptr_t>(dP) & 15)) return CRAFT_ERR_ALIGN;
-  const long nrows = (long)B * M * N;
+  if (dSpk != nullptr) {
+    if (pk_np < N || (pk_np & 31) || pk_rows < (long)B * M * pk_np || (reinterpret_cast<uintptr_t>(dSpk) & 15)) return CRAFT_ERR_ARG;
+    if (pk_prec != CRAFT_PREC_F16X3 && pk_prec != CRAFT_PREC_F16 && pk_prec != CRAFT_PREC_BF16) return CRAFT_ERR_UNSUPPORTED;
+  }
+  const long nrows = (long)B * M * (dSpk ? pk_np : N);
   const dim3 grid((unsigned)((nrows + SM_ROWS_PER_BLOCK - 1) / SM_ROWS_PER_BLOCK));
   const int iter = (int)((ld + 1023) / 1024);
-#define GO(I) hipLaunchKernelGGL(k_attn_softmax_bwd<I>, grid, dim3(256), 0, s, P, dP, ld, N, H8, W8, R, pos_w, clamp_ord, clampbits, dtab, nrows, drop_p, seed)
+#define GO(I) hipLaunchKernelGGL(k_attn_softmax_bwd<I>, grid, dim3(256), 0, s, P, dP, ld, N, H8, W8, R, pos_w, clamp_ord, clampbits, dtab, nrows, drop_p, seed, \
+                                 static_cast<unsigned short*>(dSpk), pk_rows, pk_np, pk_prec)
   if (iter <= 1) GO(1); else if (iter <= 2) GO(2); else if (iter <= 3) GO(3); else if (iter <= 4) GO(4); else if (iter <= 5) GO(5);
   else if (iter <= 6) GO(6); else if (iter <= 8) GO(8); else GO(16);
 #undef GO

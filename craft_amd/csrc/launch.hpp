@@ -56,7 +56,7 @@ int launch_pack_operand(const float* x, long ldx, int C, long rows, int B, int H
                         int prec, void* out, int cg_off, int ncg_total, float* colsum, int tail, hipStream_t s);
 int launch_pack_operands(const long* descs, int n, hipStream_t s);
 int launch_gemm_pk(const void* A, const long* a_desc, const void* B, const long* b_desc, float* C, long ldc, long c_outer, long c_inner,
-                   int inner, int nbatch, int M, int N, int K, int prec, hipStream_t s);
+                   int inner, int nbatch, int M, int N, int K, float alpha, int prec, hipStream_t s);
 int launch_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* const* Xp1, int cin0, int nseg, long dy_rows_p, int cout, long x_rows_p,
                     int cin, long guard, long K, int KH, int KW, int Wp, float* dW, int prec, hipStream_t s);
 int launch_pack_conv_weights(const float* w0, int cout0, const float* w1, int cout1, int Cin, int KH, int KW, int a0, int a1, int b0, int b1,
@@ -195,7 +195,7 @@ int launch_attn_softmax_fwd(float* S, long ld, int B, int M, int H8, int W8, con
                             void* Ppk, long pk_rows, int pk_np, int pk_prec, hipStream_t s);
 int launch_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, int H8, int W8, int R, float pos_w,
                             const unsigned* clamp_ord, const unsigned* clampbits, float* dtab, float drop_p, unsigned long long seed,
-                            hipStream_t s);
+                            void* dSpk, long pk_rows, int pk_np, int pk_prec, hipStream_t s);
 int launch_reduce_replicas(const float* rep, int nrep, int n, float* out, hipStream_t s);
 int launch_corr_pool_fwd(const float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, const float* w,
                          const unsigned* clamp_ord, float* c0, double* sums, hipStream_t s);

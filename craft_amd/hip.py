@@ -68,7 +68,7 @@ _SIGS = {
     "craft_gemm": [P, L, L, L, L, P, L, L, L, L, P, L, L, L, I, I, I, I, I, F, I, I, I, P],
     "craft_conv2d_wgrad": [P, L, I, P, L, I, I, I, I, I, I, P, P, P, L, I, P],
     "craft_pack_operand": [P, L, I, L, I, I, I, I, I, L, L, I, P, I, I, P, I, P],
-    "craft_gemm_pk": [P, P, P, P, P, L, L, L, I, I, I, I, I, I, P],
+    "craft_gemm_pk": [P, P, P, P, P, L, L, L, I, I, I, I, I, F, I, P],
     "craft_pack_conv_weights": [P, I, P, I, I, I, I, I, I, I, I, I, I, P, P],
     "craft_conv2d_nhwc2": [P, L, I, P, L, I, P, P, P, L, I, I, I, I, P, L, I, I, I, I, P],
     "craft_pack_operands": [P, I, P],
@@ -86,7 +86,7 @@ _SIGS = {
     "craft_dropout": [P, P, L, F, ctypes.c_ulonglong, P],
     "craft_tokens_bwd": [P, L, P, L, P, L, L, I, I, I, P],
     "craft_attn_softmax_fwd": [P, L, I, I, I, I, P, I, F, I, P, P, P, F, ctypes.c_ulonglong, P, L, I, I, P],
-    "craft_attn_softmax_bwd": [P, P, L, I, I, I, I, I, F, P, P, P, F, ctypes.c_ulonglong, P],
+    "craft_attn_softmax_bwd": [P, P, L, I, I, I, I, I, F, P, P, P, F, ctypes.c_ulonglong, P, L, I, I, P],
     "craft_relpos_add": [P, L, I, I, I, P, L, P, L, F, P],
     "craft_relpos_bwd": [P, L, I, I, I, P, L, I, P, L, I, F, P],
     "craft_reduce_replicas": [P, I, I, P, P],

@@ -66,13 +66,14 @@ def _attention_probs(module, x_ln, hw, prec, p_attn: float, seed: int, pk_box=No
     M = st.num_modes
     scale = 1.0 / math.sqrt(st.attention_mode_dim)
     mx = ops.score_max(q.detach(), k.detach(), hw[0], hw[1], M, scale, prec)
-    S = AG.Scores.apply(q, k, M, scale, prec)
+    link = AG.ScoreLink() if use_pk_attention(prec) else None          # scores and their gradients on packed operands too
+    S = AG.Scores.apply(q, k, M, scale, prec, link)
     pk = None
     if pk_box is not None:
         pk = AG.PkMat(S.shape[0] * S.shape[1], S.shape[2], S.shape[3], AG.pick(prec, "pv"), S.device)
         pk_box.append(pk)
     return AG.AttnSoftmax.apply(S, module.vispos_encoder.pos_coder.biases, float(st.pos_code_weight), int(module.attn_mask_radius), mx, hw,
-                                float(p_attn), int(seed), pk)
+                                float(p_attn), int(seed), pk, link)
 
 
 def _conv(x, conv, hw, act, prec, cache):

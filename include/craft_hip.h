@@ -364,7 +364,7 @@ int craft_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* co
 
 /* Batched GEMM over packed operands (round 3; craft_amd/csrc/gemm_pkb.inc.hpp) -- the attention products of the training pass
  * (autograd of setrans.py:373-384, :520-557; update.py:143-149) with nothing but copies and MFMAs in the K loop:
- *   C[z][m][n] = sum_{k < K} A_z[m, k] * B_z[n, k],   z = outer * inner + inner_index < nbatch,  C_z = C + outer * c_outer + inner_index * c_inner
+ *   C[z][m][n] = alpha * sum_{k < K} A_z[m, k] * B_z[n, k],   z = outer * inner + inner_index < nbatch,  C_z = C + outer * c_outer + inner_index * c_inner
  * A / B: packs [plane][channel group][row][32] (craft_pack_operand(s), craft_attn_softmax_fwd's Ppk), described by 9 longs each:
  *   {kind, rows_p, ncg, row0, row_outer, row_inner, cg0, cg_outer, cg_inner}: kind 0 = K runs down the ROWS of the pack and M (N) over
  *   its channels, kind 1 = K runs over the CHANNELS and M (N) down the rows; rows_p / ncg: rows and channel groups of the pack (its
@@ -373,7 +373,7 @@ int craft_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* co
  * K % 32 == 0 with ZEROS in the K padding of both packs; the M / N padding may hold anything finite or not (never stored).
  * Kind pairs (0,0), (1,0), (1,1); prec CRAFT_PREC_F16X3 / F16 / BF16 = the mode the packs were written in. */
 int craft_gemm_pk(const void* A, const long* a_desc, const void* B, const long* b_desc, float* C, long ldc, long c_outer, long c_inner,
-                  int inner, int nbatch, int M, int N, int K, int prec, void* stream);
+                  int inner, int nbatch, int M, int N, int K, float alpha, int prec, void* stream);
 
 int craft_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, void* stream);
 int craft_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,
@@ -395,13 +395,15 @@ int craft_tokens_bwd(const float* x, long ldx, const float* dy, long lddy, float
  *   gradient w.r.t. Pdrop and applies the mask while it reads the row (two 1 GB passes less per attention at 368x496, batch 8).
  * Ppk (or NULL) / pk_rows / pk_np / pk_prec: the (dropped, if drop_p > 0) probabilities also as a packed operand of craft_gemm_pk,
  *   [plane][ld / 32][pk_rows][32] in mode pk_prec with batch z = b * M + m in rows [z * pk_np, (z + 1) * pk_np), pk_np >= N a multiple
- *   of 32, rows >= N of a batch zero: rows = query i, channels = key j. */
+ *   of 32, rows >= N of a batch zero: rows = query i, channels = key j.
+ * dSpk (craft_attn_softmax_bwd; or NULL): dS leaves as such a pack INSTEAD of fp32 over dP (same layout and arguments as Ppk) -- the
+ *   operand of dQ = dS K and dK = dS^T Q on craft_gemm_pk. */
 int craft_attn_softmax_fwd(float* S, long ld, int B, int M, int H8, int W8, const float* pos_tab, int R, float pos_w, int mask_radius,
                            const unsigned* clamp_ord, unsigned* clampbits, float* Pdrop, float drop_p, unsigned long long seed,
                            void* Ppk, long pk_rows, int pk_np, int pk_prec, void* stream);
 int craft_attn_softmax_bwd(const float* P, float* dP, long ld, int B, int M, int H8, int W8, int R, float pos_w,
                            const unsigned* clamp_ord, const unsigned* clampbits, float* dtab_rep, float drop_p, unsigned long long seed,
-                           void* stream);
+                           void* dSpk, long pk_rows, int pk_np, int pk_prec, void* stream);
 int craft_reduce_replicas(const float* rep, int nrep, int n, float* out, void* stream);
 
 /* gma.Attention's relative-position scores (RelPosEmb, gma.py:21-50, :84-98) added to materialised scores S [BZ][N][ld], BZ = B*heads:

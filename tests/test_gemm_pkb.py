@@ -108,3 +108,53 @@ def test_softmax_writes_the_packed_probabilities(device):
             a = pk.buf.view(planes, pk.ncg, pk.rows_total, 32)[:, :, :B * M * pk.np_]
             b = ref.buf.view(planes, pk.ncg, pk.rows_total, 32)[:, :, :B * M * pk.np_]
             assert torch.equal(a, b)
+
+
+def test_softmax_backward_writes_dS_packed(device):
+    """craft_attn_softmax_bwd's dSpk output == craft_pack_operand of its fp32 dS (bit for bit, padding rows zero), with the dropout mask
+    and the positional-table gradient unchanged."""
+    from craft_amd import hip
+    B, M, H8, W8 = 2, 3, 7, 9
+    N = H8 * W8
+    ld = round_up(N, 32)
+    g = torch.Generator().manual_seed(2)
+    P = torch.zeros(B, M, N, ld)
+    P[..., :N] = torch.softmax(torch.randn(B, M, N, N, generator=g) * 2.0, dim=-1)
+    G = torch.randn(B, M, N, ld, generator=g)
+    P, G = P.to(device), G.to(device)
+    for prec in (PREC_F16X3, PREC_F16, PREC_BF16):
+        d1, rep1 = G.clone(), torch.zeros(hip.STATS_REPLICAS, 225, device=device)
+        AG.call("craft_attn_softmax_bwd", P, d1, ld, B, M, H8, W8, 7, 0.5, None, None, rep1, 0.2, 9, None, 0, 0, 0)
+        d2, rep2 = G.clone(), torch.zeros(hip.STATS_REPLICAS, 225, device=device)
+        pk = AG.PkMat(B * M, N, ld, prec, device)
+        pk.buf.fill_(0x7e00)
+        AG.call("craft_attn_softmax_bwd", P, d2, ld, B, M, H8, W8, 7, 0.5, None, None, rep2, 0.2, 9, pk.buf, pk.rows_total, pk.np_, prec)
+        assert torch.equal(d2, G)                                   # the fp32 gradient buffer is left alone
+        assert torch.allclose(rep1.sum(0), rep2.sum(0), rtol=1e-4, atol=1e-5)
+        ref = AG.PkMat(B * M, N, ld, prec, device).fill(d1)
+        planes = 2 if prec == PREC_F16X3 else 1
+        a = pk.buf.view(planes, pk.ncg, pk.rows_total, 32)[:, :, :B * M * pk.np_]
+        b = ref.buf.view(planes, pk.ncg, pk.rows_total, 32)[:, :, :B * M * pk.np_]
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("prec,tol", PRECS)
+def test_scores_chain_on_packed_operands(device, prec, tol):
+    """Scores -> AttnSoftmax with a ScoreLink (Q K^T, dQ = dS K, dK = dS^T Q on craft_gemm_pk, dS handed over as a pack) against the same
+    chain on the fp32-source engine: values and gradients."""
+    B, M, H8, W8, C = 2, 4, 6, 10, 128
+    N = H8 * W8
+    g = torch.Generator().manual_seed(4)
+    q0, k0 = torch.randn(B, N, C, generator=g).to(device), torch.randn(B, N, C, generator=g).to(device)
+    tab0 = (torch.randn(15, 15, generator=g) * 0.5).to(device)
+    gout = torch.randn(B, M, N, round_up(N, 32), generator=g).to(device)
+    res = []
+    for link in (None, AG.ScoreLink()):
+        q, k, tab = q0.clone().requires_grad_(True), k0.clone().requires_grad_(True), tab0.clone().requires_grad_(True)
+        S = AG.Scores.apply(q, k, M, 0.2, prec, link)
+        Pm = AG.AttnSoftmax.apply(S, tab, 0.5, -1, None, (H8, W8), 0.1, 5, None, link)
+        Pm.backward(gout.clone())
+        res.append((Pm.detach()[..., :N].clone(), q.grad, k.grad, tab.grad))
+    assert link.want and link.dS is None
+    for a, b in zip(res[0], res[1]):
+        assert ((a - b).norm() / a.norm()).item() < 2 * tol

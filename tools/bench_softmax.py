@@ -42,9 +42,10 @@ Pp = torch.zeros_like(S0); Pp[..., :N] = P
 rep = torch.zeros(hip.STATS_REPLICAS, 225, device=dev)
 dS = G.clone()
 for name, fn, nb in (
-    ("bwd (dS over dP)", lambda: AG.call("craft_attn_softmax_bwd", Pp, dS, ld, B, M, H8, W8, 7, 0.5, None, bits, rep, 0.0, 0), 3),
-    ("bwd + dropout mask", lambda: AG.call("craft_attn_softmax_bwd", Pp, dS, ld, B, M, H8, W8, 7, 0.5, None, bits, rep, 0.2, 5), 3),
-    ("bwd, no positional table", lambda: AG.call("craft_attn_softmax_bwd", Pp, dS, ld, B, M, H8, W8, 0, 0.0, None, bits, None, 0.2, 5), 3),
+    ("bwd (dS over dP)", lambda: AG.call("craft_attn_softmax_bwd", Pp, dS, ld, B, M, H8, W8, 7, 0.5, None, bits, rep, 0.0, 0, None, 0, 0, 0), 3),
+    ("bwd + dropout mask", lambda: AG.call("craft_attn_softmax_bwd", Pp, dS, ld, B, M, H8, W8, 7, 0.5, None, bits, rep, 0.2, 5, None, 0, 0, 0), 3),
+    ("bwd + dropout mask -> packed f16x3 dS", lambda: AG.call("craft_attn_softmax_bwd", Pp, dS, ld, B, M, H8, W8, 7, 0.5, None, bits, rep, 0.2, 5, pk.buf, pk.rows_total, pk.np_, pk.prec), 3),
+    ("bwd, no positional table", lambda: AG.call("craft_attn_softmax_bwd", Pp, dS, ld, B, M, H8, W8, 0, 0.0, None, bits, None, 0.2, 5, None, 0, 0, 0), 3),
 ):
     t = timeit(fn)
     print(f"{name:34s} {t:8.1f} us   {nb * gb / t * 1e3:5.2f} TB/s of the {nb} x {gb:.2f} GB it has to move")
