@@ -66,7 +66,13 @@ def _attention_probs(module, x_ln, hw, prec, p_attn: float, seed: int, pk_box=No
     M = st.num_modes
     scale = 1.0 / math.sqrt(st.attention_mode_dim)
     mx = ops.score_max(q.detach(), k.detach(), hw[0], hw[1], M, scale, prec)
-    link = AG.ScoreLink() if use_pk_attention(prec) else None          # scores and their gradients on packed operands too
+    # scores and their gradients on packed operands too -- for the single-plane modes (bf16 / fp16: dS leaves the softmax backward in half
+    # the bytes; configs[4] -1 ms).  In f16x3 the three products gain 165 us per attention and the packed dS store costs them again
+    # (measured +2 ms per step at configs[3] with it on: CRAFT_PK_SCORES=1 forces it for A/B runs)
+    sp_ = AG.pick(prec, "score")
+    link = None
+    if use_pk_attention(prec) and not os.environ.get("CRAFT_NO_PK_SCORES") and (sp_ in (PREC_BF16, PREC_F16) or os.environ.get("CRAFT_PK_SCORES")):
+        link = AG.ScoreLink()
     S = AG.Scores.apply(q, k, M, scale, prec, link)
     pk = None
     if pk_box is not None:

@@ -60,3 +60,24 @@ Pd = torch.empty_like(S)
 t = timeit(lambda: AG.call("craft_attn_softmax_fwd", S, ld, B, Mh, 46, 62, None, 0, 0.0, -1, None, None, None, 0.2, 5, pk.buf, pk.rows_total, pk.np_, prec), 5)
 t0 = timeit(lambda: AG.call("craft_attn_softmax_fwd", S, ld, B, Mh, 46, 62, None, 0, 0.0, -1, None, None, Pd, 0.2, 5, None, 0, 0, 0), 5)
 print(f"softmax fwd + dropout: packed output {t:.1f} us, fp32 Pdrop output {t0:.1f} us")
+# ---- the scores' three products (d = 64 per mode): S = scale Q K^T, dQ = dS K, dK = dS^T Q
+d_ = 64
+Cq = Mh * d_
+q = torch.randn(B, N, Cq, device=dev)
+k = torch.randn(B, N, Cq, device=dev)
+qpk, kpk = AG.PkMat(B, N, Cq, prec, dev).fill(q), AG.PkMat(B, N, Cq, prec, dev).fill(k)
+Sx, Sy = torch.empty(B, Mh, N, ld, device=dev), torch.empty(B, Mh, N, ld, device=dev)
+cgq = d_ // 32
+t = timeit(lambda: AG.gemm_pk(qpk, qpk.desc(AG.PK_CH, 1, 0, 0, 0, cgq), kpk, kpk.desc(AG.PK_CH, 1, 0, 0, 0, cgq), Sx, ld, Mh * N * ld, N * ld, Mh, B * Mh, N, N, d_, alpha=0.125))
+t0 = timeit(lambda: AG.gemm(q, Cq, 1, N * Cq, d_, k, Cq, 1, N * Cq, d_, Sy, ld, Mh * N * ld, N * ld, Mh, B * Mh, N, N, d_, alpha=0.125, prec=prec))
+print(f"S = Q K^T    pk {t:8.1f} us ({Sx.numel() * 4 / t / 1e6:5.2f} TB/s of S written)   craft_gemm {t0:8.1f} us   rel diff {float((Sx[..., :N] - Sy[..., :N]).norm() / Sy[..., :N].norm()):.2e}")
+dS = torch.zeros(B, Mh, N, ld, device=dev)
+dS[..., :N] = torch.randn(B, Mh, N, N, device=dev)
+dSpk = AG.PkMat(B * Mh, N, ld, prec, dev).fill(dS)
+dq, dq2 = torch.empty(B, N, Cq, device=dev), torch.empty(B, N, Cq, device=dev)
+t = timeit(lambda: AG.gemm_pk(dSpk, dSpk.desc(AG.PK_CH, Mh, 1), kpk, kpk.desc(AG.PK_ROWS, 1, 0, 0, 0, cgq), dq, Cq, N * Cq, d_, Mh, B * Mh, N, d_, N, alpha=0.125))
+t0 = timeit(lambda: AG.gemm(dS, ld, 1, Mh * N * ld, N * ld, k, 1, Cq, N * Cq, d_, dq2, Cq, N * Cq, d_, Mh, B * Mh, N, d_, N, alpha=0.125, prec=prec))
+print(f"dQ = dS K    pk {t:8.1f} us   craft_gemm {t0:8.1f} us   rel diff {float((dq - dq2).norm() / dq2.norm()):.2e}")
+t = timeit(lambda: AG.gemm_pk(dSpk, dSpk.desc(AG.PK_ROWS, Mh, 1), qpk, qpk.desc(AG.PK_ROWS, 1, 0, 0, 0, cgq), dq, Cq, N * Cq, d_, Mh, B * Mh, N, d_, N, alpha=0.125))
+t0 = timeit(lambda: AG.gemm(dS, 1, ld, Mh * N * ld, N * ld, q, 1, Cq, N * Cq, d_, dq2, Cq, N * Cq, d_, Mh, B * Mh, N, d_, N, alpha=0.125, prec=prec))
+print(f"dK = dS^T Q  pk {t:8.1f} us   craft_gemm {t0:8.1f} us   rel diff {float((dq - dq2).norm() / dq2.norm()):.2e}")
