@@ -610,7 +610,11 @@ class CorrVolume(Function):
         if ctx.has_tab:
             dtab = hip.zeros((T, T,), S.device)
             call("craft_reduce_replicas", rep, STATS_REPLICAS, T * T, dtab)
+        # the pyramid's (mean, rstd) tensor is this node's OUTPUT: node -> holder -> pyramid -> output -> node is a reference cycle that
+        # kept 350 MB per step alive until the cyclic collector ran; the volume is finished here
         ctx.holder.G = None
+        ctx.holder.pyr = None
+        ctx.holder = None
         return dS, dtab, (dw.float().reshape(ctx.w_shape) if ctx.needs_input_grad[2] else None), None, None, None, None, None
 
 
@@ -796,7 +800,7 @@ def gemm_pk(A: PkMat, a_desc, B: PkMat, b_desc, C: torch.Tensor, ldc: int, c_out
     """C[z][m][n] = alpha sum_k A_z[m, k] B_z[n, k] over packed operands (craft_gemm_pk; K padded to a multiple of 32 with zeros in both packs)."""
     import ctypes
     assert A.prec == B.prec
-    call("craft_gemm_pk", A.buf, (ctypes.c_long * 9)(*a_desc), B.buf, (ctypes.c_long * 9)(*b_desc), C, ldc, c_outer, c_inner, inner, nbatch, M, N,
+    call("craft_gemm_pk", A.buf, hip.carray(ctypes.c_long, a_desc), B.buf, hip.carray(ctypes.c_long, b_desc), C, ldc, c_outer, c_inner, inner, nbatch, M, N,
          round_up(K, 32), float(alpha), A.prec)
 
 
@@ -814,7 +818,7 @@ class PackBatch:
         import ctypes
         if self.descs:
             flat = [int(v) for d in self.descs for v in d]
-            call("craft_pack_operands", (ctypes.c_long * len(flat))(*flat), len(self.descs))
+            call("craft_pack_operands", hip.carray(ctypes.c_long, flat), len(self.descs))
         self.descs, self.keep = [], []
 
 
@@ -831,9 +835,9 @@ def wgrad_pk(pairs, KH: int, KW: int, acc: torch.Tensor):
         assert (x2.K, x2.guard, x2.prec, x2.rows_p, x2.C_p, hasattr(x2, "a")) == (gp.K, gp.guard, gp.prec, xp.rows_p, xp.C_p, two)
         assert not two or x2.a.C_p == xp.a.C_p
     n = len(pairs)
-    ga = (ctypes.c_void_p * n)(*[g2.buf.data_ptr() for g2, _ in pairs])
-    xa = (ctypes.c_void_p * n)(*[(x2.a if two else x2).buf.data_ptr() for _, x2 in pairs])
-    xb = (ctypes.c_void_p * n)(*[x2.b.buf.data_ptr() for _, x2 in pairs]) if two else None
+    ga = hip.carray(ctypes.c_void_p, [g2.buf.data_ptr() for g2, _ in pairs])
+    xa = hip.carray(ctypes.c_void_p, [(x2.a if two else x2).buf.data_ptr() for _, x2 in pairs])
+    xb = hip.carray(ctypes.c_void_p, [x2.b.buf.data_ptr() for _, x2 in pairs]) if two else None
     call("craft_wgrad_pk", ga, xa, xb, xp.a.C_p if two else xp.C_p, n, gp.rows_p, gp.C_p, xp.rows_p, xp.C_p, gp.guard, gp.K, KH, KW, gp.Wp, acc, gp.prec)
 
 

@@ -271,6 +271,19 @@ def call(name: str, *args):
         raise CraftHipError(f"{name} failed with code {rc}: {msg}")
 
 
+_CARRAY_TYPES = {}
+
+
+def carray(ctype, values):
+    """A ctypes array of ``values`` -- the array TYPE cached per (element type, length): ``ctype * n`` builds a new class object with a
+    reference cycle on every evaluation, hundreds per training step that only the cyclic collector frees."""
+    n = len(values)
+    t = _CARRAY_TYPES.get((ctype, n))
+    if t is None:
+        t = _CARRAY_TYPES[(ctype, n)] = ctype * n
+    return t(*values)
+
+
 class ZeroPool:
     """The many small zero-initialised buffers of a training step (gradient accumulators, statistics replicas: ~300 torch.zeros, a 4 us
     fill kernel each) from ONE zeroed allocation per step.  The first step records the (shape, dtype) sequence; later steps allocate the
