@@ -119,3 +119,43 @@ def test_reference_style_full_checkpoint_loads(tmp_path):
     with pytest.raises(pickle.UnpicklingError):
         read_checkpoint(path)
     assert "odd" in read_checkpoint(path, trusted=True)["logger"]
+
+
+def test_zero_pool_serves_a_recorded_sequence_and_falls_back():
+    """hip.ZeroPool (the per-step source of the small zero-initialised buffers): the first step records, later steps hand out disjoint
+    zeroed pieces of ONE allocation in the recorded order; a deviating request falls back to plain allocations and the plan is re-learned."""
+    from craft_amd import hip
+    pool = hip.ZeroPool()
+    dev = torch.device("cpu")
+    seq = [((3, 5), torch.float32), ((7,), torch.float64), ((2, 2, 2), torch.float32)]
+
+    def step(requests):
+        pool.begin(dev)
+        return [pool.zeros(s, dev, dt) for s, dt in requests]
+
+    first = step(seq)                                       # recording: plain tensors
+    assert pool.flat is None and all(float(t.abs().sum()) == 0 for t in first)
+    second = step(seq)                                      # served from the flat buffer
+    assert pool.flat is not None and pool.ok
+    for t, (s, dt) in zip(second, seq):
+        assert tuple(t.shape) == s and t.dtype == dt and float(t.abs().sum()) == 0
+        assert t.untyped_storage().data_ptr() == pool.flat.untyped_storage().data_ptr()
+    second[0].fill_(1.0)                                    # pieces are disjoint ...
+    assert float(second[1].abs().sum()) == 0 and float(second[2].abs().sum()) == 0
+    third = step(seq)                                       # ... and a new step starts from zeros in a NEW allocation
+    assert float(third[0].abs().sum()) == 0 and third[0].untyped_storage().data_ptr() != second[0].untyped_storage().data_ptr()
+    other = [((3, 5), torch.float32), ((9,), torch.float32), ((2, 2, 2), torch.float32)]
+    fourth = step(other)                                    # deviation at the 2nd request: fallback from there on
+    assert not pool.ok and fourth[1].shape == (9,) and float(fourth[2].abs().sum()) == 0
+    fifth = step(other)                                     # the new sequence has been learned
+    assert pool.ok and fifth[1].untyped_storage().data_ptr() == pool.flat.untyped_storage().data_ptr()
+    # outside a training step hip.zeros is torch.zeros
+    hip.set_zero_pool(None)
+    assert float(hip.zeros((4,), dev).sum()) == 0
+
+
+def test_carray_types_are_cached():
+    import ctypes
+    from craft_amd import hip
+    a, b = hip.carray(ctypes.c_long, [1, 2, 3]), hip.carray(ctypes.c_long, [4, 5, 6])
+    assert type(a) is type(b) and list(b) == [4, 5, 6] and type(hip.carray(ctypes.c_long, [1])) is not type(a)
