@@ -13,7 +13,7 @@ python $REPO/bench.py --train 4 --steps 10 --warmup 6 > $O/bench_train_cfg4.json
 python $REPO/bench.py --train 3 --steps 10 --warmup 6 --precision train_f16x3 > $O/bench_train_cfg3_f16x3.json 2>/dev/null
 python $REPO/bench.py --train 3 --steps 10 --warmup 6 --precision train_amp_bf16 --no-cpu-baseline > $O/bench_train_cfg3_amp_bf16.json 2>/dev/null
 python $REPO/bench.py --train 3 --steps 10 --warmup 6 --precision train_amp_fp16 --no-cpu-baseline > $O/bench_train_cfg3_amp_fp16.json 2>/dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_train -o train -- python $REPO/bench.py --train 3 --steps 4 --warmup 4 --no-cpu-baseline > $O/train3_under_rocprof.json 2> $O/rocprof_train.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_train -o train -- python $REPO/bench.py --train 3 --steps 4 --warmup 4 --no-cpu-baseline --precision mixed > $O/train3_under_rocprof.json 2> $O/rocprof_train.err
 python $REPO/tools/kstats.py $(find $O/trace_train -name "*kernel_stats.csv" | head -1) 70 > $O/train_cfg3_kernel_stats.txt
 rm -rf $O/trace_train
 python $REPO/tools/bench_wgrad.py --cfg 3 > $O/bench_wgrad_cfg3.txt 2>/dev/null
