@@ -158,3 +158,32 @@ def test_scores_chain_on_packed_operands(device, prec, tol):
     assert link.want and link.dS is None
     for a, b in zip(res[0], res[1]):
         assert ((a - b).norm() / a.norm()).item() < 2 * tol
+
+
+def test_benchmark_shape_against_the_fp32_source_engine(device):
+    """The three attention products at BASELINE configs[3]'s shape (8 x 4 modes x 2852 x 2852 probabilities, 128 channels per mode: batch
+    offsets of hundreds of MB inside the packs, 32 batches over the 8 XCD queues, the 4-stage 128-row tile and the 256 x 256 tile) equal
+    craft_gemm on the same fp32 tensors -- which tests/test_train_backward.py::test_gemm_layouts holds to float64."""
+    B, Mh, N, C = 8, 4, 46 * 62, 128
+    ld = round_up(N, 32)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    P = torch.zeros(B, Mh, N, ld, device=device)
+    P[..., :N] = torch.softmax(torch.randn(B, Mh, N, N, device=device) * 2.0, dim=-1)
+    V = torch.randn(B, N, Mh * C, generator=g).to(device)
+    dO = torch.randn(B, Mh, N, C, generator=g).to(device)
+    prec = PREC_F16X3
+    Ppk, Vpk, dOpk = AG.PkMat(B * Mh, N, ld, prec, device).fill(P), AG.PkMat(B, N, Mh * C, prec, device).fill(V), AG.PkMat(B * Mh, N, C, prec, device).fill(dO)
+    cg = C // 32
+    O, O2 = torch.empty(B, Mh, N, C, device=device), torch.empty(B, Mh, N, C, device=device)
+    AG.gemm_pk(Ppk, Ppk.desc(AG.PK_CH, Mh, 1), Vpk, Vpk.desc(AG.PK_ROWS, 1, 0, 0, 0, cg), O, C, Mh * N * C, N * C, Mh, B * Mh, N, C, ld)
+    AG.gemm(P, ld, 1, Mh * N * ld, N * ld, V, 1, Mh * C, N * Mh * C, C, O2, C, Mh * N * C, N * C, Mh, B * Mh, N, C, N, prec=prec)
+    assert ((O - O2).norm() / O2.norm()).item() < 1e-6
+    dV, dV2 = torch.empty(B, N, Mh, C, device=device), torch.empty(B, N, Mh, C, device=device)
+    AG.gemm_pk(Ppk, Ppk.desc(AG.PK_ROWS, Mh, 1), dOpk, dOpk.desc(AG.PK_ROWS, Mh, 1), dV, Mh * C, N * Mh * C, C, Mh, B * Mh, N, C, N)
+    AG.gemm(P, 1, ld, Mh * N * ld, N * ld, dO, 1, C, Mh * N * C, N * C, dV2, Mh * C, N * Mh * C, C, Mh, B * Mh, N, C, N, prec=prec)
+    assert ((dV - dV2).norm() / dV2.norm()).item() < 1e-6
+    dP, dP2 = torch.empty(B, Mh, N, ld, device=device), torch.zeros(B, Mh, N, ld, device=device)
+    AG.gemm_pk(dOpk, dOpk.desc(AG.PK_CH, Mh, 1), Vpk, Vpk.desc(AG.PK_CH, 1, 0, 0, 0, cg), dP, ld, Mh * N * ld, N * ld, Mh, B * Mh, N, N, C)
+    Vm = V.view(B, N, Mh, C).permute(0, 2, 1, 3).contiguous()
+    AG.gemm(dO, C, 1, Mh * N * C, N * C, Vm, C, 1, Mh * N * C, N * C, dP2, ld, Mh * N * ld, N * ld, Mh, B * Mh, N, N, C, prec=prec)
+    assert ((dP[..., :N] - dP2[..., :N]).norm() / dP2[..., :N].norm()).item() < 1e-6
