@@ -97,3 +97,26 @@ def test_async_feed_yields_the_same_batches(device, tmp_path):
     for _ in range(3):
         next(it)
     it.close()
+
+
+def test_training_driver_runs_checkpoints_validates_and_resumes(device, tmp_path):
+    """craft_amd.train_main (train.py:176-262): the sintel stage on miniature trees -- steps, periodic checkpoint + validation through the
+    evaluation harness, the final checkpoint in the reference's layout, and a resumed run that continues the schedule."""
+    from craft_amd import train_main
+    from craft_amd.utils import read_checkpoint
+    root, kroot = _trees(tmp_path)
+    out = tmp_path / "ckpt"
+    common = ["--stage", "sintel", "--validation", "sintel", "kitti", "--output", str(out), "--batch_size", "2", "--image_size", "96", "128",
+              "--iters", "2", "--print_freq", "2", "--lr", "1e-4", "--craft", "--f2", "full", "--setrans", "--sintel_root", root, "--kitti_root", kroot,
+              "--workers", "2"]
+    path = train_main.main(["--name", "mini", "--num_steps", "4", "--val_freq", "2"] + common)
+    assert path == str(out / "mini.pth") and (out / "2_mini.pth").exists() and (out / "4_mini.pth").exists()
+    ck = read_checkpoint(path)
+    assert set(ck) == {"model", "optimizer", "lr_scheduler", "logger"} and all(k.startswith("module.") for k in ck["model"])
+    assert ck["logger"]["total_steps"] == 4 and ck["logger"]["val_steps"] == [2, 4]
+    assert set(ck["logger"]["val_results"]) >= {"clean", "final", "epe", "f1"} and all(len(v) == 2 for v in ck["logger"]["val_results"].values())
+    # resume with optimizer + scheduler state under the reference's own precision recipe: two more steps of a 6-step schedule
+    path2 = train_main.main(["--name", "mini2", "--num_steps", "6", "--val_freq", "100", "--restore_ckpt", str(out / "2_mini.pth"), "--loadopt", "--loadsched",
+                             "--mixed_precision"] + common)
+    ck2 = read_checkpoint(path2)
+    assert ck2["logger"]["total_steps"] == 6 and ck2["lr_scheduler"]["last_epoch"] == 6
