@@ -60,11 +60,30 @@ def parse(argv=None) -> argparse.Namespace:
     ap.add_argument("--radius", dest="corr_radius", type=int, default=4)
     ap.add_argument("--dropout", type=float, default=0.0)
     ap.add_argument("--f1", dest="f1trans", default="none", choices=["none", "shared", "private"])
-    ap.add_argument("--f2", dest="f2trans", default="none", choices=["none", "full"])
+    ap.add_argument("--f2", dest="f2trans", default="full", choices=["none", "full"])
     ap.add_argument("--position_only", action="store_true")
     ap.add_argument("--position_and_content", action="store_true")
+    ap.add_argument("--num_heads", type=int, default=1)
     ap.add_argument("--posr", dest="pos_bias_radius", type=int, default=7)
-    return ap.parse_args(argv)
+    ap.add_argument("--f2posw", dest="f2_pos_code_weight", type=float, default=0.5)
+    ap.add_argument("--f2radius", dest="f2_attn_mask_radius", type=int, default=-1)
+    ap.add_argument("--intermodes", dest="inter_num_modes", type=int, default=4)
+    ap.add_argument("--intramodes", dest="intra_num_modes", type=int, default=4)
+    ap.add_argument("--f2modes", dest="f2_num_modes", type=int, default=4)
+    ap.add_argument("--interqknobias", dest="inter_qk_have_bias", action="store_false")
+    ap.add_argument("--interpos", dest="inter_pos_code_type", default="bias", choices=["lsinu", "bias"])
+    ap.add_argument("--interposw", dest="inter_pos_code_weight", type=float, default=0.5)
+    ap.add_argument("--intrapos", dest="intra_pos_code_type", default="bias", choices=["lsinu", "bias"])
+    ap.add_argument("--intraposw", dest="intra_pos_code_weight", type=float, default=1.0)
+    # accepted for command-line compatibility: the reference's DataParallel device list (here: one process per GPU under
+    # torch.distributed.run) and its model-family switches that this package does not build
+    ap.add_argument("--gpus", type=int, nargs="+", default=None)
+    ap.add_argument("--model_name", default="")
+    ns = ap.parse_args(argv)
+    if ns.gpus and len(ns.gpus) > 1 and int(os.environ.get("WORLD_SIZE", 1)) == 1:
+        print(f"[train_main] --gpus {ns.gpus}: this driver runs one process per GPU; start it under `python -m torch.distributed.run "
+              f"--nproc-per-node {len(ns.gpus)} -m craft_amd.train_main ...` for {len(ns.gpus)} GPUs (continuing on one)", flush=True)
+    return ns
 
 
 def fetch_sources(ns: argparse.Namespace) -> List:

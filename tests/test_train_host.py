@@ -159,3 +159,30 @@ def test_carray_types_are_cached():
     from craft_amd import hip
     a, b = hip.carray(ctypes.c_long, [1, 2, 3]), hip.carray(ctypes.c_long, [4, 5, 6])
     assert type(a) is type(b) and list(b) == [4, 5, 6] and type(hip.carray(ctypes.c_long, [1])) is not type(a)
+
+
+def test_training_driver_accepts_the_reference_command_lines():
+    """craft_amd.train_main.parse takes the argument lists of the reference's shipped training scripts (train-craft-f2full.sh, train-gma.sh,
+    train-craft-f2full-gma.sh: everything after `python3 train.py`) for the stages whose datasets have a walker here."""
+    from craft_amd import default_args
+    from craft_amd.train_main import parse
+    lines = [
+        "--name craft-chairs --stage chairs --validation chairs --output results/chairs/craft-f2full --num_steps 120000 --lr 0.00025 --image_size 368 496 "
+        "--wdecay 0.0001 --gpus 0 1 --batch_size 8 --val_freq 10000 --print_freq 100 --mixed_precision --craft --f2 full --setrans",
+        "--name craft-sintel --stage sintel --validation sintel --output results/sintel/craft-f2full --restore_ckpt results/things/craft-f2full/craft-things.pth "
+        "--num_steps 120000 --lr 0.000125 --image_size 368 768 --wdecay 0.00001 --gamma 0.85 --batch_size 6 --val_freq 10000 --print_freq 100 --mixed_precision "
+        "--craft --f2 full --setrans",
+        "--name gma-kitti --stage kitti --validation kitti --output results/kitti/gma --restore_ckpt results/sintel/gma/gma-sintel.pth --num_steps 50000 "
+        "--lr 0.000125 --image_size 288 960 --wdecay 0.00001 --gamma 0.85 --gpus 0 1 --batch_size 6 --val_freq 10000 --print_freq 100 --mixed_precision",
+    ]
+    ns = [parse(l.split()) for l in lines]
+    assert ns[0].stage == "chairs" and ns[0].image_size == [368, 496] and ns[0].craft and ns[0].use_setrans and ns[0].f2trans == "full" and ns[0].mixed_precision
+    assert ns[1].gamma == 0.85 and ns[1].restore_ckpt.endswith("craft-things.pth") and ns[1].lr == 0.000125
+    assert not ns[2].craft and not ns[2].use_setrans and ns[2].gpus == [0, 1]
+    # every model switch the parser produces is a field CRAFT(args) reads, with the reference's defaults (train.py:313-404)
+    d = parse(["--stage", "chairs"])
+    known = vars(default_args())
+    for k in ("f2trans", "f1trans", "inter_num_modes", "intra_num_modes", "f2_num_modes", "inter_qk_have_bias", "inter_pos_code_weight", "intra_pos_code_weight",
+              "f2_pos_code_weight", "f2_attn_mask_radius", "pos_bias_radius", "num_heads", "corr_radius", "dropout"):
+        assert k in known and k in vars(d)
+    assert (d.f2trans, d.lr, d.wdecay, d.batch_size, d.image_size, d.iters, d.clip, d.gamma) == ("full", 0.00002, 0.00005, 6, [384, 512], 12, 1.0, 0.8)
