@@ -120,3 +120,31 @@ def test_training_driver_runs_checkpoints_validates_and_resumes(device, tmp_path
                              "--mixed_precision"] + common)
     ck2 = read_checkpoint(path2)
     assert ck2["logger"]["total_steps"] == 6 and ck2["lr_scheduler"]["last_epoch"] == 6
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_training_driver_two_ranks(device, tmp_path, backend):
+    """The driver under torch.distributed.run: two ranks (gloo: sharing the box's GPU; nccl: one GPU each, skipped on a 1-GPU box), each on
+    its strided share of the epoch, one gradient all-reduce per step, rank 0 checkpoints and validates while rank 1 waits at the barrier."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    root, kroot = _trees(tmp_path)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["CRAFT_BENCH_BACKEND"] = backend
+    out = tmp_path / "ckpt2"
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "-m", "craft_amd.train_main", "--name", "dp", "--stage", "sintel", "--validation", "sintel", "--output", str(out), "--batch_size", "1",
+           "--image_size", "96", "128", "--iters", "2", "--num_steps", "3", "--val_freq", "2", "--print_freq", "1", "--craft", "--setrans",
+           "--sintel_root", root, "--kitti_root", kroot, "--workers", "2"]
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    assert (out / "dp.pth").exists() and (out / "2_dp.pth").exists()
+    assert "2 rank(s) x batch 1" in r.stdout and r.stdout.count("[train_main] step") == 2
