@@ -24,6 +24,9 @@ Extra objects on the line:
                 barrier / max-over-ranks protocol; 6 warm-up steps): ms_per_step, pairs_per_s and the roofline of the backward's dominant kernel
                 (the packed weight-gradient kernel k_gemm_pk, timed live), and `amp_fp16`: the same step under the reference's own
                 --mixed_precision arithmetic (fp16 operands + loss scaling; reported beside the fp32-class headline, not instead of it).
+  train_cfg4    the same short leg for configs[4] (368x768 crops, batch 4/GPU, frozen BatchNorm, bf16 MFMA attention).
+  corr_cfg2     BASELINE.json configs[2]: correlation build + radius-4 lookup at 768x1024, HIP-event timed, against the HBM peak
+                with SURVEY 8(d)'s bytes (rank 0 only; tools/bench_corr.py is the standalone form).
                 `python bench.py --train 3|4` is the full training benchmark (its own JSON line with roofline, amp_fp16 and the CPU
                 oracle's training step as cpu_baseline).
 """
@@ -194,6 +197,28 @@ def roofline_conv(B, H8, W8, prec, reps=20):
             "ms_per_launch": round(ms, 4),
             "note": "algorithmic (fp32-equivalent) flops; the f16x3 scheme executes 3 fp16 MFMAs per product, so the "
                     "matrix pipe runs at 3x this rate; peak = dense fp16 MFMA (fp32 MFMA for the fp32 policy)"}
+
+
+def corr_cfg2(reps=10):
+    """BASELINE.json configs[2] on the default line: the 768x1024 correlation build (fused scores + mode pooling + 4-level pyramid +
+    statistics) and the radius-4 lookup, timed with HIP events on the launch stream (tools/bench_corr.py).  frac = SURVEY 8(d) bytes
+    (the pyramid written once + Q / K read once) / time / 8 TB/s; traffic = FETCH_SIZE x2 + WRITE_SIZE of the build kernel from this
+    round's committed PMC passes (profiles/r4/pmc_corr_build.json; null when absent or taken at another shape)."""
+    from tools.bench_corr import measure
+    r = measure(768, 1024, 1, reps, "mixed")
+    b, lk = r["corr_build"], r["corr_lookup"]
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r4", "pmc_corr_build.json")) as fh:
+            pmc = json.load(fh)
+        if pmc.get("shape") == [1, 96, 128]:
+            traffic = int(pmc["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError, TypeError):
+        pass
+    return {"workload": r["workload"], "build_ms": b["ms"], "lookup_ms": lk["ms"], "bytes": b["bytes"],
+            "achieved": b["achieved_GBs"], "peak": 8000.0, "unit": "GB/s", "frac": b["frac_of_hbm_peak"], "traffic": traffic,
+            "lookup_achieved": lk["achieved_GBs"], "lookup_frac": lk["frac_of_hbm_peak"], "tflops_algorithmic": b["tflops_algorithmic"],
+            "bound": "hbm", "kernel": "k_corr_build4t (+ k_split_planes, statistics fill); k_corr_lookup"}
 
 
 def cpu_baseline(H, W, iters, threads):
@@ -469,12 +494,14 @@ def main():
     assert torch.isfinite(last["out"][1]).all()
 
     # the short training leg of the default line (every rank runs it: a training step contains the gradient all-reduce)
-    tl = None
+    tl = tl4 = None
     if not a.no_train_leg:
         del last["out"]
         torch.cuda.empty_cache()
         tl = train_leg(3, rank, world, dev, steps=5, warmup=6, iters=12)      # (6 warm-up steps: the caching allocator's pool settles after ~5)
         tl["amp"] = amp_leg(3, rank, world, dev, 12)
+        torch.cuda.empty_cache()
+        tl4 = train_leg(4, rank, world, dev, steps=5, warmup=6, iters=12, roofline=False)
 
     if rank == 0:
         line = {
@@ -494,6 +521,8 @@ def main():
         line["roofline_conv"] = roofline_conv(a.batch, a.height // 8, a.width // 8, prec)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.height, a.width, a.iters, a.cpu_threads)
+        if not a.no_train_leg:          # (the same switch keeps a quick run quick)
+            line["corr_cfg2"] = corr_cfg2()
         if tl is not None:
             line["train_cfg3"] = {
                 "workload": tl["name"] + ", 12 iters, whole training steps (forward + backward + gradient all-reduce + clip + AdamW), "
@@ -501,6 +530,11 @@ def main():
                 "ms_per_step": round(1e3 * tl["dt"] / tl["steps"], 3), "pairs_per_s": round(tl["value"], 3), "steps": tl["steps"],
                 "warmup": tl["warmup"], "n_gpus": world, "loss": round(tl["loss"], 4), "allreduce_ms_per_step": tl["allreduce_ms"],
                 "roofline": tl.get("roofline"), "amp_fp16": tl.get("amp")}
+        if tl4 is not None:
+            line["train_cfg4"] = {
+                "workload": tl4["name"] + ", 12 iters, whole training steps, model.train(): dropout on, frozen BatchNorm; policy " + tl4["policy"],
+                "ms_per_step": round(1e3 * tl4["dt"] / tl4["steps"], 3), "pairs_per_s": round(tl4["value"], 3), "steps": tl4["steps"],
+                "warmup": tl4["warmup"], "n_gpus": world, "loss": round(tl4["loss"], 4), "allreduce_ms_per_step": tl4["allreduce_ms"]}
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()

@@ -39,6 +39,15 @@ def test_single_gpu_line(device):
     rw = t3["roofline"]
     assert rw["bound"] == "mfma" and rw["unit"] == "TFLOP/s" and abs(rw["frac"] - rw["achieved"] / rw["peak"]) < 1e-3
     assert abs(rw["achieved"] - rw["flops_per_launch"] / (rw["ms_per_launch"] * 1e-3) / 1e12) / rw["achieved"] < 0.02
+    # configs[4] (training, 368x768 batch 4) and configs[2] (correlation stress at 768x1024) ride on the same line
+    t4 = d["train_cfg4"]
+    assert t4["ms_per_step"] > 0 and t4["pairs_per_s"] > 0 and t4["steps"] == 5 and "368x768" in t4["workload"] and t4["loss"] == t4["loss"]
+    c2 = d["corr_cfg2"]
+    assert c2["build_ms"] > 0 and c2["lookup_ms"] > 0 and "768x1024" in c2["workload"] and c2["bound"] == "hbm"
+    # SURVEY 8(d) bytes: the 4-level pyramid of a 96x128 key image per query, written once, + Q and K read once
+    n = 96 * 128
+    assert c2["bytes"] == 4 * n * (96 * 128 + 48 * 64 + 24 * 32 + 12 * 16) + 2 * n * 256 * 4
+    assert abs(c2["frac"] - c2["bytes"] / (c2["build_ms"] * 1e-3) / 8e12) < 2e-3
 
 
 def test_training_line(device):

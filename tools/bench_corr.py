@@ -34,14 +34,9 @@ def timed(fn, reps):
     return s.elapsed_time(e) / reps
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--height", type=int, default=768)
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--precision", default="mixed")
-    a = ap.parse_args()
+def measure(height=768, width=1024, batch=1, reps=10, precision="mixed"):
+    """-> the configs[2] record (dict); bench.py's `corr_cfg2` leg calls this in-process."""
+    a = argparse.Namespace(height=height, width=width, batch=batch, reps=reps, precision=precision)
     prec = Precision.parse(a.precision)
     dev = torch.device("cuda")
     B, H8, W8 = a.batch, a.height // 8, a.width // 8
@@ -78,7 +73,18 @@ def main():
                         "frac_of_hbm_peak": round(bytes_look / ms_look / 1e6 / HBM_PEAK_GBS, 4)},
         "precision": repr(prec), "hbm_peak_GBs": HBM_PEAK_GBS,
     }
-    print(json.dumps(line))
+    return line
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--height", type=int, default=768)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--precision", default="mixed")
+    a = ap.parse_args()
+    print(json.dumps(measure(a.height, a.width, a.batch, a.reps, a.precision)))
 
 
 if __name__ == "__main__":
