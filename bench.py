@@ -260,6 +260,10 @@ TRAIN_CFG = {3: (368, 496, 8, "mixed", "configs[3]: FlyingChairs-size 368x496, b
              4: (368, 768, 4, "train_bf16attn", "configs[4]: Sintel-crop 368x768, batch 4/GPU, bf16 MFMA attention")}
 
 
+# first-step loss of the training legs by (cfg, H, W, B, iters) -- measured on the MI355X, recomputed by tests/test_bench_contract.py
+FIRST_LOSS = {}
+
+
 def roofline_wgrad(step, policy, steps=2):
     """The dominant kernel family of the backward pass, the convolution weight gradients (per tap a cout x cin product over K = all
     pixels: k_gemm_pk on packed operands, craft_wgrad_pk; k_conv_wgrad in the fp32 policy), timed LIVE: HIP events around every launch
@@ -373,12 +377,22 @@ def train_leg(cfg, rank, world, dev, steps, warmup, iters, B=None, H=None, W=Non
 
     def step():
         last["m"] = tr.step(im1, im2, flow, valid)
+        last.setdefault("first", last["m"]["loss"])
 
     dt_rank = timed_steps(step, steps=steps, warmup=warmup, sync=torch.cuda.synchronize)
     value, dt = aggregate_throughput(pairs_per_rank_step=B, steps=steps, dt=dt_rank)
     assert last["m"]["loss"] == last["m"]["loss"]
+    # the first step's loss (synthetic weights seed 1234, pairs seed 100, the counter-based dropout of a fresh process) is a constant of
+    # the workload: tests/test_bench_contract.py::test_bench_training_workload_is_the_pinned_one recomputes it, and holds the same batch
+    # with dropout off to the CPU oracle's loss -- a leg that trains something else (other weights, shape, iterations) fails here
+    pinned = FIRST_LOSS.get((cfg, H, W, B, iters)) if rank == 0 and not torch_encoders else None
+    if pinned is not None and warmup + steps > 0:
+        assert abs(last["first"] - pinned) < 5e-3 * pinned, f"configs[{cfg}] first-step loss {last['first']:.5f}, pinned {pinned:.5f}"
+    if last["m"].get("skipped_steps"):
+        print(f"[bench] configs[{cfg}] {policy}: {last['m']['skipped_steps']} step(s) skipped on gradient overflow (loss scale now "
+              f"{last['m']['loss_scale']:g})", file=sys.stderr)
     out = {"H": H, "W": W, "B": B, "policy": policy, "name": name, "value": value, "dt": dt, "steps": steps, "warmup": warmup,
-           "loss": last["m"]["loss"], "numel": tr.optimizer.numel, "freeze_bn": cfg != 3,
+           "loss": last["m"]["loss"], "first_loss": last.get("first"), "skipped_steps": last["m"].get("skipped_steps", 0), "numel": tr.optimizer.numel, "freeze_bn": cfg != 3,
            "allreduce_ms": tr.allreduce_ms(), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)}
     if roofline:
         out["roofline"] = roofline_wgrad(step, policy)      # every rank runs the extra steps (they contain the collective)
@@ -427,7 +441,8 @@ def train_bench(a, rank, world, dev, dist):
                                           + ("BatchNorm batch statistics" if a.train == 3 else "frozen BatchNorm")
                                           + ", synthetic weights and pairs", "global_batch": B * world,
                        "parallelism": f"dp{world} (one all-reduce of the {r['numel'] * 4 / 1e6:.1f} MB flat gradient per step)"},
-            "loss": round(r["loss"], 4), "peak_mem_GB": r["peak_mem_GB"], "allreduce_ms_per_step": r["allreduce_ms"],
+            "loss": round(r["loss"], 4), "first_loss": round(r["first_loss"], 4), "skipped_steps": r["skipped_steps"],
+            "peak_mem_GB": r["peak_mem_GB"], "allreduce_ms_per_step": r["allreduce_ms"],
             "roofline": r.get("roofline"), "amp_fp16": amp}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_train(H, W, a.iters, a.cpu_threads, r["freeze_bn"])
@@ -528,13 +543,15 @@ def main():
                 "workload": tl["name"] + ", 12 iters, whole training steps (forward + backward + gradient all-reduce + clip + AdamW), "
                             "model.train(): dropout on, BatchNorm batch statistics; policy " + tl["policy"],
                 "ms_per_step": round(1e3 * tl["dt"] / tl["steps"], 3), "pairs_per_s": round(tl["value"], 3), "steps": tl["steps"],
-                "warmup": tl["warmup"], "n_gpus": world, "loss": round(tl["loss"], 4), "allreduce_ms_per_step": tl["allreduce_ms"],
+                "warmup": tl["warmup"], "n_gpus": world, "loss": round(tl["loss"], 4), "first_loss": round(tl["first_loss"], 4),
+                "skipped_steps": tl["skipped_steps"], "allreduce_ms_per_step": tl["allreduce_ms"],
                 "roofline": tl.get("roofline"), "amp_fp16": tl.get("amp")}
         if tl4 is not None:
             line["train_cfg4"] = {
                 "workload": tl4["name"] + ", 12 iters, whole training steps, model.train(): dropout on, frozen BatchNorm; policy " + tl4["policy"],
                 "ms_per_step": round(1e3 * tl4["dt"] / tl4["steps"], 3), "pairs_per_s": round(tl4["value"], 3), "steps": tl4["steps"],
-                "warmup": tl4["warmup"], "n_gpus": world, "loss": round(tl4["loss"], 4), "allreduce_ms_per_step": tl4["allreduce_ms"]}
+                "warmup": tl4["warmup"], "n_gpus": world, "loss": round(tl4["loss"], 4), "first_loss": round(tl4["first_loss"], 4),
+                "skipped_steps": tl4["skipped_steps"], "allreduce_ms_per_step": tl4["allreduce_ms"]}
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()

@@ -287,6 +287,19 @@ class ScoreLink:
         self.want, self.prec, self.dS = False, 0, None
 
 
+# data pointers of probability-gradient buffers that a backward of THIS module just allocated for AttnSoftmax.backward (AttnApply /
+# ProbsToken): only those may be overwritten in place with dS -- a gradient that arrives from anywhere else (a caller-held tensor, a
+# sum the engine formed) is copied first
+_FRESH_DP = set()
+
+
+def _fresh_dp(t):
+    if len(_FRESH_DP) > 64:          # (left-overs of pruned graphs)
+        _FRESH_DP.clear()
+    _FRESH_DP.add(t.data_ptr())
+    return t
+
+
 class AttnSoftmax(Function):
     """P = softmax_j(clamp?(S) + pos_w pb + mask) in place on S (setrans.py:520-551); with drop_p > 0 the dropout of the probabilities
     (setrans.py:553-557) in the same two kernels: the forward returns the dropped copy (P itself stays in S for the backward), the
@@ -317,8 +330,13 @@ class AttnSoftmax(Function):
     def backward(ctx, dP):
         P, bits, clamp_ord = ctx.saved_tensors
         B, M, N, ld = P.shape
-        # dS over the incoming gradient: it is the fresh output of the one consumer of P (AttnApply / ProbsToken), nothing else holds it
-        dS = dP if dP.is_contiguous() else dP.contiguous()
+        # dS over the incoming gradient when it is the fresh output of the one consumer of P (AttnApply / ProbsToken: nothing else
+        # holds it, 1 GB saved at configs[3]); any other gradient tensor is copied
+        if dP.is_contiguous() and dP.data_ptr() in _FRESH_DP:
+            _FRESH_DP.discard(dP.data_ptr())
+            dS = dP
+        else:
+            dS = dP.clone(memory_format=torch.contiguous_format)
         T = 2 * ctx.R + 1
         rep = hip.zeros((STATS_REPLICAS, T * T,), P.device) if ctx.has_tab else None
         dspk = PkMat(B * M, N, ld, ctx.link.prec, P.device) if ctx.link is not None else None
@@ -398,7 +416,7 @@ class AttnApply(Function):
                 dv = torch.empty(B, N, M * C, device=dO.device, dtype=torch.float32)
                 gemm_pk(pk, pk.desc(PK_ROWS, M, 1), dopk, dopk.desc(PK_ROWS, M, 1), dv, M * C, N * M * C, C, M, B * M, N, C, N)
             ctx.pk = ctx.vpk = None
-            return dP, dv, None, None
+            return (_fresh_dp(dP) if dP is not None else None), dv, None, None
         P, v = ctx.saved_tensors
         B, M, N, ld = P.shape
         C = v.shape[-1] // M
@@ -412,7 +430,7 @@ class AttnApply(Function):
             dv = torch.empty(B, N, M * C, device=P.device, dtype=torch.float32)
             # dV_m = P_m^T . dO_m : A(m = j, k = i) = P[i][j] k-major, B(n = c, k = i) = dO[i][c] k-major
             gemm(P, 1, ld, M * N * ld, N * ld, dO, 1, C, M * N * C, N * C, dv, M * C, N * M * C, C, M, B * M, N, C, N, prec=ctx.prec)
-        return dP, dv, None, None
+        return (_fresh_dp(dP) if dP is not None else None), dv, None, None
 
 
 class SharedProbs:
@@ -453,7 +471,7 @@ class ProbsToken(Function):
             K = dO.ncg * 32
             gemm_pk(dO, dO.desc(PK_CH, M, 1), V, V.desc(PK_CH, 1, 0, 0, 0, K // 32), dP, ld, M * N * ld, N * ld, M, B * M, N, N, K)
             holder.cat = holder.pk = None
-            return dP, None, None, None
+            return _fresh_dp(dP), None, None, None
         dP = torch.zeros(B, M, N, ld, device=P.device, dtype=torch.float32) if ld != N else torch.empty_like(P)
         if holder.cat is not None:
             dO, V = holder.cat
@@ -470,7 +488,7 @@ class ProbsToken(Function):
             holder.pending = []
         elif ld == N:
             dP.zero_()
-        return dP, None, None, None
+        return _fresh_dp(dP), None, None, None
 
 
 class AttnApplyShared(Function):

@@ -419,6 +419,16 @@ int craft_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
                       max_norm, S(stream));
 }
 
+int craft_loss_scale_update(const double* grad_sumsq, void* state, float grad_mul, float max_norm, float beta1, float beta2, float growth,
+                            float backoff, int growth_interval, void* stream) {
+  return launch_scaler_update(grad_sumsq, state, grad_mul, max_norm, beta1, beta2, growth, backoff, growth_interval, S(stream));
+}
+
+int craft_adamw_step_dyn(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, const void* state, void* stream) {
+  return launch_adamw_dyn(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, state, S(stream));
+}
+
 int craft_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, void* stream) {
   return launch_convex_upsample(mask, flow, B, H8, W8, up, S(stream));
 }

@@ -814,10 +814,10 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float gm = grad_mul;
-  if (sumsq != nullptr && max_norm > 0.f) {        // clip_grad_norm_: the norm is that of the (already averaged) gradient
+  if (sumsq != nullptr) {                          // clip_grad_norm_: the norm is that of the (already averaged) gradient
     const float norm = (float)sqrt(*sumsq) * grad_mul;
-    if (!(norm < 3.0e38f)) return;                  // non-finite gradient (an overflow under a loss scale): skip the update, as GradScaler.step
-    gm *= fminf(1.f, max_norm / (norm + 1e-6f));
+    if (!(norm < 3.0e38f)) return;                  // non-finite gradient: skip the update whether or not clipping is on (GradScaler.step)
+    if (max_norm > 0.f) gm *= fminf(1.f, max_norm / (norm + 1e-6f));
   }
   const float gi = g[i] * gm;
   float pi = p[i] * (1.f - lr * wd);
@@ -835,6 +835,68 @@ int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr,
   const float bc1 = 1.f - powf(beta1, (float)step), bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(k_adamw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1,
                      bc2_sqrt, grad_mul, sumsq, max_norm);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dynamic loss scaling on the device (train.py:215, 231-238: torch.cuda.amp.GradScaler -- scale halves on an overflow, the optimizer
+// step is skipped and its step count does not advance, the scale doubles after `growth_interval` clean steps).  The whole decision
+// lives in one 32-byte state record so that no host read-back sits on the step: k_scaler_update (one thread) turns the gradient's
+// sum of squares into {found_inf, the final gradient multiplier (un-scale x 1/world x clip coefficient), AdamW's bias corrections for
+// the count of APPLIED steps} and updates {scale, growth tracker, applied / skipped counters}; k_adamw_dyn reads the record.
+// ---------------------------------------------------------------------------------------------
+struct ScalerState { float scale; int growth_tracker; int opt_step; int skipped; int found_inf; float gm; float bc1; float bc2_sqrt; };
+static_assert(sizeof(ScalerState) == 32, "ScalerState is the 8-word record of include/craft_hip.h");
+
+__global__ void k_scaler_update(const double* __restrict__ sumsq, ScalerState* __restrict__ st, float grad_mul, float max_norm, float beta1,
+                                float beta2, float growth, float backoff, int growth_interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  ScalerState s = *st;
+  const double ss = *sumsq;
+  const float inv = grad_mul / s.scale;                        // the flat gradient holds scale x (sum over ranks of) the gradient
+  const float norm = (float)sqrt(ss) * inv;
+  if (!(ss >= 0.0) || !(norm < 3.0e38f)) {                     // NaN or inf anywhere in the gradient
+    s.found_inf = 1; s.skipped += 1; s.gm = 0.f; s.growth_tracker = 0;
+    s.scale = fmaxf(s.scale * backoff, 9.5367431640625e-7f);   // (2^-20 floor: the scale never reaches 0)
+  } else {
+    s.found_inf = 0; s.opt_step += 1;
+    s.gm = inv * (max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f);
+    s.bc1 = 1.f - powf(beta1, (float)s.opt_step);
+    s.bc2_sqrt = sqrtf(1.f - powf(beta2, (float)s.opt_step));
+    s.growth_tracker += 1;
+    if (growth_interval > 0 && s.growth_tracker >= growth_interval) { s.scale = fminf(s.scale * growth, 1.8446744e19f); s.growth_tracker = 0; }
+  }
+  *st = s;
+}
+int launch_scaler_update(const double* sumsq, void* state, float grad_mul, float max_norm, float beta1, float beta2, float growth,
+                         float backoff, int growth_interval, hipStream_t s) {
+  if (sumsq == nullptr || state == nullptr || !(backoff > 0.f) || !(growth > 0.f)) return CRAFT_ERR_ARG;
+  hipLaunchKernelGGL(k_scaler_update, dim3(1), dim3(64), 0, s, sumsq, (ScalerState*)state, grad_mul, max_norm, beta1, beta2, growth, backoff,
+                     growth_interval);
+  return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_adamw_dyn(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps, float wd,
+                                                   const ScalerState* __restrict__ st) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (st->found_inf) return;                                   // skipped step: weights, moments and the step count stay
+  const float gi = g[i] * st->gm;
+  float pi = p[i] * (1.f - lr * wd);
+  const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+  const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / st->bc2_sqrt + eps;
+  p[i] = pi - (lr / st->bc1) * (mi / denom);
+}
+int launch_adamw_dyn(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
+                     const void* state, hipStream_t s) {
+  if (n <= 0) return 0;
+  if (state == nullptr) return CRAFT_ERR_ARG;
+  hipLaunchKernelGGL(k_adamw_dyn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, wd,
+                     (const ScalerState*)state);
   return (int)hipGetLastError();
 }
 

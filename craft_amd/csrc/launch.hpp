@@ -145,6 +145,10 @@ int launch_flow_l1(const float* pred, const float* gt, const float* valid, int B
 int launch_sumsq(const float* x, long n, double* out, hipStream_t s);
 int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
                  int step, float grad_mul, const double* sumsq, float max_norm, hipStream_t s);
+int launch_scaler_update(const double* sumsq, void* state, float grad_mul, float max_norm, float beta1, float beta2, float growth,
+                         float backoff, int growth_interval, hipStream_t s);
+int launch_adamw_dyn(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
+                     const void* state, hipStream_t s);
 int launch_forward_interpolate(const float* flow, int B, int H, int W, float* out, hipStream_t s);
 int launch_coords_init(const float* flow_init_nchw, int B, int H8, int W8, float* coords0, float* coords1, float* flow,
                        hipStream_t s);

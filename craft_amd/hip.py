@@ -63,6 +63,8 @@ _SIGS = {
     "craft_flow_l1_loss": [P, P, P, I, I, I, F, F, P, P, P],
     "craft_sumsq": [P, L, P, P],
     "craft_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, F, P, F, P],
+    "craft_loss_scale_update": [P, P, F, F, F, F, F, F, I, P],
+    "craft_adamw_step_dyn": [P, P, P, P, L, F, F, F, F, F, P, P],
     "craft_convex_upsample": [P, P, I, I, I, P, P],
     # ---- training
     "craft_gemm": [P, L, L, L, L, P, L, L, L, L, P, L, L, L, I, I, I, I, I, F, I, I, I, P],

@@ -140,8 +140,16 @@ class FlatAdamW:
             segs.append((start, self.numel))
         self.segments = segs                     # [begin, end) ranges of the flat buffers that the optimizer updates
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
-        self.step_count = 0
         self._sumsq = torch.zeros((), device=dev, dtype=torch.float64)
+        # GradScaler's state on the device (include/craft_hip.h, craft_loss_scale_update): 8 x 32-bit words
+        # {scale f32, growth_tracker, opt_step (APPLIED updates), skipped, found_inf, gm f32, bc1 f32, bc2_sqrt f32}
+        self._scaler = torch.zeros(8, device=dev, dtype=torch.int32)
+        self._scaler_f = self._scaler.view(torch.float32)
+        self._scaler_f[0] = 1.0
+        self.growth, self.backoff, self.growth_interval = 2.0, 0.5, 0          # interval 0: static scale (set_loss_scale)
+        self._host_steps = 0                 # step() calls (applied + skipped); the applied count lives on the device
+        self._snap = torch.zeros(8, dtype=torch.int32).pin_memory() if dev.type == "cuda" else torch.zeros(8, dtype=torch.int32)
+        self._snap_event = None
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -168,26 +176,70 @@ class FlatAdamW:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return
-        sc = torch.tensor([float(self.step_count)], dtype=torch.float64)
-        for t in (self.flat, self.exp_avg, self.exp_avg_sq, sc):
+        for t in (self.flat, self.exp_avg, self.exp_avg_sq, self._scaler):      # (the scaler record carries the applied-step count)
             _broadcast(t, src, group)
-        self.step_count = int(sc.item())
         from .hip import bump_weights_epoch
         bump_weights_epoch()
 
+    # ---- loss scaling (torch.cuda.amp.GradScaler, train.py:215, 231-238) -- all of it on the device, no host read-back on the step
+    def set_loss_scale(self, scale: float, dynamic: bool = False, growth: float = 2.0, backoff: float = 0.5, growth_interval: int = 2000):
+        """``scale``: what the caller multiplies the loss gradient by (``scale_seed()``).  dynamic: GradScaler's rule -- an overflow
+        halves it, ``growth_interval`` clean steps double it; static: the scale stays, an overflow still skips (and counts) the step."""
+        self._scaler_f[0] = float(scale)
+        self._scaler[1] = 0
+        self.growth, self.backoff = (float(growth), float(backoff)) if dynamic else (1.0, 1.0)
+        self.growth_interval = int(growth_interval) if dynamic else 0
+
+    def scale_seed(self) -> torch.Tensor:
+        """The current loss scale as a 0-dim device tensor: ``loss.backward(opt.scale_seed())``.  A copy made in stream order, so
+        the update kernel of the same step can change the record afterwards."""
+        return self._scaler_f[0].clone()
+
+    @property
+    def step_count(self) -> int:
+        """APPLIED updates (torch.optim.AdamW's state['step']): skipped steps do not count.  Reads the device record (one sync):
+        for checkpoints and tests, not for the step."""
+        return int(self._scaler[2].item())
+
+    @step_count.setter
+    def step_count(self, v: int):
+        self._scaler[2] = int(v)
+
+    def scaler_snapshot(self, wait: bool = False) -> Optional[Dict[str, float]]:
+        """{'loss_scale', 'applied_steps', 'skipped_steps', 'found_inf'} of the most recent step whose asynchronous read-back has
+        landed (None before the first).  wait=True blocks on the last step's copy."""
+        ev = self._snap_event
+        if ev is None:
+            return None
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return getattr(self, "_snap_last", None)
+        w = self._snap.clone()
+        self._snap_last = {"loss_scale": float(w.view(torch.float32)[0]), "applied_steps": int(w[2]), "skipped_steps": int(w[3]),
+                           "found_inf": int(w[4])}
+        return self._snap_last
+
     def step(self, lr: Optional[float] = None, max_norm: float = 0.0, grad_mul: float = 1.0):
-        """One update; ``max_norm`` > 0 applies clip_grad_norm_(params, max_norm) (train.py:234) without a host sync."""
+        """One update; ``max_norm`` > 0 applies clip_grad_norm_(params, max_norm) (train.py:234) without a host sync.  The flat
+        gradient is expected to hold (loss scale) x the gradient (``set_loss_scale`` / ``scale_seed``; scale 1 by default) -- the
+        un-scaling, the 1/world of a summed all-reduce (``grad_mul``) and the clip coefficient are one multiplier computed on the
+        device.  A non-finite gradient norm -- with or without clipping -- skips the update: weights, moments and the applied-step
+        count (bias correction) stay, the skip is counted, a dynamic scale backs off."""
         self._check_views()
-        self.step_count += 1
-        sumsq = None
-        if max_norm > 0:
-            self._sumsq.zero_()
-            call("craft_sumsq", self.flat_grad, self.numel, self._sumsq)
-            sumsq = self._sumsq
+        self._host_steps += 1
+        self._sumsq.zero_()
+        call("craft_sumsq", self.flat_grad, self.numel, self._sumsq)
+        call("craft_loss_scale_update", self._sumsq, self._scaler, float(grad_mul), float(max_norm), float(self.betas[0]), float(self.betas[1]),
+             float(self.growth), float(self.backoff), int(self.growth_interval))
         for a, b in self.segments:
-            call("craft_adamw_step", self.flat[a:b], self.flat_grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], b - a,
+            call("craft_adamw_step_dyn", self.flat[a:b], self.flat_grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], b - a,
                  float(self.lr if lr is None else lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                 float(self.weight_decay), self.step_count, float(grad_mul), sumsq, float(max_norm))
+                 float(self.weight_decay), self._scaler)
+        if self.flat.is_cuda:              # asynchronous read-back of the record (pinned buffer + event): metrics / logs, never the step
+            self._snap.copy_(self._scaler, non_blocking=True)
+            self._snap_event = torch.cuda.Event()
+            self._snap_event.record()
         # the kernel wrote through raw pointers: p._version / data_ptr() did not move, so tell the packed-weight caches
         from .hip import bump_weights_epoch
         bump_weights_epoch()
@@ -206,11 +258,12 @@ class FlatAdamW:
     # ---- torch.optim.AdamW-compatible state (the 'optimizer' entry of the reference's checkpoints, train.py:139)
     def state_dict(self) -> Dict:
         state = {}
+        applied = float(self.step_count)
         for i, (p, off) in enumerate(zip(self.params, self.offsets)):
             n = p.numel()
             if i in self.unused_index:          # torch.optim.AdamW keeps no state for a parameter without a gradient
                 continue
-            state[i] = {"step": torch.tensor(float(self.step_count)),
+            state[i] = {"step": torch.tensor(applied),
                         "exp_avg": self.exp_avg[off:off + n].view_as(p.data).clone(),
                         "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p.data).clone()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
@@ -297,9 +350,13 @@ class Trainer:
     averaging), plus a 2-double all-reduce for the logged loss / EPE.  ``reference_loss_scaling``: train_ddp.py:60,84-88
     back-propagates the all-reduced loss divided by the world size, so its gradients carry a second 1/world on top of DDP's
     average; True reproduces that, False (default) is the plain data-parallel mean.  ``loss_scale``: "auto"
-    (default: ``auto_loss_scale`` of the loss' element count), a number, or None / 1.0 (off) -- the counterpart of train.py's GradScaler:
-    the loss gradient is multiplied by it before the backward pass and the gradients are un-scaled inside the fused AdamW (clipping
-    sees the un-scaled norm; a non-finite scaled norm skips the update like GradScaler.step)."""
+    (default: DYNAMIC, GradScaler's rule -- start at ``auto_loss_scale`` of the loss' element count, halve on an overflow, double after
+    2 000 clean steps), a number (static), or None / 1.0 (off) -- the counterpart of train.py's GradScaler: the loss gradient is
+    multiplied by the scale before the backward pass and the gradients are un-scaled inside the fused AdamW (clipping sees the
+    un-scaled norm).  A non-finite gradient skips the update exactly like GradScaler.step: weights, moments and the optimizer's step
+    count stay (the LR schedule advances, as in train.py:236-237), the skip is counted (``metrics['skipped_steps']``) and a dynamic
+    scale backs off.  The scale, the counters and the decision live in a device record (FlatAdamW._scaler); the host reads them back
+    asynchronously for the metrics only."""
 
     def __init__(self, model: torch.nn.Module, lr: float = 4e-4, wdecay: float = 1e-4, epsilon: float = 1e-8, num_steps: int = 100000,
                  clip: float = 1.0, gamma: float = 0.8, iters: int = 12, add_noise: bool = False, freeze_bn: bool = False, group=None,
@@ -313,10 +370,19 @@ class Trainer:
         self.reference_loss_scaling = reference_loss_scaling
         self.total_steps = 0
         self._ar_events = []                # (start, end) HIP events around the gradient all-reduce of recent steps
+        self._scale_set = False             # "auto" needs the loss' element count: the scaler is armed on the first step
+        if loss_scale != "auto":
+            self.optimizer.set_loss_scale(float(loss_scale or 1.0), dynamic=False)
+            self._scale_set = True
         model.train()
         if freeze_bn:
             model.freeze_bn()
         self.sync_replicas()
+
+    @property
+    def last_loss_scale(self) -> float:
+        """The loss scale the last step's backward ran under (reads the device: tests / debugging)."""
+        return float(self._seed)
 
     def sync_replicas(self, src: int = 0):
         """Rank ``src``'s parameters, optimizer state and module buffers on every rank.  torch DDP broadcasts parameters and buffers
@@ -362,10 +428,11 @@ class Trainer:
         opt.zero_grad()
         preds = model(image1, image2, iters=self.iters)
         loss, metrics = seq_loss(preds, flow, valid, self.gamma)
-        ls = self.loss_scale
-        ls = auto_loss_scale(flow.numel()) if ls == "auto" else float(ls or 1.0)
-        self.last_loss_scale = ls
-        loss.backward(torch.full((), ls, device=loss.device, dtype=loss.dtype)) if ls != 1.0 else loss.backward()
+        if not self._scale_set:            # "auto": start from auto_loss_scale and let GradScaler's rule move it (train.py:215)
+            opt.set_loss_scale(auto_loss_scale(flow.numel()), dynamic=True)
+            self._scale_set = True
+        self._seed = opt.scale_seed()                                  # the scale is read on the device, in stream order
+        loss.backward(self._seed.to(loss.dtype))
         from .autograd import pending_uses
         if pending_uses(model.__dict__.get("_train_pass_cache")):
             raise RuntimeError("backward left accumulated weight gradients incomplete (a layer call was pruned from the graph)")
@@ -379,7 +446,7 @@ class Trainer:
             self._ar_events = (self._ar_events + [(ev0, ev1)])[-64:]
         if self.reference_loss_scaling:
             mul = mul / self._world()
-        mul = mul / ls                                                 # the flat gradient buffer holds loss_scale x the gradient
+        # (the flat gradient buffer holds loss_scale x the gradient: un-scaled on the device, craft_loss_scale_update)
         opt.step(lr=self.scheduler.get_last_lr()[0], max_norm=self.clip, grad_mul=mul)
         self.scheduler.step()
         self.total_steps += 1
@@ -391,6 +458,9 @@ class Trainer:
             gc.collect()
             gc.freeze()
         metrics = dict(metrics, loss=float(loss.detach()))
+        snap = opt.scaler_snapshot()       # (float(loss) above drained the stream: this is the step just taken)
+        if snap is not None:
+            metrics.update(loss_scale=snap["loss_scale"], skipped_steps=snap["skipped_steps"], applied_steps=snap["applied_steps"])
         if self._world() > 1:                                          # logged numbers: mean over ranks (train_ddp.py:84-94)
             import torch.distributed as dist
             backend = dist.get_backend(self.group)

@@ -17,6 +17,8 @@ from __future__ import annotations
 import argparse
 import os
 import time
+
+import numpy as np
 from typing import List, Optional
 
 import torch
@@ -76,7 +78,8 @@ def parse(argv=None) -> argparse.Namespace:
     ap.add_argument("--intrapos", dest="intra_pos_code_type", default="bias", choices=["lsinu", "bias"])
     ap.add_argument("--intraposw", dest="intra_pos_code_weight", type=float, default=1.0)
     # accepted for command-line compatibility: the reference's DataParallel device list (here: one process per GPU under
-    # torch.distributed.run) and its model-family switches that this package does not build
+    # torch.distributed.run) and --model_name; the model-family switches this package does not build (--nogma, --raft,
+    # --upsample-learn) are NOT accepted
     ap.add_argument("--gpus", type=int, nargs="+", default=None)
     ap.add_argument("--model_name", default="")
     ns = ap.parse_args(argv)
@@ -141,6 +144,12 @@ def main(argv=None) -> Optional[str]:
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(os.environ.get("CRAFT_BENCH_BACKEND", "nccl"), init_method="env://")
+    # from-scratch initial weights follow --seed (the reference seeds torch / numpy before it builds the model, train.py:407-408);
+    # the per-rank augmentation draws are re-seeded below
+    import random
+    torch.manual_seed(ns.seed)
+    np.random.seed(ns.seed)
+    random.seed(ns.seed)
     policy = ns.hip_precision or ("train_amp_fp16" if ns.mixed_precision else "mixed")
     known = vars(default_args())
     over = {k: v for k, v in vars(ns).items() if k in known}

@@ -62,13 +62,15 @@ class UpdatePass:
         # so no device synchronisation behind the re-packing
         from . import update as _U
         _sync, _U.PACK_SYNC[0] = _U.PACK_SYNC[0], False
-        self.w_enc = ub.encoder.packed(self.cp)
-        # gate convolutions over [h | mf | mfg] (the inp channels 128..255 of the 512-channel input are hoisted): (zr1, q1, zr2, q2)
-        self.w_gru, _ = gru.packed_split(self.cp, 128, 256)
-        self.fields = gru.context_tokens(self.inp, hw, prec)        # [B, N, 768]: inp's share + bias of zr1 | q1 | zr2 | q2
-        self.w_fh = ub.flow_head.packed(self.cp)
-        self.w_mask = ub.packed_mask(self.cp)
-        _U.PACK_SYNC[0] = _sync
+        try:
+            self.w_enc = ub.encoder.packed(self.cp)
+            # gate convolutions over [h | mf | mfg] (the inp channels 128..255 of the 512-channel input are hoisted): (zr1, q1, zr2, q2)
+            self.w_gru, _ = gru.packed_split(self.cp, 128, 256)
+            self.fields = gru.context_tokens(self.inp, hw, prec)        # [B, N, 768]: inp's share + bias of zr1 | q1 | zr2 | q2
+            self.w_fh = ub.flow_head.packed(self.cp)
+            self.w_mask = ub.packed_mask(self.cp)
+        finally:                   # (an OOM / unsupported shape in here must not leave the inference path's re-packs unsynchronised)
+            _U.PACK_SYNC[0] = _sync
         # input-gradient operands of the gate convolutions (flipped / transposed, one launch each): the varying channels [h | mf | mfg]
         # per iteration, the hoisted inp channels once per pass
         VAR, INP_ = ((0, 128), (256, 512)), ((128, 256), (0, 0))
@@ -371,6 +373,11 @@ def _phase2(ps: UpdatePass):
     ppk = ps.pholder.pk
     docat = AG.PkMat(B * M, N, T * Cv, ppk.prec, dev) if ppk is not None else None       # rows (b, m, i), channels (t, c)
     dob = AG.PackBatch()
+    missing = [t for t in range(T) if ps.dv[t] is None or ps.saved[t] is None]
+    if missing:
+        raise RuntimeError(f"the fused update block's backward needs every refinement iteration in the graph; iteration(s) {missing} of {T} "
+                           "received no gradient (a loss over a prefix / subset of the predictions?) -- use every prediction, or "
+                           "run fewer iterations")
     for t in range(T):
         S, dv = ps.saved[t], ps.dv[t]
         mf = ps.HX[t][..., MF:MF + 128]

@@ -295,13 +295,27 @@ int craft_flow_metrics(const float* pred, const float* gt, const float* valid, i
  * craft_sumsq: *out += sum x^2 (double): the global gradient norm of clip_grad_norm_ (train.py:234).
  * craft_adamw_step: torch.optim.AdamW semantics (decoupled decay, bias correction with `step` >= 1) over flat buffers:
  *   g = grad * grad_mul (e.g. 1/world_size after a summed all-reduce), then if grad_sumsq != NULL and max_norm > 0:
- *   g *= min(1, max_norm / (sqrt(*grad_sumsq) * grad_mul + 1e-6)) -- the clip coefficient, computed on the device. */
+ *   g *= min(1, max_norm / (sqrt(*grad_sumsq) * grad_mul + 1e-6)) -- the clip coefficient, computed on the device.  With grad_sumsq
+ *   given, a non-finite norm skips the update (whether or not max_norm > 0).
+ * craft_loss_scale_update + craft_adamw_step_dyn: torch.cuda.amp.GradScaler (train.py:215, 231-238) without a host read-back.
+ *   `state` is a 32-byte device record, 8 x 32-bit words:
+ *     {float scale; int growth_tracker; int opt_step; int skipped; int found_inf; float gm; float bc1; float bc2_sqrt}
+ *   (the caller initialises scale and opt_step, zeroes the rest).  The flat gradient holds scale x (sum over ranks) the gradient and
+ *   *grad_sumsq its sum of squares.  craft_loss_scale_update: non-finite -> found_inf = 1, skipped += 1, scale *= backoff, tracker = 0;
+ *   finite -> found_inf = 0, opt_step += 1, gm = grad_mul / scale * min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: no clipping),
+ *   bc1 / bc2_sqrt = AdamW's bias corrections for opt_step, tracker += 1 and scale *= growth when tracker reaches growth_interval
+ *   (growth_interval <= 0: static scale).  craft_adamw_step_dyn: craft_adamw_step reading {found_inf, gm, bc1, bc2_sqrt} from the
+ *   record -- a skipped step leaves weights, moments and the optimizer's step count untouched, as GradScaler.step does. */
 int craft_flow_l1_loss(const float* pred, const float* gt, const float* valid, int B, int H, int W, float weight, float max_flow,
                        double* loss, float* grad_pred, void* stream);
 int craft_sumsq(const float* x, long n, double* out, void* stream);
 int craft_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int step, float grad_mul, const double* grad_sumsq,
                      float max_norm, void* stream);
+int craft_loss_scale_update(const double* grad_sumsq, void* state, float grad_mul, float max_norm, float beta1, float beta2, float growth,
+                            float backoff, int growth_interval, void* stream);
+int craft_adamw_step_dyn(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, const void* state, void* stream);
 
 /* ==== training: backward of the hot path (train.py:228-236 `loss.backward()` through network.py:164-267) =================
  * The reference gets its backward from autograd over PyTorch ops; here every operator's gradient is a kernel, bound as the

@@ -85,6 +85,21 @@ def test_two_rank_training_launch_path(device, backend):
     assert d["allreduce_ms_per_step"] is not None and d["allreduce_ms_per_step"] > 0
 
 
+def test_four_rank_training_launch_path_gloo(device):
+    """`bench.py --train 3 --gpus 4` at a miniature shape, four ranks sharing the box's GPU over gloo: the launch path, port selection,
+    rank-0-only extras (roofline, amp leg, no cpu_baseline) and the barriers beyond two ranks, before the driver's SCALE run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["CRAFT_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "bench.py", "--train", "3", "--gpus", "4", "--steps", "3", "--warmup", "1", "--batch", "1",
+                        "--height", "128", "--width", "160", "--iters", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 4 and d["config"]["global_batch"] == 4 and d["value"] > 0 and "cpu_baseline" not in d
+    assert d["allreduce_ms_per_step"] is not None and d["allreduce_ms_per_step"] > 0 and d["skipped_steps"] == 0
+    assert abs(d["value"] - 4 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 0.02
+    assert d["amp_fp16"]["pairs_per_s"] > 0 and d["roofline"]["launches_timed"] > 0
+
+
 def test_two_rank_inference_nccl(device):
     """The inference launch path under RCCL with one rank per GPU (skipped on a 1-GPU box)."""
     if "nccl" not in _backends():
@@ -132,3 +147,47 @@ def test_gpus_flag_refuses_missing_devices(device):
     r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "visible" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("cfg", [3, 4])
+def test_bench_training_workload_is_the_pinned_one(device, cfg):
+    """bench.py's training legs assert their first-step loss against bench.FIRST_LOSS (`loss == loss` said nothing
+    about WHAT was trained).  Here: (a) the constant exists for the default workload and a fresh `bench.py --train cfg` run satisfies
+    its own assertion and prints that loss; (b) the same weights and pairs with dropout off: the HIP training forward's loss equals
+    the CPU oracle's (batch 8 with BatchNorm batch statistics at configs[3] -- the largest oracle-checked training batch)."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from craft_amd import CRAFT, autograd as AG, default_args
+    from craft_amd.synth import synth_pair, synth_state_dict
+    from oracle import craft_oracle as O
+    H, W, B, policy, _ = bench.TRAIN_CFG[cfg]
+    pinned = bench.FIRST_LOSS[(cfg, H, W, B, 12)]
+    r = subprocess.run([sys.executable, "bench.py", "--train", str(cfg), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--precision",
+                        policy], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert abs(d["first_loss"] - pinned) < 5e-3 * pinned and d["skipped_steps"] == 0
+    # (b) dropout off: HIP vs oracle on bench's weights (seed 1234) and pairs (seed 100)
+    model = CRAFT(default_args(hip_precision=policy, dropout_prob=0.0, hip_loss_scaled=True))
+    sd0 = synth_state_dict(model.state_dict(), seed=1234)
+    model.load_state_dict(sd0, strict=True)
+    model = model.to(device).train()
+    if cfg != 3:
+        model.freeze_bn()
+    im1, im2, flow = synth_pair(B, H, W, seed=100)
+    valid = torch.ones(B, H, W)
+    preds = model(im1.to(device), im2.to(device), iters=12)
+    loss, _ = AG.sequence_loss(preds, flow, valid, 0.8)
+    sd = {k: v.clone() for k, v in sd0.items()}
+    sd["corr_fn.setrans.key.weight"], sd["corr_fn.setrans.key.bias"] = sd["corr_fn.setrans.query.weight"], sd["corr_fn.setrans.query.bias"]
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        preds_r, _ = O.craft_train_forward(sd, O.OracleConfig(), im1, im2, iters=12, freeze_bn=cfg != 3)
+        loss_r, _ = O.sequence_loss(preds_r, flow, valid, 0.8)
+    tol = 1e-4 if policy == "mixed" else 3e-4          # (configs[4] runs bf16 attention operands)
+    assert float(loss.detach()) == pytest.approx(float(loss_r), rel=tol)
+    worst = max((a.detach().cpu() - b).abs().max().item() for a, b in zip(preds, preds_r))
+    print(f"[bench workload] configs[{cfg}] B={B} {H}x{W} T=12 {policy}: dropout-off loss {float(loss.detach()):.6f} vs oracle {float(loss_r):.6f}; "
+          f"max prediction error {worst:.2e} px; pinned first-step loss (dropout on) {pinned}")
+    assert worst < (1e-2 if policy == "mixed" else 0.1)

@@ -59,3 +59,60 @@ def test_shard_batch_is_a_partition():
         parts = [shard_batch(n, r, w) for r in range(w)]
         assert sorted(sum(parts, [])) == list(range(n))
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+WORKER8 = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    from craft_amd.dist import shard_batch, timed_steps, aggregate_throughput
+    from craft_amd.train import FlatAdamW
+    dist.init_process_group("gloo", init_method="env://")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    assert world == 8
+    # timing protocol at the driver's largest N: rank 5 is the slow one
+    def step():
+        time.sleep(0.06 if rank == 5 else 0.01)
+    dt = timed_steps(step, steps=2, warmup=1, sync=lambda: None)
+    value, dt_max = aggregate_throughput(pairs_per_rank_step=4, steps=2, dt=dt)
+    # the training exchange: ONE all-reduce of the flat gradient; 8 different per-rank gradients -> their mean after the 1/world factor
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 2))
+    opt = FlatAdamW(net.parameters())
+    g = torch.Generator().manual_seed(100 + rank)
+    mine = torch.randn(opt.numel, generator=g)
+    opt.flat_grad.copy_(mine)
+    mul = opt.allreduce_grads()
+    want = sum(torch.randn(opt.numel, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)) / world
+    assert mul == 1.0 / world
+    assert torch.allclose(opt.flat_grad * mul, want, rtol=1e-6, atol=1e-6)
+    # replica broadcast (Trainer.sync_replicas): rank 3's weights everywhere
+    opt.flat.fill_(float(rank))
+    opt.step_count = rank
+    opt.broadcast_state(src=3)
+    assert float(opt.flat.min()) == float(opt.flat.max()) == 3.0 and opt.step_count == 3
+    if rank == 0:
+        print(json.dumps({"value": value, "dt_max": dt_max}))
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_eight_rank_timing_allreduce_and_broadcast(tmp_path):
+    """The driver's N = 8 launch on CPU (gloo): barrier / max-over-ranks timing, whole-job pairs / slowest rank's time, the flat
+    gradient all-reduce as a mean over 8 different gradients, the replica broadcast from a non-zero source rank."""
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER8 % ROOT)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["dt_max"] >= 0.12                          # 2 steps of the slow rank
+    assert abs(out["value"] - 8 * 4 * 2 / out["dt_max"]) < 1e-6

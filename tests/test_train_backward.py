@@ -474,7 +474,10 @@ def test_train_mode_rejects_other_configs_and_sizes(device):
                                                           (2, 368, 496, 12, False, "train_f16x3"),
                                                           # ... and in the library's default policy, which bench.py's configs[3] lines time:
                                                           # fp16 operands for the attention products (under the loss scale), f16x3 elsewhere
-                                                          (2, 368, 496, 12, False, "mixed")])
+                                                          (2, 368, 496, 12, False, "mixed"),
+                                                          # ... and the reference's own --mixed_precision arithmetic, which every bench
+                                                          # line prints as `amp_fp16`: fp16 operands in every contraction
+                                                          (2, 368, 496, 12, False, "train_amp_fp16")])
 def test_training_step_at_configs3_size_against_oracle(device, B, H, W, iters, freeze_bn, policy):
     """BASELINE configs[3] shape (368x496 -> 46x62 tokens, odd pooling sizes 23 / 11 / 5; batch 2 with BatchNorm batch statistics,
     2 iterations) and configs[4] shape (368x768 -> 46x96 tokens, frozen BatchNorm), fp32 policy: loss and every parameter gradient
@@ -505,12 +508,13 @@ def test_training_step_at_configs3_size_against_oracle(device, B, H, W, iters, f
     preds_r, _ = O.craft_train_forward(sd, O.OracleConfig(), im1, im2, iters=iters, freeze_bn=freeze_bn)
     loss_r, _ = O.sequence_loss(preds_r, flow, valid, 0.8)
     loss_r.backward()
-    assert float(loss) == pytest.approx(float(loss_r), rel=3e-5)
-    for a, b in zip(preds, preds_r):
-        assert (a.detach().cpu() - b.detach()).abs().max().item() < (5e-3 if policy == "mixed" else 2e-3)       # px (measured 2.4e-3 / 3.5e-4)
+    amp = policy == "train_amp_fp16"
+    assert float(loss) == pytest.approx(float(loss_r), rel=AMP_FP16_LOSS_REL if amp else 3e-5)
+    pred_err = max((a.detach().cpu() - b.detach()).abs().max().item() for a, b in zip(preds, preds_r))
+    assert pred_err < (AMP_FP16_PRED_PX if amp else 5e-3 if policy == "mixed" else 2e-3)       # px (measured 2.4e-3 / 3.5e-4)
     rms_all = sorted(float(sd[k].grad.pow(2).mean().sqrt()) for k in names if sd[k].grad is not None)
     scale = rms_all[len(rms_all) // 2]
-    worst, checked = 0.0, 0
+    worst, worst_k, checked = 0.0, None, 0
     seen = set()
     for k, p in model.named_parameters():
         if id(p) in seen or sd[k].grad is None or k.startswith("corr_fn.setrans.key."):
@@ -521,10 +525,22 @@ def test_training_step_at_configs3_size_against_oracle(device, B, H, W, iters, f
             assert float(p.grad.pow(2).mean().sqrt()) < 1e-3 * scale, k
             continue
         l2 = ((p.grad.cpu() - ref).norm() / ref.norm()).item()
-        assert l2 < 1e-2, f"{k}: relative L2 error {l2:.2e}"
-        worst, checked = max(worst, l2), checked + 1
+        if amp and p.numel() == 1:
+            continue                      # (one number: its "L2" is its own relative error; the fp32-class policies above do check them)
+        if l2 > worst:
+            worst, worst_k = l2, k
+        checked += 1
+        assert l2 < (AMP_FP16_L2_BOUND if amp else 1e-2), f"{k}: relative L2 error {l2:.2e}"
     assert checked > 100
-    print(f"[train parity] {H}x{W} B={B} T={iters} {policy}: loss {float(loss):.6f} vs oracle {float(loss_r):.6f}; worst relative L2 gradient error {worst:.2e} over {checked} parameters")
+    print(f"[train parity] {H}x{W} B={B} T={iters} {policy}: loss {float(loss):.6f} vs oracle {float(loss_r):.6f}; max prediction error {pred_err:.2e} px; "
+          f"worst relative L2 gradient error {worst:.2e} ({worst_k}) over {checked} parameters")
+
+
+# train_amp_fp16 at the benchmarked shape and depth (368x496, T = 12) against the oracle's autograd: bounds = 2x the figures measured on
+# the MI355X (the test prints them)
+AMP_FP16_LOSS_REL = 2e-3
+AMP_FP16_PRED_PX = 0.2
+AMP_FP16_L2_BOUND = 0.3
 
 
 def test_bf16attn_step_at_configs4_shape_against_fp32_step(device):
@@ -568,4 +584,4 @@ def test_bf16attn_step_at_configs4_shape_against_fp32_step(device):
     assert n > 100 and worst <= BF16ATTN_L2_BOUND
 
 
-BF16ATTN_L2_BOUND = 0.3      # 2x the measured worst case goes here once measured on the box (see the test's print)
+BF16ATTN_L2_BOUND = 0.1      # 2x the worst case measured on the MI355X (0.05; the test prints the figure)

@@ -98,3 +98,62 @@ def test_checkpoint_save_resume(device, tmp_path):
     opt2.flat_grad.fill_(1.0)
     opt2.step()
     assert not torch.equal(w0, m2.update_block.flow_head.conv2.weight.detach())
+
+
+@pytest.mark.parametrize("max_norm", [0.0, 1.0])
+def test_dynamic_loss_scale_skips_backs_off_and_recovers(device, max_norm):
+    """torch.cuda.amp.GradScaler's contract (train.py:215, 231-238) on the device record: a non-finite gradient -- with or without
+    clipping -- skips the update (weights, moments, the optimizer's step count stay), is counted, halves the scale; clean steps apply
+    with the bias correction of the APPLIED count and double the scale after `growth_interval` of them."""
+    def make():
+        torch.manual_seed(5)
+        return torch.nn.Sequential(torch.nn.Linear(7, 9), torch.nn.Tanh(), torch.nn.Linear(9, 3)).to(device)
+    a, b = make(), make()
+    ref = torch.optim.AdamW(a.parameters(), lr=3e-3, weight_decay=1e-2, eps=1e-8)
+    ours = T.FlatAdamW(b.parameters(), lr=3e-3, weight_decay=1e-2, eps=1e-8)
+    ours.set_loss_scale(1024.0, dynamic=True, growth_interval=3)
+    x = torch.randn(16, 7, device=device)
+
+    def grads(poison):
+        ref.zero_grad(); ours.zero_grad()
+        (a(x) ** 2).sum().backward()
+        (b(x) ** 2).sum().backward(ours.scale_seed())               # scaled backward, the seed read on the device
+        if poison:
+            ours.flat_grad[5] = float("inf")
+
+    def close():
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert torch.allclose(pa, pb, rtol=2e-5, atol=2e-7)
+
+    grads(False)
+    if max_norm > 0:
+        torch.nn.utils.clip_grad_norm_(a.parameters(), max_norm)
+    ref.step(); ours.step(max_norm=max_norm)
+    close()
+    s = ours.scaler_snapshot(wait=True)
+    assert s == {"loss_scale": 1024.0, "applied_steps": 1, "skipped_steps": 0, "found_inf": 0}
+    # overflow: nothing moves, the skip is counted, the scale halves, AdamW's step stays at 1
+    before = [t.clone() for t in (ours.flat, ours.exp_avg, ours.exp_avg_sq)]
+    grads(True)
+    ours.step(max_norm=max_norm)
+    for t0, t1 in zip(before, (ours.flat, ours.exp_avg, ours.exp_avg_sq)):
+        assert torch.equal(t0, t1)
+    s = ours.scaler_snapshot(wait=True)
+    assert s == {"loss_scale": 512.0, "applied_steps": 1, "skipped_steps": 1, "found_inf": 1}
+    assert float(ours.state_dict()["state"][0]["step"]) == 1.0 and ours.step_count == 1
+    # three clean steps under the halved scale: applied like torch's steps 2..4 (bias correction did not drift), then the scale doubles
+    for k in range(3):
+        assert float(ours.scale_seed()) == 512.0
+        grads(False)
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(a.parameters(), max_norm)
+        ref.step(); ours.step(max_norm=max_norm)
+        close()
+    s = ours.scaler_snapshot(wait=True)
+    assert s == {"loss_scale": 1024.0, "applied_steps": 4, "skipped_steps": 1, "found_inf": 0}
+    assert float(ours.state_dict()["state"][0]["step"]) == float(ref.state_dict()["state"][0]["step"]) == 4.0
+    # a NaN is an overflow too
+    grads(False)
+    ours.flat_grad[0] = float("nan")
+    ours.step(max_norm=max_norm)
+    assert ours.scaler_snapshot(wait=True)["skipped_steps"] == 2 and ours.step_count == 4

@@ -61,6 +61,28 @@ def test_steps_move_weights_and_inference_sees_them(device):
     assert (a - up_before).abs().max().item() > 1e-3, "training did not change the prediction"
 
 
+def test_trainer_overflow_is_skipped_counted_and_recovered(device):
+    """Trainer(loss_scale="auto") = GradScaler (train.py:215, 231-238): an overflowing backward skips the update, shows up in the
+    metrics, halves the scale, leaves the optimizer's step count alone; the next step applies."""
+    model = _model(device)
+    tr = Trainer(model, lr=2e-4, num_steps=50, iters=2, clip=1.0, freeze_bn=True)
+    im1, im2, flow, valid = _batch(2, 128, 160, 4)
+    m = tr.step(im1, im2, flow, valid)
+    assert m["skipped_steps"] == 0 and m["applied_steps"] == 1 and m["loss_scale"] == tr.last_loss_scale > 1.0
+    good = m["loss_scale"]
+    w = {k: v.clone() for k, v in model.state_dict().items()}
+    tr.optimizer._scaler_f[0] = 2.0 ** 126          # the scaled loss gradient (~1e-5 x 2^126) overflows fp32 within the backward
+    m = tr.step(im1, im2, flow, valid)
+    assert m["skipped_steps"] == 1 and m["applied_steps"] == 1 and m["loss_scale"] == 2.0 ** 125 and m["loss"] == m["loss"]
+    assert all(torch.equal(v, w[k]) for k, v in model.state_dict().items() if v.dtype.is_floating_point), "a skipped step moved weights"
+    assert float(tr.optimizer.state_dict()["state"][0]["step"]) == 1.0
+    assert tr.scheduler.last_epoch == 2             # the LR schedule advances on a skipped step, as scheduler.step() does in train.py:236
+    tr.optimizer._scaler_f[0] = good
+    m = tr.step(im1, im2, flow, valid)
+    assert m["skipped_steps"] == 1 and m["applied_steps"] == 2 and m["loss_scale"] == good
+    assert any(not torch.equal(v, w[k]) for k, v in model.state_dict().items() if v.dtype.is_floating_point)
+
+
 def test_unused_parameters_are_skipped_like_torch_adamw(device):
     model = _model(device)
     un = unused_parameters(model)
