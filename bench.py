@@ -261,7 +261,7 @@ TRAIN_CFG = {3: (368, 496, 8, "mixed", "configs[3]: FlyingChairs-size 368x496, b
 
 
 # first-step loss of the training legs by (cfg, H, W, B, iters) -- measured on the MI355X, recomputed by tests/test_bench_contract.py
-FIRST_LOSS = {}
+FIRST_LOSS = {(3, 368, 496, 8, 12): 191.4161, (4, 368, 768, 4, 12): 76.7455}
 
 
 def roofline_wgrad(step, policy, steps=2):
