@@ -1003,6 +1003,20 @@ class GruOut(Function):
         return dqp, dz, dh
 
 
+class ZeroGradEdge(Function):
+    """y = x (same storage), plus an autograd edge to ``params`` that carries an exactly-zero gradient (train_forward.
+    _touch_cancelling_biases)."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        ctx.shapes = [(p.shape, p.dtype) for p in params]
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return (dy,) + tuple(hip.zeros(tuple(sh), dy.device, dt) for sh, dt in ctx.shapes)
+
+
 class ConvexUpsample(Function):
     """CRAFT.upsample_flow (network.py:151-162): mask tokens [B,N,576], flow tokens [B,N,2] -> [B,2,8*H8,8*W8]."""
 

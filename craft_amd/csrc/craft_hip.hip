@@ -143,6 +143,14 @@ int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, 
   return launch_attn_probs(sp, P, ldp, p_prec, prec, S(stream));
 }
 
+int craft_attn_probs_fused(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d, float scale,
+                           const float* pos_tab, int R, float pos_w, int mask_radius, const unsigned* clamp_ord, void* P, long ldp,
+                           float* rowsum, void* ws, int p_prec, int prec, void* stream) {
+  ScoreParams sp = make_score(q, ldq, k, ldk, B, H8, W8, M, d, scale, pos_tab, R, pos_w, mask_radius, clamp_ord);
+  sp.rowsum = rowsum;
+  return launch_attn_probs_fused(sp, P, ldp, ws, p_prec, prec, S(stream));
+}
+
 int craft_flash_attention(const float* q, long ldq, const float* k, long ldk, const void* vT, long ldt, int B, int H8, int W8,
                           int M, int d, int Dv, float scale, const float* pos_tab, int R, float pos_w, int mask_radius,
                           const unsigned* clamp_ord, float* O, void* ws, int score_prec, int pv_prec, void* stream) {

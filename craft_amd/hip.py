@@ -42,6 +42,7 @@ _SIGS = {
     "craft_corr_lookup": [P, P, P, P, I, P, P, I, I, I, I, P, L, I, I, P],
     "craft_attn_probs": [P, L, P, L, I, I, I, I, I, F, P, I, F, I, P, P, P, F, P, L, P, I, I, P],
     "craft_attn_apply": [P, L, P, P, I, I, I, I, P, I, P],
+    "craft_attn_probs_fused": [P, L, P, L, I, I, I, I, I, F, P, I, F, I, P, P, L, P, P, I, I, P],
     "craft_flash_attention": [P, L, P, L, P, L, I, I, I, I, I, I, F, P, I, F, I, P, P, P, I, I, P],
     "craft_forward_interpolate": [P, I, I, I, P, P],
     "craft_mode_pool_ln": [P, P, L, P, P, I, I, I, I, P, L, P],

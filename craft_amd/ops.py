@@ -223,6 +223,16 @@ def attn_probs(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale
     if out is None:
         out = torch.empty(B, M, N, ldp, device=q.device, dtype=PROB_DTYPE[pick(prec, "pv")])
     R = 0 if pos_tab is None else (pos_tab.shape[0] - 1) // 2
+    pvp, sp = pick(prec, "pv"), pick(prec, "score")
+    if (defer and relpos is None and C // M == 32 and sp in (hip.PREC_F16, hip.PREC_F16X3) and pvp in (hip.PREC_F16, hip.PREC_BF16)
+            and N < 65536 and not os.environ.get("CRAFT_NO_FUSED_PROBS")):
+        # one launch of independent waves (craft_attn_probs_fused): maxima + P' + row sums, keys pre-split in fragment order
+        rowsum = torch.empty(B, M, N, device=q.device, dtype=torch.float32)
+        ws = torch.empty(B * M * ((N + 63) // 64) * 8192, device=q.device, dtype=torch.uint8)
+        call("craft_attn_probs_fused", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale,
+             None if pos_tab is None else pos_tab.contiguous(), R, pos_w, mask_radius, clamp_ord, out, ldp, rowsum, ws, pvp, sp)
+        out.craft_rowsum = rowsum
+        return out
     # row sums | scratch: row maxima, per-key-chunk partial sums (CRAFT_ATTN_CHUNK_KEYS = 1024)
     rowsum = torch.empty(2 + (N + 1023) // 1024, B, M, N, device=q.device, dtype=torch.float32) if defer else None
     rph, rpw, rpwt = (None, None, 0.0) if relpos is None else (relpos[0].contiguous(), relpos[1].contiguous(), float(relpos[2]))

@@ -86,6 +86,25 @@ def _conv(x, conv, hw, act, prec, cache):
     return AG.Conv.apply(x, conv.weight, conv.bias, hw, act, prec, cache)
 
 
+def _touch_cancelling_biases(model, preds):
+    """The bias of a softmax-over-modes score (``*.feat2score.bias``, setrans.py:448-458, 495-498) cancels in the softmax: the kernels
+    never read it, its gradient is mathematically zero -- and torch autograd hands the reference's optimizer exactly that, a zero
+    TENSOR (weight decay still applies), not None.  Tie those parameters to the last prediction with a zero-gradient edge so that any
+    optimizer wrapped around this class (torch.optim.AdamW under GradScaler / DDP, tests/test_reference_wrappers.py) treats them like
+    the reference does.  (The intra-frame attention's pooling never runs at all -- the reference leaves its gradients None too:
+    ``train.unused_parameters``.)"""
+    ps = model.__dict__.get("_cancelling_biases")
+    if ps is None:
+        from .train import unused_parameters
+        skip = {id(p) for p in unused_parameters(model)}
+        ps = model.__dict__["_cancelling_biases"] = [p for n, p in model.named_parameters() if n.endswith("feat2score.bias") and id(p) not in skip]
+    live = [p for p in ps if p.requires_grad]
+    if live:
+        preds = list(preds)
+        preds[-1] = AG.ZeroGradEdge.apply(preds[-1], *live)
+    return preds
+
+
 def forward_train(model, image1, image2, iters=12, flow_init=None):
     args = model.args
     # the reference's four shipped training scripts: --craft --f2 full --setrans (train-craft-f2full.sh), --craft --f2 full with GMA's
@@ -241,7 +260,7 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
         for t in range(iters):       # (the correlation lookup of network.py:235 is part of the node: coords1 carries no gradient, :232)
             net, up, coords1 = TU.UpdateIter.apply(net, token, ptoken, inp, ups, t, coords1, coords0, *params)
             preds.append(up)
-        return preds
+        return _touch_cancelling_biases(model, preds)
     ub = model.update_block
     enc, gru, fh, agg = ub.encoder, ub.gru, ub.flow_head, ub.aggregator
     coords0, coords1, _ = ops.coords_init(flow_init, B, H8, W8, dev)
@@ -288,4 +307,4 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
         mask = AG.Act.apply(AG.Linear.apply(mh, wm2, ub.mask[2].bias, prec.conv, wcache), ACT_NONE, 0.25)
         coords1 = coords1 + delta                                               # network.py:247
         preds.append(AG.ConvexUpsample.apply(mask, coords1 - coords0, hw))      # :258
-    return preds
+    return _touch_cancelling_biases(model, preds)

@@ -228,6 +228,44 @@ def test_attn_probs(device, prec, C, M, mask_radius, gain):
     assert float(Pd[..., N:].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("H8,W8", [(13, 19), (16, 64), (24, 128), (9, 70), (5, 32)])
+@pytest.mark.parametrize("mask_radius,gain", [(-1, 2.5), (5, 2.5), (-1, 80.0)])
+@pytest.mark.parametrize("score", ["f16x3", "fp16"])
+def test_attn_probs_fused_single_launch(device, monkeypatch, H8, W8, mask_radius, gain, score):
+    """craft_attn_probs_fused (one launch of independent waves: exact row maxima, then P' + row sums; keys pre-split in MFMA fragment
+    order) against the oracle's softmax (setrans.py:507-557) and against the two-launch path it replaces: ragged N, rows that straddle
+    64-key tiles (W8 = 19 / 70), tiles inside one row (W8 = 64 / 128), Chebyshev mask, the clamp-active case (gain 80)."""
+    B, C, M = 2, 128, 4
+    N = H8 * W8
+    x, _, Wq, Wk, _ = _qk(B, H8, W8, C, seed=52, gain=gain)
+    tab = gen(15, 15, seed=53) * 0.5
+    ref = O.self_attn_probs(x, Wq, Wk, tab, 1.0, M, H8, W8, mask_radius)
+    q = ops.linear(x.to(device), Wq.to(device), None, PREC_F32)
+    k = ops.linear(x.to(device), Wk.to(device), None, PREC_F32)
+    scale = 1.0 / math.sqrt(C // M)
+    sp = PREC_F16X3 if score == "f16x3" else PREC_F16
+    prec = hip.Precision(score=sp, pv=PREC_F16)
+    mx = ops.score_max(q, k, H8, W8, M, scale, prec)
+    calls = []
+    orig = ops.call
+    monkeypatch.setattr(ops, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+    Pd = ops.attn_probs(q, k, H8, W8, M, scale, tab.to(device), 1.0, mask_radius, mx, prec, defer=True)
+    assert calls == ["craft_attn_probs_fused"]
+    rs = Pd.craft_rowsum
+    assert Pd.dtype == torch.float16 and rs.shape == (B, M, N)
+    assert float(Pd.float().max()) <= 1.0 and float(Pd[..., :N].float().amax(-1).min()) == 1.0      # exact maxima: the largest entry is 2^0
+    assert float(Pd[..., N:].float().abs().max() if Pd.shape[-1] > N else 0.0) == 0.0, "padding columns must be zero"
+    got = Pd[..., :N].float() / rs[..., None]
+    assert (got.sum(-1) - 1).abs().max() < 2e-3
+    close(got, ref, 0.0, 2e-3 if score == "f16x3" else 0.02, "fused deferred probabilities vs oracle")
+    # the two-launch path on the same inputs
+    monkeypatch.setenv("CRAFT_NO_FUSED_PROBS", "1")
+    Po = ops.attn_probs(q, k, H8, W8, M, scale, tab.to(device), 1.0, mask_radius, mx, prec, defer=True)
+    assert calls[-1] == "craft_attn_probs"
+    close(Pd.float(), Po.float(), 2e-3, 1e-6, "fused vs two-launch P'")
+    close(rs, Po.craft_rowsum, 1e-4, 1e-6, "fused vs two-launch row sums")
+
+
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("C", [128, 256])
 def test_expanded_feat_trans(device, prec, C):

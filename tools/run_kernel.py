@@ -83,8 +83,18 @@ def main():
         q = torch.randn(B, N, C, device=dev)
         k = torch.randn(B, N, C, device=dev)
         tab = torch.randn(15, 15, device=dev)
-        for _ in range(2):
-            ops.attn_probs(q, k, H8, W8, Mm, 1 / math.sqrt(C // Mm), tab, 1.0, -1, None, prec, defer=which == "probs")
+        reps = int(os.environ.get("REPS", 2))
+        fn = lambda: ops.attn_probs(q, k, H8, W8, Mm, 1 / math.sqrt(C // Mm), tab, 1.0, -1, None, prec, defer=which == "probs")  # noqa: E731
+        out = fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        print(f"attn_probs ({which}, fused={not os.environ.get('CRAFT_NO_FUSED_PROBS')}): {s.elapsed_time(e) / reps:.3f} ms per call, "
+              f"{out.numel() * out.element_size() / 1e9:.3f} GB of P")
     elif which == "flash":
         import math
         C, Mm, Dvf = 256, 4, 256
