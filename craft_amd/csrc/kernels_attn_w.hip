@@ -9,10 +9,12 @@
 // pre-split ONCE into fp16 hi / lo planes in MFMA fragment order (one A operand = one contiguous 1 KiB: the "weights never touch LDS"
 // idiom of k_conv_halo_wf), so there is no operand staging, no block barrier, and occupancy is bounded by registers only.  Phase A walks
 // the keys for the exact row maxima (same three-term products as phase B, so P' <= 1 exactly), phase B walks them again, exponentiates and
-// writes P' through a wave-private LDS transpose as whole 128-byte row segments.  All waves of one (b, m) run on one XCD pair
+// writes P' through a wave-private LDS transpose as whole 256-byte row segments.  Both phases are software-pipelined over 32-key halves:
+// the epilogue of one half is issued between the MFMAs of the next (VALU only hides behind MFMAs of the same wave).  All waves of one (b, m) run on one XCD pair
 // (z = block % (B*M)): K of a (b, m) is 0.9 MB and stays in that XCD's L2.
 #include "gemm_engine.hpp"
 #include "launch.hpp"
+#include <type_traits>
 
 namespace craft {
 
@@ -46,12 +48,21 @@ __global__ __launch_bounds__(256) void k_pack_keys32(const float* __restrict__ K
   *reinterpret_cast<f16x8*>(dst + 2 * 512) = ll;
 }
 
+#ifndef CRAFT_AW_WAVES
+#define CRAFT_AW_WAVES 3      // waves per SIMD the register allocation is held to (tools/build_variant.py -DCRAFT_AW_WAVES=3 for A/B)
+#endif
+#ifndef CRAFT_AW_APPROX_MAX
+#define CRAFT_AW_APPROX_MAX 0  // developer A/B: 1 = phase A from the hi x hi products only (row maxima to ~1e-3 of |q||k|: P' <= 2^delta)
+#endif
+#ifndef CRAFT_AW_DBG
+#define CRAFT_AW_DBG 0        // developer ablation: 1 no global stores of P', 2 no phase A, 4 no LDS transpose, 8 plain instead of non-temporal stores
+#endif
 constexpr int AW_TABW = 33;
-constexpr int AW_PLD = 64 + 8;        // halves per staged row: 144 B (16-byte aligned rows)
+constexpr int AW_PLD = 128 + 8;       // halves per staged row: 272 B (16-byte aligned rows)
 
 // X3: f16x3 scores (hi*hi + hi*lo + lo*hi), else plain fp16 (hi planes only)
 template <bool X3, typename prob_t>
-__global__ __launch_bounds__(256, 4) void k_attn_probs_w(ScoreParams p, const _Float16* __restrict__ Kp, prob_t* __restrict__ P, long ldp,
+__global__ __launch_bounds__(256, CRAFT_AW_WAVES) void k_attn_probs_w(ScoreParams p, const _Float16* __restrict__ Kp, prob_t* __restrict__ P, long ldp,
                                                       int nt32, unsigned w8_magic) {
   __shared__ float s_tab[AW_TABW * AW_TABW];
   __shared__ __attribute__((aligned(16))) uint16_t Pst[4][32 * AW_PLD];
@@ -103,126 +114,155 @@ __global__ __launch_bounds__(256, 4) void k_attn_probs_w(ScoreParams p, const _F
     }
   }
 
-  const _Float16* kz = Kp + (long)z * nt32 * 2048 + lane * 8;        // a 32-key tile = 2 planes x 2 k-steps x 512 halves
-  const int nt = (N + 63) >> 6;                                      // 64-key tiles
-  constexpr int NA = X3 ? 8 : 4;                                     // A fragments per 64-key tile: [mt][plane][kk]
-  u32x4 fa[NA];                                                      // ONE operand set: tile t + 1 is requested right after tile t's MFMAs
-  auto fetch = [&](u32x4 (&f)[NA], int t) __attribute__((always_inline)) {
-    // (tiles beyond the packed range re-read the last one: its values are never used)
-    const int t0 = min(2 * t, nt32 - 1), t1 = min(2 * t + 1, nt32 - 1);
+  const _Float16* kz = Kp + (long)z * nt32 * 2048 + lane * 8;        // a 32-key half-tile = 2 planes x 2 k-steps x 512 halves
+  constexpr int NH = X3 ? 4 : 2;                                     // A fragments per 32-key half: [plane][kk]
+  constexpr int NM = X3 ? 6 : 2;                                     // MFMAs per half
+  // The unit of the software pipeline is a 32-key HALF tile (one 32x32 accumulator): while the matrix pipe works on the products of
+  // half h + 1, the same wave issues the epilogue of half h between those MFMAs (VALU work only hides behind MFMAs of its own wave,
+  // DESIGN 5).  Two accumulators and two operand sets alternate; the operands of half h + 2 are requested as soon as the MFMAs of half
+  // h have been issued.
+  auto fetch_half = [&](u32x4 (&f)[NH], int t32) __attribute__((always_inline)) {
+    const _Float16* base = kz + (long)min(t32, nt32 - 1) * 2048;     // (halves beyond the packed range re-read the last one: never used)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const _Float16* base = kz + (long)(mt ? t1 : t0) * 2048;
+    for (int pl = 0; pl < (X3 ? 2 : 1); ++pl)
 #pragma unroll
-      for (int pl = 0; pl < (X3 ? 2 : 1); ++pl)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-          f[(mt * (X3 ? 2 : 1) + pl) * 2 + kk] = *reinterpret_cast<const u32x4*>(base + (pl * 2 + kk) * 512);
-    }
+      for (int kk = 0; kk < 2; ++kk) f[pl * 2 + kk] = *reinterpret_cast<const u32x4*>(base + (pl * 2 + kk) * 512);
   };
-  // scores of one 64-key tile -> acc[mt][e]: key 32 mt + (e & 3) + 8 (e >> 2) + 4 g, this lane's query; base-2 logits incl. bias
-  auto products = [&](const u32x4 (&f)[NA], f32x16 (&acc)[2]) __attribute__((always_inline)) {
+  auto mma_half = [&](const u32x4 (&f)[NH], f32x16& acc, auto full_c) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const f16x8 ah = __builtin_bit_cast(f16x8, f[(mt * (X3 ? 2 : 1)) * 2 + kk]);
-        if constexpr (X3) {
-          const f16x8 al = __builtin_bit_cast(f16x8, f[(mt * 2 + 1) * 2 + kk]);
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[kk], acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[kk], acc[mt], 0, 0, 0);
-        }
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[kk], acc[mt], 0, 0, 0);
+    for (int kk = 0; kk < 2; ++kk) {
+      const f16x8 ah = __builtin_bit_cast(f16x8, f[kk]);
+      if constexpr (X3 && FULL) {
+        const f16x8 al = __builtin_bit_cast(f16x8, f[2 + kk]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[kk], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[kk], acc, 0, 0, 0);
       }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[kk], acc, 0, 0, 0);
     }
   };
-  // base-2 logits of one 64-key tile, element by element, handed to sink(mt, e, logit): key 32 mt + (e & 3) + 8 (e >> 2) + 4 g of this
-  // lane's query.  ONE wave-uniform branch per tile picks the path (bare / one-row table / generic); the accumulator tuples are only
-  // read (in-place edits of MFMA result tuples under control flow made hipcc copy them: 256 VGPRs).
-  auto logits = [&](int t, const f32x16 (&acc)[2], auto&& sink) __attribute__((always_inline)) {
-    const int j0 = t * 64;
+  // one pipeline stage: products of the NEXT half into accN, base-2 logits of half t32 from accC handed element by element to
+  // sink(e, logit) -- key 32 t32 + (e & 3) + 8 (e >> 2) + 4 g of this lane's query.  ONE wave-uniform branch per half picks the path
+  // (bare / one-row table / generic); the MFMAs are issued inside each path so that they share a basic block with the epilogue they
+  // hide, and the accumulator tuples are only read (in-place edits under control flow made hipcc copy them: 256 VGPRs).
+  auto stage = [&](const u32x4 (&fN)[NH], f32x16& accN, const f32x16& accC, int t32, auto vper_c, auto full_c, auto&& sink) __attribute__((always_inline)) {
+    constexpr int vper = decltype(vper_c)::value;
+    const int j0 = t32 * 32;
     const int kh0 = (int)__umulhi((unsigned)j0, w8_magic), kw0 = j0 - kh0 * W8;         // wave-uniform
-    const int jl = min(j0 + 63, N - 1);
-    const int k_hmax = (int)__umulhi((unsigned)jl, w8_magic);
+    const int k_hmax = (int)__umulhi((unsigned)min(j0 + 31, N - 1), w8_magic);
     const bool need_tab = clamp || mr > 0 || (p.pos_tab != nullptr && k_hmax >= q_hmin - R && kh0 <= q_hmax + R);
-    const bool ragged = j0 + 64 > N;
+    const bool ragged = j0 + 32 > N;
+    auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, vper, 0);
+      }
+    };
     if (!need_tab && !ragged) {
+      mma_half(fN, accN, full_c);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sink(mt, e, acc[mt][e]);
-    } else if (kw0 + 64 <= W8 && !ragged) {        // the tile lies in one image row: kh uniform, kw = kw0 + offset
+      for (int e = 0; e < 16; ++e) sink(e, accC[e]);
+      interleave();
+    } else if (kw0 + 32 <= W8 && !ragged) {        // the half lies in one image row: kh uniform, kw = kw0 + offset
+      mma_half(fN, accN, full_c);
       const unsigned u = min((unsigned)(kh0 + ch), umax);
       const float* trow = s_tab + u * TW;
       int vb = kw0 + cw;
-      asm volatile("" : "+v"(vb));                 // (opaque: otherwise LICM keeps 32 lane-dependent (cw + offset) values live across the loop)
+      asm volatile("" : "+v"(vb));                 // (opaque: otherwise LICM keeps 16 lane-dependent (cw + offset) values live across the loop)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const unsigned v = min((unsigned)(vb + mt * 32 + (e & 3) + 8 * (e >> 2)), umax);
-          sink(mt, e, __builtin_amdgcn_fmed3f(acc[mt][e], -clipv, clipv) + trow[v]);
-        }
+      for (int e = 0; e < 16; ++e) {
+        const unsigned v = min((unsigned)(vb + (e & 3) + 8 * (e >> 2)), umax);
+        sink(e, __builtin_amdgcn_fmed3f(accC[e], -clipv, clipv) + trow[v]);
+      }
+      interleave();
     } else {
+      mma_half(fN, accN, full_c);
       int jb = j0 + 4 * g, cwb = cw - 4 * g;
       asm volatile("" : "+v"(jb), "+v"(cwb));
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int j = jb + (mt * 32 + (e & 3) + 8 * (e >> 2));
-          const int kh = (int)__umulhi((unsigned)j, w8_magic), kw = j - kh * W8;
-          const unsigned u = min((unsigned)(kh + ch), umax), v = min((unsigned)(kw + cwb), umax);
-          const float sv = __builtin_amdgcn_fmed3f(acc[mt][e], -clipv, clipv) + s_tab[u * TW + v];
-          sink(mt, e, j < N ? sv : -INFINITY);
-          if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (rare path: keep its live ranges to one quad)
-        }
+      for (int e = 0; e < 16; ++e) {
+        const int j = jb + ((e & 3) + 8 * (e >> 2));
+        const int kh = (int)__umulhi((unsigned)j, w8_magic), kw = j - kh * W8;
+        const unsigned u = min((unsigned)(kh + ch), umax), v = min((unsigned)(kw + cwb), umax);
+        const float sv = __builtin_amdgcn_fmed3f(accC[e], -clipv, clipv) + s_tab[u * TW + v];
+        sink(e, j < N ? sv : -INFINITY);
+        if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);        // (rare path: live ranges of one quad, no interleaving)
+      }
     }
   };
+  u32x4 fa0[NH], fa1[NH];
+  f32x16 acc0, acc1;
 
-  // ---- phase A: exact row maxima
+  // ---- phase A: exact row maxima (nt32 is a multiple of 4)
   float m_run = -INFINITY;
-  fetch(fa, 0);
-  for (int t = 0; t < nt; ++t) {
-    f32x16 acc[2];
-    products(fa, acc);
+  constexpr std::integral_constant<bool, !CRAFT_AW_APPROX_MAX> FULL_A{};
+  auto sink_max = [&](int, float sv) __attribute__((always_inline)) { m_run = fmaxf(m_run, sv); };
+  fetch_half(fa0, 0);
+  fetch_half(fa1, 1);
+  mma_half(fa0, acc0, FULL_A);
+  __builtin_amdgcn_sched_barrier(0);
+  fetch_half(fa0, 2);
+  for (int t32 = 0; t32 < ((CRAFT_AW_DBG & 2) ? 2 : nt32); t32 += 2) {
+    stage(fa1, acc1, acc0, t32, std::integral_constant<int, 3>{}, FULL_A, sink_max);
     __builtin_amdgcn_sched_barrier(0);
-    fetch(fa, t + 1);                                  // (the MFMAs above have read their operands: in flight behind the epilogue)
+    fetch_half(fa1, t32 + 3);
     __builtin_amdgcn_sched_barrier(0);
-    logits(t, acc, [&](int, int, float sv) __attribute__((always_inline)) { m_run = fmaxf(m_run, sv); });
+    stage(fa0, acc0, acc1, t32 + 1, std::integral_constant<int, 3>{}, FULL_A, sink_max);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_half(fa0, t32 + 4);
+    __builtin_amdgcn_sched_barrier(0);
   }
   m_run = fmaxf(m_run, __shfl_xor(m_run, 32));       // the two half-waves hold disjoint keys of the same query
 
   // ---- phase B: P' = 2^(t - max) -> fp16 / bf16 through the wave's LDS tile, whole 128-byte row segments to HBM; row sums
   uint16_t* Tw = &Pst[wave][0];
-  const int srow = lane >> 3, sch = lane & 7;        // store mapping: 8 rows x 8 chunks of 16 bytes per instruction
-  prob_t* Pw = P + ((long)z * N + q0) * ldp + sch * 8;
   float l_run = 0.f;
-  fetch(fa, 0);
-  for (int t = 0; t < nt; ++t) {
-    f32x16 acc[2];
-    products(fa, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(fa, t + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    typedef prob_t pt4 __attribute__((ext_vector_type(4)));
-    pt4 h;
-    logits(t, acc, [&](int mt, int e, float sv) __attribute__((always_inline)) {
-      const float ex = __builtin_amdgcn_exp2f(sv - m_run);
-      h[e & 3] = (prob_t)ex;
-      l_run += ex;
-      if ((e & 3) == 3) *reinterpret_cast<pt4*>(&Tw[r * AW_PLD + mt * 32 + 8 * (e >> 2) + 4 * g]) = h;
-    });
-    const int j0 = t * 64;
+  typedef prob_t pt4 __attribute__((ext_vector_type(4)));
+  pt4 h;
+  int col0 = 4 * g;
+  auto sink_exp = [&](int e, float sv) __attribute__((always_inline)) {
+    const float ex = __builtin_amdgcn_exp2f(sv - m_run);
+    h[e & 3] = (prob_t)ex;
+    l_run += ex;
+    if ((e & 3) == 3 && (!(CRAFT_AW_DBG & 4) || ex == 123.f)) *reinterpret_cast<pt4*>(&Tw[r * AW_PLD + col0 + 8 * (e >> 2)]) = h;
+  };
+  fetch_half(fa0, 0);
+  fetch_half(fa1, 1);
+  mma_half(fa0, acc0, std::true_type{});
+  __builtin_amdgcn_sched_barrier(0);
+  fetch_half(fa0, 2);
+  const int srow = lane >> 4, sch = lane & 15;       // store mapping: 4 rows x 16 chunks of 16 bytes per instruction (256-byte row segments)
+  prob_t* Pw = P + ((long)z * N + q0) * ldp + sch * 8;
+  for (int t32 = 0; t32 < nt32; t32 += 4) {          // nt32 is a multiple of 4: one 128-key tile of P' per iteration
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp) {
+      col0 = 64 * hp + 4 * g;
+      stage(fa1, acc1, acc0, t32 + 2 * hp, std::integral_constant<int, 9>{}, std::true_type{}, sink_exp);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_half(fa1, t32 + 2 * hp + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      col0 = 64 * hp + 32 + 4 * g;
+      stage(fa0, acc0, acc1, t32 + 2 * hp + 1, std::integral_constant<int, 9>{}, std::true_type{}, sink_exp);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch_half(fa0, t32 + 2 * hp + 4);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int j0 = t32 * 32;
     const bool jok = j0 + sch * 8 < ldp;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = it * 8 + srow;
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + srow;
       const u32x4 v = *reinterpret_cast<const u32x4*>(&Tw[row * AW_PLD + sch * 8]);
-      if (jok && q0 + row < N) *reinterpret_cast<u32x4*>(Pw + (long)row * ldp + j0) = v;
+      if (jok && q0 + row < N && !(CRAFT_AW_DBG & 1)) {
+        // non-temporal: P' (1.6 GB at 448x1024, batch 4) is read back long after this kernel; measured 0.72 -> 0.625 ms
+        if (CRAFT_AW_DBG & 8) *reinterpret_cast<u32x4*>(Pw + (long)row * ldp + j0) = v;
+        else __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(Pw + (long)row * ldp + j0));
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
   const float l = l_run + __shfl_xor(l_run, 32);
   if (lane < 32 && qcol < N) p.rowsum[(long)z * N + qcol] = l;
@@ -235,7 +275,7 @@ int launch_attn_probs_fused(const ScoreParams& p, void* P, long ldp, void* ws, i
   if (p.N >= 65536 || p.N < 1) return CRAFT_ERR_UNSUPPORTED;                       // (umulhi division of key indices)
   if (ldp % 32 || ldp < p.N || (p.ldq & 3) || (p.ldk & 3) || (p.q_bs & 3) || (p.k_bs & 3)) return CRAFT_ERR_ALIGN;
   if (p.mask_radius > 15 || (p.pos_tab && p.R > 15)) return CRAFT_ERR_UNSUPPORTED;
-  const int nt32 = (p.N + 63) / 64 * 2, BM = p.B * p.M;
+  const int nt32 = (p.N + 127) / 128 * 4, BM = p.B * p.M;
   _Float16* Kp = reinterpret_cast<_Float16*>(ws);
   const long total = (long)BM * nt32 * 128;
   hipLaunchKernelGGL(k_pack_keys32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p.Kf, p.ldk, p.k_bs, p.N, p.M, nt32, Kp, total);

@@ -97,7 +97,7 @@ struct ScoreParams {
   int dbg;                            // developer ablation of k_corr_build4t's stores (CRAFT_CORR_DBG: 1 no level 0, 2 no levels 1-3), 0 in production
 };
 
-// deferred-normalisation probabilities as one launch of independent waves (kernels_attn_w.hip); ws: B*M*ceil(N/64)*8192 bytes
+// deferred-normalisation probabilities as one launch of independent waves (kernels_attn_w.hip); ws: B*M*ceil(N/128)*16384 bytes
 int launch_attn_probs_fused(const ScoreParams& p, void* P, long ldp, void* ws, int p_prec, int prec, hipStream_t s);
 
 // ---- flash-fused attention (kernels_flash.hip) ----

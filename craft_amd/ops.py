@@ -228,7 +228,7 @@ def attn_probs(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale
             and N < 65536 and not os.environ.get("CRAFT_NO_FUSED_PROBS")):
         # one launch of independent waves (craft_attn_probs_fused): maxima + P' + row sums, keys pre-split in fragment order
         rowsum = torch.empty(B, M, N, device=q.device, dtype=torch.float32)
-        ws = torch.empty(B * M * ((N + 63) // 64) * 8192, device=q.device, dtype=torch.uint8)
+        ws = torch.empty(B * M * ((N + 127) // 128) * 16384, device=q.device, dtype=torch.uint8)
         call("craft_attn_probs_fused", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale,
              None if pos_tab is None else pos_tab.contiguous(), R, pos_w, mask_radius, clamp_ord, out, ldp, rowsum, ws, pvp, sp)
         out.craft_rowsum = rowsum

@@ -131,9 +131,9 @@ int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, 
 /* The DEFERRED form of craft_attn_probs (rowsum != NULL) as ONE launch of independent waves (round 4; setrans.py:507-557 for the
  * intra-frame attention, network.py:214): P holds 2^(logit2 - rowmax) in (0, 1] (16-bit, p_prec = fp16 or bf16), rowsum [B][M][N] the
  * row sums -- the same contract as craft_attn_probs with rowsum, consumed by craft_attn_apply.  A wave owns 32 queries for the whole
- * key range: exact row maxima in a first sweep, exponentials + whole 128-byte row segments of P in a second; the keys are pre-split
+ * key range: exact row maxima in a first sweep, exponentials + whole 256-byte row segments of P in a second; the keys are pre-split
  * once into fp16 hi / lo planes in MFMA fragment order and stream from L2 straight into MFMA registers (no operand staging, no block
- * barrier).  ws: B*M*ceil(N/64)*8192 bytes of scratch (the packed keys).  Implemented for d = 32, prec = f16x3 or fp16, no
+ * barrier).  ws: B*M*ceil(N/128)*16384 bytes of scratch (the packed keys).  Implemented for d = 32, prec = f16x3 or fp16, no
  * relative-position scores, N < 65536; anything else returns CRAFT_ERR_UNSUPPORTED (10003) and the caller uses craft_attn_probs. */
 int craft_attn_probs_fused(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d, float scale,
                            const float* pos_tab, int R, float pos_w, int mask_radius, const unsigned* clamp_ord, void* P, long ldp,

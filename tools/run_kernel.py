@@ -25,6 +25,16 @@ def main():
         O = torch.empty(B, M, N, Dv, device=dev)
         for _ in range(5):
             ops.attn_apply(P, vT, Dv, pv, out=O)
+        reps = int(os.environ.get("REPS", 0))
+        if reps:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            s.record()
+            for _ in range(reps):
+                ops.attn_apply(P, vT, Dv, pv, out=O)
+            e.record()
+            torch.cuda.synchronize()
+            print(f"attn_apply (k_pv16): {s.elapsed_time(e) / reps * 1e3:.1f} us per launch")
     elif which in ("gru", "menc", "head"):
         from craft_amd import CRAFT, default_args
         from craft_amd.synth import synth_state_dict
