@@ -25,8 +25,6 @@ the forward convolution with flipped weights, weight gradients queued per layer 
 """
 from __future__ import annotations
 
-import os
-
 import torch
 from torch.autograd import Function
 
@@ -91,10 +89,6 @@ class UpdatePass:
         self.dv = [None] * iters
         self.zero1 = torch.zeros(1, device=dev, dtype=torch.float32)
         self.zero_tok = None
-        self.pack_pending = False
-        self.pack_stream = None
-        if os.environ.get("CRAFT_PACK_STREAM") and dev.type == "cuda":
-            self.pack_stream = _pack_stream(dev)
 
     # ---- gradient accumulators ------------------------------------------------------------------------------------
     def acc(self, key, shape):
@@ -113,45 +107,9 @@ class UpdatePass:
             self.ready.append((k, KH, KW, acc))
 
     def launch_ready(self):
-        if self.ready:
-            self.join_packs()
         for k, KH, KW, acc in self.ready:
             AG.wgrad_pk(self.cache.pop(k), KH, KW, acc)
         self.ready = []
-
-    # ---- operand packs beside the compute stream ---------------------------------------------------------------------
-    # A pack (fp32 tokens -> 16-bit planes) is a pure HBM pass whose result is needed much later: the forward's packs in the backward,
-    # the backward's dY packs when the LAST iteration's pair arrives (weight gradients are launched as segments).  They run on a side
-    # stream beside the MFMA-bound convolutions of the following iteration; ``join_packs`` makes the compute stream wait for them.
-    def flush(self, pb):
-        if self.pack_stream is None or not pb.descs:
-            pb.flush()
-            return
-        main = torch.cuda.current_stream()
-        side = self.pack_stream
-        side.wait_stream(main)
-        for keep in pb.keep:                       # sources / destinations were allocated on the compute stream
-            for t in keep:
-                if t is not None:
-                    t.record_stream(side)
-        with torch.cuda.stream(side):
-            pb.flush()
-        self.pack_pending = True
-
-    def join_packs(self):
-        if self.pack_pending:
-            torch.cuda.current_stream().wait_stream(self.pack_stream)
-            self.pack_pending = False
-
-
-_PACK_STREAMS = {}
-
-
-def _pack_stream(dev):
-    st = _PACK_STREAMS.get(dev.index)
-    if st is None:
-        st = _PACK_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
-    return st
 
 
 def _flow32(flow, B, N):
@@ -295,7 +253,7 @@ class UpdateIter(Function):
         S["fh1"], S["mh"], S["mask"], S["flow_new"] = fh1, mh, mask, flow_new
         S["pk_fh1"] = AG.Packed(fh1, cp, g3, batch=pb)
         S["pk_mh"] = AG.Packed(mh, cp, batch=pb)
-        ps.flush(pb)
+        pb.flush()
         ps.saved[t] = S
         ctx.ps, ctx.t = ps, t
         ctx.nparams = len(params)
@@ -378,7 +336,7 @@ class UpdateIter(Function):
         d_net = dh                                                                            # gradient of net_t
         ps.dv[t] = dv                                                                         # gradient of [mf | mfg]: phase 2
         ps.saved[t] = S
-        ps.flush(pb)
+        pb.flush()
         ps.launch_ready()
         d_inp = None
         if last:
@@ -499,7 +457,7 @@ def _phase2(ps: UpdatePass):
         # ---- correlation lookup (corr.py:47-71): the gradient goes into the shared buffers of the normalised pyramid; autograd.CorrVolume
         # (every iteration took its token) folds them into the volume's gradient after this node
         AG.lookup_bwd(ps.holders, d_corr, S["coords"], ps.radius)
-        ps.flush(pb)
+        pb.flush()
         ps.launch_ready()
         S.clear()
         ps.saved[t] = None
@@ -539,7 +497,6 @@ def update_params(model):
 
 def _param_grads(ps: UpdatePass):
     """The accumulated gradients in the layout of update_params (PyTorch's [Cout, Cin, KH, KW])."""
-    ps.join_packs()                                  # (the bias-gradient column sums ride on the pack launches)
     m = ps.model
     ub = m.update_block
     enc, gru, fh, agg = ub.encoder, ub.gru, ub.flow_head, ub.aggregator
