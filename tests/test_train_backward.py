@@ -538,9 +538,9 @@ def test_training_step_at_configs3_size_against_oracle(device, B, H, W, iters, f
 
 # train_amp_fp16 at the benchmarked shape and depth (368x496, T = 12) against the oracle's autograd: bounds = 2x the figures measured on
 # the MI355X (the test prints them)
-AMP_FP16_LOSS_REL = 2e-3
+AMP_FP16_LOSS_REL = 1e-3      # (measured 4.5e-4)
 AMP_FP16_PRED_PX = 0.5          # (measured 0.24 px: fp16 operands in all twelve refinement iterations)
-AMP_FP16_L2_BOUND = 0.3
+AMP_FP16_L2_BOUND = 0.22      # (measured worst 0.109: fnet.conv1.weight)
 
 
 def test_bf16attn_step_at_configs4_shape_against_fp32_step(device):
