@@ -10,6 +10,7 @@ lazily per in-bounds tap.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -79,8 +80,9 @@ class TransCorrBlock(CorrBlock, nn.Module):
         while len(self.pyramids) <= slot:
             self.pyramids.append(None)
         pyr = self.pyramids[slot]
-        if pyr is None or (pyr.B, pyr.H8, pyr.W8) != (B, H8, W8) or pyr.lv[0].device != q.device:
-            pyr = self.pyramids[slot] = ops.CorrPyramid(B, H8, W8, self.num_levels, q.device)
+        tiled = ops.fused_pyramid(q.shape[-1], st.num_modes, prec, self.num_levels, H8, W8) and not os.environ.get("CRAFT_NO_TILED_PYRAMID")
+        if pyr is None or (pyr.B, pyr.H8, pyr.W8, pyr.tiled) != (B, H8, W8, tiled) or pyr.lv[0].device != q.device:
+            pyr = self.pyramids[slot] = ops.CorrPyramid(B, H8, W8, self.num_levels, q.device, tiled=tiled)
         w_aggr = self._w_aggr(st) if st.num_modes > 1 else 1.0
         ops.corr_build(q, k, H8, W8, st.num_modes, scale, self.vispos_encoder.pos_coder.biases, float(st.pos_code_weight),
                        w_aggr, mx, pyr, self.do_corr_global_norm, prec)

@@ -113,7 +113,7 @@ int craft_corr_build_pyramid(const float* q, long ldq, const float* k, long ldk,
                              const float* pos_tab, int R, float pos_w, float w_aggr, const unsigned* clamp_ord, float* pyr0,
                              float* pyr1, float* pyr2, float* pyr3, double* sums, void* ws, int prec, void* stream) {
   return launch_corr_build_pyramid(make_score(q, ldq, k, ldk, B, H8, W8, M, d, scale, pos_tab, R, pos_w, -1, clamp_ord), w_aggr,
-                                   pyr0, pyr1, pyr2, pyr3, sums, ws, prec, S(stream));
+                                   pyr0, pyr1, pyr2, pyr3, sums, ws, prec & ~CRAFT_PYR_TILED, (prec & CRAFT_PYR_TILED) ? 1 : 0, S(stream));
 }
 
 int craft_corr_finish(const float* pyr0, float* pyr1, float* pyr2, float* pyr3, const double* sums, float* mu_rstd, int B,
@@ -126,8 +126,8 @@ int craft_corr_finish(const float* pyr0, float* pyr1, float* pyr2, float* pyr3, 
 int craft_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3, int levels,
                       const float* mu_rstd, const float* coords, int B, int H8, int W8, int radius, float* out, long ldo,
                       int lvl_stride, int col_off, void* stream) {
-  return launch_corr_lookup(pyr0, pyr1, pyr2, pyr3, levels, mu_rstd, coords, B, H8, W8, radius, out, ldo, lvl_stride, col_off,
-                            S(stream));
+  return launch_corr_lookup(pyr0, pyr1, pyr2, pyr3, levels & ~CRAFT_PYR_TILED, mu_rstd, coords, B, H8, W8, radius, out, ldo, lvl_stride,
+                            col_off, (levels & CRAFT_PYR_TILED) ? 1 : 0, S(stream));
 }
 
 int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d, float scale,

@@ -399,13 +399,16 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build4s(ScoreParams p, const 
 // (A first fused version kept keys across lanes and pooled with DPP / ds_bpermute: 0.95 ms against 0.75 ms unfused.)
 // Block = 4 waves: (wave >> 1) = one of two horizontally adjacent cells, (wave & 1) = one of two groups of 32 queries.
 // ---------------------------------------------------------------------------------------------
-template <bool CLAMP, bool BIAS, bool VEC>
+constexpr int CORR_STG = 128 + 4;      // floats per query in the level-0 staging tile (+ 16 B: conflict-free ds_write_b128)
+template <bool CLAMP, bool BIAS, bool VEC, bool TILED>
 __device__ __forceinline__ void corr4t_epilogue(const ScoreParams& p, const f32x16 (&acc)[4][2], float wl, long q, bool qvalid, int qh,
                                                 int qw, int cy, int cx, int g, const float* s_tab, int R, int TW, float* __restrict__ pyr0,
                                                 float* __restrict__ pyr1, float* __restrict__ pyr2, float* __restrict__ pyr3, float& s1,
-                                                float& s2) {
+                                                float& s2, float* __restrict__ stage, int ql_blk) {
   const int N = p.N, H8 = p.H8, W8 = p.W8;
   const int h1 = H8 >> 1, w1 = W8 >> 1, h2 = h1 >> 1, w2 = w1 >> 1, h3 = h2 >> 1, w3 = w2 >> 1;
+  const int ntx0 = (W8 + 15) >> 4, ntx1 = (w1 + 7) >> 3;
+  const long sz0 = (long)((H8 + 7) >> 3) * ntx0 * 128, sz1 = (long)((h1 + 3) >> 2) * ntx1 * 32;       // floats per query, tiled levels 0 / 1
   const unsigned umax = 2 * R + 2;
   const int kw0 = 8 * cx + 4 * g;
   float cell = 0.f;
@@ -440,9 +443,20 @@ __device__ __forceinline__ void corr4t_epilogue(const ScoreParams& p, const f32x
 #pragma unroll
     for (int dyl = 0; dyl < 4; ++dyl) {
       const int kh = 8 * cy + 4 * mt + dyl;
-      if (qvalid && kh < H8 && !(p.dbg & 1)) {
-        float* d = pyr0 + q * N + (long)kh * W8 + kw0;
-        if (VEC || kw0 + 3 < W8) {
+      if ((TILED || qvalid) && kh < H8 && !(p.dbg & 1)) {
+        // TILED: level 0 of a query is stored as 8 x 16-key tiles of 512 contiguous bytes -- exactly the patch one block of this kernel
+        // produces, so its 16 store instructions fill four whole 128-byte lines instead of sixteen 64-byte halves of lines that a
+        // neighbouring block completes much later (PMC: 1.31 x the level's bytes written + read-modify-write fetches)
+        // ... and the tile goes through LDS (stage: [64 queries][8 x 16 keys], query stride CORR_STG floats) so that every global store
+        // instruction of the block writes 1 KiB of contiguous lines (k_corr_build4t)
+        float* d = TILED ? stage + ql_blk * CORR_STG + (4 * mt + dyl) * 16 + ((cx & 1) * 8 + 4 * g)
+                         : pyr0 + q * N + (long)kh * W8 + kw0;
+        if (TILED) {                             // (the tile has room for the columns beyond the image: they are never read)
+          *reinterpret_cast<float4*>(d) = make_float4(cv[4 * dyl], cv[4 * dyl + 1], cv[4 * dyl + 2], cv[4 * dyl + 3]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (qvalid && (VEC || kw0 + j < W8)) { s1 += cv[4 * dyl + j]; s2 += cv[4 * dyl + j] * cv[4 * dyl + j]; }
+        } else if (VEC || kw0 + 3 < W8) {
           if (VEC) *reinterpret_cast<float4*>(d) = make_float4(cv[4 * dyl], cv[4 * dyl + 1], cv[4 * dyl + 2], cv[4 * dyl + 3]);
           else { d[0] = cv[4 * dyl]; d[1] = cv[4 * dyl + 1]; d[2] = cv[4 * dyl + 2]; d[3] = cv[4 * dyl + 3]; }
 #pragma unroll
@@ -456,15 +470,32 @@ __device__ __forceinline__ void corr4t_epilogue(const ScoreParams& p, const f32x
     }
     // level 1: 2 x 2 averages (same association as k_corr_pyramid: ((a + b) + c) + d, top row first)
     float sum16 = 0.f;
+    float l1v[2][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int y1 = 4 * cy + 2 * mt + a;
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b2 = 0; b2 < 2; ++b2) {
-        const int x1 = 4 * cx + 2 * g + b2;
-        const float v = (((cv[8 * a + 2 * b2] + cv[8 * a + 2 * b2 + 1]) + cv[8 * a + 4 + 2 * b2]) + cv[8 * a + 5 + 2 * b2]) * 0.25f;
-        sum16 += v;
-        if (qvalid && y1 < h1 && x1 < w1 && !(p.dbg & 2)) pyr1[(q * h1 + y1) * w1 + x1] = v;
+        l1v[a][b2] = (((cv[8 * a + 2 * b2] + cv[8 * a + 2 * b2 + 1]) + cv[8 * a + 4 + 2 * b2]) + cv[8 * a + 5 + 2 * b2]) * 0.25f;
+        sum16 += l1v[a][b2];
+      }
+    if (TILED) {
+      // a level-1 tile row (8 cells = 32 B) of this wave's cell half is [g = 0: 2 cells | g = 1: 2 cells]: the two half-waves swap one
+      // row each so that lane g stores row a = g of both as ONE 16-byte piece (4 scalar stores per lane before)
+      const float o0 = __shfl_xor(g ? l1v[0][0] : l1v[1][0], 32), o1 = __shfl_xor(g ? l1v[0][1] : l1v[1][1], 32);
+      const int a = g, y1 = 4 * cy + 2 * mt + a;
+      const float4 v4 = g ? make_float4(o0, o1, l1v[1][0], l1v[1][1]) : make_float4(l1v[0][0], l1v[0][1], o0, o1);
+      // (columns beyond w1 land in the tile's padding: never read)
+      if (qvalid && y1 < h1 && 4 * cx < w1 && !(p.dbg & 2))
+        *reinterpret_cast<float4*>(&pyr1[q * sz1 + ((long)cy * ntx1 + (cx >> 1)) * 32 + (2 * mt + a) * 8 + (cx & 1) * 4]) = v4;
+    } else {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int y1 = 4 * cy + 2 * mt + a;
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+          const int x1 = 4 * cx + 2 * g + b2;
+          if (qvalid && y1 < h1 && x1 < w1 && !(p.dbg & 2)) pyr1[(q * h1 + y1) * w1 + x1] = l1v[a][b2];
+        }
       }
     }
     // level 2: the lane's 4 x 4 block = mean of its four level-1 cells
@@ -584,11 +615,32 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build4t(ScoreParams p, const 
   const bool has_bias = p.pos_tab != nullptr && k_hmax >= q_hmin - R && k_hmin <= q_hmax + R;
   const bool vec = (p.W8 & 3) == 0 && 8 * cx + 7 < p.W8;        // every 4-key run of this wave is a full, 16-byte aligned float4
   float s1 = 0.f, s2 = 0.f;
+  float* stage = reinterpret_cast<float*>(As);                    // 64 x CORR_STG floats = 33 KB over the (dead) key tiles
+  static_assert(64 * CORR_STG * 4 <= (int)sizeof(As), "level-0 staging tile must fit in the key-tile buffer");
+  if (p.tiled) __syncthreads();                                  // every wave is done reading As / Bs
   if (8 * cx < p.W8) {                                           // (the second cell of the last pair may lie outside the image)
-#define EPI(CL, BI, VE) corr4t_epilogue<CL, BI, VE>(p, acc, wl, q, qvalid, qh, qw, cy, cx, g, s_tab, R, TW, pyr0, pyr1, pyr2, pyr3, s1, s2)
+#define EPI(CL, BI, VE) do { if (p.tiled) corr4t_epilogue<CL, BI, VE, true>(p, acc, wl, q, qvalid, qh, qw, cy, cx, g, s_tab, R, TW, pyr0, pyr1, pyr2, pyr3, s1, s2, stage, wq * 32 + r); \
+                            else corr4t_epilogue<CL, BI, VE, false>(p, acc, wl, q, qvalid, qh, qw, cy, cx, g, s_tab, R, TW, pyr0, pyr1, pyr2, pyr3, s1, s2, stage, wq * 32 + r); } while (0)
     if (clamp) { if (has_bias) { if (vec) EPI(true, true, true); else EPI(true, true, false); } else { if (vec) EPI(true, false, true); else EPI(true, false, false); } }
     else { if (has_bias) { if (vec) EPI(false, true, true); else EPI(false, true, false); } else { if (vec) EPI(false, false, true); else EPI(false, false, false); } }
 #undef EPI
+  }
+  if (p.tiled && !(p.dbg & 1)) {
+    // level-0 tiles of the block's 64 queries, LDS -> HBM: thread t moves 16-byte chunks t, t + 256, ... of the 64 x 512 B; a wave
+    // instruction writes two whole tiles (1 KiB of contiguous lines).  Rows / columns of the tile beyond the image carry whatever the
+    // staging buffer held: they are the tile grid's padding and are never read (k_corr_lookup tests y < h, x < w).
+    __syncthreads();
+    const int ntx0 = (p.W8 + 15) >> 4;
+    const long sz0 = (long)((p.H8 + 7) >> 3) * ntx0 * 128;
+    float* tile0 = pyr0 + ((long)b * N + q0) * sz0 + ((long)cy * ntx0 + cxp) * 128;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 256 * i, ql2 = c >> 5, w16 = c & 31;
+      if (q0 + ql2 < N) {
+        const float4 v = *reinterpret_cast<const float4*>(&stage[ql2 * CORR_STG + w16 * 4]);
+        *reinterpret_cast<float4*>(tile0 + (long)ql2 * sz0 + w16 * 4) = v;
+      }
+    }
   }
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
@@ -686,7 +738,7 @@ int launch_corr_build(const ScoreParams& p, float w_aggr, float* pyr0, double* s
 // fused build + pyramid (f16x3, 4 modes of 64, pre-split operands in ws): everything else returns CRAFT_ERR_UNSUPPORTED and the
 // caller uses craft_corr_build + craft_corr_finish
 int launch_corr_build_pyramid(const ScoreParams& p, float w_aggr, float* pyr0, float* pyr1, float* pyr2, float* pyr3, double* sums,
-                              void* ws, int prec, hipStream_t s) {
+                              void* ws, int prec, int tiled, hipStream_t s) {
   if (int e = check_score(p)) return e;
   if (!(ws != nullptr && prec == CRAFT_PREC_F16X3 && p.M == 4 && p.d == 64 && p.ldq % 4 == 0 && p.ldk % 4 == 0)) return CRAFT_ERR_UNSUPPORTED;
   if (p.H8 < 8 || p.W8 < 8 || !pyr1 || !pyr2 || !pyr3) return CRAFT_ERR_UNSUPPORTED;
@@ -702,6 +754,7 @@ int launch_corr_build_pyramid(const ScoreParams& p, float w_aggr, float* pyr0, f
   dim3 grid((p.N + 63) / 64, ((p.H8 + 7) / 8) * ncx2, p.B);
   ScoreParams pd = p;
   pd.dbg = tuning().corr_dbg;
+  pd.tiled = tiled;
   hipLaunchKernelGGL(k_corr_build4t, grid, dim3(NTHREADS), 0, s, pd, Qs, Ks, w_aggr, pyr0, pyr1, pyr2, pyr3, sums);
   return (int)hipGetLastError();
 }

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ l
                                                      const float* __restrict__ l2, const float* __restrict__ l3, int levels,
                                                      const float* __restrict__ mu_rstd, const float* __restrict__ coords,
                                                      int N, int H8, int W8, int radius, float* __restrict__ out, long ldo,
-                                                     int lvl_stride, int col_off, long nq) {
+                                                     int lvl_stride, int col_off, long nq, int tiled) {
   __shared__ float patch[4][4][LOOKUP_MAXP * LOOKUP_MAXP];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long q0 = (long)blockIdx.x * 4 + wv;
@@ -266,12 +266,20 @@ __global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ l
     // clamp the integer base far outside the image so int conversion can not overflow
     const int x0 = (int)fminf(fmaxf(x0f, -100000.f), 100000.f) - radius;
     const int y0 = (int)fminf(fmaxf(y0f, -100000.f), 100000.f) - radius;
-    const float* img = lv[l] + q * (long)h * w;
+    // CRAFT_PYR_TILED (craft_corr_build_pyramid's layout): level 0 in 8 x 16 tiles of 128 floats, level 1 in 4 x 8 tiles of 32
+    const bool tl = tiled && l < 2;
+    const int tsy = l == 0 ? 3 : 2, tsx = l == 0 ? 4 : 3;                    // log2 of the tile height / width
+    const int ntx = (w + (1 << tsx) - 1) >> tsx, nty = (h + (1 << tsy) - 1) >> tsy;
+    const float* img = lv[l] + q * (tl ? ((long)nty * ntx) << (tsy + tsx) : (long)h * w);
     for (int idx = lane; idx < PS * PS; idx += 64) {
       const int py = idx / PS, px = idx - py * PS;
       const int y = y0 + py, x = x0 + px;
       float v = 0.f;
-      if (y >= 0 && y < h && x >= 0 && x < w) v = (img[y * w + x] - mu) * rstd;
+      if (y >= 0 && y < h && x >= 0 && x < w) {
+        const long off = tl ? ((((long)(y >> tsy) * ntx + (x >> tsx)) << (tsy + tsx)) + ((y & ((1 << tsy) - 1)) << tsx) + (x & ((1 << tsx) - 1)))
+                            : (long)y * w + x;
+        v = (img[off] - mu) * rstd;
+      }
       patch[wv][l][py * LOOKUP_MAXP + px] = v;
     }
     h >>= 1; w >>= 1; sc *= 0.5f;
@@ -292,14 +300,14 @@ __global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ l
 
 int launch_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3, int levels, const float* mu_rstd,
                        const float* coords, int B, int H8, int W8, int radius, float* out, long ldo, int lvl_stride, int col_off,
-                       hipStream_t s) {
+                       int tiled, hipStream_t s) {
   if (levels < 1 || levels > 4 || radius < 0 || 2 * radius + 2 > LOOKUP_MAXP) return CRAFT_ERR_UNSUPPORTED;
   const int win2 = (2 * radius + 1) * (2 * radius + 1);
   if (lvl_stride <= 0) lvl_stride = win2;            // default: one volume, levels back to back
   if (lvl_stride < win2 || col_off < 0 || col_off + win2 > lvl_stride) return CRAFT_ERR_ARG;
   const long nq = (long)B * H8 * W8;
   hipLaunchKernelGGL(k_corr_lookup, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, l0, l1, l2, l3, levels, mu_rstd, coords,
-                     H8 * W8, H8, W8, radius, out, ldo, lvl_stride, col_off, nq);
+                     H8 * W8, H8, W8, radius, out, ldo, lvl_stride, col_off, nq, tiled);
   return (int)hipGetLastError();
 }
 

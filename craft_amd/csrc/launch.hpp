@@ -94,6 +94,7 @@ struct ScoreParams {
   const float* rb_h; const float* rb_wd; long ld_rbh, ld_rbw; float rb_w;
   float* rowsum;                      // k_attn_probs: non-null = deferred normalisation, row sums [B][M][N] out ...
   unsigned* rowmax;                   // ... followed by [B][M][N] ordered-uint row maxima (scratch): rowsum + B*M*N
+  int tiled;                          // k_corr_build4t: levels 0 / 1 of the pyramid in the tiled layout (CRAFT_PYR_TILED)
   int dbg;                            // developer ablation of k_corr_build4t's stores (CRAFT_CORR_DBG: 1 no level 0, 2 no levels 1-3), 0 in production
 };
 
@@ -117,7 +118,7 @@ int launch_flash_attn(const ScoreParams& sp, const void* vT, long ldt, int Dv, f
 int launch_score_max(const ScoreParams& p, unsigned* max_ord, int prec, hipStream_t s);
 int launch_corr_build(const ScoreParams& p, float w_aggr, float* pyr0, double* sums, void* ws, int prec, hipStream_t s);
 int launch_corr_build_pyramid(const ScoreParams& p, float w_aggr, float* pyr0, float* pyr1, float* pyr2, float* pyr3, double* sums,
-                              void* ws, int prec, hipStream_t s);
+                              void* ws, int prec, int tiled, hipStream_t s);
 int launch_attn_probs(const ScoreParams& p, void* P, long ldp, int p_prec, int prec, hipStream_t s);
 template <int D> int launch_attn_probs_d(const ScoreParams& p, void* P, long ldp, int p_prec, int prec, hipStream_t s);
 
@@ -131,7 +132,7 @@ int launch_corr_stats(const double* sums, float* mu_rstd, int B, double count, i
 int launch_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3, int levels,
                        const float* mu_rstd, const float* coords, int B, int H8, int W8, int radius,
                        float* out, long ldo, int lvl_stride, int col_off,
-                       hipStream_t s);
+                       int tiled, hipStream_t s);
 int launch_convf1(const float* flow, const float* w, const float* bias, int B, int H8, int W8, float* out, long ldo,
                   hipStream_t s);
 int launch_convf1_mfma(const float* flow, const void* w_packed, const float* bias, int B, int H8, int W8, float* out, long ldo, int prec,

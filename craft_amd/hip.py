@@ -16,6 +16,7 @@ ABI_VERSION = 2          # == CRAFT_HIP_ABI_VERSION (include/craft_hip.h): bumpe
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 W_PACKED = 0x100
+PYR_TILED = 0x200             # == CRAFT_PYR_TILED: levels 0 / 1 of a correlation pyramid in 8x16 / 4x8 tiles
 PV_ROWS_SHIFT = 20            # CRAFT_PV_ROWS(r) = r << 20, or-ed into craft_attn_apply's prec
 FRAG_ACC_ORDER = 0x10000      # == CRAFT_FRAG_ACC_ORDER
 STATS_REPLICAS = 64   # CRAFT_STATS_REPLICAS

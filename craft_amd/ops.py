@@ -143,30 +143,56 @@ def decode_ord(o: torch.Tensor) -> float:
 
 
 class CorrPyramid:
-    """Un-normalised correlation pyramid + lazy global-LayerNorm statistics."""
+    """Un-normalised correlation pyramid + lazy global-LayerNorm statistics.  ``tiled``: levels 0 / 1 are stored per query as 8 x 16 /
+    4 x 8 tiles (CRAFT_PYR_TILED: the patch one workgroup of the fused build kernel writes -- whole 128-byte lines); ``dense(l)`` gives
+    the row-major image of any level."""
 
-    def __init__(self, B: int, H8: int, W8: int, levels: int, device):
+    def __init__(self, B: int, H8: int, W8: int, levels: int, device, tiled: bool = False):
         self.B, self.H8, self.W8, self.levels = B, H8, W8, levels
+        self.tiled = bool(tiled) and levels == 4 and min(H8, W8) >= 8
         N = H8 * W8
-        self.lv = []
+        self.lv, self.dims = [], []
         h, w = H8, W8
-        for _ in range(levels):
-            self.lv.append(torch.empty(B * N, h, w, device=device, dtype=torch.float32))
+        for l in range(levels):
+            self.dims.append((h, w))
+            if self.tiled and l < 2:
+                th, tw = (8, 16) if l == 0 else (4, 8)
+                self.lv.append(torch.empty(B * N, -(-h // th) * -(-w // tw) * th * tw, device=device, dtype=torch.float32))
+            else:
+                self.lv.append(torch.empty(B * N, h, w, device=device, dtype=torch.float32))
             h, w = h // 2, w // 2
         self.sums = torch.zeros(B, 2, device=device, dtype=torch.float64)
         self.mu_rstd = torch.empty(B, 2, device=device, dtype=torch.float32)
 
     def nbytes(self) -> int:
-        return sum(t.numel() * 4 for t in self.lv)
+        """Algorithmic bytes of the pyramid (the image sizes; a tiled level's padding is not counted)."""
+        return sum(self.lv[l].shape[0] * h * w * 4 for l, (h, w) in enumerate(self.dims))
+
+    def dense(self, l: int) -> torch.Tensor:
+        """Level l as [B*N, h, w] row-major images (a copy for a tiled level: tests / debugging)."""
+        h, w = self.dims[l]
+        if not (self.tiled and l < 2):
+            return self.lv[l]
+        th, tw = (8, 16) if l == 0 else (4, 8)
+        nty, ntx = -(-h // th), -(-w // tw)
+        t = self.lv[l].view(-1, nty, ntx, th, tw).permute(0, 1, 3, 2, 4).reshape(-1, nty * th, ntx * tw)
+        return t[:, :h, :w].contiguous()
 
     def batch_slice(self, b0: int, b1: int) -> "CorrPyramid":
         """View of samples [b0, b1) (no copy): the refinement loop of a batch slice can run on its own stream."""
         v = CorrPyramid.__new__(CorrPyramid)
-        v.B, v.H8, v.W8, v.levels = b1 - b0, self.H8, self.W8, self.levels
+        v.B, v.H8, v.W8, v.levels, v.tiled, v.dims = b1 - b0, self.H8, self.W8, self.levels, self.tiled, self.dims
         N = self.H8 * self.W8
         v.lv = [t[b0 * N:b1 * N] for t in self.lv]
         v.sums, v.mu_rstd = self.sums[b0:b1], self.mu_rstd[b0:b1]
         return v
+
+
+def fused_pyramid(C: int, M: int, prec, levels: int, H8: int, W8: int) -> bool:
+    """True when ``corr_build`` will run the fused build + pyramid kernel (craft_corr_build_pyramid) -- the caller may then allocate a
+    tiled CorrPyramid (its stores fill whole 128-byte lines)."""
+    return (pick(prec, "score") == hip.PREC_F16X3 and M == 4 and C == 256 and levels == 4 and min(H8, W8) >= 8
+            and not os.environ.get("CRAFT_NO_FUSED_PYRAMID"))
 
 
 def corr_build(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale: float, pos_tab: Optional[torch.Tensor],
@@ -182,9 +208,11 @@ def corr_build(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale
     if ws is not None and len(pyr.lv) == 4 and min(H8, W8) >= 8 and not os.environ.get("CRAFT_NO_FUSED_PYRAMID"):
         # pyramid written from the tile that produced level 0 (no re-read of the 604 MB level 0 at 768x1024)
         call("craft_corr_build_pyramid", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale, tab, R, pos_w, w_aggr, clamp_ord,
-             lv[0], lv[1], lv[2], lv[3], pyr.sums, ws, sp)
+             lv[0], lv[1], lv[2], lv[3], pyr.sums, ws, sp | (hip.PYR_TILED if pyr.tiled else 0))
         call("craft_corr_finish", lv[0], None, None, None, pyr.sums, pyr.mu_rstd, B, H8, W8, int(do_norm))
         return pyr
+    if pyr.tiled:
+        raise hip.CraftHipError("a tiled CorrPyramid can only be filled by the fused build (f16x3 scores, 4 modes of 64, 4 levels, H8, W8 >= 8)")
     call("craft_corr_build", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale, tab, R, pos_w, w_aggr, clamp_ord, pyr.lv[0], pyr.sums, ws, sp)
     call("craft_corr_finish", lv[0], lv[1], lv[2], lv[3], pyr.sums, pyr.mu_rstd, B, H8, W8, int(do_norm))
     return pyr
@@ -203,8 +231,8 @@ def corr_lookup(pyr, coords: torch.Tensor, radius: int, out: Optional[torch.Tens
     co = coords.contiguous()
     for v, pv in enumerate(pyrs):
         lv = pv.lv + [None] * (4 - len(pv.lv))
-        call("craft_corr_lookup", lv[0], lv[1], lv[2], lv[3], pv.levels, pv.mu_rstd, co, B, pv.H8, pv.W8,
-             radius, out, _ld(out), win2 * V, win2 * v)
+        call("craft_corr_lookup", lv[0], lv[1], lv[2], lv[3], pv.levels | (hip.PYR_TILED if getattr(pv, "tiled", False) else 0), pv.mu_rstd, co,
+             B, pv.H8, pv.W8, radius, out, _ld(out), win2 * V, win2 * v)
     return out
 
 

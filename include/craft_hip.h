@@ -94,7 +94,10 @@ int craft_corr_build(const float* q, long ldq, const float* k, long ldk, int B, 
  * registers per query, so levels 1..3 (2x2 / 4x4 / 8x8 averages, floor sizes) are register sums of the tile that produced
  * level 0, which is never read back.  Implemented for prec = F16X3, M = 4, d = 64 with the ws of craft_corr_build, H8, W8 >= 8
  * and all four levels; anything else returns CRAFT_ERR_UNSUPPORTED (10003) and the caller uses craft_corr_build +
- * craft_corr_finish.  Follow it with craft_corr_finish(pyr0, NULL, NULL, NULL, ...) for the (mean, rstd) of the lazy LayerNorm. */
+ * craft_corr_finish.  Follow it with craft_corr_finish(pyr0, NULL, NULL, NULL, ...) for the (mean, rstd) of the lazy LayerNorm.
+ * prec | CRAFT_PYR_TILED: levels 0 and 1 are written in the tiled layout described at craft_corr_lookup (pyr0 / pyr1 then hold
+ * ceil(H8/8)*ceil(W8/16)*128 and ceil(h1/4)*ceil(w1/8)*32 floats per query). */
+#define CRAFT_PYR_TILED 0x200
 int craft_corr_build_pyramid(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d, float scale,
                              const float* pos_tab, int R, float pos_w, float w_aggr, const unsigned* clamp_ord, float* pyr0,
                              float* pyr1, float* pyr2, float* pyr3, double* sums, void* ws, int prec, void* stream);
@@ -107,7 +110,12 @@ int craft_corr_finish(const float* pyr0, float* pyr1, float* pyr2, float* pyr3, 
 /* CorrBlock.__call__ + bilinear_sampler (corr.py:47-71, utils.py:65-79): out[q][l*lvl_stride + col_off + a*(2r+1) + b] =
  * bilinear_zero_pad(LN(pyr_l)[q], x/2^l + a - r, y/2^l + b - r), q = b*N + n, coords tokens (x,y).  lvl_stride = 0 means
  * (2r+1)^2 (one volume).  The two-way correlation of --f1 (corr.py:164-171: two volumes concatenated on the channel axis
- * of every level) is two calls with lvl_stride = 2*(2r+1)^2 and col_off = 0 / (2r+1)^2. */
+ * of every level) is two calls with lvl_stride = 2*(2r+1)^2 and col_off = 0 / (2r+1)^2.
+ * levels | CRAFT_PYR_TILED: the pyramid is in craft_corr_build_pyramid's tiled layout (prec | CRAFT_PYR_TILED there): per query,
+ * level 0 as ceil(H8/8) x ceil(W8/16) tiles of 8 x 16 keys (128 floats, row-major inside the tile, tiles row-major) and level 1
+ * (h1 = H8/2, w1 = W8/2) as ceil(h1/4) x ceil(w1/8) tiles of 4 x 8; levels 2 and 3 stay row-major.  A tile is the patch one
+ * workgroup of the build kernel owns, so its stores fill whole 128-byte lines (row-major: 64-byte half lines completed by another
+ * workgroup -> 1.3 x the bytes written plus read-modify-write fetches, profiles/r3/pmc_corr_build_levels.txt). */
 int craft_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3, int levels,
                       const float* mu_rstd, const float* coords, int B, int H8, int W8, int radius,
                       float* out, long ldo, int lvl_stride, int col_off, void* stream);

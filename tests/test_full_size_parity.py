@@ -119,16 +119,19 @@ def test_corr_build_768x1024_shipped_kernel(device):
         k = ops.linear(x2.to(device), Wq.to(device), bq.to(device), PREC_F32)
         scale = 1.0 / math.sqrt(C // M)
         mx = ops.score_max(q, k, H8, W8, M, scale, prec)
-        pyr = ops.CorrPyramid(B, H8, W8, 4, device)
+        # (the shipped configuration: the fused f16x3 build writes the tiled layout, the fp32 build the row-major one)
+        pyr = ops.CorrPyramid(B, H8, W8, 4, device, tiled=ops.fused_pyramid(C, M, prec, 4, H8, W8))
         ops.corr_build(q, k, H8, W8, M, scale, tab.to(device), 0.5, w_aggr, mx, pyr, True, prec)
         sc = float(c_ref.abs().max())
-        got0 = pyr.lv[0].reshape(N, N)[rows.to(device)].cpu()
+        d0 = pyr.dense(0)
+        got0 = d0.reshape(N, N)[rows.to(device)].cpu()
+        del d0
         err0 = (got0 - c_ref[0, rows]).abs() - 1e-4 * c_ref[0, rows].abs()
         assert err0.max().item() < 2e-5 * max(1.0, sc), f"level 0 prec={prec}: {err0.max().item():.2e}"
         ref_l = c_ref[0, rows].reshape(len(rows), 1, H8, W8)
         for l in range(1, 4):
             ref_l = torch.nn.functional.avg_pool2d(ref_l, 2, stride=2)
-            got = pyr.lv[l][rows.to(device)].cpu()
+            got = pyr.dense(l)[rows.to(device)].cpu()
             assert (got - ref_l[:, 0]).abs().max().item() < 5e-5 * max(1.0, sc), f"level {l} prec={prec}"
         assert abs(pyr.mu_rstd[0, 0].item() - mu_ref.item()) < 1e-5 * max(1.0, sc)
         assert abs(pyr.mu_rstd[0, 1].item() - rstd_ref.item()) < 1e-4 * rstd_ref.item()

@@ -125,10 +125,15 @@ def _qk(B, H8, W8, C, seed, gain=2.5):
 
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("gain", [2.5, 60.0])
-def test_corr_build_pyramid_lookup(device, prec, gain):
+@pytest.mark.parametrize("tiled,H8,W8", [(False, 18, 21), (True, 18, 21), (True, 16, 48), (True, 9, 37)])
+def test_corr_build_pyramid_lookup(device, prec, gain, tiled, H8, W8):
     """craft_score_max + craft_corr_build + craft_corr_finish + craft_corr_lookup vs the oracle
-    (inter-frame attention, tied projection with bias; gain=60 triggers the global clamp)."""
-    B, H8, W8, C, M = 2, 18, 21, 256, 4       # odd sizes: ragged tiles, floor pooling
+    (inter-frame attention, tied projection with bias; gain=60 triggers the global clamp).  ``tiled``: the pyramid in the fused
+    build's tiled layout (CRAFT_PYR_TILED: 8x16 / 4x8 tiles of levels 0 / 1; only the f16x3 build writes it) -- ragged tile grids
+    (18x21, 9x37) and exact ones (16x48)."""
+    if tiled and not ops.fused_pyramid(256, 4, prec, 4, H8, W8):
+        pytest.skip("the tiled layout is written by the fused f16x3 build only")
+    B, C, M = 2, 256, 4                       # odd sizes: ragged tiles, floor pooling
     N = H8 * W8
     x1, x2, Wq, _, bq = _qk(B, H8, W8, C, seed=10, gain=gain)
     tab = gen(15, 15, seed=20) * 0.5
@@ -153,12 +158,13 @@ def test_corr_build_pyramid_lookup(device, prec, gain):
         assert float(S.max()) <= 100.0, "norm bound skipped the exact pass although a score exceeds the threshold"
     else:
         assert abs(got_max - float(S.max())) <= at * 20 + rt * abs(float(S.max())), f"score max {got_max} vs {float(S.max())}"
-    pyr = ops.CorrPyramid(B, H8, W8, 4, device)
+    pyr = ops.CorrPyramid(B, H8, W8, 4, device, tiled=tiled)
+    assert pyr.tiled == tiled
     ops.corr_build(q, k, H8, W8, M, scale, tab.to(device), 0.5, w_aggr, mx, pyr, True, prec)
     sc = float(c_ref.abs().max())
-    close(pyr.lv[0].reshape(B, N, N), c_ref, rt, at * max(1.0, sc), f"corr level 0 prec={prec}")
+    close(pyr.dense(0).reshape(B, N, N), c_ref, rt, at * max(1.0, sc), f"corr level 0 prec={prec}")
     for l in range(1, 4):
-        close(pyr.lv[l], pyr_ref[l][:, 0], rt, at * max(1.0, sc), f"corr level {l}")
+        close(pyr.dense(l), pyr_ref[l][:, 0], rt, at * max(1.0, sc), f"corr level {l}")
     close(pyr.mu_rstd[:, 0], mu_ref, rt, at * max(1.0, sc), "global mean")
     close(pyr.mu_rstd[:, 1], rstd_ref, max(rt, 1e-4), 1e-6, "global rstd")
 

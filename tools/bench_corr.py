@@ -45,7 +45,7 @@ def measure(height=768, width=1024, batch=1, reps=10, precision="mixed"):
     q = torch.randn(B, N, C, generator=g).to(dev)
     k = torch.randn(B, N, C, generator=g).to(dev)
     tab = (torch.randn(2 * R + 1, 2 * R + 1, generator=g) * 0.5).to(dev)
-    pyr = ops.CorrPyramid(B, H8, W8, L, dev)
+    pyr = ops.CorrPyramid(B, H8, W8, L, dev, tiled=ops.fused_pyramid(C, M, prec, L, H8, W8) and not os.environ.get("CRAFT_NO_TILED_PYRAMID"))
     scale = 1.0 / math.sqrt(C // M)
 
     def build():
@@ -55,7 +55,7 @@ def measure(height=768, width=1024, batch=1, reps=10, precision="mixed"):
     ms_build = timed(build, a.reps)
     # algorithmic bytes: read Q, K; write every pyramid level once.  The unfused path (CRAFT_NO_FUSED_PYRAMID,
     # other level counts, images under 64 px) reads level 0 back in its pooling pass: those bytes are counted only when that pass runs
-    lvl = [t.numel() * 4 for t in pyr.lv]
+    lvl = [pyr.lv[l].shape[0] * h * w * 4 for l, (h, w) in enumerate(pyr.dims)]           # (image sizes: a tiled level's padding is not counted)
     fused = L == 4 and min(H8, W8) >= 8 and not os.environ.get("CRAFT_NO_FUSED_PYRAMID")
     bytes_build = 2 * B * N * C * 4 + sum(lvl) + (0 if fused else lvl[0])
     coords = (torch.rand(B, N, 2, generator=g) * torch.tensor([W8 - 1.0, H8 - 1.0])).to(dev)
