@@ -319,14 +319,16 @@ def roofline_wgrad(step, policy, steps=2):
     key = max(by, key=lambda k: sum(by[k]))
     ms = sum(by[key]) / len(by[key])
     ach = flop(key) / (ms * 1e-3) / 1e12
-    from craft_amd.hip import PREC_F16X3, Precision
-    mult = 3 if Precision.parse(policy).conv == PREC_F16X3 else 1
+    from craft_amd.hip import PREC_F16, PREC_F16X3, Precision
+    pol = Precision.parse(policy)
+    # MFMAs issued per product: 3 for f16x3 operands, 2 when the activation operand is one fp16 plane (policy role wgx = fp16: "mixed"), else 1
+    mult = (2 if pol.wgx == PREC_F16 else 3) if pol.conv == PREC_F16X3 else 1
     traffic = None
     kern, cin, cout, KH, KW, rows, calls = key
     try:        # HBM bytes per launch from the PMC passes committed under profiles/r3 -- quoted only for the launch shape and operand mode profiled
-        with open(os.path.join(ROOT, "profiles", "r3", "pmc_traffic_wgrad.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r4" if mult == 2 else "r3", "pmc_traffic_wgrad.json")) as fh:
             pmc = json.load(fh)
-        if list(pmc.get("shape", [])) == list(key[1:]) and pmc.get("kernel") == kern and mult == 3:
+        if list(pmc.get("shape", [])) == list(key[1:]) and pmc.get("kernel") == kern and pmc.get("mfmas_per_product", 3) == mult:
             traffic = int(pmc["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError, TypeError):
         pass
@@ -338,6 +340,7 @@ def roofline_wgrad(step, policy, steps=2):
             "executed_frac": round(mult * ach / 2500.0, 4),
             "all_wgrad_launches": {"launches_per_step": len(evs) // steps, "ms_per_step": round(tot_ms / steps, 3),
                                    "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 1), "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / 2500.0, 4)},
+            "mfmas_per_product": mult,
             "note": "algorithmic (fp32-equivalent) flops against the dense fp16 MFMA peak; executed_frac counts the MFMAs issued "
                     f"({mult} per product in this policy); timed live with HIP events around every launch of real training steps"}
 

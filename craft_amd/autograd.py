@@ -203,7 +203,7 @@ class Linear(Function):
         if pk:
             co_p, ci_p = round_up(Cout, 32), round_up(Cin, 32)
             acc, _ = _acc_buffer(cache, wobj, "dw", (co_p, ci_p), x.device)
-            _wgrad_deferred(cache, wobj, last, (Packed(dy, pp, colsum=accb), Packed(x, pp)), 1, 1, acc)
+            _wgrad_deferred(cache, wobj, last, (Packed(dy, pp, colsum=accb), Packed(x, xprec(pp))), 1, 1, acc)
             dw = acc[:Cout, :Cin] if last else None
         elif ctx.needs_input_grad[1]:
             acc, _ = _acc_buffer(cache, wobj, "dw", (Cout, Cin), x.device)
@@ -822,6 +822,16 @@ def gemm_pk(A: PkMat, a_desc, B: PkMat, b_desc, C: torch.Tensor, ldc: int, c_out
          round_up(K, 32), float(alpha), A.prec)
 
 
+# Mode of the activation operand X of weight-gradient products (hip.Precision role `wgx`): set per training pass by
+# train_forward.forward_train.  [0] = PREC_F16: X packs of f16x3 layers hold one fp16 plane (2 MFMAs per product), None: the layer's mode.
+WGX = [None]
+
+
+def xprec(prec: int) -> int:
+    """Pack mode of a weight gradient's X operand for a layer whose dY is packed in ``prec``."""
+    return hip.PREC_F16 if (prec == hip.PREC_F16X3 and WGX[0] == hip.PREC_F16) else prec
+
+
 class PackBatch:
     """Queued craft_pack_operand calls, launched together by ``flush`` (craft_pack_operands)."""
 
@@ -850,13 +860,16 @@ def wgrad_pk(pairs, KH: int, KW: int, acc: torch.Tensor):
     two = hasattr(xp, "a")
     for g2, x2 in pairs:
         assert (g2.K, g2.guard, g2.prec, g2.rows_p, g2.C_p, g2.Wp) == (gp.K, gp.guard, gp.prec, gp.rows_p, gp.C_p, gp.Wp)
-        assert (x2.K, x2.guard, x2.prec, x2.rows_p, x2.C_p, hasattr(x2, "a")) == (gp.K, gp.guard, gp.prec, xp.rows_p, xp.C_p, two)
+        assert (x2.K, x2.guard, x2.prec, x2.rows_p, x2.C_p, hasattr(x2, "a")) == (gp.K, gp.guard, xp.prec, xp.rows_p, xp.C_p, two)
         assert not two or x2.a.C_p == xp.a.C_p
+    if xp.prec != gp.prec and (gp.prec, xp.prec) != (hip.PREC_F16X3, hip.PREC_F16):
+        raise hip.CraftHipError("craft_wgrad_pk: the X packs must be in dY's mode, or one fp16 plane beside f16x3 dY packs")
+    flag = hip.WGRAD_X_PREC(xp.prec) if xp.prec != gp.prec else 0
     n = len(pairs)
     ga = hip.carray(ctypes.c_void_p, [g2.buf.data_ptr() for g2, _ in pairs])
     xa = hip.carray(ctypes.c_void_p, [(x2.a if two else x2).buf.data_ptr() for _, x2 in pairs])
     xb = hip.carray(ctypes.c_void_p, [x2.b.buf.data_ptr() for _, x2 in pairs]) if two else None
-    call("craft_wgrad_pk", ga, xa, xb, xp.a.C_p if two else xp.C_p, n, gp.rows_p, gp.C_p, xp.rows_p, xp.C_p, gp.guard, gp.K, KH, KW, gp.Wp, acc, gp.prec)
+    call("craft_wgrad_pk", ga, xa, xb, xp.a.C_p if two else xp.C_p, n, gp.rows_p, gp.C_p, xp.rows_p, xp.C_p, gp.guard, gp.K, KH, KW, gp.Wp, acc, gp.prec | flag)
 
 
 def _wgrad_deferred(cache, wobj, last: bool, pair, KH: int, KW: int, acc: torch.Tensor):
@@ -886,7 +899,7 @@ def _conv_wgrad(xp, g, B, H8, W8, cin_p, cout_p, KH, KW, prec, db=None) -> torch
     dw = hip.zeros((cout_p, KH, KW, cin_p,), xp.device)
     if _use_pk(prec) and cin_p % 32 == 0 and cout_p % 32 == 0:
         geom = (B, H8, W8, KH // 2, KW // 2)
-        wgrad_pk([(Packed(g, prec, geom, colsum=db), Packed(xp, prec, geom))], KH, KW, dw)
+        wgrad_pk([(Packed(g, prec, geom, colsum=db), Packed(xp, xprec(prec), geom))], KH, KW, dw)
     else:
         call("craft_conv2d_wgrad", xp, xp.stride(-2), cin_p, g, g.stride(-2), cout_p, KH, KW, B, H8, W8, dw, db, None, 0, prec)
     return dw
@@ -940,7 +953,7 @@ class Conv(Function):
             if _use_pk(ctx.prec):
                 # packed operands (the bias gradient rides on the pack of dY)
                 geom = (B, H8, W8, KH // 2, KW // 2)
-                _wgrad_deferred(cache, ctx.w, last, (Packed(g, ctx.prec, geom, colsum=accb), Packed(xp, ctx.prec, geom)), KH, KW, acc)
+                _wgrad_deferred(cache, ctx.w, last, (Packed(g, ctx.prec, geom, colsum=accb), Packed(xp, xprec(ctx.prec), geom)), KH, KW, acc)
             else:
                 # (the bias gradient rides on the same launch: the blocks of tap 0 add the column sums of dY)
                 call("craft_conv2d_wgrad", xp, xp.stride(-2), cin_p, g, g.stride(-2), cout_p, KH, KW, B, H8, W8, acc, accb, None, 0, ctx.prec)

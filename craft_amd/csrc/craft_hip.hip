@@ -468,7 +468,8 @@ int craft_gemm_pk(const void* A, const long* a_desc, const void* B, const long* 
 int craft_pack_operands(const long* descs, int n, void* stream) { return launch_pack_operands(descs, n, S(stream)); }
 int craft_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* const* Xp1, int cin0, int nseg, long dy_rows_p, int cout, long x_rows_p,
                    int cin, long guard, long K, int KH, int KW, int Wp, float* dW, int prec, void* stream) {
-  return launch_wgrad_pk(dYp, Xp, Xp1, cin0, nseg, dy_rows_p, cout, x_rows_p, cin, guard, K, KH, KW, Wp, dW, prec, S(stream));
+  const int px = (prec >> 8) & 0xff;                      // CRAFT_WGRAD_X_PREC(p): the X packs' mode when it differs from dY's
+  return launch_wgrad_pk(dYp, Xp, Xp1, cin0, nseg, dy_rows_p, cout, x_rows_p, cin, guard, K, KH, KW, Wp, dW, prec & 0xff, px ? px - 1 : (prec & 0xff), S(stream));
 }
 int craft_relpos_add(float* S, long ld, int BZ, int H8, int W8, const float* Hs, long ldh, const float* Ws, long ldw, float w, void* stream) {
   return launch_relpos_add(S, ld, BZ, H8, W8, Hs, ldh, Ws, ldw, w, S(stream));

@@ -206,10 +206,13 @@ struct PkParams {
   int mode;                                  // developer ablations (CRAFT_PK_MODE), 0 in production
 };
 
-template <int PLANES, int BM, int BN, int WM, int WN, bool BF16>
+// PLANES: 2 = f16x3 (hi, lo planes of both operands: al.bh + ah.bl + ah.bh), 1 = one 16-bit plane each.  PLANES_B = 1 with PLANES = 2: the B
+// operand (the activation X of a weight gradient) is a single fp16 plane -- X rounded to fp16, dY exact: al.b + ah.b, two MFMAs per product
+// (relative error of dW 2e-4 against 2e-5: the library's "mixed" training policy, craft_amd.hip.Precision role `wgx`).
+template <int PLANES, int BM, int BN, int WM, int WN, bool BF16, int PLANES_B = PLANES>
 __global__ __launch_bounds__(512) void k_gemm_pk(PkParams p) {
   constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
-  constexpr int A_CH = PLANES * (BM / 32), B_CH = PLANES * (BN / 32);          // 2 KiB chunks per stage
+  constexpr int A_CH = PLANES * (BM / 32), B_CH = PLANES_B * (BN / 32);        // 2 KiB chunks per stage
   constexpr int STAGE = (A_CH + B_CH) * 2048;
   constexpr int NDMA = 2 * (A_CH + B_CH), DPW = (NDMA + 7) / 8;                 // 1 KiB DMA pieces per stage / per wave
   __shared__ __attribute__((aligned(1024))) unsigned char S[2 * STAGE];
@@ -334,16 +337,14 @@ __global__ __launch_bounds__(512) void k_gemm_pk(PkParams p) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         bh[nt] = frag(sb + b_base + nt * 2048u + ks * 1024u);
-        if constexpr (PLANES == 2) bl[nt] = frag(sb + b_base + (BN / 32 + nt) * 2048u + ks * 1024u);
+        if constexpr (PLANES_B == 2) bl[nt] = frag(sb + b_base + (BN / 32 + nt) * 2048u + ks * 1024u);
       }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          if constexpr (PLANES == 2) {
-            mma(al[mt], bh[nt], acc[mt][nt]);
-            mma(ah[mt], bl[nt], acc[mt][nt]);
-          }
+          if constexpr (PLANES == 2) mma(al[mt], bh[nt], acc[mt][nt]);
+          if constexpr (PLANES_B == 2) mma(ah[mt], bl[nt], acc[mt][nt]);
           mma(ah[mt], bh[nt], acc[mt][nt]);
         }
     }
@@ -371,8 +372,9 @@ __global__ __launch_bounds__(512) void k_gemm_pk(PkParams p) {
 static int pick_tile(int m) { return m > 128 ? 256 : (m > 64 ? 128 : 64); }
 
 int launch_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* const* Xp1, int cin0, int nseg, long dy_rows_p, int cout, long x_rows_p,
-                    int cin, long guard, long K, int KH, int KW, int Wp, float* dW, int prec, hipStream_t s) {
+                    int cin, long guard, long K, int KH, int KW, int Wp, float* dW, int prec, int prec_x, hipStream_t s) {
   if (cout <= 0 || cin <= 0 || K <= 0 || nseg <= 0) return 0;
+  if (prec_x != prec && !(prec == CRAFT_PREC_F16X3 && prec_x == CRAFT_PREC_F16)) return CRAFT_ERR_UNSUPPORTED;
   if ((cout & 31) || (cin & 31) || (K & 31) || KH < 1 || KW < 1) return CRAFT_ERR_ARG;
   if (Xp1 == nullptr) cin0 = cin;
   if ((cin0 & 31) || cin0 <= 0 || cin0 > cin || (Xp1 != nullptr && cin0 == cin)) return CRAFT_ERR_ARG;
@@ -380,15 +382,15 @@ int launch_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* c
   if (nseg > PK_MAX_SEG) {                              // more segments than one launch carries: in groups
     for (int i = 0; i < nseg; i += PK_MAX_SEG) {
       const int n = nseg - i < PK_MAX_SEG ? nseg - i : PK_MAX_SEG;
-      const int rc = launch_wgrad_pk(dYp + i, Xp + i, Xp1 ? Xp1 + i : nullptr, cin0, n, dy_rows_p, cout, x_rows_p, cin, guard, K, KH, KW, Wp, dW, prec, s);
+      const int rc = launch_wgrad_pk(dYp + i, Xp + i, Xp1 ? Xp1 + i : nullptr, cin0, n, dy_rows_p, cout, x_rows_p, cin, guard, K, KH, KW, Wp, dW, prec, prec_x, s);
       if (rc) return rc;
     }
     return 0;
   }
-  const int planes = prec == CRAFT_PREC_F16X3 ? 2 : 1;
+  const int planes = prec == CRAFT_PREC_F16X3 ? 2 : 1, planes_x = prec_x == CRAFT_PREC_F16X3 ? 2 : 1;
   const long max_shift = (long)(KH / 2) * Wp + KW / 2;
   if (guard < max_shift || guard + K + max_shift > x_rows_p || guard + K > dy_rows_p) return CRAFT_ERR_ARG;
-  if ((double)planes * (cout / 32) * dy_rows_p * 64.0 >= 4294967296.0 || (double)planes * (cin / 32) * x_rows_p * 64.0 >= 4294967296.0)
+  if ((double)planes * (cout / 32) * dy_rows_p * 64.0 >= 4294967296.0 || (double)planes_x * (cin / 32) * x_rows_p * 64.0 >= 4294967296.0)
     return CRAFT_ERR_UNSUPPORTED;                     // 32-bit byte offsets inside a pack
   PkParams p = {};
   for (int i = 0; i < nseg; ++i) {
@@ -415,7 +417,7 @@ int launch_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* c
   // Blocks of one K range share an XCD (block map of the kernel), an XCD has 32 CUs and a CU holds `bpc` blocks (LDS: two stages of
   // planes * (bm + bn) * 64 bytes per K-tile): the largest split count whose per-XCD share still runs in ONE round -- one split too many
   // and two XCDs run a second round (26 splits x 10 tiles measured 2 x the time of 24)
-  const int lds = 2 * planes * (bm + bn) * 64;
+  const int lds = 2 * (planes * bm + planes_x * bn) * 64;
   const int bpc = lds > 80 * 1024 ? 1 : (lds > 53 * 1024 ? 2 : (lds > 40 * 1024 ? 3 : 4));
   long per_xcd = (32L * bpc) / tiles;                   // K ranges per XCD
   if (per_xcd < 1) per_xcd = 1;
@@ -428,19 +430,20 @@ int launch_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* c
   p.ksplit = p.seg_splits * nseg;
   p.mode = tuning().pk_mode;
   dim3 grid((unsigned)(8 * tiles * ((p.ksplit + 7) / 8)));
-#define GO2(PL, BM_, BN_, WM_, WN_, BF) hipLaunchKernelGGL((k_gemm_pk<PL, BM_, BN_, WM_, WN_, BF>), grid, dim3(512), 0, s, p)
-#define GO(PL, BF) do { \
-    if (bm == 256 && bn == 256) GO2(PL, 256, 256, 2, 4, BF); \
-    else if (bm == 256 && bn == 128) GO2(PL, 256, 128, 4, 2, BF); \
-    else if (bm == 256) GO2(PL, 256, 64, 8, 1, BF); \
-    else if (bm == 128 && bn == 256) GO2(PL, 128, 256, 2, 4, BF); \
-    else if (bm == 128 && bn == 128) GO2(PL, 128, 128, 2, 4, BF); \
-    else if (bm == 128) GO2(PL, 128, 64, 4, 2, BF); \
-    else if (bn == 256) GO2(PL, 64, 256, 1, 8, BF); \
-    else GO2(PL, 64, 128, 2, 4, BF); } while (0)
-  if (prec == CRAFT_PREC_F16X3) GO(2, false);
-  else if (prec == CRAFT_PREC_F16) GO(1, false);
-  else GO(1, true);
+#define GO2(PL, BM_, BN_, WM_, WN_, BF, PB) hipLaunchKernelGGL((k_gemm_pk<PL, BM_, BN_, WM_, WN_, BF, PB>), grid, dim3(512), 0, s, p)
+#define GO(PL, BF, PB) do { \
+    if (bm == 256 && bn == 256) GO2(PL, 256, 256, 2, 4, BF, PB); \
+    else if (bm == 256 && bn == 128) GO2(PL, 256, 128, 4, 2, BF, PB); \
+    else if (bm == 256) GO2(PL, 256, 64, 8, 1, BF, PB); \
+    else if (bm == 128 && bn == 256) GO2(PL, 128, 256, 2, 4, BF, PB); \
+    else if (bm == 128 && bn == 128) GO2(PL, 128, 128, 2, 4, BF, PB); \
+    else if (bm == 128) GO2(PL, 128, 64, 4, 2, BF, PB); \
+    else if (bn == 256) GO2(PL, 64, 256, 1, 8, BF, PB); \
+    else GO2(PL, 64, 128, 2, 4, BF, PB); } while (0)
+  if (prec == CRAFT_PREC_F16X3 && prec_x == CRAFT_PREC_F16) GO(2, false, 1);
+  else if (prec == CRAFT_PREC_F16X3) GO(2, false, 2);
+  else if (prec == CRAFT_PREC_F16) GO(1, false, 1);
+  else GO(1, true, 1);
 #undef GO
 #undef GO2
   return (int)hipGetLastError();

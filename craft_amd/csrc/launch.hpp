@@ -58,7 +58,7 @@ int launch_pack_operands(const long* descs, int n, hipStream_t s);
 int launch_gemm_pk(const void* A, const long* a_desc, const void* B, const long* b_desc, float* C, long ldc, long c_outer, long c_inner,
                    int inner, int nbatch, int M, int N, int K, float alpha, int prec, hipStream_t s);
 int launch_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* const* Xp1, int cin0, int nseg, long dy_rows_p, int cout, long x_rows_p,
-                    int cin, long guard, long K, int KH, int KW, int Wp, float* dW, int prec, hipStream_t s);
+                    int cin, long guard, long K, int KH, int KW, int Wp, float* dW, int prec, int prec_x, hipStream_t s);
 int launch_pack_conv_weights(const float* w0, int cout0, const float* w1, int cout1, int Cin, int KH, int KW, int a0, int a1, int b0, int b1,
                              int transposed, int prec, void* out, hipStream_t s);
 int launch_relpos_add(float* S, long ld, int BZ, int H8, int W8, const float* Hs, long ldh, const float* Ws, long ldw, float w, hipStream_t s);

@@ -16,6 +16,12 @@ ABI_VERSION = 2          # == CRAFT_HIP_ABI_VERSION (include/craft_hip.h): bumpe
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 W_PACKED = 0x100
+
+
+def WGRAD_X_PREC(p: int) -> int:
+    """== CRAFT_WGRAD_X_PREC(p): or-ed into craft_wgrad_pk's prec when the X packs' mode differs from dY's"""
+    return (p + 1) << 8
+
 PYR_TILED = 0x200             # == CRAFT_PYR_TILED: levels 0 / 1 of a correlation pyramid in 8x16 / 4x8 tiles
 PV_ROWS_SHIFT = 20            # CRAFT_PV_ROWS(r) = r << 20, or-ed into craft_attn_apply's prec
 FRAG_ACC_ORDER = 0x10000      # == CRAFT_FRAG_ACC_ORDER
@@ -122,7 +128,7 @@ HOST_FUNCTIONS = {"craft_png_unfilter"}
 # plain fp16 storage + fp16 MFMA for the attention probabilities (P V); measured mean end-point deviation from the fp32
 # path < 1e-3 px at 448x1024 / 12 iters.  "mixed_fp32conv": fp16 attention contractions + exact
 # fp32 MFMA convolutions.
-NAMED_POLICIES = {"mixed": "proj=f16x3,score=f16x3,pv=fp16,conv=f16x3", "mixed_fp32conv": "proj=fp16,score=fp16,pv=fp16,conv=fp32",
+NAMED_POLICIES = {"mixed": "proj=f16x3,score=f16x3,pv=fp16,conv=f16x3,wgx=fp16", "mixed_fp32conv": "proj=fp16,score=fp16,pv=fp16,conv=fp32",
                   # training (activations and probabilities stay fp32 in memory; the roles select the MFMA operand mode of the
                   # forward AND backward contractions): everything fp32-class / bf16 MFMA for the cross- and self-attention
                   # contractions (BASELINE.json configs[4]: "bf16 MFMA cross-attention")
@@ -165,13 +171,16 @@ class Precision:
     pv    : attention apply O = P V (also the storage type of the probabilities P)
     conv  : update-block convolutions (motion encoder, SepConvGRU, flow / mask heads)
     enc   : the two CNN encoders' convolutions (defaults to ``conv`` when not given)
+    wgx   : (training) the ACTIVATION operand X of the weight-gradient products dW = dY^T X of f16x3 layers: "fp16" = X rounded to one
+            fp16 plane while dY keeps its hi / lo planes (2 MFMAs per product instead of 3, dW to ~2e-4 relative); default: the layer's mode
     Spec strings: "fp32" | "bf16" | "fp16" (all roles) or e.g. "score=bf16,pv=fp16,conv=fp32,proj=fp32"
     (unnamed roles default to fp32)."""
-    __slots__ = ("proj", "score", "pv", "conv", "enc")
+    __slots__ = ("proj", "score", "pv", "conv", "enc", "wgx")
 
-    def __init__(self, proj=PREC_F32, score=PREC_F32, pv=PREC_F32, conv=PREC_F32, enc=None):
+    def __init__(self, proj=PREC_F32, score=PREC_F32, pv=PREC_F32, conv=PREC_F32, enc=None, wgx=None):
         self.proj, self.score, self.pv, self.conv = proj, score, pv, conv
         self.enc = conv if enc is None else enc
+        self.wgx = wgx                   # None: every weight-gradient X operand in the mode of its layer
 
     @staticmethod
     def parse(spec) -> "Precision":
@@ -193,10 +202,12 @@ class Precision:
             seen.add(k.strip())
         if "enc" not in seen:
             p.enc = p.conv
+        if "wgx" not in seen:
+            p.wgx = None
         return p
 
     def __repr__(self):
-        inv = {0: "fp32", 1: "bf16", 2: "fp16", 3: "f16x3"}
+        inv = {0: "fp32", 1: "bf16", 2: "fp16", 3: "f16x3", None: "layer"}
         return ",".join(f"{k}={inv[getattr(self, k)]}" for k in self.__slots__)
 
 

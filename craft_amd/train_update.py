@@ -181,11 +181,12 @@ class UpdateIter(Function):
         mf = hx[..., MF:MF + 128]
         # packs of the motion encoder's conv inputs (for the weight gradients)
         g3, g7 = (B, H8, W8, 1, 1), (B, H8, W8, 3, 3)
-        S["pk_corr"] = AG.Packed(corr, cp, batch=pb)
-        S["pk_cor1"] = AG.Packed(S["cor1"], cp, g3, batch=pb)
-        S["pk_flow"] = AG.Packed(_flow32(flow, B, N), cp, g7, batch=pb)
-        S["pk_flo1"] = AG.Packed(S["flo1"], cp, g3, batch=pb)
-        S["pk_cf"] = AG.Packed(S["cf"], cp, g3, batch=pb)
+        xcp = AG.xprec(cp)                                                       # mode of the weight gradients' X operands (policy role wgx)
+        S["pk_corr"] = AG.Packed(corr, xcp, batch=pb)
+        S["pk_cor1"] = AG.Packed(S["cor1"], xcp, g3, batch=pb)
+        S["pk_flow"] = AG.Packed(_flow32(flow, B, N), xcp, g7, batch=pb)
+        S["pk_flo1"] = AG.Packed(S["flo1"], xcp, g3, batch=pb)
+        S["pk_cf"] = AG.Packed(S["cf"], xcp, g3, batch=pb)
         # ---- motion aggregator (update.py:143-149)
         P = ps.pholder.P
         Bp, M, _, ld = P.shape
@@ -217,7 +218,7 @@ class UpdateIter(Function):
         else:
             ops.gma_residual(mf, Oa.view(B, N, Cv), agg.gamma.detach(), out=hx[..., MFG:MFG + 128])
         S["va"], S["Oa"] = (va if ppk is None else None), Oa
-        S["pk_mf"] = AG.Packed(mf, pick(prec, "proj"), batch=pb)
+        S["pk_mf"] = AG.Packed(mf, AG.xprec(pick(prec, "proj")), batch=pb)
         # ---- SepConvGRU (update.py:49-64): horizontal pass h0 -> h1 (in HX_t), vertical pass h1 -> net_{t+1} (into HX_{t+1});
         # convolutions over [h | v], v = [mf | mfg]; inp's share and the biases arrive as per-pixel fields
         wzr1, wq1, wzr2, wq2 = ps.w_gru
@@ -235,12 +236,12 @@ class UpdateIter(Function):
             call("craft_conv2d_nhwc2", rh, 128, 128, v, _C, 256, wq, None, F_[..., fq:], 768, 128, KH, KW, ACT_NONE, q_pre, 256, B, H8, W8, cp | W_PACKED)
             q = torch.empty(B, N, 128, device=dev, dtype=torch.float32)
             call("craft_gru_out_fwd", q_pre, 256, z, h, _C, q, hn, _C, rows, 128)
-            S[f"pk_h{p_}"] = AG.Packed(h, cp, geom, batch=pb)
-            S[f"pk_rh{p_}"] = AG.Packed(rh, cp, geom, batch=pb)
-            S[f"pk_v{p_}"] = AG.Packed(v, cp, geom, batch=pb)                                  # shared by the z|r and the q convolution of this pass
+            S[f"pk_h{p_}"] = AG.Packed(h, xcp, geom, batch=pb)
+            S[f"pk_rh{p_}"] = AG.Packed(rh, xcp, geom, batch=pb)
+            S[f"pk_v{p_}"] = AG.Packed(v, xcp, geom, batch=pb)                                 # shared by the z|r and the q convolution of this pass
             S[f"z{p_}"], S[f"r{p_}"], S[f"q{p_}"] = z, r, q
         h2 = hxn[..., H0:H0 + 128]
-        S["pk_h2"] = AG.Packed(h2, cp, g3, batch=pb)
+        S["pk_h2"] = AG.Packed(h2, xcp, g3, batch=pb)
         # ---- heads (update.py:15-16, :124-127, :161) + coords1 += delta (network.py:247) + convex upsampling (:258)
         fh1 = torch.empty(B, N, 256, device=dev, dtype=torch.float32)
         c1n = coords1.clone()
@@ -251,8 +252,8 @@ class UpdateIter(Function):
         call("craft_mask_head", h2, _C, *ps.w_mask, B, H8, W8, mask, mh, cp | W_PACKED)
         up = ops.convex_upsample(mask, flow_new, H8, W8)
         S["fh1"], S["mh"], S["mask"], S["flow_new"] = fh1, mh, mask, flow_new
-        S["pk_fh1"] = AG.Packed(fh1, cp, g3, batch=pb)
-        S["pk_mh"] = AG.Packed(mh, cp, batch=pb)
+        S["pk_fh1"] = AG.Packed(fh1, xcp, g3, batch=pb)
+        S["pk_mh"] = AG.Packed(mh, xcp, batch=pb)
         pb.flush()
         ps.saved[t] = S
         ctx.ps, ctx.t = ps, t
@@ -343,7 +344,7 @@ class UpdateIter(Function):
             # ---- the hoisted inp channels: d_inp = sum over the four gate convolutions of conv^T(W_inp, sum_t dY_t), dW_inp = (sum_t dY_t)^T inp
             for p_, (KH, KW) in ((0, (1, 5)), (1, (5, 1))):
                 geom = (B, H8, W8, KH // 2, KW // 2)
-                pk_inp = AG.Packed(ps.inp, cp, geom)
+                pk_inp = AG.Packed(ps.inp, AG.xprec(cp), geom)
                 for kind, w_inp, co in (("zr", ps.wzrT_inp[p_], 256), ("q", ps.wqT_inp[p_], 128)):
                     g = ps.dysum.pop((kind, p_))
                     di = _conv_dx(ps, w_inp, g, co, KH, KW, cin_p=128)

@@ -385,7 +385,10 @@ int craft_colsum(const float* x, long ld, long rows, int C, float* out, void* st
  *   pointers -- the packs of the nseg calls of one layer in a pass (the update block runs every layer once per refinement iteration:
  *   their weight gradient is ONE launch over the concatenated K, one atomic epilogue per pass instead of one per iteration).
  *   Xp1 (or NULL) / cin0: the X operand as the channel concatenation of TWO packs over the same rows -- input channels [0, cin0) from
- *   Xp[s], [cin0, cin) from Xp1[s] (cat([h, x]) / cat([r*h, x]) of SepConvGRU: x is packed once per pass and shared by both gates). */
+ *   Xp[s], [cin0, cin) from Xp1[s] (cat([h, x]) / cat([r*h, x]) of SepConvGRU: x is packed once per pass and shared by both gates).
+ *   prec | CRAFT_WGRAD_X_PREC(CRAFT_PREC_F16) with prec = F16X3: the X packs hold ONE fp16 plane (X rounded to fp16) while dY keeps
+ *   its hi / lo planes -- two MFMAs per product instead of three (dW to ~2e-4 relative instead of ~2e-5). */
+#define CRAFT_WGRAD_X_PREC(p) (((p) + 1) << 8)
 int craft_pack_operand(const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
                        int prec, void* out, int cg_off, int ncg_total, float* colsum, int tail, void* stream);
 /* n craft_pack_operand calls as ONE launch (a training iteration packs ~14 convolution inputs of a few MB each: separate launches are

@@ -18,3 +18,13 @@ def device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _reset_training_globals():
+    """The mode of the weight gradients' X operands is a per-pass global set by forward_train (policy role `wgx`): operator-level tests
+    that follow a training pass in the same process must not inherit it."""
+    yield
+    mod = sys.modules.get("craft_amd.autograd")
+    if mod is not None:
+        mod.WGX[0] = None
