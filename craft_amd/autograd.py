@@ -832,6 +832,12 @@ def xprec(prec: int) -> int:
     return hip.PREC_F16 if (prec == hip.PREC_F16X3 and WGX[0] == hip.PREC_F16) else prec
 
 
+def dxflag(prec: int) -> int:
+    """CRAFT_CONV_W16 for the input-gradient convolution of a layer in ``prec`` when the policy's role wgx asks for one fp16 plane of the
+    non-gradient operand (here: the weights): two MFMAs per product, dY keeps both planes."""
+    return hip.CONV_W16 if (prec == hip.PREC_F16X3 and WGX[0] == hip.PREC_F16) else 0
+
+
 class PackBatch:
     """Queued craft_pack_operand calls, launched together by ``flush`` (craft_pack_operands)."""
 
@@ -944,7 +950,7 @@ class Conv(Function):
         if ctx.needs_input_grad[0]:
             wt, zb, flag, _ = _conv_weights(ctx.w, None, ctx.prec, cache, True)
             dxp = torch.empty(B, N, cin_p, device=dev, dtype=torch.float32)
-            call("craft_conv2d_nhwc", g, g.stride(-2), cout_p, wt, zb, cin_p, KH, KW, ACT_NONE, dxp, cin_p, B, H8, W8, ctx.prec | flag)
+            call("craft_conv2d_nhwc", g, g.stride(-2), cout_p, wt, zb, cin_p, KH, KW, ACT_NONE, dxp, cin_p, B, H8, W8, ctx.prec | flag | dxflag(ctx.prec))
             dx = dxp[..., :Cin] if cin_p != Cin else dxp
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         accb = _acc_buffer(cache, ctx.w, "db", (cout_p,), dev)[0] if want_db else None

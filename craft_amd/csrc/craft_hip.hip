@@ -189,6 +189,7 @@ int craft_gma_residual(const float* mf, long ldm, const float* O, const float* g
 
 #define PREC_OF(prec) ((prec) & 0xff)
 #define PACKED_OF(prec) ((((prec) >> 8) & 1) && PREC_OF(prec) != CRAFT_PREC_F32)
+#define W16_OF(prec) ((((prec) & CRAFT_CONV_W16) != 0) && PREC_OF(prec) == CRAFT_PREC_F16X3)
 
 static ConvGemmParams conv_params(const float* in0, int ld0, int c0, const float* in1, int ld1, int c1, int B, int H8, int W8,
                                   int KH, int KW, const float* W, const float* bias, int cout, int epi, int act, float scale,
@@ -353,6 +354,7 @@ int craft_conv2d_nhwc(const float* x, long ldx, int cin, const float* w, const f
   ConvGemmParams q = conv_params(x, (int)ldx, cin, nullptr, 0, 0, B, H, W, KH, KW, w, bias, cout, CONV_EPI_BIAS_ACT, act, 1.f, y,
                                  (int)ldy);
   q.w_packed = PACKED_OF(prec);
+  q.w16 = W16_OF(prec);
   return launch_gemm_conv(q, PREC_OF(prec), S(stream));
 }
 
@@ -370,6 +372,7 @@ int craft_conv2d_nhwc2(const float* x0, long ld0, int c0, const float* x1, long 
                                  (int)ldy);
   q.bias_field = bias_field; q.ld_bf = (int)ld_bf;
   q.w_packed = PACKED_OF(prec);
+  q.w16 = W16_OF(prec);
   return launch_gemm_conv(q, PREC_OF(prec), S(stream));
 }
 

@@ -35,7 +35,10 @@ template <int N> __device__ __forceinline__ void wf_interleave() {
 // TT: number of taps when known at compile time (5: 1x5 / 5x1, 9: 3x3; 0: run-time KH*KW).  With static taps the tap loop
 // is unrolled and the fp32 -> fp16-plane conversion of the next chunk's halo is cut into one piece per k-half, each in
 // the same scheduling region as that k-half's MFMAs (VALU work only hides behind MFMAs of the same wave).
-template <int PREC, int WM, int WN, bool ENC, int TT>
+// TERMS (f16x3 only): which terms of the split product run -- bit 0: lo(activation) x hi(weight), bit 1: hi(activation) x lo(weight),
+// bit 2: hi x hi.  7 = the fp32-class product.  5 = the WEIGHT operand as one fp16 plane (its lo plane is neither fetched nor multiplied:
+// two MFMAs per product): the input-gradient convolutions of the "mixed" training policy (CRAFT_CONV_W16; dY keeps both planes).
+template <int PREC, int WM, int WN, bool ENC, int TT, int TERMS = CRAFT_X3_TERMS>
 __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   typedef typename PrecT<PREC>::lds_t lds_t;
   typedef typename FragT<PREC>::t frag_t;
@@ -145,7 +148,8 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   auto fetch_b = [&](int kt, int kk, int slot) __attribute__((always_inline)) {
     const uint16_t* q = wb + kt * kt_stride + kk * 512;
 #pragma unroll
-    for (int pl = 0; pl < PL; ++pl) bq[pl][slot] = *reinterpret_cast<const frag_t*>(q + pl * 1024);
+    for (int pl = 0; pl < PL; ++pl)
+      if (pl == 0 || (TERMS & 2)) bq[pl][slot] = *reinterpret_cast<const frag_t*>(q + pl * 1024);
   };
 
   // lane's base halo element offsets for its MT output-row fragments
@@ -173,11 +177,11 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   // MFMAs of one k-half; term-major order so that consecutive MFMAs hit different accumulators
   auto mma_half = [&](const frag_t (&h)[MT], const frag_t (&l)[MT], int slot) __attribute__((always_inline)) {
     if constexpr (PL == 2) {
-      if constexpr (CRAFT_X3_TERMS & 1) {
+      if constexpr (TERMS & 1) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(l[mt], bq[0][slot], acc[mt][0]);
       }
-      if constexpr (CRAFT_X3_TERMS & 2) {
+      if constexpr (TERMS & 2) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(h[mt], bq[1][slot], acc[mt][0]);
       }
@@ -310,6 +314,7 @@ template <int PREC, int WM, int WN, int TT> static int launch_wf_tt(const ConvGe
   const int tiles = ((p.g.W + WF_PATCH_W - 1) / WF_PATCH_W) * ((p.g.H + WF_PATCH_H - 1) / WF_PATCH_H) * (p.g.npix / (p.g.H * p.g.W));
   dim3 grid(tiles, (ncols + BN - 1) / BN, 1);
   if (enc) hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, true, TT>), grid, dim3(NTHREADS), 0, s, p);
+  else if (PREC == CRAFT_PREC_F16X3 && TT > 0 && p.w16) hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, false, TT, 5>), grid, dim3(NTHREADS), 0, s, p);
   else hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, false, TT>), grid, dim3(NTHREADS), 0, s, p);
   return (int)hipGetLastError();
 }

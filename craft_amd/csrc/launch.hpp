@@ -47,6 +47,7 @@ struct ConvGemmParams {
   float* aux1; int ld1;
   int force_generic;     // 1: always use the generic implicit GEMM (k_gemm_conv), for A/B tests
   int w_packed;          // 1: W was produced by craft_pack_weights for this precision (halo kernel only)
+  int w16;               // 1 (f16x3, packed weights, static taps): use the weights' hi plane only -- CRAFT_CONV_W16, two MFMAs per product
   double* stats;         // optional [B][cout][2]: += (sum, sum^2) of the biased conv output per (image, channel)
   const float* bias_field; int ld_bf;   // optional per-pixel bias [npix][ld_bf] used INSTEAD of bias[col] (hoisted
                                         // iteration-invariant part of a conv: SepConvGRU context term)

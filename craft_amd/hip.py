@@ -16,6 +16,7 @@ ABI_VERSION = 2          # == CRAFT_HIP_ABI_VERSION (include/craft_hip.h): bumpe
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 W_PACKED = 0x100
+CONV_W16 = 0x400              # == CRAFT_CONV_W16: hi plane of the packed weights only (input-gradient convolutions, role wgx)
 
 
 def WGRAD_X_PREC(p: int) -> int:
@@ -171,8 +172,9 @@ class Precision:
     pv    : attention apply O = P V (also the storage type of the probabilities P)
     conv  : update-block convolutions (motion encoder, SepConvGRU, flow / mask heads)
     enc   : the two CNN encoders' convolutions (defaults to ``conv`` when not given)
-    wgx   : (training) the ACTIVATION operand X of the weight-gradient products dW = dY^T X of f16x3 layers: "fp16" = X rounded to one
-            fp16 plane while dY keeps its hi / lo planes (2 MFMAs per product instead of 3, dW to ~2e-4 relative); default: the layer's mode
+    wgx   : (training) the NON-gradient operand of the backward products of f16x3 layers -- the activations X in dW = dY^T X, the weights
+            W in dX = dY W^T: "fp16" = that operand rounded to one fp16 plane while dY keeps its hi / lo planes (2 MFMAs per product
+            instead of 3; dW / dX to ~2e-4 relative instead of ~2e-5); default: the layer's mode
     Spec strings: "fp32" | "bf16" | "fp16" (all roles) or e.g. "score=bf16,pv=fp16,conv=fp32,proj=fp32"
     (unnamed roles default to fp32)."""
     __slots__ = ("proj", "score", "pv", "conv", "enc", "wgx")

@@ -132,9 +132,10 @@ def _conv_dx(ps: UpdatePass, w, g, cout_p, KH, KW, out=None, cin_p=None, field=N
         out = torch.empty(ps.B, ps.N, cin_p, device=ps.dev, dtype=torch.float32)
     if field is not None:
         call("craft_conv2d_nhwc2", g, g.stride(-2), cout_p, None, 0, 0, wt, None, field, field.stride(-2), cin_p, KH, KW, ACT_NONE, out, out.stride(-2),
-             ps.B, ps.hw[0], ps.hw[1], ps.cp | flag)
+             ps.B, ps.hw[0], ps.hw[1], ps.cp | flag | AG.dxflag(ps.cp))
     else:
-        call("craft_conv2d_nhwc", g, g.stride(-2), cout_p, wt, zb, cin_p, KH, KW, ACT_NONE, out, out.stride(-2), ps.B, ps.hw[0], ps.hw[1], ps.cp | flag)
+        call("craft_conv2d_nhwc", g, g.stride(-2), cout_p, wt, zb, cin_p, KH, KW, ACT_NONE, out, out.stride(-2), ps.B, ps.hw[0], ps.hw[1],
+             ps.cp | flag | AG.dxflag(ps.cp))
     return out
 
 

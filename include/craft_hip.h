@@ -193,6 +193,11 @@ int craft_gma_residual(const float* mf, long ldm, const float* O, const float* g
  * 1x1 / tiny convs: wc1, wf1, flow-head w2, mask-head w2 stay raw fp32) when CRAFT_W_PACKED is or-ed into prec: a wave then
  * fetches the B operand of each 32x32x16 MFMA with one coalesced 1 KiB load and the K loop runs without per-tile barriers. */
 #define CRAFT_W_PACKED 0x100
+/* craft_conv2d_nhwc / craft_conv2d_nhwc2, prec = F16X3 | CRAFT_W_PACKED | CRAFT_CONV_W16: only the hi plane of the packed weights is
+ * used (the weights rounded to fp16, the input keeps both planes): two MFMAs per product instead of three.  For the INPUT-gradient
+ * convolutions of a training policy that asks for it (craft_amd.hip.Precision role `wgx`); stride-1 KxK with 5 or 9 taps, ignored
+ * elsewhere. */
+#define CRAFT_CONV_W16 0x400
 #define CRAFT_STATS_REPLICAS 64
 #define CRAFT_ATTN_CHUNK_KEYS 1024
 int craft_pack_weights(const float* w, int rows, int K, int prec, void* out, void* stream);

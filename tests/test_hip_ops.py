@@ -458,6 +458,33 @@ def test_conv2d_tokens(device, prec, KH, KW, cin, cout, relu):
         close(ops.tokens_to_nchw(y, H8, W8), ref, rt * 2, at * 4, f"conv {KH}x{KW} prec={prec} packed={packed}")
 
 
+@pytest.mark.parametrize("KH,KW,cin,cout", [(3, 3, 64, 192), (1, 5, 96, 256), (5, 1, 128, 128)])
+def test_conv2d_w16_is_the_full_product_on_fp16_weights(device, KH, KW, cin, cout):
+    """CRAFT_CONV_W16 (the input-gradient convolutions of the "mixed" training policy): f16x3 with only the hi plane of the packed
+    weights -- two MFMAs per product.  On weights that ARE fp16 numbers the dropped term is exactly zero, so the result must equal the
+    three-term kernel bit for bit; on arbitrary weights it is the convolution with the weights rounded to fp16 (~2e-4 relative)."""
+    from craft_amd.hip import call, CONV_W16, W_PACKED
+    B, H8, W8 = 2, 11, 21
+    x = gen(B, cin, H8, W8, seed=93)
+    w = gen(cout, cin, KH, KW, seed=94) / math.sqrt(cin * KH * KW)
+    b = gen(cout, seed=95)
+    xt = ops.tokens_from_nchw(x.to(device))
+
+    def run(wt, flag):
+        wp = ops.pack_conv_prec(wt.to(device), PREC_F16X3)
+        y = torch.empty(B, H8 * W8, cout, device=device)
+        call("craft_conv2d_nhwc", xt, xt.stride(-2), cin, wp, b.to(device), cout, KH, KW, ACT_NONE, y, cout, B, H8, W8, PREC_F16X3 | W_PACKED | flag)
+        return y
+    w16 = w.half().float()
+    assert torch.equal(run(w16, CONV_W16), run(w16, 0))
+    got = ops.tokens_to_nchw(run(w, CONV_W16), H8, W8).cpu()
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=(KH // 2, KW // 2)).float()
+    ref16 = F.conv2d(x.double(), w16.double(), b.double(), padding=(KH // 2, KW // 2)).float()
+    assert (got - ref16).abs().max().item() < 2e-5 * ref.abs().max().item()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert 1e-5 < rel < 6e-4, rel
+
+
 def test_forward_interpolate(device):
     """craft_forward_interpolate vs the reference's outputs (tests/golden/forward_interpolate.npz, generated by running
     utils.py:34-62) and vs the oracle on a batch of fresh flows, including one with no valid source."""
