@@ -321,12 +321,12 @@ def roofline_wgrad(step, policy, steps=2):
     ach = flop(key) / (ms * 1e-3) / 1e12
     from craft_amd.hip import PREC_F16, PREC_F16X3, Precision
     pol = Precision.parse(policy)
-    # MFMAs issued per product: 3 for f16x3 operands, 2 when the activation operand is one fp16 plane (policy role wgx = fp16: "mixed"), else 1
-    mult = (2 if pol.wgx == PREC_F16 else 3) if pol.conv == PREC_F16X3 else 1
+    # MFMAs issued per product of a weight gradient: 3 for f16x3 operands, 2 with the activations as one fp16 plane (role wgx), 1 with dY too (wgy: "mixed")
+    mult = (1 if pol.wgy == PREC_F16 else 2 if pol.wgx == PREC_F16 else 3) if pol.conv == PREC_F16X3 else 1
     traffic = None
     kern, cin, cout, KH, KW, rows, calls = key
     try:        # HBM bytes per launch from the PMC passes committed under profiles/r3 -- quoted only for the launch shape and operand mode profiled
-        with open(os.path.join(ROOT, "profiles", "r4" if mult == 2 else "r3", "pmc_traffic_wgrad.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r4" if mult < 3 else "r3", "pmc_traffic_wgrad.json")) as fh:
             pmc = json.load(fh)
         if list(pmc.get("shape", [])) == list(key[1:]) and pmc.get("kernel") == kern and pmc.get("mfmas_per_product", 3) == mult:
             traffic = int(pmc["hbm_bytes_per_launch"])

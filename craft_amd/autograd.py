@@ -203,7 +203,7 @@ class Linear(Function):
         if pk:
             co_p, ci_p = round_up(Cout, 32), round_up(Cin, 32)
             acc, _ = _acc_buffer(cache, wobj, "dw", (co_p, ci_p), x.device)
-            _wgrad_deferred(cache, wobj, last, (Packed(dy, pp, colsum=accb), Packed(x, xprec(pp))), 1, 1, acc)
+            _wgrad_deferred(cache, wobj, last, (Packed(dy, gprec(pp), colsum=accb), Packed(x, xprec(pp))), 1, 1, acc)
             dw = acc[:Cout, :Cin] if last else None
         elif ctx.needs_input_grad[1]:
             acc, _ = _acc_buffer(cache, wobj, "dw", (Cout, Cin), x.device)
@@ -822,20 +822,33 @@ def gemm_pk(A: PkMat, a_desc, B: PkMat, b_desc, C: torch.Tensor, ldc: int, c_out
          round_up(K, 32), float(alpha), A.prec)
 
 
-# Mode of the activation operand X of weight-gradient products (hip.Precision role `wgx`): set per training pass by
-# train_forward.forward_train.  [0] = PREC_F16: X packs of f16x3 layers hold one fp16 plane (2 MFMAs per product), None: the layer's mode.
-WGX = [None]
+# Operand modes of the backward products of f16x3 layers, set per training pass by train_forward.forward_train from the policy's roles
+# (hip.Precision): [0] = PREC_F16 -> one fp16 plane, None -> the layer's mode.
+#   WGX: the activation operand X of dW = dY^T X        WGY: its gradient operand dY (weight gradients are leaves of the backward graph:
+#   DXW: the weight operand of dX = dY W^T              their rounding error does not propagate; dY of the dX chain always keeps both planes)
+WGX, WGY, DXW = [None], [None], [None]
+
+
+def set_backward_modes(prec):
+    WGX[0], WGY[0], DXW[0] = getattr(prec, "wgx", None), getattr(prec, "wgy", None), getattr(prec, "dxw", None)
+    if WGY[0] == hip.PREC_F16:
+        WGX[0] = hip.PREC_F16               # (a one-plane dY beside a two-plane X is not an instantiation of k_gemm_pk)
 
 
 def xprec(prec: int) -> int:
-    """Pack mode of a weight gradient's X operand for a layer whose dY is packed in ``prec``."""
+    """Pack mode of a weight gradient's X operand for a layer whose mode is ``prec``."""
     return hip.PREC_F16 if (prec == hip.PREC_F16X3 and WGX[0] == hip.PREC_F16) else prec
 
 
+def gprec(prec: int) -> int:
+    """Pack mode of a weight gradient's dY operand for a layer whose mode is ``prec``."""
+    return hip.PREC_F16 if (prec == hip.PREC_F16X3 and WGY[0] == hip.PREC_F16) else prec
+
+
 def dxflag(prec: int) -> int:
-    """CRAFT_CONV_W16 for the input-gradient convolution of a layer in ``prec`` when the policy's role wgx asks for one fp16 plane of the
-    non-gradient operand (here: the weights): two MFMAs per product, dY keeps both planes."""
-    return hip.CONV_W16 if (prec == hip.PREC_F16X3 and WGX[0] == hip.PREC_F16) else 0
+    """CRAFT_CONV_W16 for the input-gradient convolution of a layer in ``prec`` when the policy's role dxw asks for one fp16 plane of the
+    weights: two MFMAs per product, dY keeps both planes."""
+    return hip.CONV_W16 if (prec == hip.PREC_F16X3 and DXW[0] == hip.PREC_F16) else 0
 
 
 class PackBatch:
@@ -905,7 +918,7 @@ def _conv_wgrad(xp, g, B, H8, W8, cin_p, cout_p, KH, KW, prec, db=None) -> torch
     dw = hip.zeros((cout_p, KH, KW, cin_p,), xp.device)
     if _use_pk(prec) and cin_p % 32 == 0 and cout_p % 32 == 0:
         geom = (B, H8, W8, KH // 2, KW // 2)
-        wgrad_pk([(Packed(g, prec, geom, colsum=db), Packed(xp, xprec(prec), geom))], KH, KW, dw)
+        wgrad_pk([(Packed(g, gprec(prec), geom, colsum=db), Packed(xp, xprec(prec), geom))], KH, KW, dw)
     else:
         call("craft_conv2d_wgrad", xp, xp.stride(-2), cin_p, g, g.stride(-2), cout_p, KH, KW, B, H8, W8, dw, db, None, 0, prec)
     return dw
@@ -959,7 +972,7 @@ class Conv(Function):
             if _use_pk(ctx.prec):
                 # packed operands (the bias gradient rides on the pack of dY)
                 geom = (B, H8, W8, KH // 2, KW // 2)
-                _wgrad_deferred(cache, ctx.w, last, (Packed(g, ctx.prec, geom, colsum=accb), Packed(xp, xprec(ctx.prec), geom)), KH, KW, acc)
+                _wgrad_deferred(cache, ctx.w, last, (Packed(g, gprec(ctx.prec), geom, colsum=accb), Packed(xp, xprec(ctx.prec), geom)), KH, KW, acc)
             else:
                 # (the bias gradient rides on the same launch: the blocks of tap 0 add the column sums of dY)
                 call("craft_conv2d_wgrad", xp, xp.stride(-2), cin_p, g, g.stride(-2), cout_p, KH, KW, B, H8, W8, acc, accb, None, 0, ctx.prec)

@@ -129,7 +129,7 @@ HOST_FUNCTIONS = {"craft_png_unfilter"}
 # plain fp16 storage + fp16 MFMA for the attention probabilities (P V); measured mean end-point deviation from the fp32
 # path < 1e-3 px at 448x1024 / 12 iters.  "mixed_fp32conv": fp16 attention contractions + exact
 # fp32 MFMA convolutions.
-NAMED_POLICIES = {"mixed": "proj=f16x3,score=f16x3,pv=fp16,conv=f16x3,wgx=fp16", "mixed_fp32conv": "proj=fp16,score=fp16,pv=fp16,conv=fp32",
+NAMED_POLICIES = {"mixed": "proj=f16x3,score=f16x3,pv=fp16,conv=f16x3,wgx=fp16,wgy=fp16,dxw=fp16", "mixed_fp32conv": "proj=fp16,score=fp16,pv=fp16,conv=fp32",
                   # training (activations and probabilities stay fp32 in memory; the roles select the MFMA operand mode of the
                   # forward AND backward contractions): everything fp32-class / bf16 MFMA for the cross- and self-attention
                   # contractions (BASELINE.json configs[4]: "bf16 MFMA cross-attention")
@@ -172,17 +172,21 @@ class Precision:
     pv    : attention apply O = P V (also the storage type of the probabilities P)
     conv  : update-block convolutions (motion encoder, SepConvGRU, flow / mask heads)
     enc   : the two CNN encoders' convolutions (defaults to ``conv`` when not given)
-    wgx   : (training) the NON-gradient operand of the backward products of f16x3 layers -- the activations X in dW = dY^T X, the weights
-            W in dX = dY W^T: "fp16" = that operand rounded to one fp16 plane while dY keeps its hi / lo planes (2 MFMAs per product
-            instead of 3; dW / dX to ~2e-4 relative instead of ~2e-5); default: the layer's mode
+    (training only) operand modes of the backward products of f16x3 layers; "fp16" = that operand rounded to ONE fp16 plane, default: the
+    layer's mode (both planes, three MFMAs per product):
+    wgx   : the activations X of the weight gradients dW = dY^T X          wgy : their gradient operand dY
+            (wgx alone: 2 MFMAs, dW to ~2e-4 relative instead of ~2e-5; both: 1 MFMA, plain fp16 products under the loss scale.  Weight
+            gradients are leaves of the backward graph: their rounding error does not propagate)
+    dxw   : the weights W of the input gradients dX = dY W^T (2 MFMAs; dY of the dX chain always keeps both planes)
     Spec strings: "fp32" | "bf16" | "fp16" (all roles) or e.g. "score=bf16,pv=fp16,conv=fp32,proj=fp32"
     (unnamed roles default to fp32)."""
-    __slots__ = ("proj", "score", "pv", "conv", "enc", "wgx")
+    __slots__ = ("proj", "score", "pv", "conv", "enc", "wgx", "wgy", "dxw")
+    BACKWARD_ROLES = ("wgx", "wgy", "dxw")
 
-    def __init__(self, proj=PREC_F32, score=PREC_F32, pv=PREC_F32, conv=PREC_F32, enc=None, wgx=None):
+    def __init__(self, proj=PREC_F32, score=PREC_F32, pv=PREC_F32, conv=PREC_F32, enc=None, wgx=None, wgy=None, dxw=None):
         self.proj, self.score, self.pv, self.conv = proj, score, pv, conv
         self.enc = conv if enc is None else enc
-        self.wgx = wgx                   # None: every weight-gradient X operand in the mode of its layer
+        self.wgx, self.wgy, self.dxw = wgx, wgy, dxw          # None: the operand in the mode of its layer
 
     @staticmethod
     def parse(spec) -> "Precision":
@@ -204,8 +208,9 @@ class Precision:
             seen.add(k.strip())
         if "enc" not in seen:
             p.enc = p.conv
-        if "wgx" not in seen:
-            p.wgx = None
+        for r in Precision.BACKWARD_ROLES:
+            if r not in seen:
+                setattr(p, r, None)
         return p
 
     def __repr__(self):

@@ -68,7 +68,7 @@ class Stem(Function):
             call("craft_stem_im2col", raw, B, H, W, cols)
             dwc = hip.zeros((64, 160,), raw.device)
             if AG._use_pk(ctx.prec):
-                AG.wgrad_pk([(AG.Packed(dy, ctx.prec), AG.Packed(cols, AG.xprec(ctx.prec)))], 1, 1, dwc)
+                AG.wgrad_pk([(AG.Packed(dy, AG.gprec(ctx.prec)), AG.Packed(cols, AG.xprec(ctx.prec)))], 1, 1, dwc)
             else:
                 AG.gemm(dy, 1, dy.stride(-2), 0, 0, cols, 1, 160, 0, 0, dwc, 160, 0, 0, 1, 1, 64, 160, P, accumulate=True, ksplit=0, prec=ctx.prec)
             dw = dwc[:, :147].reshape(64, 7, 7, 3).permute(0, 3, 1, 2)

@@ -46,9 +46,9 @@ def training_precision(prec, loss_scaled: bool = False):
         import warnings
         warnings.warn(f"craft_amd training: fp16 operand mode of role(s) {roles} promoted to f16x3 (no loss scale announced: train.Trainer "
                       "sets args.hip_loss_scaled; a bare loss.backward() should use a bf16 policy such as train_amp_bf16 for 16-bit operands)")
-    out = Precision(prec.proj, prec.score, prec.pv, prec.conv, prec.enc, prec.wgx)
+    out = Precision(prec.proj, prec.score, prec.pv, prec.conv, prec.enc, prec.wgx, prec.wgy, prec.dxw)
     for r in roles:
-        setattr(out, r, None if r == "wgx" else PREC_F16X3)
+        setattr(out, r, None if r in Precision.BACKWARD_ROLES else PREC_F16X3)
     return out
 
 
@@ -114,7 +114,7 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
     if not args.use_setrans and (model.att.heads != 1 or getattr(model.update_block.aggregator, "project", None) is not None):
         raise NotImplementedError("training gma.Aggregate with num_heads > 1 (head merge + project, gma.py:133-137) is not built")
     prec = training_precision(model.hip_prec(), bool(getattr(args, "hip_loss_scaled", False)))
-    AG.WGX[0] = getattr(prec, "wgx", None)           # mode of the weight gradients' activation operands for this pass
+    AG.set_backward_modes(prec)                      # operand modes of the backward products for this pass (roles wgx / wgy / dxw)
     B, _, H, W = image1.shape
     if H % 8 or W % 8:
         raise ValueError("image height and width must be multiples of 8")

@@ -292,16 +292,16 @@ class UpdateIter(Function):
             w2m = w2.detach().view(576, 256)
             d_mh = E(B, N, 256)
             AG.gemm(dm, 576, 1, 0, 0, w2m, 1, 256, 0, 0, d_mh, 256, 0, 0, 1, 1, rows, 256, 576, prec=cp)
-            ps.wgrad(("mask2",), (AG.Packed(dm, cp, colsum=ps.acc(("mask2", "db"), (576,)), batch=pb), S["pk_mh"]), 1, 1, ps.acc(("mask2", "dw"), (576, 256)), last)
+            ps.wgrad(("mask2",), (AG.Packed(dm, AG.gprec(cp), colsum=ps.acc(("mask2", "db"), (576,)), batch=pb), S["pk_mh"]), 1, 1, ps.acc(("mask2", "dw"), (576, 256)), last)
             g_mh = _act_bwd(d_mh, S["mh"], 256, out=d_mh)
             dh2 = _conv_dx(ps, ub.mask[0].weight, g_mh, 256, 3, 3, field=AG._rows(d_hn) if d_hn is not None else None)   # (+ the recurrence's share)
-            ps.wgrad(("mask0",), (AG.Packed(g_mh, cp, g3, colsum=ps.acc(("mask0", "db"), (256,)), batch=pb), S["pk_h2"]), 3, 3, ps.acc(("mask0", "dw"), (256, 3, 3, 128)), last)
+            ps.wgrad(("mask0",), (AG.Packed(g_mh, AG.gprec(cp), g3, colsum=ps.acc(("mask0", "db"), (256,)), batch=pb), S["pk_h2"]), 3, 3, ps.acc(("mask0", "dw"), (256, 3, 3, 128)), last)
             # ---- flow head: delta = conv2(relu(conv1(h2)))
             d_fh1 = _conv_dx(ps, fh.conv2.weight, dflow, 32, 3, 3)
-            ps.wgrad(("fh2",), (AG.Packed(dflow, cp, g3, colsum=ps.acc(("fh2", "db"), (32,)), batch=pb), S["pk_fh1"]), 3, 3, ps.acc(("fh2", "dw"), (32, 3, 3, 256)), last)
+            ps.wgrad(("fh2",), (AG.Packed(dflow, AG.gprec(cp), g3, colsum=ps.acc(("fh2", "db"), (32,)), batch=pb), S["pk_fh1"]), 3, 3, ps.acc(("fh2", "dw"), (32, 3, 3, 256)), last)
             g_fh1 = _act_bwd(d_fh1, S["fh1"], 256, out=d_fh1)
             _conv_dx(ps, fh.conv1.weight, g_fh1, 256, 3, 3, out=dh2, field=dh2)
-            ps.wgrad(("fh1",), (AG.Packed(g_fh1, cp, g3, colsum=ps.acc(("fh1", "db"), (256,)), batch=pb), S["pk_h2"]), 3, 3, ps.acc(("fh1", "dw"), (256, 3, 3, 128)), last)
+            ps.wgrad(("fh1",), (AG.Packed(g_fh1, AG.gprec(cp), g3, colsum=ps.acc(("fh1", "db"), (256,)), batch=pb), S["pk_h2"]), 3, 3, ps.acc(("fh1", "dw"), (256, 3, 3, 128)), last)
         elif d_hn is not None:
             dh2 = AG._c(d_hn).clone()
         for k in ("pk_h2", "pk_fh1", "pk_mh", "fh1", "mh", "mask", "flow_new"):
@@ -323,13 +323,13 @@ class UpdateIter(Function):
                 ps.dysum[("q", p_)], ps.dysum[("zr", p_)] = hip.zeros((B, N, 128), dev), hip.zeros((B, N, 256), dev)
             call("craft_gru_out_bwd", dh, dh.stride(-2), z, q, h, _C, dqp, dz, dhp, rows, 128, ps.dysum[("q", p_)])
             tq = _conv_dx(ps, ps.wqT[p_], dqp, 128, KH, KW, cin_p=384)                        # d[rh | mf | mfg]
-            ps.wgrad(("q", p_), (AG.Packed(dqp, cp, geom, colsum=ps.acc(("q", p_, "db"), (128,)), batch=pb), _cat_pack(S[f"pk_rh{p_}"], S[f"pk_v{p_}"])), KH, KW,
+            ps.wgrad(("q", p_), (AG.Packed(dqp, AG.gprec(cp), geom, colsum=ps.acc(("q", p_, "db"), (128,)), batch=pb), _cat_pack(S[f"pk_rh{p_}"], S[f"pk_v{p_}"])), KH, KW,
                      ps.acc(("q", p_, "dw"), (128, KH, KW, 384)), last)
             dzr = E(B, N, 256)
             # tq[:, :128] <- dhp + d(rh) r: tq is now [dh so far | d(mf, mfg) so far], the field the z|r convolution adds its own to
             call("craft_gru_zr_bwd", dz, tq, 384, z, r, h, _C, dzr, dhp, rows, 128, ps.dysum[("zr", p_)], tq, 384)
             _conv_dx(ps, ps.wzrT[p_], dzr, 256, KH, KW, cin_p=384, out=tq, field=tq)          # += d[h | mf | mfg]
-            ps.wgrad(("zr", p_), (AG.Packed(dzr, cp, geom, colsum=ps.acc(("zr", p_, "db"), (256,)), batch=pb), _cat_pack(S[f"pk_h{p_}"], S[f"pk_v{p_}"])), KH, KW,
+            ps.wgrad(("zr", p_), (AG.Packed(dzr, AG.gprec(cp), geom, colsum=ps.acc(("zr", p_, "db"), (256,)), batch=pb), _cat_pack(S[f"pk_h{p_}"], S[f"pk_v{p_}"])), KH, KW,
                      ps.acc(("zr", p_, "dw"), (256, KH, KW, 384)), last)
             dv = tq[..., 128:] if dv is None else torch.add(dv, tq[..., 128:])
             dh = tq[..., :128]
@@ -350,7 +350,7 @@ class UpdateIter(Function):
                     g = ps.dysum.pop((kind, p_))
                     di = _conv_dx(ps, w_inp, g, co, KH, KW, cin_p=128)
                     d_inp = di if d_inp is None else d_inp.add_(di)
-                    AG.wgrad_pk([(AG.Packed(g, cp, geom), pk_inp)], KH, KW, ps.acc((kind, p_, "dw_inp"), (co, KH, KW, 128)))
+                    AG.wgrad_pk([(AG.Packed(g, AG.gprec(cp), geom), pk_inp)], KH, KW, ps.acc((kind, p_, "dw_inp"), (co, KH, KW, 128)))
         if last:
             _phase2(ps)
         grads = _param_grads(ps) if last else (None,) * ctx.nparams
@@ -434,28 +434,28 @@ def _phase2(ps: UpdatePass):
         dva = dva5[:, :, :, t, :].reshape(B, N, M * Cv)              # M > 1: a contiguous copy; one mode: a strided view (row stride T*Cv)
         d_mf3 = E(B, N, 128)
         AG.gemm(dva, dva.stride(-2), 1, 0, 0, wv2, 1, 128, 0, 0, d_mf3, 128, 0, 0, 1, 1, rows, 128, M * Cv, prec=pp)
-        ps.wgrad(("agg_v",), (AG.Packed(dva, pp, batch=pb), S["pk_mf"]), 1, 1, ps.acc(("agg_v", "dw"), (M * Cv, 128)), last)
+        ps.wgrad(("agg_v",), (AG.Packed(dva, AG.gprec(pp), batch=pb), S["pk_mf"]), 1, 1, ps.acc(("agg_v", "dw"), (M * Cv, 128)), last)
         d_mf.add_(d_mf3).add_(ps.dv[t][..., 0:128])
         ps.dv[t] = None
         # ---- BasicMotionEncoder
         g_out = _act_bwd(d_mf, mf, 128, out=d_mf)
         g_out[..., 126:128] = 0.0                                                             # the two pass-through flow channels carry no gradient
         d_cf = _conv_dx(ps, enc.conv.weight, g_out, 128, 3, 3)
-        ps.wgrad(("menc",), (AG.Packed(g_out, cp, g3, colsum=ps.acc(("menc", "db"), (128,)), batch=pb), S["pk_cf"]), 3, 3, ps.acc(("menc", "dw"), (128, 3, 3, 256)), last)
+        ps.wgrad(("menc",), (AG.Packed(g_out, AG.gprec(cp), g3, colsum=ps.acc(("menc", "db"), (128,)), batch=pb), S["pk_cf"]), 3, 3, ps.acc(("menc", "dw"), (128, 3, 3, 256)), last)
         g_cf = _act_bwd(d_cf, S["cf"], 256, out=d_cf)
         g_c2, g_f2 = g_cf[..., :192], g_cf[..., 192:256]
         d_cor1 = _conv_dx(ps, enc.convc2.weight, g_c2, 192, 3, 3)
-        ps.wgrad(("c2",), (AG.Packed(g_c2, cp, g3, colsum=ps.acc(("c2", "db"), (192,)), batch=pb), S["pk_cor1"]), 3, 3, ps.acc(("c2", "dw"), (192, 3, 3, 256)), last)
+        ps.wgrad(("c2",), (AG.Packed(g_c2, AG.gprec(cp), g3, colsum=ps.acc(("c2", "db"), (192,)), batch=pb), S["pk_cor1"]), 3, 3, ps.acc(("c2", "dw"), (192, 3, 3, 256)), last)
         g_cor1 = _act_bwd(d_cor1, S["cor1"], 256, out=d_cor1)
         wc1 = enc.convc1.weight.detach().view(256, -1)
         cpl = wc1.shape[1]
         d_corr = E(B, N, cpl)
         AG.gemm(g_cor1, 256, 1, 0, 0, wc1, 1, cpl, 0, 0, d_corr, cpl, 0, 0, 1, 1, rows, cpl, 256, prec=cp)
-        ps.wgrad(("c1",), (AG.Packed(g_cor1, cp, colsum=ps.acc(("c1", "db"), (256,)), batch=pb), S["pk_corr"]), 1, 1, ps.acc(("c1", "dw"), (256, round_up(cpl, 32))), last)
+        ps.wgrad(("c1",), (AG.Packed(g_cor1, AG.gprec(cp), colsum=ps.acc(("c1", "db"), (256,)), batch=pb), S["pk_corr"]), 1, 1, ps.acc(("c1", "dw"), (256, round_up(cpl, 32))), last)
         d_flo1 = _conv_dx(ps, enc.convf2.weight, g_f2, 64, 3, 3)
-        ps.wgrad(("f2",), (AG.Packed(g_f2, cp, g3, colsum=ps.acc(("f2", "db"), (64,)), batch=pb), S["pk_flo1"]), 3, 3, ps.acc(("f2", "dw"), (64, 3, 3, 128)), last)
+        ps.wgrad(("f2",), (AG.Packed(g_f2, AG.gprec(cp), g3, colsum=ps.acc(("f2", "db"), (64,)), batch=pb), S["pk_flo1"]), 3, 3, ps.acc(("f2", "dw"), (64, 3, 3, 128)), last)
         g_flo1 = _act_bwd(d_flo1, S["flo1"], 128, out=d_flo1)
-        ps.wgrad(("f1",), (AG.Packed(g_flo1, cp, g7, colsum=ps.acc(("f1", "db"), (128,)), batch=pb), S["pk_flow"]), 7, 7, ps.acc(("f1", "dw"), (128, 7, 7, 32)), last)
+        ps.wgrad(("f1",), (AG.Packed(g_flo1, AG.gprec(cp), g7, colsum=ps.acc(("f1", "db"), (128,)), batch=pb), S["pk_flow"]), 7, 7, ps.acc(("f1", "dw"), (128, 7, 7, 32)), last)
         # ---- correlation lookup (corr.py:47-71): the gradient goes into the shared buffers of the normalised pyramid; autograd.CorrVolume
         # (every iteration took its token) folds them into the volume's gradient after this node
         AG.lookup_bwd(ps.holders, d_corr, S["coords"], ps.radius)
