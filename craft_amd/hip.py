@@ -134,7 +134,7 @@ NAMED_POLICIES = {"mixed": "proj=f16x3,score=f16x3,pv=fp16,conv=f16x3,wgx=fp16,w
                   # forward AND backward contractions): everything fp32-class / bf16 MFMA for the cross- and self-attention
                   # contractions (BASELINE.json configs[4]: "bf16 MFMA cross-attention")
                   "train_f16x3": "proj=f16x3,score=f16x3,pv=f16x3,conv=f16x3",
-                  "train_bf16attn": "proj=f16x3,score=bf16,pv=bf16,conv=f16x3",
+                  "train_bf16attn": "proj=f16x3,score=bf16,pv=bf16,conv=f16x3,wgx=fp16,wgy=fp16,dxw=fp16",
                   # + the two CNN encoders with bf16 MFMA operands (the reference's --mixed_precision runs fnet / cnet under fp16
                   # autocast, network.py:179-183; bf16 so that no loss scaling is needed).  With args.hip_encoders=False the
                   # PyTorch-ROCm modules run under torch.autocast(bfloat16) instead

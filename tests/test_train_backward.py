@@ -554,7 +554,9 @@ def test_bf16attn_step_at_configs4_shape_against_fp32_step(device):
     valid = torch.ones(B, H, W)
     out = {}
     for policy in ("train_f16x3", "train_bf16attn"):
-        model = CRAFT(default_args(hip_precision=policy, dropout_prob=0.0))
+        # (hip_loss_scaled as train.Trainer announces it: train_bf16attn then runs its weight gradients / input-gradient weights on single
+        # fp16 planes -- roles wgx / wgy / dxw -- exactly as `bench.py --train 4` times it)
+        model = CRAFT(default_args(hip_precision=policy, dropout_prob=0.0, hip_loss_scaled=True))
         model.load_state_dict(synth_state_dict(model.state_dict(), seed=78), strict=True)
         model = model.to(device).train()
         model.freeze_bn()
