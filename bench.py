@@ -135,13 +135,13 @@ def roofline_pv(model, im1, im2, iters, prec, forwards=3):
     bytes_alg = B * M * N * ldp * esz + B * M * Dv * ldp * esz + B * M * N * Dv * 4
     ach = bytes_alg / (ms * 1e-3) / 1e9
     # HBM bytes per launch from the committed PMC passes of this kernel (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
-    # separate runs, gfx950 x2 correction on FETCH_SIZE: profiles/r2/pmc_traffic_pv16.json).  Quoted only when the live launch is
+    # separate runs, gfx950 x2 correction on FETCH_SIZE: profiles/r4/pmc_traffic_pv16.json).  Quoted only when the live launch is
     # the profiled one: same shape, same element type AND the same kernel instantiation (rows per block chosen by the launcher's
     # cost function, replicated here) -- otherwise null rather than a stale constant.
     traffic = None
     try:
         import json as _json
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2", "pmc_traffic_pv16.json")) as fh:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r4", "pmc_traffic_pv16.json")) as fh:
             pmc = _json.load(fh)
         best, best_cost = 4, None
         for mt in (4, 5, 6, 7):           # launch_pv16 (kernels_gemm.hip): minimise resident rounds x rows per block
@@ -161,7 +161,7 @@ def roofline_pv(model, im1, im2, iters, prec, forwards=3):
             "bytes_per_launch": bytes_alg, "ms_per_launch": round(ms, 4), "launches_timed": len(evs),
             "note": "timed live around every launch of real forward passes (HIP events on the launch stream); algorithmic bytes "
                     "= P (fp16, read once) + V^T + O; traffic = HBM bytes per launch from the PMC passes committed under "
-                    "profiles/r2 (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; null when the live kernel instantiation is not the profiled one); measured read-only ceiling of this access pattern "
+                    "profiles/r4 (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; null when the live kernel instantiation is not the profiled one); measured read-only ceiling of this access pattern "
                     "on the same chip: 6.1 TB/s (tools/ubench/hbm_rows.hip)"}
 
 

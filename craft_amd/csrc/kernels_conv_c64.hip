@@ -19,7 +19,8 @@
 
 namespace craft {
 
-template <int PREC>
+// TERMS: as in k_conv_halo_wf (7 = three-term f16x3 product, 5 = the weights' hi plane only: CRAFT_CONV_W16, input-gradient convolutions)
+template <int PREC, int TERMS = CRAFT_X3_TERMS>
 __global__ __launch_bounds__(NTHREADS) void k_conv3x3_c64(ConvGemmParams p) {
   typedef typename PrecT<PREC>::lds_t lds_t;
   typedef typename FragT<PREC>::t frag_t;
@@ -46,7 +47,8 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_c64(ConvGemmParams p) {
     const int tap = step >> 2, c16 = step & 3;
     const uint16_t* q = wb + (long)(tap * 2 + (c16 >> 1)) * kt_stride + (c16 & 1) * 512;
 #pragma unroll
-    for (int pl = 0; pl < PL; ++pl) dst[pl] = *reinterpret_cast<const frag_t*>(q + pl * 1024);
+    for (int pl = 0; pl < PL; ++pl)
+      if (pl == 0 || (TERMS & 2)) dst[pl] = *reinterpret_cast<const frag_t*>(q + pl * 1024);
   };
   // lane's base halo element offsets for its MT output-row fragments
   int arow[MT];
@@ -165,11 +167,11 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_c64(ConvGemmParams p) {
       frag_t (&l)[MT] = al[s & 1];
       frag_t (&bw)[PL] = bfr[s % BDEPTH];
       if constexpr (PL == 2) {
-        if constexpr (CRAFT_X3_TERMS & 1) {
+        if constexpr (TERMS & 1) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(l[mt], bw[0], acc[mt][0]);
         }
-        if constexpr (CRAFT_X3_TERMS & 2) {
+        if constexpr (TERMS & 2) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(h[mt], bw[1], acc[mt][0]);
         }
@@ -217,6 +219,7 @@ int launch_conv3x3_c64(const ConvGemmParams& p, int prec, hipStream_t s) {
   dim3 grid(tiles < 512 ? tiles : 512, 1, 1);            // persistent: 2 blocks per CU
   if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_conv3x3_c64<CRAFT_PREC_BF16>), grid, dim3(NTHREADS), 0, s, p);
   else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_conv3x3_c64<CRAFT_PREC_F16>), grid, dim3(NTHREADS), 0, s, p);
+  else if (prec == CRAFT_PREC_F16X3 && p.w16) hipLaunchKernelGGL((k_conv3x3_c64<CRAFT_PREC_F16X3, 5>), grid, dim3(NTHREADS), 0, s, p);
   else if (prec == CRAFT_PREC_F16X3) hipLaunchKernelGGL((k_conv3x3_c64<CRAFT_PREC_F16X3>), grid, dim3(NTHREADS), 0, s, p);
   else return CRAFT_ERR_ARG;
   return (int)hipGetLastError();

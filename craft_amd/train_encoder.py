@@ -120,7 +120,7 @@ class EncConv(Function):
         if ctx.needs_input_grad[0]:
             wt, zb, flag, _ = AG._conv_weights(w, None, prec, ctx.cache, True)
             dx = torch.empty(B, Hin * Win, Cin, device=dev, dtype=torch.float32)
-            call("craft_conv2d_nhwc", g, g.stride(-2), Cout, wt, zb, Cin, KH, KW, ACT_NONE, dx, Cin, B, Hin, Win, prec | flag)
+            call("craft_conv2d_nhwc", g, g.stride(-2), Cout, wt, zb, Cin, KH, KW, ACT_NONE, dx, Cin, B, Hin, Win, prec | flag | AG.dxflag(prec))
         if ctx.needs_input_grad[2]:
             db = hip.zeros((Cout,), dev)
         # a bias in front of a statistics-normalised layer cannot move the loss: its gradient is exactly 0; otherwise the column sums

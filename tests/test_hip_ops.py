@@ -458,7 +458,7 @@ def test_conv2d_tokens(device, prec, KH, KW, cin, cout, relu):
         close(ops.tokens_to_nchw(y, H8, W8), ref, rt * 2, at * 4, f"conv {KH}x{KW} prec={prec} packed={packed}")
 
 
-@pytest.mark.parametrize("KH,KW,cin,cout", [(3, 3, 64, 192), (1, 5, 96, 256), (5, 1, 128, 128)])
+@pytest.mark.parametrize("KH,KW,cin,cout", [(3, 3, 64, 192), (1, 5, 96, 256), (5, 1, 128, 128), (3, 3, 64, 64)])      # (the last: k_conv3x3_c64)
 def test_conv2d_w16_is_the_full_product_on_fp16_weights(device, KH, KW, cin, cout):
     """CRAFT_CONV_W16 (the input-gradient convolutions of the "mixed" training policy): f16x3 with only the hi plane of the packed
     weights -- two MFMAs per product.  On weights that ARE fp16 numbers the dropped term is exactly zero, so the result must equal the
