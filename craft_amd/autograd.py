@@ -234,7 +234,20 @@ class Scores(Function):
         S = torch.empty(B, M, N, ld, device=q.device, dtype=torch.float32)
         sp = pick(prec, "score")
         ctx.M, ctx.scale, ctx.prec, ctx.link = M, scale, sp, None
-        if link is not None and sp != hip.PREC_F32 and d % 32 == 0:
+        bwd = getattr(prec, "sbw", None)
+        if link is not None and sp == hip.PREC_F16X3 and bwd in (hip.PREC_F16, hip.PREC_BF16) and d % 32 == 0:
+            # hybrid (policy role sbw): the scores themselves in f16x3 on the fp32-source engine (forward parity with inference), their
+            # GRADIENT products dQ = dS K, dK = dS^T Q on single-plane packs -- dS leaves the softmax backward as a 16-bit pack (half the
+            # bytes of the fp32 tensor) and the two products run on craft_gemm_pk
+            gemm(q, q.stride(-2), 1, N * q.stride(-2), d, k, k.stride(-2), 1, N * k.stride(-2), d, S, ld, M * N * ld, N * ld, M, B * M,
+                 N, N, d, alpha=scale, prec=sp)
+            qpk = PkMat(B, N, C, bwd, q.device).fill(q)
+            kpk = qpk if k is q else PkMat(B, N, C, bwd, q.device).fill(k)
+            link.want, link.prec = True, bwd
+            ctx.prec = bwd
+            ctx.link, ctx.packs, ctx.dims = link, (qpk, kpk), (B, N, C)
+            return S
+        if link is not None and sp != hip.PREC_F32 and sp != hip.PREC_F16X3 and d % 32 == 0:
             qpk = PkMat(B, N, C, sp, q.device).fill(q)                           # rows (b, i), channels (m, d)
             kpk = qpk if k is q else PkMat(B, N, C, sp, q.device).fill(k)
             cg = d // 32

@@ -46,7 +46,7 @@ def training_precision(prec, loss_scaled: bool = False):
         import warnings
         warnings.warn(f"craft_amd training: fp16 operand mode of role(s) {roles} promoted to f16x3 (no loss scale announced: train.Trainer "
                       "sets args.hip_loss_scaled; a bare loss.backward() should use a bf16 policy such as train_amp_bf16 for 16-bit operands)")
-    out = Precision(prec.proj, prec.score, prec.pv, prec.conv, prec.enc, prec.wgx, prec.wgy, prec.dxw)
+    out = Precision(prec.proj, prec.score, prec.pv, prec.conv, prec.enc, prec.wgx, prec.wgy, prec.dxw, prec.sbw)
     for r in roles:
         setattr(out, r, None if r in Precision.BACKWARD_ROLES else PREC_F16X3)
     return out
@@ -71,7 +71,7 @@ def _attention_probs(module, x_ln, hw, prec, p_attn: float, seed: int, pk_box=No
     # (measured +2 ms per step at configs[3] with it on: CRAFT_PK_SCORES=1 forces it for A/B runs)
     sp_ = AG.pick(prec, "score")
     link = None
-    if use_pk_attention(prec) and not os.environ.get("CRAFT_NO_PK_SCORES") and (sp_ in (PREC_BF16, PREC_F16) or os.environ.get("CRAFT_PK_SCORES")):
+    if use_pk_attention(prec) and not os.environ.get("CRAFT_NO_PK_SCORES") and (sp_ in (PREC_BF16, PREC_F16) or getattr(prec, "sbw", None) is not None):
         link = AG.ScoreLink()
     S = AG.Scores.apply(q, k, M, scale, prec, link)
     pk = None
