@@ -186,3 +186,25 @@ def test_training_driver_accepts_the_reference_command_lines():
               "f2_pos_code_weight", "f2_attn_mask_radius", "pos_bias_radius", "num_heads", "corr_radius", "dropout"):
         assert k in known and k in vars(d)
     assert (d.f2trans, d.lr, d.wdecay, d.batch_size, d.image_size, d.iters, d.clip, d.gamma) == ("full", 0.00002, 0.00005, 6, [384, 512], 12, 1.0, 0.8)
+
+
+def test_backward_operand_roles_of_the_policies():
+    """hip.Precision roles wgx / wgy / dxw / sbw: `mixed` and `train_bf16attn` run the backward's non-propagating products
+    on single fp16 planes -- under an announced loss scale only; without one (a bare loss.backward()) every fp16 role is promoted: the
+    forward roles to f16x3, the backward roles to "the layer's mode"."""
+    from craft_amd.hip import PREC_BF16, PREC_F16, PREC_F16X3, Precision
+    from craft_amd.train_forward import training_precision
+    m = Precision.parse("mixed")
+    assert (m.proj, m.score, m.pv, m.conv, m.enc) == (PREC_F16X3, PREC_F16X3, PREC_F16, PREC_F16X3, PREC_F16X3)
+    assert (m.wgx, m.wgy, m.dxw, m.sbw) == (PREC_F16,) * 4
+    b = Precision.parse("train_bf16attn")
+    assert (b.score, b.pv, b.conv, b.wgx, b.wgy, b.dxw, b.sbw) == (PREC_BF16, PREC_BF16, PREC_F16X3, PREC_F16, PREC_F16, PREC_F16, None)
+    f = Precision.parse("train_f16x3")
+    assert (f.wgx, f.wgy, f.dxw, f.sbw) == (None,) * 4 and Precision.parse("fp32").wgx is None
+    assert Precision.parse("proj=f16x3,conv=f16x3,wgx=fp16").wgy is None
+    assert training_precision(m, loss_scaled=True) is m
+    p = training_precision(m, loss_scaled=False)
+    assert p.pv == PREC_F16X3 and (p.wgx, p.wgy, p.dxw, p.sbw) == (None,) * 4 and p.conv == PREC_F16X3
+    pb = training_precision(b, loss_scaled=False)
+    assert pb.score == PREC_BF16 and (pb.wgx, pb.wgy, pb.dxw) == (None,) * 3
+    assert "wgx=fp16" in repr(m) and "wgx=layer" in repr(f)
