@@ -84,7 +84,7 @@ class TransCorrBlock(CorrBlock, nn.Module):
         if pyr is None or (pyr.B, pyr.H8, pyr.W8, pyr.tiled) != (B, H8, W8, tiled) or pyr.lv[0].device != q.device:
             pyr = self.pyramids[slot] = ops.CorrPyramid(B, H8, W8, self.num_levels, q.device, tiled=tiled)
         w_aggr = self._w_aggr(st) if st.num_modes > 1 else 1.0
-        ops.corr_build(q, k, H8, W8, st.num_modes, scale, self.vispos_encoder.pos_coder.biases, float(st.pos_code_weight),
+        ops.corr_build(q, k, H8, W8, st.num_modes, scale, self.vispos_encoder.pos_table, float(st.pos_code_weight),
                        w_aggr, mx, pyr, self.do_corr_global_norm, prec)
 
     def update_tokens(self, x1_ln: torch.Tensor, x2_ln: torch.Tensor, hw, prec: int, x1o_ln=None, x2o_ln=None):
@@ -105,9 +105,13 @@ class TransCorrBlock(CorrBlock, nn.Module):
     def update(self, fmap1, fmap2, fmap1o=None, fmap2o=None, coords1=None, coords2=None):
         """corr.py:148-189: single-way, or two-way when both fmap1o and fmap2o (the conv features) are given."""
         B, C, H8, W8 = fmap1.shape
-        x1 = ops.tokens_from_nchw(fmap1.float(), ln=True)
-        x2 = ops.tokens_from_nchw(fmap2.float(), ln=True)
+        enc, hw = self.vispos_encoder, (H8, W8)
+        pos1 = None
+        if coords1 is not None and enc.pos_code_type != "bias":          # corr.py:153: (x, y) grid coordinates -> (y, x) positions
+            pos1 = ops.tokens_from_nchw(coords1.float()).flip(-1)
+        tok = lambda f, pos=None: enc.ln_tokens(ops.tokens_from_nchw(f.float()), hw, pos)      # noqa: E731
+        x1, x2 = tok(fmap1, pos1), tok(fmap2, pos1)          # (frame 2 at coords1 too: the reference's eval-mode cache, setrans.py:744-758)
         two = fmap1o is not None and fmap2o is not None
-        x1o = ops.tokens_from_nchw(fmap1o.float(), ln=True) if two else None
-        x2o = ops.tokens_from_nchw(fmap2o.float(), ln=True) if two else None
+        x1o = tok(fmap1o, pos1) if two else None
+        x2o = tok(fmap2o, pos1) if two else None
         self.update_tokens(x1, x2, (H8, W8), getattr(self, "hip_prec", PREC_F32), x1o, x2o)

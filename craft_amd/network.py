@@ -181,7 +181,7 @@ class CRAFT(nn.Module):
         ops.tokens_slice(cn_tok, 0, 128, act=ACT_TANH, out=hx[..., 0:128])
         ops.tokens_slice(cn_tok, 128, 128, act=ACT_RELU, out=hx[..., 128:256])
         if self.args.use_setrans:
-            xc = ops.tokens_norm(hx[..., 128:256])
+            xc = self.att.vispos_encoder.ln_tokens(hx[..., 128:256], hw)
             attention = self.att.forward_tokens(xc, hw, prec=prec, defer=True)    # [B, 4, N, ldp] (+ row sums)
         else:
             attention = self.att.forward_tokens(hx[..., 128:256], hw, prec, defer=True)
@@ -254,16 +254,25 @@ class CRAFT(nn.Module):
                 attention, gru_fields = self._context_chain(cn_tok, hx, hw, prec)
 
             # ---- F2 transformer (network.py:185-187): tokens in, LayerNorm-ed tokens out ------------
-            x2 = ops.tokens_norm(f2_tok)
+            x2 = self.f2_trans.vispos_encoder.ln_tokens(f2_tok, hw)
             fmap2_t = self.f2_trans.forward_tokens(x2, hw, prec=prec)                 # [B, N, 256]
 
             # ---- correlation volume + pyramid (network.py:196-197, :225-228) ---------------------
             if args.craft:
-                x1 = ops.tokens_norm(f1_tok)
-                x2t = ops.tokens_norm(fmap2_t)
+                # the inter-frame encoder's tokens (corr.py:148-160): frame 1 at coords1 (= the grid, or grid + flow_init), frame 2 at the grid
+                venc = self.corr_fn.vispos_encoder
+                pos1 = None
+                if flow_init is not None and venc.pos_code_type != "bias":
+                    ys, xs = torch.meshgrid(torch.arange(H8, device=dev), torch.arange(W8, device=dev), indexing="ij")
+                    grid = torch.stack([ys, xs], dim=-1).reshape(1, N, 2).float()
+                    pos1 = grid + ops.tokens_from_nchw(flow_init.float()).flip(-1)          # (y, x)
+                # (the encoder keeps the reference's eval-mode code cache, setrans.py:744-758: the FIRST call of a shape decides the code
+                # of all later ones -- frame 2 of this pair and the next pairs of a warm-started sequence; see ln_tokens)
+                x1 = venc.ln_tokens(f1_tok, hw, pos1)
+                x2t = venc.ln_tokens(fmap2_t, hw)
                 if self.f1_trans is not None:       # two-way: (transformed 1, conv 2) and (conv 1, transformed 2)
-                    fmap1_t = self.f1_trans.forward_tokens(x1, hw, prec=prec)
-                    self.corr_fn.update_tokens(ops.tokens_norm(fmap1_t), x2t, hw, prec, x1, x2)
+                    fmap1_t = self.f1_trans.forward_tokens(self.f1_trans.vispos_encoder.ln_tokens(f1_tok, hw), hw, prec=prec)
+                    self.corr_fn.update_tokens(venc.ln_tokens(fmap1_t, hw, pos1), x2t, hw, prec, x1, venc.ln_tokens(f2_tok, hw))
                 else:
                     self.corr_fn.update_tokens(x1, x2t, hw, prec)
                 corr_fn = self.corr_fn

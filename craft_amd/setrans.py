@@ -90,17 +90,85 @@ class SlidingPosBiases2D(nn.Module):
         self.biases = nn.Parameter(torch.zeros(2 * pos_bias_radius + 1, 2 * pos_bias_radius + 1))
 
 
+class LearnedSinuPosEmbedder(nn.Module):
+    """Learnable sinusoidal positional embedding (setrans.py:624-646, `--interpos / --intrapos lsinu`):
+    E(p) = LayerNorm_C( interlace( sin(fc(p)[0::2]), cos(fc(p)[1::2]) ) ), fc = Linear(2, C), eps 1e-12, no affine.  A [N, C] table per
+    image size -- a handful of small torch ops (differentiable: the training path gets pos_fc's gradients from torch autograd), NOT a
+    hand-written kernel: the non-canonical positional code is supported for completeness, not tuned."""
+
+    def __init__(self, pos_dim: int, pos_embed_dim: int, omega: float = 1.0):
+        super().__init__()
+        self.pos_dim, self.pos_embed_dim, self.omega = pos_dim, pos_embed_dim, omega
+        self.pos_fc = nn.Linear(pos_dim, pos_embed_dim, bias=True)
+
+    def forward(self, pos_normed: torch.Tensor) -> torch.Tensor:
+        e0 = torch.nn.functional.linear(pos_normed, self.pos_fc.weight, self.pos_fc.bias)
+        mix = torch.stack((torch.sin(self.omega * e0[..., 0::2]), torch.cos(self.omega * e0[..., 1::2])), dim=-1).reshape(e0.shape)
+        return torch.nn.functional.layer_norm(mix, (self.pos_embed_dim,), None, None, 1e-12)
+
+
 class SETransInputFeatEncoder(nn.Module):
+    """Visual tokens + positional code -> LayerNorm-ed tokens (setrans.py:710-800).  `bias` (the released configuration): no embedding,
+    the [2R+1, 2R+1] table goes into the score kernels.  `lsinu`: tokens + pos_code_weight * E(position / max position) before the
+    LayerNorm, no score bias."""
+
     def __init__(self, config: SETransConfig):
         super().__init__()
-        if config.pos_code_type != "bias":
-            raise NotImplementedError("HIP path implements pos_code_type='bias' (the released configuration)")
         self.feat_dim = config.in_feat_dim
-        self.pos_coder = SlidingPosBiases2D(config.pos_dim, config.pos_bias_radius)
+        self.pos_code_type = config.pos_code_type
+        if config.pos_code_type == "bias":
+            self.pos_code_weight = 0.0
+            self.pos_coder = SlidingPosBiases2D(config.pos_dim, config.pos_bias_radius)
+        elif config.pos_code_type == "lsinu":
+            self.pos_code_weight = float(config.pos_code_weight)
+            self.pos_coder = LearnedSinuPosEmbedder(config.pos_dim, self.feat_dim, omega=1.0)
+        else:
+            raise NotImplementedError("HIP path implements pos_code_type 'bias' (the released configuration) and 'lsinu'")
+        self._code, self._code_key = None, None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.drop_code_cache())
+
+    @property
+    def pos_table(self):
+        """The score kernels' positional-bias table, or None (lsinu: setrans.py:781 pos_biases = None)."""
+        return self.pos_coder.biases if self.pos_code_type == "bias" else None
+
+    def embedding(self, hw, device, positions: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """pos_code_weight * E for the pixel grid of an H8 x W8 image ([N, C]) or for explicit (y, x) positions [B, N, 2] (the first
+        frame's coordinates after a flow_init, corr.py:153); None for `bias`.  Positions are divided by their maximum (setrans.py:772)."""
+        if self.pos_code_type == "bias":
+            return None
+        if positions is None:
+            H8, W8 = hw
+            ys, xs = torch.meshgrid(torch.arange(H8, device=device), torch.arange(W8, device=device), indexing="ij")
+            positions = torch.stack([ys, xs], dim=-1).reshape(H8 * W8, 2).float()
+        return self.pos_code_weight * self.pos_coder(positions / positions.max())
+
+    def ln_tokens(self, tok: torch.Tensor, hw, positions: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Raw tokens [B, N, C] -> LayerNorm-ed tokens (inference: no graph)."""
+        if self.pos_code_type == "bias":
+            return ops.tokens_norm(tok)
+        # the reference's eval-mode cache (setrans.py:744-758, pos_code_lookup_cache): the code is computed on the first call of a
+        # [B, N] shape and returned for every later call of that shape -- frame 2 of the same pair, and the following pairs of a
+        # warm-started sequence, get the FIRST call's code whatever their positions are.  Kept, because it decides the numbers the
+        # reference's evaluation produces; dropped on train() and on load_state_dict (the reference keeps a stale code there).
+        key = (tok.shape[0], tok.shape[1], tok.device)
+        if self._code_key != key:
+            with torch.no_grad():
+                self._code, self._code_key = self.embedding(hw, tok.device, positions), key
+        return ops.tokens_norm(tok + self._code)
+
+    def drop_code_cache(self):
+        self._code, self._code_key = None, None
+
+    def train(self, mode: bool = True):
+        self.drop_code_cache()
+        return super().train(mode)
 
     def forward(self, vis_feat: torch.Tensor) -> torch.Tensor:
         """NCHW -> LayerNorm-ed tokens [B, N, C] (setrans.py:791-795)."""
-        return ops.tokens_from_nchw(vis_feat, ln=True)
+        if self.pos_code_type == "bias":
+            return ops.tokens_from_nchw(vis_feat, ln=True)
+        return self.ln_tokens(ops.tokens_from_nchw(vis_feat), vis_feat.shape[-2:])
 
 
 class LearnedSoftAggregate(nn.Module):
@@ -173,7 +241,7 @@ class CrossAttFeatTrans(nn.Module):
         else:
             self.out_trans = ExpandedFeatTrans(config, name + "-out_trans")
         self.tie_qk_scheme = config.tie_qk_scheme
-        self.pos_code_weight = config.pos_code_weight if config.pos_code_type == "bias" else 1
+        self.pos_code_weight = config.pos_code_weight if config.pos_code_type == "bias" else 1      # (setrans.py:452: unused without a bias table)
         self.attn_clip = config.attn_clip
         self._init_weights()
 
@@ -246,7 +314,7 @@ class SelfAttVisPosTrans(nn.Module):
         self.vispos_encoder = SETransInputFeatEncoder(self.config)
 
     def forward_tokens(self, x_tokens_ln: torch.Tensor, hw, prec: Optional[int] = None, defer: bool = False):
-        return self.setrans(x_tokens_ln, pos_biases=self.vispos_encoder.pos_coder.biases,
+        return self.setrans(x_tokens_ln, pos_biases=self.vispos_encoder.pos_table,
                             attention_mask_radius=self.attn_mask_radius, hw=hw, prec=prec, defer=defer)
 
     def forward(self, x: torch.Tensor):

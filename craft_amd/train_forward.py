@@ -78,7 +78,7 @@ def _attention_probs(module, x_ln, hw, prec, p_attn: float, seed: int, pk_box=No
     if pk_box is not None:
         pk = AG.PkMat(S.shape[0] * S.shape[1], S.shape[2], S.shape[3], AG.pick(prec, "pv"), S.device)
         pk_box.append(pk)
-    return AG.AttnSoftmax.apply(S, module.vispos_encoder.pos_coder.biases, float(st.pos_code_weight), int(module.attn_mask_radius), mx, hw,
+    return AG.AttnSoftmax.apply(S, module.vispos_encoder.pos_table, float(st.pos_code_weight), int(module.attn_mask_radius), mx, hw,
                                 float(p_attn), int(seed), pk, link)
 
 
@@ -165,9 +165,15 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
 
     # ---- F2 transformer (network.py:185-187; setrans.py:578-619, 364-410); with --f1 shared | private the same block (the same
     # module or a private one, network.py:94-103) transforms frame 1 too (:180-183)
+    def ln_tok(enc, tok, positions=None):
+        """SETransInputFeatEncoder (setrans.py:763-800): LayerNorm of the tokens ('bias'), or of tokens + pos_code_weight * E ('lsinu': a
+        small differentiable torch branch -- pos_fc's gradients come from torch autograd, the LayerNorm backward is the kernel's)."""
+        e = enc.embedding(hw, tok.device, positions)
+        return AG.TokensNorm.apply(tok if e is None else tok + e, ACT_NONE, True)
+
     def feature_transformer(mod, tok, seed):
         c = mod.config
-        x = AG.dropout(AG.TokensNorm.apply(tok, ACT_NONE, True), p_hidden(c), seed)
+        x = AG.dropout(ln_tok(mod.vispos_encoder, tok), p_hidden(c), seed)
         ot = mod.setrans.out_trans
         pkb = [] if (use_pk_attention(prec) and (ot.first_linear.weight.shape[0] // mod.setrans.num_modes) % 32 == 0) else None
         Pm = _attention_probs(mod, x, hw, prec, p_attn(c), seed + 1, pkb)
@@ -187,22 +193,28 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
         scale = 1.0 / math.sqrt(st.attention_mode_dim)
         w_aggr = st.attn_softaggr.feat2score.weight if st.num_modes > 1 else torch.ones(1, 1, device=dev)
 
-        def vispos(tok, seed):                    # the correlation block's own input encoder: LayerNorm + dropout (setrans.py:791-795)
-            return AG.dropout(AG.TokensNorm.apply(tok, ACT_NONE, True), p_hidden(cc), seed)
+        pos1 = None                               # frame 1 is encoded at coords1 = grid + flow_init (corr.py:153); training recomputes the
+        if flow_init is not None and cf.vispos_encoder.pos_code_type != "bias":        # code per call, so frame 2 stays on the grid
+            ys, xs = torch.meshgrid(torch.arange(H8, device=dev), torch.arange(W8, device=dev), indexing="ij")
+            pos1 = torch.stack([ys, xs], dim=-1).reshape(1, N, 2).float() + ops.tokens_from_nchw(flow_init.detach().float()).flip(-1)
+
+        def vispos(tok, seed, positions=None):    # the correlation block's own input encoder: (+ embedding) LayerNorm + dropout (setrans.py:791-795)
+            return AG.dropout(ln_tok(cf.vispos_encoder, tok, positions), p_hidden(cc), seed)
 
         def volume(xq, xk):
             q = AG.Linear.apply(xq, st.query.weight, st.query.bias, prec)
             k = AG.Linear.apply(xk, st.key.weight, st.key.bias, prec)
             mx = ops.score_max(q.detach(), k.detach(), H8, W8, st.num_modes, scale, prec)
             Sc = AG.Scores.apply(q, k, st.num_modes, scale, prec)
-            return AG.CorrVolume.apply(Sc, cf.vispos_encoder.pos_coder.biases, w_aggr, float(st.pos_code_weight), mx, hw, box,
+            return AG.CorrVolume.apply(Sc, cf.vispos_encoder.pos_table, w_aggr, float(st.pos_code_weight), mx, hw, box,
                                        bool(cf.do_corr_global_norm))
 
         if fmap1_t is not None:
             # two-way correlation (corr.py:164-171): (transformed 1, conv 2) and (conv 1, transformed 2), concatenated per level
-            token = volume(vispos(fmap1_t, base_seed + 3), vispos(f2_tok, base_seed + 11)) + volume(vispos(f1_tok, base_seed + 12), vispos(fmap2_t, base_seed + 4))
+            token = (volume(vispos(fmap1_t, base_seed + 3, pos1), vispos(f2_tok, base_seed + 11))
+                     + volume(vispos(f1_tok, base_seed + 12, pos1), vispos(fmap2_t, base_seed + 4)))
         else:
-            token = volume(vispos(f1_tok, base_seed + 3), vispos(fmap2_t, base_seed + 4))
+            token = volume(vispos(f1_tok, base_seed + 3, pos1), vispos(fmap2_t, base_seed + 4))
         radius = cf.radius
     else:
         # CorrBlock (corr.py:17-45, :73-81): <fmap1, fmap2> / sqrt(256), no positional bias, no global LayerNorm, avg-pool pyramid
@@ -219,7 +231,7 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
     apk = [] if (fused and use_pk_attention(prec) and cv_agg % 32 == 0) else None       # (the packed P is consumed by train_update only)
     if args.use_setrans:
         ca = att.config
-        xc = AG.dropout(AG.TokensNorm.apply(inp, ACT_NONE, True), p_hidden(ca), base_seed + 5)
+        xc = AG.dropout(ln_tok(att.vispos_encoder, inp), p_hidden(ca), base_seed + 5)
         Patt = _attention_probs(att, xc, hw, prec, p_attn(ca), base_seed + 6, apk)
     else:
         # gma.Attention (gma.py:53-102): softmax(scale * q k^T) of the 1x1-conv projections of the context features, no dropout

@@ -54,6 +54,8 @@ class OracleConfig:
     num_heads: int = 1
     position_only: bool = False
     position_and_content: bool = False
+    inter_pos_code_type: str = "bias"       # 'bias' | 'lsinu' (train.py --interpos / --intrapos); the functions below read the type off the
+    intra_pos_code_type: str = "bias"       # state dict's keys (vispos_tokens), these two only let a test pass its overrides through
     extra: dict = field(default_factory=dict)
 
 
@@ -66,6 +68,32 @@ def tokens_layernorm(x_nchw: Tensor) -> Tensor:
     B, C, H, W = x_nchw.shape
     t = x_nchw.reshape(B, C, H * W).transpose(1, 2)
     return layernorm_lastdim(t)
+
+
+def vispos_tokens(x_nchw: Tensor, sd: Dict[str, Tensor], prefix: str, pos_w: float, positions: Optional[Tensor] = None) -> Tensor:
+    """SETransInputFeatEncoder.forward (setrans.py:763-800) for either positional-code type, chosen by the state dict's keys:
+    'bias' (``<prefix>.vispos_encoder.pos_coder.biases``): LayerNorm of the tokens, the table goes to the scores.
+    'lsinu' (``...pos_coder.pos_fc.weight``): tokens + pos_w * E(p / max p) before the LayerNorm, E = LearnedSinuPosEmbedder
+    (setrans.py:624-646: LayerNorm(interlace(sin(fc(p)[0::2]), cos(fc(p)[1::2]))), no affine, omega = 1); p = (y, x) grid indices
+    (gen_all_indices, setrans.py:32-39) or the given positions [B, N, 2]."""
+    B, C, H, W = x_nchw.shape
+    t = x_nchw.reshape(B, C, H * W).transpose(1, 2)
+    wk = f"{prefix}.vispos_encoder.pos_coder.pos_fc.weight"
+    if wk in sd:
+        if positions is None:
+            ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+            positions = torch.stack([ys, xs], dim=-1).reshape(1, H * W, 2).to(t.dtype).expand(B, -1, -1)
+        pn = positions / positions.max()                          # setrans.py:772
+        e0 = F.linear(pn, sd[wk], sd[f"{prefix}.vispos_encoder.pos_coder.pos_fc.bias"])
+        mix = torch.stack((torch.sin(e0[..., 0::2]), torch.cos(e0[..., 1::2])), dim=-1).reshape(e0.shape)
+        t = t + pos_w * layernorm_lastdim(mix)
+    return layernorm_lastdim(t)
+
+
+def pos_table_matrix(sd: Dict[str, Tensor], prefix: str, H8: int, W8: int):
+    """pos_w-free positional bias [N, N] of a 'bias' encoder; 0.0 for 'lsinu' (setrans.py:781: pos_biases = None)."""
+    k = f"{prefix}.vispos_encoder.pos_coder.biases"
+    return pos_bias_matrix(sd[k], H8, W8) if k in sd else 0.0
 
 
 def layernorm_lastdim(t: Tensor) -> Tensor:
@@ -137,16 +165,18 @@ def softaggr_scores(S: Tensor, w: Tensor) -> Tensor:
 # ------------------------------------------------------------------------------------------------
 # A2. inter-frame correlation volume + pyramid (corr.py:148-207)
 # ------------------------------------------------------------------------------------------------
-def inter_corr_raw(fmap1: Tensor, fmap2: Tensor, sd: Dict[str, Tensor], cfg: OracleConfig) -> Tensor:
-    """TransCorrBlock.corr before the global LayerNorm: [B, N, N] un-normalised c(i,j)."""
+def inter_corr_raw(fmap1: Tensor, fmap2: Tensor, sd: Dict[str, Tensor], cfg: OracleConfig, positions1: Optional[Tensor] = None,
+                   positions2: Optional[Tensor] = None) -> Tensor:
+    """TransCorrBlock.corr before the global LayerNorm: [B, N, N] un-normalised c(i,j).  positions1 / positions2: the two frames' (y, x)
+    positions when they are not the grid (only the 'lsinu' positional code reads them: coords1 = grid + flow_init, corr.py:153)."""
     B, C, H8, W8 = fmap1.shape
-    x1 = tokens_layernorm(fmap1)
-    x2 = tokens_layernorm(fmap2)
+    x1 = vispos_tokens(fmap1, sd, "corr_fn", cfg.inter_pos_code_weight, positions1)
+    x2 = vispos_tokens(fmap2, sd, "corr_fn", cfg.inter_pos_code_weight, positions2)
     W = sd["corr_fn.setrans.query.weight"]
     b = sd.get("corr_fn.setrans.query.bias")
     S = mm_scores(x1, x2, W, b, W, b, cfg.inter_num_modes)           # tied projection (:475-478)
     S = clamp_rule(S)
-    pb = pos_bias_matrix(sd["corr_fn.vispos_encoder.pos_coder.biases"], H8, W8)
+    pb = pos_table_matrix(sd, "corr_fn", H8, W8)
     S = S + cfg.inter_pos_code_weight * pb                            # setrans.py:538-540
     if cfg.inter_num_modes > 1:
         return softaggr_scores(S, sd["corr_fn.setrans.attn_softaggr.feat2score.weight"])
@@ -265,7 +295,8 @@ def self_attn_probs(x_tokens: Tensor, Wq: Tensor, Wk: Tensor, biases: Tensor, po
     """CrossAttFeatTrans with key_feat=query_feat up to the softmax (setrans.py:507-557). [B,M,N,N]"""
     S = mm_scores(x_tokens, x_tokens, Wq, None, Wk, None, M)
     S = clamp_rule(S)
-    S = S + pos_w * pos_bias_matrix(biases, H8, W8)
+    if biases is not None:
+        S = S + pos_w * pos_bias_matrix(biases, H8, W8)
     m = chebyshev_mask(H8, W8, mask_radius)
     if m is not None:
         S = S + m
@@ -275,9 +306,9 @@ def self_attn_probs(x_tokens: Tensor, Wq: Tensor, Wk: Tensor, biases: Tensor, po
 def f2_transform(fmap2: Tensor, sd: Dict[str, Tensor], cfg: OracleConfig, prefix: str = "f2_trans") -> Tensor:
     """A1: SelfAttVisPosTrans 'F2 transformer' (network.py:185-187; setrans.py:578-619).  NCHW->NCHW"""
     B, C, H8, W8 = fmap2.shape
-    x = tokens_layernorm(fmap2)
+    x = vispos_tokens(fmap2, sd, prefix, cfg.f2_pos_code_weight)
     P = self_attn_probs(x, sd[f"{prefix}.setrans.query.weight"], sd[f"{prefix}.setrans.key.weight"],
-                        sd[f"{prefix}.vispos_encoder.pos_coder.biases"], cfg.f2_pos_code_weight,
+                        sd.get(f"{prefix}.vispos_encoder.pos_coder.biases"), cfg.f2_pos_code_weight,
                         cfg.f2_num_modes, H8, W8, cfg.f2_attn_mask_radius)
     y = expanded_feat_trans(x, P,
                             sd[f"{prefix}.setrans.out_trans.first_linear.weight"],
@@ -289,9 +320,9 @@ def f2_transform(fmap2: Tensor, sd: Dict[str, Tensor], cfg: OracleConfig, prefix
 def intra_attention(inp_feat: Tensor, sd: Dict[str, Tensor], cfg: OracleConfig) -> Tensor:
     """A3: 'Intra-frame attention' probabilities (network.py:214).  [B,4,N,N]"""
     B, C, H8, W8 = inp_feat.shape
-    x = tokens_layernorm(inp_feat)
+    x = vispos_tokens(inp_feat, sd, "att", cfg.intra_pos_code_weight)
     return self_attn_probs(x, sd["att.setrans.query.weight"], sd["att.setrans.key.weight"],
-                           sd["att.vispos_encoder.pos_coder.biases"], cfg.intra_pos_code_weight,
+                           sd.get("att.vispos_encoder.pos_coder.biases"), cfg.intra_pos_code_weight,
                            cfg.intra_num_modes, H8, W8, -1)
 
 
@@ -449,9 +480,11 @@ def coords_grid(B: int, H8: int, W8: int, dtype=torch.float32) -> Tensor:
 # CRAFT.forward (network.py:164-267), eval mode
 # ------------------------------------------------------------------------------------------------
 def hot_path(fmap1: Tensor, fmap2: Tensor, net: Tensor, inp: Tensor, sd, cfg: OracleConfig, iters: int,
-             flow_init: Optional[Tensor] = None, test_mode: int = 1, capture: Optional[dict] = None):
+             flow_init: Optional[Tensor] = None, test_mode: int = 1, capture: Optional[dict] = None,
+             cached_positions: Optional[Tensor] = None, code_is_cached: bool = False):
     """Everything in CRAFT.forward after the CNN encoders: fmap1/fmap2 are fnet outputs, net/inp the
-    tanh/relu halves of cnet's output (network.py:185-267)."""
+    tanh/relu halves of cnet's output (network.py:185-267).  code_is_cached / cached_positions: the state of the inter-frame encoder's
+    eval-mode positional-code cache left by an earlier call of the same shape (cached_positions None = the grid); 'lsinu' only."""
     B, C, H8, W8 = fmap1.shape
     fmap2t = f2_transform(fmap2, sd, cfg) if cfg.f2trans != "none" else fmap2
     two_way = cfg.craft and cfg.f1trans != "none"
@@ -462,13 +495,23 @@ def hot_path(fmap1: Tensor, fmap2: Tensor, net: Tensor, inp: Tensor, sd, cfg: Or
         attention = intra_attention(inp, sd, cfg)
     else:
         attention = gma_attention(inp, sd, cfg.num_heads, cfg.position_only, cfg.position_and_content)
+    pos1 = None
+    if flow_init is not None:          # corr.py:153: frame 1 is encoded at coords1 = grid + flow_init, flipped to (y, x)
+        pos1 = (coords_grid(B, H8, W8, fmap1.dtype) + flow_init).permute(0, 2, 3, 1).flip(-1).reshape(B, H8 * W8, 2)
+    # EVAL-mode quirk of the reference (setrans.py:744-758, pos_code_lookup_cache): the positional code computed for frame 1 is cached
+    # by SHAPE and returned for frame 2 of the same call, so with a flow_init the second frame is encoded at coords1 as well (training
+    # mode recomputes per call and has no flow_init).  The cache also survives across calls of the same shape: a warm-started sequence
+    # (evaluate.py's Sintel submission) keeps the code of its FIRST call, which had no flow_init -> the grid.
+    if code_is_cached:
+        pos1 = cached_positions
+    pos2 = pos1
     if two_way:
-        c = [inter_corr_raw(fmap1t, fmap2, sd, cfg), inter_corr_raw(fmap1, fmap2t, sd, cfg)]
+        c = [inter_corr_raw(fmap1t, fmap2, sd, cfg, pos1, pos2), inter_corr_raw(fmap1, fmap2t, sd, cfg, pos1, pos2)]
         stats = [global_stats(ci) for ci in c]
         mu, rstd = [st[0] for st in stats], [st[1] for st in stats]
         pyr = [build_pyramid(ci, H8, W8, cfg.corr_levels) for ci in c]
     elif cfg.craft:
-        c = inter_corr_raw(fmap1, fmap2t, sd, cfg)
+        c = inter_corr_raw(fmap1, fmap2t, sd, cfg, pos1, pos2)
         mu, rstd = global_stats(c)
         pyr = build_pyramid(c, H8, W8, cfg.corr_levels)
     else:
@@ -499,8 +542,9 @@ def hot_path(fmap1: Tensor, fmap2: Tensor, net: Tensor, inp: Tensor, sd, cfg: Or
 
 
 def craft_forward(sd, cfg: OracleConfig, image1: Tensor, image2: Tensor, iters: int = 12,
-                  flow_init: Optional[Tensor] = None, test_mode: int = 1, capture: Optional[dict] = None):
-    """CRAFT.forward (network.py:164-267): images float32 [B,3,H,W] in 0..255."""
+                  flow_init: Optional[Tensor] = None, test_mode: int = 1, capture: Optional[dict] = None, code_is_cached: bool = False):
+    """CRAFT.forward (network.py:164-267): images float32 [B,3,H,W] in 0..255.  code_is_cached: an earlier call of this shape without a
+    flow_init filled the inter-frame encoder's positional-code cache (hot_path)."""
     with torch.no_grad():
         im1 = 2 * (image1 / 255.0) - 1.0
         im2 = 2 * (image2 / 255.0) - 1.0
@@ -512,7 +556,7 @@ def craft_forward(sd, cfg: OracleConfig, image1: Tensor, image2: Tensor, iters: 
         inp = torch.relu(cn[:, 128:])
         if capture is not None:
             capture.update(fmap1=fmap1, fmap2=fmap2, net0=net, inp=inp)
-        return hot_path(fmap1, fmap2, net, inp, sd, cfg, iters, flow_init, test_mode, capture)
+        return hot_path(fmap1, fmap2, net, inp, sd, cfg, iters, flow_init, test_mode, capture, None, code_is_cached)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -37,6 +37,8 @@ def test_forward_matches_reference_fp32(device, case):
     im1, im2 = g.images()
     fi = g.flow_init()
     with torch.no_grad():
+        if g.meta.get("warm"):      # the first pair of a warm-started sequence: no flow_init; it decides the cached lsinu code
+            model(im1.to(device), im2.to(device), iters=g.meta["iters"], test_mode=2)
         flow_lo, preds = model(im1.to(device), im2.to(device), iters=g.meta["iters"],
                                flow_init=None if fi is None else fi.to(device), test_mode=2)
     assert len(preds) == g.meta["iters"]

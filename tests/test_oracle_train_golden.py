@@ -19,7 +19,9 @@ TRAIN_CASES = ["train_b2_128x192_T3", "train_freezebn_b2_128x160_T2",
                "train_gma_b2_128x160_T2", "train_nocraft_b2_128x160_T2", "train_plaingma_b2_128x160_T2",
                # what CRAFT.forward accepts under model.train() beyond the shipped scripts: the two-way correlation of --f1 shared | private
                # (corr.py:164-171) and GMA's relative-position scores (gma.py:34-50, :84-98)
-               "train_f1shared_b2_128x160_T2", "train_f1private_b2_128x160_T2", "train_gmapos_b2_128x160_T2", "train_gmaposonly_b2_128x160_T2"]
+               "train_f1shared_b2_128x160_T2", "train_f1private_b2_128x160_T2", "train_gmapos_b2_128x160_T2", "train_gmaposonly_b2_128x160_T2",
+               # --interpos / --intrapos lsinu: the learned sinusoidal embedding and its pos_fc gradients
+               "train_lsinu_b2_128x160_T2"]
 
 
 def grad_scale(z):

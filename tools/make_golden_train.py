@@ -43,6 +43,10 @@ CASES = [
          qk_gain=2.5, freeze_bn=False, gamma=0.8),
     dict(name="train_gmaposonly_b2_128x160_T2", over=dict(use_setrans=False, position_only=True), B=2, H=128, W=160, iters=2, seed=71,
          qk_gain=2.5, freeze_bn=True, gamma=0.8),
+    # round 4: --interpos lsinu --intrapos lsinu (setrans.py:686-707, :763-800): the learned sinusoidal embedding added to the tokens
+    # before the LayerNorm, its pos_fc trained
+    dict(name="train_lsinu_b2_128x160_T2", over=dict(inter_pos_code_type="lsinu", intra_pos_code_type="lsinu"), B=2, H=128, W=160, iters=2,
+         seed=73, qk_gain=2.5, freeze_bn=False, gamma=0.8),
 ]
 
 
