@@ -236,14 +236,18 @@ def cpu_baseline(H, W, iters, threads):
         return None
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run
     (127.0.0.1 rendezvous on a free port), pass their output through, return the launcher's exit code."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
@@ -484,7 +488,13 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     dist = None
-    if world > 1:
+    force1 = world == 1 and os.environ.get("CRAFT_FORCE_COLLECTIVES", "0") not in ("", "0")
+    if force1:                            # a one-rank group: every collective of the N > 1 path runs (RCCL on a one-GPU box), see dist.py
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force1:
         import torch.distributed as dist
         dist.init_process_group(backend, init_method="env://")
 

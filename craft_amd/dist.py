@@ -24,6 +24,18 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
+def collective_group_active(group=None) -> bool:
+    """True when the data-parallel exchange has to run: a process group of more than one rank -- or of ONE rank with
+    CRAFT_FORCE_COLLECTIVES=1 in the environment, which makes every collective of the training step (the flat-gradient all-reduce,
+    the replica broadcasts, the timing protocol's reductions) execute on a one-GPU box: RCCL's communicator set-up and its kernels on
+    the device buffers run for real instead of being short-circuited (tests/test_bench_contract.py::test_rccl_world1_*)."""
+    import os
+    d = _dist()
+    if d is None:
+        return False
+    return d.get_world_size(group) > 1 or os.environ.get("CRAFT_FORCE_COLLECTIVES", "0") not in ("", "0")
+
+
 def timed_steps(step: Callable[[], None], steps: int, warmup: int, sync: Callable[[], None]) -> float:
     """`warmup` untimed steps, then exactly `steps` timed steps bracketed by barrier + device sync on both
     sides.  Returns this rank's elapsed seconds (which includes waiting for the slowest rank at the closing barrier)."""

@@ -15,6 +15,7 @@ from typing import Dict, Iterable, List, Optional
 
 import torch
 
+from .dist import collective_group_active
 from .hip import call
 
 MAX_FLOW = 400.0            # train.py:30
@@ -158,7 +159,7 @@ class FlatAdamW:
         """Sum the flat gradient over the data-parallel group (one collective); returns the 1/world factor that
         ``step`` folds into the update (train_ddp.py's DDP averages the gradients)."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not collective_group_active(group):
             return 1.0
         if dist.get_backend(group) == "gloo" and self.flat_grad.is_cuda:
             # test configuration (several ranks sharing one GPU over gloo): stage through the host; RCCL ("nccl") reduces in place
@@ -174,7 +175,7 @@ class FlatAdamW:
         train_ddp.py:196-200; the optimizer state matters after a resume that only one rank loaded): four collectives over the
         flat buffers."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not collective_group_active(group):
             return
         for t in (self.flat, self.exp_avg, self.exp_avg_sq, self._scaler):      # (the scaler record carries the applied-step count)
             _broadcast(t, src, group)
@@ -389,14 +390,14 @@ class Trainer:
         at construction and (broadcast_buffers=True, the default train_ddp.py:198-200 runs with) the buffers again before every
         forward -- cnet's BatchNorm running statistics are rank 0's everywhere.  Called here at construction; call it again after
         a checkpoint was loaded on one rank; ``sync_buffers`` alone before a validation pass (train_ddp.py's val_freq)."""
-        if self._world() > 1:
+        if collective_group_active(self.group):
             self.optimizer.broadcast_state(src, self.group)
             self.sync_buffers(src)
 
     def sync_buffers(self, src: int = 0):
         """BatchNorm running statistics (and every other module buffer) of rank ``src`` on all ranks: DDP's broadcast_buffers.
         The training forward in batch-statistics mode does not read them, so once per validation interval is enough."""
-        if self._world() > 1:
+        if collective_group_active(self.group):
             for b in self.model.buffers():
                 if b.is_floating_point() or b.dtype in (torch.int64, torch.int32):
                     _broadcast(b, src, self.group)
@@ -436,7 +437,7 @@ class Trainer:
         from .autograd import pending_uses
         if pending_uses(model.__dict__.get("_train_pass_cache")):
             raise RuntimeError("backward left accumulated weight gradients incomplete (a layer call was pruned from the graph)")
-        timed = self._world() > 1 and opt.flat_grad.is_cuda
+        timed = collective_group_active(self.group) and opt.flat_grad.is_cuda
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -461,7 +462,7 @@ class Trainer:
         snap = opt.scaler_snapshot()       # (float(loss) above drained the stream: this is the step just taken)
         if snap is not None:
             metrics.update(loss_scale=snap["loss_scale"], skipped_steps=snap["skipped_steps"], applied_steps=snap["applied_steps"])
-        if self._world() > 1:                                          # logged numbers: mean over ranks (train_ddp.py:84-94)
+        if collective_group_active(self.group):                        # logged numbers: mean over ranks (train_ddp.py:84-94)
             import torch.distributed as dist
             backend = dist.get_backend(self.group)
             t = torch.tensor([metrics["loss"], metrics["epe"]], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
