@@ -2,7 +2,7 @@
 """Random-shape parity sweep: craft_amd.CRAFT (HIP) vs the CPU oracle on seeded random (H, W, B, iters, flow_init,
 policy) draws at sizes the oracle finishes in about a second.  Prints one line per draw and a summary; exit code 1 if a
 draw exceeds the tolerance.  GPU box only (gpurun -- 'python tools/fuzz_parity.py 40 [seed0 [variants]]'; a third argument also
-draws the model variant: score clamp, GMA attention kinds, plain correlation, F2 mask, shared / private F1 transformer).
+draws the model variant: score clamp, GMA attention kinds, plain correlation, F2 mask, shared / private F1 transformer, lsinu positional code).
 """
 import os
 import sys
@@ -20,7 +20,9 @@ from oracle import craft_oracle as O  # noqa: E402
 # (model overrides, Q/K weight gain): the canonical model, the score clamp, and the reference's option variants
 VARIANTS = [({}, 2.5), ({}, 40.0), (dict(use_setrans=False), 2.5), (dict(craft=False), 2.5), (dict(f2_attn_mask_radius=5), 2.5),
             (dict(use_setrans=False, position_and_content=True), 2.5), (dict(use_setrans=False, position_only=True), 2.5),
-            (dict(f1trans="shared"), 2.5), (dict(f1trans="private"), 2.5)]
+            (dict(f1trans="shared"), 2.5), (dict(f1trans="private"), 2.5),
+            # --interpos / --intrapos lsinu (setrans.py:623-646, :763-800): learned sinusoidal embedding instead of the bias table
+            (dict(inter_pos_code_type="lsinu", intra_pos_code_type="lsinu"), 2.5), (dict(inter_pos_code_type="lsinu"), 2.5)]
 
 
 def sweep(n: int, seed0: int = 0, verbose: bool = True, variants: bool = False):
@@ -52,6 +54,7 @@ def sweep(n: int, seed0: int = 0, verbose: bool = True, variants: bool = False):
         H, W = 8 * H8, 8 * W8
         im1, im2, _ = synth_pair(B, H, W, seed=100 + i)
         fi = (2.0 * torch.randn(B, 2, H8, W8, generator=torch.Generator().manual_seed(i))) if use_init else None
+        model.eval()           # (a fresh call: drops the lsinu encoders' eval-mode code cache, which would carry over from an earlier draw of the shape)
         with torch.no_grad():
             lo, up = model(im1.to(dev), im2.to(dev), iters=iters, flow_init=None if fi is None else fi.to(dev), test_mode=1)
         lo_ref, up_ref = O.craft_forward(sd, cfg, im1, im2, iters=iters, flow_init=fi, test_mode=1)
