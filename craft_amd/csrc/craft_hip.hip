@@ -148,7 +148,7 @@ int craft_attn_probs_fused(const float* q, long ldq, const float* k, long ldk, i
                            float* rowsum, void* ws, int p_prec, int prec, void* stream) {
   ScoreParams sp = make_score(q, ldq, k, ldk, B, H8, W8, M, d, scale, pos_tab, R, pos_w, mask_radius, clamp_ord);
   sp.rowsum = rowsum;
-  return launch_attn_probs_fused(sp, P, ldp, ws, p_prec, prec, S(stream));
+  return launch_attn_probs_fused(sp, P, ldp, ws, p_prec & ~CRAFT_P_TILED, prec, (p_prec & CRAFT_P_TILED) ? 1 : 0, S(stream));
 }
 
 int craft_flash_attention(const float* q, long ldq, const float* k, long ldk, const void* vT, long ldt, int B, int H8, int W8,
@@ -162,8 +162,14 @@ int craft_attn_apply(const void* P, long ldp, const float* rowsum, const void* v
                      int prec, void* stream) {
   RowsGemmParams p = {};
   p.row_div = rowsum; p.rd_bs = N;
-  p.A = P; p.lda = ldp; p.a_bs0 = (long)M * N * ldp; p.a_bs1 = (long)N * ldp;
-  p.B = vT; p.ldb = ldp; p.b_bs0 = (long)M * Dv * ldp; p.b_bs1 = (long)Dv * ldp;
+  const bool tiled = (prec & CRAFT_P_TILED) != 0;
+  prec &= ~CRAFT_P_TILED;
+  // tiled P: [B][M][ceil(N/32)] bands of 32 rows x ldp keys; V^T keeps its own key extent (N rounded up to 32)
+  const long p_rows = tiled ? ((long)N + 31) / 32 * 32 : N, ldt = tiled ? ((long)N + 31) / 32 * 32 : ldp;
+  if (tiled && (prec == CRAFT_PREC_F32 || ldp % 64 || ldp < N)) return CRAFT_ERR_ALIGN;
+  p.a_tiled = tiled ? 1 : 0;
+  p.A = P; p.lda = ldp; p.a_bs0 = (long)M * p_rows * ldp; p.a_bs1 = p_rows * ldp;
+  p.B = vT; p.ldb = ldt; p.b_bs0 = (long)M * Dv * ldt; p.b_bs1 = (long)Dv * ldt;
   p.C = O; p.ldc = Dv; p.c_bs0 = (long)M * N * Dv; p.c_bs1 = (long)N * Dv;
   p.zdiv = M; p.batch = B * M; p.M = N; p.N = Dv; p.K = (int)ldp;
   p.bias = nullptr; p.scale = 1.f; p.act = CRAFT_ACT_NONE;

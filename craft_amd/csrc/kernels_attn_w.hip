@@ -61,7 +61,9 @@ constexpr int AW_TABW = 33;
 constexpr int AW_PLD = 128 + 8;       // halves per staged row: 272 B (16-byte aligned rows)
 
 // X3: f16x3 scores (hi*hi + hi*lo + lo*hi), else plain fp16 (hi planes only)
-template <bool X3, typename prob_t>
+// TILED: P' in 32-query x 64-key tiles (CRAFT_P_TILED: element (i, j) at (i >> 5) * 32 * ldp + (j >> 6) * 2048 + (i & 31) * 64 + (j & 63)) --
+// the wave's 128-key step is then 8 KiB of contiguous lines, and what k_pv16 reads per band and K-tile one contiguous 4 KiB
+template <bool X3, typename prob_t, bool TILED>
 __global__ __launch_bounds__(256, CRAFT_AW_WAVES) void k_attn_probs_w(ScoreParams p, const _Float16* __restrict__ Kp, prob_t* __restrict__ P, long ldp,
                                                       int nt32, unsigned w8_magic) {
   __shared__ float s_tab[AW_TABW * AW_TABW];
@@ -235,7 +237,8 @@ __global__ __launch_bounds__(256, CRAFT_AW_WAVES) void k_attn_probs_w(ScoreParam
   __builtin_amdgcn_sched_barrier(0);
   fetch_half(fa0, 2);
   const int srow = lane >> 4, sch = lane & 15;       // store mapping: 4 rows x 16 chunks of 16 bytes per instruction (256-byte row segments)
-  prob_t* Pw = P + ((long)z * N + q0) * ldp + sch * 8;
+  // (tiled: band qg of entry z, whose padded row count is 32 * ceil(N / 32); chunk sch -> 64-key half sch >> 3, 16 bytes (sch & 7))
+  prob_t* Pw = TILED ? P + ((long)z * ((N + 31) >> 5) + qg) * 32 * ldp + (sch >> 3) * 2048 + (sch & 7) * 8 : P + ((long)z * N + q0) * ldp + sch * 8;
   for (int t32 = 0; t32 < nt32; t32 += 4) {          // nt32 is a multiple of 4: one 128-key tile of P' per iteration
 #pragma unroll
     for (int hp = 0; hp < 2; ++hp) {
@@ -258,8 +261,9 @@ __global__ __launch_bounds__(256, CRAFT_AW_WAVES) void k_attn_probs_w(ScoreParam
       const u32x4 v = *reinterpret_cast<const u32x4*>(&Tw[row * AW_PLD + sch * 8]);
       if (jok && q0 + row < N && !(CRAFT_AW_DBG & 1)) {
         // non-temporal: P' (1.6 GB at 448x1024, batch 4) is read back long after this kernel; measured 0.72 -> 0.625 ms
-        if (CRAFT_AW_DBG & 8) *reinterpret_cast<u32x4*>(Pw + (long)row * ldp + j0) = v;
-        else __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(Pw + (long)row * ldp + j0));
+        prob_t* dst = TILED ? Pw + (long)(t32 >> 2) * 4096 + row * 64 : Pw + (long)row * ldp + j0;
+        if (CRAFT_AW_DBG & 8) *reinterpret_cast<u32x4*>(dst) = v;
+        else __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -268,12 +272,12 @@ __global__ __launch_bounds__(256, CRAFT_AW_WAVES) void k_attn_probs_w(ScoreParam
   if (lane < 32 && qcol < N) p.rowsum[(long)z * N + qcol] = l;
 }
 
-int launch_attn_probs_fused(const ScoreParams& p, void* P, long ldp, void* ws, int p_prec, int prec, hipStream_t s) {
+int launch_attn_probs_fused(const ScoreParams& p, void* P, long ldp, void* ws, int p_prec, int prec, int tiled, hipStream_t s) {
   if (p.d != 32 || p.rb_h != nullptr || p.rowsum == nullptr || ws == nullptr) return CRAFT_ERR_UNSUPPORTED;
   if (prec != CRAFT_PREC_F16X3 && prec != CRAFT_PREC_F16) return CRAFT_ERR_UNSUPPORTED;
   if (p_prec != CRAFT_PREC_F16 && p_prec != CRAFT_PREC_BF16) return CRAFT_ERR_UNSUPPORTED;
   if (p.N >= 65536 || p.N < 1) return CRAFT_ERR_UNSUPPORTED;                       // (umulhi division of key indices)
-  if (ldp % 32 || ldp < p.N || (p.ldq & 3) || (p.ldk & 3) || (p.q_bs & 3) || (p.k_bs & 3)) return CRAFT_ERR_ALIGN;
+  if (ldp % (tiled ? 64 : 32) || ldp < p.N || (p.ldq & 3) || (p.ldk & 3) || (p.q_bs & 3) || (p.k_bs & 3)) return CRAFT_ERR_ALIGN;
   if (p.mask_radius > 15 || (p.pos_tab && p.R > 15)) return CRAFT_ERR_UNSUPPORTED;
   const int nt32 = (p.N + 127) / 128 * 4, BM = p.B * p.M;
   _Float16* Kp = reinterpret_cast<_Float16*>(ws);
@@ -282,10 +286,12 @@ int launch_attn_probs_fused(const ScoreParams& p, void* P, long ldp, void* ws, i
   const unsigned magic = (unsigned)((0x100000000ull + (unsigned)p.W8 - 1) / (unsigned)p.W8);
   const int nqg = (p.N + 31) / 32;
   dim3 grid((unsigned)(((nqg + 3) / 4) * BM));
-#define GO(X3, PT) hipLaunchKernelGGL((k_attn_probs_w<X3, PT>), grid, dim3(256), 0, s, p, Kp, reinterpret_cast<PT*>(P), ldp, nt32, magic)
+#define GO1(X3, PT, TL) hipLaunchKernelGGL((k_attn_probs_w<X3, PT, TL>), grid, dim3(256), 0, s, p, Kp, reinterpret_cast<PT*>(P), ldp, nt32, magic)
+#define GO(X3, PT) do { if (tiled) GO1(X3, PT, true); else GO1(X3, PT, false); } while (0)
   if (prec == CRAFT_PREC_F16X3) { if (p_prec == CRAFT_PREC_F16) GO(true, _Float16); else GO(true, __bf16); }
   else { if (p_prec == CRAFT_PREC_F16) GO(false, _Float16); else GO(false, __bf16); }
 #undef GO
+#undef GO1
   return (int)hipGetLastError();
 }
 

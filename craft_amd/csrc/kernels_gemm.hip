@@ -130,21 +130,24 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
   const int m0 = bx * BM, n0 = (byz % gy) * 128, z = byz / gy;
   const int z0 = z / p.zdiv, z1 = z - z0 * p.zdiv;
   const uint16_t* A = reinterpret_cast<const uint16_t*>(p.A) + z0 * p.a_bs0 + z1 * p.a_bs1;
-  const int NB = p.N / 32, ng = p.K / 16;
+  const int NB = p.N / 32, ng = (int)(p.ldb / 16);
   const uint16_t* Bf = reinterpret_cast<const uint16_t*>(p.B) + z0 * p.b_bs0 + z1 * p.b_bs1 + (long)(n0 / 32 + wave) * 512 + lane * 8;
   const long g_stride = (long)NB * 512;
   const int c8 = tid & 7, r0 = tid >> 3;
   const uint16_t* pa[MT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) pa[i] = A + (long)min(m0 + r0 + 32 * i, p.M - 1) * p.lda;    // clamped: unconditional loads
+  for (int i = 0; i < MT; ++i)                                                              // clamped: unconditional loads
+    pa[i] = p.a_tiled ? A + (long)min(bx * MT + i, (p.M - 1) >> 5) * 32 * p.lda + tid * 8 : A + (long)min(m0 + r0 + 32 * i, p.M - 1) * p.lda;
   const int nk = (p.K + KT - 1) / KT;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   typedef typename std::conditional<PREC == CRAFT_PREC_BF16, bf16x8, f16x8>::type frag_t;
   u32x4 va0[MT], va1[MT];
   frag_t bq[4];
   auto fetch_a = [&](int kt, u32x4 (&va)[MT]) __attribute__((always_inline)) {
+    // tiled P: the block's 32 rows x 64 keys of a band are one contiguous 4 KiB (DRAM pages stay open; row-major P is 32 x 128 B
+    // segments 2 * ldp bytes apart, one DRAM row activation each)
     const int k = min(kt, nk - 1) * KT + c8 * 8;
-    const int kc = k < p.K ? k : p.K - 8;
+    const long kc = p.a_tiled ? (long)min(kt, nk - 1) * (32 * KT) : (long)(k < p.K ? k : p.K - 8);
 #pragma unroll
     for (int i = 0; i < MT; ++i) va[i] = *reinterpret_cast<const u32x4*>(pa[i] + kc);
   };
@@ -220,7 +223,8 @@ template <int PREC, int MT> static void launch_pv_t(const RowsGemmParams& p, hip
 
 int launch_pv16(const RowsGemmParams& p, int prec, int rows32, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return 0;
-  if ((p.K & 15) || (p.lda & 7) || (p.N & 127) || p.c_dtype != CRAFT_PREC_F32) return CRAFT_ERR_ALIGN;
+  if ((p.K & 15) || (p.lda & 7) || (p.ldb & 15) || (p.N & 127) || p.c_dtype != CRAFT_PREC_F32) return CRAFT_ERR_ALIGN;
+  if (p.a_tiled && ((p.K & 63) || p.lda != p.K)) return CRAFT_ERR_ALIGN;
   // rows per block: minimise (resident rounds) x (work per block).  Blocks per CU from the register / LDS budget of
   // each instantiation (MT = 4: 3, MT >= 5: 2).
   int best = 4; long best_cost = -1;

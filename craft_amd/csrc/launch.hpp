@@ -31,6 +31,8 @@ struct RowsGemmParams {
   int c_frag;            // > 0: C (16-bit) is stored in MFMA B-fragment order per group of c_frag rows (k_pv16's V^T operand)
   int c_frag_acc;        // with c_frag: the 16 rows (keys) of a k-group are enumerated in MFMA ACCUMULATOR order
                          // (position 8*h + j <-> key 8*(j >> 2) + 4*h + (j & 3)): k_flash_attn's V^T operand
+  int a_tiled;           // k_pv16: A (= P) in 32-row x 64-key tiles (CRAFT_P_TILED): element (i, j) at
+                         // ((i >> 5) * 32 * lda) + (j >> 6) * 2048 + (i & 31) * 64 + (j & 63); K = lda is a multiple of 64, ldb = V^T's key extent
 };
 
 enum { CONV_EPI_BIAS_ACT = 0, CONV_EPI_GRU_ZR = 1, CONV_EPI_GRU_Q = 2, CONV_EPI_MENC = 3 };
@@ -100,7 +102,7 @@ struct ScoreParams {
 };
 
 // deferred-normalisation probabilities as one launch of independent waves (kernels_attn_w.hip); ws: B*M*ceil(N/128)*16384 bytes
-int launch_attn_probs_fused(const ScoreParams& p, void* P, long ldp, void* ws, int p_prec, int prec, hipStream_t s);
+int launch_attn_probs_fused(const ScoreParams& p, void* P, long ldp, void* ws, int p_prec, int prec, int tiled, hipStream_t s);
 
 // ---- flash-fused attention (kernels_flash.hip) ----
 struct FlashParams {

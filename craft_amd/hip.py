@@ -24,6 +24,7 @@ def WGRAD_X_PREC(p: int) -> int:
     return (p + 1) << 8
 
 PYR_TILED = 0x200             # == CRAFT_PYR_TILED: levels 0 / 1 of a correlation pyramid in 8x16 / 4x8 tiles
+P_TILED = 0x400               # == CRAFT_P_TILED: attention probabilities in 32-query x 64-key tiles (probs_fused -> attn_apply)
 PV_ROWS_SHIFT = 20            # CRAFT_PV_ROWS(r) = r << 20, or-ed into craft_attn_apply's prec
 FRAG_ACC_ORDER = 0x10000      # == CRAFT_FRAG_ACC_ORDER
 STATS_REPLICAS = 64   # CRAFT_STATS_REPLICAS

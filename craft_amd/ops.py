@@ -238,16 +238,20 @@ def corr_lookup(pyr, coords: torch.Tensor, radius: int, out: Optional[torch.Tens
 
 def attn_probs(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale: float, pos_tab: Optional[torch.Tensor],
                pos_w: float, mask_radius: int, clamp_ord: Optional[torch.Tensor], prec: int,
-               out: Optional[torch.Tensor] = None, defer: bool = False, relpos=None) -> torch.Tensor:
+               out: Optional[torch.Tensor] = None, defer: bool = False, relpos=None, tiled: Optional[bool] = None) -> torch.Tensor:
     """P [B, M, N, ldp] (ldp = N rounded up to 32; the tail columns are zero).  ``defer=True``: P is left un-normalised
     (exp(logit - rowmax)) and carries its row sums as ``P.craft_rowsum`` [B, M, N]; ``attn_apply`` divides by them.
     Only for P that goes straight to ``attn_apply`` -- anything handed to a caller is normalised.
+    ``tiled`` (deferred one-launch path only; default on, ``CRAFT_P_ROWMAJOR=1`` turns it off): P is returned in 32-query x 64-key
+    tiles (``hip.P_TILED``; shape [B, M, N rounded up to 32, N rounded up to 64], ``P.craft_tiled`` / ``P.craft_n`` set) -- opaque to
+    everything but ``attn_apply`` / ``probs_slice`` / ``probs_rowmajor``.
     ``relpos = (Hs [B, M, N, 2*H8-1], Ws [B, M, N, 2*W8-1], weight)``: per-query relative-position scores (gma.RelPosEmb)."""
     B, N, C = q.shape
     ldp = round_up(N, 32)
     if pick(prec, "pv") not in PROB_DTYPE:
         raise hip.CraftHipError("inference stores the attention probabilities in the pv type: fp32, bf16 or fp16 (f16x3 is a "
                                 "training-only pv mode)")
+    given_out = out
     if out is None:
         out = torch.empty(B, M, N, ldp, device=q.device, dtype=PROB_DTYPE[pick(prec, "pv")])
     R = 0 if pos_tab is None else (pos_tab.shape[0] - 1) // 2
@@ -257,10 +261,23 @@ def attn_probs(q: torch.Tensor, k: torch.Tensor, H8: int, W8: int, M: int, scale
         # one launch of independent waves (craft_attn_probs_fused): maxima + P' + row sums, keys pre-split in fragment order
         rowsum = torch.empty(B, M, N, device=q.device, dtype=torch.float32)
         ws = torch.empty(B * M * ((N + 127) // 128) * 16384, device=q.device, dtype=torch.uint8)
+        if tiled is None:
+            tiled = given_out is None and not os.environ.get("CRAFT_P_ROWMAJOR")
+        if tiled:
+            ldp = round_up(N, 64)
+            if given_out is None:
+                out = torch.empty(B, M, round_up(N, 32), ldp, device=q.device, dtype=PROB_DTYPE[pvp])
+            elif tuple(out.shape) != (B, M, round_up(N, 32), ldp):
+                raise hip.CraftHipError("tiled probabilities need an out of shape [B, M, round_up(N, 32), round_up(N, 64)]")
         call("craft_attn_probs_fused", q, _ld(q), k, _ld(k), B, H8, W8, M, C // M, scale,
-             None if pos_tab is None else pos_tab.contiguous(), R, pos_w, mask_radius, clamp_ord, out, ldp, rowsum, ws, pvp, sp)
+             None if pos_tab is None else pos_tab.contiguous(), R, pos_w, mask_radius, clamp_ord, out, ldp, rowsum, ws,
+             pvp | (hip.P_TILED if tiled else 0), sp)
         out.craft_rowsum = rowsum
+        if tiled:
+            out.craft_tiled, out.craft_n = True, N
         return out
+    if tiled:
+        raise hip.CraftHipError("tiled probabilities exist only on the deferred one-launch path (craft_attn_probs_fused)")
     # row sums | scratch: row maxima, per-key-chunk partial sums (CRAFT_ATTN_CHUNK_KEYS = 1024)
     rowsum = torch.empty(2 + (N + 1023) // 1024, B, M, N, device=q.device, dtype=torch.float32) if defer else None
     rph, rpw, rpwt = (None, None, 0.0) if relpos is None else (relpos[0].contiguous(), relpos[1].contiguous(), float(relpos[2]))
@@ -305,7 +322,35 @@ def probs_slice(P: torch.Tensor, b0: int, b1: int) -> torch.Tensor:
     rs = getattr(P, "craft_rowsum", None)
     if rs is not None:
         v.craft_rowsum = rs[b0:b1]
+    if getattr(P, "craft_tiled", False):
+        v.craft_tiled, v.craft_n = True, P.craft_n
     return v
+
+
+def probs_rowmajor(P: torch.Tensor) -> torch.Tensor:
+    """Row-major [B, M, N, N] copy of an ``attn_probs`` result in either layout (tests / debugging; still un-normalised when
+    the row sums are deferred)."""
+    if not getattr(P, "craft_tiled", False):
+        return P[..., :P.shape[2]]
+    B, M, Nr, ldp = P.shape
+    N = P.craft_n
+    return P.view(B, M, Nr // 32, ldp // 64, 32, 64).permute(0, 1, 2, 4, 3, 5).reshape(B, M, Nr, ldp)[:, :, :N, :N]
+
+
+def probs_tiled(P: torch.Tensor, fill: float = 0.0) -> torch.Tensor:
+    """Tiled (``hip.P_TILED``) copy of a row-major P [B, M, N, >= N] (torch ops, not a kernel: tests and callers that build P
+    themselves); the padding rows are filled with ``fill`` (the kernels never write them and the consumer must not depend on them)."""
+    B, M, N = P.shape[:3]
+    Nr, ldp = round_up(N, 32), round_up(N, 64)
+    full = torch.full((B, M, Nr, ldp), fill, device=P.device, dtype=P.dtype)
+    full[:, :, :N, :N] = P[..., :N]
+    full[:, :, :N, N:] = 0
+    out = full.view(B, M, Nr // 32, 32, ldp // 64, 64).permute(0, 1, 2, 4, 3, 5).contiguous().view(B, M, Nr, ldp)
+    rs = getattr(P, "craft_rowsum", None)
+    if rs is not None:
+        out.craft_rowsum = rs
+    out.craft_tiled, out.craft_n = True, N
+    return out
 
 
 def attn_apply(P: torch.Tensor, vT: torch.Tensor, Dv: int, prec: int, out: Optional[torch.Tensor] = None,
@@ -313,6 +358,11 @@ def attn_apply(P: torch.Tensor, vT: torch.Tensor, Dv: int, prec: int, out: Optio
     """O[b][m] = P[b][m] @ V_m with vT [B, M*Dv, ldp] (16-bit: fragment order, ``linear_t(..., Dv=Dv)``) -> O [B, M, N, Dv].
     ``rows32`` (4..7, 0 = chosen from the grid size): 32-row groups per block of the 16-bit kernel (CRAFT_PV_ROWS)."""
     B, M, N, ldp = P.shape
+    tiled = getattr(P, "craft_tiled", False)
+    if tiled:
+        N = P.craft_n
+        if not P.is_contiguous():
+            raise hip.CraftHipError("tiled probabilities must be contiguous")
     if out is None:
         out = torch.empty(B, M, N, Dv, device=P.device, dtype=torch.float32)
     pv = pick(prec, "pv")
@@ -320,7 +370,8 @@ def attn_apply(P: torch.Tensor, vT: torch.Tensor, Dv: int, prec: int, out: Optio
         raise hip.CraftHipError(f"attention probabilities are {P.dtype} but the pv precision expects {PROB_DTYPE[pv]}")
     if vT.dtype != P.dtype:
         raise hip.CraftHipError(f"V^T is {vT.dtype} but P is {P.dtype}")
-    call("craft_attn_apply", P, ldp, getattr(P, "craft_rowsum", None), vT, B, N, M, Dv, out, pv | (rows32 << hip.PV_ROWS_SHIFT))
+    call("craft_attn_apply", P, ldp, getattr(P, "craft_rowsum", None), vT, B, N, M, Dv, out,
+         pv | (rows32 << hip.PV_ROWS_SHIFT) | (hip.P_TILED if tiled else 0))
     return out
 
 

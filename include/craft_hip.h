@@ -142,7 +142,13 @@ int craft_attn_probs(const float* q, long ldq, const float* k, long ldk, int B, 
  * key range: exact row maxima in a first sweep, exponentials + whole 256-byte row segments of P in a second; the keys are pre-split
  * once into fp16 hi / lo planes in MFMA fragment order and stream from L2 straight into MFMA registers (no operand staging, no block
  * barrier).  ws: B*M*ceil(N/128)*16384 bytes of scratch (the packed keys).  Implemented for d = 32, prec = f16x3 or fp16, no
- * relative-position scores, N < 65536; anything else returns CRAFT_ERR_UNSUPPORTED (10003) and the caller uses craft_attn_probs. */
+ * relative-position scores, N < 65536; anything else returns CRAFT_ERR_UNSUPPORTED (10003) and the caller uses craft_attn_probs.
+ * p_prec | CRAFT_P_TILED: P is written in 32-query x 64-key tiles -- element (i, j) of entry (b, m) at
+ *   ((b*M + m) * ceil(N/32) + (i >> 5)) * 32 * ldp + (j >> 6) * 2048 + (i & 31) * 64 + (j & 63),   ldp a multiple of 64, >= N
+ * (buffer: B*M*ceil(N/32)*32*ldp elements; rows >= N are not written, columns [N, ldp) are zeros).  The probabilities are written
+ * once and streamed 12 times by craft_attn_apply (network.py:214-230: one aggregation per refinement iteration); in this layout both
+ * sides move whole 4 KiB runs instead of 128-byte row segments 2*ldp bytes apart.  Only craft_attn_apply (prec | CRAFT_P_TILED) reads it. */
+#define CRAFT_P_TILED 0x400
 int craft_attn_probs_fused(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d, float scale,
                            const float* pos_tab, int R, float pos_w, int mask_radius, const unsigned* clamp_ord, void* P, long ldp,
                            float* rowsum, void* ws, int p_prec, int prec, void* stream);
@@ -154,7 +160,9 @@ int craft_attn_probs_fused(const float* q, long ldq, const float* k, long ldk, i
  * (craft_linear_t with frag_rows = Dv) and Dv % 128 == 0; for prec 0 it is plain row-major.  rowsum: NULL for a
  * normalised P, else the row sums craft_attn_probs produced with it (O rows are divided by them).
  * 16-bit path: a block owns 32*r query rows x 128 value columns; r (4..7) is chosen from the grid size unless the caller
- * or-s CRAFT_PV_ROWS(r) into prec (tests pin every instantiation that way). */
+ * or-s CRAFT_PV_ROWS(r) into prec (tests pin every instantiation that way).
+ * prec | CRAFT_P_TILED (16-bit only): P is in craft_attn_probs_fused's tiled layout, ldp its tiled row extent (multiple of 64); vT
+ * keeps the row stride N rounded up to 32. */
 #define CRAFT_PV_ROWS_SHIFT 20
 #define CRAFT_PV_ROWS(r) ((r) << CRAFT_PV_ROWS_SHIFT)
 int craft_attn_apply(const void* P, long ldp, const float* rowsum, const void* vT, int B, int N, int M, int Dv, float* O,

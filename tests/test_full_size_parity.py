@@ -94,6 +94,11 @@ def test_attn_apply_every_block_height(device, prec, rows32):
         Pun.craft_rowsum = scl.to(device)
         got2 = ops.attn_apply(Pun, vT, Dv, prec, rows32=rows32).cpu()
         assert (got2 - ref).abs().max().item() < 5 * tol * max(1.0, ref.abs().max().item())
+        # the same P in 32 x 64 tiles (CRAFT_P_TILED; N = 1000: ragged last band, tiled key extent 1024 > V^T's 1008): the same
+        # products in the same order -> the same bits; NaN in the padding rows must not reach any output row
+        Pt = ops.probs_tiled(Pun, fill=float("nan"))
+        got3 = ops.attn_apply(Pt, vT, Dv, prec, rows32=rows32).cpu()
+        assert torch.equal(got3, got2), f"tiled P differs from row-major P: rows32={rows32} Dv={Dv}"
 
 
 def test_corr_build_768x1024_shipped_kernel(device):

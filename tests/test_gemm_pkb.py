@@ -155,7 +155,9 @@ def test_scores_chain_on_packed_operands(device, prec, tol):
         Pm = AG.AttnSoftmax.apply(S, tab, 0.5, -1, None, (H8, W8), 0.1, 5, None, link)
         Pm.backward(gout.clone())
         res.append((Pm.detach()[..., :N].clone(), q.grad, k.grad, tab.grad))
-    assert link.want and link.dS is None
+    # f16x3 scores keep the fp32-source engine (packed three-term products measured neutral-to-negative): the link is
+    # declined unless the policy gives the score-gradient products a single-plane role (sbw: test_train_backward's mixed cases)
+    assert link.want == (prec != PREC_F16X3) and link.dS is None
     for a, b in zip(res[0], res[1]):
         assert ((a - b).norm() / a.norm()).item() < 2 * tol
 

@@ -255,8 +255,14 @@ def test_attn_probs_fused_single_launch(device, monkeypatch, H8, W8, mask_radius
     calls = []
     orig = ops.call
     monkeypatch.setattr(ops, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
-    Pd = ops.attn_probs(q, k, H8, W8, M, scale, tab.to(device), 1.0, mask_radius, mx, prec, defer=True)
-    assert calls == ["craft_attn_probs_fused"]
+    Pt = ops.attn_probs(q, k, H8, W8, M, scale, tab.to(device), 1.0, mask_radius, mx, prec, defer=True)       # default layout: tiled
+    Pd = ops.attn_probs(q, k, H8, W8, M, scale, tab.to(device), 1.0, mask_radius, mx, prec, defer=True, tiled=False)
+    assert calls == ["craft_attn_probs_fused"] * 2
+    # CRAFT_P_TILED: the same values in 32-query x 64-key tiles, zero key padding up to a multiple of 64
+    assert Pt.craft_tiled and Pt.craft_n == N and tuple(Pt.shape) == (B, M, ops.round_up(N, 32), ops.round_up(N, 64))
+    assert torch.equal(ops.probs_rowmajor(Pt), Pd[..., :N]) and torch.equal(Pt.craft_rowsum, Pd.craft_rowsum)
+    unt = Pt.view(B, M, -1, Pt.shape[-1] // 64, 32, 64).permute(0, 1, 2, 4, 3, 5).reshape(B, M, Pt.shape[2], Pt.shape[3])
+    assert float(unt[:, :, :N, N:].float().abs().max() if Pt.shape[-1] > N else 0.0) == 0.0, "tiled padding columns must be zero"
     rs = Pd.craft_rowsum
     assert Pd.dtype == torch.float16 and rs.shape == (B, M, N)
     assert float(Pd.float().max()) <= 1.0 and float(Pd[..., :N].float().amax(-1).min()) == 1.0      # exact maxima: the largest entry is 2^0
