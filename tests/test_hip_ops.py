@@ -226,7 +226,7 @@ def test_attn_probs(device, prec, C, M, mask_radius, gain):
         # logits carry the operand rounding (|S| up to ~|x||y| 2^-8), probabilities are <= 1
         close(got, ref, 0.0, 0.08 if prec == PREC_BF16 else 0.02, f"attention probs prec={prec}")
     # deferred normalisation: exp(logit - rowmax) in (0, 1] plus row sums; P' / rowsum is the same softmax
-    Pd = ops.attn_probs(q, k, H8, W8, M, scale, tab.to(device), 1.0, mask_radius, mx, prec, defer=True)
+    Pd = ops.attn_probs(q, k, H8, W8, M, scale, tab.to(device), 1.0, mask_radius, mx, prec, defer=True, tiled=False)
     rs = Pd.craft_rowsum
     assert rs.shape == (B, M, N) and float(Pd.float().max()) <= 1.0 and float(Pd[..., :N].float().amax(-1).min()) > 0.99
     store_tol = 1e-6 if Pd.dtype == torch.float32 else (8e-3 if Pd.dtype == torch.bfloat16 else 1e-3)

@@ -14,7 +14,7 @@ from craft_amd.hip import PROB_DTYPE, Precision, pick  # noqa: E402
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "pv"
     prec = Precision.parse(sys.argv[2] if len(sys.argv) > 2 else "mixed")
-    B, H8, W8 = int(os.environ.get("B", 4)), 56, 128
+    B, H8, W8 = int(os.environ.get("B", 4)), int(os.environ.get("H8", 56)), int(os.environ.get("W8", 128))
     N, M, Dv = H8 * W8, 4, 128
     dev = torch.device("cuda")
     if which == "pv":
@@ -45,13 +45,21 @@ def main():
         ws = ub.workspace(B, N, dev)
         corr = torch.randn(B, N, 324, device=dev)
         c0, c1, fl = ops.coords_init(None, B, H8, W8, dev)
-        for _ in range(3):
+        reps = int(os.environ.get("REPS", 0))
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(3 + reps):
+            if i == 3:
+                s.record()
             if which == "gru":
                 ub.gru.forward_tokens(hx, (H8, W8), ws, prec)
             elif which == "menc":
                 ub.encoder.forward_tokens(fl, corr, (H8, W8), hx[..., 256:384], ws, prec)
             else:
                 ub.flow_head_tokens(hx, (H8, W8), c1, c0, fl, None, ws, prec)
+        if reps:
+            e.record()
+            torch.cuda.synchronize()
+            print(f"{which} B={B} {H8}x{W8}: {s.elapsed_time(e) / reps * 1e3:.1f} us per call ({B * ((H8 + 7) // 8) * ((W8 + 15) // 16)} patches)")
     elif which in ("fnet", "cnet"):
         from craft_amd import CRAFT, default_args
         from craft_amd.synth import synth_state_dict, synth_pair
