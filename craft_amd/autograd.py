@@ -692,6 +692,19 @@ def _pad_cols(x: torch.Tensor, c: int) -> torch.Tensor:
     return y
 
 
+_ZERO_ROWS = {}
+
+
+def zero_row(n: int, device) -> torch.Tensor:
+    """A READ-ONLY row of >= n zeros that lives as long as the process (the absent bias of the input-gradient convolutions: a
+    torch.zeros per layer and step was 30 fill kernels of a training step)."""
+    key = (str(device), )
+    z = _ZERO_ROWS.get(key)
+    if z is None or z.numel() < n:
+        z = _ZERO_ROWS[key] = torch.zeros(max(4096, n), device=device, dtype=torch.float32)
+    return z[:n]
+
+
 def _conv_weights(w, b, cp, cache, transposed: bool):
     """Operands of the conv kernels for one weight tensor, built once per forward pass (``cache``: a dict that lives as long as
     the pass' graph -- the refinement loop calls every layer 12 times with the same weights, forward and backward):
@@ -708,9 +721,11 @@ def _conv_weights(w, b, cp, cache, transposed: bool):
         # fragment-order operand in one launch, straight from the nn.Conv2d layout (padding, flip and transposition included)
         wt = ops.pack_conv_weights(w, cp, transposed=transposed)
         rows = cin_p if transposed else cout_p
-        bias = torch.zeros(rows, device=w.device, dtype=torch.float32)
         if b is not None and not transposed:
+            bias = torch.zeros(rows, device=w.device, dtype=torch.float32)
             bias[:Cout] = b.detach()
+        else:
+            bias = zero_row(rows, w.device)
         out = (wt, bias, hip.W_PACKED, None)
         if cache is not None:
             cache[key] = out
@@ -1081,7 +1096,7 @@ class ConvexUpsample(Function):
         dup = _c(dup)
         dmask = torch.empty(B, N, 576, device=flow.device, dtype=torch.float32)
         dflow = hip.zeros((B, N, 2,), flow.device)
-        call("craft_convex_upsample_bwd", mask, mask.stride(-2), flow, dup, B, ctx.hw[0], ctx.hw[1], dmask, 576, dflow)
+        call("craft_convex_upsample_bwd", mask, mask.stride(-2), flow, dup, B, ctx.hw[0], ctx.hw[1], dmask, 576, dflow, 2)
         return dmask, dflow, None
 
 
@@ -1105,8 +1120,9 @@ class SequenceLoss(Function):
 
     @staticmethod
     def backward(ctx, dl):
-        s = dl.reshape(())
-        return (None, None, None, None) + tuple(g * s for g in ctx.grads)
+        grads, ctx.grads = ctx.grads, None
+        torch._foreach_mul_(grads, dl.reshape(()).to(grads[0].dtype))        # (one multi-tensor launch for the T predictions, in place: the buffers are this node's own)
+        return (None, None, None, None) + tuple(grads)
 
 
 def sequence_loss(flow_preds, flow_gt, valid, gamma: float = 0.8, max_flow: float = 400.0):

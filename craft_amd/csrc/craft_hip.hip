@@ -582,8 +582,12 @@ int craft_mode_pool_ln_bwd(const float* O, const float* x, long ldx, const float
   return launch_mode_pool_ln_bwd(O, x, ldx, w_agg, skip_coeff, dy, lddy, B, N, M, C, dO, dx, lddx, dw_rep, S(stream));
 }
 int craft_convex_upsample_bwd(const float* mask, long ldm, const float* flow, const float* dup, int B, int H8, int W8, float* dmask,
-                              long lddm, float* dflow, void* stream) {
-  return launch_convex_upsample_bwd(mask, ldm, flow, dup, B, H8, W8, dmask, lddm, dflow, S(stream));
+                              long lddm, float* dflow, long lddf, void* stream) {
+  return launch_convex_upsample_bwd(mask, ldm, flow, dup, B, H8, W8, dmask, lddm, dflow, lddf, S(stream));
+}
+
+int craft_flow_tokens(const float* coords1, const float* coords0, long rows, float* flow, float* flow32, float* coords1_copy, void* stream) {
+  return launch_flow_tokens(coords1, coords0, rows, flow, flow32, coords1_copy, S(stream));
 }
 int craft_gru_zr_fwd(const float* zr_pre, long ldzr, const float* h, long ldh, float* z, float* r, float* rh, long rows, int C, void* stream) {
   return launch_gru_zr_fwd(zr_pre, ldzr, h, ldh, z, r, rh, rows, C, S(stream));

@@ -829,7 +829,7 @@ int launch_mode_pool_ln_bwd(const float* O, const float* x, long ldx, const floa
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_convex_upsample_bwd(const float* __restrict__ mask, long ldm, const float* __restrict__ flow,
                                                              const float* __restrict__ dup, int H8, int W8, long npix,
-                                                             float* __restrict__ dmask, long lddm, float* __restrict__ dflow) {
+                                                             float* __restrict__ dmask, long lddm, float* __restrict__ dflow, long lddf) {
   const int lane = threadIdx.x & 63;
   const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= npix) return;
@@ -857,17 +857,45 @@ __global__ __launch_bounds__(256) void k_convex_upsample_bwd(const float* __rest
     dm[k] = g0 * f0 + g1 * f1;
     dsum += mk[k] * dm[k];
     const float d0 = wave_sum(8.f * mk[k] * g0), d1 = wave_sum(8.f * mk[k] * g1);
-    if (lane == 0 && ok) { unsafeAtomicAdd(dflow + 2 * nb, d0); unsafeAtomicAdd(dflow + 2 * nb + 1, d1); }
+    if (lane == 0 && ok) { unsafeAtomicAdd(dflow + lddf * nb, d0); unsafeAtomicAdd(dflow + lddf * nb + 1, d1); }
   }
 #pragma unroll
   for (int k = 0; k < 9; ++k) dmask[p * lddm + k * 64 + lane] = mk[k] * (dm[k] - dsum);
 }
 int launch_convex_upsample_bwd(const float* mask, long ldm, const float* flow, const float* dup, int B, int H8, int W8, float* dmask,
-                               long lddm, float* dflow, hipStream_t s) {
+                               long lddm, float* dflow, long lddf, hipStream_t s) {
   const long npix = (long)B * H8 * W8;
   if (npix <= 0) return 0;
+  if (lddf < 2) return CRAFT_ERR_ARG;
   hipLaunchKernelGGL(k_convex_upsample_bwd, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, mask, ldm, flow, dup, H8, W8, npix, dmask,
-                     lddm, dflow);
+                     lddm, dflow, lddf);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// The per-iteration coordinate bookkeeping of the training forward in one launch (network.py:232-234, :247): flow = coords1 - coords0
+// as [rows][2] (the motion encoder's input) and zero-padded to [rows][32] (the 7x7 convolution's weight-gradient operand), and a copy
+// of coords1 for the flow head to update in place.  One thread per row.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_flow_tokens(const float* __restrict__ c1, const float* __restrict__ c0, long rows, float* __restrict__ flow,
+                              float* __restrict__ flow32, float* __restrict__ c1copy) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const float2 a = *reinterpret_cast<const float2*>(c1 + 2 * i), b = *reinterpret_cast<const float2*>(c0 + 2 * i);
+  const float2 f = make_float2(a.x - b.x, a.y - b.y);
+  *reinterpret_cast<float2*>(flow + 2 * i) = f;
+  if (c1copy) *reinterpret_cast<float2*>(c1copy + 2 * i) = a;
+  if (flow32) {
+    float4* d = reinterpret_cast<float4*>(flow32 + 32 * i);
+    d[0] = make_float4(f.x, f.y, 0.f, 0.f);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+int launch_flow_tokens(const float* c1, const float* c0, long rows, float* flow, float* flow32, float* c1copy, hipStream_t s) {
+  if (rows <= 0) return 0;
+  if (!c1 || !c0 || !flow) return CRAFT_ERR_ARG;
+  hipLaunchKernelGGL(k_flow_tokens, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, c1, c0, rows, flow, flow32, c1copy);
   return (int)hipGetLastError();
 }
 

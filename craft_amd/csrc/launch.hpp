@@ -219,8 +219,9 @@ int launch_corr_lookup_bwd(const float* dout, long ldo, const float* coords, flo
                            int H8, int W8, int radius, int lvl_stride, int col_off, hipStream_t s);
 int launch_mode_pool_ln_bwd(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff, const float* dy, long lddy,
                             int B, int N, int M, int C, float* dO, float* dx, long lddx, float* dw_rep, hipStream_t s);
+int launch_flow_tokens(const float* c1, const float* c0, long rows, float* flow, float* flow32, float* c1copy, hipStream_t s);
 int launch_convex_upsample_bwd(const float* mask, long ldm, const float* flow, const float* dup, int B, int H8, int W8, float* dmask,
-                               long lddm, float* dflow, hipStream_t s);
+                               long lddm, float* dflow, long lddf, hipStream_t s);
 int launch_gru_zr_fwd(const float* zr, long ldzr, const float* h, long ldh, float* z, float* r, float* rh, long rows, int C, hipStream_t s);
 int launch_gru_out_fwd(const float* qp, long ldq, const float* z, const float* h, long ldh, float* q, float* hn, long ldhn, long rows, int C,
                        hipStream_t s);

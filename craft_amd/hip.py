@@ -12,7 +12,7 @@ from ctypes import c_double, c_float, c_int, c_long, c_void_p, c_char_p
 
 import torch
 
-ABI_VERSION = 2          # == CRAFT_HIP_ABI_VERSION (include/craft_hip.h): bumped whenever an existing entry point changes its signature
+ABI_VERSION = 3          # == CRAFT_HIP_ABI_VERSION (include/craft_hip.h): bumped whenever an existing entry point changes its signature
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 W_PACKED = 0x100
@@ -107,7 +107,8 @@ _SIGS = {
     "craft_corr_pyramid_bwd": [P, P, P, P, P, P, I, I, I, P, P],
     "craft_corr_pool_bwd": [P, L, I, I, I, I, P, I, F, P, P, P, P, P, P, I, P, P, P],
     "craft_mode_pool_ln_bwd": [P, P, L, P, P, P, L, I, I, I, I, P, P, L, P, P],
-    "craft_convex_upsample_bwd": [P, L, P, P, I, I, I, P, L, P, P],
+    "craft_convex_upsample_bwd": [P, L, P, P, I, I, I, P, L, P, L, P],
+    "craft_flow_tokens": [P, P, L, P, P, P, P],
     "craft_gru_zr_fwd": [P, L, P, L, P, P, P, L, I, P],
     "craft_gru_out_fwd": [P, L, P, P, L, P, P, L, L, I, P],
     "craft_gru_out_bwd": [P, L, P, P, P, L, P, P, P, L, I, P, P],

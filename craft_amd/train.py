@@ -11,6 +11,7 @@ clip -> AdamW -> scheduler.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Iterable, List, Optional
 
 import torch
@@ -154,6 +155,37 @@ class FlatAdamW:
 
     def zero_grad(self):
         self.flat_grad.zero_()
+
+    def load_grads(self, grads):
+        """The gradients of ``self.params`` (``torch.autograd.grad`` order; None = no gradient) into the flat buffer in ONE multi-tensor
+        copy -- instead of ``zero_grad()`` + ``backward()``, whose AccumulateGrad nodes add every gradient into its (zeroed) view with a
+        kernel of its own (127 launches of a configs[3] step).  A view whose parameter had a gradient before and has none now is zeroed;
+        the alignment padding between the views stays zero from the allocation."""
+        views = self.grad_views()
+        had = self.__dict__.setdefault("_had_grad", [False] * len(views))
+        dst, src, stale = [], [], []
+        for i, (v, g) in enumerate(zip(views, grads)):
+            if g is None:
+                if had[i]:
+                    stale.append(v)
+                had[i] = False
+            else:
+                if g.shape != v.shape:
+                    raise ValueError(f"gradient {i} has shape {tuple(g.shape)}, its parameter {tuple(v.shape)}")
+                dst.append(v)
+                src.append(g.detach())
+                had[i] = True
+        with torch.no_grad():
+            if dst:
+                torch._foreach_copy_(dst, src)
+            if stale:
+                torch._foreach_zero_(stale)
+
+    def grad_views(self):
+        v = self.__dict__.get("_grad_views")
+        if v is None:
+            v = self._grad_views = [self.flat_grad[off:off + p.numel()].view_as(p.data) for p, off in zip(self.params, self.offsets)]
+        return v
 
     def allreduce_grads(self, group=None) -> float:
         """Sum the flat gradient over the data-parallel group (one collective); returns the 1/world factor that
@@ -426,14 +458,21 @@ class Trainer:
             model.train()
             if self.freeze_bn:
                 model.freeze_bn()
-        opt.zero_grad()
+        direct = not os.environ.get("CRAFT_TRAINER_BACKWARD")        # (developer A/B: 1 = zero_grad() + loss.backward() as before round 4)
+        if not direct:
+            opt.zero_grad()
         preds = model(image1, image2, iters=self.iters)
         loss, metrics = seq_loss(preds, flow, valid, self.gamma)
         if not self._scale_set:            # "auto": start from auto_loss_scale and let GradScaler's rule move it (train.py:215)
             opt.set_loss_scale(auto_loss_scale(flow.numel()), dynamic=True)
             self._scale_set = True
         self._seed = opt.scale_seed()                                  # the scale is read on the device, in stream order
-        loss.backward(self._seed.to(loss.dtype))
+        if direct:
+            # the gradients are captured by the engine and copied into the flat buffer together (FlatAdamW.load_grads); p.grad keeps
+            # pointing at its view of that buffer
+            opt.load_grads(torch.autograd.grad(loss, opt.params, grad_outputs=self._seed.to(loss.dtype), allow_unused=True))
+        else:
+            loss.backward(self._seed.to(loss.dtype))
         from .autograd import pending_uses
         if pending_uses(model.__dict__.get("_train_pass_cache")):
             raise RuntimeError("backward left accumulated weight gradients incomplete (a layer call was pruned from the graph)")

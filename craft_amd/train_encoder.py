@@ -30,9 +30,22 @@ from .hip import ACT_NONE, ACT_RELU, PREC_BF16, PREC_F16X3, PREC_F32, STATS_REPL
 EPS = 1e-5        # nn.InstanceNorm2d / nn.BatchNorm2d default (extractor.py uses the defaults)
 
 
+PENDING_BN_COUNTS = []
+
+
+def flush_bn_counts():
+    """num_batches_tracked += 1 of every BatchNorm the training forward went through (nn.BatchNorm2d does it per module: 15 scalar
+    kernels per step)."""
+    if PENDING_BN_COUNTS:
+        with torch.no_grad():
+            torch._foreach_add_(PENDING_BN_COUNTS, 1)
+        PENDING_BN_COUNTS.clear()
+
+
 class Stem(Function):
     @staticmethod
     def forward(ctx, raw, w, b, prec, bias_dead=False):
+        ctx.set_materialize_grads(False)          # (the statistics output never has a gradient: no zero tensor made for it)
         B, _, H, W = raw.shape
         raw = raw.contiguous().float()
         out = torch.empty(B, (H // 2) * (W // 2), 64, device=raw.device, dtype=torch.float32)
@@ -84,6 +97,7 @@ class EncConv(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, hw_in, stride, prec, cache, bias_dead=False):
+        ctx.set_materialize_grads(False)          # (the statistics output never has a gradient: no zero tensor made for it)
         x = AG._rows(x)
         B, _, Cin = x.shape
         Cout, _, KH, KW = w.shape
@@ -188,7 +202,7 @@ def _norm(y, stats, count, mod, act, res=None):
             m = mod.momentum if mod.momentum is not None else 0.1
             with torch.no_grad():
                 call("craft_bn_finalize", stats, B, C, float(count), float(mod.eps), float(m), mr, mod.running_mean, mod.running_var)
-                mod.num_batches_tracked.add_(1)
+                PENDING_BN_COUNTS.append(mod.num_batches_tracked)        # += 1, all of them in one launch (flush_bn_counts)
             return NormAct.apply(y, mr, mod.weight, mod.bias, act, res, B * count)
         call("craft_bn_finalize", None, B, C, float(count), float(mod.eps), 0.0, mr, mod.running_mean, mod.running_var)
         return NormAct.apply(y, mr, mod.weight, mod.bias, act, res, 0)

@@ -112,12 +112,6 @@ class UpdatePass:
         self.ready = []
 
 
-def _flow32(flow, B, N):
-    f = torch.zeros(B, N, 32, device=flow.device, dtype=torch.float32)
-    f[..., :2] = flow
-    return f
-
-
 def _conv_dx(ps: UpdatePass, w, g, cout_p, KH, KW, out=None, cin_p=None, field=None):
     """Input gradient of a stride-1 'same' convolution: the forward kernel with flipped / transposed weights.  g [B, N, cout_p]
     (row stride may exceed cout_p) -> [B, N, cin_p].  w: the nn.Conv2d weight, or (with cin_p) an operand already packed by
@@ -160,6 +154,7 @@ class UpdateIter(Function):
 
     @staticmethod
     def forward(ctx, net, token, ptoken, inp, ps: UpdatePass, t: int, coords1, coords0, *params):
+        ctx.set_materialize_grads(False)          # (coords1 is non-differentiable, the last net unused: backward tests for None)
         m = ps.model
         ub = m.update_block
         B, N, (H8, W8) = ps.B, ps.N, ps.hw
@@ -171,7 +166,10 @@ class UpdateIter(Function):
         pb = AG.PackBatch()                                                          # the iteration's conv inputs: ONE pack launch at its end
         if ps.zero_tok is None:
             ps.zero_tok = torch.zeros_like(token)
-        flow = coords1 - coords0                                                     # [B, N, 2]
+        flow = torch.empty(B, N, 2, device=dev, dtype=torch.float32)                 # coords1 - coords0, its padded copy and coords1's
+        flow32 = torch.empty(B, N, 32, device=dev, dtype=torch.float32)              # copy for the flow head: one launch
+        c1n = torch.empty(B, N, 2, device=dev, dtype=torch.float32)
+        call("craft_flow_tokens", coords1, AG._c(coords0), rows, flow, flow32, c1n)
         # ---- BasicMotionEncoder (update.py:79-87): one fused call; its workspace keeps cor1 | [cor2 | flo2] | flo1
         me = torch.empty(rows * 640, device=dev, dtype=torch.float32)
         call("craft_motion_encoder", corr, corr.stride(-2), ub.encoder.cor_planes, flow, *ps.w_enc, B, H8, W8, hx[..., MF:MF + 128], _C, me,
@@ -185,7 +183,7 @@ class UpdateIter(Function):
         xcp = AG.xprec(cp)                                                       # mode of the weight gradients' X operands (policy role wgx)
         S["pk_corr"] = AG.Packed(corr, xcp, batch=pb)
         S["pk_cor1"] = AG.Packed(S["cor1"], xcp, g3, batch=pb)
-        S["pk_flow"] = AG.Packed(_flow32(flow, B, N), xcp, g7, batch=pb)
+        S["pk_flow"] = AG.Packed(flow32, xcp, g7, batch=pb)
         S["pk_flo1"] = AG.Packed(S["flo1"], xcp, g3, batch=pb)
         S["pk_cf"] = AG.Packed(S["cf"], xcp, g3, batch=pb)
         # ---- motion aggregator (update.py:143-149)
@@ -245,7 +243,6 @@ class UpdateIter(Function):
         S["pk_h2"] = AG.Packed(h2, xcp, g3, batch=pb)
         # ---- heads (update.py:15-16, :124-127, :161) + coords1 += delta (network.py:247) + convex upsampling (:258)
         fh1 = torch.empty(B, N, 256, device=dev, dtype=torch.float32)
-        c1n = coords1.clone()
         flow_new = torch.empty(B, N, 2, device=dev, dtype=torch.float32)
         call("craft_flow_head", h2, _C, *ps.w_fh, B, H8, W8, c1n, coords0, flow_new, None, fh1, cp | W_PACKED)
         mh = torch.empty(B, N, 256, device=dev, dtype=torch.float32)
@@ -282,10 +279,8 @@ class UpdateIter(Function):
         dh2 = None
         if d_up is not None:
             dmask = E(B, N, 576)
-            dflow = hip.zeros((B, N, 32), dev)           # (2 live columns; the flow head's padded output)
-            d2 = hip.zeros((B, N, 2), dev)
-            call("craft_convex_upsample_bwd", S["mask"], 576, S["flow_new"], AG._c(d_up), B, H8, W8, dmask, 576, d2)
-            dflow[..., :2] = d2
+            dflow = hip.zeros((B, N, 32), dev)           # (2 live columns; the flow head's padded output: accumulated in place, stride 32)
+            call("craft_convex_upsample_bwd", S["mask"], 576, S["flow_new"], AG._c(d_up), B, H8, W8, dmask, 576, dflow, 32)
             # mask = 0.25 * (W2 mh + b2): the gradient w.r.t. the pre-scale output
             dm = _act_bwd(dmask, dmask, 576, out=dmask, act=ACT_NONE, scale=0.25)
             w2 = ub.mask[2].weight
@@ -354,7 +349,9 @@ class UpdateIter(Function):
         if last:
             _phase2(ps)
         grads = _param_grads(ps) if last else (None,) * ctx.nparams
-        return (d_net, ps.zero_tok, ps.zero1, d_inp, None, None, None, None) + tuple(grads)
+        # the two token inputs only order CorrVolume / ProbsToken behind every iteration (the engine counts graph edges, defined or not):
+        # one zero gradient, from the iteration that runs last, is enough -- twelve of them were 22 additions of zeros by the engine
+        return (d_net, ps.zero_tok if last else None, ps.zero1 if last else None, d_inp, None, None, None, None) + tuple(grads)
 
 
 def _phase2(ps: UpdatePass):
@@ -432,10 +429,9 @@ def _phase2(ps: UpdatePass):
         mf = ps.HX[t][..., MF:MF + 128]
         d_mf = d_mfs[t]
         dva = dva5[:, :, :, t, :].reshape(B, N, M * Cv)              # M > 1: a contiguous copy; one mode: a strided view (row stride T*Cv)
-        d_mf3 = E(B, N, 128)
-        AG.gemm(dva, dva.stride(-2), 1, 0, 0, wv2, 1, 128, 0, 0, d_mf3, 128, 0, 0, 1, 1, rows, 128, M * Cv, prec=pp)
+        AG.gemm(dva, dva.stride(-2), 1, 0, 0, wv2, 1, 128, 0, 0, d_mf, 128, 0, 0, 1, 1, rows, 128, M * Cv, accumulate=True, prec=pp)      # d_mf += dva W_v
         ps.wgrad(("agg_v",), (AG.Packed(dva, AG.gprec(pp), batch=pb), S["pk_mf"]), 1, 1, ps.acc(("agg_v", "dw"), (M * Cv, 128)), last)
-        d_mf.add_(d_mf3).add_(ps.dv[t][..., 0:128])
+        d_mf.add_(ps.dv[t][..., 0:128])
         ps.dv[t] = None
         # ---- BasicMotionEncoder
         g_out = _act_bwd(d_mf, mf, 128, out=d_mf)

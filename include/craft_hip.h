@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CRAFT_HIP_ABI_VERSION 2
+#define CRAFT_HIP_ABI_VERSION 3
 
 #define CRAFT_PREC_F32 0
 #define CRAFT_PREC_BF16 1
@@ -488,9 +488,15 @@ int craft_corr_pool_bwd(float* S, long ld, int B, int M, int H8, int W8, const f
 int craft_mode_pool_ln_bwd(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff, const float* dy,
                            long lddy, int B, int N, int M, int C, float* dO, float* dx, long lddx, float* dw_rep, void* stream);
 
-/* backward of craft_convex_upsample: dup NCHW [B][2][8*H8][8*W8] -> dmask [B*N][576] (row stride lddm) and dflow [B*N][2] +=. */
+/* backward of craft_convex_upsample: dup NCHW [B][2][8*H8][8*W8] -> dmask [B*N][576] (row stride lddm) and dflow [B*N][>= 2] +=
+ * (row stride lddf: 2 for a dense gradient, 32 when it is written straight into the flow head's padded output gradient). */
 int craft_convex_upsample_bwd(const float* mask, long ldm, const float* flow, const float* dup, int B, int H8, int W8, float* dmask,
-                              long lddm, float* dflow, void* stream);
+                              long lddm, float* dflow, long lddf, void* stream);
+
+/* The coordinate bookkeeping of one refinement iteration of the training forward (network.py:232-234, :247) in one launch:
+ * flow [rows][2] = coords1 - coords0; flow32 (or NULL) [rows][32] the same, zero-padded (the operand of convf1's weight gradient);
+ * coords1_copy (or NULL) [rows][2] = coords1 (craft_flow_head updates it in place). */
+int craft_flow_tokens(const float* coords1, const float* coords0, long rows, float* flow, float* flow32, float* coords1_copy, void* stream);
 
 /* SepConvGRU gates as separate stages (update.py:55-63), C hidden channels (C % 4 == 0); z, r, rh, q, dz, dq_pre, dh are dense
  * [rows][C], zr_pre / dzr_pre dense [rows][2C]:
