@@ -78,7 +78,7 @@ class Aggregate(nn.Module):
 
     def forward_tokens(self, attn: torch.Tensor, mf: torch.Tensor, prec: int, out: Optional[torch.Tensor] = None):
         """attn [B, heads, N, ldp], mf tokens [B, N, dim] -> tokens [B, N, dim]."""
-        ldp = attn.shape[-1]
+        ldp = ops.vt_stride(attn)
         vT = ops.linear_t(mf, self.to_v.weight.view(self.heads * self.dim_head, -1), ldp, prec, Dv=self.dim_head)
         O = ops.attn_apply(attn, vT, self.dim_head, prec)
         return ops.gma_residual(mf, O, self.gamma, out=out)

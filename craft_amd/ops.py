@@ -316,6 +316,12 @@ def flash_attention(q: torch.Tensor, k: torch.Tensor, vT: torch.Tensor, H8: int,
     return out
 
 
+def vt_stride(P: torch.Tensor) -> int:
+    """Row stride (key extent) of the V^T operand that ``attn_apply`` expects beside ``P``: P's own row stride for a row-major P, N
+    rounded up to 32 for a tiled one (whose key extent is rounded to 64: include/craft_hip.h, craft_attn_apply)."""
+    return round_up(P.craft_n, 32) if getattr(P, "craft_tiled", False) else P.shape[-1]
+
+
 def probs_slice(P: torch.Tensor, b0: int, b1: int) -> torch.Tensor:
     """Batch slice of an ``attn_probs`` result that keeps the deferred row sums attached."""
     v = P[b0:b1]
@@ -370,6 +376,8 @@ def attn_apply(P: torch.Tensor, vT: torch.Tensor, Dv: int, prec: int, out: Optio
         raise hip.CraftHipError(f"attention probabilities are {P.dtype} but the pv precision expects {PROB_DTYPE[pv]}")
     if vT.dtype != P.dtype:
         raise hip.CraftHipError(f"V^T is {vT.dtype} but P is {P.dtype}")
+    if vT.shape[-1] != vt_stride(P):
+        raise hip.CraftHipError(f"V^T has key extent {vT.shape[-1]}, attn_apply expects {vt_stride(P)} beside this P (ops.vt_stride)")
     call("craft_attn_apply", P, ldp, getattr(P, "craft_rowsum", None), vT, B, N, M, Dv, out,
          pv | (rows32 << hip.PV_ROWS_SHIFT) | (hip.P_TILED if tiled else 0))
     return out

@@ -205,7 +205,7 @@ class ExpandedFeatTrans(nn.Module):
         """input_feat tokens [B, N, C] (also the skip input), attention_probs [B, M, N, ldp] from
         ``ops.attn_probs`` -> tokens [B, N, C]   (setrans.py:364-410)."""
         prec = _prec_of(self) if prec is None else prec
-        ldp = attention_probs.shape[-1]
+        ldp = ops.vt_stride(attention_probs)
         vT = ops.linear_t(input_feat, self.first_linear.weight, ldp, prec, Dv=self.feat_dim)
         O = ops.attn_apply(attention_probs, vT, self.feat_dim, prec)
         return ops.mode_pool_ln(O, input_feat, self.feat_softaggr.feat2score.weight, self.input_skip_coeff, out=out)

@@ -239,4 +239,5 @@ def encoder_forward_train(enc: BasicEncoder, raw: torch.Tensor, prec) -> torch.T
         x = _norm(y2, st2, n2, blk.norm2, ACT_RELU, res=xr)
         hw = hw2
     cout = enc.conv2.out_channels
+    flush_bn_counts()
     return AG.Linear.apply(x, enc.conv2.weight.view(cout, -1), enc.conv2.bias, cp)

@@ -151,7 +151,6 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
         f12 = TE.encoder_forward_train(model.fnet, torch.cat([image1, image2], dim=0).float(), prec)
         f1_tok, f2_tok = f12[:B], f12[B:]
         cn_tok = TE.encoder_forward_train(model.cnet, image1.float(), prec)
-        TE.flush_bn_counts()
     else:
         im1 = (2 * (image1.float() / 255.0) - 1.0).contiguous()
         im2 = (2 * (image2.float() / 255.0) - 1.0).contiguous()
