@@ -32,19 +32,26 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_rows(RowsGemmParams p) {
   }
   const long cbase = z0 * p.c_bs0 + z1 * p.c_bs1;
   const int rb = m0 + (wave / WN) * (BM / WM), cb = n0 + (wave % WN) * (BN / WN);
-  // Epilogue in quads of 4 consecutive rows (the accumulator layout), with the element type / layout dispatch hoisted
-  // out of the element loop.  act is NONE or RELU here (checked by the launcher).
+  // Epilogue in quads of 4 consecutive rows (the accumulator layout).  Everything that does not depend on the element is decided ONCE
+  // outside the loops -- element type / layout, the deferred row divisor, and whether the wave's tile lies inside the matrix (no bounds
+  // tests then): with the per-element forms (`p.row_div ? .. : ..`, `row0 + i < M`) hipcc branched around loads 64 times per lane and
+  // the K = 128 .. 352 products of the refinement loop (V^T projection, convc1) spent a quarter of their 31 us there (craft_gemm's
+  // kernel, same main loop, hoisted stores: 24 us -- tools/bench_1x1.py).  act is NONE or RELU here (checked by the launcher).
   const bool relu = p.act == CRAFT_ACT_RELU;
   const int c_lane = lane & 31, rh4 = 4 * (lane >> 5);
-  auto run = [&](auto dt_tag, auto frag_tag) __attribute__((always_inline)) {
+  const float scale = p.scale;
+  const int M = p.M, N = p.N;
+  const bool inside = rb + MT * 32 <= M && cb + NT * 32 <= N;
+  const float* rdiv = p.row_div ? p.row_div + (long)z * p.rd_bs : nullptr;
+  auto run = [&](auto dt_tag, auto frag_tag, auto rd_tag, auto in_tag) __attribute__((always_inline)) {
     constexpr int DT = decltype(dt_tag)::value;
-    constexpr bool FRAG = decltype(frag_tag)::value;
+    constexpr bool FRAG = decltype(frag_tag)::value, RD = decltype(rd_tag)::value, INB = decltype(in_tag)::value;
     typedef typename std::conditional<DT == CRAFT_PREC_F32, float, typename std::conditional<DT == CRAFT_PREC_BF16, __bf16, _Float16>::type>::type out_t;
     out_t* C = reinterpret_cast<out_t*>(p.C) + cbase;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int col = cb + nt * 32 + c_lane;
-      if (col >= p.N) continue;
+      if (!INB && col >= N) continue;
       const float bias = p.bias ? p.bias[col] : 0.f;
       long fbase = 0;
       if constexpr (FRAG) {      // MFMA B-fragment order per group of c_frag columns (k_pv16's V^T operand): row = key, col = V^T row
@@ -59,8 +66,8 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_rows(RowsGemmParams p) {
           float v[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            float t = acc[mt][nt][4 * q + i] * p.scale;
-            if (p.row_div) t /= p.row_div[(long)z * p.rd_bs + min(row0 + i, p.M - 1)];
+            float t = acc[mt][nt][4 * q + i] * scale;
+            if constexpr (RD) t /= rdiv[min(row0 + i, M - 1)];
             t += bias;
             v[i] = relu ? fmaxf(t, 0.f) : t;
           }
@@ -69,19 +76,19 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_rows(RowsGemmParams p) {
             // (accumulator key order: half = bit 2 of the key, position within the lane = 4 * bit 3 + low two bits)
             out_t* d = C + fbase + (long)(row0 >> 4) * (p.c_frag >> 5) * 512 +
                        (p.c_frag_acc ? ((row0 >> 2) & 1) * 256 + ((row0 >> 3) & 1) * 4 : ((row0 >> 3) & 1) * 256 + (row0 & 7));
-            if (row0 + 3 < p.M) {
+            if (INB || row0 + 3 < M) {
               typedef out_t o4 __attribute__((ext_vector_type(4)));
               o4 h;
               h[0] = (out_t)v[0]; h[1] = (out_t)v[1]; h[2] = (out_t)v[2]; h[3] = (out_t)v[3];
               *reinterpret_cast<o4*>(d) = h;
             } else {
 #pragma unroll
-              for (int i = 0; i < 4; ++i) if (row0 + i < p.M) d[i] = (out_t)v[i];
+              for (int i = 0; i < 4; ++i) if (row0 + i < M) d[i] = (out_t)v[i];
             }
           } else {
             out_t* d = C + (long)row0 * p.ldc + col;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (row0 + i < p.M) d[(long)i * p.ldc] = (out_t)v[i];
+            for (int i = 0; i < 4; ++i) if (INB || row0 + i < M) d[(long)i * p.ldc] = (out_t)v[i];
           }
         }
     }
@@ -89,9 +96,15 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_rows(RowsGemmParams p) {
   typedef std::integral_constant<int, CRAFT_PREC_F32> T32;
   typedef std::integral_constant<int, CRAFT_PREC_BF16> TBF;
   typedef std::integral_constant<int, CRAFT_PREC_F16> TF16;
-  if (p.c_dtype == CRAFT_PREC_F32) run(T32(), std::false_type());
-  else if (p.c_dtype == CRAFT_PREC_BF16) { if (p.c_frag) run(TBF(), std::true_type()); else run(TBF(), std::false_type()); }
-  else { if (p.c_frag) run(TF16(), std::true_type()); else run(TF16(), std::false_type()); }
+  auto pick_in = [&](auto dt_tag, auto frag_tag, auto rd_tag) __attribute__((always_inline)) {
+    if (inside) run(dt_tag, frag_tag, rd_tag, std::true_type()); else run(dt_tag, frag_tag, rd_tag, std::false_type());
+  };
+  auto pick_rd = [&](auto dt_tag, auto frag_tag) __attribute__((always_inline)) {
+    if (rdiv) pick_in(dt_tag, frag_tag, std::true_type()); else pick_in(dt_tag, frag_tag, std::false_type());
+  };
+  if (p.c_dtype == CRAFT_PREC_F32) pick_rd(T32(), std::false_type());
+  else if (p.c_dtype == CRAFT_PREC_BF16) { if (p.c_frag) pick_rd(TBF(), std::true_type()); else pick_rd(TBF(), std::false_type()); }
+  else { if (p.c_frag) pick_rd(TF16(), std::true_type()); else pick_rd(TF16(), std::false_type()); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -331,7 +344,8 @@ template <int PREC, int BN> static int launch_conv_t(const ConvGemmParams& p, hi
 int launch_gemm_conv(const ConvGemmParams& p, int prec, hipStream_t s) {
   if (p.g.npix <= 0) return 0;
   if ((p.g.c0 % 32) || (p.g.c1 % 32) || (p.g.ld0 & 3) || (p.g.c1 && (p.g.ld1 & 3))) return CRAFT_ERR_ALIGN;
-  if (p.g.KH * p.g.KW > 1 && !p.force_generic && p.g.stride == 1) {
+  // (1x1 with fragment-order weights takes the weight-fragment kernel too: one tap, weights from L2 straight into MFMA registers)
+  if ((p.g.KH * p.g.KW > 1 || p.w_packed) && !p.force_generic && p.g.stride == 1) {
     const int rc = launch_conv_halo(p, prec, s);
     if (rc != CRAFT_ERR_UNSUPPORTED) return rc;
   }

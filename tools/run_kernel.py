@@ -21,6 +21,8 @@ def main():
         ldp = ops.round_up(N, 32)
         pv = pick(prec, "pv")
         P = torch.rand(B, M, N, ldp, device=dev).div_(N / 2).to(PROB_DTYPE[pv])
+        if not os.environ.get("CRAFT_P_ROWMAJOR"):       # the layout the forward pass runs: 32 x 64 tiles (CRAFT_P_TILED)
+            P = ops.probs_tiled(P)
         vT = torch.randn(B, M * Dv, ldp, device=dev).to(PROB_DTYPE[pv])
         O = torch.empty(B, M, N, Dv, device=dev)
         for _ in range(5):
