@@ -842,12 +842,13 @@ PK_ROWS, PK_CH = 0, 1
 
 
 def gemm_pk(A: PkMat, a_desc, B: PkMat, b_desc, C: torch.Tensor, ldc: int, c_outer: int, c_inner: int, inner: int, nbatch: int, M: int, N: int, K: int,
-            alpha: float = 1.0):
-    """C[z][m][n] = alpha sum_k A_z[m, k] B_z[n, k] over packed operands (craft_gemm_pk; K padded to a multiple of 32 with zeros in both packs)."""
+            alpha: float = 1.0, c_blk_shift: int = 0):
+    """C[z][m][n] = alpha sum_k A_z[m, k] B_z[n, k] over packed operands (craft_gemm_pk; K padded to a multiple of 32 with zeros in both packs).
+    ``c_blk_shift`` s > 0 (CRAFT_PK_CBLK, c_inner == 2^s): output columns in blocks of 2^s, consecutive blocks inner * 2^s elements apart."""
     import ctypes
     assert A.prec == B.prec
     call("craft_gemm_pk", A.buf, hip.carray(ctypes.c_long, a_desc), B.buf, hip.carray(ctypes.c_long, b_desc), C, ldc, c_outer, c_inner, inner, nbatch, M, N,
-         round_up(K, 32), float(alpha), A.prec)
+         round_up(K, 32), float(alpha), A.prec | (c_blk_shift << 8))
 
 
 # Operand modes of the backward products of f16x3 layers, set per training pass by train_forward.forward_train from the policy's roles

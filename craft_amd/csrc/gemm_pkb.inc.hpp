@@ -39,6 +39,7 @@ struct PkbOperand {
 struct PkbParams {
   PkbOperand A, B;
   float* C; long ldc, c_outer, c_inner;
+  int c_blk_shift; long c_blk_stride;   // > 0: output columns in blocks of 2^shift, consecutive blocks c_blk_stride elements apart (CRAFT_PK_CBLK)
   float alpha;
   int inner, nbatch;
   int M, N, K;                        // K: padded to a multiple of 32 (zeros in BOTH packs)
@@ -207,13 +208,14 @@ __global__ __launch_bounds__(512) void k_gemm_pkb(PkbParams p) {
   for (int nt = 0; nt < NT; ++nt) {
     const int n = tn * BN + (wn * NT + nt) * 32 + r32;
     if (n >= p.N) continue;
+    const long noff = p.c_blk_shift ? (long)(n >> p.c_blk_shift) * p.c_blk_stride + (n & ((1 << p.c_blk_shift) - 1)) : (long)n;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int m0 = tm * BM + (wm * MT + mt) * 32 + 4 * h;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + (e & 3) + 8 * (e >> 2);
-        if (m < p.M) cb[(long)m * p.ldc + n] = acc[mt][nt][e] * p.alpha;
+        if (m < p.M) cb[(long)m * p.ldc + noff] = acc[mt][nt][e] * p.alpha;
       }
     }
   }

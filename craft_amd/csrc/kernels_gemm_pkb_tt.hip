@@ -1,5 +1,6 @@
 // craft_gemm_pk, operand kinds (ROWS, ROWS) -- dV = P^T dO, dK = dS^T Q -- and the dispatcher (see gemm_pkb.inc.hpp)
 #include "gemm_pkb.inc.hpp"
+#include "../../include/craft_hip.h"
 
 namespace craft {
 
@@ -24,6 +25,9 @@ static int fill_operand(PkbOperand& X, const void* ptr, const long* d, int K, in
 int launch_gemm_pk(const void* A, const long* a_desc, const void* B, const long* b_desc, float* C, long ldc, long c_outer, long c_inner,
                    int inner, int nbatch, int M, int N, int K, float alpha, int prec, hipStream_t s) {
   if (M <= 0 || N <= 0 || nbatch <= 0) return 0;
+  const int cshift = (prec >> CRAFT_PK_CBLK_SHIFT) & 31;          // CRAFT_PK_CBLK(s)
+  prec &= (1 << CRAFT_PK_CBLK_SHIFT) - 1;
+  if (cshift && (cshift < 5 || c_inner != (1L << cshift))) return CRAFT_ERR_ARG;
   if (K <= 0 || (K & 31) || inner <= 0 || C == nullptr || a_desc == nullptr || b_desc == nullptr) return CRAFT_ERR_ARG;
   if (prec != CRAFT_PREC_F16X3 && prec != CRAFT_PREC_F16 && prec != CRAFT_PREC_BF16) return CRAFT_ERR_UNSUPPORTED;
   PkbParams p = {};
@@ -32,6 +36,7 @@ int launch_gemm_pk(const void* A, const long* a_desc, const void* B, const long*
   rc = fill_operand(p.B, B, b_desc, K, N);
   if (rc) return rc;
   p.C = C; p.ldc = ldc; p.c_outer = c_outer; p.c_inner = c_inner; p.inner = inner; p.nbatch = nbatch; p.M = M; p.N = N; p.K = K; p.alpha = alpha;
+  p.c_blk_shift = cshift; p.c_blk_stride = (long)inner << cshift;
   const int ak = (int)a_desc[0], bk = (int)b_desc[0];
   if (ak == 0 && bk == 0) return launch_gemm_pkb_tt(p, prec, s);
   if (ak == 1 && bk == 0) return launch_gemm_pkb_ct(p, prec, s);

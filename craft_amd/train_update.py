@@ -409,7 +409,14 @@ def _phase2(ps: UpdatePass):
     # ---- B: dV of all iterations in one product over the concatenated dO (P is read once), and the operands of the deferred dP
     TC = T * Cv
     dva_cat = E(B, N, M, TC)
-    if ppk is not None:
+    cshift = Cv.bit_length() - 1 if (ppk is not None and Cv >= 32 and Cv & (Cv - 1) == 0) else 0
+    if cshift:
+        # dV of all iterations as [B, N, T, M, Cv] (CRAFT_PK_CBLK: the modes of a batch entry interleave inside every iteration's column
+        # block), so that iteration t's [B*N, M*Cv] operand below is a strided view -- not 12 contiguous copies of 47 MB
+        AG.gemm_pk(ppk, ppk.desc(AG.PK_ROWS, M, 1), docat, docat.desc(AG.PK_ROWS, M, 1), dva_cat, M * TC, N * M * TC, Cv, M, B * M, N, TC, N, c_blk_shift=cshift)
+        ps.pholder.cat = (docat, ps.vcat)
+        ps.vcat = None
+    elif ppk is not None:
         AG.gemm_pk(ppk, ppk.desc(AG.PK_ROWS, M, 1), docat, docat.desc(AG.PK_ROWS, M, 1), dva_cat, M * TC, N * M * TC, TC, M, B * M, N, TC, N)
         ps.pholder.cat = (docat, ps.vcat)
         ps.vcat = None
@@ -428,7 +435,10 @@ def _phase2(ps: UpdatePass):
         last = t == T - 1                                    # (the order of phase 2 is free: the accumulators complete with its last iteration)
         mf = ps.HX[t][..., MF:MF + 128]
         d_mf = d_mfs[t]
-        dva = dva5[:, :, :, t, :].reshape(B, N, M * Cv)              # M > 1: a contiguous copy; one mode: a strided view (row stride T*Cv)
+        if cshift:
+            dva = dva_cat.view(B, N, T, M * Cv)[:, :, t, :]             # strided view, row stride T*M*Cv
+        else:
+            dva = dva5[:, :, :, t, :].reshape(B, N, M * Cv)          # M > 1: a contiguous copy; one mode: a strided view (row stride T*Cv)
         AG.gemm(dva, dva.stride(-2), 1, 0, 0, wv2, 1, 128, 0, 0, d_mf, 128, 0, 0, 1, 1, rows, 128, M * Cv, accumulate=True, prec=pp)      # d_mf += dva W_v
         ps.wgrad(("agg_v",), (AG.Packed(dva, AG.gprec(pp), batch=pb), S["pk_mf"]), 1, 1, ps.acc(("agg_v", "dw"), (M * Cv, 128)), last)
         d_mf.add_(ps.dv[t][..., 0:128])

@@ -421,6 +421,12 @@ int craft_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* co
  *   With P packed as (rows i, channels j):  O = P V -> (P kind 1, V kind 0);  dV = P^T dO -> (0, 0);  dP = dO V^T -> (1, 1).
  * K % 32 == 0 with ZEROS in the K padding of both packs; the M / N padding may hold anything finite or not (never stored).
  * Kind pairs (0,0), (1,0), (1,1); prec CRAFT_PREC_F16X3 / F16 / BF16 = the mode the packs were written in. */
+/* prec | CRAFT_PK_CBLK(s) (s >= 5, c_inner == 2^s): the N output columns are stored in blocks of 2^s, consecutive blocks inner * 2^s elements
+ * apart -- C[z][m][n] at outer * c_outer + inner_index * 2^s + m * ldc + (n >> s) * inner * 2^s + (n & (2^s - 1)): the batch's `inner` entries
+ * interleave inside every column block, e.g. dV of all T iterations as [B][N][T][M][Cv] from batches (b, m) and columns (t, c), so that one
+ * iteration's [B*N][M*Cv] slice is a strided view instead of a copy. */
+#define CRAFT_PK_CBLK_SHIFT 8
+#define CRAFT_PK_CBLK(s) ((s) << CRAFT_PK_CBLK_SHIFT)
 int craft_gemm_pk(const void* A, const long* a_desc, const void* B, const long* b_desc, float* C, long ldc, long c_outer, long c_inner,
                   int inner, int nbatch, int M, int N, int K, float alpha, int prec, void* stream);
 
