@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from craft_amd import autograd as AG
+from craft_amd import hip
 from craft_amd.hip import PREC_BF16, PREC_F16, PREC_F16X3, round_up
 
 pytestmark = pytest.mark.gpu
@@ -57,6 +58,31 @@ def test_attention_products(device, case, prec, tol):
     assert _rel(dP[..., :N], dO.double() @ Vm.transpose(-1, -2)) < tol
     if ld > N:
         assert float((dP[..., N:] - 7.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("prec,tol", PRECS)
+def test_column_block_output(device, prec, tol):
+    """craft_gemm_pk with CRAFT_PK_CBLK: the (ROWS, ROWS) product dV = P^T [dO_1 .. dO_T] of all T iterations written as [B, N, T, Mh, C] (the
+    modes of a batch entry interleave inside every iteration's column block) holds the same values as the plain [B, N, Mh, T*C] store,
+    and an iteration's [B*N, Mh*C] slice is a strided view (train_update._phase2)."""
+    B, Mh, N, C, T = 2, 4, 200, 128, 3
+    g = torch.Generator().manual_seed(12)
+    ld = round_up(N, 32)
+    P = torch.zeros(B, Mh, N, ld)
+    P[..., :N] = torch.softmax(torch.randn(B, Mh, N, N, generator=g) * 2.0, dim=-1)
+    dO = torch.randn(B, Mh, N, T * C, generator=g)
+    Ppk = AG.PkMat(B * Mh, N, ld, prec, device).fill(P.to(device))
+    dOpk = AG.PkMat(B * Mh, N, T * C, prec, device).fill(dO.to(device))
+    TC = T * C
+    plain = torch.full((B, N, Mh, TC), 7.0, device=device)
+    AG.gemm_pk(Ppk, Ppk.desc(AG.PK_ROWS, Mh, 1), dOpk, dOpk.desc(AG.PK_ROWS, Mh, 1), plain, Mh * TC, N * Mh * TC, TC, Mh, B * Mh, N, TC, N)
+    blk = torch.full((B, N, T, Mh, C), 7.0, device=device)
+    AG.gemm_pk(Ppk, Ppk.desc(AG.PK_ROWS, Mh, 1), dOpk, dOpk.desc(AG.PK_ROWS, Mh, 1), blk, Mh * TC, N * Mh * TC, C, Mh, B * Mh, N, TC, N, c_blk_shift=7)
+    assert torch.equal(blk, plain.view(B, N, Mh, T, C).permute(0, 1, 3, 2, 4))
+    ref = (P[..., :N].double().transpose(-1, -2) @ dO.double()).permute(0, 2, 1, 3)            # [B, N, Mh, T*C]
+    assert _rel(plain, ref) < tol
+    with pytest.raises(hip.CraftHipError):                                                      # c_inner must be the block width
+        AG.gemm_pk(Ppk, Ppk.desc(AG.PK_ROWS, Mh, 1), dOpk, dOpk.desc(AG.PK_ROWS, Mh, 1), blk, Mh * TC, N * Mh * TC, TC, Mh, B * Mh, N, TC, N, c_blk_shift=7)
 
 
 @pytest.mark.parametrize("M,N,K", [(257, 129, 96), (31, 65, 700), (512, 256, 64), (300, 20, 2852)])

@@ -157,3 +157,48 @@ def test_dynamic_loss_scale_skips_backs_off_and_recovers(device, max_norm):
     ours.flat_grad[0] = float("nan")
     ours.step(max_norm=max_norm)
     assert ours.scaler_snapshot(wait=True)["skipped_steps"] == 2 and ours.step_count == 4
+
+
+def test_flow_tokens_one_launch(device):
+    """craft_flow_tokens (network.py:232-234, :247): flow = coords1 - coords0, its zero-padded 32-wide copy and the copy of coords1."""
+    from craft_amd.hip import call
+    g = torch.Generator().manual_seed(5)
+    B, N = 3, 1001
+    c1 = (torch.randn(B, N, 2, generator=g) * 50).to(device)
+    c0 = (torch.randn(B, N, 2, generator=g) * 50).to(device)
+    flow = torch.full((B, N, 2), 9.0, device=device)
+    f32 = torch.full((B, N, 32), 9.0, device=device)
+    cc = torch.full((B, N, 2), 9.0, device=device)
+    call("craft_flow_tokens", c1, c0, B * N, flow, f32, cc)
+    assert torch.equal(flow, c1 - c0) and torch.equal(cc, c1)
+    assert torch.equal(f32[..., :2], c1 - c0) and float(f32[..., 2:].abs().max()) == 0.0
+    flow2 = torch.empty_like(flow)
+    call("craft_flow_tokens", c1, c0, B * N, flow2, None, None)          # the optional outputs
+    assert torch.equal(flow2, flow)
+
+
+def test_convex_upsample_backward_into_a_padded_flow_gradient(device):
+    """craft_convex_upsample_bwd's flow-gradient row stride (ABI 3): accumulated straight into the flow head's 32-wide padded output
+    gradient it equals the dense [B*N][2] form (atomics: compared to round-off), and the other 30 columns stay untouched."""
+    from craft_amd.hip import call
+    g = torch.Generator().manual_seed(6)
+    B, H8, W8 = 2, 9, 13
+    N = H8 * W8
+    mask = torch.randn(B, N, 576, generator=g).to(device)
+    flow = torch.randn(B, N, 2, generator=g).to(device)
+    dup = torch.randn(B, 2, 8 * H8, 8 * W8, generator=g).to(device)
+    dm2, d2 = torch.empty(B, N, 576, device=device), torch.zeros(B, N, 2, device=device)
+    call("craft_convex_upsample_bwd", mask, 576, flow, dup, B, H8, W8, dm2, 576, d2, 2)
+    dm32, d32 = torch.empty(B, N, 576, device=device), torch.zeros(B, N, 32, device=device)
+    d32[..., 2:] = 3.0
+    call("craft_convex_upsample_bwd", mask, 576, flow, dup, B, H8, W8, dm32, 576, d32, 32)
+    assert torch.equal(dm2, dm32)
+    assert torch.allclose(d32[..., :2], d2, rtol=1e-5, atol=1e-5) and float((d32[..., 2:] - 3.0).abs().max()) == 0.0
+    # against torch autograd of the reference formula (network.py:151-162)
+    fl = flow.clone().requires_grad_(True)
+    mk = mask.clone().requires_grad_(True)
+    m = torch.softmax(mk.view(B, H8, W8, 9, 64).permute(0, 3, 4, 1, 2).reshape(B, 1, 9, 8, 8, H8, W8), dim=2)
+    uf = torch.nn.functional.unfold(8 * fl.view(B, H8, W8, 2).permute(0, 3, 1, 2), [3, 3], padding=1).view(B, 2, 9, 1, 1, H8, W8)
+    up = torch.sum(m * uf, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(B, 2, 8 * H8, 8 * W8)
+    up.backward(dup)
+    assert torch.allclose(d2, fl.grad, rtol=1e-4, atol=1e-4) and torch.allclose(dm2, mk.grad, rtol=1e-4, atol=1e-4)

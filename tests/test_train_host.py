@@ -57,6 +57,61 @@ def test_flat_views_and_state_layout():
     assert opt.step_count == 1 and torch.equal(opt.state_dict()["state"][1]["exp_avg"], rsd["state"][1]["exp_avg"])
 
 
+def test_load_grads_copies_captured_gradients_and_clears_stale_views():
+    """FlatAdamW.load_grads (what Trainer.step does with torch.autograd.grad's result): equal to zero_grad() + backward(), non-contiguous
+    gradients included; a parameter that loses its gradient gets its view zeroed; p.grad keeps pointing into the flat buffer."""
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Flatten(), torch.nn.Linear(100, 2), torch.nn.Linear(2, 3))
+    opt = FlatAdamW(net.parameters(), lr=1e-3)
+    x = torch.randn(2, 3, 7, 7)
+    opt.zero_grad()
+    net(x).sum().backward()
+    want = opt.flat_grad.clone()
+    opt.flat_grad.fill_(7.0)                       # (load_grads does not rely on a zeroed buffer for the views it writes)
+    pad = torch.ones_like(opt.flat_grad, dtype=torch.bool)
+    for p, off in zip(opt.params, opt.offsets):
+        pad[off:off + p.numel()] = False
+    opt.flat_grad[pad] = 0.0                       # (the alignment padding is zero from the allocation and stays so)
+    grads = list(torch.autograd.grad(net(x).sum(), opt.params, allow_unused=True))
+    grads[0] = grads[0].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)          # a strided view, as the kernels' accumulators return
+    opt.load_grads(grads)
+    assert torch.equal(opt.flat_grad, want)
+    for p, off in zip(opt.params, opt.offsets):
+        assert p.grad.data_ptr() == opt.flat_grad[off:].data_ptr()
+    # the last layer drops out of the graph: its views are cleared, the others rewritten
+    g2 = list(torch.autograd.grad(net[:3](x).sum(), opt.params, allow_unused=True))
+    assert g2[-1] is None and g2[-2] is None
+    opt.load_grads(g2)
+    n_last = opt.params[-1].numel() + opt.params[-2].numel()
+    assert float(opt.grad_views()[-1].abs().sum()) == 0.0 and float(opt.grad_views()[-2].abs().sum()) == 0.0 and n_last > 0
+    assert float(opt.grad_views()[0].abs().sum()) > 0
+    with pytest.raises(ValueError):
+        opt.load_grads([torch.zeros(1)] + g2[1:])
+
+
+def test_tiled_probability_layout_helpers():
+    """ops.probs_tiled / probs_rowmajor / vt_stride (the CRAFT_P_TILED layout of include/craft_hip.h) on the CPU: element (i, j) at
+    (i >> 5) * 32 * ldp + (j >> 6) * 2048 + (i & 31) * 64 + (j & 63), key extent rounded to 64, V^T's to 32."""
+    from craft_amd import ops
+    B, M, N = 2, 3, 100
+    P = torch.arange(B * M * N * N, dtype=torch.float32).view(B, M, N, N)
+    Pp = torch.zeros(B, M, N, ops.round_up(N, 32))
+    Pp[..., :N] = P
+    T = ops.probs_tiled(Pp, fill=-1.0)
+    assert T.craft_tiled and T.craft_n == N and tuple(T.shape) == (B, M, 128, 128) and ops.vt_stride(T) == 128 and ops.vt_stride(Pp) == 128
+    flat = T[1, 2].reshape(-1)
+    ldp = 128
+    for i, j in ((0, 0), (31, 63), (32, 64), (99, 99), (45, 70), (64, 5)):
+        assert float(flat[(i >> 5) * 32 * ldp + (j >> 6) * 2048 + (i & 31) * 64 + (j & 63)]) == float(P[1, 2, i, j])
+    assert float(flat[(3 * 32) * ldp + 0 * 2048 + 4 * 64 + 0]) == -1.0            # row 100: padding row keeps the fill
+    assert float(flat[(0 >> 5) * 32 * ldp + (100 >> 6) * 2048 + 0 * 64 + (100 & 63)]) == 0.0     # column 100 of a real row: zero
+    assert torch.equal(ops.probs_rowmajor(T), P)
+    sl = ops.probs_slice(T, 1, 2)
+    assert sl.craft_tiled and sl.craft_n == N and torch.equal(ops.probs_rowmajor(sl), P[1:2])
+    N2 = 40                                        # round_up(N, 32) = 64 = round_up(N, 64); N = 70: 96 vs 128
+    assert ops.vt_stride(ops.probs_tiled(torch.zeros(1, 1, 70, 96))) == 96
+
+
 WORKER = textwrap.dedent("""
     import sys
     sys.path.insert(0, %r)
