@@ -388,7 +388,8 @@ def train_leg(cfg, rank, world, dev, steps, warmup, iters, B=None, H=None, W=Non
 
     def step():
         last["m"] = tr.step(im1, im2, flow, valid)
-        last.setdefault("first", last["m"]["loss"])
+        # (this rank's own loss: with N > 1 ranks "loss" is the mean over the ranks, which see different pairs)
+        last.setdefault("first", last["m"].get("loss_rank", last["m"]["loss"]))
 
     dt_rank = timed_steps(step, steps=steps, warmup=warmup, sync=torch.cuda.synchronize)
     value, dt = aggregate_throughput(pairs_per_rank_step=B, steps=steps, dt=dt_rank)

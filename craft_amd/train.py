@@ -498,6 +498,7 @@ class Trainer:
             gc.collect()
             gc.freeze()
         metrics = dict(metrics, loss=float(loss.detach()))
+        metrics["loss_rank"] = metrics["loss"]        # this rank's own loss ("loss" / "epe" become the mean over the ranks below)
         snap = opt.scaler_snapshot()       # (float(loss) above drained the stream: this is the step just taken)
         if snap is not None:
             metrics.update(loss_scale=snap["loss_scale"], skipped_steps=snap["skipped_steps"], applied_steps=snap["applied_steps"])

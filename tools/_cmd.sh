@@ -1,3 +1,2 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 1500 python tools/fuzz_parity.py 60 9000 variants > gpurun_out/fuzz_parity_r4b.txt 2>&1; tail -3 gpurun_out/fuzz_parity_r4b.txt
-timeout 1500 python tools/fuzz_train_parity.py 16 9100 > gpurun_out/fuzz_train_r4b.txt 2>&1; tail -3 gpurun_out/fuzz_train_r4b.txt
+cd $GRAFT_REPO_ROOT
+timeout 1700 python -m pytest tests/test_bench_contract.py -m gpu -q --tb=short -p no:cacheprovider -k "two_rank_default or rccl_world1" 2>&1 | tail -15
