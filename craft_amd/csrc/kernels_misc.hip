@@ -239,7 +239,11 @@ int launch_corr_stats(const double* sums, float* mu_rstd, int B, double count, i
 // values per output channel k = l*(2r+1)^2 + a*(2r+1) + b  with  X = x/2^l + a - r,  Y = y/2^l + b - r
 // (the x offset runs along the FIRST window axis).
 // ---------------------------------------------------------------------------------------------
+// RADIUS > 0: the window radius as a compile-time constant (the reference's radius 4).  The patch gather and the blend index their
+// elements by `idx / PS`, `k / win^2`, `rem / win`: with run-time divisors those are ~30 VALU instructions each, 34 of them per lane -- the
+// kernel was VALU-bound on address arithmetic (52 us at 448x1024, batch 4), not on its gathers.  RADIUS = 0 keeps the run-time form.
 #define LOOKUP_MAXP 16
+template <int RADIUS>
 __global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ l0, const float* __restrict__ l1,
                                                      const float* __restrict__ l2, const float* __restrict__ l3, int levels,
                                                      const float* __restrict__ mu_rstd, const float* __restrict__ coords,
@@ -253,37 +257,71 @@ __global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ l
   const int b = (int)(q / N);
   const float cx = coords[2 * q], cy = coords[2 * q + 1];
   const float mu = mu_rstd[2 * b], rstd = mu_rstd[2 * b + 1];
-  const int PS = 2 * radius + 2, win = 2 * radius + 1;
+  if (RADIUS) radius = RADIUS;
+  const int PS = RADIUS ? 2 * RADIUS + 2 : 2 * radius + 2, win = RADIUS ? 2 * RADIUS + 1 : 2 * radius + 1;
   float fxs[4], fys[4];
   const float* lv[4] = {l0, l1, l2, l3};
-  int h = H8, w = W8;
-  float sc = 1.f;
-  for (int l = 0; l < levels; ++l) {
-    const float X = cx * sc, Y = cy * sc;
-    const float x0f = floorf(X), y0f = floorf(Y);
-    fxs[l] = X - x0f;
-    fys[l] = Y - y0f;
-    // clamp the integer base far outside the image so int conversion can not overflow
-    const int x0 = (int)fminf(fmaxf(x0f, -100000.f), 100000.f) - radius;
-    const int y0 = (int)fminf(fmaxf(y0f, -100000.f), 100000.f) - radius;
-    // CRAFT_PYR_TILED (craft_corr_build_pyramid's layout): level 0 in 8 x 16 tiles of 128 floats, level 1 in 4 x 8 tiles of 32
-    const bool tl = tiled && l < 2;
-    const int tsy = l == 0 ? 3 : 2, tsx = l == 0 ? 4 : 3;                    // log2 of the tile height / width
-    const int ntx = (w + (1 << tsx) - 1) >> tsx, nty = (h + (1 << tsy) - 1) >> tsy;
-    const float* img = lv[l] + q * (tl ? ((long)nty * ntx) << (tsy + tsx) : (long)h * w);
-    for (int idx = lane; idx < PS * PS; idx += 64) {
-      const int py = idx / PS, px = idx - py * PS;
-      const int y = y0 + py, x = x0 + px;
-      float v = 0.f;
-      if (y >= 0 && y < h && x >= 0 && x < w) {
-        const long off = tl ? ((((long)(y >> tsy) * ntx + (x >> tsx)) << (tsy + tsx)) + ((y & ((1 << tsy) - 1)) << tsx) + (x & ((1 << tsx) - 1)))
-                            : (long)y * w + x;
-        v = (img[off] - mu) * rstd;
-      }
-      patch[wv][l][py * LOOKUP_MAXP + px] = v;
+  // Phase 1 requests the patch elements of ALL levels before any of them is used (one HBM round trip per query instead of one per
+  // level: the level loop with its load -> normalise -> LDS store body made four dependent round trips, ~2 us each under load), phase 2
+  // normalises and publishes them.  NI = 64-lane passes over a (2r+2)^2 patch.
+  constexpr int NI = RADIUS ? ((2 * RADIUS + 2) * (2 * RADIUS + 2) + 63) / 64 : (LOOKUP_MAXP * LOOKUP_MAXP) / 64;
+  float vals[4][NI];
+  unsigned okm = 0u;                       // bit l * NI + j: element j of level l is inside the image
+  // (everything that reads the coordinates first, for all levels: a wait for them placed between the gathers of two levels would --
+  // the vector-memory counter retires in order -- also drain the gathers already in flight)
+  int x0s[4], y0s[4];
+  {
+    float sc = 1.f;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const float X = cx * sc, Y = cy * sc;
+      const float x0f = floorf(X), y0f = floorf(Y);
+      fxs[l] = X - x0f;
+      fys[l] = Y - y0f;
+      // clamp the integer base far outside the image so int conversion can not overflow
+      x0s[l] = (int)fminf(fmaxf(x0f, -100000.f), 100000.f) - radius;
+      y0s[l] = (int)fminf(fmaxf(y0f, -100000.f), 100000.f) - radius;
+      sc *= 0.5f;
     }
-    h >>= 1; w >>= 1; sc *= 0.5f;
   }
+  asm volatile("" : "+v"(x0s[0]), "+v"(x0s[1]), "+v"(x0s[2]), "+v"(x0s[3]), "+v"(y0s[0]), "+v"(y0s[1]), "+v"(y0s[2]), "+v"(y0s[3]));   // (materialised here)
+  int h = H8, w = W8;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    if (l < levels) {
+      const int x0 = x0s[l], y0 = y0s[l];
+      // CRAFT_PYR_TILED (craft_corr_build_pyramid's layout): level 0 in 8 x 16 tiles of 128 floats, level 1 in 4 x 8 tiles of 32
+      const bool tl = tiled && l < 2;
+      const int tsy = l == 0 ? 3 : 2, tsx = l == 0 ? 4 : 3;                    // log2 of the tile height / width
+      const int ntx = (w + (1 << tsx) - 1) >> tsx, nty = (h + (1 << tsy) - 1) >> tsy;
+      const float* img = lv[l] + q * (tl ? ((long)nty * ntx) << (tsy + tsx) : (long)h * w);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int idx = lane + 64 * j;
+        const int py = idx / PS, px = idx - py * PS;
+        const int y = y0 + py, x = x0 + px;
+        // unconditional load from a clamped address, validity kept as a mask bit: a load under the bounds test compiles to
+        // branch + load + s_waitcnt vmcnt(0) -- eight dependent round trips per query
+        const bool ok = idx < PS * PS && y >= 0 && y < h && x >= 0 && x < w;
+        const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
+        const int off_t = ((((yc >> tsy) * ntx + (xc >> tsx)) << (tsy + tsx)) + ((yc & ((1 << tsy) - 1)) << tsx) + (xc & ((1 << tsx) - 1)));
+        const int off = tl ? off_t : yc * w + xc;            // (one query's level: < 2^31 elements)
+        okm |= ok ? 1u << (l * NI + j) : 0u;
+        vals[l][j] = img[off];
+      }
+      h >>= 1; w >>= 1;
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+    if (l < levels) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int idx = lane + 64 * j;
+        const int py = idx / PS, px = idx - py * PS;
+        if (idx < PS * PS) patch[wv][l][py * LOOKUP_MAXP + px] = ((okm >> (l * NI + j)) & 1u) ? (vals[l][j] - mu) * rstd : 0.f;
+      }
+    }
   __syncthreads();
   if (!valid) return;
   const int nch = levels * win * win;
@@ -306,8 +344,12 @@ int launch_corr_lookup(const float* l0, const float* l1, const float* l2, const 
   if (lvl_stride <= 0) lvl_stride = win2;            // default: one volume, levels back to back
   if (lvl_stride < win2 || col_off < 0 || col_off + win2 > lvl_stride) return CRAFT_ERR_ARG;
   const long nq = (long)B * H8 * W8;
-  hipLaunchKernelGGL(k_corr_lookup, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, l0, l1, l2, l3, levels, mu_rstd, coords,
-                     H8 * W8, H8, W8, radius, out, ldo, lvl_stride, col_off, nq, tiled);
+  if (radius == 4)
+    hipLaunchKernelGGL(k_corr_lookup<4>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, l0, l1, l2, l3, levels, mu_rstd, coords,
+                       H8 * W8, H8, W8, radius, out, ldo, lvl_stride, col_off, nq, tiled);
+  else
+    hipLaunchKernelGGL(k_corr_lookup<0>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, l0, l1, l2, l3, levels, mu_rstd, coords,
+                       H8 * W8, H8, W8, radius, out, ldo, lvl_stride, col_off, nq, tiled);
   return (int)hipGetLastError();
 }
 

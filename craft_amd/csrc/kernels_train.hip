@@ -671,6 +671,7 @@ int launch_corr_pyramid_bwd(float* G0, const float* G1, const float* G2, const f
 // contributions of its cell and adds them with one plain read-modify-write (nothing else touches query q's images during a
 // launch) -- 100 coalesced updates per level instead of 324 fp32 atomics (the scatter form took 246 us per call at configs[3]).
 // ---------------------------------------------------------------------------------------------
+template <int RADIUS>       // > 0: compile-time window radius (constant divisors, as k_corr_lookup); 0: run-time
 __global__ __launch_bounds__(256) void k_corr_lookup_bwd(const float* __restrict__ dout, long ldo, const float* __restrict__ coords,
                                                          float* __restrict__ G0, float* __restrict__ G1, float* __restrict__ G2,
                                                          float* __restrict__ G3, int levels, int H8, int W8, int radius, int lvl_stride,
@@ -679,43 +680,88 @@ __global__ __launch_bounds__(256) void k_corr_lookup_bwd(const float* __restrict
   const long q = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= nq) return;
   const float cx = coords[2 * q], cy = coords[2 * q + 1];
-  const int win = 2 * radius + 1, fp = win + 1;
+  if (RADIUS) radius = RADIUS;
+  const int win = RADIUS ? 2 * RADIUS + 1 : 2 * radius + 1, fp = win + 1;
   float* Gl[4] = {G0, G1, G2, G3};
-  int h = H8, w = W8;
-  float sc = 1.f;
-  for (int l = 0; l < levels; ++l) {
-    const float X = cx * sc, Y = cy * sc;
-    const float x0f = floorf(X), y0f = floorf(Y);
-    const float fx = X - x0f, fy = Y - y0f;
-    const int x0 = (int)fminf(fmaxf(x0f, -100000.f), 100000.f) - radius;
-    const int y0 = (int)fminf(fmaxf(y0f, -100000.f), 100000.f) - radius;
-    float* img = Gl[l] + q * (long)h * w;
-    const float* g = dout + q * ldo + l * lvl_stride + col_off;      // g[a * win + bb]: x offset a, y offset bb
-    const float wx[2] = {1.f - fx, fx}, wy[2] = {1.f - fy, fy};
-    for (int c = lane; c < fp * fp; c += 64) {
-      const int v = c / fp, u = c - v * fp;             // footprint cell: x = x0 + u, y = y0 + v (u fastest: coalesced rows)
-      const int x = x0 + u, y = y0 + v;
-      if (x < 0 || x >= w || y < 0 || y >= h) continue;
-      float acc = 0.f;
+  // As in k_corr_lookup: every load of the query is requested before any of them is used, from clamped addresses (a load under a
+  // bounds test compiles to branch + load + s_waitcnt vmcnt(0): 40 dependent round trips per query in the first version), the bounds
+  // live on as 0 / 1 weights and as the store's predicate.  NI = 64-lane passes over the (2r+2)^2 footprint.
+  constexpr int NI = RADIUS ? ((2 * RADIUS + 2) * (2 * RADIUS + 2) + 63) / 64 : 4;
+  if (!RADIUS && fp * fp > 64 * NI) return;                       // (the launcher bounds the run-time radius)
+  float gv[4][NI][4], old[4][NI], wgt[4][NI][4];
+  int offs[4][NI];
+  unsigned okm = 0u;
+  int x0s[4], y0s[4];
+  float fxs[4], fys[4];
+  {
+    float sc = 1.f;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int a = u - (t & 1), bb = v - (t >> 1);
-        if (a >= 0 && a < win && bb >= 0 && bb < win) acc += wx[t & 1] * wy[t >> 1] * g[a * win + bb];
-      }
-      img[y * w + x] += acc;
+    for (int l = 0; l < 4; ++l) {
+      const float X = cx * sc, Y = cy * sc;
+      const float x0f = floorf(X), y0f = floorf(Y);
+      fxs[l] = X - x0f; fys[l] = Y - y0f;
+      x0s[l] = (int)fminf(fmaxf(x0f, -100000.f), 100000.f) - radius;
+      y0s[l] = (int)fminf(fmaxf(y0f, -100000.f), 100000.f) - radius;
+      sc *= 0.5f;
     }
-    h >>= 1; w >>= 1; sc *= 0.5f;
+  }
+  asm volatile("" : "+v"(x0s[0]), "+v"(x0s[1]), "+v"(x0s[2]), "+v"(x0s[3]), "+v"(y0s[0]), "+v"(y0s[1]), "+v"(y0s[2]), "+v"(y0s[3]));
+  int h = H8, w = W8;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    if (l < levels) {
+      const float* img = Gl[l] + q * (long)h * w;
+      const float* g = dout + q * ldo + l * lvl_stride + col_off;      // g[a * win + bb]: x offset a, y offset bb
+      const float wx[2] = {1.f - fxs[l], fxs[l]}, wy[2] = {1.f - fys[l], fys[l]};
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int c = lane + 64 * j;
+        const int v = c / fp, u = c - v * fp;             // footprint cell: x = x0 + u, y = y0 + v (u fastest: coalesced rows)
+        const int x = x0s[l] + u, y = y0s[l] + v;
+        const bool ok = c < fp * fp && x >= 0 && x < w && y >= 0 && y < h;
+        okm |= ok ? 1u << (l * NI + j) : 0u;
+        offs[l][j] = min(max(y, 0), h - 1) * w + min(max(x, 0), w - 1);
+        old[l][j] = img[offs[l][j]];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int a = u - (t & 1), bb = v - (t >> 1);
+          const bool in = a >= 0 && a < win && bb >= 0 && bb < win;
+          wgt[l][j][t] = in ? wx[t & 1] * wy[t >> 1] : 0.f;
+          gv[l][j][t] = g[min(max(a, 0), win - 1) * win + min(max(bb, 0), win - 1)];
+        }
+      }
+      h >>= 1; w >>= 1;
+    }
+  }
+  h = H8; w = W8;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    if (l < levels) {
+      float* img = Gl[l] + q * (long)h * w;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc += wgt[l][j][t] * gv[l][j][t];
+        if ((okm >> (l * NI + j)) & 1u) img[offs[l][j]] = old[l][j] + acc;
+      }
+      h >>= 1; w >>= 1;
+    }
   }
 }
 int launch_corr_lookup_bwd(const float* dout, long ldo, const float* coords, float* G0, float* G1, float* G2, float* G3, int levels, int B,
                            int H8, int W8, int radius, int lvl_stride, int col_off, hipStream_t s) {
-  if (levels < 1 || levels > 4 || radius < 0) return CRAFT_ERR_UNSUPPORTED;
+  if (levels < 1 || levels > 4 || radius < 0 || 2 * radius + 2 > 16) return CRAFT_ERR_UNSUPPORTED;
   const int win2 = (2 * radius + 1) * (2 * radius + 1);
   if (lvl_stride <= 0) lvl_stride = win2;
   const long nq = (long)B * H8 * W8;
   if (nq <= 0) return 0;
-  hipLaunchKernelGGL(k_corr_lookup_bwd, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, dout, ldo, coords, G0, G1, G2, G3, levels, H8, W8,
-                     radius, lvl_stride, col_off, nq);
+  if (radius == 4)
+    hipLaunchKernelGGL(k_corr_lookup_bwd<4>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, dout, ldo, coords, G0, G1, G2, G3, levels, H8, W8,
+                       radius, lvl_stride, col_off, nq);
+  else
+    hipLaunchKernelGGL(k_corr_lookup_bwd<0>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, dout, ldo, coords, G0, G1, G2, G3, levels, H8, W8,
+                       radius, lvl_stride, col_off, nq);
   return (int)hipGetLastError();
 }
 
