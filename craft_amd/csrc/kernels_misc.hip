@@ -509,14 +509,19 @@ __global__ __launch_bounds__(256) void k_convex_upsample(const float* __restrict
 #pragma unroll
   for (int k = 0; k < 9; ++k) { mk[k] = expf(mk[k] - mx); den += mk[k]; }
   float ox = 0.f, oy = 0.f;
+  // (the 9 neighbour flows from clamped addresses, zero padding applied to the values: loads under the bounds test were nine
+  // dependent round trips)
+  float2 fl[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = min(max(y + k / 3 - 1, 0), H8 - 1), xx = min(max(x + k % 3 - 1, 0), W8 - 1);
+    fl[k] = *reinterpret_cast<const float2*>(flow + ((long)b * hw + yy * W8 + xx) * 2);
+  }
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
     const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
-    float fx = 0.f, fy = 0.f;
-    if (yy >= 0 && yy < H8 && xx >= 0 && xx < W8) {
-      const float2 f = *reinterpret_cast<const float2*>(flow + ((long)b * hw + yy * W8 + xx) * 2);
-      fx = 8.f * f.x; fy = 8.f * f.y;
-    }
+    const bool ok = yy >= 0 && yy < H8 && xx >= 0 && xx < W8;
+    const float fx = ok ? 8.f * fl[k].x : 0.f, fy = ok ? 8.f * fl[k].y : 0.f;
     const float pk = mk[k] / den;
     ox += pk * fx;
     oy += pk * fy;

@@ -893,13 +893,20 @@ __global__ __launch_bounds__(256) void k_convex_upsample_bwd(const float* __rest
 #pragma unroll
   for (int k = 0; k < 9; ++k) { mk[k] = expf(mk[k] - mx); den += mk[k]; }
   float dm[9], dsum = 0.f;
+  // (the 9 neighbour flows requested together from clamped addresses; `ok ? load : 0` compiled to a load under a branch each)
+  float2 fl[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = min(max(y + k / 3 - 1, 0), H8 - 1), xx = min(max(x + k % 3 - 1, 0), W8 - 1);
+    fl[k] = *reinterpret_cast<const float2*>(flow + 2 * (b * N + yy * W8 + xx));
+  }
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
     mk[k] /= den;
     const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
     const bool ok = yy >= 0 && yy < H8 && xx >= 0 && xx < W8;
     const long nb = b * N + (ok ? yy * W8 + xx : 0);
-    const float f0 = ok ? 8.f * flow[2 * nb] : 0.f, f1 = ok ? 8.f * flow[2 * nb + 1] : 0.f;
+    const float f0 = ok ? 8.f * fl[k].x : 0.f, f1 = ok ? 8.f * fl[k].y : 0.f;
     dm[k] = g0 * f0 + g1 * f1;
     dsum += mk[k] * dm[k];
     const float d0 = wave_sum(8.f * mk[k] * g0), d1 = wave_sum(8.f * mk[k] * g1);
