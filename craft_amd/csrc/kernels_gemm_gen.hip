@@ -190,7 +190,21 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_gen(GenGemmParams p) {
     else if (mode == 1) store_all([](float* d, float t) __attribute__((always_inline)) { *d += t; }, inb);
     else store_all([](float* d, float t) __attribute__((always_inline)) { unsafeAtomicAdd(d, t); }, inb);
   };
-  if (inside) go(std::true_type());
+  if (inside && mode == 1) {
+    // C += : the 16 old values of a fragment are requested together (`*d += t` per element is load, wait, add, store: 64 dependent
+    // round trips per lane)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float* d0 = C + (long)(rb + mt * 32 + rh) * ldc + cb + nt * 32 + c;
+        float old[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) old[e] = d0[(long)((e & 3) + 8 * (e >> 2)) * ldc];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) d0[(long)((e & 3) + 8 * (e >> 2)) * ldc] = old[e] + acc[mt][nt][e] * alpha;
+      }
+  } else if (inside) go(std::true_type());
   else go(std::false_type());
 }
 
