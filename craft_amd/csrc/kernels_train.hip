@@ -516,8 +516,10 @@ __global__ __launch_bounds__(256) void k_corr_pool_fwd(const float* __restrict__
   const bool clamp = clamp_active(clamp_ord);
   const float w = M > 1 ? *wp : 1.f;
   float s1 = 0.f, s2 = 0.f;
-  for (int j = threadIdx.x; j < N; j += 256) {
-    const int hj = j / W8, wj = j - hj * W8;
+  const int dq = 256 / W8, dr = 256 - dq * W8;          // (key row / column advance incrementally: no division per element)
+  int hj = (int)threadIdx.x / W8, wj = (int)threadIdx.x - hj * W8;
+  for (int j = threadIdx.x; j < N; j += 256, wj += dr, hj += dq) {
+    if (wj >= W8) { wj -= W8; ++hj; }
     const float pb = pos_tab ? pos_w * pos_bias_at(pos_tab, R, hi, wi, hj, wj) : 0.f;
     float sm[M], a[M];
 #pragma unroll
@@ -571,8 +573,10 @@ __global__ __launch_bounds__(256) void k_corr_pool_bwd(float* __restrict__ S, lo
   const double cnt = (double)N * N;
   const float mg = do_norm ? (float)(gstats[2 * b] / cnt) : 0.f, mgc = do_norm ? (float)(gstats[2 * b + 1] / cnt) : 0.f;
   float dwl = 0.f;
-  for (int j = threadIdx.x; j < N; j += 256) {
-    const int hj = j / W8, wj = j - hj * W8;
+  const int dq = 256 / W8, dr = 256 - dq * W8;          // (key row / column advance incrementally: no division per element)
+  int hj = (int)threadIdx.x / W8, wj = (int)threadIdx.x - hj * W8;
+  for (int j = threadIdx.x; j < N; j += 256, wj += dr, hj += dq) {
+    if (wj >= W8) { wj -= W8; ++hj; }
     const int dh = hj - hi, dwd = wj - wi;
     const bool inwin = pos_tab && dh >= -R && dh <= R && dwd >= -R && dwd <= R;
     const float pb = inwin ? pos_w * pos_tab[(dh + R) * T + dwd + R] : 0.f;
@@ -641,16 +645,33 @@ __global__ __launch_bounds__(256) void k_corr_pyramid_bwd(float* __restrict__ G0
   const float mu = mu_rstd[2 * b], rstd = mu_rstd[2 * b + 1];
   const int h1 = H8 >> 1, w1 = W8 >> 1, h2 = h1 >> 1, w2 = w1 >> 1, h3 = h2 >> 1, w3 = w2 >> 1;
   float s1 = 0.f, s2 = 0.f;
+  // Every load of an element is unconditional (clamped cell of the coarser level, the bounds as 0 / 1 weights; an absent level reads G0
+  // with weight 0): under the bounds tests each was branch + load + vmcnt(0), four dependent round trips per element.  (y, x) advance
+  // incrementally (a run-time division per element is ~30 VALU instructions).
+  const float* L1 = G1 ? G1 + q * h1 * w1 : G0 + q * N;
+  const float* L2 = G2 ? G2 + q * h2 * w2 : G0 + q * N;
+  const float* L3 = G3 ? G3 + q * h3 * w3 : G0 + q * N;
+  const float k1 = G1 ? 0.25f : 0.f, k2 = G2 ? 0.0625f : 0.f, k3 = G3 ? 0.015625f : 0.f;
+  const int dq = 256 / W8, dr = 256 - dq * W8;
+  int y = (int)threadIdx.x / W8, x = (int)threadIdx.x - y * W8;
   for (int j = threadIdx.x; j < N; j += 256) {
-    const int y = j / W8, x = j - y * W8;
-    float g = G0[q * N + j];
-    if (G1 && (y >> 1) < h1 && (x >> 1) < w1) g += 0.25f * G1[q * h1 * w1 + (y >> 1) * w1 + (x >> 1)];
-    if (G2 && (y >> 2) < h2 && (x >> 2) < w2 && (y >> 1) < 2 * h2 && (x >> 1) < 2 * w2) g += 0.0625f * G2[q * h2 * w2 + (y >> 2) * w2 + (x >> 2)];
-    if (G3 && (y >> 3) < h3 && (x >> 3) < w3 && (y >> 2) < 2 * h3 && (x >> 2) < 2 * w3 && (y >> 1) < 2 * h2 && (x >> 1) < 2 * w2)
-      g += 0.015625f * G3[q * h3 * w3 + (y >> 3) * w3 + (x >> 3)];
+    const float g0 = G0[q * N + j];
+    const float cc = c0[q * N + j];
+    const float g1 = L1[min(y >> 1, max(h1 - 1, 0)) * w1 + min(x >> 1, max(w1 - 1, 0))];
+    const float g2 = L2[min(y >> 2, max(h2 - 1, 0)) * w2 + min(x >> 2, max(w2 - 1, 0))];
+    const float g3 = L3[min(y >> 3, max(h3 - 1, 0)) * w3 + min(x >> 3, max(w3 - 1, 0))];
+    const bool in1 = G1 != nullptr && (y >> 1) < h1 && (x >> 1) < w1;
+    const bool in2 = G2 != nullptr && (y >> 2) < h2 && (x >> 2) < w2 && (y >> 1) < 2 * h2 && (x >> 1) < 2 * w2;
+    const bool in3 = G3 != nullptr && (y >> 3) < h3 && (x >> 3) < w3 && (y >> 2) < 2 * h3 && (x >> 2) < 2 * w3 && (y >> 1) < 2 * h2 && (x >> 1) < 2 * w2;
+    float g = g0;
+    g += in1 ? k1 * g1 : 0.f;
+    g += in2 ? k2 * g2 : 0.f;
+    g += in3 ? k3 * g3 : 0.f;
     G0[q * N + j] = g;
     s1 += g;
-    s2 += g * (c0[q * N + j] - mu) * rstd;
+    s2 += g * (cc - mu) * rstd;
+    x += dr; y += dq;
+    if (x >= W8) { x -= W8; ++y; }
   }
   s1 = block_sum_256(s1, red);
   s2 = block_sum_256(s2, red);

@@ -1,8 +1,7 @@
 cd $GRAFT_REPO_ROOT; R=$GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_hip_ops.py tests/test_hip_e2e.py tests/test_train_backward.py tests/test_train_update.py tests/test_train_encoder.py -m gpu -q --tb=short -p no:cacheprovider -k "encoder or stem or golden or e2e or gemm or fused_iteration" 2>&1 | tail -3
-bash tools/gpu.sh ab
+timeout 1500 python -m pytest tests/test_train_backward.py tests/test_hip_ops.py -m gpu -q --tb=short -p no:cacheprovider -k "corr or pool or pyramid or volume or training_step" 2>&1 | tail -3
+for lib in libcraft_hip_prev.so libcraft_hip.so; do CRAFT_HIP_LIB=$R/craft_amd/$lib bash tools/gpu.sh kstats cp_$lib python $R/bench.py --train 3 --steps 6 --warmup 3 --no-cpu-baseline 2>/dev/null | grep 'corr_p'; done
 tr() { python -c "import sys,json; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print(d['ms_per_step'], d.get('value'))"; }
 for r in 1 2; do for lib in libcraft_hip_prev.so libcraft_hip.so; do
  echo "train $lib $(CRAFT_HIP_LIB=$R/craft_amd/$lib python bench.py --train 3 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tr)"
 done; done
-bash tools/gpu.sh kstats st python $R/bench.py --no-cpu-baseline --no-train-leg --steps 5 --warmup 2 2>/dev/null | grep 'stem'
