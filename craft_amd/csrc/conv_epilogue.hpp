@@ -99,6 +99,67 @@ __device__ __forceinline__ void conv_epilogue4(const ConvGemmParams& p, long row
   }
 }
 
+// The same epilogue in two steps for a group whose 4 pixels and column are all real (the common case: a patch inside the image): the
+// operands it reads -- per-pixel bias field, h, z -- are LOADED for several groups first (epi_load4) and only then used (epi_finish4).
+// Inside conv_epilogue4 every group's loads sit behind that group's bounds branches, so each group waits for its own round trip
+// (s_waitcnt vmcnt(0) per group: 16 dependent L2 round trips per lane at the end of every convolution launch).
+struct EpiOperands { float b[4], x0[4], x1[4]; };
+template <int EPI>
+__device__ __forceinline__ void epi_load4(const ConvGemmParams& p, long row0, int col, EpiOperands& o) {
+  if (p.bias_field) {
+    const float* bf = p.bias_field + row0 * p.ld_bf + col;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.b[i] = bf[(long)i * p.ld_bf];
+  } else {
+    const float b0 = p.bias[col];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.b[i] = b0;
+  }
+  if constexpr (EPI == CONV_EPI_GRU_ZR) {
+    if (col >= 128) {
+      const float* hp = p.aux0 + row0 * p.ld0 + (col - 128);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o.x0[i] = hp[(long)i * p.ld0];
+    }
+  } else if constexpr (EPI == CONV_EPI_GRU_Q) {
+    const float* zp = p.aux1 + row0 * p.ld1 + col;
+    const float* hp = p.aux0 + row0 * p.ld0 + col;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o.x1[i] = zp[(long)i * p.ld1]; o.x0[i] = hp[(long)i * p.ld0]; }
+  }
+}
+template <int EPI, bool FAST>
+__device__ __forceinline__ void epi_finish4(const ConvGemmParams& p, long row0, int col, const float (&v)[4], const EpiOperands& o) {
+  float r[4];
+  float* dst; long ldd;
+  if constexpr (EPI == CONV_EPI_BIAS_ACT) {
+    const bool relu = p.act == CRAFT_ACT_RELU;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float t = v[i] + o.b[i]; r[i] = (relu ? fmaxf(t, 0.f) : t) * p.scale; }
+    dst = p.out + row0 * p.ldo + col; ldd = p.ldo;
+  } else if constexpr (EPI == CONV_EPI_GRU_ZR) {
+    if (col < 128) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = epi_sigmoid<FAST>(v[i] + o.b[i]);
+      dst = p.out + row0 * p.ldo + col; ldd = p.ldo;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = epi_sigmoid<FAST>(v[i] + o.b[i]) * o.x0[i];
+      dst = p.aux1 + row0 * p.ld1 + (col - 128); ldd = p.ld1;
+    }
+  } else if constexpr (EPI == CONV_EPI_GRU_Q) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (1.f - o.x1[i]) * o.x0[i] + o.x1[i] * epi_tanh<FAST>(v[i] + o.b[i]);
+    dst = p.out + row0 * p.ldo + col; ldd = p.ldo;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = fmaxf(v[i] + o.b[i], 0.f);
+    dst = p.out + row0 * p.ldo + col; ldd = p.ldo;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dst[i * ldd] = r[i];
+}
+
 // run BODY(EPI) with the compile-time epilogue kind that matches p.epi
 #define CONV_EPI_DISPATCH(p, BODY)                                  \
   switch ((p).epi) {                                                \
@@ -126,6 +187,29 @@ template <int EPI, bool FAST, int MT, int NT, bool PERM = false>
 __device__ __forceinline__ void conv_epilogue_patch(const ConvGemmParams& p, const f32x16 (&acc)[MT][NT], int wm0, int lane,
                                                     int cb, long img, int y0, int x0) {
   const int c_lane = lane & 31, rh4 = 4 * (lane >> 5);
+  // whole patch inside the image and every column of this wave a real output channel (wave-uniform): the operands of the four groups
+  // of a row fragment are requested together (epi_load4), see there
+  if (y0 + 8 <= p.g.H && x0 + 16 <= p.g.W && cb + NT * 32 <= p.cout) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        EpiOperands ops[4];
+        long rows[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = wm0 + mt * 32 + (PERM ? patch_row_perm(8 * q + rh4) : 8 * q + rh4);
+          rows[q] = img + (long)(y0 + (r >> 4)) * p.g.W + x0 + (r & 15);
+          epi_load4<EPI>(p, rows[q], cb + nt * 32 + c_lane, ops[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v[4] = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+          epi_finish4<EPI, FAST>(p, rows[q], cb + nt * 32 + c_lane, v, ops[q]);
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT; R=$GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_train_backward.py tests/test_gemm_pkb.py -m gpu -q --tb=short -p no:cacheprovider -k "softmax or attention or chain" 2>&1 | tail -3
-for lib in libcraft_hip_prev.so libcraft_hip.so; do CRAFT_HIP_LIB=$R/craft_amd/$lib bash tools/gpu.sh kstats sm_$lib python $R/bench.py --train 3 --steps 6 --warmup 3 --no-cpu-baseline 2>/dev/null | grep 'softmax'; done
+timeout 1500 python -m pytest tests/test_hip_ops.py tests/test_hip_e2e.py tests/test_train_encoder.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -3
+bash tools/gpu.sh ab
+python tools/bench_conv_fixed.py 2>&1 | tail -4
+CRAFT_HIP_LIB=$R/craft_amd/libcraft_hip_prev.so python tools/bench_conv_fixed.py 2>&1 | tail -4
