@@ -230,6 +230,22 @@ __device__ __forceinline__ void conv_epilogue_patch(const ConvGemmParams& p, con
 template <int EPI, bool FAST, int MT, int NT>
 __device__ __forceinline__ void conv_epilogue_rows(const ConvGemmParams& p, const f32x16 (&acc)[MT][NT], int lane, long rb, int cb, long M) {
   const int c_lane = lane & 31, rh4 = 4 * (lane >> 5);
+  if (rb + MT * 32 <= M && cb + NT * 32 <= p.cout) {          // whole wave tile real: operands of four groups loaded together (epi_load4)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        EpiOperands ops[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) epi_load4<EPI>(p, rb + mt * 32 + 8 * q + rh4, cb + nt * 32 + c_lane, ops[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v[4] = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+          epi_finish4<EPI, FAST>(p, rb + mt * 32 + 8 * q + rh4, cb + nt * 32 + c_lane, v, ops[q]);
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

@@ -216,17 +216,21 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
   const int col = n0 + wave * 32 + r;
   const int rh4 = 4 * (lane >> 5);
   const float* rdiv = p.row_div ? p.row_div + (long)z * p.rd_bs : nullptr;     // deferred softmax normalisation
+  // (the 16 row sums of a fragment are requested together through clamped indices: one load + wait per element under the row
+  // guard serialised 112 round trips at the end of every block)
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int mt = 0; mt < MT; ++mt) {
+    float rd[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) rd[e] = rdiv ? rdiv[min(m0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4, p.M - 1)] : 1.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = m0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
-      if (row < p.M) {
-        float v = acc[mt][0][e];
-        if (rdiv) v *= __builtin_amdgcn_rcpf(rdiv[row]);      // (16-bit P: a 1-ulp reciprocal is far below its rounding)
-        C[(long)row * p.ldc + col] = v;
-      }
+      float v = acc[mt][0][e];
+      if (rdiv) v *= __builtin_amdgcn_rcpf(rd[e]);      // (16-bit P: a 1-ulp reciprocal is far below its rounding)
+      if (row < p.M) C[(long)row * p.ldc + col] = v;
     }
+  }
 }
 
 template <int PREC, int MT> static void launch_pv_t(const RowsGemmParams& p, hipStream_t s) {
