@@ -438,25 +438,35 @@ __global__ __launch_bounds__(256) void k_flow_head2(const float* __restrict__ hi
   }
   const float b0 = bias[0], b1 = bias[1];
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto col = [&](int xx, float4 (&c)[3]) __attribute__((always_inline)) {     // column xx of the 3 rows (zero padding)
+  struct Col3 { float4 r[3]; };
+  auto col = [&](int xx) __attribute__((always_inline)) {     // column xx of the 3 rows (zero padding), by value (arrays passed by
+    Col3 c;                                                    // reference to the lambda ended up in scratch memory: 48 bytes per lane)
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int yy = y + r - 1;
       const bool ok = yy >= 0 && yy < H8 && xx >= 0 && xx < W8;
       const float4 v = *reinterpret_cast<const float4*>(hid + (img + (long)min(max(yy, 0), H8 - 1) * W8 + min(max(xx, 0), W8 - 1)) * 256 + lane * 4);
-      c[r] = ok ? v : zero;
+      c.r[r] = ok ? v : zero;
     }
+    return c;
   };
-  float4 cl[3], cm[3], cr[3];
-  col(x0 - 1, cl);
-  col(x0, cm);
+  Col3 cl = col(x0 - 1), cm = col(x0), cr;
   const int n = min(FH2_SEG, W8 - x0);
+  // Lane i keeps pixel i's coordinates and, as the window slides, its delta: the segment's coordinates are read once before the loop and
+  // written once after it (coalesced), instead of a load -> wait -> store sequence under `lane == 0` per pixel (16 dependent round trips).
+  const long pix0 = img + (long)y * W8 + x0;
+  float2 c1v = make_float2(0.f, 0.f), c0v = make_float2(0.f, 0.f);
+  if (lane < n) {
+    c1v = *reinterpret_cast<const float2*>(coords1 + 2 * (pix0 + lane));
+    c0v = *reinterpret_cast<const float2*>(coords0 + 2 * (pix0 + lane));
+  }
+  float mdx = 0.f, mdy = 0.f;
   for (int i = 0; i < n; ++i) {
-    col(x0 + i + 1, cr);
+    cr = col(x0 + i + 1);
     float a0 = 0.f, a1 = 0.f;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const float4 h0 = cl[r], h1 = cm[r], h2 = cr[r];
+      const float4 h0 = cl.r[r], h1 = cm.r[r], h2 = cr.r[r];
       const float4 u0 = w0[r * 3], u1 = w0[r * 3 + 1], u2 = w0[r * 3 + 2];
       const float4 v0 = w1[r * 3], v1 = w1[r * 3 + 1], v2 = w1[r * 3 + 2];
       a0 += h0.x * u0.x + h0.y * u0.y + h0.z * u0.z + h0.w * u0.w + h1.x * u1.x + h1.y * u1.y + h1.z * u1.z + h1.w * u1.w +
@@ -466,18 +476,16 @@ __global__ __launch_bounds__(256) void k_flow_head2(const float* __restrict__ hi
     }
     a0 = wave_sum(a0);
     a1 = wave_sum(a1);
-    if (lane == 0) {
-      const long pix = img + (long)y * W8 + x0 + i;
-      const float dx = a0 + b0, dy = a1 + b1;
-      const float nx = coords1[2 * pix] + dx, ny = coords1[2 * pix + 1] + dy;
-      coords1[2 * pix] = nx;
-      coords1[2 * pix + 1] = ny;
-      flow[2 * pix] = nx - coords0[2 * pix];
-      flow[2 * pix + 1] = ny - coords0[2 * pix + 1];
-      if (delta) { delta[2 * pix] = dx; delta[2 * pix + 1] = dy; }
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r) { cl[r] = cm[r]; cm[r] = cr[r]; }
+    mdx = lane == i ? a0 + b0 : mdx;
+    mdy = lane == i ? a1 + b1 : mdy;
+    cl = cm; cm = cr;
+  }
+  if (lane < n) {
+    const long pix = pix0 + lane;
+    const float nx = c1v.x + mdx, ny = c1v.y + mdy;
+    *reinterpret_cast<float2*>(coords1 + 2 * pix) = make_float2(nx, ny);
+    *reinterpret_cast<float2*>(flow + 2 * pix) = make_float2(nx - c0v.x, ny - c0v.y);
+    if (delta) *reinterpret_cast<float2*>(delta + 2 * pix) = make_float2(mdx, mdy);
   }
 }
 int launch_flow_head2(const float* hid, const float* w, const float* bias, int B, int H8, int W8, float* coords1,

@@ -1,8 +1,4 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT
-bash tools/gpu.sh kstats bench_kstats python $R/bench.py --no-cpu-baseline --no-train-leg --steps 10 --warmup 3 > /dev/null
-bash tools/gpu.sh kstats train3_kstats python $R/bench.py --train 3 --precision mixed --steps 12 --warmup 6 --no-cpu-baseline > /dev/null
-python tools/step_phases.py 3 > gpurun_out/step_phases_cfg3.txt 2>&1
-python tools/bench_conv_fixed.py > gpurun_out/bench_conv_fixed.txt 2>&1; B=2 python tools/bench_conv_fixed.py >> gpurun_out/bench_conv_fixed.txt 2>&1
-for h in 48 56 64; do REPS=50 H8=$h python tools/run_kernel.py gru 2>&1 | tail -1 >> gpurun_out/bench_conv_fixed.txt; done
-python bench.py > gpurun_out/bench2.log 2>/dev/null
-head -12 gpurun_out/bench_kstats/kernel_stats.txt; grep 'lookup\|convex\|flow_head' gpurun_out/bench_kstats/kernel_stats.txt
+cd $GRAFT_REPO_ROOT; R=$GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_hip_ops.py tests/test_hip_e2e.py tests/test_train_update.py -m gpu -q --tb=short -p no:cacheprovider -k "flow_head or golden or update or fused_iteration or e2e" 2>&1 | tail -2
+for lib in libcraft_hip_prev.so libcraft_hip.so; do CRAFT_HIP_LIB=$R/craft_amd/$lib bash tools/gpu.sh kstats fh_$lib python $R/bench.py --no-cpu-baseline --no-train-leg --steps 5 --warmup 2 2>/dev/null | grep 'flow_head'; done
+bash tools/gpu.sh ab
