@@ -31,18 +31,39 @@ __global__ __launch_bounds__(256) void k_convf1_mfma(const float* __restrict__ f
   const int b = bid / ty_n;
   const long img = (long)b * H8 * W8;
   // weights: one 16-byte copy per thread and step
-  for (int i = tid; i < NFRAG * 64; i += 256) {
+  // (all of a thread's weight pieces and patch pixels are REQUESTED first and stored to LDS afterwards: as a rolled copy loop each of the
+  // 14 pieces was load -> s_waitcnt vmcnt(0) -> ds_write, 14 dependent L2 round trips in front of a block's 84 MFMAs)
+  constexpr int NWP = NFRAG * 64 / 256;                        // 16-byte pieces per thread (14 for f16x3, 7 for one plane)
+  static_assert(NFRAG * 64 % 256 == 0, "weight pieces per thread");
+  uint4 wreg[NWP];
+#pragma unroll
+  for (int k = 0; k < NWP; ++k) {
+    const int i = tid + 256 * k;
     const int f = i >> 6, pl = f % PL, n = (f / PL) & 3, ky = f / (4 * PL);
     const int src = (((ky >> 1) * 4 + n) * PL + pl) * 2 + (ky & 1);            // craft_pack_weights fragment index
-    reinterpret_cast<uint4*>(wl)[i] = reinterpret_cast<const uint4*>(wpk)[src * 64 + (i & 63)];
+    wreg[k] = reinterpret_cast<const uint4*>(wpk)[src * 64 + (i & 63)];
   }
-  // flow patch rows ty0-3 .. ty0+10, columns tx0-3 .. tx0+20 (24 columns x 2 channels), zero outside the image
-  for (int i = tid; i < F1_PH * 24; i += 256) {
+  // flow patch rows ty0-3 .. ty0+10, columns tx0-3 .. tx0+20 (24 columns x 2 channels), zero outside the image (clamped loads)
+  constexpr int NPP = (F1_PH * 24 + 255) / 256;
+  float2 preg[NPP];
+  bool pok[NPP];
+#pragma unroll
+  for (int k = 0; k < NPP; ++k) {
+    const int i = min(tid + 256 * k, F1_PH * 24 - 1);
     const int py = i / 24, px = i - py * 24;
     const int y = ty0 + py - 3, x = tx0 + px - 3;
-    float2 v = {0.f, 0.f};
-    if (y >= 0 && y < H8 && x >= 0 && x < W8) v = *reinterpret_cast<const float2*>(flow + (img + (long)y * W8 + x) * 2);
-    *reinterpret_cast<float2*>(&patch[py * F1_LD + px * 2]) = v;
+    pok[k] = y >= 0 && y < H8 && x >= 0 && x < W8;
+    preg[k] = *reinterpret_cast<const float2*>(flow + (img + (long)min(max(y, 0), H8 - 1) * W8 + min(max(x, 0), W8 - 1)) * 2);
+  }
+#pragma unroll
+  for (int k = 0; k < NWP; ++k) reinterpret_cast<uint4*>(wl)[tid + 256 * k] = wreg[k];
+#pragma unroll
+  for (int k = 0; k < NPP; ++k) {
+    const int i = tid + 256 * k;
+    if (i < F1_PH * 24) {
+      const int py = i / 24, px = i - py * 24;
+      *reinterpret_cast<float2*>(&patch[py * F1_LD + px * 2]) = pok[k] ? preg[k] : make_float2(0.f, 0.f);
+    }
   }
   __syncthreads();
   const int m = lane & 31, g = lane >> 5;
