@@ -791,102 +791,115 @@ int launch_corr_lookup_bwd(const float* dout, long ldo, const float* coords, flo
 // dw_agg / dskip: per-block partials -> replicated tables [CRAFT_STATS_REPLICAS][C + 1] (last cell: dskip).
 // ---------------------------------------------------------------------------------------------
 constexpr int MPL_TOK_PER_WAVE = 8;
+// M (modes) and C (128 / 256 channels) are template parameters: with run-time values every load sat behind `c < C` / `m < M` tests (its own
+// round trip each, 12 per token) and half of the 4 channel slots per lane were idle work at C = 128 (1.7 TB/s).  Here a token's loads
+// are straight-line code: 2 * M + 4 (C = 128) requests in flight, then the arithmetic.
+template <int M, int C>
 __global__ __launch_bounds__(256) void k_mode_pool_ln_bwd(const float* __restrict__ O, const float* __restrict__ x, long ldx,
                                                           const float* __restrict__ w_agg, const float* __restrict__ skip_coeff,
-                                                          const float* __restrict__ dy, long lddy, int N, int M, int C, long ntok,
+                                                          const float* __restrict__ dy, long lddy, int N, long ntok,
                                                           float* __restrict__ dO, float* __restrict__ dx, long lddx,
                                                           float* __restrict__ dw_rep) {
-  __shared__ float acc_w[4][257];
+  constexpr int NI = C / 64;                       // channel slots per lane: c = lane + 64 i
+  __shared__ float acc_w[4][C + 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float wl[4], dwl[4] = {0.f, 0.f, 0.f, 0.f};
+  float wl[NI], dwl[NI];
   float dskip = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; wl[i] = c < C ? w_agg[c] : 0.f; }
+  for (int i = 0; i < NI; ++i) { wl[i] = w_agg[lane + 64 * i]; dwl[i] = 0.f; }
   const float skip = *skip_coeff;
   const long t0 = ((long)blockIdx.x * 4 + wv) * MPL_TOK_PER_WAVE;
   for (long tok = t0; tok < min(ntok, t0 + MPL_TOK_PER_WAVE); ++tok) {
     const long b = tok / N, n = tok - b * N;
-    float o[4][4], t[4];                        // [mode][channel slot]; M <= 4
-    _Pragma("unroll") for (int m = 0; m < 4; ++m) if (m < M) {
+    float o[M][NI], t[M], xv[NI], g[NI];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
       const float* Om = O + ((b * M + m) * N + n) * C;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) o[m][i] = Om[lane + 64 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { xv[i] = x[tok * ldx + lane + 64 * i]; g[i] = dy[tok * lddy + lane + 64 * i]; }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
       float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; o[m][i] = c < C ? Om[c] : 0.f; s += o[m][i] * wl[i]; }
+      for (int i = 0; i < NI; ++i) s += o[m][i] * wl[i];
       t[m] = wave_sum(s);
     }
     float mx = t[0];
-    _Pragma("unroll") for (int m = 1; m < 4; ++m) if (m < M) mx = fmaxf(mx, t[m]);
-    float a[4], den = 0.f;
-    _Pragma("unroll") for (int m = 0; m < 4; ++m) if (m < M) { a[m] = expf(t[m] - mx); den += a[m]; }
-    _Pragma("unroll") for (int m = 0; m < 4; ++m) if (m < M) a[m] /= den;
-    float u[4], xv[4], g[4], s1 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = lane + 64 * i;
-      xv[i] = c < C ? x[tok * ldx + c] : 0.f;
-      g[i] = c < C ? dy[tok * lddy + c] : 0.f;
+    for (int m = 1; m < M; ++m) mx = fmaxf(mx, t[m]);
+    float a[M], den = 0.f;
+#pragma unroll
+    for (int m = 0; m < M; ++m) { a[m] = expf(t[m] - mx); den += a[m]; }
+#pragma unroll
+    for (int m = 0; m < M; ++m) a[m] /= den;
+    float u[NI], s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
       float p = 0.f;
-      _Pragma("unroll") for (int m = 0; m < 4; ++m) if (m < M) p += a[m] * o[m][i];
-      u[i] = c < C ? skip * xv[i] + p : 0.f;
+#pragma unroll
+      for (int m = 0; m < M; ++m) p += a[m] * o[m][i];
+      u[i] = skip * xv[i] + p;
       s1 += u[i];
     }
     const float mean = wave_sum(s1) / C;
     float s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; const float d = c < C ? u[i] - mean : 0.f; s2 += d * d; }
+    for (int i = 0; i < NI; ++i) { const float d = u[i] - mean; s2 += d * d; }
     const float rstd = rsqrtf(wave_sum(s2) / C + CRAFT_LN_EPS);
     float sg = 0.f, sgy = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; if (c < C) { sg += g[i]; sgy += g[i] * (u[i] - mean) * rstd; } }
+    for (int i = 0; i < NI; ++i) { sg += g[i]; sgy += g[i] * (u[i] - mean) * rstd; }
     const float mg = wave_sum(sg) / C, mgy = wave_sum(sgy) / C;
-    float du[4], sx = 0.f;
+    float du[NI], sx = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = lane + 64 * i;
-      du[i] = c < C ? rstd * (g[i] - mg - (u[i] - mean) * rstd * mgy) : 0.f;
+    for (int i = 0; i < NI; ++i) {
+      du[i] = rstd * (g[i] - mg - (u[i] - mean) * rstd * mgy);
       sx += du[i] * xv[i];
-      if (c < C) dx[tok * lddx + c] = skip * du[i];
+      dx[tok * lddx + lane + 64 * i] = skip * du[i];
     }
     dskip += sx;                                 // (lane partial; reduced at the end)
-    float da[4], dsum = 0.f;
-    _Pragma("unroll") for (int m = 0; m < 4; ++m) if (m < M) {
+    float da[M], dsum = 0.f;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
       float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s += du[i] * o[m][i];
+      for (int i = 0; i < NI; ++i) s += du[i] * o[m][i];
       da[m] = wave_sum(s);
       dsum += a[m] * da[m];
     }
-    _Pragma("unroll") for (int m = 0; m < 4; ++m) if (m < M) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
       const float dt = a[m] * (da[m] - dsum);
       float* dOm = dO + ((b * M + m) * N + n) * C;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = lane + 64 * i;
-        if (c < C) dOm[c] = a[m] * du[i] + dt * wl[i];
+      for (int i = 0; i < NI; ++i) {
+        dOm[lane + 64 * i] = a[m] * du[i] + dt * wl[i];
         dwl[i] += dt * o[m][i];
       }
     }
   }
   dskip = wave_sum(dskip);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc_w[wv][lane + 64 * i] = dwl[i];
-  if (lane == 0) acc_w[wv][256] = dskip;
+  for (int i = 0; i < NI; ++i) acc_w[wv][lane + 64 * i] = dwl[i];
+  if (lane == 0) acc_w[wv][C] = dskip;
   __syncthreads();
   float* rep = dw_rep + (long)(blockIdx.x % CRAFT_STATS_REPLICAS) * (C + 1);
-  for (int c = threadIdx.x; c < 257; c += 256) {
-    const float v = acc_w[0][c] + acc_w[1][c] + acc_w[2][c] + acc_w[3][c];
-    if (c < C) unsafeAtomicAdd(rep + c, v);
-    else if (c == 256) unsafeAtomicAdd(rep + C, v);
-  }
+  for (int c = threadIdx.x; c < C + 1; c += 256) unsafeAtomicAdd(rep + c, acc_w[0][c] + acc_w[1][c] + acc_w[2][c] + acc_w[3][c]);
 }
 int launch_mode_pool_ln_bwd(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff, const float* dy, long lddy,
                             int B, int N, int M, int C, float* dO, float* dx, long lddx, float* dw_rep, hipStream_t s) {
   if (B <= 0 || N <= 0) return 0;
-  if (C > 256 || M > 4 || M < 1) return CRAFT_ERR_UNSUPPORTED;
+  if ((C != 128 && C != 256) || M > 4 || M < 1) return CRAFT_ERR_UNSUPPORTED;
   const long ntok = (long)B * N;
-  const long nblk = (ntok + 4 * MPL_TOK_PER_WAVE - 1) / (4 * MPL_TOK_PER_WAVE);
-  hipLaunchKernelGGL(k_mode_pool_ln_bwd, dim3((unsigned)nblk), dim3(256), 0, s, O, x, ldx, w_agg, skip_coeff, dy, lddy, N, M, C, ntok, dO, dx,
-                     lddx, dw_rep);
+  const dim3 grid((unsigned)((ntok + 4 * MPL_TOK_PER_WAVE - 1) / (4 * MPL_TOK_PER_WAVE)));
+#define GO(MM, CC) hipLaunchKernelGGL((k_mode_pool_ln_bwd<MM, CC>), grid, dim3(256), 0, s, O, x, ldx, w_agg, skip_coeff, dy, lddy, N, ntok, dO, dx, lddx, dw_rep)
+#define GOC(MM) do { if (C == 128) GO(MM, 128); else GO(MM, 256); } while (0)
+  switch (M) { case 1: GOC(1); break; case 2: GOC(2); break; case 3: GOC(3); break; default: GOC(4); break; }
+#undef GOC
+#undef GO
   return (int)hipGetLastError();
 }
 

@@ -490,7 +490,7 @@ int craft_corr_pool_bwd(float* S, long ld, int B, int M, int H8, int W8, const f
                         int do_norm, float* dtab_rep, double* dw, void* stream);
 
 /* backward of craft_mode_pool_ln: dy -> dO [B][M][N][C], dx [B*N][C] (row stride lddx), and dw_rep [CRAFT_STATS_REPLICAS][C+1] +=
- * (d w_agg [C], d skip_coeff) (zero it first; craft_reduce_replicas). */
+ * (d w_agg [C], d skip_coeff) (zero it first; craft_reduce_replicas).  C = 128 or 256, M <= 4 (as craft_mode_pool_ln). */
 int craft_mode_pool_ln_bwd(const float* O, const float* x, long ldx, const float* w_agg, const float* skip_coeff, const float* dy,
                            long lddy, int B, int N, int M, int C, float* dO, float* dx, long lddx, float* dw_rep, void* stream);
 
