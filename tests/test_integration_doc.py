@@ -54,8 +54,10 @@ def test_doc_stub_matches_header_arity():
 
 
 @pytest.mark.gpu
-def test_doc_stub_runs_and_matches_oracle(device):
-    """(GPU) exec the documented stub, build a reference-style CorrBlock holder (normalised pyramid), compare with the oracle."""
+@pytest.mark.parametrize("r", [4, 3, 1])
+def test_doc_stub_runs_and_matches_oracle(device, r):
+    """(GPU) exec the documented stub, build a reference-style CorrBlock holder (normalised pyramid), compare with the oracle.
+    r = 4 is the reference's radius (the kernel's compile-time form); 3 and 1 take its run-time-radius form."""
     from oracle import craft_oracle as O
     from craft_amd import hip
     os.environ["CRAFT_HIP_LIB"] = hip.lib_path()
@@ -64,7 +66,7 @@ def test_doc_stub_runs_and_matches_oracle(device):
         exec(compile(src, "INTEGRATION.md", "exec"), ns)       # noqa: S102 -- our own document
     CorrBlock = ns["CorrBlock"]
     g = torch.Generator().manual_seed(7)
-    B, H8, W8, r = 2, 16, 24, 4
+    B, H8, W8 = 2, 16, 24
     N = H8 * W8
     c = torch.randn(B, N, N, generator=g)
     mu, rstd = O.global_stats(c)
@@ -76,5 +78,5 @@ def test_doc_stub_runs_and_matches_oracle(device):
     blk.corr_pyramid = [p.to(device) for p in pyr]
     blk.radius = r
     got = blk(coords.to(device)).cpu()
-    assert got.shape == want.shape == (B, 4 * 81, H8, W8)
+    assert got.shape == want.shape == (B, 4 * (2 * r + 1) ** 2, H8, W8)
     assert (got - want).abs().max().item() < 2e-5

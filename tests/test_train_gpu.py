@@ -202,3 +202,29 @@ def test_convex_upsample_backward_into_a_padded_flow_gradient(device):
     up = torch.sum(m * uf, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(B, 2, 8 * H8, 8 * W8)
     up.backward(dup)
     assert torch.allclose(d2, fl.grad, rtol=1e-4, atol=1e-4) and torch.allclose(dm2, mk.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("r", [4, 3, 1])
+def test_corr_lookup_backward_radii(device, r):
+    """craft_corr_lookup_bwd vs torch autograd through the oracle's lookup (corr.py:47-71) on a normalised pyramid, for the reference's
+    radius 4 (the kernel's compile-time form) and two run-time radii; coordinates that leave the image, accumulation over two calls."""
+    from craft_amd.hip import call
+    from oracle import craft_oracle as O
+    g = torch.Generator().manual_seed(40 + r)
+    B, H8, W8 = 2, 12, 20
+    N = H8 * W8
+    c = torch.randn(B, N, N, generator=g)
+    pyr = [p.clone().requires_grad_(True) for p in O.build_pyramid(c, H8, W8, 4)]
+    coords = O.coords_grid(B, H8, W8) + torch.randn(B, 2, H8, W8, generator=g) * 5.0
+    win2 = (2 * r + 1) ** 2
+    out = O.corr_lookup(pyr, coords, r)                                    # [B, 4 * win2, H8, W8]
+    dout = torch.randn(B, N, 4 * win2, generator=g)
+    out.backward(dout.transpose(1, 2).reshape(B, 4 * win2, H8, W8))
+    G = [torch.zeros(B * N, *p.shape[-2:], device=device) for p in pyr]
+    ct = coords.permute(0, 2, 3, 1).reshape(B, N, 2).contiguous().to(device)
+    dd = dout.to(device)
+    for _ in range(2):                                                     # (+=: two lookups at the same coordinates)
+        call("craft_corr_lookup_bwd", dd, dd.stride(-2), ct, G[0], G[1], G[2], G[3], 4, B, H8, W8, r, 0, 0)
+    for l in range(4):
+        ref = 2.0 * pyr[l].grad.reshape(B * N, *pyr[l].shape[-2:])
+        assert torch.allclose(G[l].cpu(), ref, rtol=1e-4, atol=1e-5), f"radius {r} level {l}"

@@ -1,3 +1,2 @@
-cd $GRAFT_REPO_ROOT; R=$GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_train_backward.py tests/test_train_update.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -3
-for lib in libcraft_hip_prev.so libcraft_hip.so; do CRAFT_HIP_LIB=$R/craft_amd/$lib bash tools/gpu.sh kstats mp_$lib python $R/bench.py --train 3 --steps 6 --warmup 3 --no-cpu-baseline 2>/dev/null | grep 'mode_pool'; done
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_train_gpu.py tests/test_integration_doc.py -m gpu -q --tb=short -p no:cacheprovider -k "radii or doc_stub" 2>&1 | tail -12
