@@ -1,2 +1,2 @@
-cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_train_gpu.py tests/test_integration_doc.py -m gpu -q --tb=short -p no:cacheprovider -k "radii or doc_stub" 2>&1 | tail -12
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 1200 python tools/train_soak.py mixed 300 > gpurun_out/train_soak_r4b.txt 2>&1; tail -16 gpurun_out/train_soak_r4b.txt
