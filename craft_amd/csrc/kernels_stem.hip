@@ -29,11 +29,25 @@ __global__ __launch_bounds__(NTHREADS) void k_stem_mfma(const float* __restrict_
   const int b = bid / tiles_y;
   const int oy0 = ty * STM_TH, ox0 = tx * STM_TW;
   const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
-  for (int i = tid; i < 3 * STM_PH * STM_PLD; i += NTHREADS) {
+  // patch staging: all of a thread's pixels requested first, from clamped addresses, then normalised / zero-padded and published (a
+  // load under the bounds test compiles to branch + load + vmcnt(0): ten dependent HBM round trips per block before its first MFMA)
+  constexpr int NPIX = 3 * STM_PH * STM_PLD, NLD = (NPIX + NTHREADS - 1) / NTHREADS;
+  float pv[NLD];
+  unsigned pok = 0u;
+  const float* imb = img + (long)b * 3 * H * W;
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int i = min(tid + k * NTHREADS, NPIX - 1);
     const int c = i / (STM_PH * STM_PLD), rem = i - c * (STM_PH * STM_PLD);
     const int r = rem / STM_PLD, q = rem - r * STM_PLD;
     const int y = iy0 + r, x = ix0 + q;
-    pat[i] = (y >= 0 && y < H && x >= 0 && x < W) ? 2.f * (img[(((long)b * 3 + c) * H + y) * W + x] / 255.f) - 1.f : 0.f;
+    pok |= (y >= 0 && y < H && x >= 0 && x < W) ? 1u << k : 0u;
+    pv[k] = imb[(c * H + min(max(y, 0), H - 1)) * W + min(max(x, 0), W - 1)];          // (one image: < 2^31 elements)
+  }
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int i = tid + k * NTHREADS;
+    if (i < NPIX) pat[i] = ((pok >> k) & 1u) ? 2.f * (pv[k] / 255.f) - 1.f : 0.f;
   }
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 32;
   const int hsel = lane >> 5;
