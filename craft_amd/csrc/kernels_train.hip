@@ -696,13 +696,16 @@ int launch_corr_pool_bwd(float* S, long ld, int B, int M, int H8, int W8, const 
 __global__ __launch_bounds__(256) void k_corr_pyramid_bwd(float* __restrict__ G0, const float* __restrict__ G1, const float* __restrict__ G2,
                                                           const float* __restrict__ G3, const float* __restrict__ c0,
                                                           const float* __restrict__ mu_rstd, int N, int H8, int W8,
-                                                          double* __restrict__ gstats) {
+                                                          double* __restrict__ gstats, int rpb) {
   __shared__ float red[4];
-  const long q = blockIdx.x;
-  const int b = (int)(q / N);
+  // rpb query rows per block (all of one image): one pair of double atomics per block -- a pair per row (45 632 same-address atomics of
+  // ~11 ns) was as long as the rest of the kernel (k_corr_pool_fwd4)
+  const int b = (int)(((long)blockIdx.x * rpb) / N);
   const float mu = mu_rstd[2 * b], rstd = mu_rstd[2 * b + 1];
   const int h1 = H8 >> 1, w1 = W8 >> 1, h2 = h1 >> 1, w2 = w1 >> 1, h3 = h2 >> 1, w3 = w2 >> 1;
   float s1 = 0.f, s2 = 0.f;
+  for (int rr = 0; rr < rpb; ++rr) {
+  const long q = (long)blockIdx.x * rpb + rr;
   // Every load of an element is unconditional (clamped cell of the coarser level, the bounds as 0 / 1 weights; an absent level reads G0
   // with weight 0): under the bounds tests each was branch + load + vmcnt(0), four dependent round trips per element.  (y, x) advance
   // incrementally (a run-time division per element is ~30 VALU instructions).
@@ -731,6 +734,7 @@ __global__ __launch_bounds__(256) void k_corr_pyramid_bwd(float* __restrict__ G0
     x += dr; y += dq;
     if (x >= W8) { x -= W8; ++y; }
   }
+  }
   s1 = block_sum_256(s1, red);
   s2 = block_sum_256(s2, red);
   if (threadIdx.x == 0) { atomicAdd(&gstats[2 * b], (double)s1); atomicAdd(&gstats[2 * b + 1], (double)s2); }
@@ -739,7 +743,8 @@ int launch_corr_pyramid_bwd(float* G0, const float* G1, const float* G2, const f
                             int H8, int W8, double* gstats, hipStream_t s) {
   const int N = H8 * W8;
   if (B <= 0 || N <= 0) return 0;
-  hipLaunchKernelGGL(k_corr_pyramid_bwd, dim3((unsigned)((long)B * N)), dim3(256), 0, s, G0, G1, G2, G3, c0, mu_rstd, N, H8, W8, gstats);
+  const int rpb = (N % POOL_ROWS == 0) ? POOL_ROWS : 1;
+  hipLaunchKernelGGL(k_corr_pyramid_bwd, dim3((unsigned)((long)B * N / rpb)), dim3(256), 0, s, G0, G1, G2, G3, c0, mu_rstd, N, H8, W8, gstats, rpb);
   return (int)hipGetLastError();
 }
 
