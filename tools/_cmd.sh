@@ -1,3 +1,5 @@
-cd $GRAFT_REPO_ROOT; R=$GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_train_backward.py -m gpu -q --tb=short -p no:cacheprovider -k "corr or volume or training_step" 2>&1 | tail -3
-for lib in libcraft_hip_prev.so libcraft_hip.so; do CRAFT_HIP_LIB=$R/craft_amd/$lib bash tools/gpu.sh kstats cp_$lib python $R/bench.py --train 3 --steps 6 --warmup 3 --no-cpu-baseline 2>/dev/null | grep "corr_p"; done
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT
+bash tools/gpu.sh kstats bench_kstats python $R/bench.py --no-cpu-baseline --no-train-leg --steps 10 --warmup 3 > /dev/null
+bash tools/gpu.sh kstats train3_kstats python $R/bench.py --train 3 --precision mixed --steps 12 --warmup 6 --no-cpu-baseline > /dev/null
+python tools/step_phases.py 3 > gpurun_out/step_phases_cfg3.txt 2>&1
+head -3 gpurun_out/bench_kstats/kernel_stats.txt; head -3 gpurun_out/train3_kstats/kernel_stats.txt
