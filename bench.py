@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true",
                     help="skip the short configs[3] training leg (3 warm-up + 5 timed steps) that the default line carries as `train_cfg3`")
+    ap.add_argument("--mini", action="store_true",
+                    help="launch-path rehearsal: the default line's extra legs at miniature shapes (training legs 128x160, batch 1, 2 iterations, no "
+                         "pinned loss; corr_cfg2 at 128x256) -- eight gloo ranks sharing one GPU run the driver's N = 8 command in seconds")
     ap.add_argument("--ops", action="store_true", help="also print a per-operator timing table to stderr")
     ap.add_argument("--torch-encoders", action="store_true",
                     help="--train only: keep the two CNN encoders on PyTorch-ROCm / MIOpen under torch autograd (developer A/B)")
@@ -199,19 +202,19 @@ def roofline_conv(B, H8, W8, prec, reps=20):
                     "matrix pipe runs at 3x this rate; peak = dense fp16 MFMA (fp32 MFMA for the fp32 policy)"}
 
 
-def corr_cfg2(reps=10):
+def corr_cfg2(reps=10, H=768, W=1024):
     """BASELINE.json configs[2] on the default line: the 768x1024 correlation build (fused scores + mode pooling + 4-level pyramid +
     statistics) and the radius-4 lookup, timed with HIP events on the launch stream (tools/bench_corr.py).  frac = SURVEY 8(d) bytes
     (the pyramid written once + Q / K read once) / time / 8 TB/s; traffic = FETCH_SIZE x2 + WRITE_SIZE of the build kernel from this
     round's committed PMC passes (profiles/r4/pmc_corr_build.json; null when absent or taken at another shape)."""
     from tools.bench_corr import measure
-    r = measure(768, 1024, 1, reps, "mixed")
+    r = measure(H, W, 1, reps, "mixed")
     b, lk = r["corr_build"], r["corr_lookup"]
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r4", "pmc_corr_build.json")) as fh:
             pmc = json.load(fh)
-        if pmc.get("shape") == [1, 96, 128]:
+        if pmc.get("shape") == [1, H // 8, W // 8]:
             traffic = int(pmc["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError, TypeError):
         pass
@@ -393,18 +396,29 @@ def train_leg(cfg, rank, world, dev, steps, warmup, iters, B=None, H=None, W=Non
 
     dt_rank = timed_steps(step, steps=steps, warmup=warmup, sync=torch.cuda.synchronize)
     value, dt = aggregate_throughput(pairs_per_rank_step=B, steps=steps, dt=dt_rank)
-    assert last["m"]["loss"] == last["m"]["loss"]
+    finite = last["m"]["loss"] == last["m"]["loss"]
     # the first step's loss (synthetic weights seed 1234, pairs seed 100, dropout hash seeded by torch.manual_seed(1234 + rank) above) is a constant of
     # the workload: tests/test_bench_contract.py::test_bench_training_workload_is_the_pinned_one recomputes it, and holds the same batch
     # with dropout off to the CPU oracle's loss -- a leg that trains something else (other weights, shape, iterations) fails here
     pinned = FIRST_LOSS.get((cfg, H, W, B, iters)) if rank == 0 and not torch_encoders else None
-    if pinned is not None and warmup + steps > 0 and not os.environ.get("CRAFT_BENCH_NO_PIN"):      # (developer switch: print instead of assert)
-        assert abs(last["first"] - pinned) < 5e-3 * pinned, f"configs[{cfg}] first-step loss {last['first']:.5f}, pinned {pinned:.5f}"
+    if pinned is not None and os.environ.get("CRAFT_BENCH_PIN_SCALE"):      # (test hook: a deliberately wrong pin, tests/test_bench_contract.py)
+        pinned *= float(os.environ["CRAFT_BENCH_PIN_SCALE"])
+    # REPORTED, not asserted (round 5): a drifting constant -- another GPU / ROCm, a legitimate rounding change -- must not cost the run its
+    # headline and every other leg.  The line carries first_loss / first_loss_pinned / first_loss_ok, main() sets "pin_failed" and exits
+    # non-zero AFTER the JSON is out; the hard assertion lives in tests/test_bench_contract.py.
+    pin_ok = None
+    if pinned is not None and warmup + steps > 0:
+        pin_ok = bool(finite and abs(last["first"] - pinned) < 5e-3 * pinned)
+        if not pin_ok:
+            print(f"[bench] WARNING configs[{cfg}] first-step loss {last['first']:.5f}, pinned {pinned:.5f}: the training leg does not train "
+                  "the pinned workload (or the arithmetic changed)", file=sys.stderr)
+    if not finite:
+        print(f"[bench] WARNING configs[{cfg}] {policy}: non-finite loss after {warmup + steps} steps", file=sys.stderr)
     if last["m"].get("skipped_steps"):
         print(f"[bench] configs[{cfg}] {policy}: {last['m']['skipped_steps']} step(s) skipped on gradient overflow (loss scale now "
               f"{last['m']['loss_scale']:g})", file=sys.stderr)
     out = {"H": H, "W": W, "B": B, "policy": policy, "name": name, "value": value, "dt": dt, "steps": steps, "warmup": warmup,
-           "loss": last["m"]["loss"], "first_loss": last.get("first"), "skipped_steps": last["m"].get("skipped_steps", 0), "numel": tr.optimizer.numel, "freeze_bn": cfg != 3,
+           "loss": last["m"]["loss"], "first_loss": last.get("first"), "first_loss_pinned": pinned, "first_loss_ok": pin_ok, "finite": bool(finite), "skipped_steps": last["m"].get("skipped_steps", 0), "numel": tr.optimizer.numel, "freeze_bn": cfg != 3,
            "allreduce_ms": tr.allreduce_ms(), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)}
     if roofline:
         out["roofline"] = roofline_wgrad(step, policy)      # every rank runs the extra steps (they contain the collective)
@@ -453,15 +467,19 @@ def train_bench(a, rank, world, dev, dist):
                                           + ("BatchNorm batch statistics" if a.train == 3 else "frozen BatchNorm")
                                           + ", synthetic weights and pairs", "global_batch": B * world,
                        "parallelism": f"dp{world} (one all-reduce of the {r['numel'] * 4 / 1e6:.1f} MB flat gradient per step)"},
-            "loss": round(r["loss"], 4), "first_loss": round(r["first_loss"], 4), "skipped_steps": r["skipped_steps"],
+            "loss": round(r["loss"], 4), "first_loss": round(r["first_loss"], 4), "first_loss_pinned": r["first_loss_pinned"],
+            "first_loss_ok": r["first_loss_ok"], "skipped_steps": r["skipped_steps"],
             "peak_mem_GB": r["peak_mem_GB"], "allreduce_ms_per_step": r["allreduce_ms"],
             "roofline": r.get("roofline"), "amp_fp16": amp}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_train(H, W, a.iters, a.cpu_threads, r["freeze_bn"])
+        if r["first_loss_ok"] is False or not r["finite"]:
+            line["pin_failed"] = True
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    return 3 if (r["first_loss_ok"] is False or not r["finite"]) else 0       # (rank 0 checks the pin; non-zero only after the JSON is out)
 
 
 def main():
@@ -524,17 +542,33 @@ def main():
 
     dt_rank = timed_steps(run_step, steps=a.steps, warmup=a.warmup, sync=torch.cuda.synchronize)
     value, dt = aggregate_throughput(pairs_per_rank_step=a.batch, steps=a.steps, dt=dt_rank)
-    assert torch.isfinite(last["out"][1]).all()
+    failures = []                    # legs that failed: the line is printed anyway, the exit code says so afterwards
+    if not bool(torch.isfinite(last["out"][1]).all()):
+        failures.append("configs[1]: non-finite flow")
 
-    # the short training leg of the default line (every rank runs it: a training step contains the gradient all-reduce)
+    # the short training leg of the default line (every rank runs it: a training step contains the gradient all-reduce).  A leg that
+    # raises (a deterministic error hits every rank at the same point) is recorded and the rest of the line still goes out.
     tl = tl4 = None
     if not a.no_train_leg:
         del last["out"]
         torch.cuda.empty_cache()
-        tl = train_leg(3, rank, world, dev, steps=5, warmup=6, iters=12)      # (6 warm-up steps: the caching allocator's pool settles after ~5)
-        tl["amp"] = amp_leg(3, rank, world, dev, 12)
+        try:
+            mini = dict(B=1, H=128, W=160) if a.mini else {}
+            it_ = 2 if a.mini else 12
+            tl = train_leg(3, rank, world, dev, steps=5, warmup=6, iters=it_, **mini)      # (6 warm-up steps: the caching allocator's pool settles after ~5)
+            tl["amp"] = amp_leg(3, rank, world, dev, it_, **mini)
+        except Exception as e:      # noqa: BLE001
+            failures.append(f"train_cfg3: {type(e).__name__}: {e}"[:300])
+            print(f"[bench] WARNING training leg configs[3] failed: {e}", file=sys.stderr)
         torch.cuda.empty_cache()
-        tl4 = train_leg(4, rank, world, dev, steps=5, warmup=6, iters=12, roofline=False)
+        try:
+            tl4 = train_leg(4, rank, world, dev, steps=5, warmup=6, iters=it_, roofline=False, **mini)
+        except Exception as e:      # noqa: BLE001
+            failures.append(f"train_cfg4: {type(e).__name__}: {e}"[:300])
+            print(f"[bench] WARNING training leg configs[4] failed: {e}", file=sys.stderr)
+    for t_ in (tl, tl4):
+        if t_ is not None and (t_["first_loss_ok"] is False or not t_["finite"]):
+            failures.append(f"{t_['name']}: first-step loss {t_['first_loss']} vs pinned {t_['first_loss_pinned']} (finite: {t_['finite']})")
 
     if rank == 0:
         line = {
@@ -555,13 +589,14 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.height, a.width, a.iters, a.cpu_threads)
         if not a.no_train_leg:          # (the same switch keeps a quick run quick)
-            line["corr_cfg2"] = corr_cfg2()
+            line["corr_cfg2"] = corr_cfg2(3, 128, 256) if a.mini else corr_cfg2()
         if tl is not None:
             line["train_cfg3"] = {
                 "workload": tl["name"] + ", 12 iters, whole training steps (forward + backward + gradient all-reduce + clip + AdamW), "
                             "model.train(): dropout on, BatchNorm batch statistics; policy " + tl["policy"],
                 "ms_per_step": round(1e3 * tl["dt"] / tl["steps"], 3), "pairs_per_s": round(tl["value"], 3), "steps": tl["steps"],
                 "warmup": tl["warmup"], "n_gpus": world, "loss": round(tl["loss"], 4), "first_loss": round(tl["first_loss"], 4),
+                "first_loss_pinned": tl["first_loss_pinned"], "first_loss_ok": tl["first_loss_ok"],
                 "skipped_steps": tl["skipped_steps"], "allreduce_ms_per_step": tl["allreduce_ms"],
                 "roofline": tl.get("roofline"), "amp_fp16": tl.get("amp")}
         if tl4 is not None:
@@ -569,12 +604,17 @@ def main():
                 "workload": tl4["name"] + ", 12 iters, whole training steps, model.train(): dropout on, frozen BatchNorm; policy " + tl4["policy"],
                 "ms_per_step": round(1e3 * tl4["dt"] / tl4["steps"], 3), "pairs_per_s": round(tl4["value"], 3), "steps": tl4["steps"],
                 "warmup": tl4["warmup"], "n_gpus": world, "loss": round(tl4["loss"], 4), "first_loss": round(tl4["first_loss"], 4),
+                "first_loss_pinned": tl4["first_loss_pinned"], "first_loss_ok": tl4["first_loss_ok"],
                 "skipped_steps": tl4["skipped_steps"], "allreduce_ms_per_step": tl4["allreduce_ms"]}
+        if failures:
+            line["pin_failed"] = any("first-step loss" in f for f in failures)
+            line["failed_legs"] = failures
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    return 3 if failures else 0           # non-zero only AFTER the JSON line is out (a failed leg must not cost the run its other numbers)
 
 
 if __name__ == "__main__":
-    main()
+    raise SystemExit(main())

@@ -179,11 +179,13 @@ class Linear(Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias, ctx.prec = b is not None, prec
         ctx.cache, ctx.wobj = cache, w          # (the Python object: saved_tensors may hand back a different wrapper, and ids key the cache)
+        ctx.bw_modes = modes()
         _count_use(cache, w)
         return ops.linear(x, w, b, prec)
 
     @staticmethod
     def backward(ctx, dy):
+        use_modes(ctx.bw_modes)
         x, w = ctx.saved_tensors
         dy = _rows(dy)
         B, N, Cin = x.shape
@@ -300,17 +302,21 @@ class ScoreLink:
         self.want, self.prec, self.dS = False, 0, None
 
 
-# data pointers of probability-gradient buffers that a backward of THIS module just allocated for AttnSoftmax.backward (AttnApply /
-# ProbsToken): only those may be overwritten in place with dS -- a gradient that arrives from anywhere else (a caller-held tensor, a
-# sum the engine formed) is copied first
-_FRESH_DP = set()
-
-
+# probability-gradient buffers that a backward of THIS module just allocated for AttnSoftmax.backward (AttnApply / ProbsToken) are TAGGED
+# as tensor objects (an attribute on the returned tensor; PyTorch keeps a tensor's Python object alive across the autograd engine): only a
+# tagged gradient may be overwritten in place with dS.  A gradient that arrives from anywhere else -- a caller-held tensor, a new sum the
+# engine formed, a tensor that merely reuses a freed address -- carries no tag and is copied first.
 def _fresh_dp(t):
-    if len(_FRESH_DP) > 64:          # (left-overs of pruned graphs)
-        _FRESH_DP.clear()
-    _FRESH_DP.add(t.data_ptr())
+    t._craft_fresh_dp = True
     return t
+
+
+def _take_fresh_dp(t):
+    """True exactly once for a tensor tagged by _fresh_dp (the tag is consumed)."""
+    if t.is_contiguous() and getattr(t, "_craft_fresh_dp", False):
+        t._craft_fresh_dp = False
+        return True
+    return False
 
 
 class AttnSoftmax(Function):
@@ -345,8 +351,7 @@ class AttnSoftmax(Function):
         B, M, N, ld = P.shape
         # dS over the incoming gradient when it is the fresh output of the one consumer of P (AttnApply / ProbsToken: nothing else
         # holds it, 1 GB saved at configs[3]); any other gradient tensor is copied
-        if dP.is_contiguous() and dP.data_ptr() in _FRESH_DP:
-            _FRESH_DP.discard(dP.data_ptr())
+        if _take_fresh_dp(dP):
             dS = dP
         else:
             dS = dP.clone(memory_format=torch.contiguous_format)
@@ -852,32 +857,53 @@ def gemm_pk(A: PkMat, a_desc, B: PkMat, b_desc, C: torch.Tensor, ldc: int, c_out
 
 
 # Operand modes of the backward products of f16x3 layers, set per training pass by train_forward.forward_train from the policy's roles
-# (hip.Precision): [0] = PREC_F16 -> one fp16 plane, None -> the layer's mode.
-#   WGX: the activation operand X of dW = dY^T X        WGY: its gradient operand dY (weight gradients are leaves of the backward graph:
-#   DXW: the weight operand of dX = dY W^T              their rounding error does not propagate; dY of the dX chain always keeps both planes)
-WGX, WGY, DXW = [None], [None], [None]
+# (hip.Precision): PREC_F16 -> one fp16 plane, None -> the layer's mode.
+#   wgx: the activation operand X of dW = dY^T X        wgy: its gradient operand dY (weight gradients are leaves of the backward graph:
+#   dxw: the weight operand of dX = dY W^T              their rounding error does not propagate; dY of the dX chain always keeps both planes)
+# The modes belong to a PASS, not to the process: every Function whose backward reads them captures the triple at forward time
+# (``ctx.bw_modes = modes()``) and re-installs it on entry (``use_modes``) -- two models or policies may interleave forward A, forward B,
+# backward A -- and the installed triple is thread-local (nn.DataParallel runs one backward thread per device).
+import threading as _threading
+
+
+class _Modes(_threading.local):
+    wgx = wgy = dxw = None
+
+
+_M = _Modes()
 
 
 def set_backward_modes(prec):
-    WGX[0], WGY[0], DXW[0] = getattr(prec, "wgx", None), getattr(prec, "wgy", None), getattr(prec, "dxw", None)
-    if WGY[0] == hip.PREC_F16:
-        WGX[0] = hip.PREC_F16               # (a one-plane dY beside a two-plane X is not an instantiation of k_gemm_pk)
+    _M.wgx, _M.wgy, _M.dxw = getattr(prec, "wgx", None), getattr(prec, "wgy", None), getattr(prec, "dxw", None)
+    if _M.wgy == hip.PREC_F16:
+        _M.wgx = hip.PREC_F16               # (a one-plane dY beside a two-plane X is not an instantiation of k_gemm_pk)
+
+
+def modes():
+    """The triple a forward captures for its backward."""
+    return (_M.wgx, _M.wgy, _M.dxw)
+
+
+def use_modes(m):
+    """Entry of a backward: the modes of the pass that built this node."""
+    if m is not None:
+        _M.wgx, _M.wgy, _M.dxw = m
 
 
 def xprec(prec: int) -> int:
     """Pack mode of a weight gradient's X operand for a layer whose mode is ``prec``."""
-    return hip.PREC_F16 if (prec == hip.PREC_F16X3 and WGX[0] == hip.PREC_F16) else prec
+    return hip.PREC_F16 if (prec == hip.PREC_F16X3 and _M.wgx == hip.PREC_F16) else prec
 
 
 def gprec(prec: int) -> int:
     """Pack mode of a weight gradient's dY operand for a layer whose mode is ``prec``."""
-    return hip.PREC_F16 if (prec == hip.PREC_F16X3 and WGY[0] == hip.PREC_F16) else prec
+    return hip.PREC_F16 if (prec == hip.PREC_F16X3 and _M.wgy == hip.PREC_F16) else prec
 
 
 def dxflag(prec: int) -> int:
     """CRAFT_CONV_W16 for the input-gradient convolution of a layer in ``prec`` when the policy's role dxw asks for one fp16 plane of the
     weights: two MFMAs per product, dY keeps both planes."""
-    return hip.CONV_W16 if (prec == hip.PREC_F16X3 and DXW[0] == hip.PREC_F16) else 0
+    return hip.CONV_W16 if (prec == hip.PREC_F16X3 and _M.dxw == hip.PREC_F16) else 0
 
 
 class PackBatch:
@@ -970,6 +996,7 @@ class Conv(Function):
         call("craft_conv2d_nhwc", xp, xp.stride(-2), cin_p, wt, bp, cout_p, KH, KW, act, y, cout_p, B, hw[0], hw[1], cp | flag)
         ctx.save_for_backward(xp, y if act != ACT_NONE else None)
         ctx.w, ctx.cache = w, cache
+        ctx.bw_modes = modes()
         ctx.dims = (B, N, Cin, Cout, KH, KW, cin_p, cout_p)
         ctx.hw, ctx.act, ctx.prec, ctx.has_bias = hw, act, cp, b is not None
         _count_use(cache, w)
@@ -977,6 +1004,7 @@ class Conv(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        use_modes(ctx.bw_modes)
         xp, y = ctx.saved_tensors
         B, N, Cin, Cout, KH, KW, cin_p, cout_p = ctx.dims
         H8, W8 = ctx.hw
@@ -1122,6 +1150,9 @@ class SequenceLoss(Function):
     @staticmethod
     def backward(ctx, dl):
         grads, ctx.grads = ctx.grads, None
+        if grads is None:          # (the gradient buffers are scaled in place and handed on: this node runs once)
+            raise RuntimeError("SequenceLoss: this graph was already consumed by a backward pass (its gradient buffers are scaled in place "
+                               "and released; call sequence_loss again instead of backward(retain_graph=True) twice)")
         torch._foreach_mul_(grads, dl.reshape(()).to(grads[0].dtype))        # (one multi-tensor launch for the T predictions, in place: the buffers are this node's own)
         return (None, None, None, None) + tuple(grads)
 

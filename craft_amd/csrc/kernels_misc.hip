@@ -343,6 +343,9 @@ int launch_corr_lookup(const float* l0, const float* l1, const float* l2, const 
   const int win2 = (2 * radius + 1) * (2 * radius + 1);
   if (lvl_stride <= 0) lvl_stride = win2;            // default: one volume, levels back to back
   if (lvl_stride < win2 || col_off < 0 || col_off + win2 > lvl_stride) return CRAFT_ERR_ARG;
+  // every level must hold at least one pixel: the kernel loads unconditionally from CLAMPED addresses (min(max(y, 0), h - 1) ...), which
+  // on an empty level (h or w == 0) is offset -1 of a null / empty buffer
+  if ((H8 >> (levels - 1)) < 1 || (W8 >> (levels - 1)) < 1) return CRAFT_ERR_ARG;
   const long nq = (long)B * H8 * W8;
   if (radius == 4)
     hipLaunchKernelGGL(k_corr_lookup<4>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, l0, l1, l2, l3, levels, mu_rstd, coords,

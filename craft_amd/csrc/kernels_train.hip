@@ -840,6 +840,7 @@ int launch_corr_lookup_bwd(const float* dout, long ldo, const float* coords, flo
   if (lvl_stride <= 0) lvl_stride = win2;
   const long nq = (long)B * H8 * W8;
   if (nq <= 0) return 0;
+  if ((H8 >> (levels - 1)) < 1 || (W8 >> (levels - 1)) < 1) return CRAFT_ERR_ARG;      // (an empty level: clamped addresses would be offset -1)
   if (radius == 4)
     hipLaunchKernelGGL(k_corr_lookup_bwd<4>, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, dout, ldo, coords, G0, G1, G2, G3, levels, H8, W8,
                        radius, lvl_stride, col_off, nq);

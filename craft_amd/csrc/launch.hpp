@@ -55,6 +55,19 @@ struct ConvGemmParams {
                                         // iteration-invariant part of a conv: SepConvGRU context term)
 };
 
+// k_conv_pk (kernels_conv_pk.hip): the activation operand as up to two packs (craft_pack_operand, spatial form) over one padded grid
+struct ConvPkIn {
+  const unsigned char* seg[2];   // pack base pointers; channel chunks [0, ncg0) come from seg[0], the rest from seg[1]
+  unsigned bytes[2];             // pack sizes (buffer range: reads beyond return zeros)
+  int ncg0;
+  unsigned plane[2], cgs[2];     // byte strides between the planes / the channel groups of each pack
+  int cg_off[2];                 // first channel group used of each pack
+  long row0;                     // pack row of image pixel (b = 0, y = -KH/2, x = -KW/2)
+  int Hp, Wp;                    // the packs' padded grid
+};
+struct ConvPkParams { ConvGemmParams c; ConvPkIn in; };
+int launch_conv_pk(const ConvPkParams& pp, int prec, hipStream_t s);
+
 int launch_pack_operand(const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
                         int prec, void* out, int cg_off, int ncg_total, float* colsum, int tail, hipStream_t s);
 int launch_pack_operands(const long* descs, int n, hipStream_t s);

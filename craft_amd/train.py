@@ -402,6 +402,7 @@ class Trainer:
         self.clip, self.gamma, self.iters, self.add_noise, self.freeze_bn, self.group = clip, gamma, iters, add_noise, freeze_bn, group
         self.reference_loss_scaling = reference_loss_scaling
         self.total_steps = 0
+        self._seed = None                   # the loss scale (0-dim device tensor) the last step's backward ran under; None before the first step
         self._ar_events = []                # (start, end) HIP events around the gradient all-reduce of recent steps
         self._scale_set = False             # "auto" needs the loss' element count: the scaler is armed on the first step
         if loss_scale != "auto":
@@ -415,6 +416,8 @@ class Trainer:
     @property
     def last_loss_scale(self) -> float:
         """The loss scale the last step's backward ran under (reads the device: tests / debugging)."""
+        if self._seed is None:
+            raise RuntimeError("Trainer.last_loss_scale: no step has run yet")
         return float(self._seed)
 
     def sync_replicas(self, src: int = 0):

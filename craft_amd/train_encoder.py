@@ -66,11 +66,13 @@ class Stem(Function):
             call("craft_stem_conv7x7_mfma", raw, packed, bias, ACT_NONE, B, H, W, out, stats, prec)
         ctx.save_for_backward(raw)
         ctx.prec, ctx.bias_dead = prec, bias_dead
+        ctx.bw_modes = AG.modes()
         ctx.mark_non_differentiable(stats)
         return out, stats
 
     @staticmethod
     def backward(ctx, dy, _):
+        AG.use_modes(ctx.bw_modes)
         (raw,) = ctx.saved_tensors
         B, _, H, W = raw.shape
         dy = AG._rows(dy)
@@ -114,11 +116,13 @@ class EncConv(Function):
              y, Cout, B, Ho, Wo, stats, prec | (W_PACKED if halo else 0))
         ctx.save_for_backward(x)
         ctx.w, ctx.cache, ctx.prec, ctx.stride, ctx.hw_in, ctx.bias_dead = w, cache, prec, stride, hw_in, bias_dead
+        ctx.bw_modes = AG.modes()
         ctx.mark_non_differentiable(stats)
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, _):
+        AG.use_modes(ctx.bw_modes)
         (x,) = ctx.saved_tensors
         w, prec, stride = ctx.w, ctx.prec, ctx.stride
         B, _, Cin = x.shape

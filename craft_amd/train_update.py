@@ -255,12 +255,14 @@ class UpdateIter(Function):
         pb.flush()
         ps.saved[t] = S
         ctx.ps, ctx.t = ps, t
+        ctx.bw_modes = AG.modes()
         ctx.nparams = len(params)
         ctx.mark_non_differentiable(c1n)
         return hxn[..., H0:H0 + 128], up, c1n
 
     @staticmethod
     def backward(ctx, d_hn, d_up, _dc):
+        AG.use_modes(ctx.bw_modes)
         ps, t = ctx.ps, ctx.t
         S = ps.saved[t]
         m = ps.model

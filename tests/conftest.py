@@ -27,4 +27,4 @@ def _reset_training_globals():
     yield
     mod = sys.modules.get("craft_amd.autograd")
     if mod is not None:
-        mod.WGX[0] = mod.WGY[0] = mod.DXW[0] = None
+        mod.use_modes((None, None, None))
