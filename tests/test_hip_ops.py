@@ -521,7 +521,7 @@ def test_conv2d_pk_equals_the_token_kernel(device, prec, KH, KW, cins, cout, rel
     x = gen(B, cin, H8, W8, seed=96)
     w = gen(cout, cin, KH, KW, seed=97) / math.sqrt(cin * KH * KW)
     b = gen(cout, seed=98)
-    xt = ops.tokens_from_nchw(x.to(device))
+    xt = x.permute(0, 2, 3, 1).reshape(B, H8 * W8, cin).contiguous().to(device)      # tokens [B, N, cin]
     wp = ops.pack_conv_prec(w.to(device), prec)
     act = ACT_RELU if relu else ACT_NONE
     parts = list(torch.split(xt, list(cins), dim=-1))

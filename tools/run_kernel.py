@@ -37,7 +37,7 @@ def main():
             e.record()
             torch.cuda.synchronize()
             print(f"attn_apply (k_pv16): {s.elapsed_time(e) / reps * 1e3:.1f} us per launch")
-    elif which in ("gru", "menc", "head"):
+    elif which in ("gru", "grustep", "menc", "head"):
         from craft_amd import CRAFT, default_args
         from craft_amd.synth import synth_state_dict
         m = CRAFT(default_args())
@@ -49,11 +49,14 @@ def main():
         c0, c1, fl = ops.coords_init(None, B, H8, W8, dev)
         reps = int(os.environ.get("REPS", 0))
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fields = ub.gru.context_tokens(hx[..., 128:256], (H8, W8), prec) if which == "grustep" else None
         for i in range(3 + reps):
             if i == 3:
                 s.record()
             if which == "gru":
                 ub.gru.forward_tokens(hx, (H8, W8), ws, prec)
+            elif which == "grustep":          # the forward pass's form: context channels hoisted into per-pixel bias fields (K 1920 per gate conv)
+                ub.gru.step_tokens(hx, (H8, W8), ws, prec, fields, 128, 256)
             elif which == "menc":
                 ub.encoder.forward_tokens(fl, corr, (H8, W8), hx[..., 256:384], ws, prec)
             else:
@@ -62,6 +65,23 @@ def main():
             e.record()
             torch.cuda.synchronize()
             print(f"{which} B={B} {H8}x{W8}: {s.elapsed_time(e) / reps * 1e3:.1f} us per call ({B * ((H8 + 7) // 8) * ((W8 + 15) // 16)} patches)")
+    elif which in ("convpk", "convtok"):
+        # the GRU's z|r convolution shape (1x5, 384 -> 256) on plane-packed activations (k_conv_pk) / on fp32 tokens (k_conv_halo_wf)
+        from craft_amd.autograd import Packed
+        from craft_amd.hip import call, ACT_NONE, W_PACKED, PREC_F16X3
+        KH, KW, cin, cout = int(os.environ.get("KH", 1)), int(os.environ.get("KW", 5)), int(os.environ.get("CIN", 384)), int(os.environ.get("COUT", 256))
+        x = torch.randn(B, N, cin, device=dev)
+        w = torch.randn(cout, cin, KH, KW, device=dev) / (cin * KH * KW) ** 0.5
+        wp = ops.pack_conv_weights(w, PREC_F16X3)
+        zb = torch.zeros(cout, device=dev)
+        y = torch.empty(B, N, cout, device=dev)
+        pk = Packed(x, PREC_F16X3, spatial=(B, H8, W8, 2, 2))
+        for _ in range(3 + int(os.environ.get("REPS", 4))):
+            if which == "convpk":
+                call("craft_conv2d_pk", pk.buf, pk.rows_p, pk.C_p // 32, 0, cin, None, 0, 0, 0, 0, pk.guard, 2, 2, 0, wp, zb, None, 0, cout, KH, KW, ACT_NONE, y, cout,
+                     B, H8, W8, PREC_F16X3 | W_PACKED)
+            else:
+                call("craft_conv2d_nhwc", x, cin, cin, wp, zb, cout, KH, KW, ACT_NONE, y, cout, B, H8, W8, PREC_F16X3 | W_PACKED)
     elif which in ("fnet", "cnet"):
         from craft_amd import CRAFT, default_args
         from craft_amd.synth import synth_state_dict, synth_pair
