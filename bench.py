@@ -99,6 +99,71 @@ def op_table(model, im1, im2, iters):
         print(f"[ops] {n:28s} calls {c:4d}  {t:9.3f} ms  {100 * t / tot:5.1f} %", file=sys.stderr)
 
 
+def pmc_lookup(kernel, group, B, H8, W8):
+    """This round's committed PMC summary of one kernel (profiles/r5/pmc_kernels.json, tools/pmc_summary.py): HBM-side bytes per launch
+    (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) and the matrix pipe's busy fraction -- only when the entry was taken at THIS shape for THIS
+    kernel instantiation; otherwise None rather than a stale constant."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r5", "pmc_kernels.json")) as fh:
+            pmc = json.load(fh)
+        sh = pmc.get("shape", {})
+        if (sh.get("B"), sh.get("H8"), sh.get("W8")) != (B, H8, W8):
+            return None
+        for e in pmc["kernels"].get(kernel, []):
+            if e.get("group") == group:
+                return e
+    except (OSError, ValueError, KeyError, TypeError):
+        pass
+    return None
+
+
+def roofline_flash(model, im1, im2, iters, prec, forwards=3):
+    """The F2 feature transformer's fused attention (k_flash_attn: Q.K^T, online softmax and P.V in one pass, setrans.py:507-557 +
+    :364-410) timed LIVE with HIP events around every craft_flash_attention call of real forward passes (the call also enqueues the two
+    k_pack_qk launches, ~25 us).  Algorithmic flops = SURVEY 8(d): 2 * (256 + 1024) * N^2 per sample; executed = 2 * (3 * 256 + 1024) * N^2
+    under f16x3 scores."""
+    import craft_amd.ops as ops_mod
+    from craft_amd.hip import PREC_F16X3, pick
+    B, _, H, W = im1.shape
+    H8, W8 = H // 8, W // 8
+    N = H8 * W8
+    orig = ops_mod.call
+    evs = []
+
+    def timed(name, *a):
+        if name != "craft_flash_attention":
+            return orig(name, *a)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        orig(name, *a)
+        e.record()
+        evs.append((s, e))
+    ops_mod.call = timed
+    try:
+        with torch.no_grad():
+            for _ in range(forwards):
+                model(im1, im2, iters=min(iters, 1), test_mode=1)
+        torch.cuda.synchronize()
+    finally:
+        ops_mod.call = orig
+    if not evs:
+        return None
+    ms = sum(s.elapsed_time(e) for s, e in evs) / len(evs)
+    x3 = pick(prec, "score") == PREC_F16X3
+    flops = 2.0 * 1280 * N * N * B
+    executed = 2.0 * ((3 if x3 else 1) * 256 + 1024) * N * N * B
+    ach = flops / (ms * 1e-3) / 1e12
+    e = pmc_lookup("k_flash_attn<64, 256, 2>" if x3 else "k_flash_attn<64, 256, 1>", "flash", B, H8, W8)
+    return {"bound": "mfma", "kernel": "k_flash_attn (F2 feature transformer: scores + online softmax + P.V fused, 1 launch per forward; + 2 k_pack_qk)",
+            "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+            "executed_frac": round(executed / (ms * 1e-3) / 1e12 / 2500.0, 4), "flops_per_launch": flops, "ms_per_launch": round(ms, 4),
+            "launches_timed": len(evs), "mfma_busy": e.get("mfma_busy") if e else None, "traffic": e.get("hbm_bytes_per_launch") if e else None,
+            "note": "timed live (HIP events on the launch stream) around craft_flash_attention in real forward passes; mfma_busy = rocprofv3 "
+                    "SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD and traffic = FETCH_SIZE x2 + WRITE_SIZE of the same kernel at this "
+                    "shape (profiles/r5/pmc_kernels.json; null when not profiled at this shape): busy is a fraction of the cycles the chip actually "
+                    "ran, frac is against the 2.4 GHz peak"}
+
+
 def roofline_pv(model, im1, im2, iters, prec, forwards=3):
     """The aggregator's P.V kernel timed LIVE: HIP events around every craft_attn_apply call of `forwards` real forward
     passes (the kernel runs on the main stream, the events are recorded on it), so the figure is what rocprof's kernel
@@ -195,8 +260,12 @@ def roofline_conv(B, H8, W8, prec, reps=20):
     flops = 2.0 * B * N * 256 * 5 * 384
     ach = flops / (ms * 1e-3) / 1e12
     peak = 157.3 if cp == PREC_F32 else 2500.0
+    from craft_amd.hip import PREC_F16X3
+    e = pmc_lookup("k_conv_halo_wf<3, 1, 4, false, 5, 7>", "convtok", B, H8, W8) if cp == PREC_F16X3 else None
     return {"bound": "mfma", "kernel": "k_conv_halo_wf (SepConvGRU z|r conv, 1x5, 384->256, 24 launches per forward)", "achieved": round(ach, 1), "peak": peak,
-            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "flops_per_launch": flops,
+            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": e.get("hbm_bytes_per_launch") if e else None,
+            "mfma_busy": e.get("mfma_busy") if e else None, "valu_per_mfma": e.get("valu_per_mfma") if e else None,
+            "lds_bank_conflict_share": e.get("lds_bank_conflict_share") if e else None, "flops_per_launch": flops,
             "ms_per_launch": round(ms, 4),
             "note": "algorithmic (fp32-equivalent) flops; the f16x3 scheme executes 3 fp16 MFMAs per product, so the "
                     "matrix pipe runs at 3x this rate; peak = dense fp16 MFMA (fp32 MFMA for the fp32 policy)"}
@@ -586,6 +655,7 @@ def main():
             op_table(model, im1, im2, a.iters)
         line["roofline"] = roofline_pv(model, im1, im2, a.iters, prec)
         line["roofline_conv"] = roofline_conv(a.batch, a.height // 8, a.width // 8, prec)
+        line["roofline_flash"] = roofline_flash(model, im1, im2, a.iters, prec)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.height, a.width, a.iters, a.cpu_threads)
         if not a.no_train_leg:          # (the same switch keeps a quick run quick)

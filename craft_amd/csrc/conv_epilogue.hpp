@@ -61,6 +61,11 @@ __device__ __forceinline__ void conv_epilogue4(const ConvGemmParams& p, long row
     const bool relu = p.act == CRAFT_ACT_RELU;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const float t = v[i] + b[i]; o[i] = (relu ? fmaxf(t, 0.f) : t) * p.scale; }
+    if (p.res) {                                       // fused residual tail: relu(x + y)
+      const float* rp = p.res + row0 * p.ld_res + col;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = fmaxf(o[i] + rp[(long)min(i, nvalid - 1) * p.ld_res], 0.f);
+    }
     dst = p.out + row0 * p.ldo + col; ldd = p.ldo;
   } else if constexpr (EPI == CONV_EPI_GRU_ZR) {       // cols [0,128): z = sigmoid -> out ; cols [128,256): r*h -> aux1
     if (col < 128) {                                   // (wave-uniform: a wave's 32 columns never straddle 128)
@@ -115,7 +120,13 @@ __device__ __forceinline__ void epi_load4(const ConvGemmParams& p, long row0, in
 #pragma unroll
     for (int i = 0; i < 4; ++i) o.b[i] = b0;
   }
-  if constexpr (EPI == CONV_EPI_GRU_ZR) {
+  if constexpr (EPI == CONV_EPI_BIAS_ACT) {
+    if (p.res) {
+      const float* rp = p.res + row0 * p.ld_res + col;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o.x0[i] = rp[(long)i * p.ld_res];
+    }
+  } else if constexpr (EPI == CONV_EPI_GRU_ZR) {
     if (col >= 128) {
       const float* hp = p.aux0 + row0 * p.ld0 + (col - 128);
 #pragma unroll
@@ -136,6 +147,10 @@ __device__ __forceinline__ void epi_finish4(const ConvGemmParams& p, long row0, 
     const bool relu = p.act == CRAFT_ACT_RELU;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const float t = v[i] + o.b[i]; r[i] = (relu ? fmaxf(t, 0.f) : t) * p.scale; }
+    if (p.res) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = fmaxf(r[i] + o.x0[i], 0.f);
+    }
     dst = p.out + row0 * p.ldo + col; ldd = p.ldo;
   } else if constexpr (EPI == CONV_EPI_GRU_ZR) {
     if (col < 128) {

@@ -364,6 +364,16 @@ int craft_conv2d_nhwc(const float* x, long ldx, int cin, const float* w, const f
   return launch_gemm_conv(q, PREC_OF(prec), S(stream));
 }
 
+int craft_conv2d_nhwc_res(const float* x, long ldx, int cin, const float* w, const float* bias, int cout, int KH, int KW, int act, const float* res,
+                          long ldr, float* y, long ldy, int B, int H, int W, int prec, void* stream) {
+  if (cin % 32) return CRAFT_ERR_ALIGN;
+  if (res == nullptr) return CRAFT_ERR_ARG;
+  ConvGemmParams q = conv_params(x, (int)ldx, cin, nullptr, 0, 0, B, H, W, KH, KW, w, bias, cout, CONV_EPI_BIAS_ACT, act, 1.f, y, (int)ldy);
+  q.w_packed = PACKED_OF(prec);
+  q.res = res; q.ld_res = (int)ldr;
+  return launch_gemm_conv(q, PREC_OF(prec), S(stream));
+}
+
 static int conv_pk_input(ConvPkIn& in, const void* x0, long rows_p0, int ncg0_total, int cg_off0, int c0, const void* x1, long rows_p1,
                          int ncg1_total, int cg_off1, int c1, long guard, int padH, int padW, int tail, int H, int W, int KH, int KW, int planes) {
   if (c0 <= 0 || c0 % 32 || c1 < 0 || c1 % 32 || (c1 > 0 && x1 == nullptr) || x0 == nullptr) return CRAFT_ERR_ALIGN;

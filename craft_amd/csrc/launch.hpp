@@ -53,6 +53,8 @@ struct ConvGemmParams {
   double* stats;         // optional [B][cout][2]: += (sum, sum^2) of the biased conv output per (image, channel)
   const float* bias_field; int ld_bf;   // optional per-pixel bias [npix][ld_bf] used INSTEAD of bias[col] (hoisted
                                         // iteration-invariant part of a conv: SepConvGRU context term)
+  const float* res; int ld_res;         // optional (CONV_EPI_BIAS_ACT): out = relu(res[pix][col] + act(conv + bias) * scale) -- the tail of a
+                                        // ResidualBlock (extractor.py:56-63) in the epilogue of its second convolution
 };
 
 // k_conv_pk (kernels_conv_pk.hip): the activation operand as up to two packs (craft_pack_operand, spatial form) over one padded grid

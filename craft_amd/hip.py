@@ -65,6 +65,7 @@ _SIGS = {
     "craft_pack_weights": [P, I, I, I, P, P],
     "craft_conv2d_nhwc": [P, L, I, P, P, I, I, I, I, P, L, I, I, I, I, P],
     "craft_conv2d_pk": [P, L, I, I, I, P, L, I, I, I, L, I, I, I, P, P, P, L, I, I, I, I, P, L, I, I, I, I, P],
+    "craft_conv2d_nhwc_res": [P, L, I, P, P, I, I, I, I, P, L, P, L, I, I, I, I, P],
     "craft_conv2d_nhwc_ex": [P, L, I, I, I, P, P, P, I, I, I, I, I, P, L, I, I, I, P, I, P],
     "craft_stem_conv7x7": [P, P, P, I, I, I, I, P, P, P],
     "craft_stem_conv7x7_mfma": [P, P, P, I, I, I, I, P, P, I, P],

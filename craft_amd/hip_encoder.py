@@ -176,12 +176,13 @@ class HipEncoder:
                      out, out.stride(1))
                 t_norm = None
             else:
+                # folded BatchNorm: the residual tail relu(x + relu(conv2(..))) is conv2's epilogue (craft_conv2d_nhwc_res)
                 c1, hw1 = self._conv(t, B, hw, pk["c1"], ACT_RELU, cp)
-                c2, _ = self._conv(c1, B, hw1, pk["c2"], ACT_RELU, cp)
                 xs = self._conv(t, B, hw, pk["ds"], ACT_NONE, cp)[0] if "ds" in pk else t
-                out = torch.empty_like(c2)
-                call("craft_residual_relu", xs, xs.stride(1), None, c2, c2.stride(1), None, 0, B, hw1[0] * hw1[1], c2.shape[-1], out,
-                     out.stride(1))
+                p2 = pk["c2"]
+                out = torch.empty(B, hw1[0] * hw1[1], p2.cout, device=dev, dtype=torch.float32)
+                call("craft_conv2d_nhwc_res", c1, c1.stride(1), p2.cin, p2.w, p2.b, p2.cout, p2.KH, p2.KW, ACT_RELU, xs, xs.stride(1), out,
+                     out.stride(1), B, hw1[0], hw1[1], cp | (W_PACKED if p2.packed else 0))
             t, hw = out, hw1
         wf, bf = self._final
         return ops.linear(t, wf, bf, prec)

@@ -256,6 +256,11 @@ int craft_conv2d_nhwc2(const float* x0, long ld0, int c0, const float* x1, long 
 int craft_conv2d_pk(const void* x0, long rows_p0, int ncg0, int cg_off0, int c0, const void* x1, long rows_p1, int ncg1, int cg_off1, int c1,
                     long guard, int padH, int padW, int tail, const float* w, const float* bias, const float* bias_field, long ld_bf, int cout,
                     int KH, int KW, int act, float* y, long ldy, int B, int H, int W, int prec, void* stream);
+/* craft_conv2d_nhwc with the tail of a ResidualBlock fused into the epilogue (round 5): y = relu(res + act(conv(x) + bias)), res fp32
+ * tokens [B*H*W][cout] with row stride ldr -- `self.relu(x + y)` of extractor.py:56-63 for the encoder whose BatchNorm is folded into the
+ * weights (cnet, eval): the standalone craft_residual_relu pass (read x, read y, write out) disappears.  Stride 1. */
+int craft_conv2d_nhwc_res(const float* x, long ldx, int cin, const float* w, const float* bias, int cout, int KH, int KW, int act, const float* res,
+                          long ldr, float* y, long ldy, int B, int H, int W, int prec, void* stream);
 int craft_conv2d_nhwc_ex(const float* x, long ldx, int cin, int Hin, int Win, const float* in_norm, const float* w,
                          const float* bias, int cout, int KH, int KW, int stride, int act, float* y, long ldy, int B,
                          int Hout, int Wout, double* stats, int prec, void* stream);

@@ -538,6 +538,28 @@ def test_conv2d_pk_equals_the_token_kernel(device, prec, KH, KW, cins, cout, rel
     close(ops.tokens_to_nchw(y, H8, W8), ref, rt * 2, at * 4, f"conv_pk {KH}x{KW} prec={prec}")
 
 
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("cin,cout,shape", [(64, 64, (2, 24, 40)), (96, 96, (2, 11, 21)), (128, 128, (1, 9, 17))])
+def test_conv2d_residual_epilogue(device, prec, cin, cout, shape):
+    """craft_conv2d_nhwc_res: relu(res + relu(conv3x3(x) + bias)) -- ResidualBlock's tail (extractor.py:56-63) in the epilogue of its second
+    convolution -- against F.conv2d; 64 -> 64 runs the persistent layer-1 kernel, the others the halo kernel (ragged patches)."""
+    from craft_amd.hip import call, W_PACKED
+    B, H8, W8 = shape
+    x = gen(B, cin, H8, W8, seed=110)
+    r = gen(B, cout, H8, W8, seed=111)
+    w = gen(cout, cin, 3, 3, seed=112) / math.sqrt(cin * 9)
+    b = gen(cout, seed=113)
+    ref = torch.relu(r + torch.relu(F.conv2d(x, w, b, padding=1)))
+    xt, rtok = ops.tokens_from_nchw(x.to(device)), ops.tokens_from_nchw(r.to(device))
+    packed = prec != PREC_F32
+    wp = ops.pack_conv_prec(w.to(device), prec) if packed else ops.pack_conv(w.to(device))
+    y = torch.empty(B, H8 * W8, cout, device=device)
+    call("craft_conv2d_nhwc_res", xt, xt.stride(1), cin, wp, b.to(device), cout, 3, 3, ACT_RELU, rtok, rtok.stride(1), y, cout, B, H8, W8,
+         prec | (W_PACKED if packed else 0))
+    rt, at = TOL[prec]
+    close(ops.tokens_to_nchw(y, H8, W8), ref, rt * 2, at * 4, f"conv + residual prec={prec}")
+
+
 def test_forward_interpolate(device):
     """craft_forward_interpolate vs the reference's outputs (tests/golden/forward_interpolate.npz, generated by running
     utils.py:34-62) and vs the oracle on a batch of fresh flows, including one with no valid source."""

@@ -60,7 +60,11 @@ def main():
                 e["wave_cycles_split"] = {"active_inst": round(v.get("SQ_ACTIVE_INST_ANY", 0.0) / w, 3), "wait_inst": round(v.get("SQ_WAIT_INST_ANY", 0.0) / w, 3),
                                           "wait_any": round(v.get("SQ_WAIT_ANY", 0.0) / w, 3)}
             res.setdefault(k, []).append(e)
-    json.dump(res, sys.stdout, indent=1)
+    # the shape tools/run_kernel.py ran at (its defaults unless the environment said otherwise)
+    out = {"shape": {"B": int(os.environ.get("B", 4)), "H8": int(os.environ.get("H8", 56)), "W8": int(os.environ.get("W8", 128))},
+           "source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ set 1 | SQ set 2 + GRBM, each its own run) + a --kernel-trace --stats run of "
+                     "tools/run_kernel.py <group> mixed; tools/pmc_r5.sh", "kernels": res}
+    json.dump(out, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":
