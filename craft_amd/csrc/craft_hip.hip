@@ -20,6 +20,7 @@ const Tuning& tuning() {
     v.no_wgrad64 = getenv("CRAFT_NO_WGRAD64") != nullptr;   // weight gradient of 64-channel layers on the generic 128-row tile (developer A/B)
     if (const char* e = getenv("CRAFT_CORR_DBG")) v.corr_dbg = atoi(e);    // store ablations of k_corr_build4t (developer, tools/corr_write_pmc.sh)
     if (const char* e = getenv("CRAFT_PK_MODE")) v.pk_mode = atoi(e);      // ablations of k_gemm_pk (developer): 1 no DMA after tile 0, 2 no epilogue, 4 no MFMA phase
+    v.flash_v1 = getenv("CRAFT_FLASH_V1") != nullptr;     // developer A/B: k_flash_attn (round 1) instead of k_flash_attn2
     return v;
   }();
   return t;

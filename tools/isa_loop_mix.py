@@ -11,7 +11,7 @@ def loops(lines):
         m = re.match(r"^(\.LBB\d+_\d+):.*Inner Loop Header", l)
         if m:
             start = (m.group(1), i)
-        elif start and re.search(r"s_cbranch_\w+ " + re.escape(start[0]) + r"\b", l):
+        elif start and re.search(r"s_c?branch\w* " + re.escape(start[0]) + r"\b", l):
             yield lines[start[1]:i + 1]
             start = None
 
