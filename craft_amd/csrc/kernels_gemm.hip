@@ -162,7 +162,14 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
     const int k = min(kt, nk - 1) * KT + c8 * 8;
     const long kc = p.a_tiled ? (long)min(kt, nk - 1) * (32 * KT) : (long)(k < p.K ? k : p.K - 8);
 #pragma unroll
+    // non-temporal: P (1.6 GB per launch at 448x1024 x 4) is streamed once per launch and must not displace V^T / O lines; on the tiled
+    // layout the same read-only stream measures 6.9 TB/s with nt against 6.1 without, LDS-DMA or not (tools/ubench/hbm_rows_dma.hip,
+    // profiles/r5/hbm_rows_dma.txt -- VERDICT r4 #6's experiment: the gain is the cache policy, not the DMA)
+#ifdef CRAFT_PV_NO_NT
     for (int i = 0; i < MT; ++i) va[i] = *reinterpret_cast<const u32x4*>(pa[i] + kc);
+#else
+    for (int i = 0; i < MT; ++i) va[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pa[i] + kc));
+#endif
   };
   auto fetch_b = [&](int kt, int kk) __attribute__((always_inline)) {
     const int g = min(min(kt, nk - 1) * 4 + kk, ng - 1);     // groups beyond K meet zeroed P columns
