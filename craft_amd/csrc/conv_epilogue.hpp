@@ -66,6 +66,11 @@ __device__ __forceinline__ void conv_epilogue4(const ConvGemmParams& p, long row
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = fmaxf(o[i] + rp[(long)min(i, nvalid - 1) * p.ld_res], 0.f);
     }
+    if (p.mask) {                                      // fused ReLU backward of the layer below
+      const float* mp = p.mask + row0 * p.ld_mask + col;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = mp[(long)min(i, nvalid - 1) * p.ld_mask] > 0.f ? o[i] : 0.f;
+    }
     dst = p.out + row0 * p.ldo + col; ldd = p.ldo;
   } else if constexpr (EPI == CONV_EPI_GRU_ZR) {       // cols [0,128): z = sigmoid -> out ; cols [128,256): r*h -> aux1
     if (col < 128) {                                   // (wave-uniform: a wave's 32 columns never straddle 128)
@@ -126,6 +131,11 @@ __device__ __forceinline__ void epi_load4(const ConvGemmParams& p, long row0, in
 #pragma unroll
       for (int i = 0; i < 4; ++i) o.x0[i] = rp[(long)i * p.ld_res];
     }
+    if (p.mask) {
+      const float* mp = p.mask + row0 * p.ld_mask + col;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o.x1[i] = mp[(long)i * p.ld_mask];
+    }
   } else if constexpr (EPI == CONV_EPI_GRU_ZR) {
     if (col >= 128) {
       const float* hp = p.aux0 + row0 * p.ld0 + (col - 128);
@@ -150,6 +160,10 @@ __device__ __forceinline__ void epi_finish4(const ConvGemmParams& p, long row0, 
     if (p.res) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) r[i] = fmaxf(r[i] + o.x0[i], 0.f);
+    }
+    if (p.mask) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = o.x1[i] > 0.f ? r[i] : 0.f;
     }
     dst = p.out + row0 * p.ldo + col; ldd = p.ldo;
   } else if constexpr (EPI == CONV_EPI_GRU_ZR) {

@@ -413,6 +413,20 @@ int craft_pack_conv_weights(const float* w0, int cout0, const float* w1, int cou
   return launch_pack_conv_weights(w0, cout0, w1, cout1, Cin, KH, KW, a0, a1, b0, b1, transposed, prec, out, S(stream));
 }
 
+int craft_conv2d_nhwc2_mask(const float* x0, long ld0, int c0, const float* x1, long ld1, int c1, const float* w, const float* bias,
+                            const float* bias_field, long ld_bf, int cout, int KH, int KW, const float* mask, long ldm, float* y, long ldy, int B,
+                            int H, int W, int prec, void* stream) {
+  if (c0 % 32 || c1 % 32 || c0 <= 0 || c1 < 0 || (c1 > 0 && x1 == nullptr)) return CRAFT_ERR_ALIGN;
+  if ((bias == nullptr) == (bias_field == nullptr) || mask == nullptr) return CRAFT_ERR_ARG;
+  ConvGemmParams q = conv_params(x0, (int)ld0, c0, c1 ? x1 : nullptr, (int)ld1, c1, B, H, W, KH, KW, w, bias, cout, CONV_EPI_BIAS_ACT, CRAFT_ACT_NONE,
+                                 1.f, y, (int)ldy);
+  q.bias_field = bias_field; q.ld_bf = (int)ld_bf;
+  q.w_packed = PACKED_OF(prec);
+  q.w16 = W16_OF(prec);
+  q.mask = mask; q.ld_mask = (int)ldm;
+  return launch_gemm_conv(q, PREC_OF(prec), S(stream));
+}
+
 int craft_conv2d_nhwc2(const float* x0, long ld0, int c0, const float* x1, long ld1, int c1, const float* w, const float* bias,
                        const float* bias_field, long ld_bf, int cout, int KH, int KW, int act, float* y, long ldy, int B, int H, int W, int prec,
                        void* stream) {
@@ -574,6 +588,10 @@ int craft_zero_stuff2(const float* g, long ldg, int B, int Hin, int Win, int C, 
   return launch_zero_stuff2(g, ldg, B, Hin, Win, C, gf, ldf, S(stream));
 }
 int craft_colsum(const float* x, long ld, long rows, int C, float* out, void* stream) { return launch_colsum(x, ld, rows, C, out, S(stream)); }
+int craft_multi_copy(const void* const* src, const long* n, const long* dst_off, int count, float* dst, void* stream) {
+  if (count <= 0) return 0;
+  return launch_multi_copy(src, n, dst_off, count, dst, S(stream));
+}
 int craft_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, void* stream) {
   return launch_act_fwd(x, ldx, y, ldy, rows, C, act, scale, S(stream));
 }

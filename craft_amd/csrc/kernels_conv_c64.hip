@@ -20,6 +20,13 @@
 namespace craft {
 
 // TERMS: as in k_conv_halo_wf (7 = three-term f16x3 product, 5 = the weights' hi plane only: CRAFT_CONV_W16, input-gradient convolutions)
+#ifdef CRAFT_C64_LINEAR            // developer A/B (tools/build_variant.py): the linear GEMM-row -> pixel assignment of rounds 2-4
+#define C64_ROW(l) (l)
+constexpr bool C64_PERM = false;
+#else
+#define C64_ROW(l) patch_row_perm(l)
+constexpr bool C64_PERM = true;
+#endif
 template <int PREC, int TERMS = CRAFT_X3_TERMS>
 __global__ __launch_bounds__(NTHREADS) void k_conv3x3_c64(ConvGemmParams p) {
   typedef typename PrecT<PREC>::lds_t lds_t;
@@ -56,7 +63,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_c64(ConvGemmParams p) {
   for (int mt = 0; mt < MT; ++mt) {
     // (patch_row_perm: every 16-lane service group of ds_read_b128 reads 16 consecutive pixels of ONE patch row -- 144-byte rows, 16 of
     // them cover the 64 banks exactly once.  Round 5 PMC of the linear assignment: SQ_LDS_BANK_CONFLICT = 0.50 of SQ_LDS_IDX_ACTIVE.)
-    const int r = wm0 + mt * 32 + patch_row_perm(lane & 31);
+    const int r = wm0 + mt * 32 + C64_ROW(lane & 31);
     arow[mt] = ((r >> 4) * HWd + (r & 15)) * LD + (lane >> 5) * 8;
   }
   auto read_a = [&](int step, frag_t (&h)[MT], frag_t (&l)[MT]) __attribute__((always_inline)) {
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_c64(ConvGemmParams p) {
     // ---- epilogue of patch pt
     const int cb = blockIdx.y * 64 + wn0;
     const int rh4 = 4 * (lane >> 5);
-    conv_epilogue_patch<CONV_EPI_BIAS_ACT, true, MT, 1, true>(p, acc, wm0, lane, cb, img, y0, x0);
+    conv_epilogue_patch<CONV_EPI_BIAS_ACT, true, MT, 1, C64_PERM>(p, acc, wm0, lane, cb, img, y0, x0);
     if (p.stats) {
       unsigned mlo = ~0u, mhi = ~0u;
       if (y0 + PH > g.H || x0 + PW > g.W) {
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(NTHREADS) void k_conv3x3_c64(ConvGemmParams p) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const int r = wm0 + mt * 32 + patch_row_perm((e & 3) + 8 * (e >> 2) + rh4);
+            const int r = wm0 + mt * 32 + C64_ROW((e & 3) + 8 * (e >> 2) + rh4);
             const bool ok = (y0 + (r >> 4)) < g.H && (x0 + (r & 15)) < g.W;
             const int bit = mt * 16 + e;
             if (ok) { if (bit < 32) mlo |= 1u << bit; else mhi |= 1u << (bit - 32); }

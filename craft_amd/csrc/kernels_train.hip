@@ -1216,4 +1216,46 @@ int launch_relpos_bwd(const float* dS, long ld, int BZ, int H8, int W8, float* d
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// craft_multi_copy: n contiguous fp32 tensors -> their places in one flat buffer, ONE launch (the parameter gradients of a step into the
+// optimizer's flat gradient buffer: torch._foreach_copy_ on this build issues one copyBuffer per tensor, 131 per configs[3] step).
+// The descriptor table travels in the kernel arguments; block -> (tensor, 8 KiB chunk) through a prefix table.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int MC_MAX = 168;                       // tensors per launch (the argument block stays under 4 KiB)
+constexpr int MC_CHUNK = 2048;                    // floats per block
+struct MultiCopy { const float* src[MC_MAX]; unsigned off[MC_MAX]; unsigned n[MC_MAX]; unsigned first[MC_MAX + 1]; int count; };
+__global__ __launch_bounds__(256) void k_multi_copy(MultiCopy m, float* __restrict__ dst) {
+  int lo = 0, hi = m.count;                       // the tensor whose chunks contain this block
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (blockIdx.x >= m.first[mid]) lo = mid; else hi = mid; }
+  const unsigned c0 = (blockIdx.x - m.first[lo]) * MC_CHUNK, n = m.n[lo];
+  const float* s = m.src[lo] + c0;
+  float* d = dst + m.off[lo] + c0;
+  const unsigned len = min((unsigned)MC_CHUNK, n - c0);
+  if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+    for (unsigned i = threadIdx.x * 4; i + 3 < len; i += 1024) *reinterpret_cast<float4*>(d + i) = *reinterpret_cast<const float4*>(s + i);
+    for (unsigned i = (len & ~3u) + threadIdx.x; i < len; i += 256) d[i] = s[i];
+  } else {
+    for (unsigned i = threadIdx.x; i < len; i += 256) d[i] = s[i];
+  }
+}
+int launch_multi_copy(const void* const* src, const long* n, const long* dst_off, int count, float* dst, hipStream_t s) {
+  for (int i0 = 0; i0 < count; i0 += MC_MAX) {
+    MultiCopy m = {};
+    m.count = count - i0 < MC_MAX ? count - i0 : MC_MAX;
+    long blocks = 0;
+    for (int i = 0; i < m.count; ++i) {
+      const long ni = n[i0 + i], oi = dst_off[i0 + i];
+      if (ni < 0 || oi < 0 || ni >= (1L << 32) || oi >= (1L << 32) || (ni > 0 && src[i0 + i] == nullptr)) return CRAFT_ERR_ARG;
+      m.src[i] = static_cast<const float*>(src[i0 + i]); m.n[i] = (unsigned)ni; m.off[i] = (unsigned)oi;
+      m.first[i] = (unsigned)blocks;
+      blocks += (ni + MC_CHUNK - 1) / MC_CHUNK;
+    }
+    if (blocks >= (1L << 31)) return CRAFT_ERR_UNSUPPORTED;
+    m.first[m.count] = (unsigned)blocks;
+    if (blocks > 0) hipLaunchKernelGGL(k_multi_copy, dim3((unsigned)blocks), dim3(256), 0, s, m, dst);
+    if (hipGetLastError() != hipSuccess) return (int)hipGetLastError();
+  }
+  return 0;
+}
+
 }  // namespace craft

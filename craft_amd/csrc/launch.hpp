@@ -55,6 +55,8 @@ struct ConvGemmParams {
                                         // iteration-invariant part of a conv: SepConvGRU context term)
   const float* res; int ld_res;         // optional (CONV_EPI_BIAS_ACT): out = relu(res[pix][col] + act(conv + bias) * scale) -- the tail of a
                                         // ResidualBlock (extractor.py:56-63) in the epilogue of its second convolution
+  const float* mask; int ld_mask;       // optional (CONV_EPI_BIAS_ACT): out = mask[pix][col] > 0 ? out : 0 -- the ReLU backward of the layer
+                                        // BELOW an input-gradient convolution (mask = that layer's saved output), fused into the epilogue
 };
 
 // k_conv_pk (kernels_conv_pk.hip): the activation operand as up to two packs (craft_pack_operand, spatial form) over one padded grid
@@ -210,6 +212,7 @@ int launch_bn_finalize(const double* stats, int B, int C, double count, float ep
 int launch_norm_bwd_finalize(const double* sums, int B, int C, double population, int per_image, float* red, float* dgamma, float* dbeta,
                              hipStream_t s);
 int launch_colsum(const float* x, long ld, long rows, int C, float* out, hipStream_t s);
+int launch_multi_copy(const void* const* src, const long* n, const long* dst_off, int count, float* dst, hipStream_t s);
 int launch_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, hipStream_t s);
 int launch_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,
                    hipStream_t s);

@@ -66,6 +66,7 @@ _SIGS = {
     "craft_conv2d_nhwc": [P, L, I, P, P, I, I, I, I, P, L, I, I, I, I, P],
     "craft_conv2d_pk": [P, L, I, I, I, P, L, I, I, I, L, I, I, I, P, P, P, L, I, I, I, I, P, L, I, I, I, I, P],
     "craft_conv2d_nhwc_res": [P, L, I, P, P, I, I, I, I, P, L, P, L, I, I, I, I, P],
+    "craft_conv2d_nhwc2_mask": [P, L, I, P, L, I, P, P, P, L, I, I, I, P, L, P, L, I, I, I, I, P],
     "craft_conv2d_nhwc_ex": [P, L, I, I, I, P, P, P, I, I, I, I, I, P, L, I, I, I, P, I, P],
     "craft_stem_conv7x7": [P, P, P, I, I, I, I, P, P, P],
     "craft_stem_conv7x7_mfma": [P, P, P, I, I, I, I, P, P, I, P],
@@ -74,6 +75,7 @@ _SIGS = {
     "craft_flow_metrics": [P, P, P, I, I, I, F, F, F, P, P],
     "craft_flow_l1_loss": [P, P, P, I, I, I, F, F, P, P, P],
     "craft_sumsq": [P, L, P, P],
+    "craft_multi_copy": [P, P, P, I, P, P],
     "craft_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, F, P, F, P],
     "craft_loss_scale_update": [P, P, F, F, F, F, F, F, I, P],
     "craft_adamw_step_dyn": [P, P, P, P, L, F, F, F, F, F, P, P],

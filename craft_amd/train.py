@@ -163,7 +163,7 @@ class FlatAdamW:
         the alignment padding between the views stays zero from the allocation."""
         views = self.grad_views()
         had = self.__dict__.setdefault("_had_grad", [False] * len(views))
-        dst, src, stale = [], [], []
+        dst, src, offs, stale = [], [], [], []
         for i, (v, g) in enumerate(zip(views, grads)):
             if g is None:
                 if had[i]:
@@ -174,9 +174,17 @@ class FlatAdamW:
                     raise ValueError(f"gradient {i} has shape {tuple(g.shape)}, its parameter {tuple(v.shape)}")
                 dst.append(v)
                 src.append(g.detach())
+                offs.append(self.offsets[i])
                 had[i] = True
         with torch.no_grad():
-            if dst:
+            if dst and self.flat_grad.is_cuda and all(g.dtype == torch.float32 for g in src):
+                # ONE launch (craft_multi_copy); torch._foreach_copy_ issues a copyBuffer per tensor on this build (131 per configs[3] step)
+                import ctypes
+                from .hip import call, carray
+                src = [g if g.is_contiguous() else g.contiguous() for g in src]
+                call("craft_multi_copy", carray(ctypes.c_void_p, [g.data_ptr() for g in src]), carray(ctypes.c_long, [g.numel() for g in src]),
+                     carray(ctypes.c_long, offs), len(src), self.flat_grad)
+            elif dst:
                 torch._foreach_copy_(dst, src)
             if stale:
                 torch._foreach_zero_(stale)

@@ -112,11 +112,13 @@ class UpdatePass:
         self.ready = []
 
 
-def _conv_dx(ps: UpdatePass, w, g, cout_p, KH, KW, out=None, cin_p=None, field=None):
+def _conv_dx(ps: UpdatePass, w, g, cout_p, KH, KW, out=None, cin_p=None, field=None, relu_y=None):
     """Input gradient of a stride-1 'same' convolution: the forward kernel with flipped / transposed weights.  g [B, N, cout_p]
     (row stride may exceed cout_p) -> [B, N, cin_p].  w: the nn.Conv2d weight, or (with cin_p) an operand already packed by
     ops.pack_conv_weights(transposed=True).  field [B, N, >= cin_p]: out = conv + field (a gradient that is already there: the
-    convolution's per-pixel bias field, `out` may be `field` itself) instead of a separate add pass."""
+    convolution's per-pixel bias field, `out` may be `field` itself) instead of a separate add pass.  relu_y [B, N, >= cin_p]: the saved
+    output of the ReLU layer BELOW this convolution -- its backward (out = relu_y > 0 ? out : 0) runs in the epilogue
+    (craft_conv2d_nhwc2_mask) instead of as a craft_act_bwd pass over the result."""
     if cin_p is None:
         wt, zb, flag, _ = AG._conv_weights(w, None, ps.cp, ps.cache, True)
         cin_p = round_up(w.shape[1], 32)
@@ -124,7 +126,11 @@ def _conv_dx(ps: UpdatePass, w, g, cout_p, KH, KW, out=None, cin_p=None, field=N
         wt, zb, flag = w, ps.zero_bias, W_PACKED
     if out is None:
         out = torch.empty(ps.B, ps.N, cin_p, device=ps.dev, dtype=torch.float32)
-    if field is not None:
+    if relu_y is not None:
+        call("craft_conv2d_nhwc2_mask", g, g.stride(-2), cout_p, None, 0, 0, wt, zb if field is None else None, field,
+             field.stride(-2) if field is not None else 0, cin_p, KH, KW, relu_y, relu_y.stride(-2), out, out.stride(-2), ps.B, ps.hw[0], ps.hw[1],
+             ps.cp | flag | AG.dxflag(ps.cp))
+    elif field is not None:
         call("craft_conv2d_nhwc2", g, g.stride(-2), cout_p, None, 0, 0, wt, None, field, field.stride(-2), cin_p, KH, KW, ACT_NONE, out, out.stride(-2),
              ps.B, ps.hw[0], ps.hw[1], ps.cp | flag | AG.dxflag(ps.cp))
     else:
@@ -294,9 +300,8 @@ class UpdateIter(Function):
             dh2 = _conv_dx(ps, ub.mask[0].weight, g_mh, 256, 3, 3, field=AG._rows(d_hn) if d_hn is not None else None)   # (+ the recurrence's share)
             ps.wgrad(("mask0",), (AG.Packed(g_mh, AG.gprec(cp), g3, colsum=ps.acc(("mask0", "db"), (256,)), batch=pb), S["pk_h2"]), 3, 3, ps.acc(("mask0", "dw"), (256, 3, 3, 128)), last)
             # ---- flow head: delta = conv2(relu(conv1(h2)))
-            d_fh1 = _conv_dx(ps, fh.conv2.weight, dflow, 32, 3, 3)
+            g_fh1 = _conv_dx(ps, fh.conv2.weight, dflow, 32, 3, 3, relu_y=S["fh1"])          # (ReLU backward of conv1's output in the epilogue)
             ps.wgrad(("fh2",), (AG.Packed(dflow, AG.gprec(cp), g3, colsum=ps.acc(("fh2", "db"), (32,)), batch=pb), S["pk_fh1"]), 3, 3, ps.acc(("fh2", "dw"), (32, 3, 3, 256)), last)
-            g_fh1 = _act_bwd(d_fh1, S["fh1"], 256, out=d_fh1)
             _conv_dx(ps, fh.conv1.weight, g_fh1, 256, 3, 3, out=dh2, field=dh2)
             ps.wgrad(("fh1",), (AG.Packed(g_fh1, AG.gprec(cp), g3, colsum=ps.acc(("fh1", "db"), (256,)), batch=pb), S["pk_h2"]), 3, 3, ps.acc(("fh1", "dw"), (256, 3, 3, 128)), last)
         elif d_hn is not None:
@@ -448,21 +453,18 @@ def _phase2(ps: UpdatePass):
         # ---- BasicMotionEncoder
         g_out = _act_bwd(d_mf, mf, 128, out=d_mf)
         g_out[..., 126:128] = 0.0                                                             # the two pass-through flow channels carry no gradient
-        d_cf = _conv_dx(ps, enc.conv.weight, g_out, 128, 3, 3)
+        g_cf = _conv_dx(ps, enc.conv.weight, g_out, 128, 3, 3, relu_y=S["cf"])
         ps.wgrad(("menc",), (AG.Packed(g_out, AG.gprec(cp), g3, colsum=ps.acc(("menc", "db"), (128,)), batch=pb), S["pk_cf"]), 3, 3, ps.acc(("menc", "dw"), (128, 3, 3, 256)), last)
-        g_cf = _act_bwd(d_cf, S["cf"], 256, out=d_cf)
         g_c2, g_f2 = g_cf[..., :192], g_cf[..., 192:256]
-        d_cor1 = _conv_dx(ps, enc.convc2.weight, g_c2, 192, 3, 3)
+        g_cor1 = _conv_dx(ps, enc.convc2.weight, g_c2, 192, 3, 3, relu_y=S["cor1"])
         ps.wgrad(("c2",), (AG.Packed(g_c2, AG.gprec(cp), g3, colsum=ps.acc(("c2", "db"), (192,)), batch=pb), S["pk_cor1"]), 3, 3, ps.acc(("c2", "dw"), (192, 3, 3, 256)), last)
-        g_cor1 = _act_bwd(d_cor1, S["cor1"], 256, out=d_cor1)
         wc1 = enc.convc1.weight.detach().view(256, -1)
         cpl = wc1.shape[1]
         d_corr = E(B, N, cpl)
         AG.gemm(g_cor1, 256, 1, 0, 0, wc1, 1, cpl, 0, 0, d_corr, cpl, 0, 0, 1, 1, rows, cpl, 256, prec=cp)
         ps.wgrad(("c1",), (AG.Packed(g_cor1, AG.gprec(cp), colsum=ps.acc(("c1", "db"), (256,)), batch=pb), S["pk_corr"]), 1, 1, ps.acc(("c1", "dw"), (256, round_up(cpl, 32))), last)
-        d_flo1 = _conv_dx(ps, enc.convf2.weight, g_f2, 64, 3, 3)
+        g_flo1 = _conv_dx(ps, enc.convf2.weight, g_f2, 64, 3, 3, relu_y=S["flo1"])
         ps.wgrad(("f2",), (AG.Packed(g_f2, AG.gprec(cp), g3, colsum=ps.acc(("f2", "db"), (64,)), batch=pb), S["pk_flo1"]), 3, 3, ps.acc(("f2", "dw"), (64, 3, 3, 128)), last)
-        g_flo1 = _act_bwd(d_flo1, S["flo1"], 128, out=d_flo1)
         ps.wgrad(("f1",), (AG.Packed(g_flo1, AG.gprec(cp), g7, colsum=ps.acc(("f1", "db"), (128,)), batch=pb), S["pk_flow"]), 7, 7, ps.acc(("f1", "dw"), (128, 7, 7, 32)), last)
         # ---- correlation lookup (corr.py:47-71): the gradient goes into the shared buffers of the normalised pyramid; autograd.CorrVolume
         # (every iteration took its token) folds them into the volume's gradient after this node

@@ -261,6 +261,12 @@ int craft_conv2d_pk(const void* x0, long rows_p0, int ncg0, int cg_off0, int c0,
  * weights (cnet, eval): the standalone craft_residual_relu pass (read x, read y, write out) disappears.  Stride 1. */
 int craft_conv2d_nhwc_res(const float* x, long ldx, int cin, const float* w, const float* bias, int cout, int KH, int KW, int act, const float* res,
                           long ldr, float* y, long ldy, int B, int H, int W, int prec, void* stream);
+/* craft_conv2d_nhwc2 (no activation) whose epilogue also applies the ReLU backward of the layer BELOW: y = mask > 0 ? conv + bias(_field) : 0,
+ * mask fp32 tokens [B*H*W][cout] (row stride ldm) = that layer's saved forward output.  The input-gradient convolutions of a chain
+ * conv -> ReLU -> conv (autograd of update.py:80-87, :12-16) hand their result straight to the next one: no separate craft_act_bwd pass. */
+int craft_conv2d_nhwc2_mask(const float* x0, long ld0, int c0, const float* x1, long ld1, int c1, const float* w, const float* bias,
+                            const float* bias_field, long ld_bf, int cout, int KH, int KW, const float* mask, long ldm, float* y, long ldy, int B,
+                            int H, int W, int prec, void* stream);
 int craft_conv2d_nhwc_ex(const float* x, long ldx, int cin, int Hin, int Win, const float* in_norm, const float* w,
                          const float* bias, int cout, int KH, int KW, int stride, int act, float* y, long ldy, int B,
                          int Hout, int Wout, double* stats, int prec, void* stream);
@@ -396,6 +402,10 @@ int craft_gemm(const float* A, long a_sm, long a_sk, long a_bs0, long a_bs1, con
 int craft_conv2d_wgrad(const float* x, long ldx, int cin, const float* dy, long ldy, int cout, int KH, int KW, int B, int H, int W,
                        float* dW, float* db, float* ws, long ws_floats, int prec, void* stream);
 int craft_colsum(const float* x, long ld, long rows, int C, float* out, void* stream);
+/* count contiguous fp32 device tensors src[i] (n[i] elements) -> dst + dst_off[i], in ONE launch (src / n / dst_off are HOST arrays): the
+ * parameter gradients of a training step into the optimizer's flat gradient buffer -- what the reference's optimizer.step() reads
+ * parameter by parameter (train.py:231-236) and torch._foreach_copy_ turns into one copy launch per tensor. */
+int craft_multi_copy(const void* const* src, const long* n, const long* dst_off, int count, float* dst, void* stream);
 /* Packed-operand weight gradients (round 3; craft_amd/csrc/kernels_gemm_pk.hip): the same contraction as craft_conv2d_wgrad /
  * craft_gemm's dW = dY^T X for the 16-bit MFMA modes, with the fp32 -> fp16-plane split taken OUT of the K loop.
  * craft_pack_operand: tokens x [rows][C] (fp32, row stride ldx, C % 4 == 0) -> out[plane][ceil(C/32)][rows_p][32] 16-bit

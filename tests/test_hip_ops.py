@@ -560,6 +560,43 @@ def test_conv2d_residual_epilogue(device, prec, cin, cout, shape):
     close(ops.tokens_to_nchw(y, H8, W8), ref, rt * 2, at * 4, f"conv + residual prec={prec}")
 
 
+def test_conv2d_relu_mask_epilogue_and_multi_copy(device):
+    """craft_conv2d_nhwc2_mask: the ReLU backward of the layer below an input-gradient convolution in its epilogue -- bit-equal to
+    craft_conv2d_nhwc2 followed by craft_act_bwd (with and without a per-pixel bias field); craft_multi_copy: ragged tensors into a flat
+    buffer in one launch."""
+    from craft_amd.hip import call, carray, W_PACKED
+    import ctypes
+    B, H8, W8, cin, cout = 2, 11, 21, 64, 96
+    x = gen(B, H8 * W8, cin, seed=120).to(device)
+    ysave = gen(B, H8 * W8, cout, seed=121).to(device)
+    field = gen(B, H8 * W8, cout, seed=122).to(device)
+    w = gen(cout, cin, 3, 3, seed=123) / math.sqrt(cin * 9)
+    wp = ops.pack_conv_prec(w.to(device), PREC_F16X3)
+    zb = torch.zeros(cout, device=device)
+    for f in (None, field):
+        a = torch.empty(B, H8 * W8, cout, device=device)
+        b = torch.empty_like(a)
+        call("craft_conv2d_nhwc2", x, cin, cin, None, 0, 0, wp, zb if f is None else None, f, cout if f is not None else 0, cout, 3, 3, ACT_NONE, a, cout,
+             B, H8, W8, PREC_F16X3 | W_PACKED)
+        call("craft_act_bwd", a, cout, ysave, cout, a, cout, B * H8 * W8, cout, ACT_RELU, 1.0)
+        call("craft_conv2d_nhwc2_mask", x, cin, cin, None, 0, 0, wp, zb if f is None else None, f, cout if f is not None else 0, cout, 3, 3, ysave, cout,
+             b, cout, B, H8, W8, PREC_F16X3 | W_PACKED)
+        assert torch.equal(a, b)
+    sizes = [1, 7, 2048, 2049, 5000, 0, 33, 12345]
+    srcs = [gen(max(n, 1), seed=130 + i)[:n].to(device) for i, n in enumerate(sizes)]
+    offs, off = [], 3
+    for n in sizes:
+        offs.append(off)
+        off += n + 5
+    flat = torch.full((off,), -7.0, device=device)
+    call("craft_multi_copy", carray(ctypes.c_void_p, [t.data_ptr() if t.numel() else 0 for t in srcs]), carray(ctypes.c_long, sizes),
+         carray(ctypes.c_long, offs), len(sizes), flat)
+    ref = torch.full((off,), -7.0)
+    for t, o, n in zip(srcs, offs, sizes):
+        ref[o:o + n] = t.cpu()
+    assert torch.equal(flat.cpu(), ref)
+
+
 def test_forward_interpolate(device):
     """craft_forward_interpolate vs the reference's outputs (tests/golden/forward_interpolate.npz, generated by running
     utils.py:34-62) and vs the oracle on a batch of fresh flows, including one with no valid source."""
