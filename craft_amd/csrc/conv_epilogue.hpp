@@ -114,12 +114,12 @@ __device__ __forceinline__ void conv_epilogue4(const ConvGemmParams& p, long row
 // Inside conv_epilogue4 every group's loads sit behind that group's bounds branches, so each group waits for its own round trip
 // (s_waitcnt vmcnt(0) per group: 16 dependent L2 round trips per lane at the end of every convolution launch).
 struct EpiOperands { float b[4], x0[4], x1[4]; };
+// rows[i]: the token index pixel i READS its operands from (a clamped, always valid index for a pixel outside the image)
 template <int EPI>
-__device__ __forceinline__ void epi_load4(const ConvGemmParams& p, long row0, int col, EpiOperands& o) {
+__device__ __forceinline__ void epi_load4r(const ConvGemmParams& p, const long (&rows)[4], int col, EpiOperands& o) {
   if (p.bias_field) {
-    const float* bf = p.bias_field + row0 * p.ld_bf + col;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o.b[i] = bf[(long)i * p.ld_bf];
+    for (int i = 0; i < 4; ++i) o.b[i] = p.bias_field[rows[i] * p.ld_bf + col];
   } else {
     const float b0 = p.bias[col];
 #pragma unroll
@@ -127,30 +127,31 @@ __device__ __forceinline__ void epi_load4(const ConvGemmParams& p, long row0, in
   }
   if constexpr (EPI == CONV_EPI_BIAS_ACT) {
     if (p.res) {
-      const float* rp = p.res + row0 * p.ld_res + col;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o.x0[i] = rp[(long)i * p.ld_res];
+      for (int i = 0; i < 4; ++i) o.x0[i] = p.res[rows[i] * p.ld_res + col];
     }
     if (p.mask) {
-      const float* mp = p.mask + row0 * p.ld_mask + col;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o.x1[i] = mp[(long)i * p.ld_mask];
+      for (int i = 0; i < 4; ++i) o.x1[i] = p.mask[rows[i] * p.ld_mask + col];
     }
   } else if constexpr (EPI == CONV_EPI_GRU_ZR) {
     if (col >= 128) {
-      const float* hp = p.aux0 + row0 * p.ld0 + (col - 128);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o.x0[i] = hp[(long)i * p.ld0];
+      for (int i = 0; i < 4; ++i) o.x0[i] = p.aux0[rows[i] * p.ld0 + (col - 128)];
     }
   } else if constexpr (EPI == CONV_EPI_GRU_Q) {
-    const float* zp = p.aux1 + row0 * p.ld1 + col;
-    const float* hp = p.aux0 + row0 * p.ld0 + col;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { o.x1[i] = zp[(long)i * p.ld1]; o.x0[i] = hp[(long)i * p.ld0]; }
+    for (int i = 0; i < 4; ++i) { o.x1[i] = p.aux1[rows[i] * p.ld1 + col]; o.x0[i] = p.aux0[rows[i] * p.ld0 + col]; }
   }
 }
-template <int EPI, bool FAST>
-__device__ __forceinline__ void epi_finish4(const ConvGemmParams& p, long row0, int col, const float (&v)[4], const EpiOperands& o) {
+template <int EPI>
+__device__ __forceinline__ void epi_load4(const ConvGemmParams& p, long row0, int col, EpiOperands& o) {
+  const long rows[4] = {row0, row0 + 1, row0 + 2, row0 + 3};
+  epi_load4r<EPI>(p, rows, col, o);
+}
+// okmask bit i: pixel i is a real output pixel (its result is stored at row0 + i); ALL: every bit set (no predicates at all)
+template <int EPI, bool FAST, bool ALL = true>
+__device__ __forceinline__ void epi_finish4(const ConvGemmParams& p, long row0, int col, const float (&v)[4], const EpiOperands& o, unsigned okmask = 15u) {
   float r[4];
   float* dst; long ldd;
   if constexpr (EPI == CONV_EPI_BIAS_ACT) {
@@ -186,7 +187,8 @@ __device__ __forceinline__ void epi_finish4(const ConvGemmParams& p, long row0, 
     dst = p.out + row0 * p.ldo + col; ldd = p.ldo;
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) dst[i * ldd] = r[i];
+  for (int i = 0; i < 4; ++i)
+    if (ALL || ((okmask >> i) & 1u)) dst[i * ldd] = r[i];
 }
 
 // run BODY(EPI) with the compile-time epilogue kind that matches p.epi
@@ -239,6 +241,41 @@ __device__ __forceinline__ void conv_epilogue_patch(const ConvGemmParams& p, con
       }
     return;
   }
+  // RAGGED patch (the image is not a multiple of 8 x 16: 46 x 62 at configs[3]) with full columns in the same batched form -- operands
+  // read from CLAMPED pixels (always valid addresses, requested together), results stored under a per-pixel predicate -- instead of the
+  // per-group path below.
+#ifdef CRAFT_EPI_RAGGED_BATCHED  // (developer A/B, tools/build_variant.py; measured SLOWER at configs[3]: 53.45 against 53.15 ms per step -- the
+                                 // per-group path skips the quads outside the image altogether -- and therefore off)
+  if (cb + NT * 32 <= p.cout) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        EpiOperands ops[4];
+        long row0[4];
+        unsigned ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = wm0 + mt * 32 + (PERM ? patch_row_perm(8 * q + rh4) : 8 * q + rh4);
+          const int y = y0 + (r >> 4), x = x0 + (r & 15);
+          const int yc = min(y, p.g.H - 1);
+          const int nv = y < p.g.H ? max(0, min(4, p.g.W - x)) : 0;
+          ok[q] = (1u << nv) - 1u;
+          row0[q] = img + (long)y * p.g.W + x;
+          long rr[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rr[i] = img + (long)yc * p.g.W + min(x + i, p.g.W - 1);
+          epi_load4r<EPI>(p, rr, cb + nt * 32 + c_lane, ops[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v[4] = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+          epi_finish4<EPI, FAST, false>(p, row0[q], cb + nt * 32 + c_lane, v, ops[q], ok[q]);
+        }
+      }
+    return;
+  }
+#endif
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

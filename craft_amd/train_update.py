@@ -25,6 +25,8 @@ the forward convolution with flipped weights, weight gradients queued per layer 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -112,6 +114,9 @@ class UpdatePass:
         self.ready = []
 
 
+_NO_MASK_EPI = bool(os.environ.get("CRAFT_NO_MASK_EPI"))
+
+
 def _conv_dx(ps: UpdatePass, w, g, cout_p, KH, KW, out=None, cin_p=None, field=None, relu_y=None):
     """Input gradient of a stride-1 'same' convolution: the forward kernel with flipped / transposed weights.  g [B, N, cout_p]
     (row stride may exceed cout_p) -> [B, N, cin_p].  w: the nn.Conv2d weight, or (with cin_p) an operand already packed by
@@ -126,6 +131,9 @@ def _conv_dx(ps: UpdatePass, w, g, cout_p, KH, KW, out=None, cin_p=None, field=N
         wt, zb, flag = w, ps.zero_bias, W_PACKED
     if out is None:
         out = torch.empty(ps.B, ps.N, cin_p, device=ps.dev, dtype=torch.float32)
+    if relu_y is not None and _NO_MASK_EPI:          # developer A/B: the separate craft_act_bwd pass
+        out = _conv_dx(ps, w if cin_p is None else wt, g, cout_p, KH, KW, out=out, cin_p=cin_p, field=field)
+        return _act_bwd(out, relu_y, out.shape[-1], out=out)
     if relu_y is not None:
         call("craft_conv2d_nhwc2_mask", g, g.stride(-2), cout_p, None, 0, 0, wt, zb if field is None else None, field,
              field.stride(-2) if field is not None else 0, cin_p, KH, KW, relu_y, relu_y.stride(-2), out, out.stride(-2), ps.B, ps.hw[0], ps.hw[1],
