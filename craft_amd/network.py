@@ -326,6 +326,7 @@ class CRAFT(nn.Module):
             for itr in range(iters):
                 for pt, st in zip(parts, streams):
                     with torch.cuda.stream(st):
+                        self.update_block.encoder.prefork(dev)                                 # (the flow branch may start beside the lookup)
                         ops.corr_lookup(pt["pyr"], pt["c1"], radius, out=pt["corr"])           # network.py:235
                         self.update_block.step_tokens(pt["hx"], pt["corr"], pt["flow"], pt["att"], hw, pt["ws"], prec,
                                                       pt["fields"])                            # :244 (to the new net)

@@ -168,6 +168,17 @@ class BasicMotionEncoder(nn.Module):
             cache[key] = (st, ev)
         return cache[key]
 
+    def prefork(self, device):
+        """Let the flow branch's side stream start from HERE (the caller's stream position now) instead of from the forward_tokens call:
+        the branch depends only on `flow`, which is final before the correlation lookup, so forking in front of the lookup gives
+        convf1 -> convf2 (86 us) the lookup's 33 us as a head start over convc1 -> convc2 (91 us) -- the join in front of `conv` then
+        rarely waits (round-5 kernel trace: 10 us of idle main stream per iteration at that join, profiles/r5/trace_gaps.txt)."""
+        if os.environ.get("CRAFT_NO_FORK") or os.environ.get("CRAFT_NO_PREFORK"):
+            return
+        side, _ = self._flow_side(device)
+        side.wait_stream(torch.cuda.current_stream())
+        self.__dict__.setdefault("_preforked", set()).add((device.index, torch.cuda.current_stream().cuda_stream))
+
     def forward_tokens(self, flow: torch.Tensor, corr: torch.Tensor, hw, out: torch.Tensor, ws: torch.Tensor, prec: int,
                        fork: bool = True):
         """flow tokens [B,N,2], corr tokens [B,N,cor_planes] -> out tokens view [B,N,128].  ``fork``: the flow branch
@@ -179,7 +190,12 @@ class BasicMotionEncoder(nn.Module):
         st = ev = None
         if fork and not os.environ.get("CRAFT_NO_FORK"):
             side, event = self._flow_side(flow.device)
-            side.wait_stream(torch.cuda.current_stream())       # the side stream sees `flow` / `ws` as the caller left them
+            key = (flow.device.index, torch.cuda.current_stream().cuda_stream)
+            pre = self.__dict__.get("_preforked")
+            if pre and key in pre:
+                pre.discard(key)                                # (prefork(): the side stream already waits for the caller's earlier position)
+            else:
+                side.wait_stream(torch.cuda.current_stream())   # the side stream sees `flow` / `ws` as the caller left them
             st, ev = side.cuda_stream, event.cuda_event
         call("craft_motion_encoder", corr, corr.stride(1), self.cor_planes, flow, wc1, bc1, wc2, bc2, wf1, bf1, wf2, bf2,
              wcv, bcv, B, H8, W8, out, out.stride(1), ws, cp | W_PACKED, st, ev)
