@@ -544,23 +544,25 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build4t(ScoreParams p, const 
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) qp[i] = Qs + ((long)b * N + min(q0 + r8 + 32 * i, N - 1)) * C + c8 * 8;
-  u32x4 ra[2][4], rb[2][2];
-  auto fetch = [&](int m) __attribute__((always_inline)) {
+  // two register sets: the operands of mode m + 2 are requested while mode m is multiplied (round 5: with one set the request for
+  // m + 1 had only the 24 MFMAs of mode m -- 0.4 us -- to come back from L2 / HBM, and a block waited ~1.5 us per mode)
+  u32x4 ra[2][2][4], rb[2][2][2];
+  auto fetch = [&](int m, int set) __attribute__((always_inline)) {
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ra[pl][i] = *reinterpret_cast<const u32x4*>(kp[i] + pl * rows_tot * C + m * D);
+      for (int i = 0; i < 4; ++i) ra[set][pl][i] = *reinterpret_cast<const u32x4*>(kp[i] + pl * rows_tot * C + m * D);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) rb[pl][i] = *reinterpret_cast<const u32x4*>(qp[i] + pl * rows_tot * C + m * D);
+      for (int i = 0; i < 2; ++i) rb[set][pl][i] = *reinterpret_cast<const u32x4*>(qp[i] + pl * rows_tot * C + m * D);
     }
   };
-  auto store = [&]() __attribute__((always_inline)) {
+  auto store = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&As[(pl * BK_ + r8 + 32 * i) * LD + c8 * 8]) = ra[pl][i];
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&As[(pl * BK_ + r8 + 32 * i) * LD + c8 * 8]) = ra[set][pl][i];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(&Bs[(pl * BQ + r8 + 32 * i) * LD + c8 * 8]) = rb[pl][i];
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(&Bs[(pl * BQ + r8 + 32 * i) * LD + c8 * 8]) = rb[set][pl][i];
     }
   };
   f32x16 acc[4][MT];
@@ -574,13 +576,14 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build4t(ScoreParams p, const 
   // MFMA A row r of tile mt must be key (dy = 4 mt + (r' >> 2 ...)): the C layout puts row (e & 3) + 8 (e >> 2) + 4 g in register e,
   // so LDS row a = wk*64 + mt*32 + rho where rho is the tile row whose (dy, dx) we want at MFMA row r: MFMA row index R_ = r maps to
   // key (dyl = R_ >> 3, dx = R_ & 7) when the tile rows are stored in that same order -- which is the staging order above.
-  fetch(0);
+  fetch(0, 0);
+  fetch(1, 1);
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     __syncthreads();
-    store();
+    store(m & 1);
     __syncthreads();
-    if (m + 1 < 4) fetch(m + 1);
+    if (m + 2 < 4) fetch(m + 2, m & 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
