@@ -222,6 +222,9 @@ def roofline_pv(model, im1, im2, iters, prec, forwards=3):
         sh = pmc.get("shape", {})
         if (sh.get("B"), sh.get("H8"), sh.get("W8")) == (B, H8, W8) and pv == PREC_F16 and pmc.get("kernel", "").replace(" ", "") == live.replace(" ", ""):
             traffic = int(pmc["hbm_bytes_per_launch"])
+        e5 = pmc_lookup(live, "pv", B, H8, W8) if pv == PREC_F16 else None      # this round's passes of the same instantiation take precedence
+        if e5:
+            traffic = int(e5["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         pass
     return {"bound": "hbm", "kernel": f"k_pv16 (attention apply O = P.V of the motion aggregator, {iters} launches per forward)",
@@ -229,7 +232,7 @@ def roofline_pv(model, im1, im2, iters, prec, forwards=3):
             "bytes_per_launch": bytes_alg, "ms_per_launch": round(ms, 4), "launches_timed": len(evs),
             "note": "timed live around every launch of real forward passes (HIP events on the launch stream); algorithmic bytes "
                     "= P (fp16, read once) + V^T + O; traffic = HBM bytes per launch from the PMC passes committed under "
-                    "profiles/r4 (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; null when the live kernel instantiation is not the profiled one); measured read-only ceiling of this access pattern "
+                    "profiles/r5/pmc_kernels.json, else profiles/r4 (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; null when the live kernel instantiation is not the profiled one); measured read-only ceiling of this access pattern "
                     "on the same chip: 6.1 TB/s (tools/ubench/hbm_rows.hip)"}
 
 

@@ -413,6 +413,15 @@ int craft_pack_conv_weights(const float* w0, int cout0, const float* w1, int cou
   return launch_pack_conv_weights(w0, cout0, w1, cout1, Cin, KH, KW, a0, a1, b0, b1, transposed, prec, out, S(stream));
 }
 
+int craft_pack_conv_job_bytes(void) { return (int)pack_conv_job_bytes(); }
+int craft_pack_conv_job_fill(void* job, const float* w0, int cout0, const float* w1, int cout1, int Cin, int KH, int KW, int a0, int a1, int b0,
+                              int b1, int transposed, int prec, void* out) {
+  return (int)fill_pack_conv_job(job, w0, cout0, w1, cout1, Cin, KH, KW, a0, a1, b0, b1, transposed, prec, out);
+}
+int craft_pack_conv_weights_batch(const void* jobs_dev, const int* first_block_dev, int n, int total_blocks, void* stream) {
+  return launch_pack_conv_weights_batch(jobs_dev, first_block_dev, n, total_blocks, S(stream));
+}
+
 int craft_conv2d_nhwc2_mask(const float* x0, long ld0, int c0, const float* x1, long ld1, int c1, const float* w, const float* bias,
                             const float* bias_field, long ld_bf, int cout, int KH, int KW, const float* mask, long ldm, float* y, long ldy, int B,
                             int H, int W, int prec, void* stream) {

@@ -14,6 +14,7 @@
 // Each wave owns 32 output channels (NT = 1) and MT = 128 / (32 * WM) row fragments:
 //   BN = 128: WM = 1, WN = 4, MT = 4   |   BN = 64: WM = 2, WN = 2, MT = 2.
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include "conv_epilogue.hpp"
 
@@ -437,6 +438,81 @@ int launch_pack_conv_weights(const float* w0, int cout0, const float* w1, int co
   else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_pack_conv_weights<CRAFT_PREC_F16>), grid, dim3(256), 0, s, p, out);
   else if (prec == CRAFT_PREC_F16X3) hipLaunchKernelGGL((k_pack_conv_weights<CRAFT_PREC_F16X3>), grid, dim3(256), 0, s, p, out);
   else return CRAFT_ERR_UNSUPPORTED;
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// craft_pack_conv_weights_batch: n craft_pack_conv_weights jobs in ONE launch (a training step re-packs every convolution weight --
+// forward and transposed forms, 71 operands at configs[3] -- after every optimizer update; the operands' addresses are stable across
+// steps, so the descriptor table lives in DEVICE memory and is built once).  Block -> (job, local block) through a prefix table.
+// ---------------------------------------------------------------------------------------------
+struct PackConvJob { PackConvParams p; void* out; int prec; int pad_; };
+template <int PREC>
+__device__ __forceinline__ void pack_conv_block(const PackConvParams& p, void* __restrict__ out, long i) {
+  typedef typename PrecT<PREC>::lds_t h_t;
+  constexpr int PL = Planes<PREC>::N;
+  const int NB = (p.rows + 31) / 32, taps = p.KH * p.KW;
+  const long K = (long)taps * p.Cp;
+  const long total = (K / 32) * NB * 128;
+  if (i >= total) return;
+  const int lane = (int)(i & 63), kk = (int)((i >> 6) & 1);
+  const long t = i >> 7;
+  const int nbi = (int)(t % NB);
+  const long kt = t / NB;
+  const int row = nbi * 32 + (lane & 31);
+  const long k = kt * 32 + kk * 16 + (lane >> 5) * 8;
+  const int tap = (int)(k / p.Cp), c0 = (int)(k - (long)tap * p.Cp);
+  const int ky = tap / p.KW, kx = tap - ky * p.KW;
+  const int nsel = (p.a1 - p.a0) + (p.b1 - p.b0), cout = p.cout0 + p.cout1;
+  h_t* o = reinterpret_cast<h_t*>(out) + (((kt * NB + nbi) * PL) * 2 + kk) * 512 + lane * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c0 + j;
+    int co, sdx, sy, sx;
+    if (p.transposed) { co = c; sdx = row; sy = p.KH - 1 - ky; sx = p.KW - 1 - kx; }
+    else { co = row; sdx = c; sy = ky; sx = kx; }
+    float v = 0.f;
+    if (co < cout && sdx < nsel) {
+      const int ci = sdx < p.a1 - p.a0 ? p.a0 + sdx : p.b0 + (sdx - (p.a1 - p.a0));
+      const float* w = co < p.cout0 ? p.w0 + (long)co * p.Cin * taps : p.w1 + (long)(co - p.cout0) * p.Cin * taps;
+      v = w[((long)ci * p.KH + sy) * p.KW + sx];
+    }
+    const h_t h = (h_t)v;
+    o[j] = h;
+    if constexpr (PL == 2) o[1024 + j] = (h_t)(v - (float)h);
+  }
+}
+__global__ __launch_bounds__(256) void k_pack_conv_weights_batch(const PackConvJob* __restrict__ jobs, const int* __restrict__ first, int n) {
+  int lo = 0, hi = n;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)blockIdx.x >= first[mid]) lo = mid; else hi = mid; }
+  const PackConvJob& j = jobs[lo];
+  const long i = (long)(blockIdx.x - first[lo]) * 256 + threadIdx.x;
+  if (j.prec == CRAFT_PREC_F16X3) pack_conv_block<CRAFT_PREC_F16X3>(j.p, j.out, i);
+  else if (j.prec == CRAFT_PREC_F16) pack_conv_block<CRAFT_PREC_F16>(j.p, j.out, i);
+  else pack_conv_block<CRAFT_PREC_BF16>(j.p, j.out, i);
+}
+size_t pack_conv_job_bytes() { return sizeof(PackConvJob); }
+// fills one job record (HOST memory, caller copies the table to the device) and returns its block count, or a negative error code
+long fill_pack_conv_job(void* job, const float* w0, int cout0, const float* w1, int cout1, int Cin, int KH, int KW, int a0, int a1, int b0, int b1,
+                        int transposed, int prec, void* out) {
+  if (cout0 <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || cout1 < 0 || (cout1 > 0 && !w1) || !w0 || !out) return -CRAFT_ERR_ARG;
+  if (a0 < 0 || a1 < a0 || a1 > Cin || b0 < 0 || b1 < b0 || b1 > Cin) return -CRAFT_ERR_ARG;
+  if (prec != CRAFT_PREC_BF16 && prec != CRAFT_PREC_F16 && prec != CRAFT_PREC_F16X3) return -CRAFT_ERR_UNSUPPORTED;
+  PackConvJob j = {};
+  PackConvParams& p = j.p;
+  p.w0 = w0; p.w1 = w1; p.cout0 = cout0; p.cout1 = cout1; p.Cin = Cin; p.KH = KH; p.KW = KW; p.a0 = a0; p.a1 = a1; p.b0 = b0; p.b1 = b1;
+  p.transposed = transposed;
+  const int nsel = (a1 - a0) + (b1 - b0), cout = cout0 + cout1;
+  p.rows = transposed ? nsel : cout;
+  p.Cp = ((transposed ? cout : nsel) + 31) / 32 * 32;
+  j.out = out; j.prec = prec;
+  memcpy(job, &j, sizeof(j));
+  const long total = ((long)KH * KW * p.Cp / 32) * ((p.rows + 31) / 32) * 128;
+  return (total + 255) / 256;
+}
+int launch_pack_conv_weights_batch(const void* jobs_dev, const int* first_dev, int n, int total_blocks, hipStream_t s) {
+  if (n <= 0 || total_blocks <= 0) return 0;
+  hipLaunchKernelGGL(k_pack_conv_weights_batch, dim3((unsigned)total_blocks), dim3(256), 0, s, static_cast<const PackConvJob*>(jobs_dev), first_dev, n);
   return (int)hipGetLastError();
 }
 

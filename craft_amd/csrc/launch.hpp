@@ -81,6 +81,10 @@ int launch_wgrad_pk(const void* const* dYp, const void* const* Xp, const void* c
                     int cin, long guard, long K, int KH, int KW, int Wp, float* dW, int prec, int prec_x, hipStream_t s);
 int launch_pack_conv_weights(const float* w0, int cout0, const float* w1, int cout1, int Cin, int KH, int KW, int a0, int a1, int b0, int b1,
                              int transposed, int prec, void* out, hipStream_t s);
+size_t pack_conv_job_bytes();
+long fill_pack_conv_job(void* job, const float* w0, int cout0, const float* w1, int cout1, int Cin, int KH, int KW, int a0, int a1, int b0, int b1,
+                        int transposed, int prec, void* out);
+int launch_pack_conv_weights_batch(const void* jobs_dev, const int* first_dev, int n, int total_blocks, hipStream_t s);
 int launch_relpos_add(float* S, long ld, int BZ, int H8, int W8, const float* Hs, long ldh, const float* Ws, long ldw, float w, hipStream_t s);
 int launch_relpos_bwd(const float* dS, long ld, int BZ, int H8, int W8, float* dHs, long ldh, int nh, float* dWs, long ldw, int nw, float w,
                       hipStream_t s);

@@ -75,6 +75,7 @@ _SIGS = {
     "craft_flow_metrics": [P, P, P, I, I, I, F, F, F, P, P],
     "craft_flow_l1_loss": [P, P, P, I, I, I, F, F, P, P, P],
     "craft_sumsq": [P, L, P, P],
+    "craft_pack_conv_weights_batch": [P, P, I, I, P],
     "craft_multi_copy": [P, P, P, I, P, P],
     "craft_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, F, P, F, P],
     "craft_loss_scale_update": [P, P, F, F, F, F, F, F, I, P],
@@ -128,7 +129,7 @@ _SIGS = {
 
 
 # host-side helpers of the library (no stream argument, host pointers): bound where they are used
-HOST_FUNCTIONS = {"craft_png_unfilter"}
+HOST_FUNCTIONS = {"craft_png_unfilter", "craft_pack_conv_job_bytes", "craft_pack_conv_job_fill"}
 
 # Named policies.  "mixed" is the default for mixed_precision=True: split-fp16 (F16X3: fp32 operands as hi + lo fp16 planes,
 # 3 fp16 MFMAs per product, fp32 accumulate -- fp32-class results) for the projections, Q K^T and every convolution, and

@@ -443,6 +443,68 @@ def pack_conv(w: torch.Tensor) -> torch.Tensor:
     return w.detach().permute(0, 2, 3, 1).contiguous().float()
 
 
+class WeightPackRegistry:
+    """Every conv-weight operand a training step packs (``pack_conv_weights``), remembered so that the NEXT steps re-pack all of them in ONE
+    launch right after the optimizer update (craft_pack_conv_weights_batch) instead of one launch per operand as the forward / backward
+    reach them (71 at configs[3]).  Owned by a ``train.Trainer``: it is the active registry only inside that trainer's steps, its entries
+    hold the weight tensors (views of the optimizer's flat buffer: addresses are stable), and ``repack()`` is called by the trainer after
+    ``optimizer.step()``.  An operand asked for while the registry is not fresh (first step, after a checkpoint load: ``invalidate``) is
+    packed on the spot, as before."""
+
+    def __init__(self, storage_ptr: Optional[int] = None):
+        self.storage_ptr = storage_ptr      # only operands of weights that live in THIS storage (the optimizer's flat buffer) are remembered:
+                                            # a temporary (torch.cat of two weights, a folded BatchNorm) has a new address every step
+        self.entries = {}           # key -> [out tensor, (w0, w1) kept alive, fill arguments]
+        self.fresh = False          # the outputs hold the CURRENT weights
+        self._tables = None         # (jobs device tensor, prefix device tensor, n, blocks) for the current entry set
+        self._epoch = None
+
+    def invalidate(self):
+        self.fresh = False
+
+    def lookup(self, key):
+        if self.fresh and self._epoch == hip.weights_epoch():
+            e = self.entries.get(key)
+            return e[0] if e is not None else None
+        return None
+
+    def remember(self, key, out, w0, w1, fill_args):
+        if key not in self.entries:
+            self._tables = None
+        self.entries[key] = [out, (w0, w1), fill_args]
+
+    def repack(self):
+        """All remembered operands from the current weights, one launch (enqueued on the current stream)."""
+        if not self.entries:
+            return
+        import ctypes
+        lib = hip.load()
+        if self._tables is None:
+            nbytes = int(lib.craft_pack_conv_job_bytes())
+            n = len(self.entries)
+            buf = (ctypes.c_ubyte * (nbytes * n))()
+            first, blocks = [0], 0
+            for i, (out, (w0, w1), fa) in enumerate(self.entries.values()):
+                cout0, cout1, Cin, KH, KW, a0, a1, b0, b1, transposed, prec = fa
+                nb = int(lib.craft_pack_conv_job_fill(ctypes.byref(buf, i * nbytes), ctypes.c_void_p(w0.data_ptr()), cout0,
+                                                      ctypes.c_void_p(w1.data_ptr() if w1 is not None else 0), cout1, Cin, KH, KW, a0, a1, b0, b1,
+                                                      transposed, prec, ctypes.c_void_p(out.data_ptr())))
+                if nb < 0:
+                    raise hip.CraftHipError(f"craft_pack_conv_job_fill failed with code {-nb}")
+                blocks += nb
+                first.append(blocks)
+            dev = next(iter(self.entries.values()))[0].device
+            jobs = torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(dev)
+            pref = torch.tensor(first, dtype=torch.int32).to(dev)
+            self._tables = (jobs, pref, n, blocks)
+        jobs, pref, n, blocks = self._tables
+        call("craft_pack_conv_weights_batch", jobs, pref, n, blocks)
+        self.fresh, self._epoch = True, hip.weights_epoch()
+
+
+ACTIVE_WEIGHT_PACKS = [None]        # the registry of the trainer whose step is running (train.Trainer.step), else None
+
+
 def pack_conv_weights(w0: torch.Tensor, prec: int, w1: Optional[torch.Tensor] = None, sel=None, transposed: bool = False) -> torch.Tensor:
     """nn.Conv2d weights [Cout, Cin, KH, KW] (w0 and optionally w1 concatenated along Cout) -> the MFMA fragment-order operand of the
     conv kernels in ONE launch (craft_pack_conv_weights): input channels ``sel`` = ((a0, a1), (b0, b1)) or None (all); ``transposed``:
@@ -460,8 +522,24 @@ def pack_conv_weights(w0: torch.Tensor, prec: int, w1: Optional[torch.Tensor] = 
     nsel, cout = (a1 - a0) + (b1 - b0), cout0 + cout1
     rows, Cp = (nsel, round_up(cout, 32)) if transposed else (cout, round_up(nsel, 32))
     planes = 2 if prec == hip.PREC_F16X3 else 1
-    out = torch.empty(planes * round_up(rows, 32) * KH * KW * Cp, device=w0.device, dtype=torch.bfloat16 if prec == hip.PREC_BF16 else torch.float16)
+    reg = ACTIVE_WEIGHT_PACKS[0]
+    key = None
+    if (reg is not None and w0.dtype == torch.float32 and (w1 is None or w1.dtype == torch.float32) and w0.is_cuda
+            and (reg.storage_ptr is None or (w0.untyped_storage().data_ptr() == reg.storage_ptr
+                                             and (w1 is None or w1.untyped_storage().data_ptr() == reg.storage_ptr)))):
+        key = (w0.data_ptr(), w1.data_ptr() if w1 is not None else 0, cout0, cout1, Cin, KH, KW, a0, a1, b0, b1, bool(transposed), prec)
+        hit = reg.lookup(key)
+        if hit is not None:
+            return hit                                       # packed by the trainer's batched launch after the last optimizer update
+        e = reg.entries.get(key)
+        out = e[0] if e is not None else None                # (same buffer every step: the batch job's output address is fixed)
+    else:
+        out = None
+    if out is None:
+        out = torch.empty(planes * round_up(rows, 32) * KH * KW * Cp, device=w0.device, dtype=torch.bfloat16 if prec == hip.PREC_BF16 else torch.float16)
     call("craft_pack_conv_weights", w0.float() if w0.dtype != torch.float32 else w0, cout0, w1, cout1, Cin, KH, KW, a0, a1, b0, b1, int(transposed), prec, out)
+    if key is not None:
+        reg.remember(key, out, w0, w1, (cout0, cout1, Cin, KH, KW, a0, a1, b0, b1, int(transposed), prec))
     return out
 
 

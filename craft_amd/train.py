@@ -411,6 +411,9 @@ class Trainer:
         self.reference_loss_scaling = reference_loss_scaling
         self.total_steps = 0
         self._seed = None                   # the loss scale (0-dim device tensor) the last step's backward ran under; None before the first step
+        from .ops import WeightPackRegistry
+        # conv-weight operands (forward and transposed forms): ONE re-pack launch per step, right behind the optimizer update
+        self._weight_packs = None if os.environ.get("CRAFT_NO_PACK_REGISTRY") else WeightPackRegistry(self.optimizer.flat.untyped_storage().data_ptr())
         self._ar_events = []                # (start, end) HIP events around the gradient all-reduce of recent steps
         self._scale_set = False             # "auto" needs the loss' element count: the scaler is armed on the first step
         if loss_scale != "auto":
@@ -472,6 +475,14 @@ class Trainer:
         direct = not os.environ.get("CRAFT_TRAINER_BACKWARD")        # (developer A/B: 1 = zero_grad() + loss.backward() as before round 4)
         if not direct:
             opt.zero_grad()
+        from . import ops as _ops
+        _ops.ACTIVE_WEIGHT_PACKS[0] = self._weight_packs if image1.is_cuda else None
+        try:
+            return self._step_body(model, opt, seq_loss, image1, image2, flow, valid, direct, dev)
+        finally:
+            _ops.ACTIVE_WEIGHT_PACKS[0] = None
+
+    def _step_body(self, model, opt, seq_loss, image1, image2, flow, valid, direct, dev):
         preds = model(image1, image2, iters=self.iters)
         loss, metrics = seq_loss(preds, flow, valid, self.gamma)
         if not self._scale_set:            # "auto": start from auto_loss_scale and let GradScaler's rule move it (train.py:215)
@@ -499,6 +510,8 @@ class Trainer:
             mul = mul / self._world()
         # (the flat gradient buffer holds loss_scale x the gradient: un-scaled on the device, craft_loss_scale_update)
         opt.step(lr=self.scheduler.get_last_lr()[0], max_norm=self.clip, grad_mul=mul)
+        if self._weight_packs is not None and image1.is_cuda:
+            self._weight_packs.repack()                                # every conv-weight operand of the next step, one launch (71 before)
         self.scheduler.step()
         self.total_steps += 1
         if self.total_steps == 2:

@@ -238,6 +238,15 @@ int craft_conv2d_nhwc(const float* x, long ldx, int cin, const float* w, const f
  * taps flipped): W'[ci][KH-1-ky][KW-1-kx][co] = W[co][ci][ky][kx].  out: planes * round_up(rows, 32) * K 16-bit elements. */
 int craft_pack_conv_weights(const float* w0, int cout0, const float* w1, int cout1, int Cin, int KH, int KW, int a0, int a1, int b0, int b1,
                             int transposed, int prec, void* out, void* stream);
+/* The same re-layout for MANY weights in one launch (round 5): a training step re-packs every convolution weight -- forward and
+ * transposed forms -- after each optimizer update (what `optimizer.step()` + the next forward's cuDNN filter transforms are in the
+ * reference, train.py:231-236).  The job table lives in device memory: craft_pack_conv_job_fill writes one record (craft_pack_conv_job_bytes
+ * each) into HOST memory and returns the job's block count (< 0: -error); the caller copies the records and the exclusive prefix sums
+ * of the block counts (n + 1 ints) to the device once and calls craft_pack_conv_weights_batch after every update. */
+int craft_pack_conv_job_bytes(void);
+int craft_pack_conv_job_fill(void* job, const float* w0, int cout0, const float* w1, int cout1, int Cin, int KH, int KW, int a0, int a1, int b0,
+                             int b1, int transposed, int prec, void* out);
+int craft_pack_conv_weights_batch(const void* jobs_dev, const int* first_block_dev, int n, int total_blocks, void* stream);
 /* craft_conv2d_nhwc over the virtual channel concatenation [x0 (c0 channels, row stride ld0) | x1 (c1, ld1)] (c1 = 0: x0 alone):
  * the conv input of SepConvGRU's q gate, cat([r*h, x]) (update.py:54, :61), without materialising the cat.  c0, c1 multiples of 32.
  * Exactly one of bias [cout] / bias_field [B*H*W][ld_bf] (a per-pixel bias: the hoisted, iteration-invariant share of a convolution,
