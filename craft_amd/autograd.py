@@ -1157,11 +1157,25 @@ class SequenceLoss(Function):
         return (None, None, None, None) + tuple(grads)
 
 
-def sequence_loss(flow_preds, flow_gt, valid, gamma: float = 0.8, max_flow: float = 400.0):
-    """Differentiable loss (0-dim tensor) and the metrics dict of train.py:63-71 (computed on the device)."""
+class DeferredMetrics:
+    """The metrics of train.py:63-71 accumulated on the device; ``resolve()`` reads them back (a host synchronisation)."""
+
+    def __init__(self, m):
+        self.m = m
+
+    def resolve(self):
+        r = self.m.result()
+        return {"epe": r["epe"], "1px": r["px1"], "3px": r["px3"], "5px": r["px5"]}
+
+
+def sequence_loss(flow_preds, flow_gt, valid, gamma: float = 0.8, max_flow: float = 400.0, defer_metrics: bool = False):
+    """Differentiable loss (0-dim tensor) and the metrics dict of train.py:63-71 (computed on the device).  ``defer_metrics``: return a
+    DeferredMetrics instead of the dict -- reading the metrics back right here drains the device queue between the forward and the
+    backward pass (train.Trainer.step resolves them at the end of the step, together with the loss)."""
     from .evaluate import FlowMetrics
     loss = SequenceLoss.apply(flow_gt, valid, gamma, max_flow, *flow_preds)
     m = FlowMetrics(flow_preds[-1].device, max_mag=max_flow)
     m.update(flow_preds[-1].detach(), flow_gt, valid)
-    r = m.result()
-    return loss, {"epe": r["epe"], "1px": r["px1"], "3px": r["px3"], "5px": r["px5"]}
+    if defer_metrics:
+        return loss, DeferredMetrics(m)
+    return loss, DeferredMetrics(m).resolve()

@@ -484,7 +484,10 @@ class Trainer:
 
     def _step_body(self, model, opt, seq_loss, image1, image2, flow, valid, direct, dev):
         preds = model(image1, image2, iters=self.iters)
-        loss, metrics = seq_loss(preds, flow, valid, self.gamma)
+        loss, metrics = seq_loss(preds, flow, valid, self.gamma, defer_metrics=True)     # (read back at the end of the step: no sync in front of the backward)
+        if os.environ.get("CRAFT_SYNC_METRICS"):           # developer A/B: the read-back between forward and backward, as before round 5
+            r_ = metrics.resolve()
+            metrics.resolve = lambda: r_
         if not self._scale_set:            # "auto": start from auto_loss_scale and let GradScaler's rule move it (train.py:215)
             opt.set_loss_scale(auto_loss_scale(flow.numel()), dynamic=True)
             self._scale_set = True
@@ -521,7 +524,7 @@ class Trainer:
             import gc
             gc.collect()
             gc.freeze()
-        metrics = dict(metrics, loss=float(loss.detach()))
+        metrics = dict(metrics.resolve(), loss=float(loss.detach()))
         metrics["loss_rank"] = metrics["loss"]        # this rank's own loss ("loss" / "epe" become the mean over the ranks below)
         snap = opt.scaler_snapshot()       # (float(loss) above drained the stream: this is the step just taken)
         if snap is not None:
