@@ -73,8 +73,8 @@ class TransCorrBlock(CorrBlock, nn.Module):
         H8, W8 = hw
         B = x1_ln.shape[0]
         st = self.setrans
-        q = ops.linear(x1_ln, st.query.weight, st.query.bias, prec)
-        k = ops.linear(x2_ln, st.key.weight, st.key.bias, prec)
+        q = ops.linear(x1_ln, st.query.weight, st.query.bias, prec, packed=ops.linear_pack(st, "query", st.query.weight, prec))
+        k = ops.linear(x2_ln, st.key.weight, st.key.bias, prec, packed=ops.linear_pack(st, "key", st.key.weight, prec))
         scale = 1.0 / math.sqrt(st.attention_mode_dim)
         mx = ops.score_max(q, k, H8, W8, st.num_modes, scale, prec)
         while len(self.pyramids) <= slot:

@@ -57,7 +57,8 @@ int craft_linear(const float* x, long ldx, const float* w, const float* bias, fl
   p.A = x; p.lda = ldx; p.B = w; p.ldb = cin; p.C = y; p.ldc = ldy;
   p.zdiv = 1; p.batch = 1; p.M = (int)rows; p.N = cout; p.K = cin;
   p.bias = bias; p.scale = 1.f; p.act = CRAFT_ACT_NONE;
-  return launch_gemm_rows(p, prec, false, S(stream));
+  p.b_packed = ((prec >> 8) & 1) && (prec & 0xff) != CRAFT_PREC_F32;          // prec | CRAFT_W_PACKED: w from craft_pack_weights(rows cout, K round_up(cin, 32))
+  return launch_gemm_rows(p, prec & 0xff, false, S(stream));
 }
 
 int craft_linear_t(const float* x, long ldx, const float* w, void* yT, long ldt, int B, int N, int cin, int cout,
@@ -82,7 +83,9 @@ int craft_linear_t(const float* x, long ldx, const float* w, void* yT, long ldt,
     p.A = w; p.lda = cin; p.B = x; p.ldb = ldx; p.b_bs0 = (long)N * ldx; p.C = yT; p.ldc = ldt; p.c_bs0 = (long)cout * ldt;
     p.M = cout; p.N = N;
   }
-  return launch_gemm_rows(p, prec, false, S(stream));
+  p.b_packed = ((prec >> 8) & 1) && (prec & 0xff) != CRAFT_PREC_F32;
+  if (p.b_packed && !frag_rows) return CRAFT_ERR_UNSUPPORTED;                 // (the un-fragmented form has the weights as the A operand)
+  return launch_gemm_rows(p, prec & 0xff, false, S(stream));
 }
 
 static ScoreParams make_score(const float* q, long ldq, const float* k, long ldk, int B, int H8, int W8, int M, int d,
@@ -227,6 +230,7 @@ int craft_motion_encoder(const float* corr, long ldc, int cor_planes, const floa
     RowsGemmParams p = {};
     p.A = corr; p.lda = ldc; p.B = wc1; p.ldb = cor_planes; p.C = cor1; p.ldc = 256;
     p.zdiv = 1; p.batch = 1; p.M = (int)npix; p.N = 256; p.K = cor_planes; p.bias = bc1; p.scale = 1.f; p.act = CRAFT_ACT_RELU;
+    p.b_packed = (prec & CRAFT_W1X1_PACKED) != 0 && PREC_OF(prec) != CRAFT_PREC_F32;     // wc1 from craft_pack_weights(256, round_up(cor_planes, 32))
     TRY(launch_gemm_rows(p, PREC_OF(prec), false, s));
   }
   const int pk = PACKED_OF(prec);

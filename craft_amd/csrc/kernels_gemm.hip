@@ -7,31 +7,10 @@
 
 namespace craft {
 
-// ---------------------------------------------------------------------------------------------
-// rows GEMM:  C[z][m, n] = act(scale * sum_k A[z][m,k] B[z][n,k] + bias[n])
-// ---------------------------------------------------------------------------------------------
-template <int PREC, int BN, bool A16>
-__global__ __launch_bounds__(NTHREADS) void k_gemm_rows(RowsGemmParams p) {
-  constexpr int BM = 128, WM = 2, WN = 2, MT = BM / WM / 32, NT = BN / WN / 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
-  const int z0 = z / p.zdiv, z1 = z - z0 * p.zdiv;
-  f32x16 acc[MT][NT];
-  acc_zero(acc);
-  LoaderRowsF32<BN> lb;
-  lb.init(reinterpret_cast<const float*>(p.B) + z0 * p.b_bs0 + z1 * p.b_bs1, p.ldb, n0, p.N, p.K, tid);
-  const int nk = (p.K + BK - 1) / BK;
-  if constexpr (A16) {
-    LoaderRowsH16<BM> la;
-    la.init(reinterpret_cast<const uint16_t*>(p.A) + z0 * p.a_bs0 + z1 * p.a_bs1, p.lda, m0, p.M, p.K, tid);
-    gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, acc, NoFold());
-  } else {
-    LoaderRowsF32<BM> la;
-    la.init(reinterpret_cast<const float*>(p.A) + z0 * p.a_bs0 + z1 * p.a_bs1, p.lda, m0, p.M, p.K, tid);
-    gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, acc, NoFold());
-  }
+// Store epilogue of a rows-GEMM wave tile (acc[MT][NT], rows rb.., columns cb..) -- shared by k_gemm_rows and k_gemm_rows_wf.
+template <int MT, int NT>
+__device__ __forceinline__ void rows_epilogue(const RowsGemmParams& p, const f32x16 (&acc)[MT][NT], int rb, int cb, int z, int z0, int z1, int lane) {
   const long cbase = z0 * p.c_bs0 + z1 * p.c_bs1;
-  const int rb = m0 + (wave / WN) * (BM / WM), cb = n0 + (wave % WN) * (BN / WN);
   // Epilogue in quads of 4 consecutive rows (the accumulator layout).  Everything that does not depend on the element is decided ONCE
   // outside the loops -- element type / layout, the deferred row divisor, and whether the wave's tile lies inside the matrix (no bounds
   // tests then): with the per-element forms (`p.row_div ? .. : ..`, `row0 + i < M`) hipcc branched around loads 64 times per lane and
@@ -105,6 +84,164 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_rows(RowsGemmParams p) {
   if (p.c_dtype == CRAFT_PREC_F32) pick_rd(T32(), std::false_type());
   else if (p.c_dtype == CRAFT_PREC_BF16) { if (p.c_frag) pick_rd(TBF(), std::true_type()); else pick_rd(TBF(), std::false_type()); }
   else { if (p.c_frag) pick_rd(TF16(), std::true_type()); else pick_rd(TF16(), std::false_type()); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rows GEMM:  C[z][m, n] = act(scale * sum_k A[z][m,k] B[z][n,k] + bias[n])
+// ---------------------------------------------------------------------------------------------
+template <int PREC, int BN, bool A16>
+__global__ __launch_bounds__(NTHREADS) void k_gemm_rows(RowsGemmParams p) {
+  constexpr int BM = 128, WM = 2, WN = 2, MT = BM / WM / 32, NT = BN / WN / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
+  const int z0 = z / p.zdiv, z1 = z - z0 * p.zdiv;
+  f32x16 acc[MT][NT];
+  acc_zero(acc);
+  LoaderRowsF32<BN> lb;
+  lb.init(reinterpret_cast<const float*>(p.B) + z0 * p.b_bs0 + z1 * p.b_bs1, p.ldb, n0, p.N, p.K, tid);
+  const int nk = (p.K + BK - 1) / BK;
+  if constexpr (A16) {
+    LoaderRowsH16<BM> la;
+    la.init(reinterpret_cast<const uint16_t*>(p.A) + z0 * p.a_bs0 + z1 * p.a_bs1, p.lda, m0, p.M, p.K, tid);
+    gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, acc, NoFold());
+  } else {
+    LoaderRowsF32<BM> la;
+    la.init(reinterpret_cast<const float*>(p.A) + z0 * p.a_bs0 + z1 * p.a_bs1, p.lda, m0, p.M, p.K, tid);
+    gemm_mainloop<PREC, BM, BN, WM, WN>(la, lb, nk, acc, NoFold());
+  }
+  const int rb = m0 + (wave / WN) * (BM / WM), cb = n0 + (wave % WN) * (BN / WN);
+  rows_epilogue<MT, NT>(p, acc, rb, cb, z, z0, z1, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gemm_rows_wf (round 5): the rows GEMM with the WEIGHT operand pre-packed in MFMA fragment order (craft_pack_weights: [K/32][N/32]
+// [plane][k-half][lane][8], K padded to a multiple of 32 with zeros) -- nn.Linear / 1x1-convolution products with short K (128 .. 352:
+// the V^T projection of the motion aggregator, convc1 of the motion encoder, the q / k projections).  k_gemm_rows stages BOTH operands
+// through LDS per 32-wide K-tile (fp32 -> planes conversion of the weights in every block, 24 MFMAs per wave between barriers: PMC
+// round 5: matrix pipe 10 - 31 % busy, 12 VALU per MFMA).  Here:
+//   * weights: one coalesced 1 KiB load per MFMA operand from L2 straight into registers (the k_conv_halo_wf idiom), requested a
+//     K-chunk ahead; never converted, never in LDS;
+//   * activations: fp32 rows -> hi / lo fp16 planes in LDS per 64-wide K chunk (double buffer, ONE barrier per chunk = 48 MFMAs per
+//     wave), the next chunk's rows requested before this chunk's MFMAs;
+//   * a wave owns all 128 rows x 32 columns (MT = 4): 12 MFMAs per 8 LDS reads + 2 weight loads per k-half.
+// Epilogue: rows_epilogue (row-major fp32 / 16-bit, MFMA fragment order for V^T, bias, ReLU, deferred row divisor).
+// ---------------------------------------------------------------------------------------------
+template <int PREC>
+__global__ __launch_bounds__(NTHREADS) void k_gemm_rows_wf(RowsGemmParams p) {
+  typedef typename PrecT<PREC>::lds_t lds_t;
+  typedef typename FragT<PREC>::t frag_t;
+  constexpr int PL = Planes<PREC>::N;
+  constexpr int BM = 128, MT = 4, BN = 128, KC = 64, LD = KC + 8;
+  constexpr int NP = BM / 16;                           // float4 per thread and chunk: thread -> (row r0 + 16 i, floats c4*4 .. +3)
+  constexpr int A_ELEMS = PL * BM * LD;
+  __shared__ __attribute__((aligned(16))) lds_t As[2 * A_ELEMS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
+  const int z0 = z / p.zdiv, z1 = z - z0 * p.zdiv;
+  const int K = p.K, nkt = (K + 31) / 32, nch = (nkt + 1) / 2;
+  const int c4 = tid & 15, r0 = tid >> 4;
+  const float* arow[NP];
+  {
+    const float* A = reinterpret_cast<const float*>(p.A) + z0 * p.a_bs0 + z1 * p.a_bs1;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) arow[i] = A + (long)min(m0 + r0 + 16 * i, p.M - 1) * p.lda;      // clamped: unconditional loads
+  }
+  float4 ra[NP];
+  auto fetch_a = [&](int ch, bool& zero) __attribute__((always_inline)) {
+    const int k = ch * KC + c4 * 4;
+    zero = k >= K;                                     // (K % 4 == 0: a float4 is in or out as a whole)
+    const int kc = zero ? K - 4 : k;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) ra[i] = *reinterpret_cast<const float4*>(arow[i] + kc);
+  };
+  auto store_a = [&](int buf, bool zero) __attribute__((always_inline)) {
+    lds_t* A0 = &As[buf * A_ELEMS];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int row = r0 + 16 * i;
+      float4 v = ra[i];
+      v.x = zero ? 0.f : v.x; v.y = zero ? 0.f : v.y; v.z = zero ? 0.f : v.z; v.w = zero ? 0.f : v.w;
+      if constexpr (PREC == CRAFT_PREC_F16X3) {
+        f16x4 h, l;
+        split_f16x3(v, h, l);
+        *reinterpret_cast<f16x4*>(&A0[row * LD + c4 * 4]) = h;
+        *reinterpret_cast<f16x4*>(&A0[(BM + row) * LD + c4 * 4]) = l;
+      } else if constexpr (PREC == CRAFT_PREC_BF16) {
+        bf16x4 h;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(&A0[row * LD + c4 * 4]) = h;
+      } else {
+        f16x4 h;
+        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+        *reinterpret_cast<f16x4*>(&A0[row * LD + c4 * 4]) = h;
+      }
+    }
+  };
+  // weight fragments of this wave's 32 columns: [kt][nb][pl][kk][lane][8]; a column block beyond N re-reads the last one (discarded)
+  const int NBtot = (p.N + 31) / 32;
+  const int nb = min(n0 / 32 + wave, NBtot - 1);
+  const uint16_t* wb = reinterpret_cast<const uint16_t*>(p.B) + (z0 * p.b_bs0 + z1 * p.b_bs1) + (long)nb * (PL * 1024) + lane * 8;
+  const long kt_stride = (long)NBtot * (PL * 1024);
+  frag_t bq[PL][4];                                    // the four k-halves of one chunk
+  auto fetch_b = [&](int ch) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int kt = min(2 * ch + (h >> 1), nkt - 1);   // (a missing second K-tile of the last chunk meets zeroed activations)
+      const uint16_t* q = wb + kt * kt_stride + (h & 1) * 512;
+#pragma unroll
+      for (int pl = 0; pl < PL; ++pl) bq[pl][h] = *reinterpret_cast<const frag_t*>(q + pl * 1024);
+    }
+  };
+  f32x16 acc[MT][1];
+  acc_zero(acc);
+  const int r = lane & 31, g8 = (lane >> 5) * 8;
+  bool zero;
+  fetch_a(0, zero);
+  fetch_b(0);
+  store_a(0, zero);
+  if (nch > 1) fetch_a(1, zero);
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    const lds_t* A0 = &As[(ch & 1) * A_ELEMS];
+    frag_t bc[PL][4];
+#pragma unroll
+    for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+      for (int h = 0; h < 4; ++h) bc[pl][h] = bq[pl][h];
+    if (ch + 1 < nch) fetch_b(ch + 1);                  // (lands behind this chunk's 48 MFMAs)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      frag_t ah[MT], al[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        ah[mt] = *reinterpret_cast<const frag_t*>(&A0[(mt * 32 + r) * LD + h * 16 + g8]);
+        if constexpr (PL == 2) al[mt] = *reinterpret_cast<const frag_t*>(&A0[(BM + mt * 32 + r) * LD + h * 16 + g8]);
+      }
+      if constexpr (PL == 2) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(al[mt], bc[0][h], acc[mt][0]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(ah[mt], bc[1][h], acc[mt][0]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt][0] = mfma16<PREC>(ah[mt], bc[0][h], acc[mt][0]);
+      if (h == 1 && ch + 1 < nch) {                     // publish the next chunk into the idle buffer, request the one after it
+        store_a((ch + 1) & 1, zero);
+        if (ch + 2 < nch) fetch_a(ch + 2, zero);
+      }
+    }
+    __syncthreads();
+  }
+  rows_epilogue<MT, 1>(p, acc, m0, n0 + wave * 32, z, z0, z1, lane);
+}
+
+static int launch_rows_wf(const RowsGemmParams& p, int prec, hipStream_t s) {
+  dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, p.batch);
+  if (prec == CRAFT_PREC_F16X3) hipLaunchKernelGGL((k_gemm_rows_wf<CRAFT_PREC_F16X3>), grid, dim3(NTHREADS), 0, s, p);
+  else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_gemm_rows_wf<CRAFT_PREC_F16>), grid, dim3(NTHREADS), 0, s, p);
+  else if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_gemm_rows_wf<CRAFT_PREC_BF16>), grid, dim3(NTHREADS), 0, s, p);
+  else return CRAFT_ERR_UNSUPPORTED;
+  return (int)hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -285,6 +422,10 @@ int launch_gemm_rows(const RowsGemmParams& p, int prec, bool a16, hipStream_t s)
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return 0;
   if (p.act != CRAFT_ACT_NONE && p.act != CRAFT_ACT_RELU) return CRAFT_ERR_UNSUPPORTED;
   if (p.c_frag && (p.c_dtype == CRAFT_PREC_F32 || p.c_frag % 32 || p.N % p.c_frag || p.ldc % 16)) return CRAFT_ERR_ALIGN;
+  if (p.b_packed) {          // weights from craft_pack_weights (K padded to 32): k_gemm_rows_wf
+    if (a16 || prec == CRAFT_PREC_F32 || (p.K & 3) || (p.lda & 3) || p.zdiv != 1 || p.b_bs0 || p.b_bs1) return CRAFT_ERR_UNSUPPORTED;
+    return launch_rows_wf(p, prec, s);
+  }
   if ((p.K & 3) || (p.lda & 3) || (p.ldb & 3)) return CRAFT_ERR_ALIGN;
   if (a16 && ((p.K & 7) || (p.lda & 7) || (prec != CRAFT_PREC_BF16 && prec != CRAFT_PREC_F16))) return CRAFT_ERR_ALIGN;
   const int bn = pick_bn(p.N);

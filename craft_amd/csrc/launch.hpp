@@ -31,6 +31,7 @@ struct RowsGemmParams {
   int c_frag;            // > 0: C (16-bit) is stored in MFMA B-fragment order per group of c_frag rows (k_pv16's V^T operand)
   int c_frag_acc;        // with c_frag: the 16 rows (keys) of a k-group are enumerated in MFMA ACCUMULATOR order
                          // (position 8*h + j <-> key 8*(j >> 2) + 4*h + (j & 3)): k_flash_attn's V^T operand
+  int b_packed;          // B (the weight operand) is craft_pack_weights' fragment order for `prec`, K padded to 32: k_gemm_rows_wf
   int a_tiled;           // k_pv16: A (= P) in 32-row x 64-key tiles (CRAFT_P_TILED): element (i, j) at
                          // ((i >> 5) * 32 * lda) + (j >> 6) * 2048 + (i & 31) * 64 + (j & 63); K = lda is a multiple of 64, ldb = V^T's key extent
 };

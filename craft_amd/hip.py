@@ -16,6 +16,7 @@ ABI_VERSION = 3          # == CRAFT_HIP_ABI_VERSION (include/craft_hip.h): bumpe
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 W_PACKED = 0x100
+W1X1_PACKED = 0x800           # == CRAFT_W1X1_PACKED: craft_motion_encoder's convc1 weights from ops.pack_linear_weight
 CONV_W16 = 0x400              # == CRAFT_CONV_W16: hi plane of the packed weights only (input-gradient convolutions, role wgx)
 
 

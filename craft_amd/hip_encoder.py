@@ -19,6 +19,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -87,6 +89,7 @@ class HipEncoder:
                     packs.append(d)
                 self._final = (self.enc.conv2.weight.detach().float().view(self.enc.conv2.out_channels, -1).contiguous(),
                                self.enc.conv2.bias.detach().float().contiguous())
+                self._final_pk = {}                     # proj precision -> ops.pack_linear_weight of the final 1x1
                 w0, b0 = _fold_bn(self.enc.conv1, self.enc.norm1 if bn else None)
                 self._stem = (w0.permute(2, 3, 1, 0).reshape(147, 64).contiguous(), b0.contiguous())
                 self._stem_mfma = None
@@ -185,4 +188,10 @@ class HipEncoder:
                      out.stride(1), B, hw1[0], hw1[1], cp | (W_PACKED if p2.packed else 0))
             t, hw = out, hw1
         wf, bf = self._final
-        return ops.linear(t, wf, bf, prec)
+        pp = pick(prec, "proj")
+        pkd = None
+        if pp != PREC_F32 and not os.environ.get("CRAFT_NO_LINEAR_PACK"):
+            pkd = self._final_pk.get(pp)
+            if pkd is None:
+                pkd = self._final_pk[pp] = ops.pack_linear_weight(wf, pp)
+        return ops.linear(t, wf, bf, prec, packed=pkd)

@@ -85,21 +85,58 @@ def tokens_to_nchw(t: torch.Tensor, H: int, W: int) -> torch.Tensor:
     return out
 
 
+def pack_linear_weight(w: torch.Tensor, prec: int) -> torch.Tensor:
+    """[Cout, Cin] fp32 -> craft_pack_weights' MFMA fragment order with Cin padded to a multiple of 32 by zero columns: the weight
+    operand craft_linear / craft_linear_t / craft_motion_encoder's convc1 take with CRAFT_W_PACKED / CRAFT_W1X1_PACKED (bf16 / fp16 /
+    f16x3)."""
+    cout, cin = w.shape
+    Kp = round_up(cin, 32)
+    m = w.detach().float()
+    if Kp != cin:
+        m = torch.cat([m, torch.zeros(cout, Kp - cin, device=w.device)], dim=1)
+    m = m.contiguous()
+    planes = 2 if prec == hip.PREC_F16X3 else 1
+    out = torch.empty(planes * round_up(cout, 32) * Kp, device=w.device, dtype=torch.bfloat16 if prec == hip.PREC_BF16 else torch.float16)
+    call("craft_pack_weights", m, cout, Kp, prec, out)
+    return out
+
+
+def linear_pack(owner, name: str, w: torch.Tensor, prec: int) -> Optional[torch.Tensor]:
+    """The packed copy of the nn.Linear / 1x1-conv weight ``w`` (2-D view) for the ``proj`` role of ``prec``, cached on the module
+    ``owner`` under ``name`` and rebuilt when the parameter is updated in place or replaced; None when the product runs in fp32, under
+    autograd (a training step re-packs through its own registry) or with CRAFT_NO_LINEAR_PACK (A/B switch)."""
+    pp = pick(prec, "proj")
+    if pp == PREC_F32 or not w.is_cuda or torch.is_grad_enabled() and w.requires_grad or os.environ.get("CRAFT_NO_LINEAR_PACK"):
+        return None
+    cache = owner.__dict__.setdefault("_linear_packs", {})
+    key = (pp, hip.weights_epoch(), w.data_ptr(), w._version, w.device, tuple(w.shape))
+    e = cache.get(name)
+    if e is None or e[0] != key:
+        with torch.no_grad():
+            e = cache[name] = (key, pack_linear_weight(w, pp))
+        torch.cuda.current_stream().synchronize()       # (once per weight update; the copy may be consumed on other HIP streams)
+    return e[1]
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], prec: int,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """nn.Linear on tokens: [B, N, Cin] x [Cout, Cin]^T (+bias) -> [B, N, Cout]."""
+           out: Optional[torch.Tensor] = None, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Linear on tokens: [B, N, Cin] x [Cout, Cin]^T (+bias) -> [B, N, Cout].  ``packed``: ``linear_pack`` of the same weight (the
+    product then reads the weights in MFMA fragment order, k_gemm_rows_wf)."""
     B, N, Cin = x.shape
     _check_rows(x)
     Cout = w.shape[0]
     if out is None:
         out = torch.empty(B, N, Cout, device=x.device, dtype=torch.float32)
     _check_rows(out)
-    call("craft_linear", x, _ld(x), w.contiguous(), bias, out, _ld(out), B * N, Cin, Cout, pick(prec, "proj"))
+    if packed is not None:
+        call("craft_linear", x, _ld(x), packed, bias, out, _ld(out), B * N, Cin, Cout, pick(prec, "proj") | hip.W_PACKED)
+    else:
+        call("craft_linear", x, _ld(x), w.contiguous(), bias, out, _ld(out), B * N, Cin, Cout, pick(prec, "proj"))
     return out
 
 
 def linear_t(x: torch.Tensor, w: torch.Tensor, ldt: int, prec: int, out: Optional[torch.Tensor] = None,
-             Dv: int = 0, acc_order: bool = False) -> torch.Tensor:
+             Dv: int = 0, acc_order: bool = False, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Per-sample transposed projection: yT[b][o][n] (row stride ldt >= N, tail zero), stored in the
     element type of the pv role (the type attn_apply consumes).  With ``Dv`` (the per-mode value width) and a 16-bit
     pv type the result is in the MFMA fragment order craft_attn_apply requires (same shape / footprint);
@@ -118,7 +155,10 @@ def linear_t(x: torch.Tensor, w: torch.Tensor, ldt: int, prec: int, out: Optiona
         if not frag:
             raise hip.CraftHipError("acc_order needs a 16-bit pv type and Dv")
         frag |= hip.FRAG_ACC_ORDER
-    call("craft_linear_t", x, _ld(x), w.contiguous(), out, ldt, B, N, Cin, Cout, pv, frag, pick(prec, "proj"))
+    if packed is not None and frag:                     # (``packed``: linear_pack of the same weight; fragment-order results only)
+        call("craft_linear_t", x, _ld(x), packed, out, ldt, B, N, Cin, Cout, pv, frag, pick(prec, "proj") | hip.W_PACKED)
+    else:
+        call("craft_linear_t", x, _ld(x), w.contiguous(), out, ldt, B, N, Cin, Cout, pv, frag, pick(prec, "proj"))
     return out
 
 

@@ -206,7 +206,8 @@ class ExpandedFeatTrans(nn.Module):
         ``ops.attn_probs`` -> tokens [B, N, C]   (setrans.py:364-410)."""
         prec = _prec_of(self) if prec is None else prec
         ldp = ops.vt_stride(attention_probs)
-        vT = ops.linear_t(input_feat, self.first_linear.weight, ldp, prec, Dv=self.feat_dim)
+        vT = ops.linear_t(input_feat, self.first_linear.weight, ldp, prec, Dv=self.feat_dim,
+                          packed=ops.linear_pack(self, "first_linear", self.first_linear.weight, prec))
         O = ops.attn_apply(attention_probs, vT, self.feat_dim, prec)
         return ops.mode_pool_ln(O, input_feat, self.feat_softaggr.feat2score.weight, self.input_skip_coeff, out=out)
 
@@ -216,7 +217,8 @@ class ExpandedFeatTrans(nn.Module):
         """The same layer with the attention fused in (``ops.flash_attention``): q, k projected tokens [B, N, C]."""
         H8, W8 = hw
         ldt = ops.round_up(H8 * W8, 32)
-        vT = ops.linear_t(input_feat, self.first_linear.weight, ldt, prec, Dv=self.feat_dim, acc_order=True)
+        vT = ops.linear_t(input_feat, self.first_linear.weight, ldt, prec, Dv=self.feat_dim, acc_order=True,
+                          packed=ops.linear_pack(self, "first_linear", self.first_linear.weight, prec))
         O = ops.flash_attention(q, k, vT, H8, W8, self.num_modes, self.feat_dim, scale, pos_biases, pos_w, mask_radius, clamp_ord, prec)
         return ops.mode_pool_ln(O, input_feat, self.feat_softaggr.feat2score.weight, self.input_skip_coeff, out=out)
 
@@ -272,8 +274,9 @@ class CrossAttFeatTrans(nn.Module):
 
     def project(self, query_feat: torch.Tensor, key_feat: Optional[torch.Tensor], prec: int):
         """Q = query(x_q), K = key(x_k) on tokens (setrans.py:507-508)."""
-        q = ops.linear(query_feat, self.query.weight, self.query.bias, prec)
-        k = ops.linear(query_feat if key_feat is None else key_feat, self.key.weight, self.key.bias, prec)
+        q = ops.linear(query_feat, self.query.weight, self.query.bias, prec, packed=ops.linear_pack(self, "query", self.query.weight, prec))
+        k = ops.linear(query_feat if key_feat is None else key_feat, self.key.weight, self.key.bias, prec,
+                       packed=ops.linear_pack(self, "key", self.key.weight, prec))
         return q, k
 
     def forward(self, query_feat, key_feat=None, pos_biases=None, attention_mask_radius: int = -1, hw=None,

@@ -32,7 +32,7 @@ from torch.autograd import Function
 
 from . import autograd as AG
 from . import hip, ops
-from .hip import ACT_NONE, ACT_RELU, STATS_REPLICAS, W_PACKED, call, pick, round_up
+from .hip import ACT_NONE, ACT_RELU, PREC_F32, STATS_REPLICAS, W1X1_PACKED, W_PACKED, call, pick, round_up
 
 _C = 512          # columns of HX
 H1, H0, MF, MFG = 0, 128, 256, 384
@@ -187,7 +187,7 @@ class UpdateIter(Function):
         # ---- BasicMotionEncoder (update.py:79-87): one fused call; its workspace keeps cor1 | [cor2 | flo2] | flo1
         me = torch.empty(rows * 640, device=dev, dtype=torch.float32)
         call("craft_motion_encoder", corr, corr.stride(-2), ub.encoder.cor_planes, flow, *ps.w_enc, B, H8, W8, hx[..., MF:MF + 128], _C, me,
-             cp | W_PACKED, None, None)
+             cp | W_PACKED | (W1X1_PACKED if (cp != PREC_F32 and not os.environ.get("CRAFT_NO_LINEAR_PACK")) else 0), None, None)
         S["cor1"] = me[: rows * 256].view(B, N, 256)
         S["cf"] = me[rows * 256: rows * 512].view(B, N, 256)
         S["flo1"] = me[rows * 512:].view(B, N, 128)

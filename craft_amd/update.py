@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import ops
 from .gma import Aggregate
-from .hip import conv_group_prec, PREC_F32, W_PACKED, call, pick, weights_epoch
+from .hip import conv_group_prec, PREC_F32, W1X1_PACKED, W_PACKED, call, pick, weights_epoch
 from .setrans import ExpandedFeatTrans
 
 
@@ -150,7 +150,10 @@ class BasicMotionEncoder(nn.Module):
 
         def b(m):
             return m.bias.detach().float().contiguous()
-        return self._pk.get(params, lambda: (self.convc1.weight.detach().view(256, -1).float().contiguous(), b(self.convc1),
+        def c1():        # convc1 (1x1): MFMA fragment order for k_gemm_rows_wf unless the group runs in fp32 (CRAFT_W1X1_PACKED)
+            w = self.convc1.weight.detach().view(256, -1).float().contiguous()
+            return w if (prec == PREC_F32 or os.environ.get("CRAFT_NO_LINEAR_PACK")) else ops.pack_linear_weight(w, prec)
+        return self._pk.get(params, lambda: (c1(), b(self.convc1),
                                              ops.pack_conv_prec(self.convc2.weight, prec), b(self.convc2),
                                              ops.pack_convf1(self.convf1.weight) if prec == PREC_F32 else ops.pack_convf1_mfma(self.convf1.weight, prec),
                                              b(self.convf1),
@@ -198,7 +201,8 @@ class BasicMotionEncoder(nn.Module):
                 side.wait_stream(torch.cuda.current_stream())   # the side stream sees `flow` / `ws` as the caller left them
             st, ev = side.cuda_stream, event.cuda_event
         call("craft_motion_encoder", corr, corr.stride(1), self.cor_planes, flow, wc1, bc1, wc2, bc2, wf1, bf1, wf2, bf2,
-             wcv, bcv, B, H8, W8, out, out.stride(1), ws, cp | W_PACKED, st, ev)
+             wcv, bcv, B, H8, W8, out, out.stride(1), ws,
+             cp | W_PACKED | (W1X1_PACKED if (cp != PREC_F32 and not os.environ.get("CRAFT_NO_LINEAR_PACK")) else 0), st, ev)
 
 
 class GMAUpdateBlock(nn.Module):

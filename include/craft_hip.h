@@ -206,6 +206,11 @@ int craft_gma_residual(const float* mf, long ldm, const float* O, const float* g
  * convolutions of a training policy that asks for it (craft_amd.hip.Precision role `wgx`); stride-1 KxK with 5 or 9 taps, ignored
  * elsewhere. */
 #define CRAFT_CONV_W16 0x400
+/* craft_linear / craft_linear_t (fragment form), prec | CRAFT_W_PACKED: w is craft_pack_weights(w, rows = cout, K = cin rounded up to 32 with zero
+ * columns, prec) instead of fp32 [cout][cin] -- the short-K products of the refinement loop then run on k_gemm_rows_wf (weights L2 ->
+ * MFMA registers, activations converted once per 64-wide K chunk).  craft_motion_encoder, prec | CRAFT_W1X1_PACKED: wc1 (the 1x1
+ * convc1, update.py:80) handed over the same way: craft_pack_weights(wc1, 256, round_up(cor_planes, 32), prec). */
+#define CRAFT_W1X1_PACKED 0x800
 #define CRAFT_STATS_REPLICAS 64
 #define CRAFT_ATTN_CHUNK_KEYS 1024
 int craft_pack_weights(const float* w, int rows, int K, int prec, void* out, void* stream);

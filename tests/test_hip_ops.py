@@ -95,6 +95,60 @@ def test_linear_t_and_column_views(device, prec):
     close(un[..., :N], ref, max(rt, 2e-3), max(at, 2e-3), "linear_t (fragment order)")
 
 
+@pytest.mark.parametrize("prec", [p for p in PRECS if p != PREC_F32])
+@pytest.mark.parametrize("rows,cin,cout", [(406, 324, 256), (300, 128, 512), (77, 256, 256), (130, 36, 40), (128, 64, 96)])
+def test_linear_with_packed_weights(device, prec, rows, cin, cout):
+    """craft_linear / craft_linear_t with CRAFT_W_PACKED (k_gemm_rows_wf: weights in MFMA fragment order, K padded to 32) against the
+    fp32 reference and against the same product with raw weights (same operand planes, another fp32 summation order); row views with
+    a column offset, ragged row / column / K tails, bias."""
+    B = 2
+    buf = torch.zeros(B, rows // 2, cin + 24)
+    buf[..., 8:8 + cin] = gen(B, rows // 2, cin, seed=31)
+    w = gen(cout, cin, seed=32) / math.sqrt(cin)
+    w[3, 5] += 2.0
+    b = gen(cout, seed=33)
+    xd = buf.to(device)[..., 8:8 + cin]
+    pk = ops.pack_linear_weight(w.to(device), prec)
+    y = ops.linear(xd, w.to(device), b.to(device), prec, packed=pk)
+    y0 = ops.linear(xd, w.to(device), b.to(device), prec)
+    ref = F.linear(buf[..., 8:8 + cin], w, b)
+    rt, at = TOL[prec]
+    close(y, ref, rt, at, f"packed linear prec={prec}")
+    close(y, y0, 2e-5 if prec == PREC_F16X3 else rt, 2e-5 if prec == PREC_F16X3 else at, "packed vs raw weights")
+    if cout % 128 == 0:                                  # the V^T projection of the aggregators (fragment order, both key orders)
+        N = rows // 2
+        ldt = ops.round_up(N, 32)
+        P = hip.Precision(proj=prec, pv=PREC_F16)
+        for acc in (False, True):
+            a = ops.linear_t(xd, w.to(device), ldt, P, Dv=128, acc_order=acc, packed=pk)
+            a0 = ops.linear_t(xd, w.to(device), ldt, P, Dv=128, acc_order=acc)
+            assert a.dtype == torch.float16 and a.shape == a0.shape
+            close(a.float(), a0.float(), 2e-3, 2e-3, f"packed V^T (acc_order={acc})")
+            # (N a multiple of 32 or not: the tail keys must read as zero in both)
+            assert int((a == 0).sum()) >= int(B * cout * (ldt - N))
+
+
+MIXED = hip.Precision.parse("mixed")
+
+
+def test_linear_pack_cache_follows_the_parameter(device):
+    """ops.linear_pack: one packed copy per (module, name, precision); an in-place update or a replaced parameter re-packs; fp32 and
+    autograd-tracked calls get None (the raw-weight path)."""
+    lin = torch.nn.Linear(96, 64).to(device)
+    with torch.no_grad():
+        a = ops.linear_pack(lin, "w", lin.weight, MIXED)
+        assert a is not None and ops.linear_pack(lin, "w", lin.weight, MIXED) is a
+        x = gen(1, 50, 96, seed=34).to(device)
+        y1 = ops.linear(x, lin.weight, lin.bias, MIXED, packed=a)
+        lin.weight.mul_(2.0)
+        b = ops.linear_pack(lin, "w", lin.weight, MIXED)
+        assert b is not a
+        y2 = ops.linear(x, lin.weight, lin.bias, MIXED, packed=b)
+        close(y2 - lin.bias, 2 * (y1 - lin.bias), 1e-5, 1e-5, "re-packed after an in-place update")
+        assert ops.linear_pack(lin, "w", lin.weight, PREC_F32) is None
+    assert ops.linear_pack(lin, "w", lin.weight, MIXED) is None      # grad mode, requires_grad
+
+
 @pytest.mark.parametrize("nchw", [True, False])
 def test_tokens(device, nchw):
     B, C, H, W = 2, 256, 9, 13

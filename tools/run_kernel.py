@@ -37,6 +37,33 @@ def main():
             e.record()
             torch.cuda.synchronize()
             print(f"attn_apply (k_pv16): {s.elapsed_time(e) / reps * 1e3:.1f} us per launch")
+    elif which == "rows":
+        # the short-K nn.Linear / 1x1 products of the forward pass: raw weights (k_gemm_rows) vs packed weights (k_gemm_rows_wf)
+        pp = pick(prec, "proj")
+        reps = int(os.environ.get("REPS", 20))
+        for name, cin, cout, vt in (("convc1 324->256", 324, 256, False), ("V^T 128->512", 128, 512, True), ("q/k 256->256", 256, 256, False),
+                                    ("q/k 128->128", 128, 128, False)):
+            x = torch.randn(B, N, cin + 4, device=dev)[..., :cin]
+            w = torch.randn(cout, cin, device=dev) / cin ** 0.5
+            bias = torch.randn(cout, device=dev)
+            pk = ops.pack_linear_weight(w, pp)
+            for label, pkd in (("raw   ", None), ("packed", pk)):
+                def run():
+                    if vt:
+                        return ops.linear_t(x, w, N, prec, Dv=128, packed=pkd)
+                    return ops.linear(x, w, bias, prec, packed=pkd)
+                for _ in range(3):
+                    y = run()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(reps):
+                    y = run()
+                e.record()
+                torch.cuda.synchronize()
+                us = s.elapsed_time(e) / reps * 1e3
+                fl = 2.0 * B * N * cin * cout * (3 if pp == 3 else 1)
+                by = 4.0 * B * N * cin + (2.0 if vt else 4.0) * B * N * cout
+                print(f"{name:18s} {label} {us:7.1f} us   {fl / us / 1e6:6.1f} TF/s (MFMA)   {by / us / 1e3:6.0f} GB/s", flush=True)
     elif which in ("gru", "grustep", "menc", "head"):
         from craft_amd import CRAFT, default_args
         from craft_amd.synth import synth_state_dict
