@@ -49,7 +49,7 @@ __device__ __forceinline__ void conv_epilogue4(const ConvGemmParams& p, long row
   if (p.bias_field) {
     const float* bf = p.bias_field + row0 * p.ld_bf + col;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) b[i] = bf[(long)min(i, nvalid - 1) * p.ld_bf];
+    for (int i = 0; i < 4; ++i) b[i] = col >= p.bf_col0 ? bf[(long)min(i, nvalid - 1) * p.ld_bf] : 0.f;
   } else {
     const float b0 = p.bias[col];
 #pragma unroll
@@ -119,7 +119,7 @@ template <int EPI>
 __device__ __forceinline__ void epi_load4r(const ConvGemmParams& p, const long (&rows)[4], int col, EpiOperands& o) {
   if (p.bias_field) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o.b[i] = p.bias_field[rows[i] * p.ld_bf + col];
+    for (int i = 0; i < 4; ++i) o.b[i] = col >= p.bf_col0 ? p.bias_field[rows[i] * p.ld_bf + col] : 0.f;
   } else {
     const float b0 = p.bias[col];
 #pragma unroll

@@ -448,6 +448,7 @@ int craft_conv2d_nhwc2(const float* x0, long ld0, int c0, const float* x1, long 
   ConvGemmParams q = conv_params(x0, (int)ld0, c0, c1 ? x1 : nullptr, (int)ld1, c1, B, H, W, KH, KW, w, bias, cout, CONV_EPI_BIAS_ACT, act, 1.f, y,
                                  (int)ldy);
   q.bias_field = bias_field; q.ld_bf = (int)ld_bf;
+  q.bf_col0 = bias_field ? ((prec >> 16) & 0xff) * 32 : 0;                 // CRAFT_CONV_FIELD_COL0
   q.w_packed = PACKED_OF(prec);
   q.w16 = W16_OF(prec);
   return launch_gemm_conv(q, PREC_OF(prec), S(stream));
@@ -601,16 +602,20 @@ int craft_zero_stuff2(const float* g, long ldg, int B, int Hin, int Win, int C, 
   return launch_zero_stuff2(g, ldg, B, Hin, Win, C, gf, ldf, S(stream));
 }
 int craft_colsum(const float* x, long ld, long rows, int C, float* out, void* stream) { return launch_colsum(x, ld, rows, C, out, S(stream)); }
-int craft_multi_copy(const void* const* src, const long* n, const long* dst_off, int count, float* dst, void* stream) {
+int craft_multi_copy(const void* const* src, const long* n, const long* dst_off, const long* chlast, int count, float* dst, void* stream) {
   if (count <= 0) return 0;
-  return launch_multi_copy(src, n, dst_off, count, dst, S(stream));
+  return launch_multi_copy(src, n, dst_off, chlast, count, dst, S(stream));
 }
 int craft_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, void* stream) {
   return launch_act_fwd(x, ldx, y, ldy, rows, C, act, scale, S(stream));
 }
 int craft_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,
                   void* stream) {
-  return launch_act_bwd(dy, lddy, y, ldy, dx, lddx, rows, C, act, scale, S(stream));
+  return launch_act_bwd(dy, lddy, nullptr, 0, y, ldy, dx, lddx, rows, C, act, scale, 0, S(stream));
+}
+int craft_act_bwd2(const float* dy, long lddy, const float* dy2, long lddy2, const float* y, long ldy, float* dx, long lddx, long rows, int C,
+                   int act, float scale, int zero_tail, void* stream) {
+  return launch_act_bwd(dy, lddy, dy2, lddy2, y, ldy, dx, lddx, rows, C, act, scale, zero_tail, S(stream));
 }
 int craft_dropout(const float* x, float* y, long n, float p, unsigned long long seed, void* stream) {
   return launch_dropout(x, y, n, p, seed, S(stream));

@@ -76,14 +76,26 @@ __global__ void k_act_fwd(const float* __restrict__ x, long ldx, float* __restri
   v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
   *reinterpret_cast<float4*>(y + r * ldy + c) = v;
 }
-__global__ void k_act_bwd(const float* __restrict__ dy, long lddy, const float* __restrict__ y, long ldy, float* __restrict__ dx,
-                          long lddx, long rows, int C, int act, float scale) {
+// dy2 (optional): a second gradient contribution, dy + dy2 is what flows back; ztail: the last `ztail` of the C channels carry no
+// gradient (the two pass-through flow channels of the motion encoder's output, update.py:93-94) -- dx = 0 there.
+__global__ void k_act_bwd(const float* __restrict__ dy, long lddy, const float* __restrict__ dy2, long lddy2, const float* __restrict__ y,
+                          long ldy, float* __restrict__ dx, long lddx, long rows, int C, int act, float scale, int ztail) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c4 = C >> 2;
   if (i >= rows * c4) return;
   const long r = i / c4;
   const int c = (int)(i - r * c4) * 4;
-  const float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+  float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+  if (dy2) {
+    const float4 g2 = *reinterpret_cast<const float4*>(dy2 + r * lddy2 + c);
+    g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+  }
+  if (c + 3 >= C - ztail) {
+    if (c >= C - ztail) g.x = 0.f;
+    if (c + 1 >= C - ztail) g.y = 0.f;
+    if (c + 2 >= C - ztail) g.z = 0.f;
+    g.w = 0.f;
+  }
   float4 o = {g.x * scale, g.y * scale, g.z * scale, g.w * scale};
   if (act != CRAFT_ACT_NONE) {
     const float4 v = *reinterpret_cast<const float4*>(y + r * ldy + c);
@@ -99,12 +111,14 @@ int launch_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int 
   hipLaunchKernelGGL(k_act_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, ldx, y, ldy, rows, C, act, scale);
   return (int)hipGetLastError();
 }
-int launch_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,
-                   hipStream_t s) {
+int launch_act_bwd(const float* dy, long lddy, const float* dy2, long lddy2, const float* y, long ldy, float* dx, long lddx, long rows, int C,
+                   int act, float scale, int ztail, hipStream_t s) {
   if (rows <= 0 || C <= 0) return 0;
-  if ((C & 3) || (lddy & 3) || (ldy & 3) || (lddx & 3)) return CRAFT_ERR_ALIGN;
+  if ((C & 3) || (lddy & 3) || (ldy & 3) || (lddx & 3) || (dy2 && (lddy2 & 3))) return CRAFT_ERR_ALIGN;
+  if (ztail < 0 || ztail > C) return CRAFT_ERR_ARG;
   const long n = rows * (C >> 2);
-  hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, lddy, y, ldy, dx, lddx, rows, C, act, scale);
+  hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, lddy, dy2, lddy2, y, ldy, dx, lddx, rows, C, act, scale,
+                     ztail);
   return (int)hipGetLastError();
 }
 
@@ -1221,16 +1235,27 @@ int launch_relpos_bwd(const float* dS, long ld, int BZ, int H8, int W8, float* d
 // optimizer's flat gradient buffer: torch._foreach_copy_ on this build issues one copyBuffer per tensor, 131 per configs[3] step).
 // The descriptor table travels in the kernel arguments; block -> (tensor, 8 KiB chunk) through a prefix table.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int MC_MAX = 168;                       // tensors per launch (the argument block stays under 4 KiB)
+constexpr int MC_MAX = 160;                       // tensors per launch (the argument block stays under 4 KiB)
 constexpr int MC_CHUNK = 2048;                    // floats per block
-struct MultiCopy { const float* src[MC_MAX]; unsigned off[MC_MAX]; unsigned n[MC_MAX]; unsigned first[MC_MAX + 1]; int count; };
+// cl[i] != 0: the source is a conv-weight gradient in the layout the weight-gradient kernels write, [cout][taps][cin] (cl = cin * 1024 + taps),
+// and lands as nn.Conv2d's [cout][cin][taps]
+struct MultiCopy { const float* src[MC_MAX]; unsigned off[MC_MAX]; unsigned n[MC_MAX]; unsigned cl[MC_MAX]; unsigned first[MC_MAX + 1]; int count; };
 __global__ __launch_bounds__(256) void k_multi_copy(MultiCopy m, float* __restrict__ dst) {
   int lo = 0, hi = m.count;                       // the tensor whose chunks contain this block
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (blockIdx.x >= m.first[mid]) lo = mid; else hi = mid; }
   const unsigned c0 = (blockIdx.x - m.first[lo]) * MC_CHUNK, n = m.n[lo];
-  const float* s = m.src[lo] + c0;
-  float* d = dst + m.off[lo] + c0;
   const unsigned len = min((unsigned)MC_CHUNK, n - c0);
+  float* d = dst + m.off[lo] + c0;
+  if (m.cl[lo]) {
+    const unsigned cin = m.cl[lo] >> 10, T = m.cl[lo] & 1023u, ct = cin * T;
+    const float* s = m.src[lo];
+    for (unsigned i = threadIdx.x; i < len; i += 256) {
+      const unsigned j = c0 + i, co = j / ct, rem = j - co * ct, ci = rem / T, t = rem - ci * T;
+      d[i] = s[(co * T + t) * cin + ci];
+    }
+    return;
+  }
+  const float* s = m.src[lo] + c0;
   if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
     for (unsigned i = threadIdx.x * 4; i + 3 < len; i += 1024) *reinterpret_cast<float4*>(d + i) = *reinterpret_cast<const float4*>(s + i);
     for (unsigned i = (len & ~3u) + threadIdx.x; i < len; i += 256) d[i] = s[i];
@@ -1238,15 +1263,16 @@ __global__ __launch_bounds__(256) void k_multi_copy(MultiCopy m, float* __restri
     for (unsigned i = threadIdx.x; i < len; i += 256) d[i] = s[i];
   }
 }
-int launch_multi_copy(const void* const* src, const long* n, const long* dst_off, int count, float* dst, hipStream_t s) {
+int launch_multi_copy(const void* const* src, const long* n, const long* dst_off, const long* chlast, int count, float* dst, hipStream_t s) {
   for (int i0 = 0; i0 < count; i0 += MC_MAX) {
     MultiCopy m = {};
     m.count = count - i0 < MC_MAX ? count - i0 : MC_MAX;
     long blocks = 0;
     for (int i = 0; i < m.count; ++i) {
-      const long ni = n[i0 + i], oi = dst_off[i0 + i];
+      const long ni = n[i0 + i], oi = dst_off[i0 + i], cl = chlast ? chlast[i0 + i] : 0;
       if (ni < 0 || oi < 0 || ni >= (1L << 32) || oi >= (1L << 32) || (ni > 0 && src[i0 + i] == nullptr)) return CRAFT_ERR_ARG;
-      m.src[i] = static_cast<const float*>(src[i0 + i]); m.n[i] = (unsigned)ni; m.off[i] = (unsigned)oi;
+      if (cl < 0 || cl >= (1L << 32) || (cl && ((cl & 1023) == 0 || (cl >> 10) == 0 || ni % ((cl >> 10) * (cl & 1023)) != 0))) return CRAFT_ERR_ARG;
+      m.src[i] = static_cast<const float*>(src[i0 + i]); m.n[i] = (unsigned)ni; m.off[i] = (unsigned)oi; m.cl[i] = (unsigned)cl;
       m.first[i] = (unsigned)blocks;
       blocks += (ni + MC_CHUNK - 1) / MC_CHUNK;
     }

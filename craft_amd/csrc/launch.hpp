@@ -52,6 +52,7 @@ struct ConvGemmParams {
   int w_packed;          // 1: W was produced by craft_pack_weights for this precision (halo kernel only)
   int w16;               // 1 (f16x3, packed weights, static taps): use the weights' hi plane only -- CRAFT_CONV_W16, two MFMAs per product
   double* stats;         // optional [B][cout][2]: += (sum, sum^2) of the biased conv output per (image, channel)
+  int bf_col0;                          // with bias_field: output columns < bf_col0 get no bias at all (CRAFT_CONV_FIELD_COL0)
   const float* bias_field; int ld_bf;   // optional per-pixel bias [npix][ld_bf] used INSTEAD of bias[col] (hoisted
                                         // iteration-invariant part of a conv: SepConvGRU context term)
   const float* res; int ld_res;         // optional (CONV_EPI_BIAS_ACT): out = relu(res[pix][col] + act(conv + bias) * scale) -- the tail of a
@@ -217,10 +218,10 @@ int launch_bn_finalize(const double* stats, int B, int C, double count, float ep
 int launch_norm_bwd_finalize(const double* sums, int B, int C, double population, int per_image, float* red, float* dgamma, float* dbeta,
                              hipStream_t s);
 int launch_colsum(const float* x, long ld, long rows, int C, float* out, hipStream_t s);
-int launch_multi_copy(const void* const* src, const long* n, const long* dst_off, int count, float* dst, hipStream_t s);
+int launch_multi_copy(const void* const* src, const long* n, const long* dst_off, const long* chlast, int count, float* dst, hipStream_t s);
 int launch_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, hipStream_t s);
-int launch_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,
-                   hipStream_t s);
+int launch_act_bwd(const float* dy, long lddy, const float* dy2, long lddy2, const float* y, long ldy, float* dx, long lddx, long rows, int C,
+                   int act, float scale, int ztail, hipStream_t s);
 int launch_dropout(const float* x, float* y, long n, float p, unsigned long long seed, hipStream_t s);
 int launch_tokens_bwd(const float* x, long ldx, const float* dy, long lddy, float* dx, long lddx, long rows, int C, int act, int do_ln,
                       hipStream_t s);

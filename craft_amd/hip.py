@@ -77,7 +77,7 @@ _SIGS = {
     "craft_flow_l1_loss": [P, P, P, I, I, I, F, F, P, P, P],
     "craft_sumsq": [P, L, P, P],
     "craft_pack_conv_weights_batch": [P, P, I, I, P],
-    "craft_multi_copy": [P, P, P, I, P, P],
+    "craft_multi_copy": [P, P, P, P, I, P, P],
     "craft_adamw_step": [P, P, P, P, L, F, F, F, F, F, I, F, P, F, P],
     "craft_loss_scale_update": [P, P, F, F, F, F, F, F, I, P],
     "craft_adamw_step_dyn": [P, P, P, P, L, F, F, F, F, F, P, P],
@@ -101,6 +101,7 @@ _SIGS = {
     "craft_colsum": [P, L, L, I, P, P],
     "craft_act_fwd": [P, L, P, L, L, I, I, F, P],
     "craft_act_bwd": [P, L, P, L, P, L, L, I, I, F, P],
+    "craft_act_bwd2": [P, L, P, L, P, L, P, L, L, I, I, F, I, P],
     "craft_dropout": [P, P, L, F, ctypes.c_ulonglong, P],
     "craft_tokens_bwd": [P, L, P, L, P, L, L, I, I, I, P],
     "craft_attn_softmax_fwd": [P, L, I, I, I, I, P, I, F, I, P, P, P, F, ctypes.c_ulonglong, P, L, I, I, P],

@@ -181,9 +181,17 @@ class FlatAdamW:
                 # ONE launch (craft_multi_copy); torch._foreach_copy_ issues a copyBuffer per tensor on this build (131 per configs[3] step)
                 import ctypes
                 from .hip import call, carray
-                src = [g if g.is_contiguous() else g.contiguous() for g in src]
+                # conv weight gradients arrive as the permuted view of the [cout][KH][KW][cin] buffer the weight-gradient kernels write: the
+                # launch transposes them on the way (a .contiguous() per weight was 45 clone launches per configs[3] step)
+                cl = [0] * len(src)
+                for i, g in enumerate(src):
+                    if not g.is_contiguous():
+                        if g.dim() == 4 and g.permute(0, 2, 3, 1).is_contiguous() and g.shape[2] * g.shape[3] < 1024 and g.shape[1] < (1 << 21):
+                            cl[i] = g.shape[1] * 1024 + g.shape[2] * g.shape[3]
+                        else:
+                            src[i] = g.contiguous()
                 call("craft_multi_copy", carray(ctypes.c_void_p, [g.data_ptr() for g in src]), carray(ctypes.c_long, [g.numel() for g in src]),
-                     carray(ctypes.c_long, offs), len(src), self.flat_grad)
+                     carray(ctypes.c_long, offs), carray(ctypes.c_long, cl), len(src), self.flat_grad)
             elif dst:
                 torch._foreach_copy_(dst, src)
             if stale:

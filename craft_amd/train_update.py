@@ -115,15 +115,17 @@ class UpdatePass:
 
 
 _NO_MASK_EPI = bool(os.environ.get("CRAFT_NO_MASK_EPI"))
+_NO_FIELD_COL0 = bool(os.environ.get("CRAFT_NO_FIELD_COL0"))          # developer A/B: the per-iteration torch.add of the two passes' d[mf | mfg]
 
 
-def _conv_dx(ps: UpdatePass, w, g, cout_p, KH, KW, out=None, cin_p=None, field=None, relu_y=None):
+def _conv_dx(ps: UpdatePass, w, g, cout_p, KH, KW, out=None, cin_p=None, field=None, relu_y=None, field_col0=0):
     """Input gradient of a stride-1 'same' convolution: the forward kernel with flipped / transposed weights.  g [B, N, cout_p]
     (row stride may exceed cout_p) -> [B, N, cin_p].  w: the nn.Conv2d weight, or (with cin_p) an operand already packed by
     ops.pack_conv_weights(transposed=True).  field [B, N, >= cin_p]: out = conv + field (a gradient that is already there: the
     convolution's per-pixel bias field, `out` may be `field` itself) instead of a separate add pass.  relu_y [B, N, >= cin_p]: the saved
     output of the ReLU layer BELOW this convolution -- its backward (out = relu_y > 0 ? out : 0) runs in the epilogue
-    (craft_conv2d_nhwc2_mask) instead of as a craft_act_bwd pass over the result."""
+    (craft_conv2d_nhwc2_mask) instead of as a craft_act_bwd pass over the result.  field_col0 (a multiple of 32, plain field form only):
+    the field is added to columns >= field_col0 (CRAFT_CONV_FIELD_COL0)."""
     if cin_p is None:
         wt, zb, flag, _ = AG._conv_weights(w, None, ps.cp, ps.cache, True)
         cin_p = round_up(w.shape[1], 32)
@@ -140,7 +142,7 @@ def _conv_dx(ps: UpdatePass, w, g, cout_p, KH, KW, out=None, cin_p=None, field=N
              ps.cp | flag | AG.dxflag(ps.cp))
     elif field is not None:
         call("craft_conv2d_nhwc2", g, g.stride(-2), cout_p, None, 0, 0, wt, None, field, field.stride(-2), cin_p, KH, KW, ACT_NONE, out, out.stride(-2),
-             ps.B, ps.hw[0], ps.hw[1], ps.cp | flag | AG.dxflag(ps.cp))
+             ps.B, ps.hw[0], ps.hw[1], ps.cp | flag | AG.dxflag(ps.cp) | ((field_col0 // 32) << 16))
     else:
         call("craft_conv2d_nhwc", g, g.stride(-2), cout_p, wt, zb, cin_p, KH, KW, ACT_NONE, out, out.stride(-2), ps.B, ps.hw[0], ps.hw[1],
              ps.cp | flag | AG.dxflag(ps.cp))
@@ -320,7 +322,7 @@ class UpdateIter(Function):
             raise RuntimeError("UpdateIter.backward without any output gradient")
 
         # ---- SepConvGRU, vertical pass then horizontal pass
-        dv = None
+        dv = tq_prev = None
         dh = dh2
         for p_, (KH, KW) in ((1, (5, 1)), (0, (1, 5))):
             h = hx[..., H0:H0 + 128] if p_ == 0 else hx[..., H1:H1 + 128]
@@ -332,7 +334,13 @@ class UpdateIter(Function):
             if ("q", p_) not in ps.dysum:
                 ps.dysum[("q", p_)], ps.dysum[("zr", p_)] = hip.zeros((B, N, 128), dev), hip.zeros((B, N, 256), dev)
             call("craft_gru_out_bwd", dh, dh.stride(-2), z, q, h, _C, dqp, dz, dhp, rows, 128, ps.dysum[("q", p_)])
-            tq = _conv_dx(ps, ps.wqT[p_], dqp, 128, KH, KW, cin_p=384)                        # d[rh | mf | mfg]
+            # d[rh | mf | mfg]; the second pass adds the first pass's d[mf | mfg] here (columns 128.. of its 384-wide result) -- it was a
+            # torch.add over [B, N, 256] per iteration
+            if tq_prev is not None and not _NO_FIELD_COL0:
+                tq = _conv_dx(ps, ps.wqT[p_], dqp, 128, KH, KW, cin_p=384, field=tq_prev, field_col0=128)
+                dv = None
+            else:
+                tq = _conv_dx(ps, ps.wqT[p_], dqp, 128, KH, KW, cin_p=384)
             ps.wgrad(("q", p_), (AG.Packed(dqp, AG.gprec(cp), geom, colsum=ps.acc(("q", p_, "db"), (128,)), batch=pb), _cat_pack(S[f"pk_rh{p_}"], S[f"pk_v{p_}"])), KH, KW,
                      ps.acc(("q", p_, "dw"), (128, KH, KW, 384)), last)
             dzr = E(B, N, 256)
@@ -343,6 +351,7 @@ class UpdateIter(Function):
                      ps.acc(("zr", p_, "dw"), (256, KH, KW, 384)), last)
             dv = tq[..., 128:] if dv is None else torch.add(dv, tq[..., 128:])
             dh = tq[..., :128]
+            tq_prev = tq
             for k in (f"pk_h{p_}", f"pk_rh{p_}", f"pk_v{p_}", f"z{p_}", f"r{p_}", f"q{p_}"):
                 S.pop(k)
         d_net = dh                                                                            # gradient of net_t
@@ -358,8 +367,7 @@ class UpdateIter(Function):
                 pk_inp = AG.Packed(ps.inp, AG.xprec(cp), geom)
                 for kind, w_inp, co in (("zr", ps.wzrT_inp[p_], 256), ("q", ps.wqT_inp[p_], 128)):
                     g = ps.dysum.pop((kind, p_))
-                    di = _conv_dx(ps, w_inp, g, co, KH, KW, cin_p=128)
-                    d_inp = di if d_inp is None else d_inp.add_(di)
+                    d_inp = _conv_dx(ps, w_inp, g, co, KH, KW, cin_p=128, out=d_inp, field=d_inp)     # (+= through the convolution's bias field)
                     AG.wgrad_pk([(AG.Packed(g, AG.gprec(cp), geom), pk_inp)], KH, KW, ps.acc((kind, p_, "dw_inp"), (co, KH, KW, 128)))
         if last:
             _phase2(ps)
@@ -456,11 +464,16 @@ def _phase2(ps: UpdatePass):
             dva = dva5[:, :, :, t, :].reshape(B, N, M * Cv)          # M > 1: a contiguous copy; one mode: a strided view (row stride T*Cv)
         AG.gemm(dva, dva.stride(-2), 1, 0, 0, wv2, 1, 128, 0, 0, d_mf, 128, 0, 0, 1, 1, rows, 128, M * Cv, accumulate=True, prec=pp)      # d_mf += dva W_v
         ps.wgrad(("agg_v",), (AG.Packed(dva, AG.gprec(pp), batch=pb), S["pk_mf"]), 1, 1, ps.acc(("agg_v", "dw"), (M * Cv, 128)), last)
-        d_mf.add_(ps.dv[t][..., 0:128])
-        ps.dv[t] = None
-        # ---- BasicMotionEncoder
-        g_out = _act_bwd(d_mf, mf, 128, out=d_mf)
-        g_out[..., 126:128] = 0.0                                                             # the two pass-through flow channels carry no gradient
+        # ---- BasicMotionEncoder: g_out = ReLU'(mf) (d_mf + the recurrence's share), the two pass-through flow channels carry no gradient
+        dv_t = ps.dv[t]
+        if os.environ.get("CRAFT_NO_ACT_BWD2"):                 # (A/B: the three launches craft_act_bwd2 replaces)
+            d_mf.add_(dv_t[..., 0:128])
+            g_out = _act_bwd(d_mf, mf, 128, out=d_mf)
+            g_out[..., 126:128] = 0.0
+        else:
+            g_out = d_mf
+            call("craft_act_bwd2", d_mf, 128, dv_t, dv_t.stride(-2), mf, mf.stride(-2), g_out, 128, rows, 128, ACT_RELU, 1.0, 2)
+        ps.dv[t] = dv_t = None
         g_cf = _conv_dx(ps, enc.conv.weight, g_out, 128, 3, 3, relu_y=S["cf"])
         ps.wgrad(("menc",), (AG.Packed(g_out, AG.gprec(cp), g3, colsum=ps.acc(("menc", "db"), (128,)), batch=pb), S["pk_cf"]), 3, 3, ps.acc(("menc", "dw"), (128, 3, 3, 256)), last)
         g_c2, g_f2 = g_cf[..., :192], g_cf[..., 192:256]

@@ -211,6 +211,10 @@ int craft_gma_residual(const float* mf, long ldm, const float* O, const float* g
  * MFMA registers, activations converted once per 64-wide K chunk).  craft_motion_encoder, prec | CRAFT_W1X1_PACKED: wc1 (the 1x1
  * convc1, update.py:80) handed over the same way: craft_pack_weights(wc1, 256, round_up(cor_planes, 32), prec). */
 #define CRAFT_W1X1_PACKED 0x800
+/* craft_conv2d_nhwc2 with a bias_field, prec | CRAFT_CONV_FIELD_COL0(c) (c a multiple of 32, < 8192): the field is added to output
+ * columns >= c only; columns below get the bare convolution.  The backward of SepConvGRU's second pass adds the first pass's
+ * gradient of [motion features | aggregate] (columns 128..383 of a 384-wide field) while its own hidden-state columns start fresh. */
+#define CRAFT_CONV_FIELD_COL0(c) ((((c) / 32) & 0xff) << 16)
 #define CRAFT_STATS_REPLICAS 64
 #define CRAFT_ATTN_CHUNK_KEYS 1024
 int craft_pack_weights(const float* w, int rows, int K, int prec, void* out, void* stream);
@@ -418,8 +422,10 @@ int craft_conv2d_wgrad(const float* x, long ldx, int cin, const float* dy, long 
 int craft_colsum(const float* x, long ld, long rows, int C, float* out, void* stream);
 /* count contiguous fp32 device tensors src[i] (n[i] elements) -> dst + dst_off[i], in ONE launch (src / n / dst_off are HOST arrays): the
  * parameter gradients of a training step into the optimizer's flat gradient buffer -- what the reference's optimizer.step() reads
- * parameter by parameter (train.py:231-236) and torch._foreach_copy_ turns into one copy launch per tensor. */
-int craft_multi_copy(const void* const* src, const long* n, const long* dst_off, int count, float* dst, void* stream);
+ * parameter by parameter (train.py:231-236) and torch._foreach_copy_ turns into one copy launch per tensor.  chlast (HOST array or NULL):
+ * chlast[i] = cin * 1024 + taps marks src[i] as a convolution weight gradient in the layout the weight-gradient kernels write,
+ * [cout][taps][cin]; it is stored as nn.Conv2d's [cout][cin][taps] (0: plain copy). */
+int craft_multi_copy(const void* const* src, const long* n, const long* dst_off, const long* chlast, int count, float* dst, void* stream);
 /* Packed-operand weight gradients (round 3; craft_amd/csrc/kernels_gemm_pk.hip): the same contraction as craft_conv2d_wgrad /
  * craft_gemm's dW = dY^T X for the 16-bit MFMA modes, with the fp32 -> fp16-plane split taken OUT of the K loop.
  * craft_pack_operand: tokens x [rows][C] (fp32, row stride ldx, C % 4 == 0) -> out[plane][ceil(C/32)][rows_p][32] 16-bit
@@ -473,6 +479,11 @@ int craft_gemm_pk(const void* A, const long* a_desc, const void* B, const long* 
 int craft_act_fwd(const float* x, long ldx, float* y, long ldy, long rows, int C, int act, float scale, void* stream);
 int craft_act_bwd(const float* dy, long lddy, const float* y, long ldy, float* dx, long lddx, long rows, int C, int act, float scale,
                   void* stream);
+/* craft_act_bwd with two more inputs: dy2 (optional, row stride lddy2) -- the gradient that flows back is dy + dy2 -- and zero_tail: the
+ * last zero_tail of the C channels carry no gradient (dx = 0 there: the two pass-through flow channels of BasicMotionEncoder's output,
+ * update.py:93-94).  One launch for what a training step did as add_ + craft_act_bwd + a slice fill per refinement iteration. */
+int craft_act_bwd2(const float* dy, long lddy, const float* dy2, long lddy2, const float* y, long ldy, float* dx, long lddx, long rows, int C,
+                   int act, float scale, int zero_tail, void* stream);
 int craft_dropout(const float* x, float* y, long n, float p, unsigned long long seed, void* stream);
 
 /* backward of craft_tokens with a token-major source: y = LayerNorm?(act(x)), x / dy / dx rows of C <= 256 channels. */

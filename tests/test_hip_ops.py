@@ -644,11 +644,64 @@ def test_conv2d_relu_mask_epilogue_and_multi_copy(device):
         off += n + 5
     flat = torch.full((off,), -7.0, device=device)
     call("craft_multi_copy", carray(ctypes.c_void_p, [t.data_ptr() if t.numel() else 0 for t in srcs]), carray(ctypes.c_long, sizes),
-         carray(ctypes.c_long, offs), len(sizes), flat)
+         carray(ctypes.c_long, offs), None, len(sizes), flat)
     ref = torch.full((off,), -7.0)
     for t, o, n in zip(srcs, offs, sizes):
         ref[o:o + n] = t.cpu()
     assert torch.equal(flat.cpu(), ref)
+    # conv weight gradients in the weight-gradient kernels' [cout][KH][KW][cin] layout land as [cout][cin][KH][KW] (chlast)
+    shapes = [(96, 3, 3, 64), (7, 1, 5, 36), (128, 7, 7, 2), (5, 1, 1, 324)]
+    cls = [gen(*sh, seed=140 + i).to(device) for i, sh in enumerate(shapes)]
+    plain = gen(77, seed=150).to(device)
+    srcs = [cls[0], plain] + cls[1:]
+    sizes = [t.numel() for t in srcs]
+    chl = [shapes[0][3] * 1024 + 9, 0, 36 * 1024 + 5, 2 * 1024 + 49, 324 * 1024 + 1]
+    offs, off = [], 1
+    for n in sizes:
+        offs.append(off)
+        off += n + 3
+    flat = torch.full((off,), -7.0, device=device)
+    call("craft_multi_copy", carray(ctypes.c_void_p, [t.data_ptr() for t in srcs]), carray(ctypes.c_long, sizes), carray(ctypes.c_long, offs),
+         carray(ctypes.c_long, chl), len(srcs), flat)
+    ref = torch.full((off,), -7.0)
+    for t, o, n, c in zip(srcs, offs, sizes, chl):
+        ref[o:o + n] = (t.permute(0, 3, 1, 2) if c else t).cpu().reshape(-1)
+    assert torch.equal(flat.cpu(), ref)
+    with pytest.raises(hip.CraftHipError):                 # a size that is not a whole number of [taps][cin] rows
+        call("craft_multi_copy", carray(ctypes.c_void_p, [plain.data_ptr()]), carray(ctypes.c_long, [77]), carray(ctypes.c_long, [0]),
+             carray(ctypes.c_long, [4 * 1024 + 9]), 1, flat)
+
+
+def test_act_bwd2_and_field_column_start(device):
+    """craft_act_bwd2 = craft_act_bwd on dy + dy2 with the last channels zeroed; craft_conv2d_nhwc2 with CRAFT_CONV_FIELD_COL0: the bias
+    field reaches columns >= c only (bit-equal to the convolution with a field whose first c columns are zero)."""
+    from craft_amd.hip import call, W_PACKED
+    B, N, C = 2, 301, 128
+    dy, dy2buf, y = gen(B, N, C, seed=160).to(device), gen(B, N, 384, seed=161).to(device), gen(B, N, 200, seed=162).to(device)
+    dy2 = dy2buf[..., 128:256]
+    ref = torch.empty(B, N, C, device=device)
+    s_ = dy + dy2
+    call("craft_act_bwd", s_, C, y, y.stride(-2), ref, C, B * N, C, ACT_RELU, 1.0)
+    ref[..., 126:] = 0.0
+    out = dy.clone()
+    call("craft_act_bwd2", out, C, dy2, dy2.stride(-2), y, y.stride(-2), out, C, B * N, C, ACT_RELU, 1.0, 2)      # in place over dy
+    assert torch.equal(out, ref)
+    out = torch.empty_like(dy)
+    call("craft_act_bwd2", dy, C, None, 0, y, y.stride(-2), out, C, B * N, C, ACT_RELU, 0.5, 0)
+    ref2 = torch.empty_like(dy)
+    call("craft_act_bwd", dy, C, y, y.stride(-2), ref2, C, B * N, C, ACT_RELU, 0.5)
+    assert torch.equal(out, ref2)
+    H8, W8, cin, cout = 9, 14, 128, 384
+    x = gen(B, H8 * W8, cin, seed=163).to(device)
+    w = (gen(cout, cin, 1, 5, seed=164) / math.sqrt(5 * cin)).to(device)
+    wp = ops.pack_conv_weights(w, PREC_F16X3)
+    field = gen(B, H8 * W8, cout, seed=165).to(device)
+    fz = field.clone()
+    fz[..., :128] = 0.0
+    a, b = torch.empty(B, H8 * W8, cout, device=device), torch.empty(B, H8 * W8, cout, device=device)
+    call("craft_conv2d_nhwc2", x, cin, cin, None, 0, 0, wp, None, field, cout, cout, 1, 5, ACT_NONE, a, cout, B, H8, W8, PREC_F16X3 | W_PACKED | ((128 // 32) << 16))
+    call("craft_conv2d_nhwc2", x, cin, cin, None, 0, 0, wp, None, fz, cout, cout, 1, 5, ACT_NONE, b, cout, B, H8, W8, PREC_F16X3 | W_PACKED)
+    assert torch.equal(a, b)
 
 
 def test_forward_interpolate(device):
