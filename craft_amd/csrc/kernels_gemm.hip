@@ -259,6 +259,9 @@ static int launch_rows_wf(const RowsGemmParams& p, int prec, hipStream_t s) {
 //   * V^T never touches LDS: each B operand is one coalesced 1 KiB load (L2 hit) straight into MFMA registers,
 //     re-requested for the next tile right after its last use; one barrier per K-tile.
 // ---------------------------------------------------------------------------------------------
+#ifndef CRAFT_PV_ABL
+#define CRAFT_PV_ABL 0      // developer ablation (tools/build_variant.py -DCRAFT_PV_ABL=n): 1 no MFMAs, 2 no A-fragment LDS reads, 4 V^T fragments loaded once
+#endif
 template <int PREC, int MT>
 __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
   typedef typename PrecT<PREC>::lds_t lds_t;
@@ -331,14 +334,26 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       frag_t a[MT];
+#if !(CRAFT_PV_ABL & 2)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const frag_t*>(&As[(mt * 32 + r) * LD + kk * 16 + g8]);
+#else
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = bq[(kk + mt) & 3];
+#endif
+#if !(CRAFT_PV_ABL & 1)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         if constexpr (PREC == CRAFT_PREC_BF16) acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], bq[kk], acc[mt][0], 0, 0, 0);
         else acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bq[kk], acc[mt][0], 0, 0, 0);
       }
+#else
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) asm volatile("" :: "v"(a[mt]), "v"(bq[kk]));
+#endif
+#if !(CRAFT_PV_ABL & 4)
       fetch_b(kt + 1, kk);
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     store(kt + 1, vnear);
