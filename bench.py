@@ -153,8 +153,10 @@ def roofline_flash(model, im1, im2, iters, prec, forwards=3):
     flops = 2.0 * 1280 * N * N * B
     executed = 2.0 * ((3 if x3 else 1) * 256 + 1024) * N * N * B
     ach = flops / (ms * 1e-3) / 1e12
-    e = pmc_lookup("k_flash_attn<64, 256, 2>" if x3 else "k_flash_attn<64, 256, 1>", "flash", B, H8, W8)
-    return {"bound": "mfma", "kernel": "k_flash_attn (F2 feature transformer: scores + online softmax + P.V fused, 1 launch per forward; + 2 k_pack_qk)",
+    v1 = bool(os.environ.get("CRAFT_FLASH_V1"))                      # (the round-4 kernel, kept behind the switch for A/B)
+    name = "k_flash_attn" if v1 else "k_flash_attn2"
+    e = pmc_lookup(f"{name}<64, 256, 2>" if x3 else f"{name}<64, 256, 1>", "flash", B, H8, W8)
+    return {"bound": "mfma", "kernel": "k_flash_attn2 (F2 feature transformer: scores + online softmax + P.V fused, 1 launch per forward; + 2 k_pack_qk)",
             "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
             "executed_frac": round(executed / (ms * 1e-3) / 1e12 / 2500.0, 4), "flops_per_launch": flops, "ms_per_launch": round(ms, 4),
             "launches_timed": len(evs), "mfma_busy": e.get("mfma_busy") if e else None, "traffic": e.get("hbm_bytes_per_launch") if e else None,
