@@ -260,7 +260,7 @@ static int launch_rows_wf(const RowsGemmParams& p, int prec, hipStream_t s) {
 //     re-requested for the next tile right after its last use; one barrier per K-tile.
 // ---------------------------------------------------------------------------------------------
 #ifndef CRAFT_PV_ABL
-#define CRAFT_PV_ABL 0      // developer ablation (tools/build_variant.py -DCRAFT_PV_ABL=n): 1 no MFMAs, 2 no A-fragment LDS reads, 4 V^T fragments loaded once
+#define CRAFT_PV_ABL 0      // developer ablation (tools/build_variant.py -DCRAFT_PV_ABL=n): 1 no MFMAs (| 8: s_sleep for their issue time instead), 2 no A-fragment LDS reads, 4 V^T fragments loaded once
 #endif
 template <int PREC, int MT>
 __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
@@ -350,6 +350,10 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
 #else
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) asm volatile("" :: "v"(a[mt]), "v"(bq[kk]));
+#if CRAFT_PV_ABL & 8                       // ... and the wave idles for about the MFMAs' issue time instead (7 x 32 cycles per k-step)
+      __builtin_amdgcn_s_sleep(3);
+      __builtin_amdgcn_s_sleep(1);
+#endif
 #endif
 #if !(CRAFT_PV_ABL & 4)
       fetch_b(kt + 1, kk);
