@@ -235,7 +235,8 @@ def roofline_pv(model, im1, im2, iters, prec, forwards=3):
             "note": "timed live around every launch of real forward passes (HIP events on the launch stream); algorithmic bytes "
                     "= P (fp16, read once) + V^T + O; traffic = HBM bytes per launch from the PMC passes committed under "
                     "profiles/r5/pmc_kernels.json, else profiles/r4 (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; null when the live kernel instantiation is not the profiled one); measured read-only ceiling of this access pattern "
-                    "on the same chip: 6.1 TB/s (tools/ubench/hbm_rows.hip)"}
+                    "on the same chip: 6.1 TB/s plain / 6.9 TB/s non-temporal with NO arithmetic (tools/ubench/hbm_rows_dma.hip); with the P.V MFMAs on, the "
+                    "package sits at its 1400 W limit and sclk falls 2.4 -> 1.58 GHz (profiles/r5/pv16_power.txt): the kernel is bound by the power cap"}
 
 
 def roofline_conv(B, H8, W8, prec, reps=20):
