@@ -118,7 +118,7 @@ def main():
         im1, im2, _ = synth_pair(B, 448, 1024, seed=0)
         raw = torch.cat([im1, im2]).cuda() if which == "fnet" else im1.cuda()
         enc = m._henc_f if which == "fnet" else m._henc_c
-        for _ in range(2):
+        for _ in range(int(os.environ.get("REPS", 2))):
             enc.forward_tokens(raw, prec)
     elif which in ("wgrad", "gemm_tt"):
         from craft_amd import hip as H
@@ -142,7 +142,7 @@ def main():
         k = torch.randn(B, N, C, device=dev)
         tab = torch.randn(15, 15, device=dev)
         pyr = ops.CorrPyramid(B, H8, W8, 4, dev)
-        for _ in range(2):
+        for _ in range(int(os.environ.get("REPS", 2))):
             ops.corr_build(q, k, H8, W8, Mm, 1 / math.sqrt(C // Mm), tab, 0.5, 0.7, None, pyr, True, prec)
     elif which in ("probs", "probs_norm"):
         import math
