@@ -38,6 +38,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # RCCL across ranks needs dmabuf IPC on this driver (must be set before HIP initialises)
 
 import torch  # noqa: E402
 
