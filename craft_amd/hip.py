@@ -290,6 +290,30 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Developer switch (tools/guard_run.py): CRAFT_HIP_DEBUG=<file> writes every entry point's name and arguments to <file> (rewound each call,
+# so the file of a dead process holds the LAST call) and synchronises the device after the call, so an asynchronous GPU fault is raised
+# inside the call that caused it.  Off (the default) the call path is untouched.
+_DEBUG_PATH = os.environ.get("CRAFT_HIP_DEBUG", "")
+_debug_file, _debug_n = None, [0]
+
+
+def _debug_note(name, args, conv):
+    global _debug_file
+    if _debug_file is None:
+        _debug_file = open(_DEBUG_PATH, "w")
+    _debug_n[0] += 1
+    desc = []
+    for a, c in zip(args, conv):
+        if isinstance(a, torch.Tensor):
+            desc.append(f"T{tuple(a.shape)}:{str(a.dtype)[6:]}@{c:#x}+{a.numel() * a.element_size()}/{a.untyped_storage().nbytes() - (c - a.untyped_storage().data_ptr())}")
+        else:
+            desc.append(repr(c))
+    _debug_file.seek(0)
+    _debug_file.write(f"#{_debug_n[0]} {name}({', '.join(desc)})\n")
+    _debug_file.truncate()
+    _debug_file.flush()
+
+
 def call(name: str, *args):
     lib = load()
     conv = []
@@ -298,10 +322,14 @@ def call(name: str, *args):
             conv.append(_ptr(a))
         else:
             conv.append(a)
+    if _DEBUG_PATH:
+        _debug_note(name, args, conv)
     rc = getattr(lib, name)(*conv, _stream())
     if rc != 0:
         msg = lib.craft_hip_error_string(rc).decode()
         raise CraftHipError(f"{name} failed with code {rc}: {msg}")
+    if _DEBUG_PATH:
+        torch.cuda.synchronize()
 
 
 _CARRAY_TYPES = {}
@@ -357,6 +385,7 @@ class ZeroPool:
 
 _ELEM_SIZE = {torch.float32: 4, torch.float64: 8, torch.int32: 4, torch.int64: 8, torch.int16: 2, torch.uint8: 1, torch.float16: 2, torch.bfloat16: 2}
 _POOL = [None]
+_NO_ZERO_POOL = bool(os.environ.get("CRAFT_NO_ZERO_POOL"))      # developer switch: every piece its own allocation (guard-page runs)
 
 
 def set_zero_pool(pool):
@@ -366,7 +395,7 @@ def set_zero_pool(pool):
 
 def zeros(shape, device, dtype=torch.float32):
     """A zero-initialised per-step temporary (see ZeroPool); plain torch.zeros outside a training step."""
-    pool = _POOL[0]
+    pool = None if _NO_ZERO_POOL else _POOL[0]
     return pool.zeros(shape, device, dtype) if pool is not None else torch.zeros(shape, device=device, dtype=dtype)
 
 
