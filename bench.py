@@ -337,7 +337,7 @@ def self_launch(n: int) -> int:
 
 # configs[3] runs the library's default policy "mixed" -- the policy of the inference headline: f16x3 (fp32-class) operands for projections,
 # scores and every convolution, fp16 operands for the attention products P.V / dV / dP (legal in training under the Trainer's loss scale);
-# gradient parity at this shape and depth: tests/test_train_backward.py::test_training_step_at_configs3_size_against_oracle[...mixed].
+# gradient parity at this shape and depth: tests/test_cfg_step_parity.py::test_training_step_at_configs3_size_against_oracle[...mixed].
 # `--precision train_f16x3` times the all-f16x3 policy (+8 % step time), the `amp_fp16` sub-leg the reference's --mixed_precision arithmetic.
 TRAIN_CFG = {3: (368, 496, 8, "mixed", "configs[3]: FlyingChairs-size 368x496, batch 8/GPU"),
              4: (368, 768, 4, "train_bf16attn", "configs[4]: Sintel-crop 368x768, batch 4/GPU, bf16 MFMA attention")}

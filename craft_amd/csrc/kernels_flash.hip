@@ -256,7 +256,8 @@ __global__ __launch_bounds__(512) void k_flash_attn2(FlashParams p) {
   constexpr int NS = 3;
   __shared__ __attribute__((aligned(1024))) uint16_t St[NS * TILE_H];
   __shared__ float s_tab[FLASH_TABW * FLASH_TABW];
-  __shared__ unsigned s_need[2048 / 32 + 2];        // bit t: tile t takes the bias / mask / ragged path (N < 65536: at most 2048 tiles)
+  __shared__ unsigned s_need[2048 / 32 + 16];       // bit t: tile t takes the bias / mask / ragged path (N < 65536: at most 2048 tiles; the fill loop below
+                                                    // writes whole 512-tile rounds up to tile nkt: 16 words past word nkt / 32 at nkt = 2048)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nqx = (p.N + 255) / 256, total = nqx * p.B * p.M;

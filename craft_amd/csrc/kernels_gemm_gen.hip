@@ -476,7 +476,7 @@ int launch_conv_wgrad(const float* x, long ldx, int cin, const float* dy, long l
                     else if (bn == 128 && sb) hipLaunchKernelGGL((k_conv_wgrad<PR, 128, true>), grid, dim3(NTHREADS), 0, s, p); \
                     else if (bn == 128) hipLaunchKernelGGL((k_conv_wgrad<PR, 128, false>), grid, dim3(NTHREADS), 0, s, p); \
                     else hipLaunchKernelGGL((k_conv_wgrad<PR, 64, false>), grid, dim3(NTHREADS), 0, s, p); \
-                    if (hipGetLastError() != hipSuccess) return (int)hipGetLastError(); \
+                    { const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } \
                     return p.ws ? launch_reduce_replicas(p.ws, p.ksplit, (int)nw, dW, s) : 0; } while (0)
   if (prec == CRAFT_PREC_F32) GO(CRAFT_PREC_F32);
   if (prec == CRAFT_PREC_BF16) GO(CRAFT_PREC_BF16);

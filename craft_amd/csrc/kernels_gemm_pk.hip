@@ -171,7 +171,7 @@ int launch_pack_operands(const long* descs, int n, hipStream_t s) {
     }
     pb.first_block[pb.n] = blocks;
     hipLaunchKernelGGL(k_pack_operands, dim3((unsigned)blocks), dim3(256), 0, s, pb);
-    if (hipGetLastError() != hipSuccess) return (int)hipGetLastError();
+    { const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; }
   }
   return 0;
 }

@@ -1279,7 +1279,8 @@ int launch_multi_copy(const void* const* src, const long* n, const long* dst_off
     if (blocks >= (1L << 31)) return CRAFT_ERR_UNSUPPORTED;
     m.first[m.count] = (unsigned)blocks;
     if (blocks > 0) hipLaunchKernelGGL(k_multi_copy, dim3((unsigned)blocks), dim3(256), 0, s, m, dst);
-    if (hipGetLastError() != hipSuccess) return (int)hipGetLastError();
+    const hipError_t e = hipGetLastError();          // (read ONCE: the call clears the sticky error)
+    if (e != hipSuccess) return (int)e;
   }
   return 0;
 }

@@ -51,6 +51,43 @@ class FlowMetrics:
         return out
 
 
+def shift_pixels(img: torch.Tensor, flow: Optional[torch.Tensor], xy_shift):
+    """evaluate.py:44-89 (the shift-robustness experiment of shifteval.sh): frame 1 moved by (x_shift, y_shift) pixels, vacated
+    pixels zero, the ground truth moved with it and reduced by the shift -> (img, flow, mask [H, W] bool: pixels that still hold
+    image content).  None / (0, 0): unchanged, mask all true.  Like the reference, only shifts with BOTH components non-zero move
+    anything (its four quadrant branches test `> 0` / `< 0` on both axes, :64-83): a shift along one axis alone yields an all-zero
+    frame 1 and an empty mask there, and does here."""
+    if xy_shift is None or (int(xy_shift[0]) == 0 and int(xy_shift[1]) == 0):
+        return img, flow, torch.ones(img.shape[-2:], dtype=torch.bool, device=img.device)
+    xs, ys = int(xy_shift[0]), int(xy_shift[1])
+    H, W = img.shape[-2:]
+    img2 = torch.zeros_like(img)
+    flow2 = None if flow is None else torch.zeros_like(flow)
+    mask = torch.zeros(H, W, dtype=torch.bool, device=img.device)
+    if xs != 0 and ys != 0 and abs(xs) < W and abs(ys) < H:
+        dst_y, src_y = (slice(ys, None), slice(None, -ys)) if ys > 0 else (slice(None, ys), slice(-ys, None))
+        dst_x, src_x = (slice(xs, None), slice(None, -xs)) if xs > 0 else (slice(None, xs), slice(-xs, None))
+        img2[..., dst_y, dst_x] = img[..., src_y, src_x]
+        mask[dst_y, dst_x] = True
+        if flow is not None:
+            flow2[..., dst_y, dst_x] = flow[..., src_y, src_x]
+    if flow2 is not None:
+        off = torch.tensor([xs, ys], dtype=flow2.dtype, device=flow2.device).reshape([1, 2, 1, 1] if flow2.dim() == 4 else [2, 1, 1])
+        flow2 = flow2 - off                               # (u, v) = (x, y): the content of frame 1 moved, its displacement shrinks
+    return img2, flow2, mask
+
+
+def _shifted(image1, flow_gt, xy_shift, valid=None):
+    """shift frame 1 and its ground truth; -> (image1, flow_gt, valid [B, H, W] float or None, gt_offset for the magnitude bins).
+    KITTI's sparse validity map is NOT moved with the flow in the reference, only masked (evaluate.py:812-814): same here."""
+    if xy_shift is None:
+        return image1, flow_gt, valid, (0.0, 0.0)
+    image1, flow_gt, mask = shift_pixels(image1, flow_gt, xy_shift)
+    m = mask.unsqueeze(0).expand(image1.shape[0], -1, -1).float()
+    valid = m if valid is None else valid.to(m.device).float() * m
+    return image1, flow_gt, valid, (float(xy_shift[0]), float(xy_shift[1]))
+
+
 def _predict(model, image1, image2, iters, pad_mode, device, flow_init=None):
     """pad -> forward (test_mode=1) -> unpad; images [B, 3, H, W] float 0..255 on any device."""
     image1, image2 = image1.to(device), image2.to(device)
@@ -69,31 +106,39 @@ def _batches(ds: FlowDataset, batch_size: int, max_count: int):
 
 @torch.no_grad()
 def validate_chairs(model, root="datasets/FlyingChairs_release/data", iters=6, batch_size=1, split_file=None, max_val_count=-1,
-                    device="cuda"):
-    """FlyingChairs validation split (evaluate.py:248-280) -> {'chairs_epe': mean EPE over all pixels}."""
+                    device="cuda", xy_shift=None):
+    """FlyingChairs validation split (evaluate.py:248-280) -> {'chairs_epe': mean EPE over all pixels}; ``xy_shift`` = (x, y):
+    frame 1 and its ground truth shifted first, EPE over the pixels that kept content (:270-276)."""
     model.eval()
+    if xy_shift is not None:
+        print(f"Apply x,y shift {int(xy_shift[0])},{int(xy_shift[1])}")
     ds = FlyingChairs(split="validation", root=root, split_file=split_file)
     m = FlowMetrics(device)
     for image1, image2, flow_gt, _ in _batches(ds, batch_size, max_val_count):
+        image1, flow_gt, valid, off = _shifted(image1.to(device), flow_gt.to(device), xy_shift)
         _, flow = _predict(model, image1, image2, iters, "sintel", device)
-        m.update(flow, flow_gt)
+        m.update(flow, flow_gt, valid, gt_offset=off)
     r = m.result()
     print("Validation Chairs EPE: %f" % r["epe"])
     return {"chairs_epe": r["epe"]}
 
 
 @torch.no_grad()
-def validate_sintel(model, root="datasets/Sintel", iters=6, dstype="both", batch_size=1, max_val_count=-1, device="cuda"):
+def validate_sintel(model, root="datasets/Sintel", iters=6, dstype="both", batch_size=1, max_val_count=-1, device="cuda", xy_shift=None):
     """MPI-Sintel training split, clean and/or final pass (evaluate.py:445-602) -> {dstype: mean EPE}; prints the
-    1/3/5 px rates and the EPE per ground-truth magnitude range like the reference."""
+    1/3/5 px rates and the EPE per ground-truth magnitude range like the reference.  ``xy_shift``: the shift experiment
+    (:510-511; the magnitude ranges are those of the UNSHIFTED ground truth, :534)."""
     model.eval()
+    if xy_shift is not None:
+        print(f"Apply x,y shift {int(xy_shift[0])},{int(xy_shift[1])}")
     results = {}
     for dst in (["clean", "final"] if dstype == "both" else [dstype]):
         ds = MpiSintel(split="training", root=root, dstype=dst)
         m = FlowMetrics(device)
         for image1, image2, flow_gt, _ in _batches(ds, batch_size, max_val_count):
+            image1, flow_gt, valid, off = _shifted(image1.to(device), flow_gt.to(device), xy_shift)
             _, flow = _predict(model, image1, image2, iters, "sintel", device)
-            m.update(flow, flow_gt)                      # the reference counts every pixel here (val_mask is all ones)
+            m.update(flow, flow_gt, valid, gt_offset=off)     # (no shift: the reference counts every pixel, val_mask is all ones)
         r = m.result()
         line = "Iter 0, Valid (%s) EPE: %f, 1px: %f, 3px: %f, 5px: %f" % (dst, r["epe"], r["px1"], r["px3"], r["px5"])
         lo = 0
@@ -107,15 +152,18 @@ def validate_sintel(model, root="datasets/Sintel", iters=6, dstype="both", batch
 
 
 @torch.no_grad()
-def validate_kitti(model, root="datasets/KITTI", iters=6, batch_size=1, max_val_count=-1, device="cuda"):
+def validate_kitti(model, root="datasets/KITTI", iters=6, batch_size=1, max_val_count=-1, device="cuda", xy_shift=None):
     """KITTI-2015 training split (evaluate.py:757-927): sparse ground truth, bottom padding; -> {'epe', 'f1'} with
     f1 = 100 * mean(epe > 3 and epe / |gt| > 0.05) over valid pixels."""
     model.eval()
+    if xy_shift is not None:
+        print(f"Apply x,y shift {int(xy_shift[0])},{int(xy_shift[1])}")
     ds = KITTI(split="training", root=root)
     m = FlowMetrics(device)
     for image1, image2, flow_gt, valid_gt in _batches(ds, batch_size, max_val_count):
+        image1, flow_gt, valid_gt, off = _shifted(image1.to(device), flow_gt.to(device), xy_shift, valid_gt)
         _, flow = _predict(model, image1, image2, iters, "kitti", device)
-        m.update(flow, flow_gt, valid_gt)
+        m.update(flow, flow_gt, valid_gt, gt_offset=off)
     r = m.result()
     print("Iter 0, Valid EPE: %.4f, F1: %.4f, 1px: %.4f, 3px: %.4f, 5px: %.4f" % (r["epe"], r["f1"], r["px1"], r["px3"], r["px5"]))
     return {"epe": r["epe"], "f1": r["f1"], "metrics": r}
@@ -186,16 +234,24 @@ def main(argv=None):
     ap.add_argument("--trust-checkpoint", dest="trust_checkpoint", action="store_true",
                     help="allow the full unpickler if the safe one (tensors + numpy scalars) cannot read the file")
     ap.add_argument("--warm_start", action="store_true", help="sintel_submission: initialise each frame with the previous flow")
+    ap.add_argument("--xshifts", dest="x_shifts", default=None, help="comma-separated x shifts of frame 1 (evaluate.py:1469; shifteval.sh)")
+    ap.add_argument("--yshifts", dest="y_shifts", default=None, help="comma-separated y shifts, paired with --xshifts")
     ns = ap.parse_args(argv)
     ns.mixed_precision = bool(ns.mixed_precision)
     model = build_model(ns)
-    if ns.dataset == "chairs":
-        return validate_chairs(model, ns.root or "datasets/FlyingChairs_release/data", ns.iters or 6, ns.batch_size,
-                               max_val_count=ns.max_val_count)
-    if ns.dataset == "sintel":
-        return validate_sintel(model, ns.root or "datasets/Sintel", ns.iters or 32, ns.dstype, ns.batch_size, ns.max_val_count)
-    if ns.dataset == "kitti":
-        return validate_kitti(model, ns.root or "datasets/KITTI", ns.iters or 24, ns.batch_size, ns.max_val_count)
+    # evaluate.py:1572-1577, :1604: one validation pass per (x, y) pair
+    shifts = list(zip([int(x) for x in ns.x_shifts.split(",")], [int(y) for y in ns.y_shifts.split(",")])) if ns.x_shifts and ns.y_shifts else [None]
+    if ns.dataset in ("chairs", "sintel", "kitti"):
+        out = None
+        for xy in shifts:
+            if ns.dataset == "chairs":
+                out = validate_chairs(model, ns.root or "datasets/FlyingChairs_release/data", ns.iters or 6, ns.batch_size,
+                                      max_val_count=ns.max_val_count, xy_shift=xy)
+            elif ns.dataset == "sintel":
+                out = validate_sintel(model, ns.root or "datasets/Sintel", ns.iters or 32, ns.dstype, ns.batch_size, ns.max_val_count, xy_shift=xy)
+            else:
+                out = validate_kitti(model, ns.root or "datasets/KITTI", ns.iters or 24, ns.batch_size, ns.max_val_count, xy_shift=xy)
+        return out
     if ns.dataset == "sintel_submission":
         return create_sintel_submission(model, ns.root or "datasets/Sintel", ns.output or "sintel_submission", ns.iters or 32,
                                         warm_start=ns.warm_start)

@@ -323,6 +323,7 @@ class CRAFT(nn.Module):
             for pt, st in zip(parts, streams):
                 with torch.cuda.stream(st):
                     pt["ws"] = GMAUpdateBlock.workspace(pt["b"][1] - pt["b"][0], N, dev)
+            self.update_block.encoder.begin_pass()
             for itr in range(iters):
                 for pt, st in zip(parts, streams):
                     with torch.cuda.stream(st):

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import math
 import os
+import threading
 from typing import Optional, Sequence
 
 import torch
@@ -502,47 +503,75 @@ class WeightPackRegistry:
     def invalidate(self):
         self.fresh = False
 
+    @staticmethod
+    def _versions(w0, w1):
+        return (w0._version, w1._version if w1 is not None else -1)
+
     def lookup(self, key):
+        """The packed operand if it holds the CURRENT weights: packed after the last raw-pointer update (the optimizer's epoch) AND the
+        source tensors untouched since (their autograd version counters: load_state_dict / load_checkpoint / any in-place edit between
+        steps moves them -- ADVICE r5)."""
         if self.fresh and self._epoch == hip.weights_epoch():
             e = self.entries.get(key)
-            return e[0] if e is not None else None
+            if e is not None and e[3] == self._versions(*e[1]):
+                return e[0]
         return None
 
     def remember(self, key, out, w0, w1, fill_args):
         if key not in self.entries:
             self._tables = None
-        self.entries[key] = [out, (w0, w1), fill_args]
+        self.entries[key] = [out, (w0, w1), fill_args, self._versions(w0, w1)]
+
+    def prepare(self):
+        """Build (and validate) the batched job table for the current entry set on the host + one upload; raises before anything of the
+        step's update is enqueued (Trainer calls it in front of optimizer.step())."""
+        if not self.entries or self._tables is not None:
+            return
+        import ctypes
+        lib = hip.load()
+        nbytes = int(lib.craft_pack_conv_job_bytes())
+        n = len(self.entries)
+        buf = (ctypes.c_ubyte * (nbytes * n))()
+        first, blocks = [0], 0
+        for i, (out, (w0, w1), fa, _) in enumerate(self.entries.values()):
+            cout0, cout1, Cin, KH, KW, a0, a1, b0, b1, transposed, prec = fa
+            nb = int(lib.craft_pack_conv_job_fill(ctypes.byref(buf, i * nbytes), ctypes.c_void_p(w0.data_ptr()), cout0,
+                                                  ctypes.c_void_p(w1.data_ptr() if w1 is not None else 0), cout1, Cin, KH, KW, a0, a1, b0, b1,
+                                                  transposed, prec, ctypes.c_void_p(out.data_ptr())))
+            if nb < 0:
+                raise hip.CraftHipError(f"craft_pack_conv_job_fill failed with code {-nb}")
+            blocks += nb
+            first.append(blocks)
+        dev = next(iter(self.entries.values()))[0].device
+        jobs = torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(dev)
+        pref = torch.tensor(first, dtype=torch.int32).to(dev)
+        self._tables = (jobs, pref, n, blocks)
 
     def repack(self):
         """All remembered operands from the current weights, one launch (enqueued on the current stream)."""
         if not self.entries:
             return
-        import ctypes
-        lib = hip.load()
-        if self._tables is None:
-            nbytes = int(lib.craft_pack_conv_job_bytes())
-            n = len(self.entries)
-            buf = (ctypes.c_ubyte * (nbytes * n))()
-            first, blocks = [0], 0
-            for i, (out, (w0, w1), fa) in enumerate(self.entries.values()):
-                cout0, cout1, Cin, KH, KW, a0, a1, b0, b1, transposed, prec = fa
-                nb = int(lib.craft_pack_conv_job_fill(ctypes.byref(buf, i * nbytes), ctypes.c_void_p(w0.data_ptr()), cout0,
-                                                      ctypes.c_void_p(w1.data_ptr() if w1 is not None else 0), cout1, Cin, KH, KW, a0, a1, b0, b1,
-                                                      transposed, prec, ctypes.c_void_p(out.data_ptr())))
-                if nb < 0:
-                    raise hip.CraftHipError(f"craft_pack_conv_job_fill failed with code {-nb}")
-                blocks += nb
-                first.append(blocks)
-            dev = next(iter(self.entries.values()))[0].device
-            jobs = torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(dev)
-            pref = torch.tensor(first, dtype=torch.int32).to(dev)
-            self._tables = (jobs, pref, n, blocks)
+        self.prepare()
         jobs, pref, n, blocks = self._tables
         call("craft_pack_conv_weights_batch", jobs, pref, n, blocks)
+        for e in self.entries.values():
+            e[3] = self._versions(*e[1])
         self.fresh, self._epoch = True, hip.weights_epoch()
 
 
-ACTIVE_WEIGHT_PACKS = [None]        # the registry of the trainer whose step is running (train.Trainer.step), else None
+class _ActivePacks(threading.local):
+    """The registry of the trainer whose step is running ON THIS THREAD (train.Trainer.step), else None: a second trainer or a validation
+    forward on another thread sees its own slot (the backward modes of autograd.py are thread-local for the same reason)."""
+    reg = None
+
+    def __getitem__(self, i):
+        return self.reg
+
+    def __setitem__(self, i, v):
+        self.reg = v
+
+
+ACTIVE_WEIGHT_PACKS = _ActivePacks()
 
 
 def pack_conv_weights(w0: torch.Tensor, prec: int, w1: Optional[torch.Tensor] = None, sel=None, transposed: bool = False) -> torch.Tensor:

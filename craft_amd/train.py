@@ -520,6 +520,8 @@ class Trainer:
         if self.reference_loss_scaling:
             mul = mul / self._world()
         # (the flat gradient buffer holds loss_scale x the gradient: un-scaled on the device, craft_loss_scale_update)
+        if self._weight_packs is not None and image1.is_cuda:
+            self._weight_packs.prepare()                               # (host-side job table: fails HERE, before the weights move)
         opt.step(lr=self.scheduler.get_last_lr()[0], max_norm=self.clip, grad_mul=mul)
         if self._weight_packs is not None and image1.is_cuda:
             self._weight_packs.repack()                                # every conv-weight operand of the next step, one launch (71 before)
@@ -568,7 +570,7 @@ def load_checkpoint(path: str, model: torch.nn.Module, optimizer: Optional[FlatA
     ``Trainer.sync_replicas(src)``."""
     from .utils import load_checkpoint as load_model, read_checkpoint
     ck = read_checkpoint(path, trusted=trusted)
-    msg = load_model(model, ck)
+    msg = load_model(model, ck)             # (bumps the weights epoch: every packed-weight cache re-packs on its next use)
     if optimizer is not None:                      # load_state_dict re-pointed nothing: the flat views stay valid, but refresh
         for p, off in zip(optimizer.params, optimizer.offsets):      # the flat copy in case a parameter was replaced
             n = p.numel()

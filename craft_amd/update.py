@@ -132,6 +132,11 @@ class SepConvGRU(nn.Module):
              ws, cp | W_PACKED)
 
 
+def _dev_index(device) -> int:
+    """torch.device('cuda') has index None: the streams / events below are keyed on the device torch would actually use."""
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
 class BasicMotionEncoder(nn.Module):
     def __init__(self, args):
         super().__init__()
@@ -164,7 +169,7 @@ class BasicMotionEncoder(nn.Module):
         """(side stream, event) for the flow branch, one pair per calling stream: the C ABI owns no stream or event
         (include/craft_hip.h), the caller hands them in."""
         cache = self.__dict__.setdefault("_side", {})
-        key = (device.index, torch.cuda.current_stream().cuda_stream)
+        key = (_dev_index(device), torch.cuda.current_stream().cuda_stream)
         if key not in cache:
             st, ev = torch.cuda.Stream(device=device), torch.cuda.Event()
             ev.record(st)                       # torch creates the hipEvent_t lazily: materialise the handle
@@ -180,7 +185,13 @@ class BasicMotionEncoder(nn.Module):
             return
         side, _ = self._flow_side(device)
         side.wait_stream(torch.cuda.current_stream())
-        self.__dict__.setdefault("_preforked", set()).add((device.index, torch.cuda.current_stream().cuda_stream))
+        self.__dict__.setdefault("_preforked", set()).add((_dev_index(device), torch.cuda.current_stream().cuda_stream))
+
+    def begin_pass(self):
+        """Forget head starts that were announced but never consumed (a prefork() followed by fork=False or by an exception): a stale entry
+        would let a later forward_tokens skip its wait and read `flow` / `ws` before they are final.  network.py calls this in front of
+        every refinement loop."""
+        self.__dict__.pop("_preforked", None)
 
     def forward_tokens(self, flow: torch.Tensor, corr: torch.Tensor, hw, out: torch.Tensor, ws: torch.Tensor, prec: int,
                        fork: bool = True):
@@ -191,9 +202,11 @@ class BasicMotionEncoder(nn.Module):
         cp = conv_group_prec(prec, "menc")
         wc1, bc1, wc2, bc2, wf1, bf1, wf2, bf2, wcv, bcv = self.packed(cp)
         st = ev = None
+        if not fork and self.__dict__.get("_preforked"):
+            self._preforked.discard((_dev_index(flow.device), torch.cuda.current_stream().cuda_stream))      # an unused head start dies here
         if fork and not os.environ.get("CRAFT_NO_FORK"):
             side, event = self._flow_side(flow.device)
-            key = (flow.device.index, torch.cuda.current_stream().cuda_stream)
+            key = (_dev_index(flow.device), torch.cuda.current_stream().cuda_stream)
             pre = self.__dict__.get("_preforked")
             if pre and key in pre:
                 pre.discard(key)                                # (prefork(): the side stream already waits for the caller's earlier position)

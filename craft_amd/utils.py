@@ -99,4 +99,7 @@ def load_checkpoint(model: torch.nn.Module, path_or_dict, strict: bool = False, 
     ck = read_checkpoint(path_or_dict, trusted) if isinstance(path_or_dict, str) else path_or_dict
     sd = ck["model"] if isinstance(ck, dict) and "model" in ck else ck
     sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
-    return model.load_state_dict(sd, strict=strict)
+    msg = model.load_state_dict(sd, strict=strict)
+    from .hip import bump_weights_epoch
+    bump_weights_epoch()              # packed / folded weight caches (and a trainer's batched re-pack registry) must not outlive the load
+    return msg

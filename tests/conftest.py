@@ -42,6 +42,26 @@ def _say(request, msg: str) -> None:
         sys.stderr.flush()
 
 
+_FAULT_FILE = []
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _compact_fatal_signal_tail():
+    """A process killed by SIGABRT / SIGSEGV (the HSA runtime aborts on a GPU memory fault) must end its log with the runtime's own
+    message and the `[gpu-test]` line of the guilty test -- not with the ~70 pluggy frames of faulthandler's Python traceback, which
+    filled the whole tail the driver keeps of round 5's dead run.  The traceback still exists: it goes to CRAFT_FAULT_LOG
+    (default /tmp/craft_pytest_fault.txt) instead of stderr."""
+    import faulthandler
+    try:
+        f = open(os.environ.get("CRAFT_FAULT_LOG", "/tmp/craft_pytest_fault.txt"), "w")
+    except OSError:
+        yield
+        return
+    _FAULT_FILE.append(f)                       # (faulthandler keeps the descriptor, not the object: it must stay open)
+    faulthandler.enable(file=f, all_threads=True)
+    yield
+
+
 @pytest.fixture(autouse=True)
 def _charge_gpu_faults_to_their_author(request):
     """Every `gpu` test (a) announces its id on the real stderr before it starts and (b) ends with a device-wide synchronise, so an

@@ -3,6 +3,7 @@ which compiles validate_chairs / validate_sintel / validate_kitti / shift_pixels
 sequence_loss from train.py's, and runs them here on synthetic data with a deterministic stand-in for the network).
 
 CPU: ``InputPadder`` against the pads and padded tensors of the reference's class.
+CPU: ``shift_pixels`` against the reference function's outputs (the shift-robustness experiment, shifteval.sh).
 GPU: our validate_* drivers (file formats -> pad -> model -> unpad -> craft_flow_metrics) on the same data written to disk in
 the datasets' own formats must return what the reference's functions returned; our ``sequence_loss`` kernel must return the
 reference's loss, metrics and gradients."""
@@ -28,6 +29,22 @@ def test_input_padder_matches_reference_table():
         (xp,) = p.pad(x)
         assert np.array_equal(xp.numpy(), Z[f"padder.{mode}.padded"])
         assert torch.equal(p.unpad(xp), x)
+
+
+def test_shift_pixels_matches_the_reference_function():
+    """craft_amd.evaluate.shift_pixels against the outputs of the reference's own function (evaluate.py:44-89): the four quadrants, a
+    shift along one axis only (moves nothing there either), (0, 0), and a 3-D (unbatched) input."""
+    from craft_amd.evaluate import shift_pixels
+    img, flow = torch.from_numpy(Z["shiftpx.img"]), torch.from_numpy(Z["shiftpx.flow"])
+    for i, xy in enumerate(Z["shiftpx.cases"].tolist()):
+        a, b, m = shift_pixels(img.clone(), flow.clone(), tuple(xy))
+        assert np.array_equal(a.numpy(), Z[f"shiftpx.{i}.img"]), xy
+        assert np.array_equal(b.numpy(), Z[f"shiftpx.{i}.flow"]), xy
+        assert np.array_equal(m.numpy(), Z[f"shiftpx.{i}.mask"]), xy
+    a, b, _ = shift_pixels(img[0].clone(), flow[0].clone(), (3, 2))
+    assert np.array_equal(a.numpy(), Z["shiftpx.3d.img"]) and np.array_equal(b.numpy(), Z["shiftpx.3d.flow"])
+    a, b, m = shift_pixels(img, None, None)
+    assert a is img and b is None and bool(m.all())
 
 
 class StandInNet(torch.nn.Module):
@@ -73,6 +90,17 @@ def test_validate_drivers_return_the_reference_numbers(device, tmp_path):
             mags.append(m[f"epe_{lo}-{hi}"])
             lo = hi
         assert mags == pytest.approx(Z[f"sintel.{dst}.mag"].tolist(), abs=5.1e-3)                               # printed with .2f
+        if dst == "clean":        # the shift experiment of shifteval.sh (xy_shift, evaluate.py:510-534) on the same tree
+            for i, xy in enumerate(Z["shiftval.sintel"].tolist()):
+                sres = evaluate.validate_sintel(net, root=str(root), iters=4, dstype="clean", batch_size=2, device=device, xy_shift=tuple(xy))
+                assert sres["clean"] == pytest.approx(float(Z[f"shiftval.sintel.{i}.epe"]), rel=2e-6), xy
+                sm = sres["clean_metrics"]
+                assert [sm["px1"], sm["px3"], sm["px5"]] == pytest.approx(Z[f"shiftval.sintel.{i}.px"].tolist(), abs=1e-6)
+                lo, smag = 0, []
+                for hi in evaluate.MAG_ENDPOINTS:
+                    smag.append(sm[f"epe_{lo}-{hi}"])
+                    lo = hi
+                assert smag == pytest.approx(Z[f"shiftval.sintel.{i}.mag"].tolist(), abs=5.1e-3)
     # ---- KITTI layout: sparse ground truth as 16-bit PNG (the fixture's flow sits on the 1/64 px grid: lossless)
     kroot = tmp_path / "KITTI"
     (kroot / "training" / "image_2").mkdir(parents=True)
@@ -92,6 +120,10 @@ def test_validate_drivers_return_the_reference_numbers(device, tmp_path):
     assert kres["f1"] == pytest.approx(float(Z["kitti.f1"]), rel=2e-6)
     km = kres["metrics"]
     assert [km["px1"], km["px3"], km["px5"]] == pytest.approx(Z["kitti.px"].tolist(), abs=5.1e-5)               # printed with .4f
+    for i, xy in enumerate(Z["shiftval.kitti"].tolist()):
+        kres = evaluate.validate_kitti(net, root=str(kroot), iters=4, device=device, xy_shift=tuple(xy))
+        assert kres["epe"] == pytest.approx(float(Z[f"shiftval.kitti.{i}.epe"]), rel=2e-6)
+        assert kres["f1"] == pytest.approx(float(Z[f"shiftval.kitti.{i}.f1"]), rel=2e-6)
     # ---- FlyingChairs layout: <id>_img1.ppm / _img2.ppm / _flow.flo + a split file (2 = validation)
     croot = tmp_path / "chairs"
     croot.mkdir()
@@ -104,6 +136,9 @@ def test_validate_drivers_return_the_reference_numbers(device, tmp_path):
     split.write_text("2\n" * nc)
     cres = evaluate.validate_chairs(net, root=str(croot), iters=4, batch_size=2, split_file=str(split), device=device)
     assert cres["chairs_epe"] == pytest.approx(float(Z["chairs.epe"]), rel=2e-6)
+    for i, xy in enumerate(Z["shiftval.chairs"].tolist()):
+        cres = evaluate.validate_chairs(net, root=str(croot), iters=4, batch_size=2, split_file=str(split), device=device, xy_shift=tuple(xy))
+        assert cres["chairs_epe"] == pytest.approx(float(Z[f"shiftval.chairs.{i}.epe"]), rel=2e-6)
 
 
 @pytest.mark.gpu

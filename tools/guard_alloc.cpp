@@ -21,7 +21,7 @@ struct Rec { void* base; size_t reserved, mapped; hipMemGenericAllocationHandle_
 std::mutex mu;
 std::unordered_map<void*, Rec> live;
 size_t gran = 0, guard = 0, n_alloc = 0, bytes_live = 0, bytes_peak = 0;
-int mode_start = -1, fill = -1;
+int mode_start = -1, fill = -1, keep_va = 1;
 
 void die(const char* what, hipError_t e) {
     fprintf(stderr, "[guard_alloc] %s failed: %s\n", what, hipGetErrorString(e));
@@ -45,6 +45,8 @@ extern "C" void* guard_malloc(ssize_t size, int device, hipStream_t) {
         mode_start = (m && !strcmp(m, "start")) ? 1 : 0;
         const char* f = getenv("GUARD_ALLOC_FILL");                        // byte pattern for fresh memory (default 0xFF = NaN): uninitialised reads show
         fill = f ? atoi(f) : 0xFF;
+        const char* kv = getenv("GUARD_ALLOC_KEEP_VA");                    // 1 (default): a freed range's ADDRESSES are never handed out again (a
+        keep_va = kv ? atoi(kv) : 1;                                       // stale GPU TLB entry of a recycled address would alias two tensors)
         fprintf(stderr, "[guard_alloc] granularity %zu B, guard %zu B each side, payload flush against the %s, fill 0x%02x\n", gran, guard,
                 mode_start ? "start" : "end", fill & 0xFF);
     }
@@ -94,8 +96,10 @@ extern "C" void guard_free(void* p, ssize_t, int, hipStream_t) {
     if (e != hipSuccess) die("hipMemUnmap", e);
     e = hipMemRelease(r.h);
     if (e != hipSuccess) die("hipMemRelease", e);
-    e = hipMemAddressFree(r.base, r.reserved);
-    if (e != hipSuccess) die("hipMemAddressFree", e);
+    if (!keep_va) {
+        e = hipMemAddressFree(r.base, r.reserved);
+        if (e != hipSuccess) die("hipMemAddressFree", e);
+    }
     bytes_live -= r.mapped;
 }
 

@@ -147,6 +147,35 @@ def main():
         out["kitti.mag"] = np.array([float(x.split()[1]) for x in m.group(6).strip(", ").split(", ")])
         res, txt = run_captured(ns["validate_chairs"], net, iters=4, test_mode=1, batch_size=2)
         out["chairs.epe"] = np.float64(res["chairs_epe"])
+        # the shift-robustness experiment (evaluate.py:44-89, xy_shift of every validator; shifteval.sh): the reference's validators on
+        # the same sets with frame 1 shifted -- one pair per quadrant of shift_pixels, plus the magnitudes of the UNSHIFTED ground truth
+        shifts = {"sintel": [(7, -5), (-9, 4)], "kitti": [(-6, -4)], "chairs": [(5, 3)]}
+        out["shiftval.sintel"], out["shiftval.kitti"], out["shiftval.chairs"] = (np.array(shifts[k]) for k in ("sintel", "kitti", "chairs"))
+        for i, xy in enumerate(shifts["sintel"]):
+            res, txt = run_captured(ns["validate_sintel"], net, iters=4, test_mode=1, batch_size=2, xy_shift=xy, dstype="clean")
+            out[f"shiftval.sintel.{i}.epe"] = np.float64(res["clean"])
+            rows = re.findall(r"Valid \((\w+)\) EPE: ([\d.]+), 1px: ([\d.]+), 3px: ([\d.]+), 5px: ([\d.]+)((?:, [\d.a-z-]+ [\d.]+)+)", txt)
+            assert len(rows) == 1, txt
+            out[f"shiftval.sintel.{i}.px"] = np.array([float(x) for x in rows[0][2:5]])
+            out[f"shiftval.sintel.{i}.mag"] = np.array([float(x.split()[1]) for x in rows[0][5].strip(", ").split(", ")])
+        for i, xy in enumerate(shifts["kitti"]):
+            res, txt = run_captured(ns["validate_kitti"], net, iters=4, test_mode=1, batch_size=1, xy_shift=xy)
+            out[f"shiftval.kitti.{i}.epe"], out[f"shiftval.kitti.{i}.f1"] = np.float64(res["epe"]), np.float64(res["f1"])
+        for i, xy in enumerate(shifts["chairs"]):
+            res, txt = run_captured(ns["validate_chairs"], net, iters=4, test_mode=1, batch_size=2, xy_shift=xy)
+            out[f"shiftval.chairs.{i}.epe"] = np.float64(res["chairs_epe"])
+        # shift_pixels itself: all four quadrants, a shift along one axis only (moves nothing: see craft_amd.evaluate.shift_pixels), 3-D input
+        gs = torch.Generator().manual_seed(21)
+        pim = torch.randint(0, 256, (2, 3, 11, 14), generator=gs).float()
+        pfl = torch.randn(2, 2, 11, 14, generator=gs) * 4
+        out["shiftpx.img"], out["shiftpx.flow"] = pim.numpy(), pfl.numpy()
+        cases = [(3, 2), (4, -3), (-2, 5), (-1, -6), (0, 3), (5, 0), (0, 0)]
+        out["shiftpx.cases"] = np.array(cases)
+        for i, xy in enumerate(cases):
+            a, b, mk = ns["shift_pixels"](pim.clone(), pfl.clone(), xy)
+            out[f"shiftpx.{i}.img"], out[f"shiftpx.{i}.flow"], out[f"shiftpx.{i}.mask"] = a.numpy(), b.numpy(), mk.numpy()
+        a, b, mk = ns["shift_pixels"](pim[0].clone(), pfl[0].clone(), (3, 2))
+        out["shiftpx.3d.img"], out["shiftpx.3d.flow"] = a.numpy(), b.numpy()
     finally:
         torch.Tensor.cuda = orig_cuda
 
