@@ -16,8 +16,11 @@ Extra objects on the line:
                 forward), timed live with HIP events on the launch stream: algorithmic bytes = the attention
                 probabilities it must stream (B*M*N*ldp*sizeof(P)) + V^T + O, against the 8 TB/s HBM peak
                 (MI355X_MICROARCH.md).
-  roofline_conv the conv engine on its largest K loop, k_conv_halo_wf (SepConvGRU z|r convolution of a refinement
-                step): algorithmic flops / time against the dense MFMA peak.
+  roofline_conv the conv engine IN SITU: HIP events around every craft_sepconv_gru_step call of real forward passes (the four
+                k_conv_halo_wf launches of a SepConvGRU update: z|r and q convolutions of both passes, gates in the epilogues):
+                algorithmic flops / time against the dense MFMA peak; standalone_*: the z|r convolution alone in a 20-launch loop.
+  infer_amp_fp16 the same forward in the reference's own default arithmetic (fp16 operands everywhere, evaluate.py:1455) with its
+                end-point deviation from the fp32-class headline policy; reported beside the headline, never instead of it.
   cpu_baseline  the CPU oracle (oracle/craft_oracle.py, fp32 torch-CPU restatement of the reference's
                 forward) timed on this box's host cores on ONE 448x1024 pair, 12 iterations.
   train_cfg3    a short leg of BASELINE.json configs[3] (training step at 368x496, batch 8/GPU: 6 warm-up + 5 timed steps, same
@@ -276,6 +279,82 @@ def roofline_conv(B, H8, W8, prec, reps=20):
             "ms_per_launch": round(ms, 4),
             "note": "algorithmic (fp32-equivalent) flops; the f16x3 scheme executes 3 fp16 MFMAs per product, so the "
                     "matrix pipe runs at 3x this rate; peak = dense fp16 MFMA (fp32 MFMA for the fp32 policy)"}
+
+
+def roofline_conv_live(model, im1, im2, iters, prec, forwards=3):
+    """The convolution family IN SITU (VERDICT r5 "next" 9): HIP events on the launch stream around every craft_sepconv_gru_step call of
+    real forward passes -- one call = the four halo convolutions of a SepConvGRU update (z|r and q of the 1x5 and the 5x1 pass, 384 ->
+    256 / 128 channels after the context hoist, gates fused into the epilogues; update.py:49-64), the largest convolution group of the
+    refinement loop.  Algorithmic flops per call = 2 * pixels * (256 + 128) * 5 * 384 * 2 passes; under f16x3 the matrix pipe executes
+    3x that."""
+    import craft_amd.update as upd_mod
+    from craft_amd.hip import PREC_F16X3, PREC_F32, pick
+    B, _, H, W = im1.shape
+    N = (H // 8) * (W // 8)
+    orig = upd_mod.call
+    evs = []
+
+    def timed(name, *a):
+        if name != "craft_sepconv_gru_step":
+            return orig(name, *a)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        orig(name, *a)
+        e.record()
+        evs.append((s, e))
+    upd_mod.call = timed
+    try:
+        with torch.no_grad():
+            for _ in range(forwards):
+                model(im1, im2, iters=iters, test_mode=1)
+        torch.cuda.synchronize()
+    finally:
+        upd_mod.call = orig
+    if not evs:
+        return None
+    ms = sum(s.elapsed_time(e) for s, e in evs) / len(evs)
+    cp = pick(prec, "conv")
+    flops = 2.0 * B * N * (256 + 128) * 5 * 384 * 2
+    peak = 157.3 if cp == PREC_F32 else 2500.0
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"ms_per_call": round(ms, 4), "calls_timed": len(evs), "flops_per_call": flops, "achieved": round(ach, 1),
+            "frac": round(ach / peak, 4), "executed_frac": round((3 if cp == PREC_F16X3 else 1) * ach / peak, 4)}
+
+
+def infer_amp_fp16(H, W, B, iters, steps, warmup, dev, seed):
+    """The reference's own default inference arithmetic beside the fp32-class headline (evaluate.py:1455: --mixed_precision is on unless
+    --fullprec; network.py:179-199 runs the encoders and the attention under fp16 autocast): policy `train_amp_fp16` = fp16 MFMA operands
+    in every contraction, fp32 accumulation and activations.  Same weights, pairs and timing protocol as the headline (one rank);
+    `epe_vs_fp32class` = mean / max end-point distance of its flow from the headline policy's flow on the same pairs (the headline is
+    held to the oracle at 5e-5 px by tests/test_full_size_parity.py, so this is the policy's deviation from the oracle to that margin)."""
+    from craft_amd import CRAFT, default_args
+    from craft_amd.synth import synth_pair, synth_state_dict
+    out = {}
+    flows = {}
+    im1, im2, _ = synth_pair(B, H, W, seed=seed)
+    im1, im2 = im1.to(dev), im2.to(dev)
+    for policy in ("mixed", "train_amp_fp16"):
+        model = CRAFT(default_args(hip_precision=policy, mixed_precision=True))
+        model.load_state_dict(synth_state_dict(model.state_dict(), seed=1234), strict=True)
+        model = model.to(dev).eval()
+        with torch.no_grad():
+            for _ in range(warmup if policy != "mixed" else 1):
+                _, up = model(im1, im2, iters=iters, test_mode=1)
+            if policy != "mixed":
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    _, up = model(im1, im2, iters=iters, test_mode=1)
+                torch.cuda.synchronize()
+                out["ms_per_step"] = round(1e3 * (time.perf_counter() - t0) / steps, 3)
+                out["pairs_per_s"] = round(B * steps / (time.perf_counter() - t0), 3)
+        flows[policy] = up.float()
+        del model
+    d = (flows["train_amp_fp16"] - flows["mixed"]).pow(2).sum(1).sqrt()
+    out.update(policy="train_amp_fp16 (fp16 MFMA operands everywhere, f32 accumulate: the reference's --mixed_precision default, evaluate.py:1455)",
+               epe_vs_fp32class_mean=round(float(d.mean()), 5), epe_vs_fp32class_max=round(float(d.max()), 4), finite=bool(torch.isfinite(d).all()),
+               steps=steps, warmup=warmup)
+    return out
 
 
 def corr_cfg2(reps=10, H=768, W=1024):
@@ -661,12 +740,28 @@ def main():
         if a.ops:
             op_table(model, im1, im2, a.iters)
         line["roofline"] = roofline_pv(model, im1, im2, a.iters, prec)
-        line["roofline_conv"] = roofline_conv(a.batch, a.height // 8, a.width // 8, prec)
+        rc = roofline_conv(a.batch, a.height // 8, a.width // 8, prec)
+        live = roofline_conv_live(model, im1, im2, a.iters, prec)
+        if rc is not None and live is not None:
+            # headline figures of the object = the LIVE in-situ measurement; the stand-alone single launch stays beside it
+            rc.update(standalone_ms_per_launch=rc["ms_per_launch"], standalone_frac=rc["frac"], standalone_achieved=rc["achieved"],
+                      achieved=live["achieved"], frac=live["frac"], executed_frac=live["executed_frac"], ms_per_launch=round(live["ms_per_call"] / 4, 4),
+                      ms_per_call=live["ms_per_call"], calls_timed=live["calls_timed"], flops_per_call=live["flops_per_call"],
+                      timing="achieved / frac / ms_per_call: HIP events on the launch stream around every craft_sepconv_gru_step call of real "
+                             "forward passes (4 k_conv_halo_wf launches per call: z|r and q convolutions of both SepConvGRU passes, gates in the "
+                             "epilogues); ms_per_launch = ms_per_call / 4; standalone_*: the z|r convolution alone in a 20-launch loop")
+        line["roofline_conv"] = rc
         line["roofline_flash"] = roofline_flash(model, im1, im2, a.iters, prec)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.height, a.width, a.iters, a.cpu_threads)
         if not a.no_train_leg:          # (the same switch keeps a quick run quick)
             line["corr_cfg2"] = corr_cfg2(3, 128, 256) if a.mini else corr_cfg2()
+            if a.precision == "mixed":
+                try:
+                    line["infer_amp_fp16"] = (infer_amp_fp16(128, 160, 1, 2, 2, 1, dev, 900) if a.mini else
+                                              infer_amp_fp16(a.height, a.width, a.batch, a.iters, max(3, a.steps // 2), 2, dev, 900))
+                except Exception as e:      # noqa: BLE001
+                    failures.append(f"infer_amp_fp16: {type(e).__name__}: {e}"[:300])
         if tl is not None:
             line["train_cfg3"] = {
                 "workload": tl["name"] + ", 12 iters, whole training steps (forward + backward + gradient all-reduce + clip + AdamW), "

@@ -72,13 +72,16 @@ class Aggregate(nn.Module):
         inner = heads * dim_head
         self.to_v = nn.Conv2d(dim, inner, 1, bias=False)
         self.gamma = nn.Parameter(torch.zeros(1))
-        if dim != inner:
-            raise NotImplementedError("multi-head GMA projection (gma.py:123-126) is outside the HIP path")
-        self.project = None
+        # --num_heads > 1 (gma.py:123-126): the heads' outputs are concatenated along the channels and projected back to dim
+        self.project = nn.Conv2d(inner, dim, 1, bias=False) if dim != inner else None
 
     def forward_tokens(self, attn: torch.Tensor, mf: torch.Tensor, prec: int, out: Optional[torch.Tensor] = None):
         """attn [B, heads, N, ldp], mf tokens [B, N, dim] -> tokens [B, N, dim]."""
         ldp = ops.vt_stride(attn)
         vT = ops.linear_t(mf, self.to_v.weight.view(self.heads * self.dim_head, -1), ldp, prec, Dv=self.dim_head)
-        O = ops.attn_apply(attn, vT, self.dim_head, prec)
+        O = ops.attn_apply(attn, vT, self.dim_head, prec)                      # [B, heads, N, dim_head]
+        if self.project is not None:
+            # 'b h (x y) d -> b (h d) x y' + the 1x1 projection (gma.py:135-138): head-major channels per token, one craft_linear
+            B, Hd, N, Dv = O.shape
+            O = ops.linear(O.permute(0, 2, 1, 3).reshape(B, N, Hd * Dv), self.project.weight.view(self.project.weight.shape[0], -1), None, prec)
         return ops.gma_residual(mf, O, self.gamma, out=out)

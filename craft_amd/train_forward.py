@@ -111,8 +111,6 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
     # attention / aggregator (train-craft-f2full-gma.sh), plain correlation + GMA (train-gma.sh), and any mix of those three switches
     if args.f2trans == "none":
         raise NotImplementedError("--f2 none: the reference's own constructor fails without the F2 transformer (network.py:93-106)")
-    if not args.use_setrans and (model.att.heads != 1 or getattr(model.update_block.aggregator, "project", None) is not None):
-        raise NotImplementedError("training gma.Aggregate with num_heads > 1 (head merge + project, gma.py:133-137) is not built")
     prec = training_precision(model.hip_prec(), bool(getattr(args, "hip_loss_scaled", False)))
     AG.set_backward_modes(prec)                      # operand modes of the backward products for this pass (roles wgx / wgy / dxw)
     B, _, H, W = image1.shape
@@ -227,6 +225,8 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
     att = model.att
     fused = getattr(args, "hip_fused_update", True) and prec.conv != PREC_F32 and not os.environ.get("CRAFT_TRAIN_UNFUSED")
     agg_ = model.update_block.aggregator
+    if getattr(agg_, "project", None) is not None:
+        fused = False          # gma.Aggregate with --num_heads > 1 (head merge + project, gma.py:133-137): the operator-level path below
     cv_agg = (agg_.first_linear.weight.shape[0] // att.setrans.num_modes) if args.use_setrans else agg_.dim_head
     apk = [] if (fused and use_pk_attention(prec) and cv_agg % 32 == 0) else None       # (the packed P is consumed by train_update only)
     if args.use_setrans:
@@ -303,7 +303,10 @@ def forward_train(model, image1, image2, iters=12, flow_init=None):
             mfg = AG.ModePoolLN.apply(Oa, mf, agg.feat_softaggr.feat2score.weight, agg.input_skip_coeff)
         else:                                                                   # gma.Aggregate (gma.py:128-140), one head
             va = AG.Linear.apply(mf, agg.to_v.weight.view(agg.heads * agg.dim_head, -1), None, prec, wcache)
-            Oa = AG.AttnApplyShared.apply(ptoken, va, pholder, prec)            # [B, 1, N, 128]
+            Oa = AG.AttnApplyShared.apply(ptoken, va, pholder, prec)            # [B, heads, N, 128]
+            if agg.project is not None:                                         # 'b h (x y) d -> b (h d) x y' + 1x1 projection (gma.py:135-138)
+                Oa = AG.Linear.apply(Oa.permute(0, 2, 1, 3).reshape(B, N, -1), agg.project.weight.view(agg.project.weight.shape[0], -1), None, prec,
+                                     wcache)
             mfg = AG.GmaResidual.apply(mf, Oa.reshape(B, N, -1), agg.gamma)
         # SepConvGRU (update.py:49-64)
         x = torch.cat([inp, mf, mfg], dim=-1)                                   # [B, N, 384]

@@ -10,7 +10,7 @@ K_SAMPLE = 4096
 STRIDE = 7919
 CASES = ["canon_128x256_T4", "canon_b2_128x192_T3_init", "clamp_128x160_T2", "gma_128x160_T2", "nocraft_128x160_T2",
          "f2mask_128x160_T2", "f1shared_128x160_T2", "f1private_b2_128x160_T2", "gmapos_128x160_T2", "gmaposonly_128x160_T2",
-         "lsinu_b2_128x160_T2_init", "interlsinu_128x160_T2", "lsinu_warm_b2_128x160_T2"]
+         "lsinu_b2_128x160_T2_init", "interlsinu_128x160_T2", "lsinu_warm_b2_128x160_T2", "gmaheads2_128x160_T2"]
 # BASELINE.json configs[1] / configs[2] at full size, one pair each, captured from the reference (tools/make_golden.py)
 FULL_CASES = ["canon_448x1024_T12", "canon_768x1024_T12"]
 

@@ -21,7 +21,9 @@ TRAIN_CASES = ["train_b2_128x192_T3", "train_freezebn_b2_128x160_T2",
                # (corr.py:164-171) and GMA's relative-position scores (gma.py:34-50, :84-98)
                "train_f1shared_b2_128x160_T2", "train_f1private_b2_128x160_T2", "train_gmapos_b2_128x160_T2", "train_gmaposonly_b2_128x160_T2",
                # --interpos / --intrapos lsinu: the learned sinusoidal embedding and its pos_fc gradients
-               "train_lsinu_b2_128x160_T2"]
+               "train_lsinu_b2_128x160_T2",
+               # --num_heads 2 with GMA's attention: head merge + the aggregator's `project` (gma.py:123-126, :133-138)
+               "train_gmaheads2_b2_128x160_T2"]
 
 
 def grad_scale(z):

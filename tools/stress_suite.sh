@@ -12,9 +12,9 @@ case $sub in
 driver)
   for i in $(seq 1 $n); do
     t0=$(date +%s)
-    /usr/bin/time -v python3 -m pytest tests/ -x -q -m gpu -p no:cacheprovider --durations=25 > $O/driver_$i.log 2> $O/driver_$i.err
+    python3 -m pytest tests/ -x -q -m gpu -p no:cacheprovider --durations=25 > $O/driver_$i.log 2> $O/driver_$i.err
     rc=$?
-    echo "driver run $i: rc=$rc $(( $(date +%s) - t0 ))s | $(grep -aE 'passed|failed' $O/driver_$i.log | tail -n 1) | maxrss $(grep -a 'Maximum resident' $O/driver_$i.err | awk '{print $NF}') kB" | tee -a $O/summary.txt
+    echo "driver run $i: rc=$rc $(( $(date +%s) - t0 ))s | $(grep -aE 'passed|failed' $O/driver_$i.log | tail -n 1)" | tee -a $O/summary.txt
     if [ $rc -ne 0 ]; then grep -a "\[gpu-test\]" $O/driver_$i.err | tail -n 2 | tee -a $O/summary.txt; grep -a -i -m5 "fault\|abort\|error" $O/driver_$i.err | tee -a $O/summary.txt; fi
   done ;;
 tail)
