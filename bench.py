@@ -217,14 +217,25 @@ def roofline_pv(model, im1, im2, iters, prec, forwards=3):
         import json as _json
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r4", "pmc_traffic_pv16.json")) as fh:
             pmc = _json.load(fh)
-        best, best_cost = 4, None
-        for mt in (4, 5, 6, 7):           # launch_pv16 (kernels_gemm.hip): minimise resident rounds x rows per block
+        best, best_wr, best_cost = 4, 1, None      # launch_pv16 (kernels_gemm.hip), replicated: the 4-wave pick, then the 8-wave kernel if it fills the chip
+        for mt in (4, 5, 6, 7):
             blocks = ((N + 32 * mt - 1) // (32 * mt)) * (Dv // 128) * B * M
             slots = 256 * (3 if mt == 4 else 2)
             cost = ((blocks + slots - 1) // slots) * mt
             if best_cost is None or cost < best_cost:
                 best, best_cost = mt, cost
-        live = f"k_pv16<{pv}, {best}>"
+        if not os.environ.get("CRAFT_PV_NO_WR2"):
+            rows_cu1, best2, rows_cu2 = best_cost * (3 if best == 4 else 2), 0, None
+            for mt in (4, 5, 6, 7):
+                blocks = ((N + 64 * mt - 1) // (64 * mt)) * (Dv // 128) * B * M
+                if blocks < 256:
+                    continue
+                c = ((blocks + 255) // 256) * 2 * mt
+                if rows_cu2 is None or c < rows_cu2:
+                    best2, rows_cu2 = mt, c
+            if best2 and rows_cu2 <= rows_cu1:
+                best, best_wr = best2, 2
+        live = f"k_pv16<{pv}, {best}, {best_wr}>"
         sh = pmc.get("shape", {})
         if (sh.get("B"), sh.get("H8"), sh.get("W8")) == (B, H8, W8) and pv == PREC_F16 and pmc.get("kernel", "").replace(" ", "") == live.replace(" ", ""):
             traffic = int(pmc["hbm_bytes_per_launch"])

@@ -21,6 +21,7 @@ const Tuning& tuning() {
     if (const char* e = getenv("CRAFT_CORR_DBG")) v.corr_dbg = atoi(e);    // store ablations of k_corr_build4t (developer, tools/corr_write_pmc.sh)
     if (const char* e = getenv("CRAFT_PK_MODE")) v.pk_mode = atoi(e);      // ablations of k_gemm_pk (developer): 1 no DMA after tile 0, 2 no epilogue, 4 no MFMA phase
     v.flash_v1 = getenv("CRAFT_FLASH_V1") != nullptr;     // developer A/B: k_flash_attn (round 1) instead of k_flash_attn2
+    v.pv_wr2 = getenv("CRAFT_PV_NO_WR2") == nullptr;      // k_pv16: the launcher may pick the 8-wave (2 x 32 MT rows) instantiation (round 6; off: developer A/B)
     return v;
   }();
   return t;

@@ -262,13 +262,17 @@ static int launch_rows_wf(const RowsGemmParams& p, int prec, hipStream_t s) {
 #ifndef CRAFT_PV_ABL
 #define CRAFT_PV_ABL 0      // developer ablation (tools/build_variant.py -DCRAFT_PV_ABL=n): 1 no MFMAs (| 8: s_sleep for their issue time instead), 2 no A-fragment LDS reads, 4 V^T fragments loaded once
 #endif
-template <int PREC, int MT>
-__global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
+// WR = 2 (round 6): an 8-wave block of 2 x 32 MT rows -- waves (wr, wc) = (wave >> 2, wave & 3) own row half wr x column group wc.  One
+// block per CU (129 KB of LDS at MT = 7) holds the same 8 waves as two 4-wave blocks, but a V^T fragment is fetched once per 64 MT rows
+// of P instead of once per 32 MT (VERDICT r5 "next" 7: the per-block V^T traffic), and 448x1024 x batch 4 x 4 modes is 256 blocks =
+// exactly one per CU.  Per-thread work is unchanged: thread t moves chunk (t & 255) of the 4 KiB band tiles of its row half.
+template <int PREC, int MT, int WR>
+__global__ __launch_bounds__(NTHREADS * WR) void k_pv16(RowsGemmParams p) {
   typedef typename PrecT<PREC>::lds_t lds_t;
-  constexpr int BM = 32 * MT, KT = 64, LD = KT + 8;
+  constexpr int BMH = 32 * MT, BM = BMH * WR, KT = 64, LD = KT + 8;
   constexpr int TILE = BM * LD;
   __shared__ __attribute__((aligned(16))) lds_t S[2 * TILE];      // A0 | A1
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wr = tid >> 8, t256 = tid & 255;
   // XCD-aware block map.  Blocks are dealt to the 8 XCDs round-robin (block b -> XCD b % 8), and every block of one batch entry z
   // re-reads that entry's V^T (N x Dv x 2 B: 1.8 MB at 448x1024) from ITS XCD's L2.  With z outermost in the grid all 8 L2s
   // fetched all batch x modes copies (8 x 29 MB of a 1.97 GB launch, 13 % over the algorithmic bytes: PMC FETCH_SIZE); here XCD x
@@ -286,11 +290,11 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
   const int NB = p.N / 32, ng = (int)(p.ldb / 16);
   const uint16_t* Bf = reinterpret_cast<const uint16_t*>(p.B) + z0 * p.b_bs0 + z1 * p.b_bs1 + (long)(n0 / 32 + wave) * 512 + lane * 8;
   const long g_stride = (long)NB * 512;
-  const int c8 = tid & 7, r0 = tid >> 3;
+  const int c8 = t256 & 7, r0 = wr * BMH + (t256 >> 3);
   const uint16_t* pa[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)                                                              // clamped: unconditional loads
-    pa[i] = p.a_tiled ? A + (long)min(bx * MT + i, (p.M - 1) >> 5) * 32 * p.lda + tid * 8 : A + (long)min(m0 + r0 + 32 * i, p.M - 1) * p.lda;
+    pa[i] = p.a_tiled ? A + (long)min((bx * WR + wr) * MT + i, (p.M - 1) >> 5) * 32 * p.lda + t256 * 8 : A + (long)min(m0 + r0 + 32 * i, p.M - 1) * p.lda;
   const int nk = (p.K + KT - 1) / KT;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   typedef typename std::conditional<PREC == CRAFT_PREC_BF16, bf16x8, f16x8>::type frag_t;
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
       frag_t a[MT];
 #if !(CRAFT_PV_ABL & 2)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const frag_t*>(&As[(mt * 32 + r) * LD + kk * 16 + g8]);
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const frag_t*>(&As[(wr * BMH + mt * 32 + r) * LD + kk * 16 + g8]);
 #else
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) a[mt] = bq[(kk + mt) & 3];
@@ -385,10 +389,10 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
   for (int mt = 0; mt < MT; ++mt) {
     float rd[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) rd[e] = rdiv ? rdiv[min(m0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4, p.M - 1)] : 1.f;
+    for (int e = 0; e < 16; ++e) rd[e] = rdiv ? rdiv[min(m0 + wr * BMH + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4, p.M - 1)] : 1.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int row = m0 + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
+      const int row = m0 + wr * BMH + mt * 32 + (e & 3) + 8 * (e >> 2) + rh4;
       float v = acc[mt][0][e];
       if (rdiv) v *= __builtin_amdgcn_rcpf(rd[e]);      // (16-bit P: a 1-ulp reciprocal is far below its rounding)
       if (row < p.M) C[(long)row * p.ldc + col] = v;
@@ -396,28 +400,46 @@ __global__ __launch_bounds__(NTHREADS) void k_pv16(RowsGemmParams p) {
   }
 }
 
-template <int PREC, int MT> static void launch_pv_t(const RowsGemmParams& p, hipStream_t s) {
-  dim3 grid((unsigned)((long)((p.M + 32 * MT - 1) / (32 * MT)) * (p.N / 128) * p.batch), 1, 1);
-  hipLaunchKernelGGL((k_pv16<PREC, MT>), grid, dim3(NTHREADS), 0, s, p);
+template <int PREC, int MT, int WR = 1> static void launch_pv_t(const RowsGemmParams& p, hipStream_t s) {
+  dim3 grid((unsigned)((long)((p.M + 32 * MT * WR - 1) / (32 * MT * WR)) * (p.N / 128) * p.batch), 1, 1);
+  hipLaunchKernelGGL((k_pv16<PREC, MT, WR>), grid, dim3(NTHREADS * WR), 0, s, p);
 }
 
 int launch_pv16(const RowsGemmParams& p, int prec, int rows32, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return 0;
   if ((p.K & 15) || (p.lda & 7) || (p.ldb & 15) || (p.N & 127) || p.c_dtype != CRAFT_PREC_F32) return CRAFT_ERR_ALIGN;
   if (p.a_tiled && ((p.K & 63) || p.lda != p.K)) return CRAFT_ERR_ALIGN;
-  // rows per block: minimise (resident rounds) x (work per block).  Blocks per CU from the register / LDS budget of
-  // each instantiation (MT = 4: 3, MT >= 5: 2).
-  int best = 4; long best_cost = -1;
-  if (rows32 && (rows32 < 4 || rows32 > 7)) return CRAFT_ERR_ARG;
-  const int force = rows32;
-  for (int mt = 4; mt <= 7; ++mt) {
+  // rows per block: minimise (resident rounds) x (rows a CU works through per round).  Blocks per CU from the register / LDS budget of
+  // each instantiation (4 waves: MT = 4: 3, MT >= 5: 2; 8 waves (WR = 2): one).  rows32 forces an instantiation (tests / A-B runs):
+  // 4..7 = MT of the 4-wave kernel, 8 / 10 / 12 / 14 = the 8-wave kernel with MT = rows32 / 2.
+  if (rows32 && !((rows32 >= 4 && rows32 <= 7) || (rows32 >= 8 && rows32 <= 14 && rows32 % 2 == 0))) return CRAFT_ERR_ARG;
+  int best = 4, best_wr = 1; long best_cost = -1;
+  for (int mt = 4; mt <= 7; ++mt) {                       // the 4-wave kernel: as in rounds 3-5
     const long blocks = (long)((p.M + 32 * mt - 1) / (32 * mt)) * (p.N / 128) * p.batch;
     const long slots = 256L * (mt == 4 ? 3 : 2);
     const long cost = ((blocks + slots - 1) / slots) * mt;
-    if (best_cost < 0 || cost < best_cost || mt == force) { best = mt; best_cost = cost; if (mt == force) break; }
+    if (best_cost < 0 || cost < best_cost) { best = mt; best_cost = cost; }
   }
-#define GO(PR) do { switch (best) { case 4: launch_pv_t<PR, 4>(p, s); break; case 5: launch_pv_t<PR, 5>(p, s); break; \
-                                    case 6: launch_pv_t<PR, 6>(p, s); break; default: launch_pv_t<PR, 7>(p, s); break; } } while (0)
+  if (tuning().pv_wr2) {
+    // the 8-wave kernel takes over when it fills every CU and a CU works through no more rows than with the pick above (a CU holds
+    // one 8-wave block or `per` 4-wave blocks side by side; ties go to the 8-wave kernel: same rounds, half the V^T fetches)
+    const long per = best == 4 ? 3 : 2;
+    const long rows_cu1 = best_cost * per;               // rounds x 32-row groups per block x resident blocks
+    int best2 = 0; long rows_cu2 = -1;
+    for (int mt = 4; mt <= 7; ++mt) {
+      const long blocks = (long)((p.M + 64 * mt - 1) / (64 * mt)) * (p.N / 128) * p.batch;
+      if (blocks < 256) continue;
+      const long c = ((blocks + 255) / 256) * 2 * mt;
+      if (rows_cu2 < 0 || c < rows_cu2) { best2 = mt; rows_cu2 = c; }
+    }
+    if (best2 && rows_cu2 <= rows_cu1) { best = best2; best_wr = 2; }
+  }
+  if (rows32 >= 8) { best = rows32 / 2; best_wr = 2; }
+  else if (rows32) { best = rows32; best_wr = 1; }
+#define GO(PR) do { if (best_wr == 2) { switch (best) { case 4: launch_pv_t<PR, 4, 2>(p, s); break; case 5: launch_pv_t<PR, 5, 2>(p, s); break; \
+                                                        case 6: launch_pv_t<PR, 6, 2>(p, s); break; default: launch_pv_t<PR, 7, 2>(p, s); break; } } \
+                    else { switch (best) { case 4: launch_pv_t<PR, 4>(p, s); break; case 5: launch_pv_t<PR, 5>(p, s); break; \
+                                           case 6: launch_pv_t<PR, 6>(p, s); break; default: launch_pv_t<PR, 7>(p, s); break; } } } while (0)
   if (prec == CRAFT_PREC_BF16) GO(CRAFT_PREC_BF16);
   else if (prec == CRAFT_PREC_F16) GO(CRAFT_PREC_F16);
   else return CRAFT_ERR_ARG;

@@ -403,7 +403,8 @@ def probs_tiled(P: torch.Tensor, fill: float = 0.0) -> torch.Tensor:
 def attn_apply(P: torch.Tensor, vT: torch.Tensor, Dv: int, prec: int, out: Optional[torch.Tensor] = None,
                rows32: int = 0) -> torch.Tensor:
     """O[b][m] = P[b][m] @ V_m with vT [B, M*Dv, ldp] (16-bit: fragment order, ``linear_t(..., Dv=Dv)``) -> O [B, M, N, Dv].
-    ``rows32`` (4..7, 0 = chosen from the grid size): 32-row groups per block of the 16-bit kernel (CRAFT_PV_ROWS)."""
+    ``rows32`` (0 = chosen from the grid size; 4..7: 32-row groups per block of the 4-wave 16-bit kernel; 8 / 10 / 12 / 14: the 8-wave kernel
+    with rows32 / 2 groups per row half -- CRAFT_PV_ROWS)."""
     B, M, N, ldp = P.shape
     tiled = getattr(P, "craft_tiled", False)
     if tiled:

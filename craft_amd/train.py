@@ -529,11 +529,14 @@ class Trainer:
         self.total_steps += 1
         if self.total_steps == 2:
             # Python's cyclic collector: its first full pass over everything the imports and the model construction allocated takes
-            # ~40 ms and lands a few steps into training (measured: one 120 ms step among 78 ms ones).  Collect once now and move the
-            # survivors to the permanent generation; later passes only see what the steps themselves allocate.
+            # ~40 ms and lands a few steps into training (measured: one 120 ms step among 78 ms ones).  Collect once now: the next full
+            # pass is then due only after the long-lived set has grown by a quarter.  CRAFT_GC_FREEZE=1 additionally moves the survivors
+            # to the permanent generation (gc.freeze) -- a process-wide side effect a library must not impose by default (round 5 did:
+            # in a long-lived host process every object alive at that moment, e.g. an earlier model, would never be collected again).
             import gc
             gc.collect()
-            gc.freeze()
+            if os.environ.get("CRAFT_GC_FREEZE"):
+                gc.freeze()
         metrics = dict(metrics.resolve(), loss=float(loss.detach()))
         metrics["loss_rank"] = metrics["loss"]        # this rank's own loss ("loss" / "epe" become the mean over the ranks below)
         snap = opt.scaler_snapshot()       # (float(loss) above drained the stream: this is the step just taken)

@@ -160,7 +160,8 @@ int craft_attn_probs_fused(const float* q, long ldq, const float* k, long ldk, i
  * (craft_linear_t with frag_rows = Dv) and Dv % 128 == 0; for prec 0 it is plain row-major.  rowsum: NULL for a
  * normalised P, else the row sums craft_attn_probs produced with it (O rows are divided by them).
  * 16-bit path: a block owns 32*r query rows x 128 value columns; r (4..7) is chosen from the grid size unless the caller
- * or-s CRAFT_PV_ROWS(r) into prec (tests pin every instantiation that way).
+ * or-s CRAFT_PV_ROWS(r) into prec (tests pin every instantiation that way); r = 8 / 10 / 12 / 14 selects the 8-wave kernel (a block owns
+ * 2 x 32*(r/2) rows: one V^T fetch per two row halves).
  * prec | CRAFT_P_TILED (16-bit only): P is in craft_attn_probs_fused's tiled layout, ldp its tiled row extent (multiple of 64); vT
  * keeps the row stride N rounded up to 32. */
 #define CRAFT_PV_ROWS_SHIFT 20

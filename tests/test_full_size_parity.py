@@ -66,10 +66,11 @@ def test_bench_shape_batch4_against_oracle(device):
         assert (lo[b:b + 1].cpu() - lo_ref).abs().max().item() < 1.5e-3
 
 
-@pytest.mark.parametrize("rows32", [4, 5, 6, 7])
+@pytest.mark.parametrize("rows32", [4, 5, 6, 7, 8, 10, 12, 14])
 @pytest.mark.parametrize("prec", [PREC_F16, hip.PREC_BF16])
 def test_attn_apply_every_block_height(device, prec, rows32):
-    """k_pv16<prec, MT> for MT = 4..7 (CRAFT_PV_ROWS): N = 1000 rows gives >= 2 row blocks and a ragged last block for every
+    """k_pv16<prec, MT, WR> for MT = 4..7 of the 4-wave kernel and rows32 = 8 / 10 / 12 / 14 = the 8-wave kernel (WR = 2) with MT = rows32 / 2
+    (CRAFT_PV_ROWS): N = 1000 rows gives >= 2 row blocks and a ragged last block for every
     MT; Dv = 128 (the aggregator) and 256; normalised and deferred-normalisation forms."""
     B, M, N = 2, 4, 1000 - 32 * (rows32 & 1)          # (N = 968: V^T's key extent 992 differs from the tiled P's 1024)
     g = torch.Generator().manual_seed(77 + rows32)
