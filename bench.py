@@ -103,12 +103,17 @@ def op_table(model, im1, im2, iters):
         print(f"[ops] {n:28s} calls {c:4d}  {t:9.3f} ms  {100 * t / tot:5.1f} %", file=sys.stderr)
 
 
+# Every PMC figure on the line comes from THIS directory: re-collected each round on the final tree; tests/test_profiles.py fails when a
+# kernel source is newer (by commit time) than the counter file that describes it (VERDICT r5 "next" 9)
+PMC_DIR = "r6"
+
+
 def pmc_lookup(kernel, group, B, H8, W8):
-    """This round's committed PMC summary of one kernel (profiles/r5/pmc_kernels.json, tools/pmc_summary.py): HBM-side bytes per launch
+    """This round's committed PMC summary of one kernel (profiles/r6/pmc_kernels.json, tools/pmc_r6.sh + tools/pmc_r6_json.py; PMC_DIR): HBM-side bytes per launch
     (FETCH_SIZE x2 on gfx950 + WRITE_SIZE) and the matrix pipe's busy fraction -- only when the entry was taken at THIS shape for THIS
     kernel instantiation; otherwise None rather than a stale constant."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r5", "pmc_kernels.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", PMC_DIR, "pmc_kernels.json")) as fh:
             pmc = json.load(fh)
         sh = pmc.get("shape", {})
         if (sh.get("B"), sh.get("H8"), sh.get("W8")) != (B, H8, W8):
@@ -157,8 +162,7 @@ def roofline_flash(model, im1, im2, iters, prec, forwards=3):
     flops = 2.0 * 1280 * N * N * B
     executed = 2.0 * ((3 if x3 else 1) * 256 + 1024) * N * N * B
     ach = flops / (ms * 1e-3) / 1e12
-    v1 = bool(os.environ.get("CRAFT_FLASH_V1"))                      # (the round-4 kernel, kept behind the switch for A/B)
-    name = "k_flash_attn" if v1 else "k_flash_attn2"
+    name = "k_flash_attn2"
     e = pmc_lookup(f"{name}<64, 256, 2>" if x3 else f"{name}<64, 256, 1>", "flash", B, H8, W8)
     return {"bound": "mfma", "kernel": "k_flash_attn2 (F2 feature transformer: scores + online softmax + P.V fused, 1 launch per forward; + 2 k_pack_qk)",
             "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
@@ -166,7 +170,7 @@ def roofline_flash(model, im1, im2, iters, prec, forwards=3):
             "launches_timed": len(evs), "mfma_busy": e.get("mfma_busy") if e else None, "traffic": e.get("hbm_bytes_per_launch") if e else None,
             "note": "timed live (HIP events on the launch stream) around craft_flash_attention in real forward passes; mfma_busy = rocprofv3 "
                     "SQ_VALU_MFMA_BUSY_CYCLES per SIMD / GRBM_GUI_ACTIVE per XCD and traffic = FETCH_SIZE x2 + WRITE_SIZE of the same kernel at this "
-                    "shape (profiles/r5/pmc_kernels.json; null when not profiled at this shape): busy is a fraction of the cycles the chip actually "
+                    "shape (profiles/r6/pmc_kernels.json; null when not profiled at this shape): busy is a fraction of the cycles the chip actually "
                     "ran, frac is against the 2.4 GHz peak"}
 
 
@@ -209,14 +213,11 @@ def roofline_pv(model, im1, im2, iters, prec, forwards=3):
     bytes_alg = B * M * N * ldp * esz + B * M * Dv * ldp * esz + B * M * N * Dv * 4
     ach = bytes_alg / (ms * 1e-3) / 1e9
     # HBM bytes per launch from the committed PMC passes of this kernel (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
-    # separate runs, gfx950 x2 correction on FETCH_SIZE: profiles/r4/pmc_traffic_pv16.json).  Quoted only when the live launch is
+    # separate runs, gfx950 x2 correction on FETCH_SIZE: profiles/<PMC_DIR>/pmc_kernels.json).  Quoted only when the live launch is
     # the profiled one: same shape, same element type AND the same kernel instantiation (rows per block chosen by the launcher's
     # cost function, replicated here) -- otherwise null rather than a stale constant.
     traffic = None
     try:
-        import json as _json
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r4", "pmc_traffic_pv16.json")) as fh:
-            pmc = _json.load(fh)
         best, best_wr, best_cost = 4, 1, None      # launch_pv16 (kernels_gemm.hip), replicated: the 4-wave pick, then the 8-wave kernel if it fills the chip
         for mt in (4, 5, 6, 7):
             blocks = ((N + 32 * mt - 1) // (32 * mt)) * (Dv // 128) * B * M
@@ -236,10 +237,7 @@ def roofline_pv(model, im1, im2, iters, prec, forwards=3):
             if best2 and rows_cu2 <= rows_cu1:
                 best, best_wr = best2, 2
         live = f"k_pv16<{pv}, {best}, {best_wr}>"
-        sh = pmc.get("shape", {})
-        if (sh.get("B"), sh.get("H8"), sh.get("W8")) == (B, H8, W8) and pv == PREC_F16 and pmc.get("kernel", "").replace(" ", "") == live.replace(" ", ""):
-            traffic = int(pmc["hbm_bytes_per_launch"])
-        e5 = pmc_lookup(live, "pv", B, H8, W8) if pv == PREC_F16 else None      # this round's passes of the same instantiation take precedence
+        e5 = pmc_lookup(live, "pv", B, H8, W8) if pv == PREC_F16 else None      # this round's passes of the SAME instantiation, else null
         if e5:
             traffic = int(e5["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
@@ -249,7 +247,7 @@ def roofline_pv(model, im1, im2, iters, prec, forwards=3):
             "bytes_per_launch": bytes_alg, "ms_per_launch": round(ms, 4), "launches_timed": len(evs),
             "note": "timed live around every launch of real forward passes (HIP events on the launch stream); algorithmic bytes "
                     "= P (fp16, read once) + V^T + O; traffic = HBM bytes per launch from the PMC passes committed under "
-                    "profiles/r5/pmc_kernels.json, else profiles/r4 (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; null when the live kernel instantiation is not the profiled one); measured read-only ceiling of this access pattern "
+                    "profiles/r6/pmc_kernels.json (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; null when the live kernel instantiation is not the profiled one); measured read-only ceiling of this access pattern "
                     "on the same chip: 6.1 TB/s plain / 6.9 TB/s non-temporal with NO arithmetic (tools/ubench/hbm_rows_dma.hip); with the P.V MFMAs on, the "
                     "package sits at its 1400 W limit and sclk falls 2.4 -> 1.58 GHz (profiles/r5/pv16_power.txt): the kernel is bound by the power cap"}
 
@@ -372,13 +370,13 @@ def corr_cfg2(reps=10, H=768, W=1024):
     """BASELINE.json configs[2] on the default line: the 768x1024 correlation build (fused scores + mode pooling + 4-level pyramid +
     statistics) and the radius-4 lookup, timed with HIP events on the launch stream (tools/bench_corr.py).  frac = SURVEY 8(d) bytes
     (the pyramid written once + Q / K read once) / time / 8 TB/s; traffic = FETCH_SIZE x2 + WRITE_SIZE of the build kernel from this
-    round's committed PMC passes (profiles/r4/pmc_corr_build.json; null when absent or taken at another shape)."""
+    round's committed PMC passes (profiles/<PMC_DIR>/pmc_corr_build.json; null when absent or taken at another shape)."""
     from tools.bench_corr import measure
     r = measure(H, W, 1, reps, "mixed")
     b, lk = r["corr_build"], r["corr_lookup"]
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r4", "pmc_corr_build.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", PMC_DIR, "pmc_corr_build.json")) as fh:
             pmc = json.load(fh)
         if pmc.get("shape") == [1, H // 8, W // 8]:
             traffic = int(pmc["hbm_bytes_per_launch"])
@@ -498,8 +496,8 @@ def roofline_wgrad(step, policy, steps=2):
     mult = (1 if pol.wgy == PREC_F16 else 2 if pol.wgx == PREC_F16 else 3) if pol.conv == PREC_F16X3 else 1
     traffic = None
     kern, cin, cout, KH, KW, rows, calls = key
-    try:        # HBM bytes per launch from the PMC passes committed under profiles/r3 -- quoted only for the launch shape and operand mode profiled
-        with open(os.path.join(ROOT, "profiles", "r4" if mult < 3 else "r3", "pmc_traffic_wgrad.json")) as fh:
+    try:        # HBM bytes per launch from this round's PMC passes -- quoted only for the launch shape and operand mode profiled
+        with open(os.path.join(ROOT, "profiles", PMC_DIR, "pmc_traffic_wgrad.json")) as fh:
             pmc = json.load(fh)
         if list(pmc.get("shape", [])) == list(key[1:]) and pmc.get("kernel") == kern and pmc.get("mfmas_per_product", 3) == mult:
             traffic = int(pmc["hbm_bytes_per_launch"])

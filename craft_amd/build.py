@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libcraft_hip.so")
-SOURCES = ["kernels_gemm.hip", "kernels_conv.hip", "kernels_conv_wf.hip", "kernels_conv_pk.hip", "kernels_conv_c64.hip", "kernels_stem.hip", "kernels_flash.hip", "kernels_attn.hip", "kernels_attn_d32.hip", "kernels_attn_d64.hip", "kernels_attn_d128.hip", "kernels_attn_w.hip",
+SOURCES = ["kernels_gemm.hip", "kernels_conv.hip", "kernels_conv_wf.hip", "kernels_conv_c64.hip", "kernels_stem.hip", "kernels_flash.hip", "kernels_attn.hip", "kernels_attn_d32.hip", "kernels_attn_d64.hip", "kernels_attn_d128.hip", "kernels_attn_w.hip",
            "kernels_misc.hip", "kernels_convf1.hip", "kernels_gemm_gen.hip", "kernels_gemm_pk.hip", "kernels_gemm_pkb_tt.hip", "kernels_gemm_pkb_ct.hip", "kernels_gemm_pkb_cc.hip", "kernels_train.hip", "kernels_enc_train.hip", "kernels_augment.hip", "craft_hip.hip"]
 HEADERS = ["common.hpp", "gemm_engine.hpp", "launch.hpp", "attn_probs.inc.hpp", "conv_epilogue.hpp", "gemm_pkb.inc.hpp", os.path.join("..", "..", "include", "craft_hip.h")]
 ARCH = "gfx950"

@@ -20,7 +20,6 @@ const Tuning& tuning() {
     v.no_wgrad64 = getenv("CRAFT_NO_WGRAD64") != nullptr;   // weight gradient of 64-channel layers on the generic 128-row tile (developer A/B)
     if (const char* e = getenv("CRAFT_CORR_DBG")) v.corr_dbg = atoi(e);    // store ablations of k_corr_build4t (developer, tools/corr_write_pmc.sh)
     if (const char* e = getenv("CRAFT_PK_MODE")) v.pk_mode = atoi(e);      // ablations of k_gemm_pk (developer): 1 no DMA after tile 0, 2 no epilogue, 4 no MFMA phase
-    v.flash_v1 = getenv("CRAFT_FLASH_V1") != nullptr;     // developer A/B: k_flash_attn (round 1) instead of k_flash_attn2
     v.pv_wr2 = getenv("CRAFT_PV_NO_WR2") == nullptr;      // k_pv16: the launcher may pick the 8-wave (2 x 32 MT rows) instantiation (round 6; off: developer A/B)
     return v;
   }();
@@ -378,39 +377,6 @@ int craft_conv2d_nhwc_res(const float* x, long ldx, int cin, const float* w, con
   q.w_packed = PACKED_OF(prec);
   q.res = res; q.ld_res = (int)ldr;
   return launch_gemm_conv(q, PREC_OF(prec), S(stream));
-}
-
-static int conv_pk_input(ConvPkIn& in, const void* x0, long rows_p0, int ncg0_total, int cg_off0, int c0, const void* x1, long rows_p1,
-                         int ncg1_total, int cg_off1, int c1, long guard, int padH, int padW, int tail, int H, int W, int KH, int KW, int planes) {
-  if (c0 <= 0 || c0 % 32 || c1 < 0 || c1 % 32 || (c1 > 0 && x1 == nullptr) || x0 == nullptr) return CRAFT_ERR_ALIGN;
-  if (padH < KH / 2 || padW < KW / 2 || tail < 0 || guard < 0) return CRAFT_ERR_ARG;
-  if (cg_off0 < 0 || cg_off0 + c0 / 32 > ncg0_total || (c1 > 0 && (cg_off1 < 0 || cg_off1 + c1 / 32 > ncg1_total))) return CRAFT_ERR_ARG;
-  const double b0 = (double)planes * ncg0_total * rows_p0 * 64.0, b1 = c1 > 0 ? (double)planes * ncg1_total * rows_p1 * 64.0 : 0.0;
-  if (b0 >= 4294967296.0 || b1 >= 4294967296.0) return CRAFT_ERR_UNSUPPORTED;          // 32-bit byte offsets inside a pack
-  in = ConvPkIn{};
-  in.seg[0] = static_cast<const unsigned char*>(x0); in.seg[1] = c1 > 0 ? static_cast<const unsigned char*>(x1) : in.seg[0];
-  in.bytes[0] = (unsigned)b0; in.bytes[1] = c1 > 0 ? (unsigned)b1 : in.bytes[0];
-  in.ncg0 = c0 / 32;
-  in.cgs[0] = (unsigned)(rows_p0 * 64); in.plane[0] = (unsigned)((long)ncg0_total * rows_p0 * 64);
-  in.cgs[1] = c1 > 0 ? (unsigned)(rows_p1 * 64) : in.cgs[0]; in.plane[1] = c1 > 0 ? (unsigned)((long)ncg1_total * rows_p1 * 64) : in.plane[0];
-  in.cg_off[0] = cg_off0; in.cg_off[1] = c1 > 0 ? cg_off1 : cg_off0;
-  in.Hp = H + 2 * padH; in.Wp = W + 2 * padW + tail;
-  in.row0 = guard + (long)(padH - KH / 2) * in.Wp + (padW - KW / 2);
-  return 0;
-}
-
-int craft_conv2d_pk(const void* x0, long rows_p0, int ncg0, int cg_off0, int c0, const void* x1, long rows_p1, int ncg1, int cg_off1, int c1,
-                    long guard, int padH, int padW, int tail, const float* w, const float* bias, const float* bias_field, long ld_bf, int cout,
-                    int KH, int KW, int act, float* y, long ldy, int B, int H, int W, int prec, void* stream) {
-  if ((bias == nullptr) == (bias_field == nullptr)) return CRAFT_ERR_ARG;          // exactly one of the two
-  if (!PACKED_OF(prec)) return CRAFT_ERR_ARG;
-  ConvPkParams pp = {};
-  pp.c = conv_params(nullptr, 0, c0, nullptr, 0, c1, B, H, W, KH, KW, w, bias, cout, CONV_EPI_BIAS_ACT, act, 1.f, y, (int)ldy);
-  pp.c.bias_field = bias_field; pp.c.ld_bf = (int)ld_bf;
-  pp.c.w_packed = 1; pp.c.w16 = W16_OF(prec);
-  TRY(conv_pk_input(pp.in, x0, rows_p0, ncg0, cg_off0, c0, x1, rows_p1, ncg1, cg_off1, c1, guard, padH, padW, tail, H, W, KH, KW,
-                    PREC_OF(prec) == CRAFT_PREC_F16X3 ? 2 : 1));
-  return launch_conv_pk(pp, PREC_OF(prec), S(stream));
 }
 
 int craft_pack_conv_weights(const float* w0, int cout0, const float* w1, int cout1, int Cin, int KH, int KW, int a0, int a1, int b0, int b1,

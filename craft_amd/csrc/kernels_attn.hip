@@ -400,7 +400,14 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build4s(ScoreParams p, const 
 // Block = 4 waves: (wave >> 1) = one of two horizontally adjacent cells, (wave & 1) = one of two groups of 32 queries.
 // ---------------------------------------------------------------------------------------------
 constexpr int CORR_STG = 128 + 4;      // floats per query in the level-0 staging tile (+ 16 B: conflict-free ds_write_b128)
-template <bool CLAMP, bool BIAS, bool VEC, bool TILED>
+// FAST (round 6): the softmax over the four modes with mode 0 as the reference instead of the row maximum --
+//     c = (s0 + s1 e1 + s2 e2 + s3 e3) / (1 + e1 + e2 + e3),   e_m = 2^(wl (s_m - s0))
+// -- THREE exponentials per element instead of four (mode 0's is exactly 1), no maximum, and wl (s_m - s0) as one FMA per mode: 13
+// full-rate + 4 quarter-rate instructions per element against 25 + 5.  The epilogue (32 elements per lane) is what this kernel's time
+// is made of (13.5 VALU per MFMA, matrix pipe 19 % busy: profiles/r5/pmc_kernels.json).  Exact for every input whose exponents stay
+// below 2^110 (then 3 x 100 x 2^110 < FLT_MAX: the scores are bounded by 100, by the clamp or by the Cauchy-Schwarz test that switched
+// it off); the caller checks wl (max_m s_m - s0) <= 110 over the wave's tile first and takes the max-referenced form otherwise.
+template <bool CLAMP, bool BIAS, bool VEC, bool TILED, bool FAST>
 __device__ __forceinline__ void corr4t_epilogue(const ScoreParams& p, const f32x16 (&acc)[4][2], float wl, long q, bool qvalid, int qh,
                                                 int qw, int cy, int cx, int g, const float* s_tab, int R, int TW, float* __restrict__ pyr0,
                                                 float* __restrict__ pyr1, float* __restrict__ pyr2, float* __restrict__ pyr3, float& s1,
@@ -417,21 +424,32 @@ __device__ __forceinline__ void corr4t_epilogue(const ScoreParams& p, const f32x
     float cv[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      float sv[4], tv[4];
+      float sv[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        sv[m] = CLAMP ? __builtin_amdgcn_fmed3f(acc[m][mt][e], -CRAFT_ATTN_CLIP, CRAFT_ATTN_CLIP) : acc[m][mt][e];
-        tv[m] = wl * sv[m];
-      }
-      const float mx = fmaxf(fmaxf(tv[0], tv[1]), fmaxf(tv[2], tv[3]));
-      float den = 0.f, num = 0.f;
+      for (int m = 0; m < 4; ++m) sv[m] = CLAMP ? __builtin_amdgcn_fmed3f(acc[m][mt][e], -CRAFT_ATTN_CLIP, CRAFT_ATTN_CLIP) : acc[m][mt][e];
+      float c;
+      if constexpr (FAST) {
+        const float t0 = wl * sv[0];
+        const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(wl, sv[1], -t0));
+        const float e2 = __builtin_amdgcn_exp2f(__builtin_fmaf(wl, sv[2], -t0));
+        const float e3 = __builtin_amdgcn_exp2f(__builtin_fmaf(wl, sv[3], -t0));
+        const float den = (1.f + e1) + (e2 + e3);
+        const float num = __builtin_fmaf(sv[3], e3, __builtin_fmaf(sv[2], e2, __builtin_fmaf(sv[1], e1, sv[0])));
+        c = num * __builtin_amdgcn_rcpf(den);
+      } else {
+        float tv[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const float ex = __builtin_amdgcn_exp2f(tv[m] - mx);
-        den += ex;
-        num += sv[m] * ex;
+        for (int m = 0; m < 4; ++m) tv[m] = wl * sv[m];
+        const float mx = fmaxf(fmaxf(tv[0], tv[1]), fmaxf(tv[2], tv[3]));
+        float den = 0.f, num = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float ex = __builtin_amdgcn_exp2f(tv[m] - mx);
+          den += ex;
+          num += sv[m] * ex;
+        }
+        c = num * __builtin_amdgcn_rcpf(den);
       }
-      float c = num * __builtin_amdgcn_rcpf(den);
       if (BIAS) {
         const int kh = 8 * cy + 4 * mt + (e >> 2), kw = kw0 + (e & 3);
         const unsigned u = min((unsigned)(R + 1 + kh - qh), umax), v = min((unsigned)(R + 1 + kw - qw), umax);
@@ -622,11 +640,37 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build4t(ScoreParams p, const 
   static_assert(64 * CORR_STG * 4 <= (int)sizeof(As), "level-0 staging tile must fit in the key-tile buffer");
   if (p.tiled) __syncthreads();                                  // every wave is done reading As / Bs
   if (8 * cx < p.W8) {                                           // (the second cell of the last pair may lie outside the image)
-#define EPI(CL, BI, VE) do { if (p.tiled) corr4t_epilogue<CL, BI, VE, true>(p, acc, wl, q, qvalid, qh, qw, cy, cx, g, s_tab, R, TW, pyr0, pyr1, pyr2, pyr3, s1, s2, stage, wq * 32 + r); \
-                            else corr4t_epilogue<CL, BI, VE, false>(p, acc, wl, q, qvalid, qh, qw, cy, cx, g, s_tab, R, TW, pyr0, pyr1, pyr2, pyr3, s1, s2, stage, wq * 32 + r); } while (0)
+    // may the mode-0-referenced softmax run?  wl (s_m - s0) <= 110 for every element of the wave's tile (a NaN fails the test: the
+    // max-referenced form propagates it as before); 3 VALU per element, wave-uniform outcome
+    bool fast;
+    {
+      float dd = 0.f;
+      auto scan = [&](auto pos_, auto clamp_) __attribute__((always_inline)) {
+        constexpr bool POS = decltype(pos_)::value, CL = decltype(clamp_)::value;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float hi = POS ? fmaxf(fmaxf(acc[1][mt][e], acc[2][mt][e]), acc[3][mt][e]) : fminf(fminf(acc[1][mt][e], acc[2][mt][e]), acc[3][mt][e]);
+            float lo = acc[0][mt][e];
+            if (CL) {                          // (the clamped scores are what the epilogue exponentiates)
+              hi = __builtin_amdgcn_fmed3f(hi, -CRAFT_ATTN_CLIP, CRAFT_ATTN_CLIP);
+              lo = __builtin_amdgcn_fmed3f(lo, -CRAFT_ATTN_CLIP, CRAFT_ATTN_CLIP);
+            }
+            dd = POS ? fmaxf(dd, hi - lo) : fminf(dd, hi - lo);
+          }
+      };
+      if (wl >= 0.f) { if (clamp) scan(std::true_type(), std::true_type()); else scan(std::true_type(), std::false_type()); }
+      else { if (clamp) scan(std::false_type(), std::true_type()); else scan(std::false_type(), std::false_type()); }
+      fast = __all(wl * dd <= 110.f) && !(p.dbg & 4);
+    }
+#define EPI2(CL, BI, VE, FA) do { if (p.tiled) corr4t_epilogue<CL, BI, VE, true, FA>(p, acc, wl, q, qvalid, qh, qw, cy, cx, g, s_tab, R, TW, pyr0, pyr1, pyr2, pyr3, s1, s2, stage, wq * 32 + r); \
+                                 else corr4t_epilogue<CL, BI, VE, false, FA>(p, acc, wl, q, qvalid, qh, qw, cy, cx, g, s_tab, R, TW, pyr0, pyr1, pyr2, pyr3, s1, s2, stage, wq * 32 + r); } while (0)
+#define EPI(CL, BI, VE) do { if (fast) EPI2(CL, BI, VE, true); else EPI2(CL, BI, VE, false); } while (0)
     if (clamp) { if (has_bias) { if (vec) EPI(true, true, true); else EPI(true, true, false); } else { if (vec) EPI(true, false, true); else EPI(true, false, false); } }
     else { if (has_bias) { if (vec) EPI(false, true, true); else EPI(false, true, false); } else { if (vec) EPI(false, false, true); else EPI(false, false, false); } }
 #undef EPI
+#undef EPI2
   }
   if (p.tiled && !(p.dbg & 1)) {
     // level-0 tiles of the block's 64 queries, LDS -> HBM: thread t moves 16-byte chunks t, t + 256, ... of the 64 x 512 B; a wave

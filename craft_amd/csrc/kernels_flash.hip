@@ -37,200 +37,6 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 constexpr int FLASH_TABW = 33;          // bias / mask table width: 2 * 15 + 3
 constexpr float FLASH_RESCALE_THR = 8.f;
 
-template <int D, int DV, int PL>
-__global__ __launch_bounds__(512) void k_flash_attn(FlashParams p) {
-  constexpr int KS = D / 16;                  // k-steps of the score product
-  constexpr int NB = DV / 32;                 // 32-row blocks of O^T
-  constexpr int KT_H = KS * PL * 512;         // 16-bit elements per K tile
-  constexpr int VT_H = NB * 2 * 512;          // ... per V^T tile (two 16-key groups)
-  constexpr int TILE_H = KT_H + VT_H;
-  constexpr int NL = (TILE_H + 4095) / 4096;  // 16-byte pieces per thread and tile
-  static_assert(TILE_H % 8 == 0, "tile");
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  __shared__ __attribute__((aligned(16))) uint16_t St[2 * TILE_H];
-  __shared__ float s_tab[FLASH_TABW * FLASH_TABW];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // XCD-aware work mapping: the hardware deals consecutive block ids round-robin over the 8 XCDs (each with its own L2).
-  // Every block of one z streams the same K / V^T (5.5 MB at 448x1024), so the blocks of a z are given to ONE XCD:
-  // virtual id v = (blocks of lower XCDs) + (id / 8), z = v / nqx, query block = v % nqx  (bijective for any count).
-  const int nqx = (p.N + 255) / 256, total = nqx * p.B * p.M;
-  const int v = xcd_chunk(blockIdx.x, total);
-  const int z = v / nqx, bx = v - z * nqx, b = z / p.M, m = z - b * p.M;
-  const int N = p.N, W8 = p.W8, R = p.R;
-  const int q0 = bx * 256;
-  const int qb = bx * 8 + wave;
-  const int qidx = qb * 32 + (lane & 31);
-  const int hh = lane >> 5;
-
-  // ---- bias / mask table (same construction as k_attn_probs)
-  constexpr float LOG2E = 1.4426950408889634f;
-  const bool clamp = p.clamp_ord != nullptr && ord2f(*p.clamp_ord) > CRAFT_ATTN_CLIP;
-  const int mr = p.mask_radius > 0 ? p.mask_radius : 0;
-  const int Re = max(p.pos_tab ? R : 0, mr), TW = 2 * Re + 3;
-  for (int i = tid; i < TW * TW; i += 512) {
-    const int dh = i / TW - Re - 1, dw = i - (i / TW) * TW - Re - 1;
-    float v = 0.f;
-    if (p.pos_tab && abs(dh) <= R && abs(dw) <= R) v = p.pos_tab[(dh + R) * (2 * R + 1) + dw + R] * (p.pos_w * LOG2E);
-    if (mr > 0 && max(abs(dh), abs(dw)) > mr) v += -1e9f;
-    s_tab[i] = v;
-  }
-  const float clipv = clamp ? CRAFT_ATTN_CLIP * LOG2E : 3.0e38f;
-  const int qc = min(qidx, N - 1);
-  const int h1 = qc / W8, w1 = qc - h1 * W8;
-  const int ch = Re + 1 - h1, cw = Re + 1 - w1;
-  const unsigned umax = 2 * Re + 2;
-  const int q_hmin = q0 / W8, q_hmax = min(q0 + 255, N - 1) / W8;
-  const bool always_tab = clamp || mr > 0;
-
-  // ---- Q fragments of this wave (resident)
-  f16x8 qf[KS][PL];
-  {
-    const uint16_t* qs = p.Qf + ((long)z * p.nqb + qb) * (KS * PL * 512) + lane * 8;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int pl = 0; pl < PL; ++pl) qf[ks][pl] = *reinterpret_cast<const f16x8*>(qs + (ks * PL + pl) * 512);
-  }
-
-  // ---- tile staging: piece i of thread tid = 16 bytes at element offset i*4096 + tid*8 of [K tile | V^T tile]
-  const uint16_t* kbase = p.Kf + (long)z * p.nkb * KT_H;
-  const uint16_t* vbase = p.Vf + (long)b * p.v_bs + (long)m * p.v_ms;
-  u32x4 rs[NL];
-  auto fetch = [&](int t) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int off = i * 4096 + tid * 8;
-      if (off < KT_H) rs[i] = *reinterpret_cast<const u32x4*>(kbase + (long)t * KT_H + off);
-      else if (off < TILE_H) rs[i] = *reinterpret_cast<const u32x4*>(vbase + (long)t * VT_H + (off - KT_H));
-    }
-  };
-  auto stash = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int off = i * 4096 + tid * 8;
-      if (off < TILE_H) *reinterpret_cast<u32x4*>(&St[buf * TILE_H + off]) = rs[i];
-    }
-  };
-
-  const int nkt = p.nkt;
-  fetch(0);
-  stash(0);
-  __syncthreads();
-
-  f32x16 o[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) o[nb][e] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  for (int t = 0; t < nkt; ++t) {
-    const int buf = t & 1;
-    fetch(min(t + 1, nkt - 1));
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- S^T = K . Q^T (32 keys x 32 queries), base-2 logits.  All K fragments are requested up front (counted waits).
-    const uint16_t* Kt = &St[buf * TILE_H + lane * 8];
-    const uint16_t* Vt = &St[buf * TILE_H + KT_H + lane * 8];
-    f16x8 kf[KS][PL];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int pl = 0; pl < PL; ++pl) kf[ks][pl] = *reinterpret_cast<const f16x8*>(Kt + (ks * PL + pl) * 512);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 s;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) s[e] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if constexpr (PL == 2) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][1], qf[ks][0], s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], qf[ks][1], s, 0, 0, 0);
-      }
-      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks][0], qf[ks][0], s, 0, 0, 0);
-    }
-    // the first V^T fragments travel while the softmax runs (they take the registers of the K fragments)
-    constexpr int VPF = NB < 2 ? NB : 2;
-    f16x8 va[VPF][2];
-#pragma unroll
-    for (int nb = 0; nb < VPF; ++nb) {
-      va[nb][0] = *reinterpret_cast<const f16x8*>(Vt + nb * 512);
-      va[nb][1] = *reinterpret_cast<const f16x8*>(Vt + (NB + nb) * 512);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- bias window / mask / clamp / ragged last tile: one block-uniform branch per tile
-    const int j0 = t * 32;
-    const int k_hmin = j0 / W8, k_hmax = min(j0 + 31, N - 1) / W8;
-    const bool ragged = j0 + 32 > N;
-    const bool need_tab = always_tab || (p.pos_tab != nullptr && k_hmax >= q_hmin - R && k_hmin <= q_hmax + R);
-    if (need_tab || ragged) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = j0 + 8 * (e >> 2) + 4 * hh + (e & 3);
-        const int kh = (int)__umulhi((unsigned)key, p.w8_magic), kw = key - kh * W8;
-        const unsigned u = min((unsigned)(kh + ch), umax), v = min((unsigned)(kw + cw), umax);
-        float sv = __builtin_amdgcn_fmed3f(s[e], -clipv, clipv) + s_tab[u * TW + v];
-        if (key >= N) sv = -INFINITY;
-        s[e] = sv;
-      }
-    }
-
-    // ---- online softmax.  The running maximum is only raised when some row's tile maximum exceeds it by more than
-    // 2^THR (P' then stays <= 2^THR, exact in fp16's range; the final division by the row sum uses the same stale max).
-    float tm = s[0];
-#pragma unroll
-    for (int e = 1; e < 16; ++e) tm = fmaxf(tm, s[e]);
-    tm = xhalf_max(tm);
-    if (__any(tm > m_run + FLASH_RESCALE_THR)) {
-      const float m_new = fmaxf(m_run, tm);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);       // m_run = -inf (first tile): 0
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[nb][e] *= alpha;
-      l_run *= alpha;
-      m_run = m_new;
-    }
-    f16x8 pb[2];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const float ex = __builtin_amdgcn_exp2f(s[e] - m_run);
-      l_run += ex;
-      pb[e >> 3][e & 7] = (_Float16)ex;
-    }
-
-    // ---- O^T += V^T . P^T; a fragment pair is re-requested (4 blocks ahead) right after the MFMAs that consumed it
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[nb % VPF][0], pb[0], o[nb], 0, 0, 0);
-      o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[nb % VPF][1], pb[1], o[nb], 0, 0, 0);
-      if (nb + VPF < NB) {
-        va[nb % VPF][0] = *reinterpret_cast<const f16x8*>(Vt + (nb + VPF) * 512);
-        va[nb % VPF][1] = *reinterpret_cast<const f16x8*>(Vt + (NB + nb + VPF) * 512);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    stash(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- normalise and store: O[z][q][nb*32 + 8*(e >> 2) + 4*hh + (e & 3)]
-  const float inv = 1.f / xhalf_sum(l_run);
-  if (qidx < N) {
-    float* orow = p.O + ((long)z * N + qidx) * DV + 4 * hh;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(orow + nb * 32 + 8 * g) =
-            make_float4(o[nb][4 * g] * inv, o[nb][4 * g + 1] * inv, o[nb][4 * g + 2] * inv, o[nb][4 * g + 3] * inv);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // k_flash_attn2 (round 5): the same arithmetic as k_flash_attn, software-pipelined INSIDE the wave.
 //
@@ -606,14 +412,8 @@ int launch_flash_attn(const ScoreParams& sp, const void* vT, long ldt, int Dv, f
   dim3 grid(((sp.N + 255) / 256) * Z);
   // k_flash_attn2 reads whole K / V^T tiles by LDS-DMA with no range limit: tile nkt - 1 must exist in full (nkb K blocks are allocated by
   // flash_ws_bytes; V^T needs ldt >= 32 * nkb, which ldt % 32 == 0 && ldt >= N guarantees)
-  const bool v1 = tuning().flash_v1;                 // developer A/B: the round-1 kernel
-  if (v1) {
-    if (PL == 2) hipLaunchKernelGGL((k_flash_attn<64, 256, 2>), grid, dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((k_flash_attn<64, 256, 1>), grid, dim3(512), 0, s, p);
-  } else {
-    if (PL == 2) hipLaunchKernelGGL((k_flash_attn2<64, 256, 2>), grid, dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((k_flash_attn2<64, 256, 1>), grid, dim3(512), 0, s, p);
-  }
+  if (PL == 2) hipLaunchKernelGGL((k_flash_attn2<64, 256, 2>), grid, dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((k_flash_attn2<64, 256, 1>), grid, dim3(512), 0, s, p);
   return (int)hipGetLastError();
 }
 

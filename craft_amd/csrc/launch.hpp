@@ -14,7 +14,7 @@ namespace craft {
 // Developer A/B overrides from the environment, read ONCE when the library is loaded (never in a launch path):
 // CRAFT_HALO_BN (64 | 128), CRAFT_NO_C64, CRAFT_WF_DYNAMIC_TAPS.  Everything a caller may legitimately vary per call is an
 // argument of the C ABI instead (e.g. CRAFT_PV_ROWS in craft_attn_apply's prec).
-struct Tuning { int halo_bn; bool no_c64, wf_dynamic_taps, no_wgrad64, wgrad_sb; int pk_mode, corr_dbg; bool flash_v1, pv_wr2; };
+struct Tuning { int halo_bn; bool no_c64, wf_dynamic_taps, no_wgrad64, wgrad_sb; int pk_mode, corr_dbg; bool pv_wr2; };
 const Tuning& tuning();
 
 struct RowsGemmParams {
@@ -60,19 +60,6 @@ struct ConvGemmParams {
   const float* mask; int ld_mask;       // optional (CONV_EPI_BIAS_ACT): out = mask[pix][col] > 0 ? out : 0 -- the ReLU backward of the layer
                                         // BELOW an input-gradient convolution (mask = that layer's saved output), fused into the epilogue
 };
-
-// k_conv_pk (kernels_conv_pk.hip): the activation operand as up to two packs (craft_pack_operand, spatial form) over one padded grid
-struct ConvPkIn {
-  const unsigned char* seg[2];   // pack base pointers; channel chunks [0, ncg0) come from seg[0], the rest from seg[1]
-  unsigned bytes[2];             // pack sizes (buffer range: reads beyond return zeros)
-  int ncg0;
-  unsigned plane[2], cgs[2];     // byte strides between the planes / the channel groups of each pack
-  int cg_off[2];                 // first channel group used of each pack
-  long row0;                     // pack row of image pixel (b = 0, y = -KH/2, x = -KW/2)
-  int Hp, Wp;                    // the packs' padded grid
-};
-struct ConvPkParams { ConvGemmParams c; ConvPkIn in; };
-int launch_conv_pk(const ConvPkParams& pp, int prec, hipStream_t s);
 
 int launch_pack_operand(const float* x, long ldx, int C, long rows, int B, int H, int W, int padH, int padW, long guard, long rows_p,
                         int prec, void* out, int cg_off, int ncg_total, float* colsum, int tail, hipStream_t s);

@@ -12,7 +12,7 @@ from ctypes import c_double, c_float, c_int, c_long, c_void_p, c_char_p
 
 import torch
 
-ABI_VERSION = 3          # == CRAFT_HIP_ABI_VERSION (include/craft_hip.h): bumped whenever an existing entry point changes its signature
+ABI_VERSION = 4          # == CRAFT_HIP_ABI_VERSION (include/craft_hip.h): bumped whenever an existing entry point changes its signature or goes away
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_TANH, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 W_PACKED = 0x100
@@ -65,7 +65,6 @@ _SIGS = {
     "craft_mask_head": [P, L, P, P, P, P, I, I, I, P, P, I, P],
     "craft_pack_weights": [P, I, I, I, P, P],
     "craft_conv2d_nhwc": [P, L, I, P, P, I, I, I, I, P, L, I, I, I, I, P],
-    "craft_conv2d_pk": [P, L, I, I, I, P, L, I, I, I, L, I, I, I, P, P, P, L, I, I, I, I, P, L, I, I, I, I, P],
     "craft_conv2d_nhwc_res": [P, L, I, P, P, I, I, I, I, P, L, P, L, I, I, I, I, P],
     "craft_conv2d_nhwc2_mask": [P, L, I, P, L, I, P, P, P, L, I, I, I, P, L, P, L, I, I, I, I, P],
     "craft_conv2d_nhwc_ex": [P, L, I, I, I, P, P, P, I, I, I, I, I, P, L, I, I, I, P, I, P],

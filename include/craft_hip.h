@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define CRAFT_HIP_ABI_VERSION 3
+/* 4 (round 6): craft_conv2d_pk (round 5's halo convolution over plane-packed activations, which no product code called) was REMOVED, and
+ * craft_attn_apply accepts CRAFT_PV_ROWS(8 | 10 | 12 | 14) (the 8-wave kernel).  No signature changed. */
+#define CRAFT_HIP_ABI_VERSION 4
 
 #define CRAFT_PREC_F32 0
 #define CRAFT_PREC_BF16 1
@@ -264,17 +266,6 @@ int craft_pack_conv_weights_batch(const void* jobs_dev, const int* first_block_d
 int craft_conv2d_nhwc2(const float* x0, long ld0, int c0, const float* x1, long ld1, int c1, const float* w, const float* bias,
                        const float* bias_field, long ld_bf, int cout, int KH, int KW, int act, float* y, long ldy, int B, int H, int W, int prec,
                        void* stream);
-/* craft_conv2d_nhwc2 over PLANE-PACKED activations (round 5): the conv input of SepConvGRU / BasicMotionEncoder / FlowHead
- * (update.py:49-64, :79-87, :8-16) handed over as the 16-bit planes the matrix cores consume instead of fp32 tokens, so that the
- * K loop copies its halo (LDS-DMA) instead of converting it.  x0 (and x1: the virtual channel concatenation [x0 | x1]) are packs in
- * the SPATIAL form of craft_pack_operand -- [plane][ncg][rows_p][32] 16-bit over the zero-padded grid [B][H + 2 padH][W + 2 padW + tail]
- * with `guard` rows in front (F16X3: two fp16 planes; F16 / BF16: one) -- of which channel groups [cg_off, cg_off + c/32) are read;
- * both packs share guard / padH / padW / tail; padH >= KH/2, padW >= KW/2.  Stride 1, (KH, KW) in {(1,5), (5,1), (3,3)}; w from
- * craft_pack_weights / craft_pack_conv_weights (prec | CRAFT_W_PACKED, optionally | CRAFT_CONV_W16); y fp32 tokens [B*H*W][cout].
- * Exactly one of bias / bias_field.  Bit-identical to craft_conv2d_nhwc2 on the tensors the packs were made from. */
-int craft_conv2d_pk(const void* x0, long rows_p0, int ncg0, int cg_off0, int c0, const void* x1, long rows_p1, int ncg1, int cg_off1, int c1,
-                    long guard, int padH, int padW, int tail, const float* w, const float* bias, const float* bias_field, long ld_bf, int cout,
-                    int KH, int KW, int act, float* y, long ldy, int B, int H, int W, int prec, void* stream);
 /* craft_conv2d_nhwc with the tail of a ResidualBlock fused into the epilogue (round 5): y = relu(res + act(conv(x) + bias)), res fp32
  * tokens [B*H*W][cout] with row stride ldr -- `self.relu(x + y)` of extractor.py:56-63 for the encoder whose BatchNorm is folded into the
  * weights (cnet, eval): the standalone craft_residual_relu pass (read x, read y, write out) disappears.  Stride 1. */

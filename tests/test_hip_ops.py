@@ -545,53 +545,6 @@ def test_conv2d_w16_is_the_full_product_on_fp16_weights(device, KH, KW, cin, cou
     assert 1e-5 < rel < 6e-4, rel
 
 
-def _conv_pk(xt_list, hw, pad, wp, bias, cout, KH, KW, act, prec, device, field=None, tail=0):
-    """craft_conv2d_pk on packs made from the token tensors ``xt_list`` (one or two: a virtual channel cat)."""
-    from craft_amd.autograd import Packed
-    from craft_amd.hip import call, W_PACKED
-    B, N, _ = xt_list[0].shape
-    H8, W8 = hw
-    pks = [Packed(t, prec, spatial=(B, H8, W8, pad[0], pad[1])) for t in xt_list]
-    y = torch.empty(B, N, cout, device=device)
-    a, b = pks[0], (pks[1] if len(pks) > 1 else None)
-    call("craft_conv2d_pk", a.buf, a.rows_p, a.C_p // 32, 0, a.C_p, b.buf if b else None, b.rows_p if b else 0, b.C_p // 32 if b else 0, 0,
-         b.C_p if b else 0, a.guard, pad[0], pad[1], tail, wp, None if field is not None else bias, field, field.stride(-2) if field is not None else 0,
-         cout, KH, KW, act, y, cout, B, H8, W8, prec | W_PACKED)
-    return y
-
-
-@pytest.mark.parametrize("prec", [PREC_F16X3, PREC_F16, PREC_BF16])
-@pytest.mark.parametrize("KH,KW,cins,cout,relu,pad,shape", [
-    (1, 5, (96,), 256, False, (0, 2), (2, 11, 21)), (5, 1, (128,), 126, True, (2, 0), (2, 11, 21)), (3, 3, (64,), 192, True, (1, 1), (2, 11, 21)),
-    (1, 5, (128, 256), 256, False, (2, 2), (1, 16, 32)), (5, 1, (128, 256), 128, False, (2, 2), (1, 16, 32)), (3, 3, (32, 32), 64, True, (2, 3), (3, 9, 17)),
-    (3, 3, (256,), 126, True, (1, 1), (1, 24, 48))])
-def test_conv2d_pk_equals_the_token_kernel(device, prec, KH, KW, cins, cout, relu, pad, shape):
-    """craft_conv2d_pk (LDS-DMA halo over plane-packed activations) must reproduce craft_conv2d_nhwc2 BIT FOR BIT on the tensors the packs
-    were made from: same planes (split_f16x3), same weights, same MFMA order -- ragged patches, zero padding at every border, a pack
-    border wider than the convolution's, two-pack virtual concatenation; and it is held to F.conv2d like test_conv2d_tokens."""
-    from craft_amd.hip import call, W_PACKED
-    B, H8, W8 = shape
-    cin = sum(cins)
-    x = gen(B, cin, H8, W8, seed=96)
-    w = gen(cout, cin, KH, KW, seed=97) / math.sqrt(cin * KH * KW)
-    b = gen(cout, seed=98)
-    xt = x.permute(0, 2, 3, 1).reshape(B, H8 * W8, cin).contiguous().to(device)      # tokens [B, N, cin]
-    wp = ops.pack_conv_prec(w.to(device), prec)
-    act = ACT_RELU if relu else ACT_NONE
-    parts = list(torch.split(xt, list(cins), dim=-1))
-    y_ref = torch.empty(B, H8 * W8, cout, device=device)
-    x1 = parts[1] if len(parts) > 1 else None
-    call("craft_conv2d_nhwc2", parts[0], xt.stride(-2), cins[0], x1, xt.stride(-2) if x1 is not None else 0, cins[1] if x1 is not None else 0, wp,
-         b.to(device), None, 0, cout, KH, KW, act, y_ref, cout, B, H8, W8, prec | W_PACKED)
-    y = _conv_pk(parts, (H8, W8), pad, wp, b.to(device), cout, KH, KW, act, prec, device)
-    assert torch.equal(y, y_ref), f"max |diff| {float((y - y_ref).abs().max()):.3e}"
-    ref = F.conv2d(x, w, b, padding=(KH // 2, KW // 2))
-    if relu:
-        ref = torch.relu(ref)
-    rt, at = TOL[prec]
-    close(ops.tokens_to_nchw(y, H8, W8), ref, rt * 2, at * 4, f"conv_pk {KH}x{KW} prec={prec}")
-
-
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("cin,cout,shape", [(64, 64, (2, 24, 40)), (96, 96, (2, 11, 21)), (128, 128, (1, 9, 17))])
 def test_conv2d_residual_epilogue(device, prec, cin, cout, shape):

@@ -6,7 +6,7 @@ set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 TAG=${1:-pmc_r5}; shift || true
-GROUPS_=${*:-"grustep convtok convpk menc flash fnet cnet corr pv probs"}
+GROUPS_=${*:-"grustep convtok menc flash fnet cnet corr pv probs"}
 O=$REPO/gpurun_out/$TAG; mkdir -p $O
 SQ1="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES"
 SQ2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"

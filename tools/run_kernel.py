@@ -92,9 +92,8 @@ def main():
             e.record()
             torch.cuda.synchronize()
             print(f"{which} B={B} {H8}x{W8}: {s.elapsed_time(e) / reps * 1e3:.1f} us per call ({B * ((H8 + 7) // 8) * ((W8 + 15) // 16)} patches)")
-    elif which in ("convpk", "convtok"):
-        # the GRU's z|r convolution shape (1x5, 384 -> 256) on plane-packed activations (k_conv_pk) / on fp32 tokens (k_conv_halo_wf)
-        from craft_amd.autograd import Packed
+    elif which == "convtok":
+        # the GRU's z|r convolution shape (1x5, 384 -> 256) on fp32 tokens (k_conv_halo_wf)
         from craft_amd.hip import call, ACT_NONE, W_PACKED, PREC_F16X3
         KH, KW, cin, cout = int(os.environ.get("KH", 1)), int(os.environ.get("KW", 5)), int(os.environ.get("CIN", 384)), int(os.environ.get("COUT", 256))
         x = torch.randn(B, N, cin, device=dev)
@@ -102,13 +101,8 @@ def main():
         wp = ops.pack_conv_weights(w, PREC_F16X3)
         zb = torch.zeros(cout, device=dev)
         y = torch.empty(B, N, cout, device=dev)
-        pk = Packed(x, PREC_F16X3, spatial=(B, H8, W8, 2, 2))
         for _ in range(3 + int(os.environ.get("REPS", 4))):
-            if which == "convpk":
-                call("craft_conv2d_pk", pk.buf, pk.rows_p, pk.C_p // 32, 0, cin, None, 0, 0, 0, 0, pk.guard, 2, 2, 0, wp, zb, None, 0, cout, KH, KW, ACT_NONE, y, cout,
-                     B, H8, W8, PREC_F16X3 | W_PACKED)
-            else:
-                call("craft_conv2d_nhwc", x, cin, cin, wp, zb, cout, KH, KW, ACT_NONE, y, cout, B, H8, W8, PREC_F16X3 | W_PACKED)
+            call("craft_conv2d_nhwc", x, cin, cin, wp, zb, cout, KH, KW, ACT_NONE, y, cout, B, H8, W8, PREC_F16X3 | W_PACKED)
     elif which in ("fnet", "cnet"):
         from craft_amd import CRAFT, default_args
         from craft_amd.synth import synth_state_dict, synth_pair
