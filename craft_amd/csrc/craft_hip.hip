@@ -20,6 +20,8 @@ const Tuning& tuning() {
     v.no_wgrad64 = getenv("CRAFT_NO_WGRAD64") != nullptr;   // weight gradient of 64-channel layers on the generic 128-row tile (developer A/B)
     if (const char* e = getenv("CRAFT_CORR_DBG")) v.corr_dbg = atoi(e);    // store ablations of k_corr_build4t (developer, tools/corr_write_pmc.sh)
     if (const char* e = getenv("CRAFT_PK_MODE")) v.pk_mode = atoi(e);      // ablations of k_gemm_pk (developer): 1 no DMA after tile 0, 2 no epilogue, 4 no MFMA phase
+    v.corr_ncp = 8;                                       // k_corr_build4t: cell pairs per block (the row band); CRAFT_CORR_NCP=1: one pair per block (developer A/B)
+    if (const char* e = getenv("CRAFT_CORR_NCP")) v.corr_ncp = atoi(e);
     v.pv_wr2 = getenv("CRAFT_PV_NO_WR2") == nullptr;      // k_pv16: the launcher may pick the 8-wave (2 x 32 MT rows) instantiation (round 6; off: developer A/B)
     return v;
   }();

@@ -400,6 +400,13 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build4s(ScoreParams p, const 
 // Block = 4 waves: (wave >> 1) = one of two horizontally adjacent cells, (wave & 1) = one of two groups of 32 queries.
 // ---------------------------------------------------------------------------------------------
 constexpr int CORR_STG = 128 + 4;      // floats per query in the level-0 staging tile (+ 16 B: conflict-free ds_write_b128)
+// Row band (round 6; VERDICT r5 "next" 3): a block walks up to CORR_NCP_MAX cell pairs of ONE cell row with the same 64 queries.  Levels 2
+// and 3 were 4-byte stores per lane, 64 different lines per instruction, each line completed by eight blocks that run far apart in time:
+// the memory side wrote (and partly read back) a whole sector per float -- 64 MB of payload, ~0.5 GB of traffic at 448x1024 x batch 4
+// (PMC WRITE_SIZE 1.57 GB for 1.09 GB of pyramid).  Here the band's level-2 rows (2 per query, 4 floats per cell pair) and level-3 row
+// collect in LDS and leave as whole rows -- 128-byte lines at W8 = 128 -- once per block; the bias table and the statistics' atomics are
+// per band as well.  Strides odd in floats: a wave's 32 queries x 2 key halves hit 64 different banks.
+constexpr int CORR_NCP_MAX = 8, CORR_B2W = 4 * CORR_NCP_MAX + 1, CORR_B3W = 2 * CORR_NCP_MAX + 1;
 // FAST (round 6): the softmax over the four modes with mode 0 as the reference instead of the row maximum --
 //     c = (s0 + s1 e1 + s2 e2 + s3 e3) / (1 + e1 + e2 + e3),   e_m = 2^(wl (s_m - s0))
 // -- THREE exponentials per element instead of four (mode 0's is exactly 1), no maximum, and wl (s_m - s0) as one FMA per mode: 13
@@ -411,7 +418,8 @@ template <bool CLAMP, bool BIAS, bool VEC, bool TILED, bool FAST>
 __device__ __forceinline__ void corr4t_epilogue(const ScoreParams& p, const f32x16 (&acc)[4][2], float wl, long q, bool qvalid, int qh,
                                                 int qw, int cy, int cx, int g, const float* s_tab, int R, int TW, float* __restrict__ pyr0,
                                                 float* __restrict__ pyr1, float* __restrict__ pyr2, float* __restrict__ pyr3, float& s1,
-                                                float& s2, float* __restrict__ stage, int ql_blk) {
+                                                float& s2, float* __restrict__ stage, int ql_blk, float* __restrict__ band2,
+                                                float* __restrict__ band3, int c_lo) {
   const int N = p.N, H8 = p.H8, W8 = p.W8;
   const int h1 = H8 >> 1, w1 = W8 >> 1, h2 = h1 >> 1, w2 = w1 >> 1, h3 = h2 >> 1, w3 = w2 >> 1;
   const int ntx0 = (W8 + 15) >> 4, ntx1 = (w1 + 7) >> 3;
@@ -519,15 +527,19 @@ __device__ __forceinline__ void corr4t_epilogue(const ScoreParams& p, const f32x
     // level 2: the lane's 4 x 4 block = mean of its four level-1 cells
     const int y2 = 2 * cy + mt, x2 = 2 * cx + g;
     const float v2 = sum16 * 0.25f;
-    if (qvalid && y2 < h2 && x2 < w2 && !(p.dbg & 2)) pyr2[(q * h2 + y2) * w2 + x2] = v2;
+    // (row band: levels 2 / 3 of the block's whole key band are collected in LDS and leave as whole lines after the last cell pair)
+    if (band2) band2[(ql_blk * 2 + mt) * CORR_B2W + (x2 - 4 * c_lo)] = v2;
+    else if (qvalid && y2 < h2 && x2 < w2 && !(p.dbg & 2)) pyr2[(q * h2 + y2) * w2 + x2] = v2;
     cell += v2;
   }
   // level 3: 8 x 8 cell = the two tiles of this lane + the partner lane (g ^ 1)
   cell += __shfl_xor(cell, 32);
-  if (g == 0 && qvalid && cy < h3 && cx < w3 && !(p.dbg & 2)) pyr3[(q * h3 + cy) * w3 + cx] = cell * 0.25f;
+  if (band3) { if (g == 0) band3[ql_blk * CORR_B3W + (cx - 2 * c_lo)] = cell * 0.25f; }
+  else if (g == 0 && qvalid && cy < h3 && cx < w3 && !(p.dbg & 2)) pyr3[(q * h3 + cy) * w3 + cx] = cell * 0.25f;
 }
 
-__global__ __launch_bounds__(NTHREADS) void k_corr_build4t(ScoreParams p, const _Float16* __restrict__ Qs, const _Float16* __restrict__ Ks,
+// (two blocks per CU: the unified register file holds two waves of <= 256 registers per SIMD; the row-band loop must not tip it over)
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_corr_build4t(ScoreParams p, const _Float16* __restrict__ Qs, const _Float16* __restrict__ Ks,
                                                           float w_aggr, float* __restrict__ pyr0, float* __restrict__ pyr1,
                                                           float* __restrict__ pyr2, float* __restrict__ pyr3, double* __restrict__ sums) {
   constexpr int BK_ = 128, BQ = 64, D = 64, LD = D + 8, MT = 2;       // keys x queries per block
@@ -535,10 +547,16 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build4t(ScoreParams p, const 
   __shared__ __attribute__((aligned(16))) _Float16 Bs[2 * BQ * LD];       // queries
   __shared__ float s_tab[33 * 33];
   __shared__ float s_red[8];
+  __shared__ float s_band2[BQ * 2 * CORR_B2W];
+  __shared__ float s_band3[BQ * CORR_B3W];
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ncx2 = (((p.W8 + 7) >> 3) + 1) >> 1;                    // cell pairs per cell row
-  const int cy = blockIdx.y / ncx2, cxp = blockIdx.y - cy * ncx2;
+  const int ncp = p.ncp > 1 ? p.ncp : 1, nsplit = (ncx2 + ncp - 1) / ncp;
+  const int cy_ = blockIdx.y / nsplit, c_lo = (blockIdx.y - cy_ * nsplit) * ncp, c_hi = min(ncx2, c_lo + ncp);
+  const bool band = p.ncp > 1;
+  float* const band2 = band ? s_band2 : nullptr;
+  float* const band3 = band ? s_band3 : nullptr;
   const int q0 = blockIdx.x * BQ, b = blockIdx.z;
   const int N = p.N, C = 4 * D;
   const long rows_tot = (long)p.B * N;
@@ -552,16 +570,41 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build4t(ScoreParams p, const 
   // staging: thread -> (row r8 + 32 i, 16-byte chunk c8 of the 128-byte mode row).  Key row a of the tile = cell (a >> 6) of the
   // pair, key (dy, dx) = ((a >> 3) & 7, a & 7) -- MFMA row r of tile mt is a = cell*64 + mt*32 + r, i.e. dy = 4 mt + (r >> 3), dx = r & 7
   const int c8 = tid & 7, r8 = tid >> 3;
-  const _Float16* kp[4];
   const _Float16* qp[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) qp[i] = Qs + ((long)b * N + min(q0 + r8 + 32 * i, N - 1)) * C + c8 * 8;
+  float s1 = 0.f, s2 = 0.f;
+  const int r_ = lane & 31;
+  const float wl = w_aggr * 1.4426950408889634f;
+  // this lane's query
+  const int ql = q0 + wq * 32 + r_;
+  const bool qvalid = ql < N;
+  const int qi = min(ql, N - 1);
+  const int qh_ = qi / p.W8, qw_ = qi - qh_ * p.W8;
+  const long q_ = (long)b * N + qi;
+  // positional window: rows of the key cell vs rows of the query tile (block-uniform)
+  const int q_hmin = q0 / p.W8, q_hmax = min(q0 + BQ - 1, N - 1) / p.W8;
+  const int k_hmin = 8 * cy_, k_hmax = min(8 * cy_ + 7, p.H8 - 1);
+  const bool has_bias = p.pos_tab != nullptr && k_hmax >= q_hmin - R && k_hmin <= q_hmax + R;
+  float* stage = reinterpret_cast<float*>(As);                    // 64 x CORR_STG floats = 33 KB over the (dead) key tiles
+  static_assert(64 * CORR_STG * 4 <= (int)sizeof(As), "level-0 staging tile must fit in the key-tile buffer");
+#pragma unroll 1
+  for (int cxp = c_lo; cxp < c_hi; ++cxp) {      // ---- the row band: one cell pair per iteration (one iteration without it)
+  // (hipcc hoists every loop-invariant piece of the epilogue's address arithmetic -- q * size per level, the bias-table rows of the eight
+  // key rows, the staging offsets -- out of the band loop and then spills 87 registers to scratch to keep them alive across the MFMA
+  // phase: the values below are re-derived per iteration on purpose, the asm statements hide that they do not change)
+  int cy = cy_, qh = qh_, qw = qw_, r = r_, g = lane >> 5;
+  long q = q_;
+  asm volatile("" : "+s"(cy));
+  asm volatile("" : "+v"(qh), "+v"(qw), "+v"(q), "+v"(r), "+v"(g));
+  const int g8 = g * 8;
+  const _Float16* kp[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int a = r8 + 32 * i;
     const int ky = min(8 * cy + ((a >> 3) & 7), p.H8 - 1), kx = min(8 * (2 * cxp + (a >> 6)) + (a & 7), p.W8 - 1);
     kp[i] = Ks + ((long)b * N + (long)ky * p.W8 + kx) * C + c8 * 8;
   }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) qp[i] = Qs + ((long)b * N + min(q0 + r8 + 32 * i, N - 1)) * C + c8 * 8;
   // two register sets: the operands of mode m + 2 are requested while mode m is multiplied (round 5: with one set the request for
   // m + 1 had only the 24 MFMAs of mode m -- 0.4 us -- to come back from L2 / HBM, and a block waited ~1.5 us per mode)
   u32x4 ra[2][2][4], rb[2][2][2];
@@ -590,7 +633,6 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build4t(ScoreParams p, const 
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[m][mt][e] = 0.f;
-  const int r = lane & 31, g = lane >> 5, g8 = g * 8;
   // MFMA A row r of tile mt must be key (dy = 4 mt + (r' >> 2 ...)): the C layout puts row (e & 3) + 8 (e >> 2) + 4 g in register e,
   // so LDS row a = wk*64 + mt*32 + rho where rho is the tile row whose (dy, dx) we want at MFMA row r: MFMA row index R_ = r maps to
   // key (dyl = R_ >> 3, dx = R_ & 7) when the tile rows are stored in that same order -- which is the staging order above.
@@ -622,22 +664,8 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build4t(ScoreParams p, const 
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  const float wl = w_aggr * 1.4426950408889634f;
-  // this lane's query and cell
-  const int ql = q0 + wq * 32 + r;
-  const bool qvalid = ql < N;
-  const int qi = min(ql, N - 1);
-  const int qh = qi / p.W8, qw = qi - qh * p.W8;
-  const int cx = 2 * cxp + wk;
-  const long q = (long)b * N + qi;
-  // positional window: rows of the key cell vs rows of the query tile (block-uniform)
-  const int q_hmin = q0 / p.W8, q_hmax = min(q0 + BQ - 1, N - 1) / p.W8;
-  const int k_hmin = 8 * cy, k_hmax = min(8 * cy + 7, p.H8 - 1);
-  const bool has_bias = p.pos_tab != nullptr && k_hmax >= q_hmin - R && k_hmin <= q_hmax + R;
+  const int cx = 2 * cxp + wk;                                   // this wave's cell
   const bool vec = (p.W8 & 3) == 0 && 8 * cx + 7 < p.W8;        // every 4-key run of this wave is a full, 16-byte aligned float4
-  float s1 = 0.f, s2 = 0.f;
-  float* stage = reinterpret_cast<float*>(As);                    // 64 x CORR_STG floats = 33 KB over the (dead) key tiles
-  static_assert(64 * CORR_STG * 4 <= (int)sizeof(As), "level-0 staging tile must fit in the key-tile buffer");
   if (p.tiled) __syncthreads();                                  // every wave is done reading As / Bs
   if (8 * cx < p.W8) {                                           // (the second cell of the last pair may lie outside the image)
     // may the mode-0-referenced softmax run?  wl (s_m - s0) <= 110 for every element of the wave's tile (a NaN fails the test: the
@@ -664,8 +692,8 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build4t(ScoreParams p, const 
       else { if (clamp) scan(std::false_type(), std::true_type()); else scan(std::false_type(), std::false_type()); }
       fast = __all(wl * dd <= 110.f) && !(p.dbg & 4);
     }
-#define EPI2(CL, BI, VE, FA) do { if (p.tiled) corr4t_epilogue<CL, BI, VE, true, FA>(p, acc, wl, q, qvalid, qh, qw, cy, cx, g, s_tab, R, TW, pyr0, pyr1, pyr2, pyr3, s1, s2, stage, wq * 32 + r); \
-                                 else corr4t_epilogue<CL, BI, VE, false, FA>(p, acc, wl, q, qvalid, qh, qw, cy, cx, g, s_tab, R, TW, pyr0, pyr1, pyr2, pyr3, s1, s2, stage, wq * 32 + r); } while (0)
+#define EPI2(CL, BI, VE, FA) do { if (p.tiled) corr4t_epilogue<CL, BI, VE, true, FA>(p, acc, wl, q, qvalid, qh, qw, cy, cx, g, s_tab, R, TW, pyr0, pyr1, pyr2, pyr3, s1, s2, stage, wq * 32 + r, band2, band3, c_lo); \
+                                 else corr4t_epilogue<CL, BI, VE, false, FA>(p, acc, wl, q, qvalid, qh, qw, cy, cx, g, s_tab, R, TW, pyr0, pyr1, pyr2, pyr3, s1, s2, stage, wq * 32 + r, band2, band3, c_lo); } while (0)
 #define EPI(CL, BI, VE) do { if (fast) EPI2(CL, BI, VE, true); else EPI2(CL, BI, VE, false); } while (0)
     if (clamp) { if (has_bias) { if (vec) EPI(true, true, true); else EPI(true, true, false); } else { if (vec) EPI(true, false, true); else EPI(true, false, false); } }
     else { if (has_bias) { if (vec) EPI(false, true, true); else EPI(false, true, false); } else { if (vec) EPI(false, false, true); else EPI(false, false, false); } }
@@ -680,12 +708,45 @@ __global__ __launch_bounds__(NTHREADS) void k_corr_build4t(ScoreParams p, const 
     const int ntx0 = (p.W8 + 15) >> 4;
     const long sz0 = (long)((p.H8 + 7) >> 3) * ntx0 * 128;
     float* tile0 = pyr0 + ((long)b * N + q0) * sz0 + ((long)cy * ntx0 + cxp) * 128;
+    int tid2 = tid;
+    asm volatile("" : "+v"(tid2));               // (as above: the eight (query, chunk) offsets are not to live across the MFMA phase)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int c = tid + 256 * i, ql2 = c >> 5, w16 = c & 31;
+      const int c = tid2 + 256 * i, ql2 = c >> 5, w16 = c & 31;
       if (q0 + ql2 < N) {
         const float4 v = *reinterpret_cast<const float4*>(&stage[ql2 * CORR_STG + w16 * 4]);
         *reinterpret_cast<float4*>(tile0 + (long)ql2 * sz0 + w16 * 4) = v;
+      }
+    }
+  }
+  }      // (row band)
+  if (band && !(p.dbg & 2)) {
+    // levels 2 and 3 of the band, LDS -> HBM as whole rows: per query two level-2 rows of up to 4 ncp floats and one level-3 row of 2 ncp
+    __syncthreads();
+    const int h1 = p.H8 >> 1, w1 = p.W8 >> 1, h2 = h1 >> 1, w2 = w1 >> 1, h3 = h2 >> 1, w3 = w2 >> 1;
+    const int n2 = min(4 * (c_hi - c_lo), w2 - 4 * c_lo), n3 = min(2 * (c_hi - c_lo), w3 - 2 * c_lo);
+    if (n2 > 0) {
+      if ((w2 & 3) == 0) {                                        // 16-byte pieces: a wave instruction writes 8 rows x 128 B
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int idx = tid + 256 * i, row = idx >> 3, ch = idx & 7, ql2 = row >> 1, y2 = 2 * cy_ + (row & 1);
+          if (4 * ch < n2 && q0 + ql2 < N && y2 < h2) {
+            const float* sb = &s_band2[row * CORR_B2W + 4 * ch];
+            *reinterpret_cast<float4*>(pyr2 + (((long)b * N + q0 + ql2) * h2 + y2) * w2 + 4 * c_lo + 4 * ch) = make_float4(sb[0], sb[1], sb[2], sb[3]);
+          }
+        }
+      } else {
+        for (int idx = tid; idx < 128 * 32; idx += 256) {
+          const int row = idx >> 5, j = idx & 31, ql2 = row >> 1, y2 = 2 * cy_ + (row & 1);
+          if (j < n2 && q0 + ql2 < N && y2 < h2) pyr2[(((long)b * N + q0 + ql2) * h2 + y2) * w2 + 4 * c_lo + j] = s_band2[row * CORR_B2W + j];
+        }
+      }
+    }
+    if (n3 > 0 && cy_ < h3) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i, ql2 = idx >> 4, j = idx & 15;
+        if (j < n3 && q0 + ql2 < N) pyr3[(((long)b * N + q0 + ql2) * h3 + cy_) * w3 + 2 * c_lo + j] = s_band3[ql2 * CORR_B3W + j];
       }
     }
   }
@@ -798,10 +859,14 @@ int launch_corr_build_pyramid(const ScoreParams& p, float w_aggr, float* pyr0, f
   hipLaunchKernelGGL(k_split_planes, g1, dim3(256), 0, s, p.Q, p.ldq, rows, 256, p.scale, Qs);
   hipLaunchKernelGGL(k_split_planes, g1, dim3(256), 0, s, p.Kf, p.ldk, rows, 256, 1.f, Ks);
   const int ncx2 = (((p.W8 + 7) / 8) + 1) / 2;
-  dim3 grid((p.N + 63) / 64, ((p.H8 + 7) / 8) * ncx2, p.B);
+  // the row band: a block walks ncp cell pairs (<= CORR_NCP_MAX) of one cell row; the row is cut into equal parts
+  const int want = tuning().corr_ncp < 1 ? 1 : (tuning().corr_ncp > CORR_NCP_MAX ? CORR_NCP_MAX : tuning().corr_ncp);
+  const int nsplit = (ncx2 + want - 1) / want, ncp = (ncx2 + nsplit - 1) / nsplit;
+  dim3 grid((p.N + 63) / 64, ((p.H8 + 7) / 8) * ((ncx2 + ncp - 1) / ncp), p.B);
   ScoreParams pd = p;
   pd.dbg = tuning().corr_dbg;
   pd.tiled = tiled;
+  pd.ncp = ncp;
   hipLaunchKernelGGL(k_corr_build4t, grid, dim3(NTHREADS), 0, s, pd, Qs, Ks, w_aggr, pyr0, pyr1, pyr2, pyr3, sums);
   return (int)hipGetLastError();
 }

@@ -14,7 +14,7 @@ namespace craft {
 // Developer A/B overrides from the environment, read ONCE when the library is loaded (never in a launch path):
 // CRAFT_HALO_BN (64 | 128), CRAFT_NO_C64, CRAFT_WF_DYNAMIC_TAPS.  Everything a caller may legitimately vary per call is an
 // argument of the C ABI instead (e.g. CRAFT_PV_ROWS in craft_attn_apply's prec).
-struct Tuning { int halo_bn; bool no_c64, wf_dynamic_taps, no_wgrad64, wgrad_sb; int pk_mode, corr_dbg; bool pv_wr2; };
+struct Tuning { int halo_bn; bool no_c64, wf_dynamic_taps, no_wgrad64, wgrad_sb; int pk_mode, corr_dbg; bool pv_wr2; int corr_ncp; };
 const Tuning& tuning();
 
 struct RowsGemmParams {
@@ -108,7 +108,8 @@ struct ScoreParams {
   float* rowsum;                      // k_attn_probs: non-null = deferred normalisation, row sums [B][M][N] out ...
   unsigned* rowmax;                   // ... followed by [B][M][N] ordered-uint row maxima (scratch): rowsum + B*M*N
   int tiled;                          // k_corr_build4t: levels 0 / 1 of the pyramid in the tiled layout (CRAFT_PYR_TILED)
-  int dbg;                            // developer ablation of k_corr_build4t's stores (CRAFT_CORR_DBG: 1 no level 0, 2 no levels 1-3), 0 in production
+  int dbg;                            // developer ablation of k_corr_build4t's stores (CRAFT_CORR_DBG: 1 no level 0, 2 no levels 1-3, 4 no mode-0 softmax), 0 in production
+  int ncp;                            // k_corr_build4t: cell pairs of a cell row one block walks (the row band; <= 1: one pair per block as in rounds 2-5)
 };
 
 // deferred-normalisation probabilities as one launch of independent waves (kernels_attn_w.hip); ws: B*M*ceil(N/128)*16384 bytes

@@ -36,6 +36,36 @@ def _batch(B, H, W, seed):
     return im1, im2, flow, valid
 
 
+def test_step_load_step_uses_the_loaded_weights(device, tmp_path):
+    """the trainer's batched weight-pack registry (ops.WeightPackRegistry: every conv-weight operand of a step re-packed in one
+    launch after the optimizer update) must not hand out packs of the OLD weights after a checkpoint load / load_state_dict between two
+    steps.  step -> load other weights -> step must produce the loss of a FRESH trainer built on those weights, in a policy that packs
+    (f16x3) -- with the stale packs the second loss is the old model's."""
+    from craft_amd.train import load_checkpoint, save_checkpoint
+    im1, im2, flow, valid = _batch(2, 128, 160, 5)
+
+    def mk(seed):
+        m = CRAFT(default_args(hip_precision="train_f16x3", dropout_prob=0.0))
+        m.load_state_dict(synth_state_dict(m.state_dict(), seed=seed), strict=True)
+        return m.to(device)
+    other = mk(4321)
+    tr_o = Trainer(other, lr=1e-4, num_steps=50, iters=2, clip=1.0)
+    ck = str(tmp_path / "other.pth")
+    save_checkpoint(ck, other, tr_o.optimizer, tr_o.scheduler)
+    expect = tr_o.step(im1, im2, flow, valid)["loss"]                 # first step of a fresh trainer on the OTHER weights
+    model = mk(1234)
+    tr = Trainer(model, lr=1e-4, num_steps=50, iters=2, clip=1.0)
+    l0 = tr.step(im1, im2, flow, valid)["loss"]
+    tr.step(im1, im2, flow, valid)                                    # (the registry is fresh from here on: packs of THESE weights)
+    assert abs(l0 - expect) > 1e-3 * abs(expect), "the two weight sets must give different losses for this test to mean anything"
+    load_checkpoint(ck, model, tr.optimizer)                          # in-place copy into the flat buffer's views
+    got = tr.step(im1, im2, flow, valid)["loss"]
+    assert got == pytest.approx(expect, rel=2e-5), (got, expect, l0)
+    # ... and the same through a bare load_state_dict (no helper that could bump an epoch)
+    model.load_state_dict({k: v.detach().clone() for k, v in mk(1234).state_dict().items()}, strict=True)
+    assert tr.step(im1, im2, flow, valid)["loss"] == pytest.approx(l0, rel=2e-5)
+
+
 def test_steps_move_weights_and_inference_sees_them(device):
     model = _model(device)
     tr = Trainer(model, lr=2e-4, num_steps=50, iters=3, clip=1.0)

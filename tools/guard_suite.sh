@@ -4,7 +4,7 @@
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; cd $REPO
 MODE=${1:-end}; TMO=${2:-600}; shift 2 || true
-FILES=${@:-$(ls tests/test_train_*.py tests/test_trainer_gpu.py tests/test_hip_ops.py tests/test_hip_e2e.py tests/test_gemm_pk*.py tests/test_full_size_parity.py tests/test_fuzz_parity.py tests/test_augment.py tests/test_eval_harness.py tests/test_harness_golden.py tests/test_integration_doc.py tests/test_reference_wrappers.py tests/test_bench_contract.py)}
+FILES=${@:-$(ls tests/test_cfg_step_parity.py tests/test_train_*.py tests/test_trainer_gpu.py tests/test_hip_ops.py tests/test_hip_e2e.py tests/test_gemm_pk*.py tests/test_full_size_parity.py tests/test_fuzz_parity.py tests/test_augment.py tests/test_eval_harness.py tests/test_harness_golden.py tests/test_integration_doc.py tests/test_reference_wrappers.py tests/test_bench_contract.py)}
 O=gpurun_out/guard_$MODE; mkdir -p $O
 for f in $FILES; do
   b=$(basename $f .py)
