@@ -22,7 +22,9 @@ VARIANTS = [({}, 2.5), ({}, 40.0), (dict(use_setrans=False), 2.5), (dict(craft=F
             (dict(use_setrans=False, position_and_content=True), 2.5), (dict(use_setrans=False, position_only=True), 2.5),
             (dict(f1trans="shared"), 2.5), (dict(f1trans="private"), 2.5),
             # --interpos / --intrapos lsinu (setrans.py:623-646, :763-800): learned sinusoidal embedding instead of the bias table
-            (dict(inter_pos_code_type="lsinu", intra_pos_code_type="lsinu"), 2.5), (dict(inter_pos_code_type="lsinu"), 2.5)]
+            (dict(inter_pos_code_type="lsinu", intra_pos_code_type="lsinu"), 2.5), (dict(inter_pos_code_type="lsinu"), 2.5),
+            # --num_heads 2 with GMA's attention (gma.py:123-126, :133-138): head merge + project (round 6)
+            (dict(use_setrans=False, num_heads=2), 2.5)]
 
 
 def sweep(n: int, seed0: int = 0, verbose: bool = True, variants: bool = False):
@@ -47,7 +49,7 @@ def sweep(n: int, seed0: int = 0, verbose: bool = True, variants: bool = False):
             m.load_state_dict(synth_state_dict(m.state_dict(), seed=1234 + vi, qk_gain=qk_gain))
             cfg = O.OracleConfig(craft=args.craft, use_setrans=args.use_setrans, f2_attn_mask_radius=args.f2_attn_mask_radius,
                                  f1trans=args.f1trans, position_only=args.position_only,
-                                 position_and_content=args.position_and_content)
+                                 position_and_content=args.position_and_content, num_heads=args.num_heads)
             models[key] = (m.to(dev).eval(), cfg)
         model, cfg = models[key]
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}

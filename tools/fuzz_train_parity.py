@@ -20,7 +20,7 @@ from craft_amd.synth import synth_pair, synth_state_dict  # noqa: E402
 from oracle import craft_oracle as O  # noqa: E402
 
 VARIANTS = [dict(), dict(use_setrans=False), dict(craft=False), dict(craft=False, use_setrans=False),
-            dict(inter_pos_code_type="lsinu", intra_pos_code_type="lsinu")]
+            dict(inter_pos_code_type="lsinu", intra_pos_code_type="lsinu"), dict(use_setrans=False, num_heads=2)]
 H_MIN, H_MAX = int(os.environ.get("FUZZ_H_MIN", 64)), int(os.environ.get("FUZZ_H_MAX", 136))
 W_MIN, W_MAX = int(os.environ.get("FUZZ_W_MIN", 64)), int(os.environ.get("FUZZ_W_MAX", 200))
 
