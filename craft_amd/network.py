@@ -39,6 +39,28 @@ from .setrans import SelfAttVisPosTrans, SETransConfig
 from .update import GMAUpdateBlock
 
 
+class _JoinOnError:
+    """Fork / join hygiene of CRAFT.forward: if the pass leaves between a fork and its join (a launch that fails, a refused shape), the side
+    streams are still joined into the caller's stream -- tensors allocated on the caller's stream and written by side-stream kernels go back
+    to the caching allocator's pool of the CALLER's stream when the exception unwinds, and its next allocation must not race with them."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is not None:
+            for main, side in self.pairs:
+                try:
+                    main.wait_stream(side)
+                except Exception:          # noqa: BLE001  (the original exception is the one to report)
+                    pass
+        self.pairs.clear()
+        return False
+
+
 def _autocast(enabled: bool):
     """The reference runs the CNN encoders under fp16 autocast when mixed_precision is set (network.py:179);
     here the encoders stay fp32 unless ``args.encoder_autocast`` is set, because their rounding dominates the
@@ -222,7 +244,7 @@ class CRAFT(nn.Module):
         hw = (H8, W8)
         dev = image1.device
 
-        with torch.no_grad():
+        with torch.no_grad(), _JoinOnError() as joins:
             use_henc = getattr(args, "hip_encoders", True)
             # The context chain (cnet -> net / inp -> intra-frame attention -> GRU context fields) and the feature
             # chain (fnet -> F2 transformer -> correlation volume) are independent until the refinement loop: the
@@ -232,6 +254,8 @@ class CRAFT(nn.Module):
             main = torch.cuda.current_stream()
             fork = use_henc and getattr(args, "hip_fork", True) and not os.environ.get("CRAFT_NO_FORK")
             side = self._streams(1, dev)[0] if fork else main
+            if side is not main:
+                joins.pairs.append((main, side))
             hx = torch.empty(B, N, 512, device=dev, dtype=torch.float32)              # [net | inp | mf | mfg]
             if use_henc:
                 # CNN encoders on the HIP conv engine, channels-last end to end
@@ -315,6 +339,8 @@ class CRAFT(nn.Module):
                                   c0=coords0[b0:b1], c1=coords1[b0:b1], mask=mask[b0:b1], fields=gru_fields[b0:b1],
                                   pyr=[pv.batch_slice(b0, b1) for pv in pyramids], ws=None))
             streams = [main] if nstr == 1 else self._streams(nstr, dev)
+            if nstr > 1:
+                joins.pairs.extend((main, st) for st in streams)
             if nstr > 1:
                 fork = torch.cuda.Event()
                 fork.record(main)

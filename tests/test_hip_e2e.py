@@ -265,3 +265,34 @@ def test_side_streams_and_fused_attention_do_not_change_results(device, monkeypa
     lo_nl, up_nl = run(("CRAFT_NO_FLASH",))
     assert (up - up_nf).abs().max().item() < 1e-4, "side streams changed the result"
     assert (up - up_nl).abs().max().item() < 5e-3 and (lo - lo_nl).abs().max().item() < 1e-3, "fused attention deviates"
+
+
+def test_an_exception_between_fork_and_join_leaves_the_streams_joined(device, monkeypatch):
+    """CRAFT.forward forks the context chain onto a side stream (and, for batches of 6..12, the refinement loop onto two): when the pass
+    dies between a fork and its join -- here: the F2 transformer raises while the side stream still runs cnet and the intra-frame
+    attention into `hx`, a tensor of the CALLER's stream -- the side stream must be joined before the exception leaves (network._JoinOnError),
+    and the next forward on the same model gives the result of an undisturbed one."""
+    B, H, W = 2, 128, 192
+    model = CRAFT(default_args(hip_precision="mixed", mixed_precision=True))
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=9), strict=True)
+    model = model.to(device).eval()
+    im1, im2, _ = synth_pair(B, H, W, seed=10)
+    im1, im2 = im1.to(device), im2.to(device)
+    with torch.no_grad():
+        ref = model(im1, im2, iters=3, test_mode=1)[1].clone()
+    side = model._streams(1, im1.device)[0]
+    orig = model.f2_trans.forward_tokens
+
+    def boom(*a, **k):
+        raise RuntimeError("injected failure between fork and join")
+    for _ in range(3):
+        monkeypatch.setattr(model.f2_trans, "forward_tokens", boom)
+        with torch.no_grad(), pytest.raises(RuntimeError, match="injected failure"):
+            model(im1, im2, iters=3, test_mode=1)
+        # everything the side stream was given has been ordered in front of whatever the caller's stream does next
+        torch.cuda.current_stream().synchronize()
+        assert side.query(), "the side stream still has work the caller's stream never waited for"
+        monkeypatch.setattr(model.f2_trans, "forward_tokens", orig)
+        with torch.no_grad():
+            again = model(im1, im2, iters=3, test_mode=1)[1]
+        assert (again - ref).abs().max().item() < 1e-4          # (px; the statistics' double atomics may reorder the last bit)
