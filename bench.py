@@ -59,6 +59,9 @@ def parse():
                     help="fp32 | bf16 | fp16 or a per-role policy such as score=bf16,pv=fp16,conv=fp32 (craft_amd.hip.Precision)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0: min(32, logical CPUs))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="time eager launches only (default: a step of the headline is ONE hipGraph replay of the forward pass, CRAFT.capture; "
+                         "the eager rate of the same pass is reported beside it as `eager_ms_per_step`)")
     ap.add_argument("--no-train-leg", action="store_true",
                     help="skip the short configs[3] training leg (3 warm-up + 5 timed steps) that the default line carries as `train_cfg3`")
     ap.add_argument("--mini", action="store_true",
@@ -700,13 +703,37 @@ def main():
 
     from craft_amd.dist import aggregate_throughput, timed_steps
     last = {}
+    failures = []                    # legs that failed: the line is printed anyway, the exit code says so afterwards
 
     def run_step():
         last["out"] = step()
 
-    dt_rank = timed_steps(run_step, steps=a.steps, warmup=a.warmup, sync=torch.cuda.synchronize)
+    # The headline step: the forward pass recorded once as a hipGraph (the same ~600 kernels on the same three streams, bit-identical
+    # results: tests/test_graphed_forward.py) and replayed per step; a step copies the batch into the graph's input buffers and replays.
+    # The eager launch sequence of the same pass is timed right after it with the same protocol.
+    graphed, eager_dt = None, None
+    if not a.no_graph:
+        try:
+            for _ in range(2):
+                step()
+            graphed = model.capture(im1, im2, iters=a.iters, test_mode=1)
+        except Exception as e:      # noqa: BLE001  (every rank falls back the same way: capture is deterministic)
+            failures.append(f"graph capture: {type(e).__name__}: {e}"[:300])
+            print(f"[bench] WARNING hipGraph capture failed, timing eager launches: {e}", file=sys.stderr)
+            graphed = None
+
+    def run_graphed():
+        last["out"] = graphed(im1, im2)
+
+    dt_rank = timed_steps(run_graphed if graphed is not None else run_step, steps=a.steps, warmup=a.warmup, sync=torch.cuda.synchronize)
     value, dt = aggregate_throughput(pairs_per_rank_step=a.batch, steps=a.steps, dt=dt_rank)
-    failures = []                    # legs that failed: the line is printed anyway, the exit code says so afterwards
+    if graphed is not None:
+        last["out"] = tuple(t.clone() for t in last["out"])
+        _, eager_dt = aggregate_throughput(pairs_per_rank_step=a.batch, steps=a.steps,
+                                           dt=timed_steps(run_step, steps=a.steps, warmup=a.warmup, sync=torch.cuda.synchronize))
+        d_graph = float((last["out"][1] - step()[1]).abs().max())
+        if not d_graph < 1e-4:
+            failures.append(f"configs[1]: hipGraph replay deviates from the eager pass by {d_graph} px")
     if not bool(torch.isfinite(last["out"][1]).all()):
         failures.append("configs[1]: non-finite flow")
 
@@ -744,8 +771,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"configs[1]: {a.height}x{a.width} synthetic pairs, batch {a.batch}/GPU, {a.iters} iters, "
                                    "craft-sintel architecture with synthetic weights (checkpoints absent), test_mode=1",
-                       "global_batch": a.batch * world, "parallelism": f"dp{world} (pairs sharded by batch, no collective)"},
+                       "global_batch": a.batch * world, "parallelism": f"dp{world} (pairs sharded by batch, no collective)",
+                       "launch": "one hipGraph replay per step (CRAFT.capture; inputs copied into the graph's buffers inside the timed region)"
+                                 if graphed is not None else "eager launches"},
         }
+        if eager_dt is not None:
+            line["eager_ms_per_step"] = round(1e3 * eager_dt / a.steps, 3)
+            line["graph_vs_eager_max_abs_px"] = d_graph
         if a.ops:
             op_table(model, im1, im2, a.iters)
         line["roofline"] = roofline_pv(model, im1, im2, a.iters, prec)

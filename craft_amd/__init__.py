@@ -4,7 +4,7 @@
 (correlation volume + lookup, SETrans attention, SepConvGRU refinement) runs on hand-written
 gfx950 HIP kernels behind the C ABI of ``include/craft_hip.h`` (``libcraft_hip.so``).
 """
-from .network import CRAFT  # noqa: F401
+from .network import CRAFT, GraphedForward  # noqa: F401
 from .utils import InputPadder, default_args, load_checkpoint  # noqa: F401
 
 RAFTER = CRAFT  # alias the reference keeps for un-pickling old checkpoints (evaluate.py:18-19)

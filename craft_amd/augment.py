@@ -76,6 +76,17 @@ def erase(img: torch.Tensor, rects, mean_color) -> torch.Tensor:
     return img
 
 
+def gaussian_blur(img: torch.Tensor, ksize: int, sigma: float) -> torch.Tensor:
+    """cv2.GaussianBlur(img, (ksize, ksize), sigma) of an HWC image in 0..255 (augmentor.py:195-198): separable Gaussian weights of
+    cv2.getGaussianKernel for sigma > 0, BORDER_REFLECT_101, result rounded to integer levels (the reference blurs uint8 arrays; cv2's
+    fixed-point 8-bit path is not pinned: cv2 is absent from this image)."""
+    img = _f(img)
+    H, W, C = img.shape
+    out = torch.empty_like(img)
+    call("craft_aug_blur", img, H, W, C, int(ksize), float(sigma), out)
+    return out
+
+
 class FlowAugmentor:
     """Dense-flow augmentation (augmentor.py:80-204) on GPU tensors: ``__call__(img1, img2, flow)`` with HWC float (or uint8)
     images in 0..255 and flow [H, W, 2] -> (img1, img2, flow, valid or None), all cropped to ``crop_size``."""
@@ -89,8 +100,9 @@ class FlowAugmentor:
         self.shift_prob, self.shift_sigmas = shift_prob, shift_sigmas
         self.jitter = dict(brightness=0.4, contrast=0.4, saturation=0.4, hue=0.5 / 3.14)
         self.asymmetric_color_aug_prob, self.eraser_aug_prob = 0.2, 0.5
-        if blur_sigma > 0:
-            raise NotImplementedError("Gaussian blur augmentation (blur_sigma > 0) is not built")
+        self.blur_kernel, self.blur_sigma = int(blur_kernel), float(blur_sigma)
+        if self.blur_sigma > 0 and (self.blur_kernel < 1 or self.blur_kernel % 2 == 0 or self.blur_kernel > 31):
+            raise ValueError(f"blur_kernel must be odd and in 1..31 (cv2.GaussianBlur needs an odd size), got {blur_kernel}")
 
     # -- photometric (augmentor.py:106-123) -----------------------------------------------------------------------------
     def _jitter_params(self):
@@ -159,6 +171,8 @@ class FlowAugmentor:
         if self.shift_prob > 0 and random.random() < self.shift_prob:
             dx, dy = draw_shift(self.shift_sigmas)
             img1, img2, flow, valid = random_shift(img1, img2, flow, dx, dy)
+        if self.blur_sigma > 0:                                   # augmentor.py:195-198
+            img1, img2 = gaussian_blur(img1, self.blur_kernel, self.blur_sigma), gaussian_blur(img2, self.blur_kernel, self.blur_sigma)
         return img1, img2, flow, valid
 
 

@@ -30,6 +30,9 @@ const Tuning& tuning() {
 }  // namespace craft
 static const craft::Tuning& g_tuning_at_load = craft::tuning();     // evaluated by the dynamic loader, not by a launch
 
+// (declared here rather than in launch.hpp, the header of every kernel translation unit)
+namespace craft { int launch_aug_blur(const float* src, int H, int W, int C, int K, float sigma, float* out, hipStream_t s); }
+
 extern "C" {
 
 int craft_hip_abi_version(void) { return CRAFT_HIP_ABI_VERSION; }
@@ -672,6 +675,9 @@ int craft_aug_erase(float* img, int H, int W, const int* rects, int nrect, float
 int craft_aug_shift(const float* img1, const float* img2, const float* flow, int H, int W, int dx, int dy, float* out1, float* out2,
                     float* out_flow, float* valid, void* stream) {
   return launch_aug_shift(img1, img2, flow, H, W, dx, dy, out1, out2, out_flow, valid, S(stream));
+}
+int craft_aug_blur(const float* src, int H, int W, int C, int K, float sigma, float* out, void* stream) {
+  return craft::launch_aug_blur(src, H, W, C, K, sigma, out, S(stream));
 }
 
 // ---- host-side helper of the evaluation harness (no device work) ----------------------------------------------------

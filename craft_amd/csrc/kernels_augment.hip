@@ -8,6 +8,10 @@
 //   * k_aug_photo   : one ColorJitter step (torchvision semantics on a uint8 image, augmentor.py:106-123): brightness /
 //                     contrast / saturation / hue, result rounded to integer levels.
 //   * k_aug_erase   : eraser rectangles filled with the mean colour (augmentor.py:125-139).
+//   * k_aug_blur    : cv2.GaussianBlur((K, K), sigma) of the cropped frames (augmentor.py:195-198): separable Gaussian weights
+//                     exp(-(i - (K-1)/2)^2 / (2 sigma^2)) normalised to 1 (cv2.getGaussianKernel for sigma > 0), BORDER_REFLECT_101,
+//                     applied as ONE K x K gather per output value (rows of a 368 x 496 crop: the whole image is L2-resident), rounded
+//                     to integer levels.
 //   * k_aug_shift   : random_shift (augmentor.py:16-78): crop both frames against each other by (dx, dy), subtract the shift from
 //                     the flow, zero-pad back to the input size, emit the valid mask.
 #include "launch.hpp"
@@ -154,6 +158,30 @@ __global__ void k_aug_sparse_gather(const float* __restrict__ flow, const int* _
   oflow[2 * i] = u; oflow[2 * i + 1] = v; ovalid[i] = ok;
 }
 
+// Gaussian blur of an HWC image, K x K taps (K odd, <= 31), cv2's default border (BORDER_REFLECT_101: ... 2 1 | 0 1 2 ... ).  The row pass
+// is accumulated first for each tap row (cv2's separable order: horizontal filter, then vertical), in float.
+struct BlurTaps { float w[32]; };
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+  return i;
+}
+__global__ void k_aug_blur(const float* __restrict__ src, int H, int W, int C, int K, BlurTaps t, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)H * W * C) return;
+  const int c = (int)(i % C);
+  const long p = i / C;
+  const int x = (int)(p % W), y = (int)(p / W), r = K / 2;
+  float acc = 0.f;
+  for (int dy = 0; dy < K; ++dy) {
+    const float* row = src + (long)reflect101(y + dy - r, H) * W * C + c;
+    float a = 0.f;
+    for (int dx = 0; dx < K; ++dx) a += t.w[dx] * row[(long)reflect101(x + dx - r, W) * C];
+    acc += t.w[dy] * a;
+  }
+  out[i] = q255(acc);
+}
+
 #define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, s
 int launch_aug_sparse(const float* flow, const float* valid, int H, int W, float fx, float fy, int hflip, int y0, int x0, int ch, int cw,
                       int* owner, float* oflow, float* ovalid, hipStream_t s) {
@@ -183,6 +211,17 @@ int launch_aug_photo(float* img, long npix, int op, float factor, float mean, hi
 int launch_aug_erase(float* img, int H, int W, const int* rects, int nrect, float mr, float mg, float mb, hipStream_t s) {
   if (nrect <= 0) return 0;
   hipLaunchKernelGGL(k_aug_erase, GRID1((long)H * W), img, H, W, rects, nrect, mr, mg, mb);
+  return (int)hipGetLastError();
+}
+int launch_aug_blur(const float* src, int H, int W, int C, int K, float sigma, float* out, hipStream_t s) {
+  if (H <= 0 || W <= 0 || C <= 0 || !src || !out || src == out) return CRAFT_ERR_ARG;
+  if (K < 1 || !(K & 1) || !(sigma > 0.f)) return CRAFT_ERR_ARG;
+  if (K > 31) return CRAFT_ERR_UNSUPPORTED;
+  BlurTaps t = {};
+  double sum = 0.0, w[32];
+  for (int i = 0; i < K; ++i) { const double x = i - 0.5 * (K - 1); w[i] = exp(-x * x / (2.0 * (double)sigma * (double)sigma)); sum += w[i]; }
+  for (int i = 0; i < K; ++i) t.w[i] = (float)(w[i] / sum);
+  hipLaunchKernelGGL(k_aug_blur, GRID1((long)H * W * C), src, H, W, C, K, t, out);
   return (int)hipGetLastError();
 }
 int launch_aug_shift(const float* img1, const float* img2, const float* flow, int H, int W, int dx, int dy, float* o1, float* o2, float* oflow,

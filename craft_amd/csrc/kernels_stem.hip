@@ -19,7 +19,11 @@ __global__ __launch_bounds__(NTHREADS) void k_stem_mfma(const float* __restrict_
   typedef typename FragT<PREC>::t frag_t;
   typedef typename PrecT<PREC>::lds_t h_t;
   constexpr int PL = Planes<PREC>::N, MT = 2;
-  __shared__ __attribute__((aligned(16))) float pat[3 * STM_PH * STM_PLD];
+  // the patch lives in LDS as 16-bit planes (hi, and lo = x - hi for the split-fp16 product): converted ONCE while it is staged.  (Rounds
+  // 2-5 kept it in fp32 and every wave converted its A fragments inside the K loop -- each patch value ~20 times per block: PMC round 6:
+  // 19-22 VALU per MFMA, matrix pipe 22 % busy.)
+  constexpr int NPIX = 3 * STM_PH * STM_PLD;
+  __shared__ __attribute__((aligned(16))) h_t pat[PL * NPIX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H2 = p.g.H, W2 = p.g.W;
   const int tiles_x = (W2 + STM_TW - 1) / STM_TW, tiles_y = (H2 + STM_TH - 1) / STM_TH;
@@ -31,7 +35,7 @@ __global__ __launch_bounds__(NTHREADS) void k_stem_mfma(const float* __restrict_
   const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
   // patch staging: all of a thread's pixels requested first, from clamped addresses, then normalised / zero-padded and published (a
   // load under the bounds test compiles to branch + load + vmcnt(0): ten dependent HBM round trips per block before its first MFMA)
-  constexpr int NPIX = 3 * STM_PH * STM_PLD, NLD = (NPIX + NTHREADS - 1) / NTHREADS;
+  constexpr int NLD = (NPIX + NTHREADS - 1) / NTHREADS;
   float pv[NLD];
   unsigned pok = 0u;
   const float* imb = img + (long)b * 3 * H * W;
@@ -47,7 +51,12 @@ __global__ __launch_bounds__(NTHREADS) void k_stem_mfma(const float* __restrict_
 #pragma unroll
   for (int k = 0; k < NLD; ++k) {
     const int i = tid + k * NTHREADS;
-    if (i < NPIX) pat[i] = ((pok >> k) & 1u) ? 2.f * (pv[k] / 255.f) - 1.f : 0.f;
+    if (i < NPIX) {
+      const float x = ((pok >> k) & 1u) ? 2.f * (pv[k] / 255.f) - 1.f : 0.f;
+      const h_t hi = (h_t)x;
+      pat[i] = hi;
+      if constexpr (PL == 2) pat[NPIX + i] = (h_t)(x - (float)hi);
+    }
   }
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 32;
   const int hsel = lane >> 5;
@@ -65,15 +74,17 @@ __global__ __launch_bounds__(NTHREADS) void k_stem_mfma(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[mt][0][e] = 0.f;
   __syncthreads();
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int s = 0; s < 12; ++s) {
-    // k-groups 2s (lanes 0-31) and 2s+1 (lanes 32-63): group g = (ky, c) = (g / 3, g % 3); groups 21..23 are zero padding
+    // k-groups 2s (lanes 0-31) and 2s+1 (lanes 32-63): group g = (ky, c) = (g / 3, g % 3); groups 21..23 are zero padding -- their
+    // weights (and the weight of the padding tap kx = 7) are zero, so the A fragment may hold any FINITE patch values there: group 0's
+    // run is re-read (8 halves from an even column: 4-byte aligned, four ds_read_b32)
     constexpr int NG = 21;
     const int g0 = 2 * s, g1 = 2 * s + 1;
     const int off0 = g0 < NG ? ((g0 % 3) * STM_PH + g0 / 3) * STM_PLD : 0;
     const int off1 = g1 < NG ? ((g1 % 3) * STM_PH + g1 / 3) * STM_PLD : 0;
     const int off = hsel ? off1 : off0;
-    const bool live = hsel ? (g1 < NG) : (g0 < NG);
     frag_t bw[PL];
     {
       const uint16_t* q = wb + (long)(s >> 1) * kt_stride + (s & 1) * 512;
@@ -83,16 +94,16 @@ __global__ __launch_bounds__(NTHREADS) void k_stem_mfma(const float* __restrict_
     frag_t ah[MT], al[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const float2* src = reinterpret_cast<const float2*>(&pat[off + base[mt]]);
-      float v[8];
+      const unsigned* sh = reinterpret_cast<const unsigned*>(&pat[off + base[mt]]);
+      u32x4 t;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const float2 t = src[j]; v[2 * j] = t.x; v[2 * j + 1] = t.y; }
+      for (int j = 0; j < 4; ++j) t[j] = sh[j];
+      ah[mt] = __builtin_bit_cast(frag_t, t);
+      if constexpr (PL == 2) {
+        const unsigned* sl = reinterpret_cast<const unsigned*>(&pat[NPIX + off + base[mt]]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float x = (live && j < 7) ? v[j] : 0.f;           // kx = 7 is the padding tap (its weight is zero as well)
-        const h_t hi = (h_t)x;
-        ah[mt][j] = hi;
-        if constexpr (PL == 2) al[mt][j] = (h_t)(x - (float)hi);
+        for (int j = 0; j < 4; ++j) t[j] = sl[j];
+        al[mt] = __builtin_bit_cast(frag_t, t);
       }
     }
     if constexpr (PL == 2) {

@@ -126,6 +126,7 @@ _SIGS = {
     "craft_aug_sparse": [P, P, I, I, F, F, I, I, I, I, I, P, P, P, P],
     "craft_aug_erase": [P, I, I, P, I, F, F, F, P],
     "craft_aug_shift": [P, P, P, I, I, I, I, P, P, P, P, P],
+    "craft_aug_blur": [P, I, I, I, I, F, P, P],
 }
 
 

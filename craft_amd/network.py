@@ -68,6 +68,76 @@ def _autocast(enabled: bool):
     return torch.autocast(device_type="cuda", dtype=torch.float16, enabled=bool(enabled) and torch.cuda.is_available())
 
 
+class GraphedForward:
+    """One forward pass of a CRAFT model (inference path) recorded as a hipGraph and replayed per call.
+
+    The inference pass enqueues ~600 kernels on up to three HIP streams with a fixed launch sequence for a given input shape (no host
+    read-back, no data-dependent launch geometry), so the whole dependency structure -- including the fork / join of the context chain and
+    of the motion encoder's flow branch -- can be handed to the runtime at once: ``torch.cuda.graph`` capture over the model's own streams,
+    ``replay()`` per call.  Same kernels, same order of floating-point operations: the replay is bit-identical to the eager pass
+    (tests/test_graphed_forward.py); what it removes are the launch gaps between dependent kernels (tools/graph_probe.py: 16.42 -> 16.26 ms
+    at 448x1024 x 4, 5.43 -> 5.29 ms at 368x768 x 1).
+
+    ``__call__(image1, image2, flow_init=None)`` copies the inputs into the graph's static buffers, replays, and returns what
+    ``CRAFT.forward`` returns for the captured ``test_mode`` -- tensors OWNED BY THE GRAPH, overwritten by the next call (``.clone()`` what must
+    outlive it).  The graph reads the weight operands packed at capture time; a parameter or buffer changed since (optimizer step,
+    ``load_state_dict``) is detected by its version counter and the pass is re-captured."""
+
+    def __init__(self, model, image1, image2, iters=12, flow_init=None, test_mode=1, warmup=2):
+        if model.training:
+            raise RuntimeError("GraphedForward records the inference path: call model.eval() first")
+        if not image1.is_cuda:
+            raise RuntimeError("craft_amd.CRAFT runs its hot path on HIP kernels: inputs must be on the GPU (there is no CPU fallback)")
+        if image1.shape != image2.shape:
+            raise ValueError("image1 and image2 must have the same shape")
+        self.model, self.iters, self.test_mode, self.warmup = model, iters, test_mode, max(1, int(warmup))
+        self.im1 = image1.detach().float().contiguous().clone()
+        self.im2 = image2.detach().float().contiguous().clone()
+        self.flow_init = None if flow_init is None else flow_init.detach().float().contiguous().clone()
+        self.graph, self.out, self.versions, self.replays = None, None, None, 0
+        self._stream = torch.cuda.Stream(device=image1.device)
+        self._capture()
+
+    def _versions(self):
+        m = self.model
+        return tuple(t._version for t in list(m.parameters()) + list(m.buffers()))
+
+    def _run(self):
+        return self.model(self.im1, self.im2, iters=self.iters, flow_init=self.flow_init, test_mode=self.test_mode)
+
+    def _capture(self):
+        cur, s = torch.cuda.current_stream(self.im1.device), self._stream
+        s.wait_stream(cur)
+        with torch.no_grad(), torch.cuda.stream(s):
+            for _ in range(self.warmup):        # weight packs, position codes, side streams and workspaces exist before the capture
+                self._run()
+        cur.wait_stream(s)
+        torch.cuda.synchronize(self.im1.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph, stream=s):
+            self.out = self._run()
+        self.versions = self._versions()
+
+    def __call__(self, image1, image2, flow_init=None):
+        if tuple(image1.shape) != tuple(self.im1.shape) or tuple(image2.shape) != tuple(self.im2.shape):
+            raise ValueError(f"this graph was captured for images of shape {tuple(self.im1.shape)}, got {tuple(image1.shape)}")
+        if (flow_init is None) != (self.flow_init is None):
+            raise ValueError("this graph was captured " + ("with" if self.flow_init is not None else "without") + " flow_init")
+        if self.model.training:
+            raise RuntimeError("GraphedForward replays the inference path: the model is in training mode")
+        if self._versions() != self.versions:   # weights changed since the capture: the graph holds the OLD packed operands
+            self.graph, self.out = None, None
+            self._capture()
+        self.im1.copy_(image1)
+        self.im2.copy_(image2)
+        if flow_init is not None:
+            self.flow_init.copy_(flow_init)
+        self.graph.replay()
+        self.replays += 1
+        self.model.call_counter += 1
+        return self.out
+
+
 class CRAFT(nn.Module):
     def __init__(self, args):
         super().__init__()
@@ -173,6 +243,10 @@ class CRAFT(nn.Module):
         for m in self.modules():
             if isinstance(m, nn.BatchNorm2d):
                 m.eval()
+
+    def capture(self, image1, image2, iters=12, flow_init=None, test_mode=1, warmup=2) -> "GraphedForward":
+        """The inference pass for inputs of this shape as ONE hipGraph (see GraphedForward): ``g = model.capture(im1, im2); lo, up = g(im1, im2)``."""
+        return GraphedForward(self, image1, image2, iters=iters, flow_init=flow_init, test_mode=test_mode, warmup=warmup)
 
     def initialize_flow(self, img):
         """coords0, coords1 as NCHW grids (network.py:142-149); kept for API parity."""

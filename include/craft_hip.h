@@ -612,7 +612,10 @@ int craft_zero_stuff2(const float* g, long ldg, int B, int Hin, int Win, int C, 
  * craft_aug_erase: FlowAugmentor.eraser_transform (augmentor.py:125-139): rects [nrect][4] = (x0, y0, dx, dy) (device ints) filled
  *   with (mr, mg, mb).
  * craft_aug_shift: random_shift (augmentor.py:16-78) for even (dx, dy): the two frames cropped against each other by the shift,
- *   flow - (dx, dy), zero-padded back to [H][W], valid [H][W] = 1 inside the remaining area. */
+ *   flow - (dx, dy), zero-padded back to [H][W], valid [H][W] = 1 inside the remaining area.
+ * craft_aug_blur: cv2.GaussianBlur(img, (K, K), sigma) of FlowAugmentor.__call__ (augmentor.py:195-198; blur_sigma > 0): out [H][W][C] =
+ *   src filtered with the separable Gaussian exp(-(i - (K-1)/2)^2 / (2 sigma^2)) / sum (cv2.getGaussianKernel for sigma > 0), border
+ *   BORDER_REFLECT_101, rounded to integer levels.  K odd, 1 <= K <= 31; out must not alias src. */
 int craft_aug_spatial(const float* src, int H, int W, int C, int do_resize, float fx, float fy, int hflip, int vflip, int y0, int x0, int ch,
                       int cw, int is_flow, float* out, void* stream);
 int craft_aug_photo(float* img, long npix, int op, float factor, float mean, void* stream);
@@ -625,6 +628,7 @@ int craft_aug_sparse(const float* flow, const float* valid, int H, int W, float 
 int craft_aug_erase(float* img, int H, int W, const int* rects, int nrect, float mr, float mg, float mb, void* stream);
 int craft_aug_shift(const float* img1, const float* img2, const float* flow, int H, int W, int dx, int dy, float* out1, float* out2,
                     float* out_flow, float* valid, void* stream);
+int craft_aug_blur(const float* src, int H, int W, int C, int K, float sigma, float* out, void* stream);
 
 /* Host helper of the evaluation harness (frame_utils.py:70-120 reads KITTI's 16-bit PNGs through cv2): PNG scan-line unfiltering,
  * filter types 0-4; rows [h][1 + stride] -> out [h][stride], bpp = bytes per pixel.  HOST pointers, no stream, no device work. */

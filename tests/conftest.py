@@ -45,6 +45,22 @@ def _say(request, msg: str) -> None:
 _FAULT_FILE = []
 
 
+def _mem_note() -> str:
+    """Host RSS and the caching allocator's reserved bytes, on the announce line of every `gpu` test: a run that dies of memory exhaustion
+    (the HIP runtime aborts when one of its own allocations fails) shows the growth in the lines above its last test id."""
+    try:
+        with open("/proc/self/statm") as f:
+            rss = int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 2 ** 30
+    except (OSError, ValueError, IndexError):
+        return ""
+    torch = sys.modules.get("torch")
+    dev = ""
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        free, total = torch.cuda.mem_get_info()
+        dev = f" hbm_reserved={torch.cuda.memory_reserved() / 2 ** 30:.1f}G hbm_free={free / 2 ** 30:.0f}G"
+    return f"  [rss={rss:.1f}G{dev}]"
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _compact_fatal_signal_tail():
     """A process killed by SIGABRT / SIGSEGV (the HSA runtime aborts on a GPU memory fault) must end its log with the runtime's own
@@ -71,7 +87,7 @@ def _charge_gpu_faults_to_their_author(request):
     if request.node.get_closest_marker("gpu") is None:
         yield
         return
-    _say(request, f"\n[gpu-test] {request.node.nodeid}\n")
+    _say(request, f"\n[gpu-test] {request.node.nodeid}{_mem_note()}\n")
     yield
     torch = sys.modules.get("torch")
     if torch is not None and torch.cuda.is_available():

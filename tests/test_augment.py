@@ -4,6 +4,7 @@
   re-drawn by our sampler from the same seeds -- so the draw order is pinned too (CPU part) and the kernel (GPU part).
 * spatial gather (resize -> flips -> crop), ColorJitter steps, eraser: against numpy restatements written here (cv2 / PIL /
   torchvision are not in this image: their 8-bit rounding is not pinned).
+* Gaussian blur (augmentor.py:195-198): against a numpy restatement of cv2.getGaussianKernel (sigma > 0) + BORDER_REFLECT_101.
 * FlowAugmentor end to end: shapes, ranges, flow consistency under a pure flip / crop."""
 import os
 import random
@@ -186,3 +187,53 @@ def test_sparse_augmentor_end_to_end(device):
         a, b, f, v = aug(img1, img2, flow, valid)
         assert a.shape == (crop[0], crop[1], 3) and f.shape == (crop[0], crop[1], 2) and v.shape == crop
         assert 0.05 < float(v.mean()) < 0.6 and float((f.abs().sum(-1) * (1 - v)).max()) == 0.0
+
+
+def _np_gaussian_blur(img, K, sigma):
+    """cv2.GaussianBlur(img, (K, K), sigma) restated: getGaussianKernel for sigma > 0, separable, BORDER_REFLECT_101, float arithmetic."""
+    x = np.arange(K, dtype=np.float64) - 0.5 * (K - 1)
+    w = np.exp(-x * x / (2.0 * sigma * sigma))
+    w /= w.sum()
+    r = K // 2
+    p = np.pad(img.astype(np.float64), ((r, r), (r, r), (0, 0)), mode="reflect")           # numpy 'reflect' == cv2 BORDER_REFLECT_101
+    H, W = img.shape[:2]
+    rows = sum(w[d] * p[:, d:d + W] for d in range(K))
+    return sum(w[d] * rows[d:d + H] for d in range(K))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,sigma,shape", [(5, 1.3, (37, 53, 3)), (3, 0.6, (8, 9, 3)), (9, 2.5, (40, 33, 3)), (5, 1.0, (3, 2, 1)), (1, 1.0, (6, 7, 3))])
+def test_gaussian_blur(device, K, sigma, shape):
+    from craft_amd.augment import gaussian_blur
+    rng = np.random.RandomState(K * 100 + shape[0])
+    img = rng.randint(0, 256, size=shape).astype(np.float32)
+    got = gaussian_blur(torch.from_numpy(img).to(device), K, sigma).cpu().numpy()
+    ref = _np_gaussian_blur(img, K, sigma)
+    assert got.shape == img.shape and np.array_equal(got, np.rint(got)) and got.min() >= 0 and got.max() <= 255
+    # integer levels: equal to the rounded float reference except where the float sum sits within 1e-3 of a .5 boundary
+    d = np.abs(got - np.clip(np.rint(ref), 0, 255))
+    near_half = np.abs(ref - np.floor(ref) - 0.5) < 1e-3
+    assert d[~near_half].max(initial=0.0) == 0.0 and d.max(initial=0.0) <= 1.0
+    if K == 1:
+        assert np.array_equal(got, img)
+
+
+@pytest.mark.gpu
+def test_flow_augmentor_blur_branch(device):
+    """blur_sigma > 0 (augmentor.py:195-198): both frames are blurred after the spatial transform / shift, the flow is not; the random
+    draws are those of the run without blur (cv2.GaussianBlur draws nothing)."""
+    from craft_amd.augment import FlowAugmentor, gaussian_blur
+    rng = np.random.RandomState(3)
+    img1 = torch.from_numpy(rng.randint(0, 256, size=(160, 200, 3)).astype(np.float32)).to(device)
+    img2 = torch.from_numpy(rng.randint(0, 256, size=(160, 200, 3)).astype(np.float32)).to(device)
+    flow = torch.from_numpy(rng.randn(160, 200, 2).astype(np.float32)).to(device)
+    outs = []
+    for sig in (-1, 1.5):
+        random.seed(11); np.random.seed(11)
+        outs.append(FlowAugmentor("chairs", (96, 128), blur_kernel=5, blur_sigma=sig, shift_prob=0.5)(img1, img2, flow))
+    (a1, a2, af, av), (b1, b2, bf, bv) = outs
+    assert torch.equal(af, bf) and (av is None) == (bv is None)
+    assert torch.equal(b1, gaussian_blur(a1, 5, 1.5)) and torch.equal(b2, gaussian_blur(a2, 5, 1.5))
+    assert not torch.equal(a1, b1)
+    with pytest.raises(ValueError, match="odd"):
+        FlowAugmentor("chairs", (96, 128), blur_kernel=4, blur_sigma=1.0)
