@@ -6,9 +6,10 @@ pixel work as HIP kernels (``csrc/kernels_augment.hip``) over images that alread
 eraser rectangles / shift as the reference would; the photometric factors are drawn the way torchvision's ``ColorJitter``
 does (uniform factors, random order of the four operations) from ``np.random`` as well (torchvision uses torch's generator:
 those draws cannot be replayed).  Pixel semantics: ``random_shift`` is pinned bit-for-bit by a fixture produced by the
-reference's own function (tests/golden/harness.npz); resize / colour steps restate cv2.INTER_LINEAR / PIL in float and are
-checked against numpy restatements in the tests -- cv2, PIL's enhancers and torchvision are absent from this image, so their
-8-bit fixed-point rounding is NOT pinned (documented gap).  ``SparseFlowAugmentor`` (KITTI): the sparse flow map is moved, not interpolated (``craft_aug_sparse``; exact integer logic, checked against a numpy restatement of resize_sparse_flow_map).
+reference's own function (tests/golden/harness.npz); the four ColorJitter operations are Pillow's 8-bit arithmetic bit for bit, pinned
+by a fixture Pillow itself produced (tests/golden/photo_pil.npz; torchvision's PIL path is a thin wrapper over Pillow); resize / blur
+restate cv2.INTER_LINEAR / cv2.GaussianBlur in float and are checked against numpy restatements in the tests -- cv2 is absent from
+this image, so its 8-bit fixed-point rounding is NOT pinned (documented gap).  ``SparseFlowAugmentor`` (KITTI): the sparse flow map is moved, not interpolated (``craft_aug_sparse``; exact integer logic, checked against a numpy restatement of resize_sparse_flow_map).
 """
 from __future__ import annotations
 
@@ -57,13 +58,23 @@ def spatial(src: torch.Tensor, crop, y0: int, x0: int, fx: float = 1.0, fy: floa
     return out
 
 
+def hue_shift(factor: float) -> int:
+    """torchvision's adjust_hue on PIL images: ``np_h += np.int32(hue_factor * 255).astype(np.uint8)`` -- the integer added (mod 256) to the
+    uint8 hue plane."""
+    return int(np.int32(factor * 255).astype(np.uint8))
+
+
 def photo_step(img: torch.Tensor, op: int, factor: float) -> torch.Tensor:
-    """One ColorJitter operation in place on a float HWC image (0 brightness, 1 contrast, 2 saturation, 3 hue)."""
-    mean = 0.0
-    if op == 1:       # torchvision: mean of the grey-scale version, rounded like PIL's 'L' conversion
-        g = (0.299 * img[..., 0] + 0.587 * img[..., 1] + 0.114 * img[..., 2]).round().clamp(0, 255)
-        mean = float(int(g.mean().item() + 0.5))
-    call("craft_aug_photo", img, img.numel() // 3, int(op), float(factor), float(mean))
+    """One ColorJitter operation in place on a float HWC image of integer levels (0 brightness, 1 contrast, 2 saturation, 3 hue): Pillow's
+    8-bit arithmetic, bit for bit (tests/golden/photo_pil.npz)."""
+    aux = 0.0
+    if op == 1:       # ImageEnhance.Contrast: int(mean of the "L" image + 0.5), "L" = (R*19595 + G*38470 + B*7471 + 0x8000) >> 16
+        q = img.round().to(torch.int64)
+        L = (q[..., 0] * 19595 + q[..., 1] * 38470 + q[..., 2] * 7471 + 0x8000) >> 16
+        aux = float(int(int(L.sum().item()) / L.numel() + 0.5))
+    elif op == 3:
+        aux = float(hue_shift(factor))
+    call("craft_aug_photo", img, img.numel() // 3, int(op), float(factor), aux)
     return img
 
 
@@ -130,7 +141,8 @@ class FlowAugmentor:
     def eraser_transform(self, img1, img2, bounds=(50, 100)):
         ht, wd = img1.shape[:2]
         if np.random.rand() < self.eraser_aug_prob:
-            mean_color = img2.reshape(-1, 3).mean(dim=0).tolist()
+            # np.mean(img2.reshape(-1, 3), axis=0) assigned into a uint8 array (augmentor.py:129-137): the float64 mean is truncated
+            mean_color = img2.reshape(-1, 3).double().mean(dim=0).floor().tolist()
             rects = []
             for _ in range(np.random.randint(1, 3)):
                 x0, y0 = np.random.randint(0, wd), np.random.randint(0, ht)

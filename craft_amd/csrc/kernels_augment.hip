@@ -54,51 +54,84 @@ __global__ void k_aug_spatial(const float* __restrict__ src, int H, int W, int C
   out[i] = v;
 }
 
-__device__ __forceinline__ float gray_of(float r, float g, float b) { return 0.299f * r + 0.587f * g + 0.114f * b; }   // PIL "L"
 __device__ __forceinline__ float q255(float v) { return fminf(fmaxf(rintf(v), 0.f), 255.f); }
 
-// op: 0 brightness (blend with black), 1 contrast (blend with the mean grey `mean`), 2 saturation (blend with the pixel's grey),
-// 3 hue (shift of the HSV hue by `factor` turns, PIL's integer HSV).  img [npix][3], in place.
-__global__ void k_aug_photo(float* __restrict__ img, long npix, int op, float factor, float mean) {
+// ---- ColorJitter on 8-bit images = Pillow's arithmetic (torchvision's PIL path wraps ImageEnhance and the "HSV" mode; augmentor.py:104,
+// :111-123).  Restated from libImaging (Blend.c ImagingBlend, Convert.c rgb2l / rgb2hsv_row / hsv2rgb) and pinned bit for bit by
+// tests/golden/photo_pil.npz, which Pillow itself produced (tools/make_golden_photo.py; oracle/augment_oracle.py is the numpy form).
+__device__ __forceinline__ int gray_L(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }   // Convert.c rgb2l
+// ImagingBlend(degenerate d, image i, alpha): float d + alpha * (i - d), product and sum rounded separately (no FMA contraction: Pillow is
+// built for baseline x86-64); alpha inside [0, 1]: (UINT8) truncation, outside: clipped to [0, 255] first
+__device__ __forceinline__ float blend8(int d, int i, float alpha, bool inside) {
+#pragma clang fp contract(off)
+  const float prod = alpha * (float)(i - d);
+  const float t = (float)d + prod;
+  if (inside) return (float)(int)t;
+  return t <= 0.f ? 0.f : (t >= 255.f ? 255.f : (float)(int)t);
+}
+
+// op: 0 brightness (blend with black), 1 contrast (blend with the grey level `aux` = int(mean of the "L" image + 0.5), which the caller
+// reduces), 2 saturation (blend with the pixel's own "L"), 3 hue (8-bit HSV round trip, hue + `aux` mod 256 where aux = the integer shift
+// int32(hue_factor * 255) & 255 that torchvision adds to the uint8 hue plane).  img [npix][3] integer levels stored as float, in place.
+__global__ void k_aug_photo(float* __restrict__ img, long npix, int op, float factor, float aux) {
+#pragma clang fp contract(off)                     // (every product and sum rounded on its own, like the host library)
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npix) return;
-  float r = img[3 * i], g = img[3 * i + 1], b = img[3 * i + 2];
+  const int r = (int)rintf(img[3 * i]), g = (int)rintf(img[3 * i + 1]), b = (int)rintf(img[3 * i + 2]);
+  float ro, go, bo;
+  const bool inside = factor >= 0.f && factor <= 1.f;
   if (op == 0) {
-    r = q255(r * factor); g = q255(g * factor); b = q255(b * factor);
+    ro = blend8(0, r, factor, inside); go = blend8(0, g, factor, inside); bo = blend8(0, b, factor, inside);
   } else if (op == 1) {
-    r = q255((r - mean) * factor + mean); g = q255((g - mean) * factor + mean); b = q255((b - mean) * factor + mean);
+    const int m = (int)aux;
+    ro = blend8(m, r, factor, inside); go = blend8(m, g, factor, inside); bo = blend8(m, b, factor, inside);
   } else if (op == 2) {
-    const float gr = q255(gray_of(r, g, b));
-    r = q255((r - gr) * factor + gr); g = q255((g - gr) * factor + gr); b = q255((b - gr) * factor + gr);
+    const int gr = gray_L(r, g, b);
+    ro = blend8(gr, r, factor, inside); go = blend8(gr, g, factor, inside); bo = blend8(gr, b, factor, inside);
   } else {
-    // RGB -> HSV (h in [0,1)), h += factor, HSV -> RGB; 8-bit channels like PIL's 'HSV' mode
-    const float mx = fmaxf(r, fmaxf(g, b)), mn = fminf(r, fminf(g, b));
-    const float d = mx - mn;
-    float h = 0.f;
-    if (d > 0.f) {
-      if (mx == r) h = (g - b) / d; else if (mx == g) h = 2.f + (b - r) / d; else h = 4.f + (r - g) / d;
-      h /= 6.f;
-      h -= floorf(h);
+    // Convert.c rgb2hsv_row: float quotients, sums with the double literals in double, h = fmod(h / 6.0 + 1.0, 1.0) stored to float,
+    // (int)(x * 255.0) truncation
+    const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+    int uh = 0, us = 0;
+    const int uv = maxc;
+    if (minc != maxc) {
+      const float cr = (float)(maxc - minc);
+      const float s = cr / (float)maxc;
+      const float rc = (float)(maxc - r) / cr, gc = (float)(maxc - g) / cr, bc = (float)(maxc - b) / cr;
+      float h;
+      if (r == maxc) h = bc - gc;
+      else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+      else h = (float)(4.0 + (double)gc - (double)rc);
+      h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
+      uh = min(max((int)((double)h * 255.0), 0), 255);
+      us = min(max((int)((double)s * 255.0), 0), 255);
     }
-    const float s = mx > 0.f ? d / mx : 0.f, v = mx;
-    float h8 = rintf(h * 255.f) + rintf(factor * 255.f);          // uint8 wrap-around of the hue channel
-    h8 -= 256.f * floorf(h8 / 256.f);
-    const float hh = h8 / 255.f * 6.f;
-    const int sect = (int)floorf(hh) % 6;
-    const float f = hh - floorf(hh);
-    const float s8 = rintf(s * 255.f) / 255.f;
-    const float p = v * (1.f - s8), q = v * (1.f - s8 * f), t = v * (1.f - s8 * (1.f - f));
-    switch (sect) {
-      case 0: r = v; g = t; b = p; break;
-      case 1: r = q; g = v; b = p; break;
-      case 2: r = p; g = v; b = t; break;
-      case 3: r = p; g = q; b = v; break;
-      case 4: r = t; g = p; b = v; break;
-      default: r = v; g = p; b = q; break;
+    uh = (uh + (int)aux) & 255;                      // the uint8 hue plane wraps around
+    if (us == 0) {
+      ro = go = bo = (float)uv;
+    } else {
+      // Convert.c hsv2rgb: i = floor(h * 6.0 / 255.0); f, fs stored to float; p / q / t = round(...) in double (arguments >= 0)
+      const double hh = (double)(float)uh * 6.0 / 255.0;
+      const int sect = (int)floor(hh);
+      const float f = (float)(hh - (double)(float)sect);
+      const float fs = (float)((double)(float)us / 255.0);
+      const double v = (double)uv;
+      const int pp = min(max((int)floor(v * (1.0 - (double)fs) + 0.5), 0), 255);
+      const int qq = min(max((int)floor(v * (1.0 - (double)fs * (double)f) + 0.5), 0), 255);
+      const int tt = min(max((int)floor(v * (1.0 - (double)fs * (1.0 - (double)f)) + 0.5), 0), 255);
+      int R, G, B;
+      switch (sect % 6) {
+        case 0: R = uv; G = tt; B = pp; break;
+        case 1: R = qq; G = uv; B = pp; break;
+        case 2: R = pp; G = uv; B = tt; break;
+        case 3: R = pp; G = qq; B = uv; break;
+        case 4: R = tt; G = pp; B = uv; break;
+        default: R = uv; G = pp; B = qq; break;
+      }
+      ro = (float)R; go = (float)G; bo = (float)B;
     }
-    r = q255(r); g = q255(g); b = q255(b);
   }
-  img[3 * i] = r; img[3 * i + 1] = g; img[3 * i + 2] = b;
+  img[3 * i] = ro; img[3 * i + 1] = go; img[3 * i + 2] = bo;
 }
 
 // rects [n][4] = (x0, y0, dx, dy); img [H][W][3]

@@ -606,9 +606,11 @@ int craft_zero_stuff2(const float* g, long ldg, int B, int Hin, int Win, int C, 
  *   v-flip(h-flip(resize(src))) where resize is cv2.INTER_LINEAR's mapping src = (dst + 0.5) / f - 0.5 with replicated borders on
  *   a (round(H*fy), round(W*fx)) grid (do_resize = 0: no resize).  is_flow: C = 2, values scaled by (fx, fy) and negated by the
  *   flips; else resized values are rounded to integer levels in 0..255.
- * craft_aug_photo: one ColorJitter step on img [npix][3] in place (torchvision / PIL semantics on 8-bit images): op 0 brightness
- *   (x * factor), 1 contrast (blend with `mean` = the mean grey level, which the caller reduces), 2 saturation (blend with the
- *   pixel's grey), 3 hue (HSV hue shifted by `factor` turns); results rounded to integer levels.
+ * craft_aug_photo: one ColorJitter step on img [npix][3] (integer levels) in place -- torchvision.transforms.ColorJitter on a PIL image
+ *   (augmentor.py:104, :111-123) = Pillow's 8-bit arithmetic, bit for bit (tests/golden/photo_pil.npz, produced by Pillow): op 0 brightness
+ *   / 1 contrast / 2 saturation = ImagingBlend(degenerate, image, factor) with degenerate = black / the grey level `mean` (= int(mean of
+ *   the "L" image + 0.5), which the caller reduces) / the pixel's "L"; op 3 hue = RGB -> 8-bit HSV, hue + `mean` mod 256 (`mean` carries
+ *   the integer shift int32(hue_factor * 255) & 255 torchvision adds to the hue plane; `factor` unused), HSV -> RGB.
  * craft_aug_erase: FlowAugmentor.eraser_transform (augmentor.py:125-139): rects [nrect][4] = (x0, y0, dx, dy) (device ints) filled
  *   with (mr, mg, mb).
  * craft_aug_shift: random_shift (augmentor.py:16-78) for even (dx, dy): the two frames cropped against each other by the shift,
