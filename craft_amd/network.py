@@ -404,6 +404,10 @@ class CRAFT(nn.Module):
             nstr = int(os.environ.get("CRAFT_HIP_STREAMS", getattr(args, "hip_streams", 0)))
             if nstr <= 0:                      # auto: two slices of 3..6 samples each (measured below); else one stream
                 nstr = 2 if 6 <= B <= 12 else 1
+            if torch.cuda.is_current_stream_capturing():
+                # under a hipGraph capture (GraphedForward) the batch stays in one piece: the graph already carries the dependency
+                # structure, and hipStreamEndCapture of a pass with two sliced loops at 448x1024 x 4 crashed inside the runtime (round 6)
+                nstr = 1
             nstr = max(1, min(nstr, B))
             cuts = [B * i // nstr for i in range(nstr + 1)]
             parts = []
@@ -416,10 +420,10 @@ class CRAFT(nn.Module):
             if nstr > 1:
                 joins.pairs.extend((main, st) for st in streams)
             if nstr > 1:
-                fork = torch.cuda.Event()
-                fork.record(main)
+                # (wait_stream, not hand-made Events: an Event object created here dies while a hipGraph capture of this pass is still
+                # recording -- hipEventDestroy under capture took the process down in GraphedForward with two slices)
                 for st in streams:
-                    st.wait_event(fork)
+                    st.wait_stream(main)
             for pt, st in zip(parts, streams):
                 with torch.cuda.stream(st):
                     pt["ws"] = GMAUpdateBlock.workspace(pt["b"][1] - pt["b"][0], N, dev)
@@ -440,9 +444,7 @@ class CRAFT(nn.Module):
                             ops.convex_upsample(pt["mask"], pt["flow"], H8, W8, out=flow_ups[itr if need_all else 0][b0:b1])  # :258
             if nstr > 1:
                 for st in streams:
-                    done = torch.cuda.Event()
-                    done.record(st)
-                    main.wait_event(done)
+                    main.wait_stream(st)
             flow_predictions = flow_ups
             flow_up = flow_ups[-1] if flow_ups else None
             flow_lo = ops.tokens_to_nchw(flow, H8, W8)

@@ -87,3 +87,20 @@ def test_changed_weights_are_recaptured(device):
     again = gf.graph
     gf(im1, im2)
     assert gf.graph is again
+
+
+@pytest.mark.gpu
+def test_capture_with_batch_sliced_streams(device):
+    """args.hip_streams = 2 (the auto rule for 6..12 pairs) slices the eager loop over two streams; under a capture the batch stays in one
+    piece (network.py: hipStreamEndCapture of the two-slice pass crashed inside the runtime at 448x1024 x 4) and the replay equals the
+    sliced eager pass."""
+    g = Golden("canon_b2_128x192_T3_init")
+    model = build(g, device, "mixed")
+    model.args.hip_streams = 2
+    im1, im2 = (t.to(device) for t in g.images())
+    with torch.no_grad():
+        lo_e, up_e = (t.clone() for t in model(im1, im2, iters=3, test_mode=1))
+    gf = model.capture(im1, im2, iters=3, test_mode=1)
+    for _ in range(2):
+        lo, up = gf(im1, im2)
+        assert (lo - lo_e).abs().max().item() < 1e-4 and (up - up_e).abs().max().item() < 1e-4
