@@ -445,7 +445,11 @@ int craft_stem_conv7x7(const float* image, const float* w, const float* bias, in
 
 int craft_stem_conv7x7_mfma(const float* image, const void* w_packed, const float* bias, int act, int B, int H, int W,
                             float* out, double* stats, int prec, void* stream) {
-  return launch_stem_mfma(image, w_packed, bias, act, B, H, W, out, stats, PREC_OF(prec), S(stream));
+  return launch_stem_mfma(image, nullptr, B, w_packed, bias, act, B, H, W, out, stats, PREC_OF(prec), S(stream));
+}
+int craft_stem_conv7x7_mfma_pair(const float* image_a, int Ba, const float* image_b, const void* w_packed, const float* bias, int act, int B, int H,
+                                 int W, float* out, double* stats, int prec, void* stream) {
+  return launch_stem_mfma(image_a, image_b, Ba, w_packed, bias, act, B, H, W, out, stats, PREC_OF(prec), S(stream));
 }
 
 int craft_stats_finalize(const double* sums, long n, double count, float eps, float* mean_rstd, void* stream) {

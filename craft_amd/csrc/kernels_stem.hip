@@ -15,7 +15,7 @@ namespace craft {
 constexpr int STM_TH = 8, STM_TW = 16, STM_PH = 2 * STM_TH + 5, STM_PLD = 40;     // patch 21 rows x (37 -> 40) columns
 
 template <int PREC>
-__global__ __launch_bounds__(NTHREADS) void k_stem_mfma(const float* __restrict__ img, ConvGemmParams p, int H, int W) {
+__global__ __launch_bounds__(NTHREADS) void k_stem_mfma(const float* __restrict__ img, const float* __restrict__ img2, int bsplit, ConvGemmParams p, int H, int W) {
   typedef typename FragT<PREC>::t frag_t;
   typedef typename PrecT<PREC>::lds_t h_t;
   constexpr int PL = Planes<PREC>::N, MT = 2;
@@ -38,7 +38,9 @@ __global__ __launch_bounds__(NTHREADS) void k_stem_mfma(const float* __restrict_
   constexpr int NLD = (NPIX + NTHREADS - 1) / NTHREADS;
   float pv[NLD];
   unsigned pok = 0u;
-  const float* imb = img + (long)b * 3 * H * W;
+  // images [0, bsplit) from `img`, the rest from `img2`: frames 1 and 2 of the pairs go through fnet as one batch without being
+  // concatenated first (torch.cat of 2 x 22 MB: 40-58 us in front of the first kernel of the main stream, profiles/r6/timeline_fw.txt)
+  const float* imb = b < bsplit ? img + (long)b * 3 * H * W : img2 + (long)(b - bsplit) * 3 * H * W;
 #pragma unroll
   for (int k = 0; k < NLD; ++k) {
     const int i = min(tid + k * NTHREADS, NPIX - 1);
@@ -137,17 +139,18 @@ __global__ __launch_bounds__(NTHREADS) void k_stem_mfma(const float* __restrict_
 }
 
 // image NCHW [B][3][H][W] raw 0..255; w: craft_pack_weights(rows 64, K 192) of the (ky, c, kx8)-ordered matrix
-int launch_stem_mfma(const float* img, const void* w_packed, const float* bias, int act, int B, int H, int W, float* out,
+int launch_stem_mfma(const float* img, const float* img2, int bsplit, const void* w_packed, const float* bias, int act, int B, int H, int W, float* out,
                      double* stats, int prec, hipStream_t s) {
   if ((H & 1) || (W & 1)) return CRAFT_ERR_ALIGN;
+  if (bsplit < 0 || bsplit > B || (bsplit < B && !img2)) return CRAFT_ERR_ARG;
   ConvGemmParams p = {};
   p.g.H = H / 2; p.g.W = W / 2; p.g.npix = B * p.g.H * p.g.W;
   p.W = reinterpret_cast<const float*>(w_packed); p.bias = bias; p.cout = 64; p.epi = CONV_EPI_BIAS_ACT; p.act = act; p.scale = 1.f;
   p.out = out; p.ldo = 64; p.stats = stats;
   const int tiles = ((p.g.W + STM_TW - 1) / STM_TW) * ((p.g.H + STM_TH - 1) / STM_TH) * B;
-  if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_stem_mfma<CRAFT_PREC_BF16>), dim3(tiles), dim3(NTHREADS), 0, s, img, p, H, W);
-  else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_stem_mfma<CRAFT_PREC_F16>), dim3(tiles), dim3(NTHREADS), 0, s, img, p, H, W);
-  else if (prec == CRAFT_PREC_F16X3) hipLaunchKernelGGL((k_stem_mfma<CRAFT_PREC_F16X3>), dim3(tiles), dim3(NTHREADS), 0, s, img, p, H, W);
+  if (prec == CRAFT_PREC_BF16) hipLaunchKernelGGL((k_stem_mfma<CRAFT_PREC_BF16>), dim3(tiles), dim3(NTHREADS), 0, s, img, img2, bsplit, p, H, W);
+  else if (prec == CRAFT_PREC_F16) hipLaunchKernelGGL((k_stem_mfma<CRAFT_PREC_F16>), dim3(tiles), dim3(NTHREADS), 0, s, img, img2, bsplit, p, H, W);
+  else if (prec == CRAFT_PREC_F16X3) hipLaunchKernelGGL((k_stem_mfma<CRAFT_PREC_F16X3>), dim3(tiles), dim3(NTHREADS), 0, s, img, img2, bsplit, p, H, W);
   else return CRAFT_ERR_ARG;
   return (int)hipGetLastError();
 }

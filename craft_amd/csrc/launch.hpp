@@ -154,7 +154,7 @@ int launch_convf1_mfma(const float* flow, const void* w_packed, const float* bia
 int launch_flow_head2(const float* hid, const float* w, const float* bias, int B, int H8, int W8, float* coords1,
                       const float* coords0, float* flow, float* delta, hipStream_t s);
 int launch_convex_upsample(const float* mask, const float* flow, int B, int H8, int W8, float* up, hipStream_t s);
-int launch_stem_mfma(const float* img, const void* w_packed, const float* bias, int act, int B, int H, int W, float* out,
+int launch_stem_mfma(const float* img, const float* img2, int bsplit, const void* w_packed, const float* bias, int act, int B, int H, int W, float* out,
                      double* stats, int prec, hipStream_t s);
 int launch_flow_metrics(const float* pred, const float* gt, const float* valid, int B, int H, int W, float offx, float offy,
                         float max_mag, double* out, hipStream_t s);

@@ -70,6 +70,7 @@ _SIGS = {
     "craft_conv2d_nhwc_ex": [P, L, I, I, I, P, P, P, I, I, I, I, I, P, L, I, I, I, P, I, P],
     "craft_stem_conv7x7": [P, P, P, I, I, I, I, P, P, P],
     "craft_stem_conv7x7_mfma": [P, P, P, I, I, I, I, P, P, I, P],
+    "craft_stem_conv7x7_mfma_pair": [P, I, P, P, P, I, I, I, I, P, P, I, P],
     "craft_stats_finalize": [P, L, c_double, F, P, P],
     "craft_residual_relu": [P, L, P, P, L, P, I, I, I, I, P, L, P],
     "craft_flow_metrics": [P, P, P, I, I, I, F, F, F, P, P],

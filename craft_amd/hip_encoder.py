@@ -121,24 +121,41 @@ class HipEncoder:
         call("craft_stats_finalize", stats, B * C, float(count), IN_EPS, mr)
         return mr
 
-    def forward_tokens(self, raw: torch.Tensor, prec) -> torch.Tensor:
+    def forward_tokens(self, raw, prec) -> torch.Tensor:
         """raw: images [B, 3, H, W] in 0..255 (the normalisation 2*(x/255)-1 of network.py:169-173 is fused into the
-        stem) -> tokens [B, (H/8)*(W/8), output_dim]."""
+        stem) -> tokens [B, (H/8)*(W/8), output_dim].  ``raw`` may be a pair (frames1, frames2) of equally shaped tensors: the batch is
+        their concatenation (extractor.py:171-176), read from the two tensors in place by the MFMA stem."""
         enc = self.enc
-        B, _, H, W = raw.shape
+        pair = None
+        if isinstance(raw, (tuple, list)):
+            a_, b_ = raw
+            if a_.shape != b_.shape:
+                raise ValueError("the two frame batches must have the same shape")
+            pair = (a_.contiguous(), b_.contiguous())
+            B, _, H, W = a_.shape
+            B *= 2
+            raw_dev = a_.device
+            cp_ = pick(prec, "enc")
+            if not self.supported(H, W) or cp_ == PREC_F32:
+                raw, pair = torch.cat(pair, dim=0), None          # (the PyTorch fallback / the direct fp32 stem take one tensor)
+        if pair is None:
+            B, _, H, W = raw.shape
+            raw_dev = raw.device
         cp = pick(prec, "enc")
         if not self.supported(H, W):
             return ops.tokens_from_nchw(enc((2 * (raw / 255.0) - 1.0).contiguous()).float())
         packs = self._get_packs(cp)
         inorm = self.kind == "instance"
-        dev = raw.device
+        dev = raw_dev
         hw = (H // 2, W // 2)
         # ---- stem: 7x7 / s2 conv (+ folded BatchNorm + ReLU for cnet; raw output + statistics for fnet)
         sw, sb = self._stem
         t = torch.empty(B, hw[0] * hw[1], 64, device=dev, dtype=torch.float32)
         t_norm = None
         def stem(act, stats):
-            if self._stem_mfma is not None:
+            if self._stem_mfma is not None and pair is not None:
+                call("craft_stem_conv7x7_mfma_pair", pair[0], B // 2, pair[1], self._stem_mfma, sb, act, B, H, W, t, stats, cp)
+            elif self._stem_mfma is not None:
                 call("craft_stem_conv7x7_mfma", raw.contiguous(), self._stem_mfma, sb, act, B, H, W, t, stats, cp)
             else:
                 call("craft_stem_conv7x7", raw.contiguous(), sw, sb, act, B, H, W, t, stats)

@@ -338,7 +338,7 @@ class CRAFT(nn.Module):
                 with torch.cuda.stream(side):
                     cn_tok = self._henc_c.forward_tokens(raw1, prec)                            # [B, N, 256]
                     attention, gru_fields = self._context_chain(cn_tok, hx, hw, prec)
-                fm = self._henc_f.forward_tokens(torch.cat([raw1, raw2], dim=0), prec)         # [2B, N, 256]
+                fm = self._henc_f.forward_tokens((raw1, raw2), prec)                           # [2B, N, 256] (both frames, one batch)
                 f1_tok, f2_tok = fm[:B], fm[B:]
             else:
                 image1 = (2 * (raw1 / 255.0) - 1.0).contiguous()

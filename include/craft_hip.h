@@ -287,6 +287,11 @@ int craft_stem_conv7x7(const float* image, const float* w, const float* bias, in
  * 8 consecutive pixels of an input row.  Same outputs / statistics as craft_stem_conv7x7. */
 int craft_stem_conv7x7_mfma(const float* image, const void* w_packed, const float* bias, int act, int B, int H, int W,
                             float* out, double* stats, int prec, void* stream);
+/* The same with the batch taken from TWO image tensors: images [0, Ba) from image_a [Ba][3][H][W], images [Ba, B) from image_b -- fnet
+ * runs both frames of every pair as one batch (network.py:176-180: self.fnet([image1, image2]) concatenates them inside the encoder,
+ * extractor.py:171-176) without a concatenated copy. */
+int craft_stem_conv7x7_mfma_pair(const float* image_a, int Ba, const float* image_b, const void* w_packed, const float* bias, int act, int B, int H,
+                                 int W, float* out, double* stats, int prec, void* stream);
 int craft_stats_finalize(const double* sums, long n, double count, float eps, float* mean_rstd, void* stream);
 int craft_residual_relu(const float* x, long ldx, const float* xnorm, const float* y, long ldy, const float* ynorm,
                         int y_relu, int B, int HW, int C, float* out, long ldo, void* stream);

@@ -196,6 +196,26 @@ def test_hip_encoder_matches_pytorch_module(device, which, precision, H, W):
     assert err < 2e-4 * max(1.0, scale), f"{which}/{precision}: max abs diff {err:.3e} (|ref| max {scale:.2f})"
 
 
+@pytest.mark.parametrize("precision", ["fp32", "mixed", "bf16"])
+def test_hip_encoder_reads_the_two_frames_in_place(device, precision):
+    """fnet's batch = [frames 1 | frames 2] (extractor.py:171-176): handed over as a pair, the MFMA stem reads the two tensors where they lie
+    (craft_stem_conv7x7_mfma_pair) -- the same bits as the concatenated batch, InstanceNorm statistics included."""
+    from craft_amd.hip import Precision
+    from craft_amd.hip_encoder import HipEncoder
+    model = _full_model(device, precision)
+    im1, im2, _ = synth_pair(3, 136, 200, seed=9)
+    im1, im2 = im1.to(device), im2.to(device)
+    for which in ("fnet", "cnet"):
+        henc = HipEncoder(getattr(model, which))
+        with torch.no_grad():
+            a = henc.forward_tokens(torch.cat([im1, im2]), Precision.parse(precision))
+            b = henc.forward_tokens((im1, im2), Precision.parse(precision))
+        # (the statistics' double-precision atomics make two passes agree to rounding, not to the bit)
+        assert a.shape == b.shape and (a - b).abs().max().item() < 1e-5 * max(1.0, a.abs().max().item()), which
+    with pytest.raises(ValueError, match="same shape"):
+        henc.forward_tokens((im1, im2[:1]), Precision.parse(precision))
+
+
 @pytest.mark.parametrize("H,W,B", [(136, 200, 2), (128, 264, 1)])
 def test_ragged_sizes_against_oracle(device, H, W, B):
     """Image sizes whose token grid is not a multiple of any tile (17x25 = 425 tokens, 16x33 = 528): ragged MFMA
