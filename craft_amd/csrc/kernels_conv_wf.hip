@@ -40,7 +40,7 @@ template <int N> __device__ __forceinline__ void wf_interleave() {
 // bit 2: hi x hi.  7 = the fp32-class product.  5 = the WEIGHT operand as one fp16 plane (its lo plane is neither fetched nor multiplied:
 // two MFMAs per product): the input-gradient convolutions of the "mixed" training policy (CRAFT_CONV_W16; dY keeps both planes).
 template <int PREC, int WM, int WN, bool ENC, int TT, int TERMS = CRAFT_X3_TERMS>
-__global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
+__global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p, int xcd_map) {
   typedef typename PrecT<PREC>::lds_t lds_t;
   typedef typename FragT<PREC>::t frag_t;
   constexpr int LD = PrecT<PREC>::LD, PL = Planes<PREC>::N;
@@ -56,7 +56,9 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p) {
   const int KH = g.KH, KW = g.KW, T = TT ? TT : KH * KW;
   const int HWd = WF_PATCH_W + KW - 1, HH = WF_PATCH_H + KH - 1, HR = HH * HWd;
   const int tiles_x = (g.W + WF_PATCH_W - 1) / WF_PATCH_W, tiles_y = (g.H + WF_PATCH_H - 1) / WF_PATCH_H;
-  int bid = blockIdx.x;
+  // (xcd_map: block b runs on XCD b % 8; give each XCD a contiguous eighth of the patch list so that neighbouring patches share the
+  // halo rows they both read through ONE L2 -- CRAFT_CONV_XCD, developer A/B)
+  int bid = xcd_map ? xcd_chunk(blockIdx.x, gridDim.x) : blockIdx.x;
   const int tx = bid % tiles_x; bid /= tiles_x;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
@@ -314,9 +316,10 @@ template <int PREC, int WM, int WN, int TT> static int launch_wf_tt(const ConvGe
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   const int tiles = ((p.g.W + WF_PATCH_W - 1) / WF_PATCH_W) * ((p.g.H + WF_PATCH_H - 1) / WF_PATCH_H) * (p.g.npix / (p.g.H * p.g.W));
   dim3 grid(tiles, (ncols + BN - 1) / BN, 1);
-  if (enc) hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, true, TT>), grid, dim3(NTHREADS), 0, s, p);
-  else if (PREC == CRAFT_PREC_F16X3 && TT > 0 && p.w16) hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, false, TT, 5>), grid, dim3(NTHREADS), 0, s, p);
-  else hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, false, TT>), grid, dim3(NTHREADS), 0, s, p);
+  const int xm = tuning().conv_xcd ? 1 : 0;
+  if (enc) hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, true, TT>), grid, dim3(NTHREADS), 0, s, p, xm);
+  else if (PREC == CRAFT_PREC_F16X3 && TT > 0 && p.w16) hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, false, TT, 5>), grid, dim3(NTHREADS), 0, s, p, xm);
+  else hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, false, TT>), grid, dim3(NTHREADS), 0, s, p, xm);
   return (int)hipGetLastError();
 }
 template <int PREC, int WM, int WN> static int launch_wf_t(const ConvGemmParams& p, hipStream_t s) {

@@ -131,7 +131,7 @@ class HipEncoder:
             a_, b_ = raw
             if a_.shape != b_.shape:
                 raise ValueError("the two frame batches must have the same shape")
-            pair = (a_.contiguous(), b_.contiguous())
+            pair = (a_.float().contiguous(), b_.float().contiguous())
             B, _, H, W = a_.shape
             B *= 2
             raw_dev = a_.device

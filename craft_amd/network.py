@@ -99,8 +99,11 @@ class GraphedForward:
         self._capture()
 
     def _versions(self):
+        """What the recorded launches depend on besides the inputs: every parameter / buffer (by version counter) and the precision policy."""
         m = self.model
-        return tuple(t._version for t in list(m.parameters()) + list(m.buffers()))
+        a = m.args
+        return (str(getattr(a, "hip_precision", None)), bool(getattr(a, "mixed_precision", False)),
+                tuple(t._version for t in list(m.parameters()) + list(m.buffers())))
 
     def _run(self):
         return self.model(self.im1, self.im2, iters=self.iters, flow_init=self.flow_init, test_mode=self.test_mode)

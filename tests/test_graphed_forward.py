@@ -87,6 +87,13 @@ def test_changed_weights_are_recaptured(device):
     again = gf.graph
     gf(im1, im2)
     assert gf.graph is again
+    # the precision policy is part of what was recorded
+    model.args.hip_precision = "fp32"
+    lo2, up2 = gf(im1, im2)
+    assert gf.graph is not again
+    with torch.no_grad():
+        lo_f, up_f = model(im1, im2, iters=2, test_mode=1)
+    assert (up2 - up_f).abs().max().item() < 1e-4
 
 
 @pytest.mark.gpu
