@@ -37,6 +37,10 @@ def test_single_gpu_line(device):
     assert rc["bound"] == "mfma" and rc["calls_timed"] >= 2 and rc["ms_per_call"] > 0 and "HIP events" in rc["timing"]
     assert abs(rc["achieved"] - rc["flops_per_call"] / (rc["ms_per_call"] * 1e-3) / 1e12) <= 0.06 + 0.01 * rc["achieved"]
     assert abs(rc["frac"] - rc["achieved"] / rc["peak"]) < 1e-3 and rc["standalone_ms_per_launch"] > 0
+    # the same pass replayed as one hipGraph, timed beside the eager headline (captured in a child process first)
+    hg = d["hipgraph"]
+    assert hg["ms_per_step"] > 0 and hg["pairs_per_s"] > 0 and hg["steps"] == 2 and hg["max_abs_px_vs_eager"] < 1e-4, hg
+    assert d["config"]["launch"] == "eager launches"
     # the reference's own default inference arithmetic beside the fp32-class headline, with its deviation from it
     ia = d["infer_amp_fp16"]
     assert ia["pairs_per_s"] > 0 and ia["finite"] and 0 <= ia["epe_vs_fp32class_mean"] < 0.5 and "evaluate.py:1455" in ia["policy"]

@@ -116,3 +116,37 @@ def test_eight_rank_timing_allreduce_and_broadcast(tmp_path):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["dt_max"] >= 0.12                          # 2 steps of the slow rank
     assert abs(out["value"] - 8 * 4 * 2 / out["dt_max"]) < 1e-6
+
+
+def test_bench_graph_probe_child_runs_outside_the_process_group(monkeypatch):
+    """bench.py tries the hipGraph capture in a CHILD first (a crash inside the runtime must not cost the line): the child must not inherit
+    the rank / rendezvous variables of a torch.distributed.run launch (it would try to join the parent's group) and runs on this rank's device;
+    only `graph-probe ok` with exit code 0 counts."""
+    import argparse
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("bench_for_probe", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, seen.get("rc", 0), stdout=seen.get("out", "graph-probe ok\n"), stderr="boom\n")
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    for k, v in (("RANK", "3"), ("LOCAL_RANK", "3"), ("WORLD_SIZE", "8"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29500"),
+                 ("CRAFT_FORCE_COLLECTIVES", "1"), ("CRAFT_BENCH_BACKEND", "gloo")):
+        monkeypatch.setenv(k, v)
+    a = argparse.Namespace(batch=4, height=448, width=1024, iters=12, precision="mixed")
+    ok, note = bench.graph_probe_child(a, 3)
+    assert ok and note == ""
+    env, cmd = seen["env"], seen["cmd"]
+    assert not {"RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CRAFT_FORCE_COLLECTIVES"} & set(env)
+    assert env["CRAFT_PROBE_DEVICE"] == "3" and env["CRAFT_BENCH_BACKEND"] == "gloo"
+    assert "--graph-probe" in cmd and cmd[cmd.index("--batch") + 1] == "4" and cmd[cmd.index("--width") + 1] == "1024"
+    seen["rc"] = -11                                # the child died of SIGSEGV
+    ok, note = bench.graph_probe_child(a, 0)
+    assert not ok and "-11" in note
+    seen["rc"], seen["out"] = 0, ""                 # exit 0 without the marker (e.g. an early return) is not a pass either
+    assert not bench.graph_probe_child(a, 0)[0]
