@@ -570,7 +570,8 @@ def train_leg(cfg, rank, world, dev, steps, warmup, iters, B=None, H=None, W=Non
     finite = last["m"]["loss"] == last["m"]["loss"]
     # the first step's loss (synthetic weights seed 1234, pairs seed 100, dropout hash seeded by torch.manual_seed(1234 + rank) above) is a constant of
     # the workload: tests/test_bench_contract.py::test_bench_training_workload_is_the_pinned_one recomputes it, and holds the same batch
-    # with dropout off to the CPU oracle's loss -- a leg that trains something else (other weights, shape, iterations) fails here
+    # with dropout off to the CPU oracle's loss -- a leg that trains something else (other weights, shape, iterations) fails here; the
+    # step WITH dropout on is held to the oracle (same masks) at these shapes by tests/test_train_dropout_parity.py
     pinned = FIRST_LOSS.get((cfg, H, W, B, iters)) if rank == 0 and not torch_encoders else None
     if pinned is not None and os.environ.get("CRAFT_BENCH_PIN_SCALE"):      # (test hook: a deliberately wrong pin, tests/test_bench_contract.py)
         pinned *= float(os.environ["CRAFT_BENCH_PIN_SCALE"])

@@ -33,6 +33,20 @@ Tensor = torch.Tensor
 LN_EPS = 1e-12          # setrans.py:715 (comb_norm_layer), :362 (skip_layer_norm), corr.py:203
 ATTN_CLIP = 100.0       # setrans.py:98  (attn_clip)
 
+# The reference's model.train() forward applies nn.Dropout at six places of the canonical configuration: to the LayerNorm-ed tokens of
+# every SETransInputFeatEncoder (setrans.py:791-795, hidden_dropout_prob 0.1) and to the attention probabilities of the two self-attentions
+# (setrans.py:553-557, attention_probs_dropout_prob 0.2).  Its masks come from torch's generator and cannot be replayed; the functions below
+# take them as DATA instead: a dict {site: mask already scaled by 1 / (1 - p), broadcastable to the site's tensor}, or None (no dropout).
+# Sites: "<prefix>.hidden" / "<prefix>.attn" for prefix in f2_trans, f1_trans, att; "corr_fn.x1" / "corr_fn.x2" for the correlation
+# block's encoder applied to frame 1 / frame 2.  Set by the tests around a call (tests/test_train_dropout_parity.py).
+DROPOUT_MASKS: Optional[Dict[str, "torch.Tensor"]] = None
+
+
+def _drop(t: "torch.Tensor", site: Optional[str]) -> "torch.Tensor":
+    if DROPOUT_MASKS is None or site is None or site not in DROPOUT_MASKS:
+        return t
+    return t * DROPOUT_MASKS[site]
+
 
 @dataclass
 class OracleConfig:
@@ -70,7 +84,8 @@ def tokens_layernorm(x_nchw: Tensor) -> Tensor:
     return layernorm_lastdim(t)
 
 
-def vispos_tokens(x_nchw: Tensor, sd: Dict[str, Tensor], prefix: str, pos_w: float, positions: Optional[Tensor] = None) -> Tensor:
+def vispos_tokens(x_nchw: Tensor, sd: Dict[str, Tensor], prefix: str, pos_w: float, positions: Optional[Tensor] = None,
+                  drop_site: Optional[str] = None) -> Tensor:
     """SETransInputFeatEncoder.forward (setrans.py:763-800) for either positional-code type, chosen by the state dict's keys:
     'bias' (``<prefix>.vispos_encoder.pos_coder.biases``): LayerNorm of the tokens, the table goes to the scores.
     'lsinu' (``...pos_coder.pos_fc.weight``): tokens + pos_w * E(p / max p) before the LayerNorm, E = LearnedSinuPosEmbedder
@@ -87,7 +102,7 @@ def vispos_tokens(x_nchw: Tensor, sd: Dict[str, Tensor], prefix: str, pos_w: flo
         e0 = F.linear(pn, sd[wk], sd[f"{prefix}.vispos_encoder.pos_coder.pos_fc.bias"])
         mix = torch.stack((torch.sin(e0[..., 0::2]), torch.cos(e0[..., 1::2])), dim=-1).reshape(e0.shape)
         t = t + pos_w * layernorm_lastdim(mix)
-    return layernorm_lastdim(t)
+    return _drop(layernorm_lastdim(t), drop_site)                # (training: self.dropout(feat_normed), setrans.py:791-795)
 
 
 def pos_table_matrix(sd: Dict[str, Tensor], prefix: str, H8: int, W8: int):
@@ -170,8 +185,8 @@ def inter_corr_raw(fmap1: Tensor, fmap2: Tensor, sd: Dict[str, Tensor], cfg: Ora
     """TransCorrBlock.corr before the global LayerNorm: [B, N, N] un-normalised c(i,j).  positions1 / positions2: the two frames' (y, x)
     positions when they are not the grid (only the 'lsinu' positional code reads them: coords1 = grid + flow_init, corr.py:153)."""
     B, C, H8, W8 = fmap1.shape
-    x1 = vispos_tokens(fmap1, sd, "corr_fn", cfg.inter_pos_code_weight, positions1)
-    x2 = vispos_tokens(fmap2, sd, "corr_fn", cfg.inter_pos_code_weight, positions2)
+    x1 = vispos_tokens(fmap1, sd, "corr_fn", cfg.inter_pos_code_weight, positions1, drop_site="corr_fn.x1")
+    x2 = vispos_tokens(fmap2, sd, "corr_fn", cfg.inter_pos_code_weight, positions2, drop_site="corr_fn.x2")
     W = sd["corr_fn.setrans.query.weight"]
     b = sd.get("corr_fn.setrans.query.bias")
     S = mm_scores(x1, x2, W, b, W, b, cfg.inter_num_modes)           # tied projection (:475-478)
@@ -291,7 +306,7 @@ def expanded_feat_trans(x: Tensor, P: Tensor, Wv: Tensor, w_agg: Tensor, skip_co
 
 
 def self_attn_probs(x_tokens: Tensor, Wq: Tensor, Wk: Tensor, biases: Tensor, pos_w: float, M: int,
-                    H8: int, W8: int, mask_radius: int = -1) -> Tensor:
+                    H8: int, W8: int, mask_radius: int = -1, drop_site: Optional[str] = None) -> Tensor:
     """CrossAttFeatTrans with key_feat=query_feat up to the softmax (setrans.py:507-557). [B,M,N,N]"""
     S = mm_scores(x_tokens, x_tokens, Wq, None, Wk, None, M)
     S = clamp_rule(S)
@@ -300,16 +315,16 @@ def self_attn_probs(x_tokens: Tensor, Wq: Tensor, Wk: Tensor, biases: Tensor, po
     m = chebyshev_mask(H8, W8, mask_radius)
     if m is not None:
         S = S + m
-    return torch.softmax(S, dim=-1)
+    return _drop(torch.softmax(S, dim=-1), drop_site)            # (training: self.att_dropout(attention_probs), setrans.py:553-557)
 
 
 def f2_transform(fmap2: Tensor, sd: Dict[str, Tensor], cfg: OracleConfig, prefix: str = "f2_trans") -> Tensor:
     """A1: SelfAttVisPosTrans 'F2 transformer' (network.py:185-187; setrans.py:578-619).  NCHW->NCHW"""
     B, C, H8, W8 = fmap2.shape
-    x = vispos_tokens(fmap2, sd, prefix, cfg.f2_pos_code_weight)
+    x = vispos_tokens(fmap2, sd, prefix, cfg.f2_pos_code_weight, drop_site=f"{prefix}.hidden")
     P = self_attn_probs(x, sd[f"{prefix}.setrans.query.weight"], sd[f"{prefix}.setrans.key.weight"],
                         sd.get(f"{prefix}.vispos_encoder.pos_coder.biases"), cfg.f2_pos_code_weight,
-                        cfg.f2_num_modes, H8, W8, cfg.f2_attn_mask_radius)
+                        cfg.f2_num_modes, H8, W8, cfg.f2_attn_mask_radius, drop_site=f"{prefix}.attn")
     y = expanded_feat_trans(x, P,
                             sd[f"{prefix}.setrans.out_trans.first_linear.weight"],
                             sd[f"{prefix}.setrans.out_trans.feat_softaggr.feat2score.weight"],
@@ -320,10 +335,10 @@ def f2_transform(fmap2: Tensor, sd: Dict[str, Tensor], cfg: OracleConfig, prefix
 def intra_attention(inp_feat: Tensor, sd: Dict[str, Tensor], cfg: OracleConfig) -> Tensor:
     """A3: 'Intra-frame attention' probabilities (network.py:214).  [B,4,N,N]"""
     B, C, H8, W8 = inp_feat.shape
-    x = vispos_tokens(inp_feat, sd, "att", cfg.intra_pos_code_weight)
+    x = vispos_tokens(inp_feat, sd, "att", cfg.intra_pos_code_weight, drop_site="att.hidden")
     return self_attn_probs(x, sd["att.setrans.query.weight"], sd["att.setrans.key.weight"],
                            sd.get("att.vispos_encoder.pos_coder.biases"), cfg.intra_pos_code_weight,
-                           cfg.intra_num_modes, H8, W8, -1)
+                           cfg.intra_num_modes, H8, W8, -1, drop_site="att.attn")
 
 
 def gma_attention(inp_feat: Tensor, sd: Dict[str, Tensor], heads: int, position_only: bool = False,
@@ -579,7 +594,8 @@ def sequence_loss(flow_preds: List[Tensor], flow_gt: Tensor, valid: Tensor, gamm
 
 
 def craft_train_forward(sd, cfg: OracleConfig, image1: Tensor, image2: Tensor, iters: int = 12, freeze_bn: bool = False):
-    """CRAFT.forward under model.train() with every dropout at p = 0 (network.py:164-267): differentiable w.r.t. the tensors
+    """CRAFT.forward under model.train() (network.py:164-267), every dropout at p = 0 unless DROPOUT_MASKS hands the masks in (see the top of
+    this file): differentiable w.r.t. the tensors
     of ``sd`` that require grad; cnet's BatchNorm uses batch statistics unless ``freeze_bn`` (network.py:136-140).
     -> (flow_predictions, {buffer name: updated running statistic})."""
     im1 = 2 * (image1 / 255.0) - 1.0
