@@ -23,7 +23,10 @@ TRAIN_CASES = ["train_b2_128x192_T3", "train_freezebn_b2_128x160_T2",
                # --interpos / --intrapos lsinu: the learned sinusoidal embedding and its pos_fc gradients
                "train_lsinu_b2_128x160_T2",
                # --num_heads 2 with GMA's attention: head merge + the aggregator's `project` (gma.py:123-126, :133-138)
-               "train_gmaheads2_b2_128x160_T2"]
+               "train_gmaheads2_b2_128x160_T2",
+               # the canonical configuration WITH the reference's dropout on (0.1 / 0.2), the masks handed in as data: nn.Dropout.forward of the
+               # imported reference replaced by x * mask (tools/make_golden_train_dropout.py), the oracle fed the same masks (DROPOUT_MASKS)
+               "train_dropout_b2_128x160_T2"]
 
 
 def grad_scale(z):
@@ -67,7 +70,13 @@ def test_oracle_training_step_matches_reference(case):
         for k in [k for k in sd if k.startswith("f1_trans.")]:
             sd[k] = sd["f2_trans." + k[len("f1_trans."):]]
     im1, im2 = torch.from_numpy(z["image1"].astype(np.float32)), torch.from_numpy(z["image2"].astype(np.float32))
-    preds, bn = O.craft_train_forward(sd, O.OracleConfig(**over), im1, im2, iters=meta["iters"], freeze_bn=meta["freeze_bn"])
+    if meta.get("dropout"):
+        from dropout_hash import pass_masks
+        O.DROPOUT_MASKS = pass_masks(meta["dropout_base"], meta["B"], (meta["H"] // 8) * (meta["W"] // 8))
+    try:
+        preds, bn = O.craft_train_forward(sd, O.OracleConfig(**over), im1, im2, iters=meta["iters"], freeze_bn=meta["freeze_bn"])
+    finally:
+        O.DROPOUT_MASKS = None
     loss, metrics = O.sequence_loss(preds, torch.from_numpy(z["flow_gt"]), torch.from_numpy(z["valid"]), meta["gamma"])
     loss.backward()
     assert float(loss) == pytest.approx(float(z["loss"]), rel=2e-5)

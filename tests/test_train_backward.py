@@ -333,11 +333,20 @@ def grad_check_l2(z, key, g, l2_tol, elem_tol):
 
 
 def _train_model(device, meta, precision="fp32"):
-    model = CRAFT(default_args(hip_precision=precision, dropout_prob=0.0, **meta.get("over", {})))
+    # (a fixture captured with the reference's dropout ON -- masks as data, tools/make_golden_train_dropout.py -- keeps the config's 0.1 / 0.2)
+    drop = {} if meta.get("dropout") else {"dropout_prob": 0.0}
+    model = CRAFT(default_args(hip_precision=precision, **drop, **meta.get("over", {})))
     model.load_state_dict(synth_state_dict(model.state_dict(), seed=meta["seed"], qk_gain=meta["qk_gain"]), strict=True)
     model = model.to(device).train()
     if meta["freeze_bn"]:
         model.freeze_bn()
+    if meta.get("dropout"):
+        # the six dropout seeds of the model's NEXT pass derive from torch's seed and the pass counter (craft_amd/train_forward.py): the
+        # fixture's masks were made by tests/dropout_hash.py from the same base and applied inside the imported reference
+        from dropout_hash import pass_base
+        torch.manual_seed(meta["torch_seed"])
+        model.__dict__["_train_calls"] = 0
+        assert pass_base(torch.initial_seed()) == meta["dropout_base"]
     return model
 
 
@@ -385,7 +394,10 @@ def test_training_step_matches_reference_gradients(device, case, precision):
         mul = 15.0 if p.numel() == 1 else 1.0
         # "mixed" (what args.mixed_precision=True selects) trains with its fp16 roles promoted to f16x3 (train_forward.training_precision:
         # no loss scaling is built): fp32-class, measured <= 5e-3 relative L2 -> 2e-2
-        worst = max(worst, grad_check_l2(z, k, p.grad, l2_tol=mul * (1e-2 if tight else 2e-2), elem_tol=mul * (0.25 if tight else 0.3)))
+        # (the fixture with the reference's dropout ON: 1.7e-2 measured in `mixed` on corr_fn.setrans.query.weight -- the masks thin the sums
+        # that gradient is made of -- so its bound is 2 x that, as in tests/test_train_dropout_parity.py)
+        mixed_tol = 4e-2 if meta.get("dropout") else 2e-2
+        worst = max(worst, grad_check_l2(z, k, p.grad, l2_tol=mul * (1e-2 if tight else mixed_tol), elem_tol=mul * (0.25 if tight else 0.3)))
         checked += 1
     assert checked == len({id(p) for k, p in model.named_parameters() if not k.startswith("corr_fn.setrans.key.")}) - len(unused) and checked >= 130
     print(f"[train parity] {case} {precision}: loss {float(loss):.6f} (reference {float(z['loss']):.6f}), worst relative L2 gradient error {worst:.2e}")

@@ -4,8 +4,8 @@ ran with dropout off + mask statistics).
 
 The HIP step draws its masks from a counter-based hash, keep(i) = mix32(seed * phi + i) >= p * 2^32 over the flat element index i of the
 tensor (``craft_dropout`` / the fused softmax kernels: csrc/kernels_train.hip), with one seed per site derived from ``torch.initial_seed()``
-and the model's pass counter (craft_amd/train_forward.py).  Here that hash is RESTATED in numpy (nothing of the product is called to make a
-mask), the six masks of a pass are built from the seeds alone and handed to the oracle as data (``oracle.craft_oracle.DROPOUT_MASKS``), and
+and the model's pass counter (craft_amd/train_forward.py).  That hash is RESTATED in numpy (tests/dropout_hash.py: nothing of the product is
+called to make a mask), the six masks of a pass are built from the seeds alone and handed to the oracle as data (``oracle.craft_oracle.DROPOUT_MASKS``), and
 the oracle's loss, predictions and every parameter gradient under torch autograd are compared with the HIP step's.  The CPU part pins the
 restated hash to the kernel's published constants and statistics; the GPU part is the parity test proper.
 """
@@ -13,44 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-PHI = 0x9E3779B97F4A7C15
-MASK64 = (1 << 64) - 1
-
-
-def mix32(k: np.ndarray) -> np.ndarray:
-    """The 64-bit finaliser of the kernels (murmur3's fmix64), low 32 bits.  k: uint64 array."""
-    k = k.copy()
-    with np.errstate(over="ignore"):
-        k ^= k >> np.uint64(33)
-        k *= np.uint64(0xff51afd7ed558ccd)
-        k ^= k >> np.uint64(33)
-        k *= np.uint64(0xc4ceb9fe1a85ec53)
-        k ^= k >> np.uint64(33)
-    return (k & np.uint64(0xFFFFFFFF)).astype(np.uint64)
-
-
-def dropout_scale(seed: int, index: np.ndarray, p: float) -> np.ndarray:
-    """x -> x * keep / (1 - p) as a float32 factor per flat element index: keep = mix32(seed * PHI + index) >= (unsigned)(p * 2^32)."""
-    p32 = np.float32(p)
-    thr = np.uint64(int(min(np.float32(p32 * np.float32(4294967296.0)), np.float32(4294967040.0))))
-    base = np.uint64((int(seed) * PHI) & MASK64)
-    with np.errstate(over="ignore"):
-        keep = mix32(base + index.astype(np.uint64)) >= thr
-    inv = np.float32(1.0) / (np.float32(1.0) - p32)
-    return np.where(keep, inv, np.float32(0.0)).astype(np.float32)
-
-
-def token_mask(seed: int, shape, p: float) -> torch.Tensor:
-    n = int(np.prod(shape))
-    return torch.from_numpy(dropout_scale(seed, np.arange(n, dtype=np.uint64), p).reshape(shape))
-
-
-def probs_mask(seed: int, B: int, M: int, N: int, p: float) -> torch.Tensor:
-    """The probabilities live in rows of ld = N rounded up to 32 floats: flat index = ((b M + m) N + i) ld + j."""
-    ld = (N + 31) // 32 * 32
-    rows = np.arange(B * M * N, dtype=np.uint64)[:, None] * np.uint64(ld)
-    idx = rows + np.arange(N, dtype=np.uint64)[None, :]
-    return torch.from_numpy(dropout_scale(seed, idx, p).reshape(B, M, N, N))
+from dropout_hash import MASK64, dropout_scale, mix32, pass_base, pass_masks, probs_mask, token_mask
 
 
 def test_restated_hash_constants_and_statistics():
@@ -113,7 +76,7 @@ def test_training_step_with_dropout_on_against_oracle(device, policy, B, H, W, i
     valid = (torch.rand(B, H, W, generator=torch.Generator().manual_seed(1)) > 0.15).float()
     torch.manual_seed(20260930)
     model.__dict__["_train_calls"] = 0
-    base = (torch.initial_seed() * 1000003 + 0 * 64) & 0x7FFFFFFFFFFFFFF                # craft_amd/train_forward.py: the pass's seed schedule
+    base = pass_base(torch.initial_seed())                                               # craft_amd/train_forward.py: the pass's seed schedule
     preds = model(im1.to(device), im2.to(device), iters=iters)
     loss, _ = AG.sequence_loss(preds, flow, valid, 0.8)
     ls = auto_loss_scale(flow.numel())
@@ -122,10 +85,7 @@ def test_training_step_with_dropout_on_against_oracle(device, policy, B, H, W, i
         if p_.grad is not None:
             p_.grad.mul_(1.0 / ls)
     # ---- the oracle with the same six masks (sites and seeds: train_forward.py; mask = the restated hash, nothing of the product)
-    N, M = (H // 8) * (W // 8), 4
-    masks = {"f2_trans.hidden": token_mask(base + 1, (B, N, 256), ph), "f2_trans.attn": probs_mask(base + 2, B, M, N, pa),
-             "corr_fn.x1": token_mask(base + 3, (B, N, 256), ph), "corr_fn.x2": token_mask(base + 4, (B, N, 256), ph),
-             "att.hidden": token_mask(base + 5, (B, N, 128), ph), "att.attn": probs_mask(base + 6, B, M, N, pa)}
+    masks = pass_masks(base, B, (H // 8) * (W // 8), 4, ph, pa)
     names = [k for k, _ in model.named_parameters()]
     sd = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in sd0.items()}
     sd["corr_fn.setrans.key.weight"], sd["corr_fn.setrans.key.bias"] = sd["corr_fn.setrans.query.weight"], sd["corr_fn.setrans.query.bias"]
