@@ -236,3 +236,72 @@ def test_trainer_gma_variant_skips_unused_position_embeddings(device):
     assert all(l == l and l < 1e4 for l in losses), losses
     for k, v in before.items():
         assert torch.equal(model.state_dict()[k], v), k
+
+
+def test_three_steps_follow_the_reference_training_loop(device):
+    """Trainer.step x 3 against THREE iterations of the reference's own loop (train.py:215-236 on the imported model, optimizer and scheduler
+    from train.py's fetch_optimizer, dropout ON with the masks of every pass handed in as data: tools/make_golden_train_traj.py): the
+    losses of the three (different) batches, the learning rates, every parameter's change after the third update, BatchNorm statistics."""
+    import json
+
+    import numpy as np
+    from golden_util import GOLDEN_DIR, sample_idx
+    z = np.load(os.path.join(GOLDEN_DIR, "train_traj_b2_128x160_T2.npz"))
+    zg = np.load(os.path.join(GOLDEN_DIR, "train_dropout_b2_128x160_T2.npz"))          # (its gradients tell which parameters have none)
+    c = json.loads(str(z["meta"]))
+    model = CRAFT(default_args(hip_precision="fp32"))                                   # dropout at the config's 0.1 / 0.2
+    sd0 = synth_state_dict(model.state_dict(), seed=c["seed"], qk_gain=c["qk_gain"])
+    model.load_state_dict(sd0, strict=True)
+    model = model.to(device)
+    tr = Trainer(model, lr=c["lr"], wdecay=c["wdecay"], epsilon=c["epsilon"], num_steps=c["num_steps"], clip=c["clip"], gamma=c["gamma"],
+                 iters=c["iters"], loss_scale=None)
+    torch.manual_seed(c["torch_seed"])                     # the dropout seeds of pass s: pass_base(torch_seed, s) (craft_amd/train_forward.py)
+    model.__dict__["_train_calls"] = 0
+    losses, lrs = [], []
+    for s in range(c["steps"]):
+        lrs.append(tr.scheduler.get_last_lr()[0] if hasattr(tr.scheduler, "get_last_lr") else None)
+        m = tr.step(torch.from_numpy(z[f"image1.{s}"].astype(np.float32)).to(device), torch.from_numpy(z[f"image2.{s}"].astype(np.float32)).to(device),
+                    torch.from_numpy(z[f"flow_gt.{s}"]).to(device), torch.from_numpy(z[f"valid.{s}"]).to(device))
+        losses.append(float(m["loss"]))
+    torch.cuda.synchronize()
+    # losses: the first one is the dropout-on forward alone; the second and third have one / two updates behind them
+    assert losses[0] == pytest.approx(z["losses"][0], rel=3e-5)
+    # (measured: 2e-6 and 5e-6 relative)
+    assert losses[1] == pytest.approx(z["losses"][1], rel=1e-4) and losses[2] == pytest.approx(z["losses"][2], rel=1e-4), (losses, z["losses"])
+    if lrs[0] is not None:
+        assert lrs == pytest.approx(z["lrs"].tolist(), rel=1e-6)
+    # which parameters carry a real gradient (the others -- biases in front of a normalisation layer -- receive rounding noise, which AdamW's
+    # first steps turn into +-lr whatever its size: not comparable, and without effect on the loss)
+    r = [np.sqrt(zg[k][1] / max(1, int(np.prod(zg[k[:-2] + ".shape"])))) for k in zg.files if k.startswith("grad.") and k.endswith(".s")]
+    scale = float(np.median(r))
+    unused = set(json.loads(str(zg["unused"])))
+    worst, worst_k, checked, seen = 0.0, None, 0, set()
+    l2s = []
+    for k, p in model.named_parameters():
+        if id(p) in seen or k.startswith("corr_fn.setrans.key."):
+            continue
+        seen.add(id(p))
+        dw = (p.detach().cpu() - sd0[k]).reshape(-1).numpy()
+        if k in unused:
+            assert float(np.abs(dw).max()) == 0.0, f"{k}: unused in the reference (no gradient, no decay)"
+            continue
+        gs = zg[f"grad.{k}.s"]
+        if np.sqrt(gs[1] / dw.size) < 1e-4 * scale:
+            continue
+        ref = z[f"dw.{k}.v"]
+        got = dw[sample_idx(dw.size)]
+        l2 = float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
+        if l2 > worst:
+            worst, worst_k = l2, k
+        checked += 1
+        l2s.append((l2, k, dw.size))
+        # AdamW's first updates are -lr * m / (sqrt(v) + eps) ~ -lr * sign(g): an element whose gradient is near zero flips on rounding noise
+        # (a flipped fraction f costs 2 sqrt(f) of relative L2: the 4e-2 of the large fnet weights is 0.04 % of their elements).  Measured on the
+        # MI355X: median 1.2e-2, worst 7.3e-2 (a 96-element BatchNorm bias); bound = 2 x the worst.  The losses above are the sharp check.
+        assert l2 < 0.15, f"{k}: change after three updates differs by {l2:.2e} (relative L2 over the sample)"
+    assert checked >= 100
+    for k in [f for f in z.files if f.startswith("bn.")]:
+        assert np.allclose(model.state_dict()[k[3:]].cpu().numpy(), z[k], rtol=1e-3, atol=1e-5), k
+    print("[trajectory] largest:", [(f"{a:.2e}", b, n) for a, b, n in sorted(l2s, reverse=True)[:8]], "median", f"{sorted(l2s)[len(l2s) // 2][0]:.2e}")
+    print(f"[trajectory] losses {['%.6f' % v for v in losses]} vs reference {['%.6f' % v for v in z['losses']]}; worst relative L2 of a parameter's "
+          f"three-step change {worst:.2e} ({worst_k}), {checked} parameters")
