@@ -4,8 +4,10 @@
   re-drawn by our sampler from the same seeds -- so the draw order is pinned too (CPU part) and the kernel (GPU part).
 * ColorJitter's four operations: bit for bit against outputs of Pillow itself (tests/golden/photo_pil.npz; torchvision's PIL path wraps
   Pillow) -- the oracle (CPU part) and the kernel (GPU part).
-* spatial gather (resize -> flips -> crop), eraser: against numpy restatements written here (cv2 is not in this image: its 8-bit
-  fixed-point resize is not pinned).
+* eraser (both augmentors) and the sparse flow-map resize: against the reference's OWN pure-numpy methods, compiled out of augmentor.py's AST
+  (tests/golden/augment_ref.npz, tools/make_golden_augment.py).
+* spatial gather (resize -> flips -> crop), blur: against numpy restatements written here (cv2 is not in this image: its 8-bit
+  fixed-point filters are not pinned).
 * Gaussian blur (augmentor.py:195-198): against a numpy restatement of cv2.getGaussianKernel (sigma > 0) + BORDER_REFLECT_101.
 * FlowAugmentor end to end: shapes, ranges, flow consistency under a pure flip / crop."""
 import os
@@ -90,6 +92,7 @@ def test_spatial_gather(device, do_resize, hflip, vflip):
 
 
 PHOTO = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "photo_pil.npz"))
+AUGREF = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "augment_ref.npz"))      # the reference's own numpy methods
 PHOTO_IMAGES = ("rand", "grey", "dark", "prim")
 
 
@@ -161,103 +164,39 @@ def test_eraser(device):
     ref[3:10, 5:15] = (1.0, 2.0, 3.0)
     ref[25:75, 30:80] = (1.0, 2.0, 3.0)
     assert np.array_equal(e, ref)
-    # eraser_transform end to end against the reference's statements (augmentor.py:127-139, pure numpy: restated here on a uint8 array --
-    # the float64 mean colour is TRUNCATED by the assignment into the uint8 image), same seed -> same rectangles
-    from craft_amd.augment import FlowAugmentor
-    a1 = r.randint(0, 256, size=(120, 150, 3)).astype(np.uint8)
-    a2 = r.randint(0, 256, size=(120, 150, 3)).astype(np.uint8)
-    for seed in (0, 1, 2, 3, 5):
-        np.random.seed(seed)
-        want = a2.copy()
-        fired = np.random.rand() < 0.5
-        if fired:
-            mean_color = np.mean(want.reshape(-1, 3), axis=0)
-            for _ in range(np.random.randint(1, 3)):
-                x0, y0 = np.random.randint(0, 150), np.random.randint(0, 120)
-                dx, dy = np.random.randint(50, 100), np.random.randint(50, 100)
-                want[y0:y0 + dy, x0:x0 + dx, :] = mean_color
-        np.random.seed(seed)
-        aug = FlowAugmentor("chairs", (96, 128))
-        g1, g2 = aug.eraser_transform(torch.from_numpy(a1.astype(np.float32)).to(device), torch.from_numpy(a2.astype(np.float32)).to(device))
-        assert np.array_equal(g2.cpu().numpy(), want.astype(np.float32)), seed
-        assert np.array_equal(g1.cpu().numpy(), a1.astype(np.float32))
+    # eraser_transform end to end against the REFERENCE'S OWN METHODS (tests/golden/augment_ref.npz: FlowAugmentor / SparseFlowAugmentor
+    # .eraser_transform compiled out of augmentor.py's AST and run on seeded draws, tools/make_golden_augment.py): same seed -> same
+    # rectangles, and the float64 mean colour TRUNCATED by the assignment into the uint8 image
+    from craft_amd.augment import FlowAugmentor, SparseFlowAugmentor
+    a1, a2 = AUGREF["erase.img1"], AUGREF["erase.img2"]
+    fired = 0
+    for kind, cls in (("FlowAugmentor", FlowAugmentor), ("SparseFlowAugmentor", SparseFlowAugmentor)):
+        for seed in AUGREF["erase.seeds"].tolist():
+            want = AUGREF[f"erase.{kind}.{seed}"]
+            fired += int(not np.array_equal(want, a2))
+            np.random.seed(seed)
+            aug = cls("chairs", (96, 128))
+            g1, g2 = aug.eraser_transform(torch.from_numpy(a1.astype(np.float32)).to(device), torch.from_numpy(a2.astype(np.float32)).to(device))
+            assert np.array_equal(g2.cpu().numpy(), want.astype(np.float32)), (kind, seed)
+            assert np.array_equal(g1.cpu().numpy(), a1.astype(np.float32))
+    assert fired >= 4, "the fixture must contain draws that erase something"
 
 
 @pytest.mark.gpu
-def test_flow_augmentor_end_to_end(device):
-    from craft_amd.augment import FlowAugmentor
-    r = np.random.RandomState(6)
-    H, W, crop = 120, 160, (64, 96)
-    img1 = torch.from_numpy(r.randint(0, 256, size=(H, W, 3)).astype(np.float32)).to(device)
-    img2 = torch.from_numpy(r.randint(0, 256, size=(H, W, 3)).astype(np.float32)).to(device)
-    flow = torch.from_numpy((r.standard_normal((H, W, 2)) * 3).astype(np.float32)).to(device)
-    aug = FlowAugmentor("chairs", crop, min_scale=-0.1, max_scale=1.0, do_flip=True, shift_prob=0.5, shift_sigmas=(16, 10))
-    shifted = 0
-    for sd in range(12):
-        random.seed(sd); np.random.seed(sd)
-        a, b, f, v = aug(img1, img2, flow)
-        assert a.shape == (crop[0], crop[1], 3) and b.shape == a.shape and f.shape == (crop[0], crop[1], 2)
-        assert float(a.min()) >= 0 and float(a.max()) <= 255 and torch.equal(a, a.round())
-        assert torch.isfinite(f).all()
-        if v is not None:
-            shifted += 1
-            assert v.shape == crop and set(np.unique(v.cpu().numpy())) <= {0.0, 1.0}
-            assert float((f.abs().sum(-1) * (1 - v)).max()) == 0.0            # padded area: zero flow
-    assert 0 < shifted < 12
-    # same seed, same result (all randomness comes from the seeded module-level generators)
-    random.seed(3); np.random.seed(3)
-    x = aug(img1, img2, flow)
-    random.seed(3); np.random.seed(3)
-    y = aug(img1, img2, flow)
-    assert all(torch.equal(p, q) for p, q in zip(x[:3], y[:3]))
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("fx,hflip", [(1.0, False), (1.31, False), (0.77, True)])
-def test_sparse_flow_resize(device, fx, hflip):
-    """craft_aug_sparse vs a numpy restatement of SparseFlowAugmentor.resize_sparse_flow_map + flip + crop (augmentor.py:249-316),
-    including numpy's last-writer-wins order on contested targets (fx < 1 makes many collisions)."""
+def test_sparse_flow_resize_matches_the_reference_method(device):
+    """craft_aug_sparse (resize part: crop = the whole resized map) against SparseFlowAugmentor.resize_sparse_flow_map run from the
+    reference's own source (tests/golden/augment_ref.npz): which target pixels are valid, and their flow."""
     from craft_amd.augment import sparse_resize_crop
-    r = np.random.RandomState(8)
-    H, W = 50, 70
-    flow = (r.standard_normal((H, W, 2)) * 6).astype(np.float32)
-    valid = (r.random_sample((H, W)) > 0.5).astype(np.float32)
-    fy = fx
-    coords = np.stack(np.meshgrid(np.arange(W), np.arange(H)), axis=-1).reshape(-1, 2).astype(np.float32)
-    fl, va = flow.reshape(-1, 2), valid.reshape(-1)
-    c0, f0 = coords[va >= 1], fl[va >= 1]
-    ht1, wd1 = int(round(H * fy)), int(round(W * fx))
-    c1, f1 = c0 * [fx, fy], f0 * [fx, fy]
-    xx, yy = np.round(c1[:, 0]).astype(np.int32), np.round(c1[:, 1]).astype(np.int32)
-    v = (xx > 0) & (xx < wd1) & (yy > 0) & (yy < ht1)
-    fimg, vimg = np.zeros([ht1, wd1, 2], np.float32), np.zeros([ht1, wd1], np.int32)
-    fimg[yy[v], xx[v]] = f1[v]
-    vimg[yy[v], xx[v]] = 1
-    if hflip:
-        fimg, vimg = fimg[:, ::-1] * [-1.0, 1.0], vimg[:, ::-1]
-    crop = (min(30, ht1 - 3), min(40, wd1 - 4))
-    y0, x0 = 2, 3
-    ref_f, ref_v = fimg[y0:y0 + crop[0], x0:x0 + crop[1]], vimg[y0:y0 + crop[0], x0:x0 + crop[1]]
-    gf, gv = sparse_resize_crop(torch.from_numpy(flow).to(device), torch.from_numpy(valid).to(device), crop, y0, x0, fx, fy, hflip)
-    assert np.array_equal(gv.cpu().numpy(), ref_v.astype(np.float32))
-    assert np.allclose(gf.cpu().numpy(), ref_f, rtol=1e-6, atol=1e-6)
-
-
-@pytest.mark.gpu
-def test_sparse_augmentor_end_to_end(device):
-    from craft_amd.augment import SparseFlowAugmentor
-    r = np.random.RandomState(9)
-    H, W, crop = 150, 400, (96, 256)
-    img1 = torch.from_numpy(r.randint(0, 256, size=(H, W, 3)).astype(np.float32)).to(device)
-    img2 = torch.from_numpy(r.randint(0, 256, size=(H, W, 3)).astype(np.float32)).to(device)
-    flow = torch.from_numpy((r.standard_normal((H, W, 2)) * 3).astype(np.float32)).to(device)
-    valid = torch.from_numpy((r.random_sample((H, W)) > 0.6).astype(np.float32)).to(device)
-    aug = SparseFlowAugmentor("kitti", crop, min_scale=-0.2, max_scale=0.4, do_flip=False)
-    for sd in range(6):
-        random.seed(sd); np.random.seed(sd)
-        a, b, f, v = aug(img1, img2, flow, valid)
-        assert a.shape == (crop[0], crop[1], 3) and f.shape == (crop[0], crop[1], 2) and v.shape == crop
-        assert 0.05 < float(v.mean()) < 0.6 and float((f.abs().sum(-1) * (1 - v)).max()) == 0.0
+    flow, valid = AUGREF["sparse.flow"], AUGREF["sparse.valid"]
+    H, W = valid.shape
+    for k, (fx, fy) in enumerate(AUGREF["sparse.scales"].tolist()):
+        want_f, want_v = AUGREF[f"sparse.{k}.flow"], AUGREF[f"sparse.{k}.valid"]
+        Hs, Ws = int(round(H * fy)), int(round(W * fx))
+        assert want_v.shape == (Hs, Ws)
+        f, v = sparse_resize_crop(torch.from_numpy(flow).to(device), torch.from_numpy(valid).to(device), (Hs, Ws), 0, 0, fx, fy, False)
+        assert np.array_equal(v.cpu().numpy(), want_v.astype(np.float32)), (fx, fy)
+        # (the reference multiplies float32 flow by the float64 scale and stores float32: one rounding; the kernel multiplies in float32)
+        assert np.allclose(f.cpu().numpy(), want_f, rtol=2e-7, atol=0), (fx, fy)
 
 
 def _np_gaussian_blur(img, K, sigma):
