@@ -220,10 +220,9 @@ class SparseFlowAugmentor(FlowAugmentor):
     def eraser_transform(self, img1, img2):
         return super().eraser_transform(img1, img2, bounds=(50, 100))
 
-    def __call__(self, img1, img2, flow, valid):
-        img1, img2, flow, valid = _f(img1).clone(), _f(img2).clone(), _f(flow), _f(valid)
-        img1, img2 = self.color_transform(img1, img2)
-        img1, img2 = self.eraser_transform(img1, img2)
+    def spatial_transform(self, img1, img2, flow, valid):
+        """augmentor.py:290-330: one isotropic scale (clipped so that the crop fits), resize with probability spatial_aug_prob, h-flip, a crop
+        drawn with margins and clipped back into the frame; same ``np.random`` calls in the same order."""
         ht, wd = img1.shape[:2]
         min_scale = np.maximum((self.crop_size[0] + 1) / float(ht), (self.crop_size[1] + 1) / float(wd))
         scale = 2 ** np.random.uniform(self.min_scale, self.max_scale)
@@ -249,3 +248,9 @@ class SparseFlowAugmentor(FlowAugmentor):
                 flow, valid = flow.flip(1) * torch.tensor([-1.0, 1.0], device=flow.device), valid.flip(1)
             f, v = flow[y0:y0 + ch, x0:x0 + cw].contiguous(), valid[y0:y0 + ch, x0:x0 + cw].contiguous()
         return a, b, f, v
+
+    def __call__(self, img1, img2, flow, valid):
+        img1, img2, flow, valid = _f(img1).clone(), _f(img2).clone(), _f(flow), _f(valid)
+        img1, img2 = self.color_transform(img1, img2)
+        img1, img2 = self.eraser_transform(img1, img2)
+        return self.spatial_transform(img1, img2, flow, valid)

@@ -199,6 +199,29 @@ def test_sparse_flow_resize_matches_the_reference_method(device):
         assert np.allclose(f.cpu().numpy(), want_f, rtol=2e-7, atol=0), (fx, fy)
 
 
+@pytest.mark.gpu
+def test_spatial_transforms_without_resize_match_the_reference_methods(device):
+    """FlowAugmentor / SparseFlowAugmentor.spatial_transform with spatial_aug_prob = 0 (the branch that calls cv2.resize is never entered:
+    the reference's own methods run in numpy, tools/make_golden_augment.py): the scale / stretch / flip / crop DRAW ORDER, the flips with
+    their flow signs, the dense crop and the sparse augmentor's crop with margins -- bit for bit."""
+    from craft_amd.augment import FlowAugmentor, SparseFlowAugmentor
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.float32)).to(device)
+    b1, b2, bf, bv = (AUGREF[f"spatial.{k}"] for k in ("img1", "img2", "flow", "valid"))
+    crop = tuple(int(v) for v in AUGREF["spatial.crop"])
+    flipped = 0
+    for sd in AUGREF["spatial.seeds"].tolist():
+        np.random.seed(sd)
+        o1, o2, of = FlowAugmentor("chairs", crop, spatial_aug_prob=0.0).spatial_transform(up(b1), up(b2), up(bf))
+        for got, key in ((o1, "img1"), (o2, "img2"), (of, "flow")):
+            assert np.array_equal(got.cpu().numpy(), AUGREF[f"spatial.dense.{sd}.{key}"].astype(np.float32)), ("dense", sd, key)
+        np.random.seed(sd)
+        o1, o2, of, ov = SparseFlowAugmentor("kitti", crop, spatial_aug_prob=0.0, do_flip=True).spatial_transform(up(b1), up(b2), up(bf), up(bv))
+        for got, key in ((o1, "img1"), (o2, "img2"), (of, "flow"), (ov, "valid")):
+            assert np.array_equal(got.cpu().numpy(), AUGREF[f"spatial.sparse.{sd}.{key}"].astype(np.float32)), ("sparse", sd, key)
+        flipped += int(np.sign(of.cpu().numpy()[..., 0]).sum() != np.sign(bf[..., 0]).sum())
+    assert flipped >= 1
+
+
 def _np_gaussian_blur(img, K, sigma):
     """cv2.GaussianBlur(img, (K, K), sigma) restated: getGaussianKernel for sigma > 0, separable, BORDER_REFLECT_101, float arithmetic."""
     x = np.arange(K, dtype=np.float64) - 0.5 * (K - 1)
