@@ -23,7 +23,7 @@ const Tuning& tuning() {
     v.corr_ncp = 8;                                       // k_corr_build4t: cell pairs per block (the row band); CRAFT_CORR_NCP=1: one pair per block (developer A/B)
     if (const char* e = getenv("CRAFT_CORR_NCP")) v.corr_ncp = atoi(e);
     v.pv_wr2 = getenv("CRAFT_PV_NO_WR2") == nullptr;      // k_pv16: the launcher may pick the 8-wave (2 x 32 MT rows) instantiation (round 6; off: developer A/B)
-    v.conv_xcd = getenv("CRAFT_CONV_XCD") != nullptr;     // k_conv_halo_wf: XCD x owns a contiguous eighth of the patch list (developer A/B, round 6)
+    if (const char* e = getenv("CRAFT_CONV_XCD")) v.conv_xcd = atoi(e);     // k_conv_halo_wf: XCD x owns a contiguous eighth of the patch list (developer A/B, round 6)
     return v;
   }();
   return t;

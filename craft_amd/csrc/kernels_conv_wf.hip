@@ -58,12 +58,24 @@ __global__ __launch_bounds__(NTHREADS) void k_conv_halo_wf(ConvGemmParams p, int
   const int tiles_x = (g.W + WF_PATCH_W - 1) / WF_PATCH_W, tiles_y = (g.H + WF_PATCH_H - 1) / WF_PATCH_H;
   // (xcd_map: block b runs on XCD b % 8; give each XCD a contiguous eighth of the patch list so that neighbouring patches share the
   // halo rows they both read through ONE L2 -- CRAFT_CONV_XCD, developer A/B)
-  int bid = xcd_map ? xcd_chunk(blockIdx.x, gridDim.x) : blockIdx.x;
+  int bid = xcd_map == 1 ? xcd_chunk(blockIdx.x, gridDim.x) : blockIdx.x;
+  int by = blockIdx.y;
+  if (xcd_map == 2 && gridDim.y == 2) {
+    // CRAFT_CONV_XCD=2 (developer A/B): 256 < blocks <= 512 = at most two per CU.  If the dispatcher gives CU slot j the blocks j and j + 256,
+    // make that pair share ONE column block (and be neighbouring patches), so that their weight-fragment loads -- the same addresses at
+    // about the same time -- can meet in the CU's vector L1 instead of both going to L2.
+    const int total = 2 * gridDim.x, lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int r1 = total - 256, T = total / 4;
+    if (r1 > 0 && T <= r1 && T <= 256) {
+      const int j = lin & 255, r = lin >> 8;
+      if (j < T) { by = 0; bid = j + r * T; } else { by = 1; bid = (j - T) + r * (256 - T); }
+    }
+  }
   const int tx = bid % tiles_x; bid /= tiles_x;
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
   const int y0 = ty * WF_PATCH_H, x0 = tx * WF_PATCH_W;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = by * BN;
   const int ctot = g.c0 + g.c1, nchunk = ctot / BK;
   const long img = (long)b * g.H * g.W;
   const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * 32;
@@ -316,7 +328,7 @@ template <int PREC, int WM, int WN, int TT> static int launch_wf_tt(const ConvGe
   const int ncols = p.epi == CONV_EPI_MENC ? p.cout + 2 : p.cout;
   const int tiles = ((p.g.W + WF_PATCH_W - 1) / WF_PATCH_W) * ((p.g.H + WF_PATCH_H - 1) / WF_PATCH_H) * (p.g.npix / (p.g.H * p.g.W));
   dim3 grid(tiles, (ncols + BN - 1) / BN, 1);
-  const int xm = tuning().conv_xcd ? 1 : 0;
+  const int xm = tuning().conv_xcd;
   if (enc) hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, true, TT>), grid, dim3(NTHREADS), 0, s, p, xm);
   else if (PREC == CRAFT_PREC_F16X3 && TT > 0 && p.w16) hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, false, TT, 5>), grid, dim3(NTHREADS), 0, s, p, xm);
   else hipLaunchKernelGGL((k_conv_halo_wf<PREC, WM, WN, false, TT>), grid, dim3(NTHREADS), 0, s, p, xm);

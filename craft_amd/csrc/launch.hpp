@@ -14,7 +14,7 @@ namespace craft {
 // Developer A/B overrides from the environment, read ONCE when the library is loaded (never in a launch path):
 // CRAFT_HALO_BN (64 | 128), CRAFT_NO_C64, CRAFT_WF_DYNAMIC_TAPS.  Everything a caller may legitimately vary per call is an
 // argument of the C ABI instead (e.g. CRAFT_PV_ROWS in craft_attn_apply's prec).
-struct Tuning { int halo_bn; bool no_c64, wf_dynamic_taps, no_wgrad64, wgrad_sb; int pk_mode, corr_dbg; bool pv_wr2; int corr_ncp; bool conv_xcd; };
+struct Tuning { int halo_bn; bool no_c64, wf_dynamic_taps, no_wgrad64, wgrad_sb; int pk_mode, corr_dbg; bool pv_wr2; int corr_ncp; int conv_xcd; };
 const Tuning& tuning();
 
 struct RowsGemmParams {
