@@ -245,7 +245,8 @@ def test_bench_training_workload_is_the_pinned_one(device, cfg):
     """bench.py's training legs assert their first-step loss against bench.FIRST_LOSS (`loss == loss` said nothing
     about WHAT was trained).  Here: (a) the constant exists for the default workload and a fresh `bench.py --train cfg` run satisfies
     its own assertion and prints that loss; (b) the same weights and pairs with dropout off: the HIP training forward's loss equals
-    the CPU oracle's (batch 8 with BatchNorm batch statistics at configs[3] -- the largest oracle-checked training batch)."""
+    the CPU oracle's (batch 8 with BatchNorm batch statistics at configs[3] -- the largest oracle-checked training batch); (c) the pinned
+    dropout-ON loss equals the oracle's when it is fed that pass's six masks."""
     import torch
     sys.path.insert(0, ROOT)
     import bench
@@ -282,3 +283,17 @@ def test_bench_training_workload_is_the_pinned_one(device, cfg):
     print(f"[bench workload] configs[{cfg}] B={B} {H}x{W} T=12 {policy}: dropout-off loss {float(loss.detach()):.6f} vs oracle {float(loss_r):.6f}; "
           f"max prediction error {worst:.2e} px; pinned first-step loss (dropout on) {pinned}")
     assert worst < (1e-2 if policy == "mixed" else 0.1)
+    # (c) the pinned constant itself -- the leg's first step WITH dropout on -- is what the oracle computes when it is fed that pass's masks:
+    # the leg seeds torch with 1234 + rank (bench.py), the fresh model's first pass has number 0, and the six masks follow from the seed
+    # alone (tests/dropout_hash.py: the kernels' hash restated; tests/test_train_dropout_parity.py holds gradients to the same construction)
+    from dropout_hash import pass_base, pass_masks
+    O.DROPOUT_MASKS = pass_masks(pass_base(1234), B, (H // 8) * (W // 8))
+    try:
+        with torch.no_grad():
+            preds_d, _ = O.craft_train_forward(sd, O.OracleConfig(), im1, im2, iters=12, freeze_bn=cfg != 3)
+            loss_d, _ = O.sequence_loss(preds_d, flow, valid, 0.8)
+    finally:
+        O.DROPOUT_MASKS = None
+    print(f"[bench workload] configs[{cfg}]: first-step loss with dropout on: bench {d['first_loss']:.4f}, pinned {pinned}, oracle + masks {float(loss_d):.4f}")
+    assert float(loss_d) == pytest.approx(d["first_loss"], rel=5e-4 if policy == "mixed" else 2e-3)
+    assert float(loss_d) == pytest.approx(pinned, rel=1e-3 if policy == "mixed" else 3e-3)
