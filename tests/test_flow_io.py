@@ -199,3 +199,30 @@ def test_read_image_palette_and_grey_alpha(tmp_path):
     Image.fromarray(la, mode="LA").save(str(tmp_path / "la.png"))
     got = flow_io.read_image(str(tmp_path / "la.png"))
     assert got.shape == (9, 13, 3) and np.array_equal(got[..., 0], la[..., 0]) and np.array_equal(got[..., 2], la[..., 0])
+
+
+FLOWIO = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flowio_ref.npz"))
+
+
+def test_flo_and_pfm_against_the_references_own_functions(tmp_path):
+    """tests/golden/flowio_ref.npz (tools/make_golden_flowio.py): readFlow / writeFlow / readPFM compiled out of the reference's
+    core/utils/frame_utils.py and run on seeded arrays.  write_flo produces the reference's BYTES (both call forms, float64 input included:
+    one cast to float32), read_flo returns what readFlow returns for them, read_pfm what readPFM returns for colour / grey, little- / big-endian
+    files with non-unit scales (the reference, like this reader, ignores the scale's magnitude)."""
+    p = str(tmp_path / "x.flo")
+    for k in range(3):
+        uv, raw = FLOWIO[f"flo.{k}.uv"], FLOWIO[f"flo.{k}.bytes"].tobytes()
+        flow_io.write_flo(p, uv)
+        assert open(p, "rb").read() == raw
+        flow_io.write_flo(p, uv[..., 0], uv[..., 1])
+        assert open(p, "rb").read() == raw
+        open(p, "wb").write(raw)
+        got = flow_io.read_flo(p)
+        assert got.dtype == np.float32 and np.array_equal(got, FLOWIO[f"flo.{k}.read"]) and np.array_equal(got, uv)
+    flow_io.write_flo(p, FLOWIO["flo.f64.uv"])
+    assert open(p, "rb").read() == FLOWIO["flo.f64.bytes"].tobytes()
+    q = str(tmp_path / "x.pfm")
+    for k in range(int(FLOWIO["pfm.n"])):
+        open(q, "wb").write(FLOWIO[f"pfm.{k}.bytes"].tobytes())
+        got = flow_io.read_pfm(q)
+        assert got.dtype == np.float32 and np.array_equal(got, FLOWIO[f"pfm.{k}.read"]), k
