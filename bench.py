@@ -753,7 +753,7 @@ def main():
 
     # Beside it: the same pass recorded once as a hipGraph (CRAFT.capture: same kernels, same streams, bit-identical results --
     # tests/test_graphed_forward.py) and replayed per step; a step copies the batch into the graph's input buffers and replays.  Timed with
-    # the same protocol right after the headline; box to box it is between 1.6 % slower and 2 % faster than the eager sequence
+    # the same protocol right after the headline; box to box it is between 2.3 % slower and 2 % faster than the eager sequence (it runs second, on a warmed-up chip)
     # (profiles/r6/graph_ab.txt).  The
     # capture runs in a child process first (graph_probe_child): a crash inside the runtime must not cost the line.
     graph_leg = None
