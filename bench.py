@@ -664,7 +664,7 @@ def graph_probe_child(a, local_dev):
     cmd = [sys.executable, os.path.abspath(__file__), "--graph-probe", "--batch", str(a.batch), "--height", str(a.height), "--width", str(a.width),
            "--iters", str(a.iters), "--precision", a.precision]
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)      # (normally ~8 s)
     except subprocess.TimeoutExpired:
         return False, "graph probe timed out"
     if r.returncode == 0 and "graph-probe ok" in r.stdout:
