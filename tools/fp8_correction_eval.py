@@ -13,7 +13,8 @@ every F.conv2d of oracle/craft_oracle.py by an emulation of
 (fp32 accumulation in all of them) and reports the deviation of the final prediction from the plain fp32 oracle at bench.py's workload
 (synthetic weights seed 1234, one 448x1024 pair, 12 iterations).  Only the convolutions are emulated: the attention products stay fp32.
 
-    python tools/fp8_correction_eval.py [--height 448 --width 1024 --iters 12 --modes f16x3,fp8corr,f16x1]
+    python tools/fp8_correction_eval.py [--height 448 --width 1024 --iters 12 --modes "f16x3;fp8corr;f16x1"]
+    python tools/fp8_correction_eval.py --modes "fnet.=w16;cnet.=w16;update_block.mask=w16"       (a plan per run: weight-name prefix = mode)
 """
 import argparse
 import os
@@ -49,21 +50,42 @@ def q8_blocks(t, dim):
 
 
 class Emul:
-    def __init__(self, mode):
-        self.mode, self.calls = mode, 0
+    """mode: one of f16x3 | fp8corr | f16x1 | w16 (weights as ONE fp16 plane: hi.hi + lo_x.hi_w, two MFMAs) | x16 (activations as one plane:
+    hi.hi + hi_x.lo_w) for every convolution -- or a PLAN "prefix=mode,prefix=mode,..." over the state-dict names of the weights
+    (e.g. "fnet.=w16,cnet.=w16"), every convolution the plan does not name staying f16x3."""
+
+    def __init__(self, mode, sd=None):
+        self.calls, self.names = 0, {}
+        self.plan = None
+        if "=" in mode:
+            self.plan = [tuple(kv.split("=")) for kv in mode.split(",")]
+            self.names = {id(v): k for k, v in sd.items()}
+            self.mode = "f16x3"
+        else:
+            self.mode = mode
 
     def conv2d(self, x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
         self.calls += 1
+        mode = self.mode
+        if self.plan is not None:
+            name = self.names.get(id(w), "?")
+            for pre, m in self.plan:
+                if name.startswith(pre):
+                    mode = m
         kw = dict(stride=stride, padding=padding, dilation=dilation, groups=groups)
         hx, lx = split16(x)
         hw, lw = split16(w)
         y = F.conv2d(hx, hw, None, **kw)
-        if self.mode == "f16x3":
+        if mode == "f16x3":
             y = y + F.conv2d(lx, hw, None, **kw) + F.conv2d(hx, lw, None, **kw)
-        elif self.mode == "fp8corr":
+        elif mode == "fp8corr":
             y = y + F.conv2d(q8_blocks(lx, 1), q8_blocks(hw, 1), None, **kw) + F.conv2d(q8_blocks(hx, 1), q8_blocks(lw, 1), None, **kw)
-        elif self.mode != "f16x1":
-            raise ValueError(self.mode)
+        elif mode == "w16":
+            y = y + F.conv2d(lx, hw, None, **kw)
+        elif mode == "x16":
+            y = y + F.conv2d(hx, lw, None, **kw)
+        elif mode != "f16x1":
+            raise ValueError(mode)
         return y if b is None else y + b.view(1, -1, 1, 1)
 
 
@@ -82,7 +104,7 @@ def main():
     ap.add_argument("--height", type=int, default=448)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=12)
-    ap.add_argument("--modes", default="f16x3,fp8corr,f16x1")
+    ap.add_argument("--modes", default="f16x3;fp8corr;f16x1", help="';'-separated: a mode for every convolution, or a plan prefix=mode,prefix=mode")
     ap.add_argument("--seed", type=int, default=100)
     a = ap.parse_args()
     torch.set_num_threads(min(32, torch.get_num_threads()))
@@ -96,8 +118,8 @@ def main():
         _, ref = O.craft_forward(sd, O.OracleConfig(), im1, im2, iters=a.iters, test_mode=1)
     print(f"# fp32 oracle: {time.time() - t0:.1f} s; |flow_up| mean {ref.abs().mean():.3f} px, max {ref.abs().max():.2f} px", flush=True)
     real_F = O.F
-    for mode in a.modes.split(","):
-        e = Emul(mode)
+    for mode in a.modes.split(";"):
+        e = Emul(mode, sd)
         O.F = _FProxy(e)
         try:
             t0 = time.time()
@@ -106,7 +128,7 @@ def main():
         finally:
             O.F = real_F
         epe = (up - ref).pow(2).sum(1).sqrt()
-        print(f"{mode:8s} {e.calls:4d} convolutions emulated, {time.time() - t0:6.1f} s: EPE vs fp32 oracle mean {epe.mean():.3e} px  max {epe.max():.3e} px",
+        print(f"{mode:28s} {e.calls:4d} convolutions emulated, {time.time() - t0:6.1f} s: EPE vs fp32 oracle mean {epe.mean():.3e} px  max {epe.max():.3e} px",
               flush=True)
 
 
