@@ -7,7 +7,7 @@ script also RECORDS which Dropout modules ran, in order -- the six sites the ora
 
 Only runs in the build container (same layout as tools/make_golden_train.py's fixtures, + the torch seed the pass's seeds derive from).
 
-    python tools/make_golden_train_dropout.py
+    python tools/make_golden_train_dropout.py [--check]
 """
 import json
 import os
@@ -91,6 +91,11 @@ def main():
         for kk, v in sample(p).items():
             out[f"up{it}.{kk}"] = v
     path = os.path.join(ROOT, "tests", "golden", c["name"] + ".npz")
+    if "--check" in sys.argv:                      # the generator is a no-op on the committed tree
+        z = np.load(path)
+        bad = [k for k in out if k != "meta" and not np.array_equal(z[k], out[k])]
+        print("differs:", bad if bad else "nothing")
+        raise SystemExit(1 if bad else 0)
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes; loss", float(loss), "; dropout calls:", calls, "; unused:", len(unused))
 

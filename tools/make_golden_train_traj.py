@@ -7,7 +7,7 @@ Recorded: the three losses and learning rates, a strided sample + (sum, sum^2) o
 from the initial value, cnet's BatchNorm running statistics.  craft_amd.train.Trainer.step is held to it on the GPU
 (tests/test_trainer_gpu.py::test_three_steps_follow_the_reference_training_loop).
 
-Only runs in the build container.      python tools/make_golden_train_traj.py
+Only runs in the build container.      python tools/make_golden_train_traj.py [--check]
 """
 import ast
 import json
@@ -111,6 +111,11 @@ def main():
         if k.startswith("cnet.") and (k.endswith("running_mean") or k.endswith("running_var")):
             out[f"bn.{k}"] = v.numpy()
     path = os.path.join(ROOT, "tests", "golden", c["name"] + ".npz")
+    if "--check" in sys.argv:                      # the generator is a no-op on the committed tree
+        z = np.load(path)
+        bad = [k for k in out if k != "meta" and not np.array_equal(z[k], out[k])]
+        print("differs:", bad if bad else "nothing")
+        raise SystemExit(1 if bad else 0)
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes; losses", losses, "lrs", lrs)
 
